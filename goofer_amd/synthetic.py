@@ -1,0 +1,184 @@
+"""Synthetic voicebank sources and UTAU note requests (SURVEY.md §8 d).
+
+Nothing here touches the reference or the oracle: these are the seeded inputs that the golden
+generator, the parity tests and ``bench.py`` all share, so that "identical inputs" means
+identical bytes on every box.
+
+A *source* is what a ``<stem>_features.goofy`` file holds (reference layout,
+``GOOFER.py:287-304``): mel-knot log envelope in fp16 ``[K, T]``, per-sample f0 / voicing mask,
+per-frame formant tracks F1..F4.  A *note request* is the 13-argument UTAU resampler call
+(``SillySampler.py:1226-1234``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_B64 = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/"
+
+FORMANT_HZ = np.array([700.0, 1200.0, 2500.0, 3500.0])
+FORMANT_AMP = np.array([0.5, 0.4, 0.3, 0.2])
+FORMANT_BW = np.array([150.0, 200.0, 300.0, 400.0])
+
+NOTE_NAMES = ["C", "C#", "D", "D#", "E", "F", "F#", "G", "G#", "A", "A#", "B"]
+
+
+def mel_knots_hz(sr: int, n_knots: int) -> np.ndarray:
+    """Mel-spaced knot frequencies 0..sr/2 in fp32 (same grid the reference codec uses,
+    ``GOOFER.py:74-82``; O'Shaughnessy mel, 2595*log10(1+f/700))."""
+    top = 2595.0 * np.log10(1.0 + (sr / 2.0) / 700.0)
+    mel = np.linspace(0.0, top, n_knots, dtype=np.float32)
+    return (700.0 * (10 ** (mel / 2595.0) - 1.0)).astype(np.float32)
+
+
+def encode_cents(cents) -> str:
+    """UTAU pitch-bend string: two base64 chars per 12-bit two's-complement value, with
+    ``#n#`` run-length for repeats (inverse of ``SillySampler.py:56-84``)."""
+    vals = [int(v) for v in cents]
+    out, i = [], 0
+    while i < len(vals):
+        v = vals[i]
+        if not -2048 <= v <= 2047:
+            raise ValueError("pitch bend out of 12-bit range")
+        u = v & 0xFFF
+        out.append(_B64[u >> 6] + _B64[u & 63])
+        run = 0
+        while i + 1 + run < len(vals) and vals[i + 1 + run] == v:
+            run += 1
+        if run >= 2:
+            out.append("#%d#" % run)
+            i += run
+        i += 1
+    return "".join(out)
+
+
+def midi_name(m: int) -> str:
+    return "%s%d" % (NOTE_NAMES[m % 12], m // 12 - 1)
+
+
+def make_source(seed: int, sr: int = 44100, n_fft: int = 1024, hop: int = 256,
+                seconds: float = 0.6, n_knots: int = 64) -> dict:
+    """One synthetic voicebank sample in ``.goofy`` form.
+
+    env(f, t) = exp(-f/3000) * (1 + sum_k a_k exp(-((f-F_k)/bw_k)^2/2)) * (1 + 0.1 sin(t/7 + phi))
+    sampled at the mel knots, stored as log in fp16 — i.e. what the knot codec would hold.
+    """
+    rng = np.random.default_rng(seed)
+    n = int(round(seconds * sr))
+    T = 1 + n // hop
+    F = FORMANT_HZ * rng.uniform(0.9, 1.1, 4)
+    phi = rng.uniform(0.0, 2.0 * np.pi)
+    hz = mel_knots_hz(sr, n_knots).astype(np.float64)
+    t = np.arange(T, dtype=np.float64)
+    spec = np.exp(-hz / 3000.0)
+    spec = spec * (1.0 + (FORMANT_AMP[None, :] * np.exp(-0.5 * ((hz[:, None] - F[None, :]) / FORMANT_BW[None, :]) ** 2)).sum(1))
+    env = spec[:, None] * (1.0 + 0.1 * np.sin(t / 7.0 + phi))[None, :]
+    walk = np.cumsum(rng.normal(0.0, 5.0, (4, T)), axis=1)
+    formants = {k + 1: (F[k] + walk[k]).astype(np.float64) for k in range(4)}
+    mask = np.ones(n, dtype=np.float32)
+    mask[: int(0.08 * n)] = 0.0
+    f0 = (220.0 * mask).astype(np.float32)
+    return {
+        "env_pack": {
+            "mode": "knots",
+            "knot_vals_log": np.log(env).astype(np.float16),
+            "hz_knots": hz.astype(np.float32),
+            "n_bins": n_fft // 2 + 1,
+            "n_fft": n_fft,
+            "sr": sr,
+        },
+        "f0": f0.astype(np.float16).astype(np.float32),
+        "mask": mask.astype(np.float16).astype(np.float32),
+        "formants": formants,
+        "sr": sr,
+        "y_len": n,
+        "hop": hop,
+        "n_fft": n_fft,
+    }
+
+
+def make_request(seed: int, flags: str, length_ms: float = 1000.0, offset_ms: float = 50.0,
+                 consonant_ms: float = 100.0, cutoff_ms: float = 100.0, velocity: float = 100.0,
+                 volume: float = 100.0, tempo: float = 120.0) -> dict:
+    """The 11 non-path arguments of one resampler call, seeded: uniform MIDI 55..72 and a smooth
+    +-50 cent pitch-bend curve at 96 ticks per quarter note."""
+    rng = np.random.default_rng(seed)
+    midi = int(rng.integers(55, 73))
+    total_s = (length_ms + consonant_ms) / 1000.0
+    ticks = int(np.ceil(total_s * tempo * 96.0 / 60.0)) + 2
+    ctrl = rng.uniform(-50.0, 50.0, max(2, ticks // 24 + 2))
+    x = np.linspace(0.0, len(ctrl) - 1.0, ticks)
+    bend = np.interp(x, np.arange(len(ctrl)), ctrl)
+    bend = np.round(0.5 * (bend + np.roll(bend, 1))).astype(int)
+    return {
+        "pitch": midi_name(midi),
+        "velocity": "%g" % velocity,
+        "flags": flags,
+        "offset": "%g" % offset_ms,
+        "length": "%g" % length_ms,
+        "consonant": "%g" % consonant_ms,
+        "cutoff": "%g" % cutoff_ms,
+        "volume": "%g" % volume,
+        "modulation": "0",
+        "tempo": "!%g" % tempo,
+        "pitch_string": encode_cents(bend),
+    }
+
+
+def request_args(req: dict) -> list:
+    """Positional tail (arguments 3..13) in the reference's order."""
+    return [req[k] for k in ("pitch", "velocity", "flags", "offset", "length", "consonant",
+                             "cutoff", "volume", "modulation", "tempo", "pitch_string")]
+
+
+def phase_matrix(seed: int, n_bins: int, n_frames: int) -> np.ndarray:
+    """The random-phase draw of the aperiodic branch, pinned: exactly the call the reference
+    makes (``GOOFER.py:1151-1152``) but on a seeded generator.  Shape ``[n_bins, n_frames]``."""
+    return np.random.default_rng(seed).uniform(0.0, 2.0 * np.pi, size=(n_bins, n_frames)).astype(np.float32)
+
+
+# --- BASELINE.json configurations ------------------------------------------------------------
+
+FULL_FORMANT_FLAGS = "fa30fb-20fc10fd-10fw50fst40fsta20fstb-20fstc10fstd-10V80B20U-30"
+
+
+def _flip(flags: str, i: int) -> str:
+    """Per-note sign flips for config 3: odd notes negate every signed formant flag."""
+    if i % 2 == 0:
+        return flags
+    import re
+    def neg(m):
+        k, v = m.group(1), int(m.group(2))
+        return "%s%d" % (k, v if k in ("V", "B", "U") else -v)
+    return re.sub(r"([A-Za-z]+)([+-]?\d+)", neg, flags)
+
+
+def config_flags(config: int, i: int) -> str:
+    if config == 1:
+        return "t0g0"
+    if config == 2:
+        return ("t12" if i % 2 == 0 else "t-12") + ("g50" if (i // 2) % 2 == 0 else "g-50")
+    if config == 3:
+        return _flip(FULL_FORMANT_FLAGS, i)
+    if config == 4:
+        return "L%d" % (i % 3)
+    if config == 5:
+        return "br40es-50" if i % 2 == 0 else "br-40es60"
+    raise ValueError(config)
+
+
+def config_geometry(config: int) -> dict:
+    if config == 5:
+        return {"sr": 96000, "n_fft": 2048, "hop": 96}
+    return {"sr": 44100, "n_fft": 1024, "hop": 256}
+
+
+def config_note(config: int, i: int) -> tuple:
+    """(source, request, phi_seed) for note ``i`` of a BASELINE config (seeds 1000+i / 5000+i)."""
+    geo = config_geometry(config)
+    src = make_source(1000 + i, geo["sr"], geo["n_fft"], geo["hop"])
+    length = 1000.0
+    if config == 4:
+        rng = np.random.default_rng(9000 + i)
+        length = float(np.exp(rng.uniform(np.log(100.0), np.log(3000.0))))
+    req = make_request(1000 + i, config_flags(config, i), length_ms=round(length))
+    return src, req, 5000 + i
