@@ -1,0 +1,191 @@
+"""The GOOFER.py analyse/synth call surface, served by the MI355X backend.
+
+Drop-in for the functions ``SillySampler.py`` / ``test.py`` call on the reference module
+(``import goofer_amd.core as gf``): same names, positional order, array layouts (``[bins, frames]``
+numpy arrays in, numpy arrays out) and error behaviour, but every array operation on the hot path
+runs in libgoofer_hip.so on the GPU.  Host code here only marshals: it never computes audio.
+
+Reference: GOOFER.py:355-413 (stft/istft), :473-554 (pulse train), :149-168 (knot decode),
+:971-1220 (synthesize).  Per-call overheads (H2D/D2H of one note) make this single-note surface a
+convenience; throughput comes from :func:`synthesize_batch`.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .device import Context, default_context, default_params, row_stride
+
+DSTORAGE = np.float16
+DCOMPUTE = np.float32
+
+_UNSUPPORTED = ("f0_jitter", "volume_jitter", "add_subharm", "roughness_on")
+
+
+def _ctx(sr, n_fft, hop, ctx=None) -> Context:
+    return (ctx or default_context()).plan(sr, n_fft, hop)
+
+
+# -- feature files (host-side format code, byte-compatible with GOOFER.py:287-339) -----------------
+def formants_to_int_keys(d):
+    out = {}
+    if isinstance(d, dict):
+        for k, v in d.items():
+            if isinstance(k, str) and k[:1].upper() == "F":
+                try:
+                    k = int(k[1:])
+                except Exception:
+                    continue
+            if isinstance(k, (int, np.integer)) and 1 <= int(k) <= 4:
+                out[int(k)] = np.asarray(v)
+    for i in (1, 2, 3, 4):
+        out.setdefault(i, np.zeros(1, dtype=np.float64))
+    return out
+
+
+def save_features(path, features, f0_interp, voicing_mask, formants, sr, y_len):
+    fields = {}
+    if isinstance(features, dict) and features.get("mode") == "knots":
+        fields.update(mode=np.array(["knots"]), knot_vals_log=features["knot_vals_log"], hz_knots=features["hz_knots"],
+                      n_bins=np.array([features["n_bins"]], dtype=np.int32),
+                      n_fft=np.array([features["n_fft"]], dtype=np.int32),
+                      env_sr=np.array([features["sr"]], dtype=np.int32))
+    else:
+        dense = np.asarray(features, dtype=DSTORAGE)
+        fields.update(mode=np.array(["full"]), env_spec=dense, n_fft=np.array([dense.shape[0] * 2 - 2], dtype=np.int32))
+    fields.update(f0_interp=np.asarray(f0_interp).astype(DSTORAGE), voicing_mask=np.asarray(voicing_mask).astype(DSTORAGE),
+                  formants=formants_to_int_keys(formants), sr=np.array([sr], dtype=np.int32),
+                  y_len=np.array([y_len], dtype=np.int64))
+    with open(path, "wb") as fh:
+        np.savez_compressed(fh, **fields)
+
+
+def load_features(path):
+    z = np.load(path, allow_pickle=True)
+    if str(z["mode"][0]) == "knots":
+        env = {"mode": "knots", "knot_vals_log": z["knot_vals_log"], "hz_knots": z["hz_knots"],
+               "n_bins": int(z["n_bins"][0]), "n_fft": int(z["n_fft"][0]), "sr": int(z["env_sr"][0])}
+    else:
+        env = np.asarray(z["env_spec"], dtype=DCOMPUTE)
+    return (env, np.asarray(z["f0_interp"], dtype=DCOMPUTE), np.asarray(z["voicing_mask"], dtype=DCOMPUTE),
+            formants_to_int_keys(z["formants"].item()), int(z["sr"][0]), int(z["y_len"][0]))
+
+
+# -- single-array entry points ---------------------------------------------------------------------
+def stft(x, n_fft=2048, hop_length=512, window=None, sr=44100, ctx=None):
+    """complex64 ``[bins, T]``.  ``window`` is accepted for signature parity; the backend always uses
+    the reference's cached sqrt-Hann (the only window the reference ever passes)."""
+    c = _ctx(sr, n_fft, hop_length, ctx)
+    x = np.asarray(x, dtype=np.float32)
+    n = len(x)
+    T = 1 + n // hop_length
+    S = c.rfft_frames(c.tensor(x), c.tensor(np.array([0, n], dtype=np.int64)), c.tensor(np.array([0, T], dtype=np.int64)), T)
+    return np.ascontiguousarray(S.cpu().numpy().T)
+
+
+def istft(S, hop_length=512, window=None, length=None, sr=44100, ctx=None):
+    S = np.asarray(S, dtype=np.complex64)
+    n_fft = (S.shape[0] - 1) * 2
+    c = _ctx(sr, n_fft, hop_length, ctx)
+    T = S.shape[1]
+    n = hop_length * (T - 1) if length is None else int(length)
+    # the backend derives T from the note length (T = 1 + n//hop); feed it a length in that class
+    n_dev = hop_length * (T - 1)
+    St = c.tensor(np.ascontiguousarray(S.T))
+    y = c.irfft_ola(St, c.tensor(np.array([0, n_dev], dtype=np.int64)), c.tensor(np.array([0, T], dtype=np.int64)), n_dev)
+    y = y.cpu().numpy()
+    if n > n_dev:
+        y = np.pad(y, (0, n - n_dev))
+    return y[:n]
+
+
+def pulse_train_numba(f0_interp, sr, Ra=0.02, Rg=1.7, Rk=0.8, ctx=None):
+    if (Ra, Rg, Rk) != (0.02, 1.7, 0.8):
+        raise NotImplementedError("the backend fixes Ra=0.02, Rg=1.7, Rk=0.8 (the only values the reference uses)")
+    c = ctx or default_context()
+    if c.geom is None:
+        c.plan(int(sr), 1024, 256)
+    elif c.geom[0] != int(sr):
+        c.plan(int(sr), c.geom[1], c.geom[2])
+    f0 = np.asarray(f0_interp, dtype=np.float32)
+    if f0.size == 0:
+        return np.zeros(0, dtype=np.float32)
+    return c.pulse_train(c.tensor(f0), c.tensor(np.array([0, f0.size], dtype=np.int64))).cpu().numpy()
+
+
+def decode_env_from_knots(env_pack, ctx=None):
+    """fp32 ``[bins, T]`` from a knots dict (GOOFER.py:149-168)."""
+    assert env_pack["mode"] == "knots"
+    c = _ctx(int(env_pack["sr"]), int(env_pack["n_fft"]), int(env_pack["n_fft"]) // 4, ctx)
+    knots = np.ascontiguousarray(np.asarray(env_pack["knot_vals_log"]).astype(np.float16).T)
+    env = c.knot_decode(c.tensor(knots.view(np.uint16)).view(torch.float16), np.asarray(env_pack["hz_knots"], dtype=np.float32))
+    out = env.cpu().numpy().T
+    return np.ascontiguousarray(out[: int(env_pack["n_bins"])])
+
+
+def gaussian_taps(sigma, truncate=4.0):
+    """Normalised fp64 taps, radius int(truncate*sigma + 0.5) (GOOFER.py:247-252)."""
+    r = int(truncate * sigma + 0.5)
+    t = np.arange(-r, r + 1)
+    k = np.exp(-0.5 * (t / sigma) ** 2)
+    return k / k.sum()
+
+
+# -- synthesize --------------------------------------------------------------------------------------
+def _fit(x, T):
+    x = np.asarray(x, dtype=np.float64)
+    if x.size >= T:
+        return x[:T]
+    return np.zeros(T) if x.size == 0 else np.pad(x, (0, T - x.size), mode="edge")
+
+
+def note_params_from_kwargs(n=1, **kw):
+    p = default_params(n)
+    p["pitch_shift"] = kw.get("pitch_shift", 1.0)
+    p["formant_shift"] = kw.get("formant_shift", 1.0)
+    p["f_shift"] = [kw.get("F1_shift", 1.0), kw.get("F2_shift", 1.0), kw.get("F3_shift", 1.0), kw.get("F4_shift", 1.0)]
+    p["uv_strength"] = kw.get("uv_strength", 0.75)
+    p["breath_strength"] = kw.get("breath_strength", 0.1)
+    p["normalize"] = kw.get("normalize", 1.0)
+    p["apply_brightness"] = int(bool(kw.get("apply_brightness", True)))
+    p["cut_below_f0"] = int(bool(kw.get("cut_subharm_below_f0", True)))
+    return p
+
+
+def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=256, phi=None, seed=None, ctx=None, **kw):
+    """gf.synthesize for one note on the GPU -> (reconstruct, harmonic, aper_uv, aper_bre), fp32.
+
+    ``phi`` ``[bins, T]`` injects the aperiodic branch's random phases (parity runs); otherwise the
+    device draws them from Philox keyed by ``seed`` (a fresh key per call when None, like the
+    reference's unseeded generator)."""
+    for k in _UNSUPPORTED:
+        if kw.get(k):
+            raise NotImplementedError(f"{k} is not on the device path yet (SURVEY.md §8 f)")
+    if kw.get("stretch_factor", 1.0) != 1.0:
+        raise NotImplementedError("stretch_factor != 1 is not on the device path yet")
+    c = _ctx(sr, n_fft, hop_length, ctx)
+    if isinstance(env_spec, dict) and env_spec.get("mode") == "knots":
+        env_spec = decode_env_from_knots(env_spec, ctx=c)
+        c.plan(sr, n_fft, hop_length)
+    env = np.asarray(env_spec, dtype=np.float32)
+    n = len(y)
+    f0 = np.asarray(f0_interp, dtype=np.float32)
+    mask = np.asarray(voicing_mask, dtype=np.float32)
+    if n == 0:
+        z = np.zeros(0, dtype=np.float32)
+        return z, z.copy(), z.copy(), z.copy()
+    T_env = env.shape[1]
+    fm = formants_to_int_keys(kw.get("formants"))
+    F = np.stack([_fit(fm[i], T_env) for i in (1, 2, 3, 4)], axis=1)           # [T_env, 4] fp64
+    params = note_params_from_kwargs(1, **kw)
+    d_env = c.rows_from(env.T)
+    d_phi = None
+    if phi is not None:
+        d_phi = c.rows_from(np.asarray(phi, dtype=np.float32).T)
+    if seed is None:
+        seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
+    out = c.synth_batch(d_env, [T_env], c.tensor(f0[:n]), c.tensor(mask[:n]), [n], params, formants=c.tensor(F),
+                        phi=d_phi, seed=seed, transition_sigma=float(kw.get("noise_transition_smoothness", 100)),
+                        want_mix=False)
+    return tuple(out[k].cpu().numpy() for k in ("rec", "harm", "uv", "bre"))

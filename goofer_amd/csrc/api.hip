@@ -1,0 +1,498 @@
+// C ABI of libgoofer_hip.so: handle lifetime, per-(sr, n_fft, hop) tables, scratch arena and the
+// batch driver that strings the kernels into gf.synthesize (GOOFER.py:971-1220).
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+// launchers living in the other translation units
+int launch_frame_note(goofer_ctx *, const int64_t *, int, int64_t, int *, hipStream_t);
+int launch_rfft_frames_mapped(goofer_ctx *, const float *, const int64_t *, const int64_t *, const int *, int64_t, float2 *, int,
+                              hipStream_t);
+int launch_pulse_peak(goofer_ctx *, float *, double, hipStream_t);
+struct onset_t;
+int launch_pulse_train(goofer_ctx *, const float *, float, const int64_t *, int, int64_t, float *, double *, onset_t *, int32_t *,
+                       int32_t *, hipStream_t);
+int launch_gauss_bins(goofer_ctx *, const float *, float *, int64_t, int, int, const double *, int, const int64_t *, hipStream_t);
+int launch_warp_bins(goofer_ctx *, const float *, float *, int64_t, int, int, const double *, const double *,
+                     const goofer_note_params *, const int *, const int64_t *, double, hipStream_t);
+int launch_knot_decode(goofer_ctx *, const uint16_t *, int, int64_t, const int *, const float *, const float *, float *, int, int,
+                       hipStream_t);
+int launch_harm_shape(goofer_ctx *, float2 *, int, int64_t, const int *, const int64_t *, const int64_t *, const float *,
+                      const float *, const float *, int, const goofer_note_params *, float *, hipStream_t);
+int launch_noise_spectra(goofer_ctx *, float2 *, float2 *, int, int64_t, const int *, const int64_t *, const int64_t *,
+                         const float *, const float *, const float *, const float *, int, const goofer_note_params *, uint64_t,
+                         hipStream_t);
+int launch_mask_short(goofer_ctx *, const float *, const int64_t *, int, int64_t, const double *, int, double *, hipStream_t);
+int launch_stem_gains(goofer_ctx *, float *, float *, float *, const double *, const int64_t *, int, int64_t,
+                      const goofer_note_params *, float *, hipStream_t);
+int launch_apply_gain(goofer_ctx *, float *, float *, float *, float *, float *, const int64_t *, int, int64_t,
+                      const goofer_note_params *, const float *, hipStream_t);
+
+static const size_t ONSET_BYTES = 24;
+
+int goofer_fail(goofer_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small helper kernels of the batch driver
+__global__ void k_row_src(const int64_t *__restrict__ frame_off, const int64_t *__restrict__ env_off,
+                          const int *__restrict__ frame_note, int64_t total_frames, int64_t *__restrict__ row_src)
+{
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= total_frames) return;
+    int note = frame_note[f];
+    int64_t t = f - frame_off[note];
+    int64_t rows = env_off[note + 1] - env_off[note];
+    if (t > rows - 1) t = rows - 1;     // edge-repeat (np.pad mode='edge'); truncation is implicit
+    if (t < 0) t = 0;
+    row_src[f] = env_off[note] + t;
+}
+
+__global__ void k_scale_f0(const float *__restrict__ f0, const int64_t *__restrict__ sample_off, int n_notes, int64_t total,
+                           const goofer_note_params *__restrict__ params, float *__restrict__ out)
+{
+    __shared__ int s_lo;
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    if (threadIdx.x == 0) s_lo = csr_find(sample_off, n_notes, g0);
+    __syncthreads();
+    const int64_t g = g0 + threadIdx.x;
+    if (g >= total) return;
+    int note = s_lo;
+    while (sample_off[note + 1] <= g) ++note;
+    out[g] = f0[g] * params[note].pitch_shift;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scratch arena
+struct arena {
+    char *base;
+    size_t size, used;
+    template <typename T> T *take(size_t count)
+    {
+        size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        if (used + bytes > size) return nullptr;
+        T *p = reinterpret_cast<T *>(base + used);
+        used += bytes;
+        return p;
+    }
+};
+
+static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t samples, int64_t notes)
+{
+    size_t ldc = p.n_bins + 1, ld = (p.n_bins + 3) & ~3;
+    size_t b = 0;
+    auto add = [&](size_t bytes) { b += (bytes + 255) & ~(size_t)255; };
+    add(frames * sizeof(int));                    // frame_note
+    add(frames * sizeof(int64_t));                // row_src
+    add(samples * sizeof(float));                 // f0 scaled
+    add(samples * sizeof(double));                // phase increments
+    add((samples / 2 + 16 * notes + 16) * ONSET_BYTES);
+    add(notes * sizeof(int32_t) + 64);            // onset counts
+    add(64);                                      // overflow flag
+    add(samples * sizeof(float));                 // pulse
+    add(3 * frames * ldc * sizeof(float2));       // S_h, S_uv, S_br
+    add(frames * (size_t)p.n_fft * sizeof(float));  // windowed time frames
+    add(2 * frames * ld * sizeof(float));         // env_h, env_n
+    add((samples / 4 + notes + 16) * sizeof(double));  // smoothed decimated mask
+    add(2 * notes * sizeof(float) + 64);          // note_mag, note_peak
+    return b + 4096;
+}
+
+static int ensure_scratch(goofer_ctx *ctx, size_t bytes)
+{
+    if (ctx->scratch_bytes >= bytes) return GOOFER_OK;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (ctx->scratch) HIP_TRY(ctx, hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->scratch, bytes);
+    if (e != hipSuccess) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    ctx->scratch_bytes = bytes;
+    return GOOFER_OK;
+}
+
+static int ensure_small(goofer_ctx *ctx, size_t bytes)
+{
+    if (ctx->small_bytes >= bytes) return GOOFER_OK;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (ctx->small) HIP_TRY(ctx, hipFree(ctx->small));
+    ctx->small = nullptr;
+    ctx->small_bytes = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->small, bytes));
+    ctx->small_bytes = bytes;
+    return GOOFER_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side table construction (fp64 then rounded exactly where numpy rounds)
+static void gauss_taps_host(double sigma, std::vector<double> &taps, int &radius)
+{
+    radius = (int)(4.0 * sigma + 0.5);          // GOOFER.py:247
+    taps.assign(2 * radius + 1, 0.0);
+    double sum = 0.0;
+    for (int t = -radius; t <= radius; ++t) {
+        double q = (double)t / sigma;
+        taps[t + radius] = exp(-0.5 * (q * q));
+        sum += taps[t + radius];
+    }
+    for (auto &v : taps) v /= sum;
+}
+
+static void ramp_gain_host(int n_bins, double sr, double lo, double hi, double db, std::vector<float> &out)
+{
+    std::vector<double> f(n_bins), g(n_bins, 1.0);
+    double step = (sr / 2.0) / (double)(n_bins - 1);
+    for (int i = 0; i < n_bins; ++i) f[i] = (double)i * step;
+    f[n_bins - 1] = sr / 2.0;
+    int a = (int)(std::lower_bound(f.begin(), f.end(), lo) - f.begin());
+    int b = (int)(std::lower_bound(f.begin(), f.end(), hi) - f.begin());
+    double top = pow(10.0, db / 20.0);
+    int m = b - a;
+    for (int i = 0; i < m; ++i) {
+        double rise = m > 1 ? (i == m - 1 ? 1.0 : (double)i * (1.0 / (double)(m - 1))) : 0.0;
+        g[a + i] = 1.0 + rise * (top - 1.0);
+    }
+    for (int i = b; i < n_bins; ++i) g[i] = top;
+    out.resize(n_bins);
+    for (int i = 0; i < n_bins; ++i) out[i] = (float)g[i];
+}
+
+template <typename T> static int upload(goofer_ctx *ctx, T **dst, const std::vector<T> &src)
+{
+    if (*dst) HIP_TRY(ctx, hipFree(*dst));
+    *dst = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)dst, src.size() * sizeof(T)));
+    HIP_TRY(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return GOOFER_OK;
+}
+
+static void free_plan(goofer_plan_t &p)
+{
+    void *ptrs[] = {p.window, p.win_sq, p.freqs, p.boost, p.bright_h, p.bright_b, p.tw_full, p.tw_half, p.pulse_peak, p.blur5, p.blur175};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    p = goofer_plan_t();
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *goofer_version(void) { return "goofer_hip 0.1 (gfx950)"; }
+
+int goofer_create(int device_id, goofer_ctx **out)
+{
+    if (!out) return GOOFER_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device_id < 0 || device_id >= count) return GOOFER_EHIP;
+    if (hipSetDevice(device_id) != hipSuccess) return GOOFER_EHIP;
+    goofer_ctx *c = new goofer_ctx();
+    c->device = device_id;
+    *out = c;
+    return GOOFER_OK;
+}
+
+void goofer_destroy(goofer_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_plan(ctx->plan);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->small) (void)hipFree(ctx->small);
+    if (ctx->mask_taps) (void)hipFree(ctx->mask_taps);
+    delete ctx;
+}
+
+const char *goofer_last_error(const goofer_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int goofer_plan(goofer_ctx *ctx, int sr, int n_fft, int hop)
+{
+    if (!ctx) return GOOFER_EINVAL;
+    if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return goofer_fail(ctx, GOOFER_EINVAL, "n_fft must be 512, 1024 or 2048 (got %d)", n_fft);
+    if (hop <= 0 || hop > n_fft || sr <= 0) return goofer_fail(ctx, GOOFER_EINVAL, "bad sr/hop (%d, %d)", sr, hop);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    free_plan(ctx->plan);
+    goofer_plan_t &p = ctx->plan;
+    const int B = n_fft / 2 + 1, M = n_fft / 2;
+    const double PI = 3.14159265358979323846;
+
+    std::vector<float> win(n_fft), wsq(n_fft), freqs(B), boost(B), bh, bb;
+    for (int i = 0; i < n_fft; ++i) {
+        // np.hanning: 0.5 + 0.5 cos(pi n/(M-1)), n = 1-M, 3-M, ...   -> fp32 -> sqrt (numpy's ** 0.5)
+        double n = (double)(1 - n_fft + 2 * i);
+        float h = (float)(0.5 + 0.5 * cos(PI * n / (double)(n_fft - 1)));
+        win[i] = sqrtf(h);
+        wsq[i] = win[i] * win[i];
+    }
+    {
+        double val = 1.0 / ((double)n_fft * (1.0 / (double)sr));   // np.fft.rfftfreq
+        for (int k = 0; k < B; ++k) freqs[k] = (float)((double)k * val);
+        double step = 99.0 / (double)(B - 1);                      // np.linspace(1, 100, B)
+        for (int k = 0; k < B; ++k) boost[k] = (float)((double)k * step + 1.0);
+        boost[B - 1] = 100.0f;
+    }
+    ramp_gain_host(B, (double)sr, 2000.0, 3500.0, 3.0, bh);
+    ramp_gain_host(B, (double)sr, 3500.0, 5000.0, 20.0, bb);
+    std::vector<float2> twf(M), twh(M / 2 + 1);
+    for (int k = 0; k < M; ++k) twf[k] = make_float2((float)cos(-2.0 * PI * k / M), (float)sin(-2.0 * PI * k / M));
+    for (int k = 0; k <= M / 2; ++k) twh[k] = make_float2((float)cos(-PI * k / M), (float)sin(-PI * k / M));
+    std::vector<double> t5, t175;
+    int r5, r175;
+    gauss_taps_host(0.5, t5, r5);
+    gauss_taps_host(1.75, t175, r175);
+
+    int rc;
+    if ((rc = upload(ctx, &p.window, win))) return rc;
+    if ((rc = upload(ctx, &p.win_sq, wsq))) return rc;
+    if ((rc = upload(ctx, &p.freqs, freqs))) return rc;
+    if ((rc = upload(ctx, &p.boost, boost))) return rc;
+    if ((rc = upload(ctx, &p.bright_h, bh))) return rc;
+    if ((rc = upload(ctx, &p.bright_b, bb))) return rc;
+    if ((rc = upload(ctx, &p.tw_full, twf))) return rc;
+    if ((rc = upload(ctx, &p.tw_half, twh))) return rc;
+    if ((rc = upload(ctx, &p.blur5, t5))) return rc;
+    if ((rc = upload(ctx, &p.blur175, t175))) return rc;
+    HIP_TRY(ctx, hipMalloc((void **)&p.pulse_peak, 8193 * sizeof(float)));
+    p.sr = sr; p.n_fft = n_fft; p.hop = hop; p.n_bins = B;
+    if ((rc = launch_pulse_peak(ctx, p.pulse_peak, (double)sr, 0))) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return GOOFER_OK;
+}
+
+int goofer_reserve(goofer_ctx *ctx, int64_t max_frames, int64_t max_samples, int64_t max_notes)
+{
+    if (!ctx) return GOOFER_EINVAL;
+    if (!ctx->plan.n_fft) return goofer_fail(ctx, GOOFER_ENOPLAN, "goofer_plan first");
+    return ensure_scratch(ctx, scratch_need(ctx->plan, max_frames, max_samples, max_notes));
+}
+
+// copy one plan table to host memory (tests / debugging); which: 0 window 1 freqs 2 boost 3 bright_h
+// 4 bright_b 5 pulse_peak; returns the element count or a negative error
+int goofer_debug_table(goofer_ctx *ctx, int which, float *host_out, int capacity)
+{
+    if (!ctx || !ctx->plan.n_fft) return GOOFER_ENOPLAN;
+    const goofer_plan_t &p = ctx->plan;
+    const float *src[] = {p.window, p.freqs, p.boost, p.bright_h, p.bright_b, p.pulse_peak};
+    const int cnt[] = {p.n_fft, p.n_bins, p.n_bins, p.n_bins, p.n_bins, 8193};
+    if (which < 0 || which > 5) return GOOFER_EINVAL;
+    int n = std::min(cnt[which], capacity);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(host_out, src[which], n * sizeof(float), hipMemcpyDeviceToHost));
+    return cnt[which];
+}
+
+#define NEED_PLAN(ctx)                                                                    \
+    if (!(ctx)) return GOOFER_EINVAL;                                                     \
+    if (!(ctx)->plan.n_fft) return goofer_fail((ctx), GOOFER_ENOPLAN, "goofer_plan first")
+
+int goofer_rfft_frames(goofer_ctx *ctx, const float *x, const int64_t *sample_off, const int64_t *frame_off, int n_notes,
+                       int64_t total_frames, float *S, int ldc, void *stream)
+{
+    NEED_PLAN(ctx);
+    if (ldc < ctx->plan.n_bins) return goofer_fail(ctx, GOOFER_EINVAL, "ldc %d < n_bins %d", ldc, ctx->plan.n_bins);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_scratch(ctx, total_frames * sizeof(int) + 4096);
+    if (rc) return rc;
+    int *frame_note = (int *)ctx->scratch;
+    if ((rc = launch_frame_note(ctx, frame_off, n_notes, total_frames, frame_note, st))) return rc;
+    return launch_rfft_frames_mapped(ctx, x, sample_off, frame_off, frame_note, total_frames, (float2 *)S, ldc, st);
+}
+
+int goofer_irfft_ola(goofer_ctx *ctx, const float *S, int ldc, const int64_t *sample_off, const int64_t *frame_off, int n_notes,
+                     int64_t total_frames, int64_t total_samples, float *y, void *stream)
+{
+    NEED_PLAN(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_scratch(ctx, (size_t)total_frames * ctx->plan.n_fft * sizeof(float) + 4096);
+    if (rc) return rc;
+    float *frames = (float *)ctx->scratch;
+    if ((rc = launch_irfft_frames(ctx, (const float2 *)S, ldc, total_frames, frames, st))) return rc;
+    return launch_ola_gather(ctx, frames, sample_off, frame_off, n_notes, total_samples, y, nullptr, st);
+}
+
+int goofer_pulse_train(goofer_ctx *ctx, const float *f0, const int64_t *sample_off, int n_notes, int64_t total_samples,
+                       float *pulse, void *stream)
+{
+    NEED_PLAN(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    size_t need = total_samples * sizeof(double) + (total_samples / 2 + 16 * (size_t)n_notes + 16) * ONSET_BYTES +
+                  n_notes * sizeof(int32_t) + 4096;
+    int rc = ensure_scratch(ctx, need);
+    if (rc) return rc;
+    arena a{(char *)ctx->scratch, ctx->scratch_bytes, 0};
+    double *inc = a.take<double>(total_samples);
+    char *onsets = a.take<char>((total_samples / 2 + 16 * (size_t)n_notes + 16) * ONSET_BYTES);
+    int32_t *cnt = a.take<int32_t>(n_notes + 16);
+    int32_t *ovf = a.take<int32_t>(16);
+    if (!inc || !onsets || !cnt || !ovf) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
+    HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), st));
+    return launch_pulse_train(ctx, f0, 1.0f, sample_off, n_notes, total_samples, pulse, inc, (onset_t *)onsets, cnt, ovf, st);
+}
+
+int goofer_gauss_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows, int n_bins, int ld, const double *taps,
+                      int radius, void *stream)
+{
+    if (!ctx) return GOOFER_EINVAL;
+    if (radius < 0 || radius > 4096 || n_bins <= 0 || ld < n_bins) return goofer_fail(ctx, GOOFER_EINVAL, "bad gauss geometry");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_small(ctx, 65536);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->small, taps, (2 * radius + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+    return launch_gauss_bins(ctx, in, out, rows, n_bins, ld, (const double *)ctx->small, radius, nullptr, st);
+}
+
+int goofer_warp_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows, int n_bins, int ld, const double *formants,
+                     const double *f_shift, double ratio, void *stream)
+{
+    NEED_PLAN(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    const double *d_shift = nullptr;
+    if (f_shift) {
+        int rc = ensure_small(ctx, 65536);
+        if (rc) return rc;
+        d_shift = (const double *)((char *)ctx->small + 32768);
+        HIP_TRY(ctx, hipMemcpyAsync((void *)d_shift, f_shift, 4 * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    return launch_warp_bins(ctx, in, out, rows, n_bins, ld, formants, d_shift, nullptr, nullptr, nullptr, ratio, st);
+}
+
+int goofer_knot_decode(goofer_ctx *ctx, const uint16_t *knots_f16, int K, const float *hz_knots, int64_t rows, float *env,
+                       int n_bins, int ld, void *stream)
+{
+    NEED_PLAN(ctx);
+    if (K < 2 || K > 4096) return goofer_fail(ctx, GOOFER_EINVAL, "bad knot count %d", K);
+    hipStream_t st = (hipStream_t)stream;
+    const goofer_plan_t &p = ctx->plan;
+    // 2-tap lerp plan, fp32 arithmetic like precompute_interp_matrix (GOOFER.py:84-90)
+    std::vector<int> idx(n_bins);
+    std::vector<float> w0(n_bins), w1(n_bins);
+    double val = 1.0 / ((double)p.n_fft * (1.0 / (double)p.sr));
+    for (int b = 0; b < n_bins; ++b) {
+        float f = (float)((double)b * val);
+        int i = (int)(std::upper_bound(hz_knots, hz_knots + K, f) - hz_knots) - 1;   // searchsorted(side='right') - 1
+        i = std::min(std::max(i, 0), K - 2);
+        float x0 = hz_knots[i], x1 = hz_knots[i + 1];
+        float den = std::max(x1 - x0, 1e-12f);
+        float b1 = (f - x0) / den;
+        idx[b] = i; w1[b] = b1; w0[b] = 1.0f - b1;
+    }
+    int rc = ensure_small(ctx, 65536);
+    if (rc) return rc;
+    if ((size_t)n_bins * 12 > 32768) return goofer_fail(ctx, GOOFER_EINVAL, "n_bins too large");
+    char *d = (char *)ctx->small;
+    int *d_idx = (int *)d;
+    float *d_w0 = (float *)(d + 4 * (size_t)n_bins), *d_w1 = (float *)(d + 8 * (size_t)n_bins);
+    HIP_TRY(ctx, hipMemcpyAsync(d_idx, idx.data(), n_bins * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_w0, w0.data(), n_bins * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_w1, w1.data(), n_bins * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));   // the host vectors die at return
+    return launch_knot_decode(ctx, knots_f16, K, rows, d_idx, d_w0, d_w1, env, n_bins, ld, st);
+}
+
+int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
+{
+    NEED_PLAN(ctx);
+    if (!b) return goofer_fail(ctx, GOOFER_EINVAL, "null batch");
+    const goofer_plan_t &p = ctx->plan;
+    if (b->n_bins != p.n_bins || b->ld < p.n_bins) return goofer_fail(ctx, GOOFER_EINVAL, "batch geometry does not match the plan");
+    if (b->n_notes <= 0 || b->total_samples <= 0) return GOOFER_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t F = b->total_frames, N = b->total_samples;
+    const int n = b->n_notes, ld = b->ld, ldc = p.n_bins + 1;
+
+    int rc = ensure_scratch(ctx, scratch_need(p, F, N, n) + (size_t)F * (ld - ((p.n_bins + 3) & ~3)) * 2 * sizeof(float));
+    if (rc) return rc;
+    arena a{(char *)ctx->scratch, ctx->scratch_bytes, 0};
+    int *frame_note = a.take<int>(F);
+    int64_t *row_src = a.take<int64_t>(F);
+    float *f0s = a.take<float>(N);
+    double *inc = a.take<double>(N);
+    char *onsets = a.take<char>((N / 2 + 16 * (size_t)n + 16) * ONSET_BYTES);
+    int32_t *onset_cnt = a.take<int32_t>(n + 16);
+    int32_t *ovf = a.take<int32_t>(16);
+    float *pulse = a.take<float>(N);
+    float2 *S_h = a.take<float2>((size_t)F * ldc);
+    float2 *S_uv = a.take<float2>((size_t)F * ldc);
+    float2 *S_br = a.take<float2>((size_t)F * ldc);
+    float *frames = a.take<float>((size_t)F * p.n_fft);
+    float *env_h = a.take<float>((size_t)F * ld);
+    float *env_n = a.take<float>((size_t)F * ld);
+    double *short_s = a.take<double>(N / 4 + n + 16);
+    float *note_mag = a.take<float>(2 * (size_t)n + 16);
+    if (!frame_note || !row_src || !f0s || !inc || !onsets || !onset_cnt || !ovf || !pulse || !S_h || !S_uv || !S_br || !frames ||
+        !env_h || !env_n || !short_s || !note_mag)
+        return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
+    float *note_peak = note_mag + n;
+
+    // mask-smoothing taps for this call's sigma; device copy cached on the handle (steady state:
+    // no host work, no synchronisation)
+    if (ctx->mask_taps_sigma != b->transition_sigma || !ctx->mask_taps) {
+        std::vector<double> mtaps;
+        int mrad;
+        gauss_taps_host(std::max(1.0, (double)b->transition_sigma / 4.0), mtaps, mrad);   // GOOFER.py:561
+        if (mrad > 2048) return goofer_fail(ctx, GOOFER_EINVAL, "transition sigma too large");
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        if (!ctx->mask_taps) HIP_TRY(ctx, hipMalloc((void **)&ctx->mask_taps, 4097 * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpy(ctx->mask_taps, mtaps.data(), mtaps.size() * sizeof(double), hipMemcpyHostToDevice));
+        ctx->mask_taps_sigma = b->transition_sigma;
+        ctx->mask_taps_radius = mrad;
+    }
+    const double *d_mtaps = ctx->mask_taps;
+    const int mrad = ctx->mask_taps_radius;
+
+    HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), st));
+
+    unsigned fb = (unsigned)((F + 255) / 256), sb = (unsigned)((N + 255) / 256);
+    if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, st))) return rc;
+    hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, st, b->frame_off, b->env_off, frame_note, F, row_src);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_scale_f0, dim3(sb), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s);
+    LAUNCH_CHECK(ctx);
+
+    // envelopes: noise envelope from the un-warped rows (GOOFER.py:993), harmonic envelope warped
+    if ((rc = launch_gauss_bins(ctx, b->env, env_n, F, p.n_bins, ld, p.blur175, 7, row_src, st))) return rc;
+    if ((rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, st)))
+        return rc;
+
+    // harmonic branch
+    if ((rc = launch_pulse_train(ctx, f0s, 1.0f, b->sample_off, n, N, pulse, inc, (onset_t *)onsets, onset_cnt, ovf, st))) return rc;
+    if ((rc = launch_rfft_frames_mapped(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, st))) return rc;
+    if ((rc = launch_harm_shape(ctx, S_h, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, env_h, ld, b->params,
+                                note_mag, st)))
+        return rc;
+    if ((rc = launch_irfft_frames(ctx, S_h, ldc, F, frames, st))) return rc;
+    if ((rc = launch_ola_gather(ctx, frames, b->sample_off, b->frame_off, n, N, b->harm, note_mag, st))) return rc;
+
+    // aperiodic branch
+    if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, env_n, b->phi, ld,
+                                   b->params, b->seed, st)))
+        return rc;
+    if ((rc = launch_irfft_frames(ctx, S_br, ldc, F, frames, st))) return rc;
+    if ((rc = launch_ola_gather(ctx, frames, b->sample_off, b->frame_off, n, N, b->bre, nullptr, st))) return rc;
+    if ((rc = launch_irfft_frames(ctx, S_uv, ldc, F, frames, st))) return rc;
+    if ((rc = launch_ola_gather(ctx, frames, b->sample_off, b->frame_off, n, N, b->uv, nullptr, st))) return rc;
+
+    // gains, peak normalisation, mix
+    if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, short_s, st))) return rc;
+    if ((rc = launch_stem_gains(ctx, b->harm, b->uv, b->bre, short_s, b->sample_off, n, N, b->params, note_peak, st))) return rc;
+    if ((rc = launch_apply_gain(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, N, b->params, note_peak, st))) return rc;
+    return GOOFER_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,470 @@
+// Bin-axis kernels on the [frames x bins] matrix for gfx950: one 64-lane wave owns one frame row,
+// the row is staged in LDS, neighbours along the bin axis come from LDS, reductions are wavefront
+// shuffles.  All HBM traffic is row-contiguous (coalesced); no MFMA (2-tap lerps and <=57-tap FIRs).
+//
+//   k_gauss_bins     gf.gaussian_filter1d(axis=0)                      GOOFER.py:241-261
+//   k_warp_bins      gf.warp_env_by_formants + gf.shift_formants       GOOFER.py:840-875, 618-627
+//   k_knot_decode    gf.decode_env_from_knots                          GOOFER.py:149-168
+//   k_harm_shape     high-pass mask, env*boost, brightness + 5-tap blur GOOFER.py:1102-1144
+//   k_noise_spectra  random-phase noise stems                          GOOFER.py:1148-1173
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+constexpr int ROWS_PER_BLOCK = 4;   // one wave per row, 256-thread workgroups
+
+// ---------------------------------------------------------------------------------------------
+// Gaussian FIR along bins; taps fp64 [2r+1]; numpy 'reflect' padding; fp64 accumulate, fp32 store.
+__global__ __launch_bounds__(256) void k_gauss_bins(const float *__restrict__ in, float *__restrict__ out, int64_t rows,
+                                                    int n_bins, int ld, const double *__restrict__ taps, int radius,
+                                                    const int64_t *__restrict__ row_src)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *s_taps = reinterpret_cast<double *>(smem);
+    float *s_rows = reinterpret_cast<float *>(s_taps + (2 * radius + 1));
+    for (int i = threadIdx.x; i < 2 * radius + 1; i += blockDim.x) s_taps[i] = taps[i];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
+    float *r = s_rows + wave * n_bins;
+    if (row < rows) {
+        const int64_t src = row_src ? row_src[row] : row;
+        for (int b = lane; b < n_bins; b += WAVE) r[b] = in[src * ld + b];
+    }
+    __syncthreads();
+    if (row >= rows) return;
+    for (int b = lane; b < n_bins; b += WAVE) {
+        double acc = 0.0;
+        if (b >= radius && b + radius < n_bins) {
+            for (int j = 0; j <= 2 * radius; ++j) acc += s_taps[j] * (double)r[b + j - radius];
+        } else {
+            for (int j = 0; j <= 2 * radius; ++j) acc += s_taps[j] * (double)r[reflect_index(b + j - radius, n_bins)];
+        }
+        out[row * ld + b] = (float)acc;
+    }
+}
+
+int launch_gauss_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows, int n_bins, int ld, const double *d_taps,
+                      int radius, const int64_t *row_src, hipStream_t st)
+{
+    if (rows <= 0) return GOOFER_OK;
+    size_t lds = sizeof(double) * (2 * radius + 1) + sizeof(float) * ROWS_PER_BLOCK * n_bins;
+    hipLaunchKernelGGL(k_gauss_bins, dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), lds, st, in, out,
+                       rows, n_bins, ld, d_taps, radius, row_src);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// numpy's binary_search_with_guess (numpy/_core/src/multiarray/compiled_base.c) restated for the
+// short anchor arrays of warp_env_by_formants: np.interp is called there with a possibly
+// NON-monotone xp (anchors are not sorted, GOOFER.py:855-870), so the index it returns depends on
+// the guess carried over from the previous (ascending) query.  We reproduce that exactly.
+__device__ __forceinline__ int np_search_guess(double key, const double *arr, int len, int guess)
+{
+    if (key > arr[len - 1]) return len;
+    if (key < arr[0]) return -1;
+    if (len <= 4) {
+        int i = 1;
+        while (i < len && key >= arr[i]) ++i;
+        return i - 1;
+    }
+    if (guess > len - 3) guess = len - 3;
+    if (guess < 1) guess = 1;
+    int imin = 0, imax = len;
+    if (key < arr[guess]) {
+        if (key < arr[guess - 1]) {
+            imax = guess - 1;   // (the LIKELY_IN_CACHE_SIZE=8 refinement can never trigger for len <= 6)
+        } else {
+            return guess - 1;
+        }
+    } else {
+        if (key < arr[guess + 1]) return guess;
+        if (key < arr[guess + 2]) return guess + 1;
+        imin = guess + 2;
+    }
+    while (imin < imax) {
+        int imid = imin + ((imax - imin) >> 1);
+        if (key >= arr[imid]) imin = imid + 1; else imax = imid;
+    }
+    return imin - 1;
+}
+
+// np.interp value for index j (arr_interp inner body), xp/fp short arrays
+__device__ __forceinline__ double np_interp_eval(double x, int j, const double *xp, const double *fp, int len)
+{
+    if (j == -1) return fp[0];
+    if (j == len) return fp[len - 1];
+    if (j == len - 1) return fp[j];
+    if (x == xp[j]) return fp[j];
+    double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    double v = slope * (x - xp[j]) + fp[j];
+    if (isnan(v)) {
+        v = slope * (x - xp[j + 1]) + fp[j + 1];
+        if (isnan(v) && fp[j] == fp[j + 1]) v = fp[j];
+    }
+    return v;
+}
+
+// linear interpolation of an fp32 row sampled on the uniform grid b*step, at x in [0, nyq]
+// (np.interp with sorted xp: largest j with xp[j] <= x), plus gf.interp1d's linear extrapolation.
+__device__ __forceinline__ double row_interp(const float *r, int n_bins, double step, double nyq, double x)
+{
+    if (x < 0.0) {
+        double sl = (double)(r[1] - r[0]) / (step + 1e-10);           // fp32 difference, like the reference
+        return (double)r[0] + sl * (x - 0.0);
+    }
+    if (x > nyq) {
+        double xl = (double)(n_bins - 2) * step;
+        double sl = (double)(r[n_bins - 1] - r[n_bins - 2]) / (nyq - xl + 1e-10);
+        return (double)r[n_bins - 1] + sl * (x - nyq);
+    }
+    int j = (int)floor(x / step);
+    if (j > n_bins - 1) j = n_bins - 1;
+    if (j < 0) j = 0;
+    // grid point j is j*step, except the last which linspace pins to nyq
+    auto grid = [&](int q) { return q >= n_bins - 1 ? nyq : (double)q * step; };
+    while (j + 1 <= n_bins - 1 && grid(j + 1) <= x) ++j;
+    while (j > 0 && grid(j) > x) --j;
+    if (j >= n_bins - 1) return (double)r[n_bins - 1];
+    double xj = grid(j);
+    if (x == xj) return (double)r[j];
+    double slope = ((double)r[j + 1] - (double)r[j]) / (grid(j + 1) - xj);
+    return slope * (x - xj) + (double)r[j];
+}
+
+// Per-row formant-anchored warp then uniform warp.  f_shift == nullptr skips the first stage,
+// ratio == 1 the second; each stage rounds to fp32 (np.zeros_like(env) in the reference).
+// rows may be addressed through row_map (source row per output row), or identity when nullptr.
+__global__ __launch_bounds__(256) void k_warp_bins(const float *__restrict__ in, float *__restrict__ out, int64_t rows,
+                                                   int n_bins, int ld, const double *__restrict__ formants,
+                                                   const double *__restrict__ f_shift_global,
+                                                   const goofer_note_params *__restrict__ params,
+                                                   const int *__restrict__ row_note, const int64_t *__restrict__ row_src,
+                                                   double ratio_global, double nyq)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *s_all = reinterpret_cast<float *>(smem);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
+    if (row >= rows) return;                       // no block-level barrier below
+    float *ra = s_all + (2 * wave) * n_bins;
+    float *rb = ra + n_bins;
+    const int64_t src = row_src ? row_src[row] : row;
+    for (int b = lane; b < n_bins; b += WAVE) ra[b] = in[src * ld + b];
+    wave_lds_sync();
+
+    double fs[4];
+    double ratio = ratio_global;
+    bool warp = false;
+    if (params) {
+        const goofer_note_params &p = params[row_note[row]];
+        for (int i = 0; i < 4; ++i) fs[i] = p.f_shift[i];
+        ratio = (double)p.formant_shift;
+        warp = (fs[0] != 1.0) || (fs[1] != 1.0) || (fs[2] != 1.0) || (fs[3] != 1.0);
+    } else if (f_shift_global) {
+        for (int i = 0; i < 4; ++i) fs[i] = f_shift_global[i];
+        warp = true;   // the caller decides (gf.synthesize tests any(shift != 1))
+    }
+    const double step = nyq / (double)(n_bins - 1);
+    float *cur = ra, *nxt = rb;
+
+    if (warp && formants) {
+        // anchors: (0,0), valid (shifted -> orig), (nyq, nyq)      GOOFER.py:850-865
+        double dst[6], sp[6];
+        int len = 0;
+        dst[len] = 0.0; sp[len] = 0.0; ++len;
+        for (int i = 0; i < 4; ++i) {
+            double fo = formants[src * 4 + i];
+            double fsft = fo * fs[i];
+            if (fo > 50.0 && fo < nyq && fsft > 50.0) { dst[len] = fsft; sp[len] = fo; ++len; }
+        }
+        dst[len] = nyq; sp[len] = nyq; ++len;
+
+        // Resolve np.interp's guess chain over the ascending bin frequencies.  The clamped guess
+        // takes at most 3 values (1..len-3), so each bin is a map state->state; lanes own
+        // contiguous chunks, compose their maps, scan across the wave, then replay.
+        const int per = (n_bins + WAVE - 1) / WAVE;
+        const int b0 = lane * per;
+        auto clampg = [&](int g) { int hi = len - 3; if (g > hi) g = hi; if (g < 1) g = 1; return g; };
+        int m1 = 1, m2 = 2, m3 = 3;                 // composed map of this lane's chunk: state s -> m_s
+        if (len > 4) {
+            for (int q = 0; q < per; ++q) {
+                int b = b0 + q;
+                if (b >= n_bins) break;
+                double x = b >= n_bins - 1 ? nyq : (double)b * step;
+                m1 = clampg(np_search_guess(x, dst, len, m1));
+                m2 = clampg(np_search_guess(x, dst, len, m2));
+                m3 = clampg(np_search_guess(x, dst, len, m3));
+            }
+            // inclusive scan of map composition (earlier lanes apply first)
+            for (int off = 1; off < WAVE; off <<= 1) {
+                int p1 = __shfl_up(m1, off, WAVE), p2 = __shfl_up(m2, off, WAVE), p3 = __shfl_up(m3, off, WAVE);
+                if (lane >= off) {
+                    // new(s) = mine(prev(s))
+                    int a1 = p1 == 1 ? m1 : (p1 == 2 ? m2 : m3);
+                    int a2 = p2 == 1 ? m1 : (p2 == 2 ? m2 : m3);
+                    int a3 = p3 == 1 ? m1 : (p3 == 2 ? m2 : m3);
+                    m1 = a1; m2 = a2; m3 = a3;
+                }
+            }
+        }
+        // state entering this lane's chunk = inclusive result of lane-1 applied to the initial guess
+        int incoming = __shfl_up(m1, 1, WAVE);       // initial j = 0 clamps to state 1
+        int state = lane == 0 ? 1 : incoming;
+        int guess = lane == 0 ? 0 : state;
+        for (int q = 0; q < per; ++q) {
+            int b = b0 + q;
+            if (b >= n_bins) break;
+            double x = b >= n_bins - 1 ? nyq : (double)b * step;
+            int j = np_search_guess(x, dst, len, guess);
+            guess = j;
+            double wf = np_interp_eval(x, j, dst, sp, len);
+            nxt[b] = (float)row_interp(cur, n_bins, step, nyq, wf);
+        }
+        wave_lds_sync();
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    if (ratio != 1.0) {
+        for (int b = lane; b < n_bins; b += WAVE) {
+            double x = b >= n_bins - 1 ? nyq : (double)b * step;
+            double q = x / ratio;
+            q = q < 0.0 ? 0.0 : (q > nyq ? nyq : q);
+            nxt[b] = (float)row_interp(cur, n_bins, step, nyq, q);
+        }
+        wave_lds_sync();
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    for (int b = lane; b < n_bins; b += WAVE) out[row * ld + b] = cur[b];
+}
+
+int launch_warp_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows, int n_bins, int ld, const double *formants,
+                     const double *d_f_shift, const goofer_note_params *params, const int *row_note,
+                     const int64_t *row_src, double ratio, hipStream_t st)
+{
+    if (rows <= 0) return GOOFER_OK;
+    size_t lds = sizeof(float) * 2 * ROWS_PER_BLOCK * n_bins;
+    hipLaunchKernelGGL(k_warp_bins, dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), lds, st, in, out,
+                       rows, n_bins, ld, formants, d_f_shift, params, row_note, row_src, ratio, (double)ctx->plan.sr / 2.0);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// env[row][b] = exp(w0[b]*knot[idx[b]] + w1[b]*knot[idx[b]+1]); the reference's dense W @ knots
+// has exactly these two non-zeros per row.
+__global__ __launch_bounds__(256) void k_knot_decode(const __half *__restrict__ knots, int K, int64_t rows,
+                                                     const int *__restrict__ idx, const float *__restrict__ w0,
+                                                     const float *__restrict__ w1, float *__restrict__ env, int n_bins, int ld)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *s_k = reinterpret_cast<float *>(smem);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
+    if (row >= rows) return;
+    float *kv = s_k + wave * K;
+    for (int k = lane; k < K; k += WAVE) kv[k] = __half2float(knots[row * K + k]);
+    wave_lds_sync();
+    for (int b = lane; b < n_bins; b += WAVE) {
+        int i = idx[b];
+        float v = w0[b] * kv[i] + w1[b] * kv[i + 1];
+        env[row * ld + b] = expf(v);
+    }
+}
+
+int launch_knot_decode(goofer_ctx *ctx, const uint16_t *knots, int K, int64_t rows, const int *idx, const float *w0,
+                       const float *w1, float *env, int n_bins, int ld, hipStream_t st)
+{
+    if (rows <= 0) return GOOFER_OK;
+    hipLaunchKernelGGL(k_knot_decode, dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256),
+                       sizeof(float) * ROWS_PER_BLOCK * K, st, reinterpret_cast<const __half *>(knots), K, rows, idx, w0, w1, env,
+                       n_bins, ld);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame -> per-frame picks of the per-sample arrays: x[::hop] edge-padded to T (GOOFER.py:1104-1106)
+__device__ __forceinline__ int64_t pick_index(int64_t t, int64_t n, int hop)
+{
+    int64_t cnt = (n + hop - 1) / hop;            // len(x[::hop])
+    if (cnt <= 0) return 0;
+    int64_t q = t < cnt ? t : cnt - 1;
+    return q * hop;
+}
+
+__device__ __forceinline__ float hp_mask(float freq, float f0f)
+{
+    float z = (freq - f0f) / 5.0f;
+    z = fminf(fmaxf(z, -60.0f), 60.0f);
+    return 1.0f / (1.0f + expf(-z));
+}
+
+// 5-tap sigma=0.5 blur of a complex row held in LDS (reflect padded), complex128 accumulate
+__device__ __forceinline__ float2 blur5(const float2 *r, int k, int n_bins, const double *t5)
+{
+    double re = 0.0, im = 0.0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        int q = k + j - 2;
+        q = q < 0 ? -q : (q >= n_bins ? 2 * (n_bins - 1) - q : q);
+        float2 v = r[q];
+        re += t5[j] * (double)v.x;
+        im += t5[j] * (double)v.y;
+    }
+    return make_float2((float)re, (float)im);
+}
+
+// In place on S: optional high-pass, per-note max(|S| + 1e-8), then * env * boost, and on voiced
+// frames * brightness followed by the 5-tap blur.  The 1/max normalisation commutes with the
+// (linear) rest of the chain and is applied after the overlap-add.
+__global__ __launch_bounds__(256) void k_harm_shape(float2 *__restrict__ S, int ldc, int64_t total_frames,
+                                                    const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
+                                                    const int64_t *__restrict__ sample_off, const float *__restrict__ f0,
+                                                    const float *__restrict__ mask, const float *__restrict__ env, int ld,
+                                                    const goofer_note_params *__restrict__ params, float *__restrict__ note_mag,
+                                                    const float *__restrict__ freqs, const float *__restrict__ boost,
+                                                    const float *__restrict__ bright, const double *__restrict__ taps5,
+                                                    int n_bins, int hop)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *s_rows = reinterpret_cast<float2 *>(smem);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t f = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
+    if (f >= total_frames) return;
+    float2 *r = s_rows + wave * n_bins;
+    const int note = frame_note[f];
+    const goofer_note_params p = params[note];
+    const int64_t t = f - frame_off[note];
+    const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+    const int64_t pk = pick_index(t, n, hop);
+    const float f0f = n > 0 ? f0[base + pk] : 0.f;   // f0 already carries pitch_shift
+    const bool voiced = p.apply_brightness && n > 0 && mask[base + pk] > 0.f;
+    double t5[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) t5[j] = taps5[j];
+
+    float2 *row = S + f * (int64_t)ldc;
+    const float *er = env + f * (int64_t)ld;
+    float mx = 0.f;
+    for (int k = lane; k < n_bins; k += WAVE) {
+        float2 s = row[k];
+        if (p.cut_below_f0) {
+            float h = hp_mask(freqs[k], f0f);
+            s.x *= h; s.y *= h;
+        }
+        mx = fmaxf(mx, hypotf(s.x, s.y) + 1e-8f);
+        float g = er[k];
+        s.x = (s.x * g) * boost[k];
+        s.y = (s.y * g) * boost[k];
+        if (voiced) { s.x *= bright[k]; s.y *= bright[k]; }
+        r[k] = s;
+    }
+    mx = wave_max(mx);
+    if (lane == 0) atomic_max_pos(note_mag + note, mx);
+    if (voiced) {
+        wave_lds_sync();
+        for (int k = lane; k < n_bins; k += WAVE) row[k] = blur5(r, k, n_bins, t5);
+    } else {
+        for (int k = lane; k < n_bins; k += WAVE) row[k] = r[k];
+    }
+}
+
+int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames, const int *frame_note, const int64_t *frame_off,
+                      const int64_t *sample_off, const float *f0, const float *mask, const float *env, int ld,
+                      const goofer_note_params *params, float *note_mag, hipStream_t st)
+{
+    if (total_frames <= 0) return GOOFER_OK;
+    const goofer_plan_t &pl = ctx->plan;
+    hipLaunchKernelGGL(k_harm_shape, dim3((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256),
+                       sizeof(float2) * ROWS_PER_BLOCK * pl.n_bins, st, S, ldc, total_frames, frame_note, frame_off, sample_off, f0,
+                       mask, env, ld, params, note_mag, pl.freqs, pl.boost, pl.bright_h, pl.blur5, pl.n_bins, pl.hop);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox-4x32-10 keyed by (seed), counter (frame, bin): uniform phase in [0, 2 pi) when no phase
+// matrix is injected.
+__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t ctr_hi, uint32_t ctr_lo)
+{
+    uint32_t c0 = ctr_lo, c1 = (uint32_t)ctr_hi, c2 = (uint32_t)(ctr_hi >> 32), c3 = 0x9E3779B9u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+// S_uv = U * env_noise ; S_br = (U * env_noise) * HP, brightened + blurred on voiced frames.
+__global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv, float2 *__restrict__ S_br, int ldc,
+                                                       int64_t total_frames, const int *__restrict__ frame_note,
+                                                       const int64_t *__restrict__ frame_off, const int64_t *__restrict__ sample_off,
+                                                       const float *__restrict__ f0, const float *__restrict__ mask,
+                                                       const float *__restrict__ env_noise, const float *__restrict__ phi, int ld,
+                                                       const goofer_note_params *__restrict__ params, uint64_t seed,
+                                                       const float *__restrict__ freqs, const float *__restrict__ bright,
+                                                       const double *__restrict__ taps5, int n_bins, int hop)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *s_rows = reinterpret_cast<float2 *>(smem);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t f = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
+    if (f >= total_frames) return;
+    float2 *r = s_rows + wave * n_bins;
+    const int note = frame_note[f];
+    const goofer_note_params p = params[note];
+    const int64_t t = f - frame_off[note];
+    const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+    const int64_t pk = pick_index(t, n, hop);
+    const float f0f = n > 0 ? f0[base + pk] : 0.f;   // f0 already carries pitch_shift
+    const bool voiced = p.apply_brightness && n > 0 && mask[base + pk] > 0.f;
+    double t5[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) t5[j] = taps5[j];
+
+    const float *er = env_noise + f * (int64_t)ld;
+    float2 *ru = S_uv + f * (int64_t)ldc;
+    float2 *rb = S_br + f * (int64_t)ldc;
+    for (int k = lane; k < n_bins; k += WAVE) {
+        float ph;
+        if (phi) {
+            ph = phi[f * (int64_t)ld + k];
+        } else {
+            uint32_t u = philox_u32(seed, (uint64_t)f, (uint32_t)k);
+            ph = (float)(u >> 8) * (6.283185307179586f / 16777216.0f);
+        }
+        float c = cosf(ph), s = sinf(ph);
+        float e = er[k];
+        float2 u = make_float2(c * e, s * e);
+        ru[k] = u;
+        float h = hp_mask(freqs[k], f0f);
+        float2 b = make_float2(u.x * h, u.y * h);
+        if (voiced) { b.x *= bright[k]; b.y *= bright[k]; }
+        r[k] = b;
+    }
+    if (voiced) {
+        wave_lds_sync();
+        for (int k = lane; k < n_bins; k += WAVE) rb[k] = blur5(r, k, n_bins, t5);
+    } else {
+        for (int k = lane; k < n_bins; k += WAVE) rb[k] = r[k];
+    }
+}
+
+int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, int64_t total_frames, const int *frame_note,
+                         const int64_t *frame_off, const int64_t *sample_off, const float *f0, const float *mask,
+                         const float *env_noise, const float *phi, int ld, const goofer_note_params *params, uint64_t seed,
+                         hipStream_t st)
+{
+    if (total_frames <= 0) return GOOFER_OK;
+    const goofer_plan_t &pl = ctx->plan;
+    hipLaunchKernelGGL(k_noise_spectra, dim3((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256),
+                       sizeof(float2) * ROWS_PER_BLOCK * pl.n_bins, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,
+                       sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins, pl.hop);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}

@@ -1,0 +1,109 @@
+// Internal declarations shared by the HIP translation units of libgoofer_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/goofer_hip.h"
+
+#define WAVE 64
+
+struct goofer_plan_t {
+    int sr = 0, n_fft = 0, hop = 0, n_bins = 0;
+    float *window = nullptr;      // [n_fft] sqrt-Hann, fp32                      GOOFER.py:12-18
+    float *win_sq = nullptr;      // [n_fft] window*window in fp32 (OLA weights)  GOOFER.py:385
+    float *freqs = nullptr;       // [n_bins] rfftfreq fp32                       GOOFER.py:20-26
+    float *boost = nullptr;       // [n_bins] linspace(1,100)                     GOOFER.py:28-35
+    float *bright_h = nullptr;    // [n_bins] harmonic brightness                 GOOFER.py:42
+    float *bright_b = nullptr;    // [n_bins] breath brightness                   GOOFER.py:43
+    float2 *tw_full = nullptr;    // [n_fft/2]   exp(-2 pi i k / (n_fft/2))
+    float2 *tw_half = nullptr;    // [n_fft/4+1] exp(-2 pi i k / n_fft)
+    float *pulse_peak = nullptr;  // [8193] 1/peak-normaliser of the LF shape per T0 (fp64 math)
+    double *blur5 = nullptr;      // [5] sigma=0.5 taps (brightness blur)         GOOFER.py:1143
+    double *blur175 = nullptr;    // [15] sigma=1.75 taps                         GOOFER.py:993
+};
+
+struct goofer_ctx {
+    int device = 0;
+    char err[512] = {0};
+    goofer_plan_t plan;
+    // scratch (grown by ensure_scratch)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void *small = nullptr;        // small staging buffer for taps etc.
+    size_t small_bytes = 0;
+    double *mask_taps = nullptr;  // device taps of the voicing-mask smoother, cached per sigma
+    float mask_taps_sigma = -1.f;
+    int mask_taps_radius = 0;
+};
+
+int goofer_fail(goofer_ctx *ctx, int code, const char *fmt, ...);
+
+#define HIP_TRY(ctx, call)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return goofer_fail((ctx), GOOFER_EHIP, "%s failed: %s (%s:%d)", #call,               \
+                               hipGetErrorString(e_), __FILE__, __LINE__);                       \
+    } while (0)
+
+#define LAUNCH_CHECK(ctx)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = hipGetLastError();                                                       \
+        if (e_ != hipSuccess)                                                                    \
+            return goofer_fail((ctx), GOOFER_EHIP, "kernel launch failed: %s (%s:%d)",           \
+                               hipGetErrorString(e_), __FILE__, __LINE__);                       \
+    } while (0)
+
+// ---- device helpers ------------------------------------------------------------------------
+
+// numpy 'reflect' (no edge repeat) as a periodic map; n == 1 degenerates to 'edge'.
+__device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n)
+{
+    if (n <= 1) return 0;
+    int64_t period = 2 * (n - 1);
+    int64_t m = i % period;
+    if (m < 0) m += period;
+    return m < n ? m : period - m;
+}
+
+// note owning global frame/sample index g given CSR offsets off[0..n]: largest k with off[k] <= g.
+__device__ __forceinline__ int csr_find(const int64_t *__restrict__ off, int n, int64_t g)
+{
+    int lo = 0, hi = n;  // invariant off[lo] <= g < off[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (off[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS ops of one wave complete in issue order; this only stops the compiler reordering
+    // across the exchange and waits for outstanding LDS traffic.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// atomic max on a non-negative float through its bit pattern
+__device__ __forceinline__ void atomic_max_pos(float *addr, float v)
+{
+    atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
+}
+
+// ---- kernel launchers implemented in the .hip files ---------------------------------------
+int launch_rfft_frames(goofer_ctx *ctx, const float *x, const int64_t *sample_off, const int64_t *frame_off,
+                       int n_notes, int64_t total_frames, float2 *S, int ldc, hipStream_t st);
+int launch_irfft_frames(goofer_ctx *ctx, const float2 *S, int ldc, int64_t total_frames, float *frames, hipStream_t st);
+int launch_ola_gather(goofer_ctx *ctx, const float *frames, const int64_t *sample_off, const int64_t *frame_off,
+                      int n_notes, int64_t total_samples, float *y, const float *scale_per_note, hipStream_t st);

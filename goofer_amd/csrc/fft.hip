@@ -1,0 +1,392 @@
+// Framewise real FFT / inverse FFT / overlap-add for gfx950.
+//
+//   k_rfft_frames   replaces gf.stft        (GOOFER.py:355-370)
+//   k_irfft_frames  replaces np.fft.irfft in gf.istft (GOOFER.py:399-400) and the `frames*window`
+//                   product of _overlap_add (GOOFER.py:383)
+//   k_ola_gather    replaces _overlap_add + trim/pad of istft (GOOFER.py:372-390, 402-413)
+//
+// One 64-lane wave owns one frame.  A real n_fft-point transform is a complex M = n_fft/2 point
+// Stockham autosort FFT (lane holds M/64 points; first radix-(M/64) pass in registers straight from
+// global memory, then two radix-8 passes exchanged through a padded per-wave LDS buffer) followed by
+// the even/odd split that recovers the n_fft/2+1 real-input bins.  No MFMA: ~5 flop/B, HBM-bound.
+#include "common.h"
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+
+// In-register forward DFTs (exp(-2 pi i nk/R)), natural-order output, decimation in frequency.
+template <int R> struct dft;
+
+template <> struct dft<2> {
+    __device__ __forceinline__ static void run(float2 *v)
+    {
+        float2 a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+
+template <> struct dft<4> {
+    __device__ __forceinline__ static void run(float2 *v)
+    {
+        float2 a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]);
+        float2 a2 = cadd(v[1], v[3]), a3 = mul_mi(csub(v[1], v[3]));
+        v[0] = cadd(a0, a2);
+        v[2] = csub(a0, a2);
+        v[1] = cadd(a1, a3);
+        v[3] = csub(a1, a3);
+    }
+};
+
+template <> struct dft<8> {
+    __device__ __forceinline__ static void run(float2 *v)
+    {
+        const float h = 0.70710678118654752440f;
+        float2 e[4], o[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            e[n] = cadd(v[n], v[n + 4]);
+            o[n] = csub(v[n], v[n + 4]);
+        }
+        o[1] = make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));   // * W8^1 = (1-i)/sqrt2
+        o[2] = mul_mi(o[2]);                                               // * W8^2 = -i
+        o[3] = make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));  // * W8^3 = (-1-i)/sqrt2
+        dft<4>::run(e);
+        dft<4>::run(o);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            v[2 * m] = e[m];
+            v[2 * m + 1] = o[m];
+        }
+    }
+};
+
+template <> struct dft<16> {
+    __device__ __forceinline__ static void run(float2 *v)
+    {
+        // W16^n, n = 0..7
+        const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+        const float2 w[8] = {{1.f, 0.f}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.f, -1.f}, {-s1, -c1}, {-h, -h}, {-c1, -s1}};
+        float2 e[8], o[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            e[n] = cadd(v[n], v[n + 8]);
+            o[n] = cmul(csub(v[n], v[n + 8]), w[n]);
+        }
+        dft<8>::run(e);
+        dft<8>::run(o);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            v[2 * m] = e[m];
+            v[2 * m + 1] = o[m];
+        }
+    }
+};
+
+__host__ __device__ __forceinline__ constexpr int lds_pad(int i) { return i + (i >> 5); }
+
+template <int M> struct fft_cfg {
+    static constexpr int R = M / 64;           // points per lane == first-pass radix
+    static constexpr int BUF = M + (M >> 5);   // padded float2 slots per wave
+};
+
+// Radix-8 Stockham pass over the per-wave LDS buffer.  NS = product of the radices already applied.
+// Reads x[b + t*M/8], writes y[(b/NS)*NS*8 + b%NS + t*NS]; all reads precede all writes.
+template <int M, int NS>
+__device__ __forceinline__ void radix8_pass(float2 *buf, const float2 *tw, int lane)
+{
+    constexpr int NB = M / 8;                       // butterflies in this pass
+    constexpr int PER = (NB + WAVE - 1) / WAVE;     // per lane
+    float2 v[PER][8];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        int b = lane + WAVE * u;
+        if (NB >= WAVE || b < NB) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[u][t] = buf[lds_pad(b + t * NB)];
+        }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        int b = lane + WAVE * u;
+        if (NB >= WAVE || b < NB) {
+            int k = b % NS;
+            // twiddle exp(-2 pi i t k / (8 NS)) = tw[t * k * (M / (8 NS))]
+            constexpr int STEP = M / (8 * NS);
+#pragma unroll
+            for (int t = 1; t < 8; ++t) v[u][t] = cmul(v[u][t], tw[(t * k * STEP) & (M - 1)]);
+            dft<8>::run(v[u]);
+            int j0 = (b / NS) * NS * 8 + k;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) buf[lds_pad(j0 + t * NS)] = v[u][t];
+        }
+    }
+    wave_lds_sync();
+}
+
+// Complex forward FFT of size M for one wave.  `v` holds x[lane + 64 t], t < R on entry; the result
+// is left in natural order in `buf` (padded).
+template <int M>
+__device__ __forceinline__ void wave_fft(float2 *v, float2 *buf, const float2 *tw, int lane)
+{
+    constexpr int R = fft_cfg<M>::R;
+    dft<R>::run(v);                       // pass 0: NS = 1, no twiddle, y[lane*R + t]
+#pragma unroll
+    for (int t = 0; t < R; ++t) buf[lds_pad(lane * R + t)] = v[t];
+    wave_lds_sync();
+    radix8_pass<M, R>(buf, tw, lane);
+    radix8_pass<M, R * 8>(buf, tw, lane);
+    static_assert(R * 64 == M, "M must be 64 * first radix");
+}
+
+template <int M>
+__device__ __forceinline__ void load_tables(float2 *tw, float2 *twh, float *win, const float2 *g_tw,
+                                            const float2 *g_twh, const float *g_win)
+{
+    for (int i = threadIdx.x; i < M; i += blockDim.x) tw[i] = g_tw[i];
+    for (int i = threadIdx.x; i < M / 2 + 1; i += blockDim.x) twh[i] = g_twh[i];
+    for (int i = threadIdx.x; i < 2 * M; i += blockDim.x) win[i] = g_win[i];
+    __syncthreads();
+}
+
+constexpr int FRAMES_PER_BLOCK = 32;   // contiguous frames per workgroup: overlapping reads stay in L1/L2
+constexpr int WAVES_PER_BLOCK = 4;
+
+template <int M> constexpr size_t fft_lds_bytes()
+{
+    return sizeof(float2) * (M + M / 2 + 1 + WAVES_PER_BLOCK * fft_cfg<M>::BUF) + sizeof(float) * 2 * M + 16;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256) void k_rfft_frames(const float *__restrict__ x, const int64_t *__restrict__ sample_off,
+                                                     const int64_t *__restrict__ frame_off, const int *__restrict__ frame_note,
+                                                     int64_t total_frames, float2 *__restrict__ S, int ldc, int hop,
+                                                     const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twh,
+                                                     const float *__restrict__ g_win)
+{
+    constexpr int R = fft_cfg<M>::R;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *tw = reinterpret_cast<float2 *>(smem);
+    float2 *twh = tw + M;
+    float2 *bufs = twh + (M / 2 + 1);
+    float *win = reinterpret_cast<float *>(bufs + WAVES_PER_BLOCK * fft_cfg<M>::BUF);
+    load_tables<M>(tw, twh, win, g_tw, g_twh, g_win);
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float2 *buf = bufs + wave * fft_cfg<M>::BUF;
+    const int64_t f_begin = (int64_t)blockIdx.x * FRAMES_PER_BLOCK;
+
+    for (int i = wave; i < FRAMES_PER_BLOCK; i += WAVES_PER_BLOCK) {
+        const int64_t f = f_begin + i;
+        if (f >= total_frames) break;                 // wave-uniform
+        const int note = frame_note[f];
+        const int64_t base = sample_off[note];
+        const int64_t n = sample_off[note + 1] - base;
+        const int64_t t = f - frame_off[note];
+        const int64_t start = t * hop - M;            // first sample of the frame, un-padded coordinates
+        const float *xs = x + base;
+
+        float2 v[R];
+        if (start >= 0 && start + 2 * M <= n) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int m = lane + WAVE * r;
+                v[r] = make_float2(xs[start + 2 * m] * win[2 * m], xs[start + 2 * m + 1] * win[2 * m + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int m = lane + WAVE * r;
+                float a = n > 0 ? xs[reflect_index(start + 2 * m, n)] : 0.f;
+                float b = n > 0 ? xs[reflect_index(start + 2 * m + 1, n)] : 0.f;
+                v[r] = make_float2(a * win[2 * m], b * win[2 * m + 1]);
+            }
+        }
+        wave_fft<M>(v, buf, tw, lane);
+
+        // even/odd split: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 e^{-i pi k/M} (Z[k] - conj Z[M-k])
+        float2 *row = S + f * (int64_t)ldc;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int k = lane + WAVE * r;
+            float2 zk = buf[lds_pad(k)];
+            float2 zm = buf[lds_pad((M - k) & (M - 1))];
+            float2 w = (k <= M / 2) ? twh[k] : make_float2(-twh[M - k].x, twh[M - k].y);
+            float2 A = make_float2(zk.x + zm.x, zk.y - zm.y);
+            float2 B = make_float2(zk.x - zm.x, zk.y + zm.y);
+            float2 C = cmul(w, B);
+            row[k] = make_float2(0.5f * (A.x + C.y), 0.5f * (A.y - C.x));
+        }
+        if (lane == 0) {
+            float2 z0 = buf[0];
+            row[M] = make_float2(z0.x - z0.y, 0.f);
+        }
+        wave_lds_sync();
+    }
+}
+
+// S row -> windowed time frame (fp32 irfft value times window[j], the `val` of _overlap_add).
+template <int M>
+__global__ __launch_bounds__(256) void k_irfft_frames(const float2 *__restrict__ S, int ldc, int64_t total_frames,
+                                                      float *__restrict__ frames, const float2 *__restrict__ g_tw,
+                                                      const float2 *__restrict__ g_twh, const float *__restrict__ g_win)
+{
+    constexpr int R = fft_cfg<M>::R;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *tw = reinterpret_cast<float2 *>(smem);
+    float2 *twh = tw + M;
+    float2 *bufs = twh + (M / 2 + 1);
+    float *win = reinterpret_cast<float *>(bufs + WAVES_PER_BLOCK * fft_cfg<M>::BUF);
+    load_tables<M>(tw, twh, win, g_tw, g_twh, g_win);
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float2 *buf = bufs + wave * fft_cfg<M>::BUF;
+    const int64_t f_begin = (int64_t)blockIdx.x * FRAMES_PER_BLOCK;
+    const float inv_m = 1.0f / (float)M;
+
+    for (int i = wave; i < FRAMES_PER_BLOCK; i += WAVES_PER_BLOCK) {
+        const int64_t f = f_begin + i;
+        if (f >= total_frames) break;
+        const float2 *row = S + f * (int64_t)ldc;
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int k = lane + WAVE * r;
+            float2 xk = row[k];
+            float2 xm = row[M - k];
+            if (k == 0) { xk.y = 0.f; xm.y = 0.f; }   // irfft ignores Im of DC and Nyquist
+            float2 wc = (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y);
+            float2 A = make_float2(xk.x + xm.x, xk.y - xm.y);
+            float2 D = make_float2(xk.x - xm.x, xk.y + xm.y);
+            float2 C = cmul(wc, D);
+            // Z = (A + i C)/2 ; inverse FFT = conj(FFT(conj Z))
+            v[r] = make_float2(0.5f * (A.x - C.y), -0.5f * (A.y + C.x));
+        }
+        wave_fft<M>(v, buf, tw, lane);
+        float2 *out = reinterpret_cast<float2 *>(frames + f * (int64_t)(2 * M));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int m = lane + WAVE * r;
+            float2 z = buf[lds_pad(m)];
+            float a = z.x * inv_m, b = -z.y * inv_m;
+            out[m] = make_float2(a * win[2 * m], b * win[2 * m + 1]);
+        }
+        wave_lds_sync();
+    }
+}
+
+// y[i] = (sum over covering frames, ascending, of frames[fr][p - fr*hop]) / (same sum of w^2), fp32,
+// p = i + n_fft/2; samples past hop*(T-1) are the zero padding of istft.  Optional per-note scale.
+__global__ __launch_bounds__(256) void k_ola_gather(const float *__restrict__ frames, const float *__restrict__ win_sq,
+                                                    const int64_t *__restrict__ sample_off, const int64_t *__restrict__ frame_off,
+                                                    int n_notes, int64_t total_samples, int n_fft, int hop,
+                                                    float *__restrict__ y, const float *__restrict__ inv_scale)
+{
+    __shared__ int s_lo;
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    if (threadIdx.x == 0) s_lo = csr_find(sample_off, n_notes, g0);
+    __syncthreads();
+    const int64_t g = g0 + threadIdx.x;
+    if (g >= total_samples) return;
+    int note = s_lo;
+    while (sample_off[note + 1] <= g) ++note;
+    const int64_t i = g - sample_off[note];
+    const int64_t fbase = frame_off[note];
+    const int64_t T = frame_off[note + 1] - fbase;
+    float out = 0.f;
+    if (i < (int64_t)hop * (T - 1)) {
+        const int64_t p = i + n_fft / 2;
+        int64_t lo = p - n_fft + 1;
+        lo = lo <= 0 ? 0 : (lo + hop - 1) / hop;
+        int64_t hi = p / hop;
+        if (hi > T - 1) hi = T - 1;
+        float acc = 0.f, ws = 0.f;
+        for (int64_t fr = lo; fr <= hi; ++fr) {
+            int j = (int)(p - fr * hop);
+            acc += frames[(fbase + fr) * n_fft + j];
+            ws += win_sq[j];
+        }
+        if (ws > 1e-9f) acc /= ws;
+        out = acc;
+        if (inv_scale) out = out / inv_scale[note];
+    }
+    y[g] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void k_frame_note(const int64_t *__restrict__ frame_off, int n_notes, int64_t total_frames, int *__restrict__ frame_note)
+{
+    int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < total_frames) frame_note[f] = csr_find(frame_off, n_notes, f);
+}
+
+int launch_frame_note(goofer_ctx *ctx, const int64_t *frame_off, int n_notes, int64_t total_frames, int *frame_note, hipStream_t st)
+{
+    if (total_frames <= 0) return GOOFER_OK;
+    hipLaunchKernelGGL(k_frame_note, dim3((unsigned)((total_frames + 255) / 256)), dim3(256), 0, st, frame_off, n_notes,
+                       total_frames, frame_note);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+template <int M>
+static int rfft_impl(goofer_ctx *ctx, const float *x, const int64_t *sample_off, const int64_t *frame_off,
+                     const int *frame_note, int64_t total_frames, float2 *S, int ldc, hipStream_t st)
+{
+    const goofer_plan_t &p = ctx->plan;
+    unsigned blocks = (unsigned)((total_frames + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK);
+    hipLaunchKernelGGL(k_rfft_frames<M>, dim3(blocks), dim3(256), fft_lds_bytes<M>(), st, x, sample_off, frame_off, frame_note,
+                       total_frames, S, ldc, p.hop, p.tw_full, p.tw_half, p.window);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+int launch_rfft_frames_mapped(goofer_ctx *ctx, const float *x, const int64_t *sample_off, const int64_t *frame_off,
+                              const int *frame_note, int64_t total_frames, float2 *S, int ldc, hipStream_t st)
+{
+    if (total_frames <= 0) return GOOFER_OK;
+    switch (ctx->plan.n_fft) {
+    case 512: return rfft_impl<256>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
+    case 1024: return rfft_impl<512>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
+    case 2048: return rfft_impl<1024>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
+    }
+    return goofer_fail(ctx, GOOFER_EINVAL, "unsupported n_fft %d", ctx->plan.n_fft);
+}
+
+template <int M>
+static int irfft_impl(goofer_ctx *ctx, const float2 *S, int ldc, int64_t total_frames, float *frames, hipStream_t st)
+{
+    const goofer_plan_t &p = ctx->plan;
+    unsigned blocks = (unsigned)((total_frames + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK);
+    hipLaunchKernelGGL(k_irfft_frames<M>, dim3(blocks), dim3(256), fft_lds_bytes<M>(), st, S, ldc, total_frames, frames,
+                       p.tw_full, p.tw_half, p.window);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+int launch_irfft_frames(goofer_ctx *ctx, const float2 *S, int ldc, int64_t total_frames, float *frames, hipStream_t st)
+{
+    if (total_frames <= 0) return GOOFER_OK;
+    switch (ctx->plan.n_fft) {
+    case 512: return irfft_impl<256>(ctx, S, ldc, total_frames, frames, st);
+    case 1024: return irfft_impl<512>(ctx, S, ldc, total_frames, frames, st);
+    case 2048: return irfft_impl<1024>(ctx, S, ldc, total_frames, frames, st);
+    }
+    return goofer_fail(ctx, GOOFER_EINVAL, "unsupported n_fft %d", ctx->plan.n_fft);
+}
+
+int launch_ola_gather(goofer_ctx *ctx, const float *frames, const int64_t *sample_off, const int64_t *frame_off,
+                      int n_notes, int64_t total_samples, float *y, const float *inv_scale, hipStream_t st)
+{
+    if (total_samples <= 0) return GOOFER_OK;
+    const goofer_plan_t &p = ctx->plan;
+    hipLaunchKernelGGL(k_ola_gather, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, st, frames, p.win_sq,
+                       sample_off, frame_off, n_notes, total_samples, p.n_fft, p.hop, y, inv_scale);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}

@@ -1,0 +1,223 @@
+"""Device context: one libgoofer_hip handle per GPU, PyTorch-ROCm tensors as the buffer currency.
+
+torch is plumbing here (allocation, streams, H2D/D2H); every number is produced by the HIP
+kernels behind the C ABI.  Matrices are ``[frames, bins]`` row-major on the device — the transpose
+of the reference's ``[bins, frames]`` — with fp32 rows padded to ``ld`` (a multiple of 4 floats).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def row_stride(n_bins: int) -> int:
+    return (n_bins + 3) & ~3
+
+
+class GooferError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Context:
+    """Owns a ``goofer_ctx`` for one device and the current (sr, n_fft, hop) plan."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise GooferError("no ROCm device visible: goofer_amd needs an MI355X (there is no CPU path)")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        rc = self.lib.goofer_create(device, C.byref(h))
+        if rc != 0:
+            raise GooferError(f"goofer_create failed ({rc})")
+        self.h = h
+        self.geom = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.goofer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise GooferError(f"libgoofer_hip error {rc}: {self.lib.goofer_last_error(self.h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def tensor(self, a, dtype=None):
+        t = torch.as_tensor(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device)
+
+    def plan(self, sr: int, n_fft: int, hop: int):
+        g = (int(sr), int(n_fft), int(hop))
+        if self.geom != g:
+            self._check(self.lib.goofer_plan(self.h, *g))
+            self.geom = g
+        return self
+
+    @property
+    def n_bins(self):
+        return self.geom[1] // 2 + 1
+
+    def reserve(self, frames: int, samples: int, notes: int):
+        self._check(self.lib.goofer_reserve(self.h, frames, samples, notes))
+
+    def table(self, which: int) -> np.ndarray:
+        out = np.zeros(8193, dtype=np.float32)
+        n = self.lib.goofer_debug_table(self.h, which, out.ctypes.data_as(C.c_void_p), out.size)
+        if n < 0:
+            self._check(n)
+        return out[:n]
+
+    # -- CSR helpers ---------------------------------------------------------------------------
+    def offsets(self, lengths):
+        off = np.zeros(len(lengths) + 1, dtype=np.int64)
+        np.cumsum(np.asarray(lengths, dtype=np.int64), out=off[1:])
+        return off
+
+    def frame_counts(self, sample_lengths):
+        hop = self.geom[2]
+        return [1 + int(n) // hop for n in sample_lengths]
+
+    # -- single-kernel entry points -------------------------------------------------------------
+    def rfft_frames(self, x, sample_off, frame_off, total_frames: int):
+        """x fp32 [N_total] -> complex64 [F_total, n_bins] (gf.stft per note)."""
+        nb = self.n_bins
+        ldc = nb + 1
+        S = torch.empty((total_frames, ldc), dtype=torch.complex64, device=self.device)
+        self._check(self.lib.goofer_rfft_frames(self.h, _ptr(x), _ptr(sample_off), _ptr(frame_off), sample_off.numel() - 1,
+                                                total_frames, _ptr(S), ldc, self._stream()))
+        return S[:, :nb]
+
+    def irfft_ola(self, S, sample_off, frame_off, total_samples: int):
+        """complex64 [F_total, >=n_bins] (row stride taken from the tensor) -> fp32 [N_total] (gf.istft)."""
+        assert S.dtype == torch.complex64 and S.stride(1) == 1
+        y = torch.empty(total_samples, dtype=torch.float32, device=self.device)
+        self._check(self.lib.goofer_irfft_ola(self.h, _ptr(S), S.stride(0), _ptr(sample_off), _ptr(frame_off),
+                                              sample_off.numel() - 1, S.shape[0], total_samples, _ptr(y), self._stream()))
+        return y
+
+    def pulse_train(self, f0, sample_off):
+        out = torch.empty_like(f0)
+        self._check(self.lib.goofer_pulse_train(self.h, _ptr(f0), _ptr(sample_off), sample_off.numel() - 1, f0.numel(),
+                                                _ptr(out), self._stream()))
+        return out
+
+    def gauss_bins(self, rows, taps: np.ndarray):
+        """rows fp32 [R, ld-strided]; taps fp64 host array of odd length."""
+        taps = np.ascontiguousarray(taps, dtype=np.float64)
+        out = torch.empty_like(rows)
+        n_bins = rows.shape[1]
+        self._check(self.lib.goofer_gauss_bins(self.h, _ptr(rows), _ptr(out), rows.shape[0], n_bins, rows.stride(0),
+                                               taps.ctypes.data_as(C.c_void_p), (taps.size - 1) // 2, self._stream()))
+        return out
+
+    def warp_bins(self, rows, formants=None, f_shift=None, ratio: float = 1.0):
+        out = torch.empty_like(rows)
+        fs = None if f_shift is None else np.ascontiguousarray(f_shift, dtype=np.float64)
+        self._check(self.lib.goofer_warp_bins(self.h, _ptr(rows), _ptr(out), rows.shape[0], rows.shape[1], rows.stride(0),
+                                              _ptr(formants), fs.ctypes.data_as(C.c_void_p) if fs is not None else None,
+                                              float(ratio), self._stream()))
+        return out
+
+    def knot_decode(self, knots_f16, hz_knots: np.ndarray):
+        """knots fp16 [rows, K] -> env fp32 [rows, n_bins] (view of an ld-strided buffer)."""
+        hz = np.ascontiguousarray(hz_knots, dtype=np.float32)
+        rows, K = knots_f16.shape
+        nb = self.n_bins
+        env = self.rows(rows, nb)
+        self._check(self.lib.goofer_knot_decode(self.h, _ptr(knots_f16), K, hz.ctypes.data_as(C.c_void_p), rows, _ptr(env),
+                                                nb, env.stride(0), self._stream()))
+        return env
+
+    def rows(self, n_rows: int, n_bins: int, dtype=torch.float32):
+        """Uninitialised [n_rows, n_bins] view of an ld-strided device buffer."""
+        ld = row_stride(n_bins)
+        return torch.empty((n_rows, ld), dtype=dtype, device=self.device)[:, :n_bins]
+
+    def rows_from(self, a: np.ndarray):
+        """Upload a host [n_rows, n_bins] fp32 matrix into an ld-strided buffer."""
+        r = self.rows(a.shape[0], a.shape[1])
+        r.copy_(torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)))
+        return r
+
+    # -- the batch ------------------------------------------------------------------------------
+    def synth_batch(self, env, env_lengths, f0, mask, sample_lengths, params: np.ndarray, formants=None, phi=None,
+                    seed: int = 0, transition_sigma: float = 100.0, want_rec=True, want_mix=True):
+        """Run goofer_synth_batch.
+
+        env fp32 [R_total, n_bins] ld-strided device tensor; env_lengths rows per note;
+        f0 / mask fp32 [N_total]; sample_lengths per note; params structured array (NOTE_PARAMS);
+        formants fp64 [R_total, 4] or None; phi fp32 [F_total, n_bins] ld-strided or None.
+        Returns dict of device tensors harm / uv / bre / rec / mix, plus the CSR offsets.
+        """
+        nb = self.n_bins
+        n = len(sample_lengths)
+        s_off = self.offsets(sample_lengths)
+        f_off = self.offsets(self.frame_counts(sample_lengths))
+        e_off = self.offsets(env_lengths)
+        N, F, R = int(s_off[-1]), int(f_off[-1]), int(e_off[-1])
+        assert env.shape == (R, nb) and f0.numel() == N and mask.numel() == N and params.shape == (n,)
+        d_s, d_f, d_e = self.tensor(s_off), self.tensor(f_off), self.tensor(e_off)
+        d_par = self.tensor(params.view(np.uint8))
+        out = {k: torch.empty(N, dtype=torch.float32, device=self.device) for k in ("harm", "uv", "bre")}
+        if want_rec:
+            out["rec"] = torch.empty(N, dtype=torch.float32, device=self.device)
+        if want_mix:
+            out["mix"] = torch.empty(N, dtype=torch.float32, device=self.device)
+        if phi is not None:
+            assert phi.shape == (F, nb) and phi.stride(0) == env.stride(0)
+        b = _lib.Batch(n_notes=n, n_bins=nb, ld=env.stride(0), total_frames=F, total_samples=N, total_env_rows=R,
+                       sample_off=d_s.data_ptr(), frame_off=d_f.data_ptr(), env_off=d_e.data_ptr(), env=env.data_ptr(),
+                       formants=formants.data_ptr() if formants is not None else None, f0=f0.data_ptr(),
+                       mask=mask.data_ptr(), phi=phi.data_ptr() if phi is not None else None, params=d_par.data_ptr(),
+                       seed=seed, transition_sigma=float(transition_sigma), harm=out["harm"].data_ptr(),
+                       uv=out["uv"].data_ptr(), bre=out["bre"].data_ptr(),
+                       rec=out["rec"].data_ptr() if want_rec else None, mix=out["mix"].data_ptr() if want_mix else None)
+        self._check(self.lib.goofer_synth_batch(self.h, C.byref(b), self._stream()))
+        out["_keep"] = (d_s, d_f, d_e, d_par)   # keep device-side descriptors alive until the caller syncs
+        out["sample_off"], out["frame_off"] = s_off, f_off
+        return out
+
+
+_default = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default:
+        _default[device] = Context(device)
+    return _default[device]
+
+
+def default_params(n: int) -> np.ndarray:
+    """NOTE_PARAMS array with gf.synthesize's defaults (GOOFER.py:971-983) and a unity mix."""
+    p = np.zeros(n, dtype=_lib.NOTE_PARAMS)
+    p["pitch_shift"] = 1.0
+    p["formant_shift"] = 1.0
+    p["f_shift"] = 1.0
+    p["uv_strength"] = 0.75
+    p["breath_strength"] = 0.1
+    p["normalize"] = 1.0
+    p["apply_brightness"] = 1
+    p["cut_below_f0"] = 1
+    p["mix_harm"] = p["mix_breath"] = p["mix_unvoiced"] = p["volume"] = 1.0
+    return p

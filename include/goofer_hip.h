@@ -1,0 +1,131 @@
+/*
+ * goofer_hip.h — C ABI of libgoofer_hip.so, the MI355X (gfx950) backend for GOOFER's per-frame
+ * source-filter resampler loop.
+ *
+ * The reference is pure Python: its "FFI" for this path is the set of numpy calls made by
+ * GOOFER.py / SillySampler.py.  Each entry point below names the reference function it replaces
+ * (file:line under the reference repo).  Conventions:
+ *   - plain C, no torch types: device pointers are raw (e.g. torch.Tensor.data_ptr()), the stream is
+ *     a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); NULL = default stream
+ *   - every call is asynchronous on that stream; the caller owns all buffers; the library only
+ *     allocates per-plan tables and scratch owned by the handle (goofer_reserve grows it, never
+ *     inside a timed region if the caller reserved up front)
+ *   - return 0 on success, negative GOOFER_E* on failure; goofer_last_error() gives the text
+ *   - ragged batches are CSR: sample_off[n_notes+1], frame_off[n_notes+1] (int64, device memory)
+ *   - device matrices are [frames x bins] row-major (the reference is [bins, frames]) with an
+ *     explicit row stride `ld` in elements (ld >= n_bins; 516 keeps fp32 rows 16-byte aligned)
+ *   - one handle per device per host thread; no global state
+ */
+#ifndef GOOFER_HIP_H
+#define GOOFER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOOFER_OK 0
+#define GOOFER_EINVAL (-1)   /* bad argument / unsupported geometry */
+#define GOOFER_EHIP (-2)     /* a HIP runtime call failed */
+#define GOOFER_ENOPLAN (-3)  /* goofer_plan() has not been called */
+#define GOOFER_ENOMEM (-4)
+
+typedef struct goofer_ctx goofer_ctx;
+
+/* Per-note scalars of one synthesize() call — the keyword arguments of GOOFER.py:971-983 that the
+ * sampler actually varies (SillySampler.py:1006-1035), plus the V/B/U mix of :1142-1151. */
+typedef struct {
+    float pitch_shift;          /* f0 *= pitch_shift (fp32)                       GOOFER.py:995  */
+    float formant_shift;        /* 'g' flag: uniform warp ratio, 1 = off          GOOFER.py:1016 */
+    double f_shift[4];          /* 'fa'..'fd': per-formant ratios, all 1 = off    GOOFER.py:1004 */
+    float uv_strength;          /* default 0.75                                    GOOFER.py:1181 */
+    float breath_strength;      /* default 0.1                                     GOOFER.py:1180 */
+    float normalize;            /* 0..1 exponent of 1/peak                         GOOFER.py:1208 */
+    int32_t apply_brightness;   /* default 1                                       GOOFER.py:1131 */
+    int32_t cut_below_f0;       /* cut_subharm_below_f0, default 1                 GOOFER.py:1113 */
+    float mix_harm, mix_breath, mix_unvoiced, volume;   /* V, (B+100)/100, (U+100)/100, volume */
+} goofer_note_params;
+
+/* One ragged batch of notes for goofer_synth_batch.  All pointers are device memory. */
+typedef struct {
+    int32_t n_notes;
+    int32_t n_bins;             /* n_fft/2 + 1 */
+    int32_t ld;                 /* row stride of env / phi in floats */
+    int32_t reserved;
+    int64_t total_frames;       /* frame_off[n_notes]: sum over notes of 1 + n_samples/hop */
+    int64_t total_samples;      /* sample_off[n_notes] */
+    int64_t total_env_rows;     /* env_off[n_notes] */
+    const int64_t *sample_off;  /* [n_notes+1] */
+    const int64_t *frame_off;   /* [n_notes+1] synthesis frames (pulse STFT frames)            */
+    const int64_t *env_off;     /* [n_notes+1] envelope rows; a note's rows are truncated or   */
+                                /*             edge-repeated to its frame count (GOOFER.py:1115-1119) */
+    const float *env;           /* [total_env_rows x ld] spectral envelope                     */
+    const double *formants;     /* [total_env_rows x 4] F1..F4 in Hz, or NULL when no f_shift  */
+    const float *f0;            /* [total_samples] Hz, 0 where unvoiced                        */
+    const float *mask;          /* [total_samples] voicing mask                                */
+    const float *phi;           /* [total_frames x ld] random phases, or NULL: on-device Philox */
+    const goofer_note_params *params;  /* [n_notes] */
+    uint64_t seed;              /* Philox key when phi == NULL */
+    float transition_sigma;     /* noise_transition_smoothness of this call (default 100; the 'sa'  */
+    float reserved2;            /* layer uses 1) — one value per batch            GOOFER.py:1179 */
+    float *harm, *uv, *bre;     /* [total_samples] stems, gain-normalised like the reference   */
+    float *rec;                 /* [total_samples] harm+uv+bre (reconstruct), may be NULL      */
+    float *mix;                 /* [total_samples] (harm*V + bre*B + uv*U)*volume, may be NULL */
+} goofer_batch;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int goofer_create(int device_id, goofer_ctx **out);
+void goofer_destroy(goofer_ctx *ctx);
+const char *goofer_last_error(const goofer_ctx *ctx);
+const char *goofer_version(void);
+
+/* Tables per (sr, n_fft, hop): sqrt-Hann window, bin freqs, boost, brightness curves, FFT twiddles
+ * (GOOFER.py:12-46, 585-595).  n_fft in {512, 1024, 2048}; re-planning replaces the tables. */
+int goofer_plan(goofer_ctx *ctx, int sr, int n_fft, int hop);
+
+/* Pre-size handle-owned scratch for batches up to these totals (else grown on demand). */
+int goofer_reserve(goofer_ctx *ctx, int64_t max_frames, int64_t max_samples, int64_t max_notes);
+
+/* ---- single-kernel entry points (unit parity + roofline runs) ------------------------------ */
+
+/* gf.stft (GOOFER.py:355-370): per note reflect-pad n_fft/2, frame, sqrt-Hann, rFFT.
+ * x [total_samples] -> S [total_frames x ldc] complex64 (interleaved re,im; ldc in complex elements). */
+int goofer_rfft_frames(goofer_ctx *ctx, const float *x, const int64_t *sample_off, const int64_t *frame_off,
+                       int n_notes, int64_t total_frames, float *S, int ldc, void *stream);
+
+/* gf.istft + _overlap_add (GOOFER.py:372-413): irFFT, windowed OLA normalised by the summed squared
+ * window, trim n_fft/2, zero-pad to the note length.  S [total_frames x ldc] -> y [total_samples]. */
+int goofer_irfft_ola(goofer_ctx *ctx, const float *S, int ldc, const int64_t *sample_off, const int64_t *frame_off,
+                     int n_notes, int64_t total_frames, int64_t total_samples, float *y, void *stream);
+
+/* gf.pulse_train_numba (GOOFER.py:473-554), Ra=0.02 Rg=1.7 Rk=0.8: f0 [total_samples] -> pulse. */
+int goofer_pulse_train(goofer_ctx *ctx, const float *f0, const int64_t *sample_off, int n_notes,
+                       int64_t total_samples, float *pulse, void *stream);
+
+/* gf.gaussian_filter1d(axis=bins) (GOOFER.py:241-261): fp64 taps [2*radius+1] (host memory, the
+ * caller normalises them exactly as the reference does), numpy-'reflect' padding, fp64 accumulate.
+ * in/out [rows x ld] fp32. */
+int goofer_gauss_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows, int n_bins, int ld,
+                      const double *taps, int radius, void *stream);
+
+/* gf.warp_env_by_formants then gf.shift_formants (GOOFER.py:840-875, 618-627) on rows of env.
+ * formants [rows x 4] fp64 (may be NULL when all f_shift == 1); f_shift NULL = no anchor warp;
+ * ratio 1 = no uniform warp.  Each stage rounds to fp32 like the reference. */
+int goofer_warp_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows, int n_bins, int ld,
+                     const double *formants, const double *f_shift, double ratio, void *stream);
+
+/* gf.decode_env_from_knots (GOOFER.py:149-168): knots fp16 [rows x K] (frames-major) -> env fp32
+ * [rows x ld]; hz_knots fp32 [K] in host memory. */
+int goofer_knot_decode(goofer_ctx *ctx, const uint16_t *knots_f16, int K, const float *hz_knots,
+                       int64_t rows, float *env, int n_bins, int ld, void *stream);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+
+/* gf.synthesize for a ragged batch (GOOFER.py:971-1220) + the V/B/U mix (SillySampler.py:1142-1151). */
+int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *batch, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOOFER_HIP_H */

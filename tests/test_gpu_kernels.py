@@ -1,0 +1,192 @@
+"""GPU: every single-kernel C-ABI entry point against the reference's golden vectors and the oracle."""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_rms, rms_err
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from goofer_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _off(c, lengths):
+    return c.tensor(c.offsets(lengths))
+
+
+def test_plan_tables_match_reference(ctx):
+    g = golden("tables")
+    for sr, n_fft, hop in ((44100, 1024, 256), (96000, 2048, 96), (48000, 512, 128)):
+        ctx.plan(sr, n_fft, hop)
+        t = f"{sr}_{n_fft}"
+        assert np.max(np.abs(ctx.table(0) - g["win_" + t])) <= 6e-8          # libm cos vs numpy: <=1 ulp
+        assert np.array_equal(ctx.table(1), g["freqs_" + t][:, 0])
+        assert np.array_equal(ctx.table(2), g["boost_" + t][:, 0])
+        assert np.array_equal(ctx.table(3), g["bright_harm_" + t][:, 0])
+        assert np.array_equal(ctx.table(4), g["bright_breath_" + t][:, 0])
+
+
+def test_rfft_and_irfft_against_reference(ctx):
+    g = golden("stft_istft")
+    for tag in g["cases"]:
+        n_fft, hop = (int(v) for v in g[f"geo_{tag}"])
+        ctx.plan(44100, n_fft, hop)
+        x, S_ref, y_ref = g[f"x_{tag}"], g[f"S_{tag}"], g[f"y_{tag}"]
+        n = len(x)
+        T = 1 + n // hop
+        assert S_ref.shape[1] == T
+        S = ctx.rfft_frames(ctx.tensor(x), _off(ctx, [n]), _off(ctx, [T]), T)
+        torch.cuda.synchronize()
+        S = S.cpu().numpy().T
+        assert rel_rms(S, S_ref) < 5e-7, (tag, rel_rms(S, S_ref))
+        # inverse: device irfft+OLA of the REFERENCE spectrum vs the reference's istft
+        St = ctx.tensor(np.ascontiguousarray(S_ref.T))
+        n_dev = hop * (T - 1)
+        if n_dev == 0:
+            continue
+        y = ctx.irfft_ola(St, _off(ctx, [n_dev]), _off(ctx, [T]), n_dev).cpu().numpy()
+        assert n_dev <= len(y_ref) and not y_ref[n_dev:].any()
+        assert rms_err(y, y_ref[:n_dev]) < 3e-7 * max(1.0, np.abs(y_ref).max()), tag
+
+
+def test_rfft_ragged_batch_equals_per_note(ctx):
+    from oracle import goofer_ref as R
+    ctx.plan(44100, 1024, 256)
+    rng = np.random.default_rng(5)
+    lens = [4000, 1, 700, 256, 2, 12345, 511, 513]
+    xs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    Ts = [1 + n // 256 for n in lens]
+    S = ctx.rfft_frames(ctx.tensor(np.concatenate(xs)), _off(ctx, lens), _off(ctx, Ts), sum(Ts)).cpu().numpy()
+    o = 0
+    win = R.sqrt_hann(1024)
+    for x, T in zip(xs, Ts):
+        ref = R.stft(x, 1024, 256, win).T
+        assert ref.shape[0] == T
+        assert rel_rms(S[o:o + T], ref) < 5e-7
+        o += T
+    # round trip through the device inverse: istft(stft(x)) == x away from the zero-padded tail
+    y = ctx.irfft_ola(ctx.tensor(S), _off(ctx, lens), _off(ctx, Ts), sum(lens)).cpu().numpy()
+    o = 0
+    for x, n in zip(xs, lens):
+        valid = 256 * (n // 256)
+        assert np.max(np.abs(y[o:o + valid] - x[:valid])) < 2e-5
+        assert not y[o + valid:o + n].any()
+        o += n
+
+
+def test_pulse_train_against_reference(ctx):
+    g = golden("pulse_train")
+    ctx.plan(44100, 1024, 256)
+    names = list(g["names"])
+    f0s = [g["f0_" + k] for k in names]
+    lens = [len(f) for f in f0s]
+    out = ctx.pulse_train(ctx.tensor(np.concatenate(f0s)), _off(ctx, lens)).cpu().numpy()
+    o = 0
+    for k, n in zip(names, lens):
+        ref = g["pulse_" + k]
+        err = np.max(np.abs(out[o:o + n] - ref))
+        assert err < 5e-6, (k, err)     # a one-sample onset slip would be O(1)
+        o += n
+    ctx.plan(96000, 2048, 96)
+    f = g["f0_sr96"]
+    out = ctx.pulse_train(ctx.tensor(f), _off(ctx, [len(f)])).cpu().numpy()
+    assert np.max(np.abs(out - g["pulse_sr96"])) < 5e-6
+
+
+def test_pulse_train_many_random_notes_vs_oracle(ctx):
+    from oracle import goofer_ref as R
+    ctx.plan(44100, 1024, 256)
+    rng = np.random.default_rng(17)
+    f0s = []
+    for i in range(70):   # > 64: more than one wave of note-lanes
+        n = int(rng.integers(50, 9000))
+        t = np.arange(n) / 44100
+        base = rng.uniform(60, 900)
+        f = base * 2 ** (rng.uniform(-0.5, 0.5) * np.sin(2 * np.pi * rng.uniform(1, 9) * t))
+        f[rng.uniform(size=n) < 0.02] = 0
+        if i % 7 == 0:
+            f[:] = [440.0, 441.0, 220.5, 110.25, 882.0][i % 5]   # knife-edge rationals
+        f0s.append(f.astype(np.float32))
+    lens = [len(f) for f in f0s]
+    out = ctx.pulse_train(ctx.tensor(np.concatenate(f0s)), _off(ctx, lens)).cpu().numpy()
+    o = 0
+    for f, n in zip(f0s, lens):
+        ref = R.pulse_train(f, 44100)
+        assert np.max(np.abs(out[o:o + n] - ref)) < 2e-6
+        o += n
+
+
+def test_gauss_bins(ctx):
+    from goofer_amd.core import gaussian_taps
+    g = golden("gauss")
+    ctx.plan(44100, 1024, 256)
+    env = g["env"]
+    rows = ctx.rows_from(env.T)
+    for s in (0.5, 1.75, 2.0, 3.4, 7.0):
+        out = ctx.gauss_bins(rows, gaussian_taps(s)).cpu().numpy().T
+        ref = g["ax0_s%g" % s]
+        assert np.max(np.abs(out - ref.astype(np.float32))) <= 1.2e-7 * np.abs(ref).max()
+    small = g["small"]      # radius 8 on 9 bins: multiple reflections
+    out = ctx.gauss_bins(ctx.rows_from(small.T), gaussian_taps(2.0)).cpu().numpy().T
+    assert np.max(np.abs(out - g["small_s2"].astype(np.float32))) <= 1.2e-7 * np.abs(small).max()
+
+
+def test_warp_bins_against_reference(ctx):
+    g = golden("warps")
+    ctx.plan(44100, 1024, 256)
+    env = g["env"]
+    rows = ctx.rows_from(env.T)
+    for r in (0.75, 1.25, 1.5, 0.5):
+        out = ctx.warp_bins(rows, ratio=r).cpu().numpy().T
+        ref = g["shift_%g" % r]
+        assert np.max(np.abs(out - ref)) <= 2e-7 * np.abs(ref).max(), r
+    F = g["formants"]
+    dF = ctx.tensor(np.ascontiguousarray(F.T))
+    for i in range(3):
+        out = ctx.warp_bins(rows, formants=dF, f_shift=g[f"ratios_{i}"]).cpu().numpy().T
+        ref = g[f"warp_{i}"]
+        assert np.max(np.abs(out - ref)) <= 2e-7 * np.abs(ref).max(), i
+
+
+def test_warp_bins_crossing_anchors_follow_numpy_interp(ctx):
+    """Unsorted anchors: np.interp's answer depends on its guess chain; the kernel reproduces it."""
+    from oracle import goofer_ref as R
+    from goofer_amd import synthetic as syn
+    ctx.plan(44100, 1024, 256)
+    src = syn.make_source(123, seconds=0.3)
+    env = R.decode_env_from_knots(src["env_pack"])
+    T = env.shape[1]
+    rng = np.random.default_rng(9)
+    F = np.stack([src["formants"][i][:T] for i in (1, 2, 3, 4)], 0)
+    F[0] = rng.uniform(600, 1100, T)
+    F[1] = rng.uniform(700, 1400, T)
+    F[2, ::5] = 0.0
+    F[3, ::7] = rng.uniform(100, 21000, len(F[3, ::7]))
+    rows = ctx.rows_from(env.T)
+    dF = ctx.tensor(np.ascontiguousarray(F.T))
+    for ratios in ([1.3, 0.8, 1.1, 0.9], [1.5, 0.6, 0.7, 1.4], [0.7, 1.3, 1.3, 0.6]):
+        sh = F * np.asarray(ratios)[:, None]
+        crossing = np.mean(np.any(np.diff(np.where((F > 50) & (F < 22050) & (sh > 50), sh, np.nan), axis=0) < 0, axis=0))
+        ref = R.warp_env_by_formants(env, F, sh, 44100)
+        out = ctx.warp_bins(rows, formants=dF, f_shift=ratios).cpu().numpy().T
+        assert crossing > 0.1
+        assert np.max(np.abs(out - ref)) <= 2e-7 * np.abs(ref).max(), ratios
+        both = ctx.warp_bins(rows, formants=dF, f_shift=ratios, ratio=1.25).cpu().numpy().T
+        assert np.max(np.abs(both - R.shift_formants(ref, 1.25, 44100))) <= 3e-7 * np.abs(ref).max()
+
+
+def test_knot_decode(ctx):
+    from goofer_amd import core
+    g = golden("knots")
+    pack = {"mode": "knots", "knot_vals_log": g["knot_vals_log"], "hz_knots": g["hz_knots"],
+            "n_bins": 513, "n_fft": 1024, "sr": 44100}
+    out = core.decode_env_from_knots(pack, ctx=ctx)
+    assert out.dtype == np.float32 and out.shape == g["decoded"].shape
+    np.testing.assert_allclose(out, g["decoded"], rtol=1e-6)

@@ -1,0 +1,146 @@
+"""GPU: goofer_synth_batch (the hot path) against the reference's golden vectors and the oracle.
+
+Tolerance: BASELINE.json's north_star asks <= 1e-4 sample-RMS on identical (features, flags, pitch
+curve, injected phases); outputs are peak-normalised (|x| <= 1), so this is an absolute figure.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden, rms_err
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+TOL = 1e-4          # north_star bound
+TIGHT = 2e-5        # what we actually expect (fp32 FFT + deferred 1/max scaling)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from goofer_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _case(g, name):
+    sr, n_fft, hop, seed = (int(v) for v in g[f"{name}_geo"])
+    kw = {k: float(v) for k, v in zip(g[f"{name}_kw_keys"], g[f"{name}_kw_vals"]) if k != "_"}
+    if "apply_brightness" in kw:
+        kw["apply_brightness"] = bool(kw["apply_brightness"])
+    env = g[f"{name}_env"]
+    n = len(g[f"{name}_f0"])
+    T = 1 + n // hop
+    phi = np.random.default_rng(seed).uniform(0.0, 2.0 * np.pi, size=(env.shape[0], T)).astype(np.float32)
+    F = g[f"{name}_formants"]
+    return dict(env=env, f0=g[f"{name}_f0"], mask=g[f"{name}_mask"], n=n, sr=sr, n_fft=n_fft, hop=hop, phi=phi,
+                formants={i + 1: F[i] for i in range(4)}, kw=kw)
+
+
+def test_synthesize_against_reference(ctx):
+    from goofer_amd import core
+    g = golden("synthesize")
+    worst = 0.0
+    for name in g["names"]:
+        c = _case(g, name)
+        outs = core.synthesize(c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"], n_fft=c["n_fft"],
+                               hop_length=c["hop"], formants=c["formants"], phi=c["phi"], ctx=ctx, **c["kw"])
+        for got, key in zip(outs, ("rec", "harm", "uv", "bre")):
+            ref = g[f"{name}_{key}"]
+            assert got.dtype == np.float32 and got.shape == ref.shape
+            e = rms_err(got, ref) / max(1.0, float(np.max(np.abs(ref))))
+            worst = max(worst, e)
+            assert e < TOL, (name, key, e)
+            assert e < TIGHT, (name, key, e)
+    print("worst sample-RMS vs reference:", worst)
+
+
+def _sampler_io(name):
+    g = golden("sampler_" + name)
+    if "env_new" not in g.files:
+        return None
+    kw = json.loads(str(g["kw"]))
+    return g, kw
+
+
+SAMPLER = ["default", "t12g50", "tm12gm50", "formants", "formants_flip", "L0", "L1", "L2", "br_es_neg", "br_es_pos",
+           "vel60", "vel150", "R1", "FV1_P50", "negcut"]
+
+
+def _params_from_kw(kw):
+    from goofer_amd.core import note_params_from_kwargs
+    return note_params_from_kwargs(1, **kw)
+
+
+def test_sampler_synth_calls_as_one_ragged_batch(ctx):
+    """The main gf.synthesize call of 15 reference renders (different flags, lengths, envelope row
+    counts), run as ONE goofer_synth_batch; stems must match the reference note by note."""
+    ctx.plan(44100, 1024, 256)
+    envs, f0s, masks, forms, params, phis, refs, env_len, lens = [], [], [], [], [], [], [], [], []
+    for name in SAMPLER:
+        g, kw = _sampler_io(name)
+        seed = int(g["seed"][0])
+        env = np.asarray(g["env_new"], dtype=np.float32)
+        n = len(g["mask_new"])
+        T = 1 + n // 256
+        envs.append(env.T)
+        env_len.append(env.shape[1])
+        f0s.append(np.asarray(g["f0_new"], dtype=np.float32))
+        masks.append(np.asarray(g["mask_new"], dtype=np.float32))
+        F = np.asarray(g["formants_new"], dtype=np.float64)        # [4, T_env]
+        assert F.shape[1] == env.shape[1]
+        forms.append(F.T)
+        params.append(_params_from_kw(kw))
+        phis.append(np.random.default_rng(seed).uniform(0.0, 2.0 * np.pi, size=(513, T)).astype(np.float32).T)
+        refs.append((g["harm"], g["uv"], g["bre"]))
+        lens.append(n)
+    out = ctx.synth_batch(ctx.rows_from(np.concatenate(envs)), env_len, ctx.tensor(np.concatenate(f0s)),
+                          ctx.tensor(np.concatenate(masks)), lens, np.concatenate(params),
+                          formants=ctx.tensor(np.concatenate(forms)), phi=ctx.rows_from(np.concatenate(phis)))
+    torch.cuda.synchronize()
+    o = 0
+    worst = 0.0
+    for name, n, ref in zip(SAMPLER, lens, refs):
+        for key, r in zip(("harm", "uv", "bre"), ref):
+            got = out[key][o:o + n].cpu().numpy()
+            e = rms_err(got, r)
+            worst = max(worst, e)
+            assert e < TOL, (name, key, e)
+            assert e < TIGHT, (name, key, e)
+        o += n
+    print("worst stem sample-RMS over 15 sampler notes:", worst)
+
+
+def test_batch_equals_single_notes_bitwise(ctx):
+    """Notes are independent: rendering a note alone or inside a batch gives identical bits."""
+    ctx.plan(44100, 1024, 256)
+    from goofer_amd.device import default_params
+    from oracle import goofer_ref as R
+    from goofer_amd import synthetic as syn
+    notes = []
+    for i in range(5):
+        src = syn.make_source(40 + i, seconds=0.1 + 0.07 * i)
+        env = R.decode_env_from_knots(src["env_pack"]).T.copy()
+        n = src["y_len"] - 37 * i
+        f0 = (180.0 + 40 * i) * src["mask"][:n]
+        notes.append((env, f0.astype(np.float32), src["mask"][:n]))
+    lens = [len(n[1]) for n in notes]
+    env_len = [n[0].shape[0] for n in notes]
+    par = default_params(len(notes))
+    par["formant_shift"] = [1.0, 1.2, 0.8, 1.0, 1.1]
+    big = ctx.synth_batch(ctx.rows_from(np.concatenate([n[0] for n in notes])), env_len,
+                          ctx.tensor(np.concatenate([n[1] for n in notes])), ctx.tensor(np.concatenate([n[2] for n in notes])),
+                          lens, par, seed=77)
+    torch.cuda.synchronize()
+    o = 0
+    for i, (env, f0, m) in enumerate(notes):
+        one = ctx.synth_batch(ctx.rows_from(env), [env_len[i]], ctx.tensor(f0), ctx.tensor(m), [lens[i]], par[i:i + 1], seed=77)
+        for key in ("harm", "bre", "mix"):
+            a = big[key][o:o + lens[i]].cpu().numpy()
+            b = one[key].cpu().numpy()
+            if key == "harm":
+                assert np.array_equal(a, b), (i, key)
+        o += lens[i]
