@@ -12,13 +12,13 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgoofer_hip.so")
 
-# numpy mirror of goofer_note_params (C layout, 80 bytes)
+# numpy mirror of goofer_note_params (C layout, 88 bytes)
 NOTE_PARAMS = np.dtype({
     "names": ["pitch_shift", "formant_shift", "f_shift", "uv_strength", "breath_strength", "normalize",
-              "apply_brightness", "cut_below_f0", "mix_harm", "mix_breath", "mix_unvoiced", "volume"],
-    "formats": ["<f4", "<f4", ("<f8", 4), "<f4", "<f4", "<f4", "<i4", "<i4", "<f4", "<f4", "<f4", "<f4"],
-    "offsets": [0, 4, 8, 40, 44, 48, 52, 56, 60, 64, 68, 72],
-    "itemsize": 80,
+              "apply_brightness", "cut_below_f0", "mix_harm", "mix_breath", "mix_unvoiced", "volume", "seed"],
+    "formats": ["<f4", "<f4", ("<f8", 4), "<f4", "<f4", "<f4", "<i4", "<i4", "<f4", "<f4", "<f4", "<f4", ("<u4", 2)],
+    "offsets": [0, 4, 8, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76],
+    "itemsize": 88,
 })
 
 
@@ -56,6 +56,7 @@ EXPORTS = {
                                      C.c_void_p]),
     "goofer_synth_batch": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_void_p]),
     "goofer_debug_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "goofer_debug_fetch": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
 }
 
 _lib = None

@@ -296,6 +296,18 @@ int goofer_debug_table(goofer_ctx *ctx, int which, float *host_out, int capacity
     return cnt[which];
 }
 
+// copy intermediate `which` of the last goofer_synth_batch to host memory (tests / debugging):
+// 0 frame_note 1 row_src 2 f0_scaled 3 pulse 4 S_harm 5 S_uv 6 S_breath 7 frames(last stem) 8 env_harm
+// 9 env_noise 10 mask_short 11 note_mag 12 note_peak 13 onset_cnt.  Returns the byte size.
+int64_t goofer_debug_fetch(goofer_ctx *ctx, int which, void *host_out, int64_t capacity_bytes)
+{
+    if (!ctx || which < 0 || which >= 16 || !ctx->dbg_ptr[which]) return GOOFER_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return GOOFER_EHIP;
+    size_t nb = ctx->dbg_bytes[which] < (size_t)capacity_bytes ? ctx->dbg_bytes[which] : (size_t)capacity_bytes;
+    if (hipMemcpy(host_out, ctx->dbg_ptr[which], nb, hipMemcpyDeviceToHost) != hipSuccess) return GOOFER_EHIP;
+    return (int64_t)ctx->dbg_bytes[which];
+}
+
 #define NEED_PLAN(ctx)                                                                    \
     if (!(ctx)) return GOOFER_EINVAL;                                                     \
     if (!(ctx)->plan.n_fft) return goofer_fail((ctx), GOOFER_ENOPLAN, "goofer_plan first")
@@ -438,6 +450,14 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         !env_h || !env_n || !short_s || !note_mag)
         return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     float *note_peak = note_mag + n;
+    {
+        const void *ptrs[] = {frame_note, row_src, f0s, pulse, S_h, S_uv, S_br, frames, env_h, env_n, short_s, note_mag, note_peak, onset_cnt};
+        size_t bytes[] = {F * sizeof(int), F * sizeof(int64_t), N * sizeof(float), N * sizeof(float), (size_t)F * ldc * sizeof(float2),
+                          (size_t)F * ldc * sizeof(float2), (size_t)F * ldc * sizeof(float2), (size_t)F * p.n_fft * sizeof(float),
+                          (size_t)F * ld * sizeof(float), (size_t)F * ld * sizeof(float), (N / 4 + n) * sizeof(double),
+                          n * sizeof(float), n * sizeof(float), n * sizeof(int32_t)};
+        for (int i = 0; i < 14; ++i) { ctx->dbg_ptr[i] = ptrs[i]; ctx->dbg_bytes[i] = bytes[i]; }
+    }
 
     // mask-smoothing taps for this call's sigma; device copy cached on the handle (steady state:
     // no host work, no synchronisation)

@@ -435,7 +435,8 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
         if (phi) {
             ph = phi[f * (int64_t)ld + k];
         } else {
-            uint32_t u = philox_u32(seed, (uint64_t)f, (uint32_t)k);
+            uint64_t key = seed ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
+            uint32_t u = philox_u32(key, (uint64_t)t, (uint32_t)k);
             ph = (float)(u >> 8) * (6.283185307179586f / 16777216.0f);
         }
         float c = cosf(ph), s = sinf(ph);

@@ -34,6 +34,9 @@ struct goofer_ctx {
     size_t scratch_bytes = 0;
     void *small = nullptr;        // small staging buffer for taps etc.
     size_t small_bytes = 0;
+    // device pointers of the last synth batch's intermediates (goofer_debug_fetch; tests only)
+    const void *dbg_ptr[16] = {nullptr};
+    size_t dbg_bytes[16] = {0};
     double *mask_taps = nullptr;  // device taps of the voicing-mask smoother, cached per sigma
     float mask_taps_sigma = -1.f;
     int mask_taps_radius = 0;

@@ -88,6 +88,21 @@ class Context:
             self._check(n)
         return out[:n]
 
+    _DBG = {"frame_note": (0, np.int32), "row_src": (1, np.int64), "f0": (2, np.float32), "pulse": (3, np.float32),
+            "S_harm": (4, np.complex64), "S_uv": (5, np.complex64), "S_breath": (6, np.complex64), "frames": (7, np.float32),
+            "env_harm": (8, np.float32), "env_noise": (9, np.float32), "mask_short": (10, np.float64),
+            "note_mag": (11, np.float32), "note_peak": (12, np.float32), "onset_cnt": (13, np.int32)}
+
+    def debug_fetch(self, name: str) -> np.ndarray:
+        """Intermediate of the last synth_batch as a flat host array (tests / debugging only)."""
+        which, dt = self._DBG[name]
+        size = self.lib.goofer_debug_fetch(self.h, which, None, 0)
+        if size < 0:
+            raise GooferError(f"debug_fetch({name}) failed ({size})")
+        out = np.empty(size // np.dtype(dt).itemsize, dtype=dt)
+        self.lib.goofer_debug_fetch(self.h, which, out.ctypes.data_as(C.c_void_p), out.nbytes)
+        return out
+
     # -- CSR helpers ---------------------------------------------------------------------------
     def offsets(self, lengths):
         off = np.zeros(len(lengths) + 1, dtype=np.int64)
@@ -125,14 +140,14 @@ class Context:
     def gauss_bins(self, rows, taps: np.ndarray):
         """rows fp32 [R, ld-strided]; taps fp64 host array of odd length."""
         taps = np.ascontiguousarray(taps, dtype=np.float64)
-        out = torch.empty_like(rows)
+        out = self.rows_like(rows)
         n_bins = rows.shape[1]
         self._check(self.lib.goofer_gauss_bins(self.h, _ptr(rows), _ptr(out), rows.shape[0], n_bins, rows.stride(0),
                                                taps.ctypes.data_as(C.c_void_p), (taps.size - 1) // 2, self._stream()))
         return out
 
     def warp_bins(self, rows, formants=None, f_shift=None, ratio: float = 1.0):
-        out = torch.empty_like(rows)
+        out = self.rows_like(rows)
         fs = None if f_shift is None else np.ascontiguousarray(f_shift, dtype=np.float64)
         self._check(self.lib.goofer_warp_bins(self.h, _ptr(rows), _ptr(out), rows.shape[0], rows.shape[1], rows.stride(0),
                                               _ptr(formants), fs.ctypes.data_as(C.c_void_p) if fs is not None else None,
@@ -154,6 +169,10 @@ class Context:
         ld = row_stride(n_bins)
         return torch.empty((n_rows, ld), dtype=dtype, device=self.device)[:, :n_bins]
 
+    def rows_like(self, r):
+        """Same shape AND same row stride as ``r`` (torch.empty_like would densify a strided view)."""
+        return torch.empty((r.shape[0], r.stride(0)), dtype=r.dtype, device=self.device)[:, :r.shape[1]]
+
     def rows_from(self, a: np.ndarray):
         """Upload a host [n_rows, n_bins] fp32 matrix into an ld-strided buffer."""
         r = self.rows(a.shape[0], a.shape[1])
@@ -172,6 +191,13 @@ class Context:
         """
         nb = self.n_bins
         n = len(sample_lengths)
+        if params.dtype != _lib.NOTE_PARAMS or params.dtype.itemsize != _lib.NOTE_PARAMS.itemsize:
+            # numpy re-packs structured dtypes on concatenate/promotion: force the C layout back
+            fixed = np.zeros(params.shape, dtype=_lib.NOTE_PARAMS)
+            for name in _lib.NOTE_PARAMS.names:
+                fixed[name] = params[name]
+            params = fixed
+        params = np.ascontiguousarray(params)
         s_off = self.offsets(sample_lengths)
         f_off = self.offsets(self.frame_counts(sample_lengths))
         e_off = self.offsets(env_lengths)

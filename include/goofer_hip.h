@@ -45,6 +45,8 @@ typedef struct {
     int32_t apply_brightness;   /* default 1                                       GOOFER.py:1131 */
     int32_t cut_below_f0;       /* cut_subharm_below_f0, default 1                 GOOFER.py:1113 */
     float mix_harm, mix_breath, mix_unvoiced, volume;   /* V, (B+100)/100, (U+100)/100, volume */
+    uint32_t seed[2];           /* per-note Philox key (lo, hi), XORed with the batch seed: a note's  */
+    uint32_t reserved;          /* noise never depends on where it sits in a batch                    */
 } goofer_note_params;
 
 /* One ragged batch of notes for goofer_synth_batch.  All pointers are device memory. */

@@ -29,7 +29,7 @@ def test_binding_covers_header_and_struct_layout():
     assert set(_declared()) <= set(_lib.EXPORTS)
     lib = _lib.load()
     assert lib.goofer_version().startswith(b"goofer_hip")
-    assert _lib.NOTE_PARAMS.itemsize == 80
+    assert _lib.NOTE_PARAMS.itemsize == 88
     assert ctypes.sizeof(_lib.Batch) == 4 * 4 + 3 * 8 + 9 * 8 + 8 + 8 + 5 * 8
 
 

@@ -76,7 +76,8 @@ def test_rfft_ragged_batch_equals_per_note(ctx):
     o = 0
     for x, n in zip(xs, lens):
         valid = 256 * (n // 256)
-        assert np.max(np.abs(y[o:o + valid] - x[:valid])) < 2e-5
+        if valid:
+            assert np.max(np.abs(y[o:o + valid] - x[:valid])) < 2e-5
         assert not y[o + valid:o + n].any()
         o += n
 
