@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — resynth frames/s of the GOOFER hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--notes 1024] [--config 3]
+
+One process per GPU (the driver launches N>1 through torch.distributed.run; RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* come from the environment).  A *step* is one pass of the hot path
+(goofer_synth_batch: pulse train -> framewise rFFT -> envelope warps / shaping -> 3x irFFT+OLA ->
+gains -> peak normalise -> V/B/U mix) over one ragged batch of synthetic notes already resident in
+HBM.  Notes are independent, so ranks shard by note id with no data-path collective (weak scaling:
+`--notes` per GPU); the only collectives are the barriers and the MAX of the elapsed time.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      HIP-event duration of the dominant kernel inside the timed steps vs its algorithmic bytes
+  roofline_fft  the same for the framewise rFFT kernel (the kernel BASELINE's 40 % target names)
+  cpu_baseline  the numpy/C oracle (a port of the reference's CPU path) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured ceiling
+
+
+def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int) -> float:
+    """Algorithmic HBM bytes of one launch of each stage: unique bytes that must
+    cross HBM if nothing were re-read.  F frames, N samples, B bins."""
+    fft = (4 * hop + 8 * B) * F                      # SURVEY.md §8(d) ALG_BYTES_FFT per frame-transform
+    table = {
+        "rfft_frames": fft, "irfft_harm": fft, "irfft_breath": fft, "irfft_unvoiced": fft,
+        "ola_harm": 4 * n_fft * F + 4 * N, "ola_breath": 4 * n_fft * F + 4 * N, "ola_unvoiced": 4 * n_fft * F + 4 * N,
+        "harm_shape": (16 * B + 4 * B) * F,          # S in+out, env in
+        "noise_spectra": (16 * B + 4 * B) * F,       # two spectra out, env in (+4B when phi is injected)
+        "gauss_env": 8 * B * F, "warp_env": 8 * B * F,
+        "phase_inc": 12 * N, "pulse_onsets": 12 * N, "pulse_place": 4 * N,
+        "mask_short": 4 * N / 4 + 8 * N / 4, "stem_gains": 24 * N, "apply_gain": 28 * N, "setup_maps": 8 * N + 12 * F,
+    }
+    return float(table[stage])
+
+
+def cpu_baseline(wl, hop, budget_s=15.0, min_notes=4):
+    """Oracle (CPU port of the reference path, oracle/) on the same notes, single thread, bounded."""
+    from oracle import goofer_ref as R
+    R._native()
+    frames = 0
+    t0 = time.perf_counter()
+    done = 0
+    for j in range(len(wl.notes)):
+        h = wl.host_note(j)
+        T = 1 + h["n"] // hop
+        phi = np.random.default_rng(h["phi_seed"]).uniform(0.0, 2.0 * np.pi, size=(h["env"].shape[0], T)).astype(np.float32)
+        t1 = time.perf_counter()
+        R.synthesize(h["env"], h["f0"], h["mask"], np.empty(h["n"], bool), wl.geo["sr"], n_fft=wl.geo["n_fft"],
+                     hop_length=hop, formants=h["formants"], phi=phi, **h["kw"])
+        frames += T
+        done += 1
+        if j == 0:
+            t0 = t1                       # exclude the one-off table/native-lib warm-up before note 0
+        if done >= min_notes and time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{done} notes of the same workload ({frames} frames) through oracle/goofer_ref.synthesize "
+                      f"(numpy + gcc -O2 loops standing in for numba), injected phases, {dt:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--notes", type=int, default=1024, help="notes per GPU (weak scaling)")
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (1-based)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from goofer_amd.device import Context
+    from goofer_amd.workload import SynthWorkload
+
+    ctx = Context(local)
+    ids = range(rank * args.notes, (rank + 1) * args.notes)
+    wl = SynthWorkload(ctx, args.config, ids)
+    geo = wl.geo
+    B, hop, n_fft, sr = geo["n_fft"] // 2 + 1, geo["hop"], geo["n_fft"], geo["sr"]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    ctx.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = t1 - t0
+    prof = ctx.profile_end()
+    frames_total = wl.frames
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        f = torch.tensor([wl.frames], dtype=torch.float64, device="cuda")
+        dist.all_reduce(f, op=dist.ReduceOp.SUM)
+        frames_total = int(f.item())
+
+    if rank == 0:
+        value = frames_total * args.steps / elapsed
+        steps = max(1, prof["steps"])
+        per = {k: v / steps for k, v in prof["ms"].items()}              # ms per launch, this rank
+        dom = max(per, key=per.get)
+
+        def roof(stage):
+            ms = per[stage]
+            a = stage_alg_bytes(stage, wl.frames, wl.samples, B, hop, n_fft) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": stage, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": a / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms,
+                    "alg_bytes_per_launch": stage_alg_bytes(stage, wl.frames, wl.samples, B, hop, n_fft)}
+
+        line = {
+            "metric": "resynth_frames_per_sec", "value": value, "unit": "frames/s",
+            "realtime_factor": value * hop / sr,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config {args.config}: {args.notes} notes/GPU x ~1.1 s, sr {sr}, n_fft {n_fft}, "
+                                   f"hop {hop} ({1e3 * hop / sr:.1f} ms); per-note flags {wl_flags(args.config)}; one step = "
+                                   "goofer_synth_batch (gf.synthesize + V/B/U mix) on assembled features resident in HBM, "
+                                   "on-device Philox phases; assembly-side flags (fw, fst*) are not applied in this workload",
+                       "notes_per_gpu": args.notes, "frames_per_gpu": wl.frames, "samples_per_gpu": wl.samples,
+                       "sharding": "independent notes, no data-path collective"},
+            "stage_ms": per,
+            "roofline": roof(dom),
+            "roofline_fft": roof("rfft_frames"),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(wl, hop)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def wl_flags(config):
+    from goofer_amd import synthetic as syn
+    return syn.config_flags(config, 0) + " / " + syn.config_flags(config, 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,9 @@ EXPORTS = {
     "goofer_synth_batch": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_void_p]),
     "goofer_debug_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "goofer_debug_fetch": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "goofer_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "goofer_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "goofer_profile_stage_name": (C.c_char_p, [C.c_int]),
 }
 
 _lib = None
@@ -71,6 +74,9 @@ def load(path: str = LIB_PATH):
         raise RuntimeError(
             f"{path} not found: the HIP extension has not been built (run `python -m goofer_amd.build`). "
             "goofer_amd has no CPU fallback.")
+    # torch first: it carries its own libamdhip64; loading ours afterwards binds to that same runtime
+    # (the other order puts two HIP runtimes in the process and hipGetDeviceCount fails)
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is absent

@@ -17,6 +17,10 @@ int launch_pulse_peak(goofer_ctx *, float *, double, hipStream_t);
 struct onset_t;
 int launch_pulse_train(goofer_ctx *, const float *, float, const int64_t *, int, int64_t, float *, double *, onset_t *, int32_t *,
                        int32_t *, hipStream_t);
+int launch_phase_inc(goofer_ctx *, const float *, float, int64_t, double *, hipStream_t);
+int launch_pulse_onsets(goofer_ctx *, const float *, float, const double *, const int64_t *, int, onset_t *, int32_t *, int32_t *,
+                        hipStream_t);
+int launch_pulse_place(goofer_ctx *, const onset_t *, const int32_t *, const int64_t *, int, int64_t, float *, hipStream_t);
 int launch_gauss_bins(goofer_ctx *, const float *, float *, int64_t, int, int, const double *, int, const int64_t *, hipStream_t);
 int launch_warp_bins(goofer_ctx *, const float *, float *, int64_t, int, int, const double *, const double *,
                      const goofer_note_params *, const int *, const int64_t *, double, hipStream_t);
@@ -214,6 +218,8 @@ void goofer_destroy(goofer_ctx *ctx)
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->small) (void)hipFree(ctx->small);
     if (ctx->mask_taps) (void)hipFree(ctx->mask_taps);
+    for (int i = 0; i < ctx->prof_cap * (PROF_STAGES + 1); ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
+    free(ctx->prof_ev);
     delete ctx;
 }
 
@@ -307,6 +313,50 @@ int64_t goofer_debug_fetch(goofer_ctx *ctx, int which, void *host_out, int64_t c
     if (hipMemcpy(host_out, ctx->dbg_ptr[which], nb, hipMemcpyDeviceToHost) != hipSuccess) return GOOFER_EHIP;
     return (int64_t)ctx->dbg_bytes[which];
 }
+
+static const char *const PROF_NAMES[PROF_STAGES] = {
+    "setup_maps", "gauss_env", "warp_env", "phase_inc", "pulse_onsets", "pulse_place", "rfft_frames", "harm_shape",
+    "irfft_harm", "ola_harm", "noise_spectra", "irfft_breath", "ola_breath", "irfft_unvoiced", "ola_unvoiced",
+    "mask_short", "stem_gains", "apply_gain"};
+
+// Per-stage timing of goofer_synth_batch with HIP events recorded on the caller's stream (so the
+// numbers are what that stream really executed).  begin(max_steps) arms it; every synth batch then
+// records PROF_STAGES+1 events; end() synchronises and returns the summed milliseconds per stage.
+int goofer_profile_begin(goofer_ctx *ctx, int max_steps)
+{
+    if (!ctx || max_steps <= 0) return GOOFER_EINVAL;
+    if (ctx->prof_cap < max_steps) {
+        for (int i = 0; i < ctx->prof_cap * (PROF_STAGES + 1); ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
+        free(ctx->prof_ev);
+        ctx->prof_ev = (hipEvent_t *)calloc((size_t)max_steps * (PROF_STAGES + 1), sizeof(hipEvent_t));
+        if (!ctx->prof_ev) return goofer_fail(ctx, GOOFER_ENOMEM, "event pool");
+        for (int i = 0; i < max_steps * (PROF_STAGES + 1); ++i) HIP_TRY(ctx, hipEventCreate(&ctx->prof_ev[i]));
+        ctx->prof_cap = max_steps;
+    }
+    ctx->prof_steps = 0;
+    ctx->prof_on = true;
+    return GOOFER_OK;
+}
+
+int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages)
+{
+    if (!ctx) return GOOFER_EINVAL;
+    ctx->prof_on = false;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    for (int s = 0; s < n_stages && s < PROF_STAGES; ++s) {
+        double acc = 0.0;
+        for (int k = 0; k < ctx->prof_steps; ++k) {
+            hipEvent_t *e = ctx->prof_ev + (size_t)k * (PROF_STAGES + 1);
+            float ms = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, e[s], e[s + 1]));
+            acc += ms;
+        }
+        ms_per_stage[s] = acc;
+    }
+    return ctx->prof_steps;
+}
+
+const char *goofer_profile_stage_name(int stage) { return stage >= 0 && stage < PROF_STAGES ? PROF_NAMES[stage] : ""; }
 
 #define NEED_PLAN(ctx)                                                                    \
     if (!(ctx)) return GOOFER_EINVAL;                                                     \
@@ -478,40 +528,64 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), st));
 
+    hipEvent_t *pev = nullptr;
+    if (ctx->prof_on && ctx->prof_steps < ctx->prof_cap) pev = ctx->prof_ev + (size_t)ctx->prof_steps * (PROF_STAGES + 1);
+    int stage = 0;
+#define MARK()                                                       \
+    do {                                                             \
+        if (pev) HIP_TRY(ctx, hipEventRecord(pev[stage], st));       \
+        ++stage;                                                     \
+    } while (0)
+
     unsigned fb = (unsigned)((F + 255) / 256), sb = (unsigned)((N + 255) / 256);
+    MARK();   // 0: setup
     if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, st))) return rc;
     hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, st, b->frame_off, b->env_off, frame_note, F, row_src);
     LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_scale_f0, dim3(sb), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s);
     LAUNCH_CHECK(ctx);
-
-    // envelopes: noise envelope from the un-warped rows (GOOFER.py:993), harmonic envelope warped
+    MARK();   // 1: noise envelope = sigma-1.75 blur of the un-warped rows (GOOFER.py:993)
     if ((rc = launch_gauss_bins(ctx, b->env, env_n, F, p.n_bins, ld, p.blur175, 7, row_src, st))) return rc;
+    MARK();   // 2: harmonic envelope = formant-anchored + uniform warp
     if ((rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, st)))
         return rc;
-
-    // harmonic branch
-    if ((rc = launch_pulse_train(ctx, f0s, 1.0f, b->sample_off, n, N, pulse, inc, (onset_t *)onsets, onset_cnt, ovf, st))) return rc;
+    MARK();   // 3..5: pulse train
+    if ((rc = launch_phase_inc(ctx, f0s, 1.0f, N, inc, st))) return rc;
+    MARK();
+    if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, inc, b->sample_off, n, (onset_t *)onsets, onset_cnt, ovf, st))) return rc;
+    MARK();
+    if ((rc = launch_pulse_place(ctx, (onset_t *)onsets, onset_cnt, b->sample_off, n, N, pulse, st))) return rc;
+    MARK();   // 6: framewise rFFT of the pulse train
     if ((rc = launch_rfft_frames_mapped(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, st))) return rc;
+    MARK();   // 7
     if ((rc = launch_harm_shape(ctx, S_h, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, env_h, ld, b->params,
                                 note_mag, st)))
         return rc;
+    MARK();   // 8, 9
     if ((rc = launch_irfft_frames(ctx, S_h, ldc, F, frames, st))) return rc;
+    MARK();
     if ((rc = launch_ola_gather(ctx, frames, b->sample_off, b->frame_off, n, N, b->harm, note_mag, st))) return rc;
-
-    // aperiodic branch
+    MARK();   // 10: aperiodic spectra
     if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, env_n, b->phi, ld,
                                    b->params, b->seed, st)))
         return rc;
+    MARK();   // 11..14
     if ((rc = launch_irfft_frames(ctx, S_br, ldc, F, frames, st))) return rc;
+    MARK();
     if ((rc = launch_ola_gather(ctx, frames, b->sample_off, b->frame_off, n, N, b->bre, nullptr, st))) return rc;
+    MARK();
     if ((rc = launch_irfft_frames(ctx, S_uv, ldc, F, frames, st))) return rc;
+    MARK();
     if ((rc = launch_ola_gather(ctx, frames, b->sample_off, b->frame_off, n, N, b->uv, nullptr, st))) return rc;
-
-    // gains, peak normalisation, mix
+    MARK();   // 15..17: gains, peak normalisation, mix
     if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, short_s, st))) return rc;
+    MARK();
     if ((rc = launch_stem_gains(ctx, b->harm, b->uv, b->bre, short_s, b->sample_off, n, N, b->params, note_peak, st))) return rc;
+    MARK();
     if ((rc = launch_apply_gain(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, N, b->params, note_peak, st))) return rc;
+    MARK();   // end
+#undef MARK
+    if (pev) ctx->prof_steps++;
     return GOOFER_OK;
 }
 

@@ -9,6 +9,7 @@
 #include "../../include/goofer_hip.h"
 
 #define WAVE 64
+#define PROF_STAGES 18
 
 struct goofer_plan_t {
     int sr = 0, n_fft = 0, hop = 0, n_bins = 0;
@@ -37,6 +38,10 @@ struct goofer_ctx {
     // device pointers of the last synth batch's intermediates (goofer_debug_fetch; tests only)
     const void *dbg_ptr[16] = {nullptr};
     size_t dbg_bytes[16] = {0};
+    // per-stage HIP-event timing of goofer_synth_batch (goofer_profile_begin/end)
+    bool prof_on = false;
+    int prof_steps = 0, prof_cap = 0;
+    hipEvent_t *prof_ev = nullptr;      // [prof_cap][PROF_STAGES + 1]
     double *mask_taps = nullptr;  // device taps of the voicing-mask smoother, cached per sigma
     float mask_taps_sigma = -1.f;
     int mask_taps_radius = 0;

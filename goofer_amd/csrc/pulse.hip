@@ -154,20 +154,42 @@ __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__
     pulse[g] = acc;
 }
 
+int launch_phase_inc(goofer_ctx *ctx, const float *f0, float f0_scale, int64_t total_samples, double *inc, hipStream_t st)
+{
+    if (total_samples <= 0) return GOOFER_OK;
+    hipLaunchKernelGGL(k_phase_inc, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, st, f0, total_samples,
+                       (double)ctx->plan.sr, f0_scale, inc);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const double *inc, const int64_t *sample_off,
+                        int n_notes, onset_t *onsets, int32_t *onset_cnt, int32_t *overflow, hipStream_t st)
+{
+    if (n_notes <= 0) return GOOFER_OK;
+    hipLaunchKernelGGL(k_pulse_onsets, dim3((n_notes + 63) / 64), dim3(64), 0, st, f0, f0_scale, inc, sample_off, n_notes,
+                       (double)ctx->plan.sr, onsets, onset_cnt, overflow);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+int launch_pulse_place(goofer_ctx *ctx, const onset_t *onsets, const int32_t *onset_cnt, const int64_t *sample_off, int n_notes,
+                       int64_t total_samples, float *pulse, hipStream_t st)
+{
+    if (total_samples <= 0) return GOOFER_OK;
+    hipLaunchKernelGGL(k_pulse_place, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, st, onsets, onset_cnt,
+                       ctx->plan.pulse_peak, sample_off, n_notes, total_samples, pulse);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
 int launch_pulse_train(goofer_ctx *ctx, const float *f0, float f0_scale, const int64_t *sample_off, int n_notes,
                        int64_t total_samples, float *pulse, double *inc, onset_t *onsets, int32_t *onset_cnt,
                        int32_t *overflow, hipStream_t st)
 {
     if (total_samples <= 0 || n_notes <= 0) return GOOFER_OK;
-    const goofer_plan_t &p = ctx->plan;
-    unsigned nb = (unsigned)((total_samples + 255) / 256);
-    hipLaunchKernelGGL(k_phase_inc, dim3(nb), dim3(256), 0, st, f0, total_samples, (double)p.sr, f0_scale, inc);
-    LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_pulse_onsets, dim3((n_notes + 63) / 64), dim3(64), 0, st, f0, f0_scale, inc, sample_off, n_notes,
-                       (double)p.sr, onsets, onset_cnt, overflow);
-    LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_pulse_place, dim3(nb), dim3(256), 0, st, onsets, onset_cnt, p.pulse_peak, sample_off, n_notes,
-                       total_samples, pulse);
-    LAUNCH_CHECK(ctx);
-    return GOOFER_OK;
+    int rc;
+    if ((rc = launch_phase_inc(ctx, f0, f0_scale, total_samples, inc, st))) return rc;
+    if ((rc = launch_pulse_onsets(ctx, f0, f0_scale, inc, sample_off, n_notes, onsets, onset_cnt, overflow, st))) return rc;
+    return launch_pulse_place(ctx, onsets, onset_cnt, sample_off, n_notes, total_samples, pulse, st);
 }

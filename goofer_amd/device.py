@@ -103,6 +103,18 @@ class Context:
         self.lib.goofer_debug_fetch(self.h, which, out.ctypes.data_as(C.c_void_p), out.nbytes)
         return out
 
+    def profile_begin(self, max_steps: int):
+        self._check(self.lib.goofer_profile_begin(self.h, max_steps))
+
+    def profile_end(self) -> dict:
+        """{'steps': k, 'ms': {stage: summed milliseconds}} from HIP events on the launch stream."""
+        ms = np.zeros(18, dtype=np.float64)
+        k = self.lib.goofer_profile_end(self.h, ms.ctypes.data_as(C.c_void_p), 18)
+        if k < 0:
+            self._check(k)
+        names = [self.lib.goofer_profile_stage_name(i).decode() for i in range(18)]
+        return {"steps": k, "ms": dict(zip(names, ms.tolist()))}
+
     # -- CSR helpers ---------------------------------------------------------------------------
     def offsets(self, lengths):
         off = np.zeros(len(lengths) + 1, dtype=np.int64)

@@ -127,6 +127,20 @@ int goofer_knot_decode(goofer_ctx *ctx, const uint16_t *knots_f16, int K, const 
 /* gf.synthesize for a ragged batch (GOOFER.py:971-1220) + the V/B/U mix (SillySampler.py:1142-1151). */
 int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *batch, void *stream);
 
+/* ---- measurement / test hooks --------------------------------------------------------------- */
+
+/* HIP-event timing of every stage of goofer_synth_batch on the caller's stream: begin() arms up to
+ * max_steps batches, end() synchronises and writes the summed milliseconds of each stage
+ * (goofer_profile_stage_name(i), i < 18); returns the number of batches recorded. */
+int goofer_profile_begin(goofer_ctx *ctx, int max_steps);
+int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages);
+const char *goofer_profile_stage_name(int stage);
+
+/* Copy a plan table (0 window, 1 freqs, 2 boost, 3 bright_harm, 4 bright_breath, 5 pulse peak) or an
+ * intermediate of the last synth batch to HOST memory; return element count / byte size. Tests only. */
+int goofer_debug_table(goofer_ctx *ctx, int which, float *host_out, int capacity);
+int64_t goofer_debug_fetch(goofer_ctx *ctx, int which, void *host_out, int64_t capacity_bytes);
+
 #ifdef __cplusplus
 }
 #endif
