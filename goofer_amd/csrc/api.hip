@@ -16,10 +16,10 @@ int launch_rfft_frames_mapped(goofer_ctx *, const float *, const int64_t *, cons
 int launch_pulse_peak(goofer_ctx *, float *, double, hipStream_t);
 struct onset_t;
 int launch_pulse_train(goofer_ctx *, const float *, float, const int64_t *, int, int64_t, float *, double *, onset_t *, int32_t *,
-                       int32_t *, hipStream_t);
+                       int32_t *, int32_t *, hipStream_t);
 int launch_phase_inc(goofer_ctx *, const float *, float, int64_t, double *, hipStream_t);
 int launch_pulse_onsets(goofer_ctx *, const float *, float, const double *, const int64_t *, int, onset_t *, int32_t *, int32_t *,
-                        hipStream_t);
+                        int32_t *, hipStream_t);
 int launch_pulse_place(goofer_ctx *, const onset_t *, const int32_t *, const int64_t *, int, int64_t, float *, hipStream_t);
 int launch_gauss_bins(goofer_ctx *, const float *, float *, int64_t, int, int, const double *, int, const int64_t *, hipStream_t);
 int launch_warp_bins(goofer_ctx *, const float *, float *, int64_t, int, int, const double *, const double *,
@@ -33,7 +33,7 @@ int launch_noise_spectra(goofer_ctx *, float2 *, float2 *, int, int64_t, const i
                          hipStream_t);
 int launch_mask_short(goofer_ctx *, const float *, const int64_t *, int, int64_t, const double *, int, double *, hipStream_t);
 int launch_stem_gains(goofer_ctx *, float *, float *, float *, const double *, const int64_t *, int, int64_t,
-                      const goofer_note_params *, float *, hipStream_t);
+                      const goofer_note_params *, float *, double *, hipStream_t);
 int launch_apply_gain(goofer_ctx *, float *, float *, float *, float *, float *, const int64_t *, int, int64_t,
                       const goofer_note_params *, const float *, hipStream_t);
 
@@ -68,15 +68,19 @@ __global__ void k_row_src(const int64_t *__restrict__ frame_off, const int64_t *
 __global__ void k_scale_f0(const float *__restrict__ f0, const int64_t *__restrict__ sample_off, int n_notes, int64_t total,
                            const goofer_note_params *__restrict__ params, float *__restrict__ out)
 {
-    __shared__ int s_lo;
+    __shared__ int s_pair[2];
     const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
-    if (threadIdx.x == 0) s_lo = csr_find(sample_off, n_notes, g0);
-    __syncthreads();
+    int lo, hi;
+    block_note_range(sample_off, n_notes, g0, total, s_pair, lo, hi);
     const int64_t g = g0 + threadIdx.x;
     if (g >= total) return;
-    int note = s_lo;
-    while (sample_off[note + 1] <= g) ++note;
-    out[g] = f0[g] * params[note].pitch_shift;
+    if (lo == hi) {
+        out[g] = f0[g] * params[lo].pitch_shift;
+    } else {
+        int note = lo;
+        while (sample_off[note + 1] <= g) ++note;
+        out[g] = f0[g] * params[note].pitch_shift;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -104,6 +108,7 @@ static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t sampl
     add(samples * sizeof(float));                 // f0 scaled
     add(samples * sizeof(double));                // phase increments
     add((samples / 2 + 16 * notes + 16) * ONSET_BYTES);
+    add((samples / 2 + 16 * notes + 16) * sizeof(int32_t));   // raw onset sample indices
     add(notes * sizeof(int32_t) + 64);            // onset counts
     add(64);                                      // overflow flag
     add(samples * sizeof(float));                 // pulse
@@ -112,6 +117,7 @@ static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t sampl
     add(2 * frames * ld * sizeof(float));         // env_h, env_n
     add((samples / 4 + notes + 16) * sizeof(double));  // smoothed decimated mask
     add(2 * notes * sizeof(float) + 64);          // note_mag, note_peak
+    add(2 * notes * sizeof(double) + 64);         // per-note linspace steps
     return b + 4096;
 }
 
@@ -392,18 +398,19 @@ int goofer_pulse_train(goofer_ctx *ctx, const float *f0, const int64_t *sample_o
 {
     NEED_PLAN(ctx);
     hipStream_t st = (hipStream_t)stream;
-    size_t need = total_samples * sizeof(double) + (total_samples / 2 + 16 * (size_t)n_notes + 16) * ONSET_BYTES +
-                  n_notes * sizeof(int32_t) + 4096;
+    size_t need = total_samples * sizeof(double) + (total_samples / 2 + 16 * (size_t)n_notes + 16) * (ONSET_BYTES + 4) +
+                  n_notes * sizeof(int32_t) + 8192;
     int rc = ensure_scratch(ctx, need);
     if (rc) return rc;
     arena a{(char *)ctx->scratch, ctx->scratch_bytes, 0};
     double *inc = a.take<double>(total_samples);
     char *onsets = a.take<char>((total_samples / 2 + 16 * (size_t)n_notes + 16) * ONSET_BYTES);
+    int32_t *oidx = a.take<int32_t>(total_samples / 2 + 16 * (size_t)n_notes + 16);
     int32_t *cnt = a.take<int32_t>(n_notes + 16);
     int32_t *ovf = a.take<int32_t>(16);
-    if (!inc || !onsets || !cnt || !ovf) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
+    if (!inc || !onsets || !oidx || !cnt || !ovf) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), st));
-    return launch_pulse_train(ctx, f0, 1.0f, sample_off, n_notes, total_samples, pulse, inc, (onset_t *)onsets, cnt, ovf, st);
+    return launch_pulse_train(ctx, f0, 1.0f, sample_off, n_notes, total_samples, pulse, inc, (onset_t *)onsets, oidx, cnt, ovf, st);
 }
 
 int goofer_gauss_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows, int n_bins, int ld, const double *taps,
@@ -485,6 +492,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     float *f0s = a.take<float>(N);
     double *inc = a.take<double>(N);
     char *onsets = a.take<char>((N / 2 + 16 * (size_t)n + 16) * ONSET_BYTES);
+    int32_t *onset_idx = a.take<int32_t>(N / 2 + 16 * (size_t)n + 16);
     int32_t *onset_cnt = a.take<int32_t>(n + 16);
     int32_t *ovf = a.take<int32_t>(16);
     float *pulse = a.take<float>(N);
@@ -496,8 +504,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     float *env_n = a.take<float>((size_t)F * ld);
     double *short_s = a.take<double>(N / 4 + n + 16);
     float *note_mag = a.take<float>(2 * (size_t)n + 16);
-    if (!frame_note || !row_src || !f0s || !inc || !onsets || !onset_cnt || !ovf || !pulse || !S_h || !S_uv || !S_br || !frames ||
-        !env_h || !env_n || !short_s || !note_mag)
+    double *note_steps = a.take<double>(2 * (size_t)n + 16);
+    if (!frame_note || !row_src || !f0s || !inc || !onsets || !onset_idx || !onset_cnt || !ovf || !pulse || !S_h || !S_uv || !S_br || !frames ||
+        !env_h || !env_n || !short_s || !note_mag || !note_steps)
         return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     float *note_peak = note_mag + n;
     {
@@ -552,7 +561,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     MARK();   // 3..5: pulse train
     if ((rc = launch_phase_inc(ctx, f0s, 1.0f, N, inc, st))) return rc;
     MARK();
-    if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, inc, b->sample_off, n, (onset_t *)onsets, onset_cnt, ovf, st))) return rc;
+    if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, inc, b->sample_off, n, (onset_t *)onsets, onset_idx, onset_cnt, ovf, st))) return rc;
     MARK();
     if ((rc = launch_pulse_place(ctx, (onset_t *)onsets, onset_cnt, b->sample_off, n, N, pulse, st))) return rc;
     MARK();   // 6: framewise rFFT of the pulse train
@@ -580,7 +589,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     MARK();   // 15..17: gains, peak normalisation, mix
     if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, short_s, st))) return rc;
     MARK();
-    if ((rc = launch_stem_gains(ctx, b->harm, b->uv, b->bre, short_s, b->sample_off, n, N, b->params, note_peak, st))) return rc;
+    if ((rc = launch_stem_gains(ctx, b->harm, b->uv, b->bre, short_s, b->sample_off, n, N, b->params, note_peak, note_steps, st))) return rc;
     MARK();
     if ((rc = launch_apply_gain(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, N, b->params, note_peak, st))) return rc;
     MARK();   // end

@@ -96,7 +96,7 @@ __device__ __forceinline__ double np_interp_eval(double x, int j, const double *
     if (j == len) return fp[len - 1];
     if (j == len - 1) return fp[j];
     if (x == xp[j]) return fp[j];
-    double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    double slope = (fp[j + 1] - fp[j]) * fast_rcp(xp[j + 1] - xp[j]);
     double v = slope * (x - xp[j]) + fp[j];
     if (isnan(v)) {
         v = slope * (x - xp[j + 1]) + fp[j + 1];
@@ -107,7 +107,9 @@ __device__ __forceinline__ double np_interp_eval(double x, int j, const double *
 
 // linear interpolation of an fp32 row sampled on the uniform grid b*step, at x in [0, nyq]
 // (np.interp with sorted xp: largest j with xp[j] <= x), plus gf.interp1d's linear extrapolation.
-__device__ __forceinline__ double row_interp(const float *r, int n_bins, double step, double nyq, double x)
+// The index is exact (multiply estimate, compare fix-up against the true grid); the slope uses
+// inv_step = 1/step instead of a division (grid spacing is exactly `step`: b*step is exact in fp64).
+__device__ __forceinline__ double row_interp(const float *r, int n_bins, double step, double inv_step, double nyq, double x)
 {
     if (x < 0.0) {
         double sl = (double)(r[1] - r[0]) / (step + 1e-10);           // fp32 difference, like the reference
@@ -118,18 +120,17 @@ __device__ __forceinline__ double row_interp(const float *r, int n_bins, double 
         double sl = (double)(r[n_bins - 1] - r[n_bins - 2]) / (nyq - xl + 1e-10);
         return (double)r[n_bins - 1] + sl * (x - nyq);
     }
-    int j = (int)floor(x / step);
+    int j = (int)(x * inv_step);
     if (j > n_bins - 1) j = n_bins - 1;
-    if (j < 0) j = 0;
-    // grid point j is j*step, except the last which linspace pins to nyq
-    auto grid = [&](int q) { return q >= n_bins - 1 ? nyq : (double)q * step; };
-    while (j + 1 <= n_bins - 1 && grid(j + 1) <= x) ++j;
-    while (j > 0 && grid(j) > x) --j;
+    // grid point q is q*step, except the last which linspace pins to nyq
+    if (j + 1 <= n_bins - 1 && (j + 1 >= n_bins - 1 ? nyq : (double)(j + 1) * step) <= x) ++j;
+    if (j > 0 && (j >= n_bins - 1 ? nyq : (double)j * step) > x) --j;
     if (j >= n_bins - 1) return (double)r[n_bins - 1];
-    double xj = grid(j);
-    if (x == xj) return (double)r[j];
-    double slope = ((double)r[j + 1] - (double)r[j]) / (grid(j + 1) - xj);
-    return slope * (x - xj) + (double)r[j];
+    const double xj = (double)j * step;
+    const double r0 = (double)r[j];
+    if (x == xj) return r0;
+    const double slope = ((double)r[j + 1] - r0) * inv_step;
+    return slope * (x - xj) + r0;
 }
 
 // Per-row formant-anchored warp then uniform warp.  f_shift == nullptr skips the first stage,
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(256) void k_warp_bins(const float *__restrict__ in,
         warp = true;   // the caller decides (gf.synthesize tests any(shift != 1))
     }
     const double step = nyq / (double)(n_bins - 1);
+    const double inv_step = fast_rcp(step);
     float *cur = ra, *nxt = rb;
 
     if (warp && formants) {
@@ -180,6 +182,22 @@ __global__ __launch_bounds__(256) void k_warp_bins(const float *__restrict__ in,
         }
         dst[len] = nyq; sp[len] = nyq; ++len;
 
+        bool sorted = true;
+        for (int k = 1; k < len; ++k) sorted &= dst[k - 1] <= dst[k];
+        if (sorted || len <= 4) {
+            // monotone anchors (or numpy's guess-free linear search): the answer does not depend on the
+            // guess chain — index = last anchor <= x, found with a few compares, bins strided over lanes
+            for (int b = lane; b < n_bins; b += WAVE) {
+                const double x = b >= n_bins - 1 ? nyq : (double)b * step;
+                int j = np_search_guess(x, dst, len, 1);
+                if (len > 4) {
+                    j = 0;
+                    for (int k = 1; k < len; ++k) j += dst[k] <= x;
+                }
+                const double wf = np_interp_eval(x, j, dst, sp, len);
+                nxt[b] = (float)row_interp(cur, n_bins, step, inv_step, nyq, wf);
+            }
+        } else {
         // Resolve np.interp's guess chain over the ascending bin frequencies.  The clamped guess
         // takes at most 3 values (1..len-3), so each bin is a map state->state; lanes own
         // contiguous chunks, compose their maps, scan across the wave, then replay.
@@ -187,31 +205,27 @@ __global__ __launch_bounds__(256) void k_warp_bins(const float *__restrict__ in,
         const int b0 = lane * per;
         auto clampg = [&](int g) { int hi = len - 3; if (g > hi) g = hi; if (g < 1) g = 1; return g; };
         int m1 = 1, m2 = 2, m3 = 3;                 // composed map of this lane's chunk: state s -> m_s
-        if (len > 4) {
-            for (int q = 0; q < per; ++q) {
-                int b = b0 + q;
-                if (b >= n_bins) break;
-                double x = b >= n_bins - 1 ? nyq : (double)b * step;
-                m1 = clampg(np_search_guess(x, dst, len, m1));
-                m2 = clampg(np_search_guess(x, dst, len, m2));
-                m3 = clampg(np_search_guess(x, dst, len, m3));
-            }
-            // inclusive scan of map composition (earlier lanes apply first)
-            for (int off = 1; off < WAVE; off <<= 1) {
-                int p1 = __shfl_up(m1, off, WAVE), p2 = __shfl_up(m2, off, WAVE), p3 = __shfl_up(m3, off, WAVE);
-                if (lane >= off) {
-                    // new(s) = mine(prev(s))
-                    int a1 = p1 == 1 ? m1 : (p1 == 2 ? m2 : m3);
-                    int a2 = p2 == 1 ? m1 : (p2 == 2 ? m2 : m3);
-                    int a3 = p3 == 1 ? m1 : (p3 == 2 ? m2 : m3);
-                    m1 = a1; m2 = a2; m3 = a3;
-                }
+        for (int q = 0; q < per; ++q) {
+            int b = b0 + q;
+            if (b >= n_bins) break;
+            double x = b >= n_bins - 1 ? nyq : (double)b * step;
+            m1 = clampg(np_search_guess(x, dst, len, m1));
+            m2 = clampg(np_search_guess(x, dst, len, m2));
+            m3 = clampg(np_search_guess(x, dst, len, m3));
+        }
+        // inclusive scan of map composition (earlier lanes apply first)
+        for (int off = 1; off < WAVE; off <<= 1) {
+            int p1 = __shfl_up(m1, off, WAVE), p2 = __shfl_up(m2, off, WAVE), p3 = __shfl_up(m3, off, WAVE);
+            if (lane >= off) {
+                int a1 = p1 == 1 ? m1 : (p1 == 2 ? m2 : m3);
+                int a2 = p2 == 1 ? m1 : (p2 == 2 ? m2 : m3);
+                int a3 = p3 == 1 ? m1 : (p3 == 2 ? m2 : m3);
+                m1 = a1; m2 = a2; m3 = a3;
             }
         }
         // state entering this lane's chunk = inclusive result of lane-1 applied to the initial guess
         int incoming = __shfl_up(m1, 1, WAVE);       // initial j = 0 clamps to state 1
-        int state = lane == 0 ? 1 : incoming;
-        int guess = lane == 0 ? 0 : state;
+        int guess = lane == 0 ? 0 : incoming;
         for (int q = 0; q < per; ++q) {
             int b = b0 + q;
             if (b >= n_bins) break;
@@ -219,17 +233,19 @@ __global__ __launch_bounds__(256) void k_warp_bins(const float *__restrict__ in,
             int j = np_search_guess(x, dst, len, guess);
             guess = j;
             double wf = np_interp_eval(x, j, dst, sp, len);
-            nxt[b] = (float)row_interp(cur, n_bins, step, nyq, wf);
+            nxt[b] = (float)row_interp(cur, n_bins, step, inv_step, nyq, wf);
+        }
         }
         wave_lds_sync();
         float *t = cur; cur = nxt; nxt = t;
     }
     if (ratio != 1.0) {
+        const double inv_ratio = fast_rcp(ratio);
         for (int b = lane; b < n_bins; b += WAVE) {
             double x = b >= n_bins - 1 ? nyq : (double)b * step;
-            double q = x / ratio;
+            double q = x * inv_ratio;
             q = q < 0.0 ? 0.0 : (q > nyq ? nyq : q);
-            nxt[b] = (float)row_interp(cur, n_bins, step, nyq, q);
+            nxt[b] = (float)row_interp(cur, n_bins, step, inv_step, nyq, q);
         }
         wave_lds_sync();
         float *t = cur; cur = nxt; nxt = t;

@@ -88,6 +88,24 @@ __device__ __forceinline__ int csr_find(const int64_t *__restrict__ off, int n, 
     return lo;
 }
 
+// Kernels that tile the concatenated sample axis call this first: it finds the notes of the block's
+// first and last sample.  When they coincide (almost always: a note is ~190 blocks long) the caller
+// runs its body with that index held in an SGPR, so every per-note load behind it (offsets, params,
+// constants) is a scalar load instead of a chain of dependent per-lane vector loads.
+__device__ __forceinline__ void block_note_range(const int64_t *__restrict__ off, int n_notes, int64_t g0, int64_t total,
+                                                 int *s_pair, int &lo, int &hi)
+{
+    if (threadIdx.x == 0) {
+        s_pair[0] = csr_find(off, n_notes, g0);
+        int64_t gl = g0 + blockDim.x - 1;
+        if (gl > total - 1) gl = total - 1;
+        s_pair[1] = csr_find(off, n_notes, gl);
+    }
+    __syncthreads();
+    lo = __builtin_amdgcn_readfirstlane(s_pair[0]);
+    hi = __builtin_amdgcn_readfirstlane(s_pair[1]);
+}
+
 __device__ __forceinline__ void wave_lds_sync()
 {
     // LDS ops of one wave complete in issue order; this only stops the compiler reordering
@@ -101,6 +119,17 @@ __device__ __forceinline__ float wave_max(float v)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// ~1e-16-accurate reciprocal (v_rcp_f64 + two Newton steps), used where the reference divides but
+// the quotient only positions or scales a continuous interpolant (the fp32 result is unaffected
+// except in knife-edge roundings)
+__device__ __forceinline__ double fast_rcp(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
 }
 
 // atomic max on a non-negative float through its bit pattern

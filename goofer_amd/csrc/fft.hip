@@ -285,37 +285,45 @@ __global__ __launch_bounds__(256) void k_irfft_frames(const float2 *__restrict__
 __global__ __launch_bounds__(256) void k_ola_gather(const float *__restrict__ frames, const float *__restrict__ win_sq,
                                                     const int64_t *__restrict__ sample_off, const int64_t *__restrict__ frame_off,
                                                     int n_notes, int64_t total_samples, int n_fft, int hop,
-                                                    float *__restrict__ y, const float *__restrict__ inv_scale)
+                                                    float *__restrict__ y, const float *__restrict__ divisor)
 {
-    __shared__ int s_lo;
+    __shared__ int s_pair[2];
     const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
-    if (threadIdx.x == 0) s_lo = csr_find(sample_off, n_notes, g0);
-    __syncthreads();
+    int lo_n, hi_n;
+    block_note_range(sample_off, n_notes, g0, total_samples, s_pair, lo_n, hi_n);
     const int64_t g = g0 + threadIdx.x;
     if (g >= total_samples) return;
-    int note = s_lo;
-    while (sample_off[note + 1] <= g) ++note;
-    const int64_t i = g - sample_off[note];
-    const int64_t fbase = frame_off[note];
-    const int64_t T = frame_off[note + 1] - fbase;
-    float out = 0.f;
-    if (i < (int64_t)hop * (T - 1)) {
-        const int64_t p = i + n_fft / 2;
-        int64_t lo = p - n_fft + 1;
-        lo = lo <= 0 ? 0 : (lo + hop - 1) / hop;
-        int64_t hi = p / hop;
-        if (hi > T - 1) hi = T - 1;
-        float acc = 0.f, ws = 0.f;
-        for (int64_t fr = lo; fr <= hi; ++fr) {
-            int j = (int)(p - fr * hop);
-            acc += frames[(fbase + fr) * n_fft + j];
-            ws += win_sq[j];
+
+    auto body = [&](int note) {
+        const int64_t i = g - sample_off[note];
+        const int64_t fbase = frame_off[note];
+        const int64_t T = frame_off[note + 1] - fbase;
+        float out = 0.f;
+        if (i < (int64_t)hop * (T - 1)) {
+            const int64_t p = i + n_fft / 2;
+            int64_t lo = p - n_fft + 1;
+            lo = lo <= 0 ? 0 : (lo + hop - 1) / hop;
+            int64_t hi = p / hop;
+            if (hi > T - 1) hi = T - 1;
+            float acc = 0.f, ws = 0.f;
+            for (int64_t fr = lo; fr <= hi; ++fr) {
+                int j = (int)(p - fr * hop);
+                acc += frames[(fbase + fr) * n_fft + j];
+                ws += win_sq[j];
+            }
+            if (ws > 1e-9f) acc /= ws;
+            out = acc;
+            if (divisor) out = out / divisor[note];
         }
-        if (ws > 1e-9f) acc /= ws;
-        out = acc;
-        if (inv_scale) out = out / inv_scale[note];
+        y[g] = out;
+    };
+    if (lo_n == hi_n) {
+        body(lo_n);
+    } else {
+        int note = lo_n;
+        while (sample_off[note + 1] <= g) ++note;
+        body(note);
     }
-    y[g] = out;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -75,83 +75,209 @@ struct onset_t {
     double T;         // period used for the shape
 };
 
-// One lane per note.  cap_off[note] = first slot of the note's onset list; capacity = cap_off[note+1]-cap_off[note].
-__global__ __launch_bounds__(64) void k_pulse_onsets(const float *__restrict__ f0, float f0_scale, const double *__restrict__ inc,
-                                                     const int64_t *__restrict__ sample_off, int n_notes, double sr,
-                                                     onset_t *__restrict__ onsets, int32_t *__restrict__ onset_cnt,
-                                                     int32_t *__restrict__ overflow)
+// One wave per note.  The walk itself is wave-uniform (every lane carries the same phase), which lets
+// the memory side be fully parallel: the wave fetches 512-sample chunks of increments with coalesced
+// vector loads (next chunk prefetched into registers while the current one is walked), parks them in
+// LDS, and reads them back as uniform 16-byte broadcasts.  A lone wave issues roughly one instruction
+// per 4 cycles whatever its kind, so the hot loop is kept minimal: per 16 samples 8 LDS reads, 16
+// dependent v_add_f64, one compare and one branch.  The 16 partial sums ARE the reference's
+// sequential phases (same additions, same order: GOOFER.py:491), so onsets are bit-exact.
+// Increments are >= 0 in practice, so a block of 16 can only contain an onset if its last partial
+// sum reaches next_k; the per-sample checks (the reference's `while`) run only then, and only record
+// the sample index.  A negative increment anywhere in the chunk (found in parallel at fetch time)
+// forces the per-sample checks for every block of that chunk.  Zero padding of the last chunk adds
+// +0.0, which leaves the phase unchanged.  T0, the period and the look-back bound of every onset are
+// filled in afterwards, in parallel, by k_onset_finish.
+#define OC 512   // samples per chunk (64 lanes x 8)
+#define OB 16    // samples per walk block
+
+// Placement: a workgroup is 4 waves = 4 notes (one per SIMD of a CU), and the launcher pads the
+// dynamic LDS request so that only ceil(blocks/256) workgroups fit on a CU — otherwise the dispatcher
+// packs many of these latency-bound waves onto a few CUs and they time-slice one SIMD.
+__global__ __launch_bounds__(256) void k_pulse_onsets(const double *__restrict__ inc, const int64_t *__restrict__ sample_off,
+                                                      int n_notes, int32_t *__restrict__ onset_idx,
+                                                      int32_t *__restrict__ onset_cnt, int32_t *__restrict__ overflow)
 {
-    int note = blockIdx.x * 64 + threadIdx.x;
-    if (note >= n_notes) return;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int note = blockIdx.x * 4 + wv;
+    if (note >= n_notes) return;                              // whole wave; no block barrier below
+    double (*tile)[OC] = reinterpret_cast<double (*)[OC]>(smem) + 2 * wv;
     const int64_t base = sample_off[note];
     const int64_t n = sample_off[note + 1] - base;
     const int64_t obase = base / 2 + 16 * (int64_t)note;
-    const int64_t cap = (sample_off[note + 1] / 2 + 16 * (int64_t)(note + 1)) - obase;
-    const float *f = f0 + base;
-    const double *a = inc + base;
-    double phase = 0.0, next_k = 1.0, last = 160.0;
-    int32_t cnt = 0, end_max = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        float fi = f[i] * f0_scale;
-        if (fi > 1e-6f) last = (double)fi;
-        phase += a[i];
-        while (phase >= next_k) {
-            double T = 1.0 / fmax(last, 1e-6);
-            long T0 = (long)rint(sr * T);       // round-half-even, like Python round()
-            T0 = T0 < 3 ? 3 : (T0 > 8192 ? 8192 : T0);
-            if (cnt < cap) {
-                int32_t e = (int32_t)i + (int32_t)T0;
-                end_max = e > end_max ? e : end_max;
-                onset_t o;
-                o.i = (int32_t)i; o.T0 = (int32_t)T0; o.end_max = end_max; o.pad = 0; o.T = T;
-                onsets[obase + cnt] = o;
-            } else {
-                *overflow = 1;
+    const int32_t cap = (int32_t)((sample_off[note + 1] / 2 + 16 * (int64_t)(note + 1)) - obase);
+    const double *__restrict__ a = inc + base;
+    int32_t *__restrict__ out = onset_idx + obase;
+    double phase = 0.0, next_k = 1.0;
+    int32_t cnt = 0;
+
+    double r[8];
+    // NOTE the branch is wave-uniform on purpose: a per-lane if/else writing the same registers makes
+    // the compiler drain vmcnt(0) between the two arms, i.e. right after issuing the prefetch.
+    auto fetch = [&](int64_t c0) {
+        const int64_t s = c0 + (int64_t)lane * 8;
+        if (c0 + OC <= n) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] = a[s + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t i = s + k;
+                const double v = a[i < n ? i : n - 1];
+                r[k] = i < n ? v : 0.0;
             }
-            ++cnt;
-            next_k += 1.0;
+        }
+    };
+    fetch(0);
+    int buf = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += OC, buf ^= 1) {
+        double *t = tile[buf];
+        bool r_neg = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            t[lane * 8 + k] = r[k];
+            r_neg |= r[k] < 0.0;
+        }
+        const bool chunk_neg = __any(r_neg);
+        wave_lds_sync();
+        if (c0 + OC < n) fetch(c0 + OC);                    // in flight during the walk below
+        const int64_t left = n - c0;
+        const int blocks = left >= OC ? OC / OB : (int)((left + OB - 1) / OB);
+        // one walk block from registers: chain, group test, rare per-sample checks
+        auto walk = [&](const double (&x)[OB], int g) {
+            double ps[OB];
+            ps[0] = phase + x[0];
+#pragma unroll
+            for (int k = 1; k < OB; ++k) ps[k] = ps[k - 1] + x[k];
+            phase = ps[OB - 1];
+            if (__any((phase >= next_k) || chunk_neg)) {     // wave-uniform: every lane holds the same phase
+                const int32_t i0 = (int32_t)c0 + g * OB;
+#pragma unroll
+                for (int j = 0; j < OB; ++j) {
+                    while (__any(ps[j] >= next_k)) {
+                        if (cnt < cap) {
+                            if (lane == 0) out[cnt] = i0 + j;
+                        } else if (lane == 0) {
+                            *overflow = 1;
+                        }
+                        ++cnt;
+                        next_k += 1.0;
+                    }
+                }
+            }
+        };
+        auto load = [&](double (&x)[OB], int g) {
+            const double *q = t + (g < blocks ? g : blocks - 1) * OB;
+#pragma unroll
+            for (int k = 0; k < OB; ++k) x[k] = q[k];
+        };
+        // ping-pong two register sets: the LDS broadcasts of block g+1 are in flight during block g's adds
+        double xa[OB], xb[OB];
+        load(xa, 0);
+#pragma unroll 1
+        for (int g = 0; g < blocks; g += 2) {
+            load(xb, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            walk(xa, g);
+            load(xa, g + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < blocks) walk(xb, g + 1);
         }
     }
-    onset_cnt[note] = cnt < cap ? cnt : (int32_t)cap;
+    if (lane == 0) onset_cnt[note] = cnt < cap ? cnt : cap;
+}
+
+// One wave per note, lanes over onsets: T = 1/max(last_valid_f0, 1e-6) with last_valid_f0 the most
+// recent f0 > 1e-6 at or before the onset sample (160 Hz before any), T0 = clip(round_half_even(sr*T),
+// 3, 8192) (GOOFER.py:488-499), and end_max = running max of (sample + T0) in onset order (the bound
+// k_pulse_place uses to stop its look-back).
+__global__ __launch_bounds__(64) void k_onset_finish(const float *__restrict__ f0, const int64_t *__restrict__ sample_off,
+                                                     int n_notes, double sr, const int32_t *__restrict__ onset_idx,
+                                                     const int32_t *__restrict__ onset_cnt, onset_t *__restrict__ onsets)
+{
+    const int note = blockIdx.x, lane = threadIdx.x;
+    const int64_t base = sample_off[note];
+    const int64_t obase = base / 2 + 16 * (int64_t)note;
+    const float *__restrict__ f = f0 + base;
+    const int cnt = onset_cnt[note];
+    int32_t carry = 0;
+    for (int k0 = 0; k0 < cnt; k0 += WAVE) {
+        const int k = k0 + lane;
+        int32_t i = 0, T0 = 0, e = 0;
+        double T = 0.0;
+        if (k < cnt) {
+            i = onset_idx[obase + k];
+            int64_t b = i;
+            while (b >= 0 && !(f[b] > 1e-6f)) --b;
+            const double last = b >= 0 ? (double)f[b] : 160.0;
+            T = 1.0 / fmax(last, 1e-6);
+            long t0 = (long)rint(sr * T);                    // round-half-even, like Python round()
+            T0 = (int32_t)(t0 < 3 ? 3 : (t0 > 8192 ? 8192 : t0));
+            e = i + T0;
+        }
+        // inclusive prefix max across the wave, then across chunks
+        int32_t m = e;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            int32_t o = __shfl_up(m, off, WAVE);
+            if (lane >= off) m = o > m ? o : m;
+        }
+        m = m > carry ? m : carry;
+        if (k < cnt) {
+            onset_t o;
+            o.i = i; o.T0 = T0; o.end_max = m; o.pad = 0; o.T = T;
+            onsets[obase + k] = o;
+        }
+        carry = __shfl(m, WAVE - 1, WAVE);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__ onsets, const int32_t *__restrict__ onset_cnt,
                                                      const float *__restrict__ peak, const int64_t *__restrict__ sample_off,
                                                      int n_notes, int64_t total_samples, float *__restrict__ pulse)
 {
-    __shared__ int s_lo;
+    __shared__ int s_pair[2];
     const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
-    if (threadIdx.x == 0) s_lo = csr_find(sample_off, n_notes, g0);
-    __syncthreads();
+    int lo_n, hi_n;
+    block_note_range(sample_off, n_notes, g0, total_samples, s_pair, lo_n, hi_n);
     const int64_t g = g0 + threadIdx.x;
     if (g >= total_samples) return;
-    int note = s_lo;
-    while (sample_off[note + 1] <= g) ++note;
-    const int32_t j = (int32_t)(g - sample_off[note]);
-    const onset_t *ol = onsets + (sample_off[note] / 2 + 16 * (int64_t)note);
-    const int cnt = onset_cnt[note];
-    float acc = 0.f;
-    // last onset with i <= j
-    int lo = -1, hi = cnt;   // ol[lo].i <= j < ol[hi].i
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (ol[mid].i <= j) lo = mid; else hi = mid;
-    }
-    if (lo >= 0) {
-        int first = lo;
-        while (first > 0 && ol[first - 1].end_max > j) --first;
-        for (int k = first; k <= lo; ++k) {
-            onset_t o = ol[k];
-            int d = j - o.i;
-            if (d < o.T0) {
-                float raw = lf_raw(d, o.T0, o.T);
-                double m = (double)peak[o.T0];
-                float v = m > 0.0 ? (float)((double)raw / m) : raw;
-                acc += v;
+
+    auto body = [&](int note) {
+        const int64_t base = sample_off[note];
+        const int32_t j = (int32_t)(g - base);
+        const onset_t *ol = onsets + (base / 2 + 16 * (int64_t)note);
+        const int cnt = onset_cnt[note];
+        float acc = 0.f;
+        int lo = -1, hi = cnt;   // last onset with i <= j:  ol[lo].i <= j < ol[hi].i
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (ol[mid].i <= j) lo = mid; else hi = mid;
+        }
+        if (lo >= 0) {
+            int first = lo;
+            while (first > 0 && ol[first - 1].end_max > j) --first;
+            for (int k = first; k <= lo; ++k) {
+                onset_t o = ol[k];
+                int d = j - o.i;
+                if (d < o.T0) {
+                    float raw = lf_raw(d, o.T0, o.T);
+                    double m = (double)peak[o.T0];
+                    float v = m > 0.0 ? (float)((double)raw / m) : raw;
+                    acc += v;
+                }
             }
         }
+        pulse[g] = acc;
+    };
+    if (lo_n == hi_n) {
+        body(lo_n);
+    } else {
+        int note = lo_n;
+        while (sample_off[note + 1] <= g) ++note;
+        body(note);
     }
-    pulse[g] = acc;
 }
 
 int launch_phase_inc(goofer_ctx *ctx, const float *f0, float f0_scale, int64_t total_samples, double *inc, hipStream_t st)
@@ -164,11 +290,27 @@ int launch_phase_inc(goofer_ctx *ctx, const float *f0, float f0_scale, int64_t t
 }
 
 int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const double *inc, const int64_t *sample_off,
-                        int n_notes, onset_t *onsets, int32_t *onset_cnt, int32_t *overflow, hipStream_t st)
+                        int n_notes, onset_t *onsets, int32_t *onset_idx, int32_t *onset_cnt, int32_t *overflow, hipStream_t st)
 {
     if (n_notes <= 0) return GOOFER_OK;
-    hipLaunchKernelGGL(k_pulse_onsets, dim3((n_notes + 63) / 64), dim3(64), 0, st, f0, f0_scale, inc, sample_off, n_notes,
-                       (double)ctx->plan.sr, onsets, onset_cnt, overflow);
+    if (f0_scale != 1.0f) return goofer_fail(ctx, GOOFER_EINVAL, "pulse onsets expect pre-scaled f0");
+    {
+        const int blocks = (n_notes + 3) / 4;
+        const int per_cu = (blocks + 255) / 256;              // MI355X: 256 CUs, 160 KiB LDS each
+        size_t lds = (size_t)(160 * 1024) / per_cu;
+        lds = lds / 1024 * 1024;
+        const size_t need = 4 * 2 * OC * sizeof(double);      // 32 KiB actually used
+        if (lds < need) lds = need;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_pulse_onsets, dim3(blocks), dim3(256), lds, st, inc, sample_off, n_notes, onset_idx, onset_cnt, overflow);
+        LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(k_onset_finish, dim3(n_notes), dim3(64), 0, st, f0, sample_off, n_notes, (double)ctx->plan.sr, onset_idx,
+                       onset_cnt, onsets);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
@@ -184,12 +326,12 @@ int launch_pulse_place(goofer_ctx *ctx, const onset_t *onsets, const int32_t *on
 }
 
 int launch_pulse_train(goofer_ctx *ctx, const float *f0, float f0_scale, const int64_t *sample_off, int n_notes,
-                       int64_t total_samples, float *pulse, double *inc, onset_t *onsets, int32_t *onset_cnt,
+                       int64_t total_samples, float *pulse, double *inc, onset_t *onsets, int32_t *onset_idx, int32_t *onset_cnt,
                        int32_t *overflow, hipStream_t st)
 {
     if (total_samples <= 0 || n_notes <= 0) return GOOFER_OK;
     int rc;
     if ((rc = launch_phase_inc(ctx, f0, f0_scale, total_samples, inc, st))) return rc;
-    if ((rc = launch_pulse_onsets(ctx, f0, f0_scale, inc, sample_off, n_notes, onsets, onset_cnt, overflow, st))) return rc;
+    if ((rc = launch_pulse_onsets(ctx, f0, f0_scale, inc, sample_off, n_notes, onsets, onset_idx, onset_cnt, overflow, st))) return rc;
     return launch_pulse_place(ctx, onsets, onset_cnt, sample_off, n_notes, total_samples, pulse, st);
 }
