@@ -98,8 +98,10 @@ def main():
     from goofer_amd.device import Context
     from goofer_amd.workload import SynthWorkload
 
+    from goofer_amd.shard import note_range, reduce_timing
+
     ctx = Context(local)
-    ids = range(rank * args.notes, (rank + 1) * args.notes)
+    ids = note_range(rank, world, args.notes)
     wl = SynthWorkload(ctx, args.config, ids)
     geo = wl.geo
     B, hop, n_fft, sr = geo["n_fft"] // 2 + 1, geo["hop"], geo["n_fft"], geo["sr"]
@@ -121,14 +123,7 @@ def main():
     barrier()
     elapsed = t1 - t0
     prof = ctx.profile_end()
-    frames_total = wl.frames
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        f = torch.tensor([wl.frames], dtype=torch.float64, device="cuda")
-        dist.all_reduce(f, op=dist.ReduceOp.SUM)
-        frames_total = int(f.item())
+    elapsed, frames_total = reduce_timing(elapsed, wl.frames, device="cuda")
 
     if rank == 0:
         value = frames_total * args.steps / elapsed
