@@ -22,6 +22,33 @@ NOTE_PARAMS = np.dtype({
 })
 
 
+# numpy mirror of goofer_note_plan (align=True reproduces the C layout; checked against goofer_sizeof)
+NOTE_PLAN = np.dtype([
+    ("knot_off", "<i8"), ("edit_off", "<i8"), ("tap_off", "<i8"), ("env_off", "<i8"), ("src_sample_off", "<i8"),
+    ("out_sample_off", "<i8"), ("ylen", "<i8"), ("bend_off", "<i8"),
+    ("es_amount", "<f8"), ("vel_factor", "<f8"), ("pitch_m", "<f8"), ("pitch_t", "<f8"), ("tick_dt", "<f8"),
+    ("fst", "<f8", 4),
+    ("K", "<i4"), ("lerp_plan", "<i4"), ("n_src_rows", "<i4"), ("reverse", "<i4"), ("row_lo", "<i4"), ("n_edit", "<i4"),
+    ("tilt", "<i4"), ("es_mode", "<i4"), ("es_taps_off", "<i4"), ("es_radius", "<i4"), ("fw_plan", "<i4"),
+    ("n_out_rows", "<i4"), ("env_f64", "<i4"), ("n_out", "<i4"), ("n_pre", "<i4"), ("s_pre", "<i4"), ("s_tail", "<i4"),
+    ("tail_len", "<i4"), ("want_samples", "<i4"), ("n_before_vel", "<i4"), ("pre_new", "<i4"), ("vel_active", "<i4"),
+    ("force_voiced", "<i4"), ("n_bend", "<i4"), ("reserved", "<i4"),
+], align=True)
+
+
+class Assembly(C.Structure):
+    """goofer_assembly"""
+    _fields_ = [
+        ("n_notes", C.c_int32), ("n_bins", C.c_int32), ("ld", C.c_int32), ("sr", C.c_int32), ("max_K", C.c_int32),
+        ("reserved", C.c_int32),
+        ("total_edit_rows", C.c_int64), ("total_out_rows", C.c_int64), ("total_samples", C.c_int64),
+        ("notes", C.c_void_p), ("knots", C.c_void_p), ("lerp_idx", C.c_void_p), ("lerp_w0", C.c_void_p), ("lerp_w1", C.c_void_p),
+        ("tilts", C.c_void_p), ("es_taps", C.c_void_p), ("fw_lo", C.c_void_p), ("fw_hi", C.c_void_p), ("fw_frac", C.c_void_p),
+        ("tap_idx", C.c_void_p), ("tap_w", C.c_void_p), ("fst_tracks", C.c_void_p), ("mask_src", C.c_void_p), ("bend", C.c_void_p),
+        ("edit_rows", C.c_void_p), ("env_out", C.c_void_p), ("f0_out", C.c_void_p), ("mask_out", C.c_void_p),
+    ]
+
+
 class Batch(C.Structure):
     """goofer_batch"""
     _fields_ = [
@@ -57,6 +84,8 @@ EXPORTS = {
     "goofer_synth_batch": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_void_p]),
     "goofer_debug_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "goofer_debug_fetch": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "goofer_sizeof": (C.c_int, [C.c_int]),
+    "goofer_assemble_batch": (C.c_int, [C.c_void_p, C.POINTER(Assembly), C.c_void_p]),
     "goofer_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "goofer_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "goofer_profile_stage_name": (C.c_char_p, [C.c_int]),

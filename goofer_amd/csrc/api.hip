@@ -32,6 +32,7 @@ int launch_noise_spectra(goofer_ctx *, float2 *, float2 *, int, int64_t, const i
                          const float *, const float *, const float *, const float *, int, const goofer_note_params *, uint64_t,
                          hipStream_t);
 int launch_mask_short(goofer_ctx *, const float *, const int64_t *, int, int64_t, const double *, int, double *, hipStream_t);
+int launch_assemble(goofer_ctx *, const goofer_assembly *, int *, int *, hipStream_t);
 int launch_stem_gains(goofer_ctx *, float *, float *, float *, const double *, const int64_t *, int, int64_t,
                       const goofer_note_params *, float *, double *, hipStream_t);
 int launch_apply_gain(goofer_ctx *, float *, float *, float *, float *, float *, const int64_t *, int, int64_t,
@@ -223,6 +224,7 @@ void goofer_destroy(goofer_ctx *ctx)
     free_plan(ctx->plan);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->small) (void)hipFree(ctx->small);
+    if (ctx->asm_scratch) (void)hipFree(ctx->asm_scratch);
     if (ctx->mask_taps) (void)hipFree(ctx->mask_taps);
     for (int i = 0; i < ctx->prof_cap * (PROF_STAGES + 1); ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
     free(ctx->prof_ev);
@@ -364,6 +366,17 @@ int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages)
 
 const char *goofer_profile_stage_name(int stage) { return stage >= 0 && stage < PROF_STAGES ? PROF_NAMES[stage] : ""; }
 
+int goofer_sizeof(int which)
+{
+    switch (which) {
+    case 0: return (int)sizeof(goofer_note_params);
+    case 1: return (int)sizeof(goofer_batch);
+    case 2: return (int)sizeof(goofer_note_plan);
+    case 3: return (int)sizeof(goofer_assembly);
+    }
+    return -1;
+}
+
 #define NEED_PLAN(ctx)                                                                    \
     if (!(ctx)) return GOOFER_EINVAL;                                                     \
     if (!(ctx)->plan.n_fft) return goofer_fail((ctx), GOOFER_ENOPLAN, "goofer_plan first")
@@ -471,6 +484,31 @@ int goofer_knot_decode(goofer_ctx *ctx, const uint16_t *knots_f16, int K, const 
     HIP_TRY(ctx, hipMemcpyAsync(d_w1, w1.data(), n_bins * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));   // the host vectors die at return
     return launch_knot_decode(ctx, knots_f16, K, rows, d_idx, d_w0, d_w1, env, n_bins, ld, st);
+}
+
+int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *asmb, void *stream)
+{
+    if (!ctx || !asmb) return GOOFER_EINVAL;
+    if (asmb->n_notes <= 0) return GOOFER_OK;
+    if (asmb->ld < asmb->n_bins || asmb->max_K < 2 || asmb->max_K > 4096) return goofer_fail(ctx, GOOFER_EINVAL, "bad assembly geometry");
+    hipStream_t st = (hipStream_t)stream;
+    goofer_assembly a = *asmb;
+    size_t map_bytes = ((size_t)(a.total_edit_rows + a.total_out_rows) * sizeof(int) + 511) & ~(size_t)255;
+    size_t rows_bytes = a.edit_rows ? 0 : (size_t)a.total_edit_rows * a.ld * sizeof(float);
+    size_t need = map_bytes + rows_bytes + 4096;
+    if (ctx->asm_bytes < need) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        if (ctx->asm_scratch) HIP_TRY(ctx, hipFree(ctx->asm_scratch));
+        ctx->asm_scratch = nullptr;
+        ctx->asm_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->asm_scratch, need);
+        if (e != hipSuccess) return goofer_fail(ctx, GOOFER_ENOMEM, "assembly scratch hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+        ctx->asm_bytes = need;
+    }
+    int *map_edit = (int *)ctx->asm_scratch;
+    int *map_out = map_edit + a.total_edit_rows;
+    if (!a.edit_rows) a.edit_rows = (float *)((char *)ctx->asm_scratch + map_bytes);
+    return launch_assemble(ctx, &a, map_edit, map_out, st);
 }
 
 int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)

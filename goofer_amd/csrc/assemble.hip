@@ -1,0 +1,277 @@
+// Note assembly on the device — executes the plans of goofer_amd/sampler.py (SillySampler.resample).
+//
+//   k_env_edit         knot decode + br tilt + es smooth/sharpen + fw width warp on the source rows a note
+//                      uses                                 GOOFER.py:149-168, SillySampler.py:502-574
+//   k_env_loop         4-tap frame gather (slicing, L0 cross-fades / L1 mirror mean / L2 stretch, velocity
+//                      prefix stretch) + formant-strength gain bells
+//                                                           SillySampler.py:625-696, 765-773, 791-833
+//   k_sample_assemble  per-sample voicing mask (slice, tile, reverse, force-voiced, velocity stretch) and
+//                      pitch curve -> f0                    SillySampler.py:698-712, 787-788, 835-855
+// One wave per row for the matrix kernels (row staged in LDS), one thread per sample for the last.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+constexpr int A_ROWS = 4;   // rows (waves) per workgroup
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64_t total_edit_rows, const int *__restrict__ row_note)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int B = a.n_bins;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t er = (int64_t)blockIdx.x * A_ROWS + wave;
+    if (er >= total_edit_rows) return;                       // no block barrier below
+    const int stride = (3 * B + a.max_K + 3) & ~3;            // floats per wave, 16-byte multiple
+    double *tmp = reinterpret_cast<double *>(reinterpret_cast<float *>(smem) + (size_t)wave * stride);   // [B] fp64 scratch
+    float *row = reinterpret_cast<float *>(tmp + B);          // [B] current row
+    float *kv = row + B;                                      // [max_K] decoded knot values
+    const int note = row_note[er];
+    const goofer_note_plan p = a.notes[note];
+    const int r = (int)(er - p.edit_off);                     // index inside the note's edited window
+    const int logical = p.row_lo + r;
+    const int phys = p.reverse ? p.n_src_rows - 1 - logical : logical;
+
+    // 1. knot decode (2-tap lerp in the log domain + exp)     GOOFER.py:164-165
+    const __half *kn = reinterpret_cast<const __half *>(a.knots) + p.knot_off + (int64_t)phys * p.K;
+    for (int k = lane; k < p.K; k += WAVE) kv[k] = __half2float(kn[k]);
+    wave_lds_sync();
+    const int *li = a.lerp_idx + (int64_t)p.lerp_plan * B;
+    const float *l0 = a.lerp_w0 + (int64_t)p.lerp_plan * B, *l1 = a.lerp_w1 + (int64_t)p.lerp_plan * B;
+    const float *tilt = p.tilt >= 0 ? a.tilts + (int64_t)p.tilt * B : nullptr;
+    for (int b = lane; b < B; b += WAVE) {
+        int i = li[b];
+        float v = expf(l0[b] * kv[i] + l1[b] * kv[i + 1]);
+        if (tilt) v *= tilt[b];                               // 2. br: env *= tilt (fp32)   :513-515
+        row[b] = v;
+    }
+    wave_lds_sync();
+
+    // 3. es: smooth (blur, rematch frame mean, clamp) or sharpen (unsharp, clamp, rematch)   :517-551
+    if (p.es_mode) {
+        const double *taps = a.es_taps + p.es_taps_off;
+        const int rad = p.es_radius;
+        double s_src = 0.0, s_mod = 0.0;
+        for (int b = lane; b < B; b += WAVE) {
+            double acc = 0.0;
+            for (int j = 0; j <= 2 * rad; ++j) acc += taps[j] * (double)row[reflect_index(b + j - rad, B)];
+            double src = (double)row[b];
+            double mod = p.es_mode == 1 ? acc : fmax(0.0, src + p.es_amount * (src - acc));
+            tmp[b] = mod;
+            s_src += src;
+            s_mod += mod;
+        }
+        s_src = wave_sum(s_src);
+        s_mod = wave_sum(s_mod);
+        const float m0 = (float)(s_src / (double)B);          // np.mean of the fp32 block row -> fp32
+        const double scale = (double)m0 / (s_mod / (double)B + 1e-12);
+        wave_lds_sync();
+        for (int b = lane; b < B; b += WAVE) {
+            float v = (float)(tmp[b] * scale);
+            row[b] = p.es_mode == 1 ? fmaxf(0.0f, v) : v;
+        }
+        wave_lds_sync();
+    }
+
+    // 4. fw: affine stretch of the bin axis about its centre, linear interpolation   :553-574
+    float *out = a.edit_rows + er * (int64_t)a.ld;
+    if (p.fw_plan >= 0) {
+        const int *lo = a.fw_lo + (int64_t)p.fw_plan * B, *hi = a.fw_hi + (int64_t)p.fw_plan * B;
+        const double *fr = a.fw_frac + (int64_t)p.fw_plan * B;
+        for (int b = lane; b < B; b += WAVE) out[b] = (float)((1.0 - fr[b]) * (double)row[lo[b]] + fr[b] * (double)row[hi[b]]);
+    } else {
+        for (int b = lane; b < B; b += WAVE) out[b] = row[b];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64_t total_out_rows, const int *__restrict__ row_note)
+{
+    const int B = a.n_bins;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t orow = (int64_t)blockIdx.x * A_ROWS + wave;
+    if (orow >= total_out_rows) return;
+    const int note = row_note[orow];
+    const goofer_note_plan p = a.notes[note];
+    const int64_t t = orow - p.env_off;
+    const int32_t *ti = a.tap_idx + (p.tap_off + t) * 4;
+    const double *tw = a.tap_w + (p.tap_off + t) * 4;
+    const float *src[4];
+    double w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        w[k] = tw[k];
+        src[k] = a.edit_rows + (p.edit_off + (ti[k] - p.row_lo)) * (int64_t)a.ld;
+    }
+    // formant-strength bells for this frame                    SillySampler.py:817-830
+    float Fk[4];
+    double sv[4];
+    bool on[4];
+    const float nyq = (float)((double)a.sr * 0.5);
+    const float sig[4] = {100.0f, 200.0f, 350.0f, 500.0f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sv[k] = p.fst[k];
+        Fk[k] = a.fst_tracks[(p.env_off + t) * 4 + k];
+        on[k] = !(fabs(sv[k]) < 1e-6) && isfinite(Fk[k]) && !(Fk[k] <= 50.0f) && !(Fk[k] >= nyq);
+    }
+    const double fstep = ((double)a.sr / 2.0) / (double)(B - 1);
+    float *out = a.env_out + orow * (int64_t)a.ld;
+    for (int b = lane; b < B; b += WAVE) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (w[k] != 0.0) v += w[k] * (double)src[k][b];
+        float gain = 1.0f;
+        const float fb = (float)(b >= B - 1 ? (double)a.sr / 2.0 : (double)b * fstep);    // np.linspace(0, sr/2, B) as fp32
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (on[k]) {
+                float z = (fb - Fk[k]) / sig[k];
+                float wt = expf(-0.5f * (z * z));
+                float gk = (float)((1.0 + sv[k]) - 1.0);            // python-float (gain - 1.0), weak-cast to fp32
+                gain *= 1.0f + gk * wt;
+            }
+        }
+        out[b] = p.env_f64 ? (float)(v * (double)gain) : ((float)v) * gain;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// source mask value at index q of the (possibly reversed) source, before tiling
+__device__ __forceinline__ double mask_src(const float *__restrict__ m, const goofer_note_plan &p, int64_t idx)
+{
+    if (p.force_voiced) return 1.0;
+    return (double)m[p.reverse ? p.ylen - 1 - idx : idx];
+}
+
+// mask of the assembled note BEFORE the velocity stretch, at index q in [0, n_before_vel)
+__device__ __forceinline__ double mask_stage1(const float *__restrict__ m, const goofer_note_plan &p, int64_t q)
+{
+    if (q < p.n_pre) return mask_src(m, p, p.s_pre + q);
+    int64_t k = q - p.n_pre;
+    if (p.tail_len < p.want_samples) k = k % p.tail_len;
+    return mask_src(m, p, p.s_tail + k);
+}
+
+__global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a, int64_t total_samples)
+{
+    __shared__ int s_pair[2];
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    if (threadIdx.x == 0) {
+        // notes own [out_sample_off, out_sample_off + n_out): find by binary search over the plan array
+        auto find = [&](int64_t g) {
+            int lo = 0, hi = a.n_notes;
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (a.notes[mid].out_sample_off <= g) lo = mid; else hi = mid;
+            }
+            return lo;
+        };
+        s_pair[0] = find(g0);
+        int64_t gl = g0 + blockDim.x - 1;
+        if (gl > total_samples - 1) gl = total_samples - 1;
+        s_pair[1] = find(gl);
+    }
+    __syncthreads();
+    const int64_t g = g0 + threadIdx.x;
+    if (g >= total_samples) return;
+    int note = s_pair[0];
+    while (note + 1 < a.n_notes && a.notes[note + 1].out_sample_off <= g) ++note;
+    const goofer_note_plan p = a.notes[note];
+    const int64_t i = g - p.out_sample_off;
+    const float *m = a.mask_src + p.src_sample_off;
+
+    // voicing mask: direct, or np.interp over the pre-velocity sequence at old_pos   :176-187, 787-788
+    double mk;
+    if (p.vel_active) {
+        double pos = i < p.pre_new ? (double)i / p.vel_factor : (double)(i - p.pre_new) + (double)p.n_pre;
+        int64_t n1 = p.n_before_vel;
+        int64_t j = (int64_t)floor(pos);
+        if (j > n1 - 1) j = n1 - 1;
+        if (j < 0) j = 0;
+        if (j >= n1 - 1) {
+            mk = mask_stage1(m, p, n1 - 1);
+        } else {
+            double y0 = mask_stage1(m, p, j), y1 = mask_stage1(m, p, j + 1);
+            mk = pos == (double)j ? y0 : (y1 - y0) * (pos - (double)j) + y0;
+        }
+    } else {
+        mk = mask_stage1(m, p, i);
+    }
+
+    // pitch curve: bend cents/100 + MIDI (+t), ticks of 60/(tempo*96) s, clamped linear interpolation
+    const float *bend = a.bend + p.bend_off;
+    double tsec = (double)i / (double)a.sr;
+    const double t_last = (double)(p.n_bend - 1) * p.tick_dt;
+    tsec = tsec < 0.0 ? 0.0 : (tsec > t_last ? t_last : tsec);
+    double midi;
+    auto semi = [&](int64_t k) { return ((double)bend[k] / 100.0 + p.pitch_m) + p.pitch_t; };   // two adds, like the reference
+    if (p.n_bend == 1) {
+        midi = semi(0);
+    } else {
+        int64_t j = (int64_t)floor(tsec / p.tick_dt);
+        if (j > p.n_bend - 1) j = p.n_bend - 1;
+        while (j + 1 <= p.n_bend - 1 && (double)(j + 1) * p.tick_dt <= tsec) ++j;
+        while (j > 0 && (double)j * p.tick_dt > tsec) --j;
+        if (j >= p.n_bend - 1) {
+            midi = semi(p.n_bend - 1);
+        } else {
+            double y0 = semi(j), y1 = semi(j + 1);
+            double x0 = (double)j * p.tick_dt, x1 = (double)(j + 1) * p.tick_dt;
+            midi = tsec == x0 ? y0 : ((y1 - y0) / (x1 - x0)) * (tsec - x0) + y0;
+        }
+    }
+    const double hz = 440.0 * exp2((midi - 69.0) / 12.0);
+    a.mask_out[g] = (float)mk;
+    a.f0_out[g] = (float)(mk * hz);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void k_row_notes(const goofer_note_plan *__restrict__ notes, int n_notes, int64_t total_rows, int which,
+                            int *__restrict__ row_note)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= total_rows) return;
+    int lo = 0, hi = n_notes;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        int64_t off = which == 0 ? notes[mid].edit_off : notes[mid].env_off;
+        if (off <= r) lo = mid; else hi = mid;
+    }
+    row_note[r] = lo;
+}
+
+int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edit, int *row_note_out, hipStream_t st)
+{
+    const int B = a->n_bins;
+    if (a->total_edit_rows > 0) {
+        hipLaunchKernelGGL(k_row_notes, dim3((unsigned)((a->total_edit_rows + 255) / 256)), dim3(256), 0, st, a->notes, a->n_notes,
+                           a->total_edit_rows, 0, row_note_edit);
+        LAUNCH_CHECK(ctx);
+        size_t lds = (size_t)A_ROWS * ((3 * B + a->max_K + 3) & ~3) * sizeof(float);
+        hipLaunchKernelGGL(k_env_edit, dim3((unsigned)((a->total_edit_rows + A_ROWS - 1) / A_ROWS)), dim3(256), lds, st, *a,
+                           a->total_edit_rows, row_note_edit);
+        LAUNCH_CHECK(ctx);
+    }
+    if (a->total_out_rows > 0) {
+        hipLaunchKernelGGL(k_row_notes, dim3((unsigned)((a->total_out_rows + 255) / 256)), dim3(256), 0, st, a->notes, a->n_notes,
+                           a->total_out_rows, 1, row_note_out);
+        LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(k_env_loop, dim3((unsigned)((a->total_out_rows + A_ROWS - 1) / A_ROWS)), dim3(256), 0, st, *a,
+                           a->total_out_rows, row_note_out);
+        LAUNCH_CHECK(ctx);
+    }
+    if (a->total_samples > 0) {
+        hipLaunchKernelGGL(k_sample_assemble, dim3((unsigned)((a->total_samples + 255) / 256)), dim3(256), 0, st, *a, a->total_samples);
+        LAUNCH_CHECK(ctx);
+    }
+    return GOOFER_OK;
+}

@@ -33,6 +33,8 @@ struct goofer_ctx {
     // scratch (grown by ensure_scratch)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    void *asm_scratch = nullptr;  // assembly scratch: edited rows + row->note maps
+    size_t asm_bytes = 0;
     void *small = nullptr;        // small staging buffer for taps etc.
     size_t small_bytes = 0;
     // device pointers of the last synth batch's intermediates (goofer_debug_fetch; tests only)

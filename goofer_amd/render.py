@@ -1,0 +1,262 @@
+"""Batch renderer: UTAU note requests -> audio, entirely on the MI355X.
+
+``Renderer.render(jobs)`` takes any number of (source features, 13-argument request) pairs, plans them on
+the host (``sampler.plan_note``: scalars, index plans, few-hundred-value tracks), uploads the plans and
+runs two C-ABI calls: ``goofer_assemble_batch`` (SillySampler.resample up to the synthesize call) and
+``goofer_synth_batch`` (gf.synthesize + V/B/U mix).  ``GooferResampler`` keeps the reference's
+construct-to-render, one-note call surface (SillySampler.py:285-413) on top of it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import sampler as S
+from .device import Context, default_context, default_params, row_stride
+
+
+@dataclass
+class Source:
+    """Features of one voicebank sample, as stored in ``<stem>_features.goofy`` (knots mode)."""
+    knots: np.ndarray        # fp16 [K, T] log-envelope knot values (reference layout)
+    hz_knots: np.ndarray     # fp32 [K]
+    mask: np.ndarray         # fp32 [ylen] voicing mask
+    formants: dict           # {1..4: [T]} Hz
+    sr: int
+    ylen: int
+    n_fft: int = S.N_FFT
+
+    @staticmethod
+    def from_pack(env_pack, f0, mask, formants, sr, ylen):
+        if not (isinstance(env_pack, dict) and env_pack.get("mode") == "knots"):
+            raise NotImplementedError("dense ('full' mode) feature files are not on the device path yet")
+        return Source(np.asarray(env_pack["knot_vals_log"], dtype=np.float16), np.asarray(env_pack["hz_knots"], dtype=np.float32),
+                      np.asarray(mask, dtype=np.float32), formants, int(sr), int(ylen), int(env_pack["n_fft"]))
+
+
+def _lerp_plan(sr, n_fft, hz):
+    """2-tap lerp of precompute_interp_matrix (GOOFER.py:84-90) in fp32."""
+    f = np.fft.rfftfreq(n_fft, 1.0 / sr).astype(np.float32)
+    K = len(hz)
+    idx = np.clip(np.searchsorted(hz, f, side="right") - 1, 0, K - 2)
+    x0, x1 = hz[idx], hz[idx + 1]
+    w1 = ((f - x0) / np.maximum(x1 - x0, 1e-12)).astype(np.float32)
+    return idx.astype(np.int32), (1.0 - w1).astype(np.float32), w1
+
+
+def _tilt(sr, n_bins, brightness_env):
+    """br flag curve (SillySampler.py:506-510): fp64 power of an fp32 ramp, mean-normalised, cast to fp32."""
+    fr = np.linspace(1e-6, sr * 0.5, n_bins, dtype=np.float32)
+    nf = np.clip(fr / (sr * 0.5), 0.02, 1.0)
+    t = nf ** np.clip(brightness_env - 1.0, -0.9, 1.0)
+    t /= (t.mean() + 1e-12)
+    return t.astype(np.float32)
+
+
+def _fw_plan(n_bins, amount):
+    """fw flag (SillySampler.py:555-564): bins stretched about the centre, clipped; (lo, hi, frac)."""
+    bins = np.arange(n_bins, dtype=np.float64)
+    c = n_bins / 2.0
+    w = np.clip((bins - c) * (1.0 + amount) + c, 0, n_bins - 1)
+    lo = np.floor(w).astype(int)
+    return lo.astype(np.int32), np.minimum(lo + 1, n_bins - 1).astype(np.int32), (w - lo)
+
+
+class Renderer:
+    def __init__(self, ctx: Context | None = None, hop: int = S.HOP):
+        self.ctx = ctx or default_context()
+        self.hop = hop
+
+    def render(self, jobs, seed: int = 0, phi_seeds=None, return_parts: bool = False):
+        """jobs: list of (Source, Request).  Returns a list of fp32 arrays (the mix the reference writes to
+        out.wav); with ``return_parts`` also a dict of device-side intermediates for tests.
+        ``phi_seeds``: per-note seeds for INJECTED phases (parity with a seeded reference run); otherwise the
+        device draws phases from Philox keyed by ``seed`` and the note index."""
+        ctx = self.ctx
+        if not jobs:
+            return []
+        sr, n_fft = jobs[0][0].sr, jobs[0][0].n_fft
+        if any(j[0].sr != sr or j[0].n_fft != n_fft for j in jobs):
+            raise ValueError("one batch must share sr / n_fft")
+        ctx.plan(sr, n_fft, self.hop)
+        B, ld = ctx.n_bins, row_stride(ctx.n_bins)
+        n = len(jobs)
+        plans = []
+        for src, req in jobs:
+            T_src = src.knots.shape[1]
+            plans.append(S.plan_note(req, src.sr, src.ylen, T_src, src.formants, self.hop))
+
+        # tables shared across notes
+        lerp_keys, tilt_keys, fw_keys, es_keys = {}, {}, {}, {}
+        lerp_tabs, tilt_tabs, fw_tabs, es_taps, es_off = [], [], [], [], 0
+        P = np.zeros(n, dtype=_lib.NOTE_PLAN)
+        knots_cat, mask_cat, bend_cat, tapi_cat, tapw_cat, fst_cat, F_cat = [], [], [], [], [], [], []
+        k_off = e_off = t_off = s_off = o_off = b_off = 0
+        for i, ((src, req), p) in enumerate(zip(jobs, plans)):
+            K = src.knots.shape[0]
+            key = (K, src.hz_knots.tobytes())
+            if key not in lerp_keys:
+                lerp_keys[key] = len(lerp_tabs)
+                lerp_tabs.append(_lerp_plan(sr, n_fft, src.hz_knots))
+            q = P[i]
+            q["knot_off"], q["K"], q["lerp_plan"], q["n_src_rows"] = k_off, K, lerp_keys[key], src.knots.shape[1]
+            q["reverse"] = int(req.reverse)
+            q["row_lo"], q["n_edit"], q["edit_off"] = p.row_lo, p.row_hi - p.row_lo, e_off
+            q["tilt"] = -1
+            if req.brightness_env != 1.0:
+                tk = float(req.brightness_env)
+                if tk not in tilt_keys:
+                    tilt_keys[tk] = len(tilt_tabs)
+                    tilt_tabs.append(_tilt(sr, B, req.brightness_env))
+                q["tilt"] = tilt_keys[tk]
+            q["es_mode"] = 0
+            if req.env_shape != 0.0:
+                s_ = abs(req.env_shape)
+                mode = 1 if req.env_shape < 0.0 else 2
+                sigma = (1.0 + 6.0 * s_) if mode == 1 else (0.8 + 4.0 * s_)
+                ek = (mode, sigma)
+                if ek not in es_keys:
+                    taps = S.gauss_taps(sigma)
+                    es_keys[ek] = (es_off, (taps.size - 1) // 2)
+                    es_taps.append(taps)
+                    es_off += taps.size
+                q["es_mode"], q["es_amount"] = mode, 5 * s_
+                q["es_taps_off"], q["es_radius"] = es_keys[ek]
+            q["fw_plan"] = -1
+            if req.formant_width != 0.0:
+                fk = float(req.formant_width)
+                if fk not in fw_keys:
+                    fw_keys[fk] = len(fw_tabs)
+                    fw_tabs.append(_fw_plan(B, req.formant_width))
+                q["fw_plan"] = fw_keys[fk]
+            T_env = p.tap_idx.shape[0]
+            q["tap_off"], q["env_off"], q["n_out_rows"], q["env_f64"] = t_off, t_off, T_env, int(p.env_f64)
+            q["fst"] = req.formant_strength
+            q["src_sample_off"], q["ylen"], q["out_sample_off"] = s_off, src.ylen, o_off
+            q["n_out"], q["n_pre"], q["s_pre"], q["s_tail"] = p.n_out, p.n_pre, p.extra["s_pre"], p.extra["s_tail"]
+            q["tail_len"], q["want_samples"], q["n_before_vel"] = p.tail_len, p.want_samples, p.n_before_vel
+            q["vel_active"], q["vel_factor"] = int(p.vel_active), p.vel_factor
+            q["pre_new"] = max(1, int(round(p.n_pre * p.vel_factor))) if p.vel_active else p.n_pre
+            q["force_voiced"] = int(req.force_voiced)
+            q["bend_off"], q["n_bend"] = b_off, len(req.bend)
+            q["pitch_m"] = float(req.pitch_m)
+            tc = req.flags.get("t", 0)
+            q["pitch_t"] = (tc / 100.0) if tc else 0.0
+            q["tick_dt"] = 60.0 / (req.tempo * 96.0)
+            knots_cat.append(np.ascontiguousarray(src.knots.T))
+            mask_cat.append(src.mask[:src.ylen])
+            bend_cat.append(req.bend)
+            tapi_cat.append(p.tap_idx)
+            tapw_cat.append(p.tap_w)
+            fst_cat.append(p.fst_tracks)
+            F_cat.append(p.formants)
+            k_off += src.knots.size
+            e_off += p.row_hi - p.row_lo
+            t_off += T_env
+            s_off += src.ylen
+            o_off += p.n_out
+            b_off += len(req.bend)
+        if any(pl.n_out <= 0 for pl in plans):
+            raise ValueError("a note assembles to zero samples")
+
+        def cat_tab(tabs, k, dtype):
+            return ctx.tensor(np.concatenate([t[k] for t in tabs]).astype(dtype)) if tabs else None
+
+        d = dict(
+            notes=ctx.tensor(P.view(np.uint8)),
+            knots=ctx.tensor(np.concatenate([k.reshape(-1) for k in knots_cat]).view(np.uint16)),
+            lerp_idx=cat_tab(lerp_tabs, 0, np.int32), lerp_w0=cat_tab(lerp_tabs, 1, np.float32), lerp_w1=cat_tab(lerp_tabs, 2, np.float32),
+            tilts=ctx.tensor(np.concatenate(tilt_tabs)) if tilt_tabs else None,
+            es_taps=ctx.tensor(np.concatenate(es_taps)) if es_taps else None,
+            fw_lo=cat_tab(fw_tabs, 0, np.int32), fw_hi=cat_tab(fw_tabs, 1, np.int32), fw_frac=cat_tab(fw_tabs, 2, np.float64),
+            tap_idx=ctx.tensor(np.concatenate(tapi_cat).astype(np.int32)), tap_w=ctx.tensor(np.concatenate(tapw_cat)),
+            fst_tracks=ctx.tensor(np.concatenate(fst_cat).astype(np.float32)),
+            mask_src=ctx.tensor(np.concatenate(mask_cat).astype(np.float32)),
+            bend=ctx.tensor(np.concatenate(bend_cat).astype(np.float32)),
+        )
+        env = ctx.rows(t_off, B)
+        f0 = torch.empty(o_off, dtype=torch.float32, device=ctx.device)
+        mask = torch.empty(o_off, dtype=torch.float32, device=ctx.device)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        a = _lib.Assembly(n_notes=n, n_bins=B, ld=ld, sr=sr, max_K=int(max(s.knots.shape[0] for s, _ in jobs)),
+                          total_edit_rows=e_off, total_out_rows=t_off, total_samples=o_off,
+                          notes=ptr(d["notes"]), knots=ptr(d["knots"]), lerp_idx=ptr(d["lerp_idx"]), lerp_w0=ptr(d["lerp_w0"]),
+                          lerp_w1=ptr(d["lerp_w1"]), tilts=ptr(d["tilts"]), es_taps=ptr(d["es_taps"]), fw_lo=ptr(d["fw_lo"]),
+                          fw_hi=ptr(d["fw_hi"]), fw_frac=ptr(d["fw_frac"]), tap_idx=ptr(d["tap_idx"]), tap_w=ptr(d["tap_w"]),
+                          fst_tracks=ptr(d["fst_tracks"]), mask_src=ptr(d["mask_src"]), bend=ptr(d["bend"]), edit_rows=None,
+                          env_out=env.data_ptr(), f0_out=f0.data_ptr(), mask_out=mask.data_ptr())
+        ctx._check(ctx.lib.goofer_assemble_batch(ctx.h, C.byref(a), ctx._stream()))
+
+        # synthesize + mix
+        par = default_params(n)
+        for i, (_, req) in enumerate(jobs):
+            par[i]["formant_shift"] = req.formant_shift
+            par[i]["f_shift"] = req.f_shift
+            par[i]["normalize"] = req.normalize
+            par[i]["mix_harm"], par[i]["mix_breath"], par[i]["mix_unvoiced"] = req.harmonic_mix, req.breathiness_mix, req.unvoiced_mix
+            par[i]["volume"] = req.volume
+            par[i]["seed"] = [i & 0xFFFFFFFF, 0]
+        lens = [p.n_out for p in plans]
+        env_lens = [p.tap_idx.shape[0] for p in plans]
+        phi = None
+        if phi_seeds is not None:
+            mats = []
+            for p, sd in zip(plans, phi_seeds):
+                T = 1 + p.n_out // self.hop
+                mats.append(np.random.default_rng(sd).uniform(0.0, 2.0 * np.pi, size=(B, T)).astype(np.float32).T)
+            phi = ctx.rows_from(np.concatenate(mats))
+        out = ctx.synth_batch(env, env_lens, f0, mask, lens, par, formants=ctx.tensor(np.concatenate(F_cat)), phi=phi,
+                              seed=seed, want_rec=False, want_mix=True)
+        torch.cuda.synchronize(ctx.device)
+        mix = out["mix"].cpu().numpy()
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        res = [mix[offs[i]:offs[i + 1]] for i in range(n)]
+        if return_parts:
+            eo = np.concatenate([[0], np.cumsum(env_lens)])
+            parts = {"env": env, "f0": f0, "mask": mask, "env_off": eo, "sample_off": offs, "plans": plans, "stems": out, "keep": d}
+            return res, parts
+        return res
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's one-note call surface
+# ---------------------------------------------------------------------------------------------
+class GooferResampler:
+    """``GooferResampler(in_file, out_file, pitch, velocity, flags, offset, length, consonant, cutoff, volume,
+    modulation, tempo, pitch_string)`` — construction renders and writes ``out_file`` (SillySampler.py:285-413).
+
+    Needs ``<in_stem>_features.goofy`` next to the input wav (analysis of raw audio needs Praat — SURVEY §8 c).
+    wav output uses the stdlib ``wave`` module (PCM16, what soundfile's default WAV subtype writes)."""
+
+    def __init__(self, in_file, out_file, pitch, velocity, flags="", offset=0, length=1000, consonant=0, cutoff=0,
+                 volume=100, modulation=0, tempo="!120", pitch_string="AA", renderer: Renderer | None = None, seed=None):
+        from pathlib import Path
+        from . import core
+        self.in_file, self.out_file = Path(in_file), Path(out_file)
+        self.request = S.decode_request(pitch, velocity, flags, offset, length, consonant, cutoff, volume, modulation, tempo,
+                                        pitch_string)
+        feat = self.in_file.with_name(f"{self.in_file.stem}_features.goofy")
+        if not feat.exists():
+            raise FileNotFoundError(f"{feat} not found: feature extraction from raw audio needs Praat (not on the device path)")
+        env, f0, mask, forms, sr, ylen = core.load_features(feat)
+        self.source = Source.from_pack(env, f0, mask, forms, sr, ylen)
+        self.renderer = renderer or Renderer()
+        if seed is None:
+            seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
+        self.out = self.renderer.render([(self.source, self.request)], seed=seed)[0]
+        write_wav(self.out_file, self.out, sr)
+
+
+def write_wav(path, x, sr):
+    import wave
+    pcm = np.clip(np.asarray(x, dtype=np.float64), -1.0, 1.0 - 1.0 / 32768)
+    pcm = np.round(pcm * 32768.0).astype("<i2")
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(int(sr))
+        w.writeframes(pcm.tobytes())

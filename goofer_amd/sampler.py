@@ -1,0 +1,434 @@
+"""UTAU resampler front half for the MI355X backend: flag decode and note-assembly *plans*.
+
+Mirrors ``SillySampler.py``'s 13-argument call surface (``GooferResampler``, flag string, pitch-bend
+string, CLI / HTTP argument split).  The host side only does what is inherently host work: string
+decode, scalar flag scaling, and *planning* — integer cut points, per-frame gather indices with lerp
+weights, per-note formant tracks (arrays of a few hundred values).  Every ``[bins x frames]`` or
+per-sample array operation is executed on the GPU by ``goofer_assemble_batch`` + ``goofer_synth_batch``.
+
+Reference: ``SillySampler.py:50-93`` (decode), ``:286-411`` (flag scaling), ``:449-500`` (slicing),
+``:625-763`` (loop modes), ``:765-788`` (velocity), ``:791-833`` (formant strength), ``:835-855`` (pitch).
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+
+import numpy as np
+
+N_FFT = 1024            # SillySampler.py:14-15 (not settable from the CLI)
+HOP = N_FFT // 4
+VERSION = "v2.6.1-mi355x"
+
+_NOTE = re.compile(r"([A-G]#?)(-?\d+)")
+_FLAG = re.compile(r"([A-Za-z]{1,4})([+-]?\d+)?")
+_SEMI = {"C": 0, "C#": 1, "D": 2, "D#": 3, "E": 4, "F": 5, "F#": 6, "G": 7, "G#": 8, "A": 9, "A#": 10, "B": 11}
+
+# flags whose processing is not on the device yet (SURVEY.md §8 f): fail loudly instead of ignoring
+UNSUPPORTED_FLAGS = ("su", "sj", "sa", "st", "sd", "vf", "pd", "sh", "sr", "sg")
+
+
+# ---------------------------------------------------------------------------------------------
+# string decode (integer path — bit-exact)
+# ---------------------------------------------------------------------------------------------
+def parse_flags(text: str) -> dict:
+    return {k: (int(v) if v else None) for k, v in _FLAG.findall(text.replace("/", ""))}
+
+
+def _b64(c: str) -> int:
+    o = ord(c)
+    if o >= 97:
+        return o - 71
+    if o >= 65:
+        return o - 65
+    if o >= 48:
+        return o + 4
+    if o == 43:
+        return 62
+    if o == 47:
+        return 63
+    raise ValueError(f"Bad b64 '{c}'")
+
+
+def pitch_string_to_cents(text: str) -> np.ndarray:
+    vals = []
+    parts = text.split("#")
+    for i in range(0, len(parts), 2):
+        seg = parts[i]
+        for j in range(0, len(seg), 2):
+            v = (_b64(seg[j]) << 6) | _b64(seg[j + 1])
+            vals.append(v - 4096 if v & 0x800 else v)
+        if i + 1 < len(parts):
+            vals += [vals[-1]] * int(parts[i + 1])
+    a = np.array(vals, dtype=np.float32)
+    return a if a.size else np.array([0.0], dtype=np.float32)
+
+
+def note_to_midi(name: str) -> int:
+    m = _NOTE.match(name)
+    if not m:
+        raise ValueError(f"Bad note '{name}'")
+    return (int(m.group(2)) + 1) * 12 + _SEMI[m.group(1)]
+
+
+def midi_to_hz(m):
+    return 440.0 * 2 ** ((m - 69) / 12)
+
+
+def split_arguments(body: str) -> list:
+    toks = body.split(" ")
+    wavs = re.findall(r"([^\s]+\.wav)", " ".join(toks[:-11]))
+    if len(wavs) < 2:
+        raise ValueError("Missing .wav file paths in POST string")
+    return wavs[:2] + toks[-11:]
+
+
+def _ci(flags: dict, name: str, default=0):
+    return next((v for k, v in flags.items() if k.lower() == name), default)
+
+
+@dataclass
+class Request:
+    """One resampler call after flag scaling (GooferResampler.__init__)."""
+    pitch_m: int
+    velocity: float
+    flags: dict
+    offset: float
+    length: float
+    consonant: float
+    cutoff: float
+    volume: float
+    modulation: float
+    tempo: float
+    bend: np.ndarray
+    formant_shift: float = 1.0
+    brightness_env: float = 1.0
+    f_shift: tuple = (1.0, 1.0, 1.0, 1.0)
+    breathiness_mix: float = 1.0
+    unvoiced_mix: float = 1.0
+    harmonic_mix: float = 1.0
+    loop_mode: str = "concat"
+    reverse: bool = False
+    normalize: float = 1.0
+    env_shape: float = 0.0
+    force_voiced: bool = False
+    formant_width: float = 0.0
+    formant_strength: tuple = (0.0, 0.0, 0.0, 0.0)
+    use_editor: bool = False
+
+
+def decode_request(pitch, velocity, flags="", offset=0, length=1000, consonant=0, cutoff=0, volume=100,
+                   modulation=0, tempo="!120", pitch_string="AA") -> Request:
+    fl = parse_flags(flags)
+    g = fl.get
+    r = Request(pitch_m=note_to_midi(pitch), velocity=float(velocity), flags=fl, offset=float(offset) / 1000.0,
+                length=float(length) / 1000.0, consonant=float(consonant) / 1000.0, cutoff=float(cutoff) / 1000.0,
+                volume=float(volume) / 100.0, modulation=float(modulation) / 100.0, tempo=float(tempo.lstrip("!")),
+                bend=pitch_string_to_cents(pitch_string))
+    r.use_editor = _ci(fl, "se") == 1
+    r.formant_shift = 1.0 + (g("g", 0) / 200.0)                       # TypeError on a bare 'g', like the reference
+    r.brightness_env = (g("br", 0) + 100) / 100.0
+    r.f_shift = tuple(1.0 + (g(k, 0) / 100.0) for k in ("fa", "fb", "fc", "fd"))
+    r.breathiness_mix = (g("B", 0) + 100) / 100.0
+    r.unvoiced_mix = (g("U", 0) + 100) / 100.0
+    r.harmonic_mix = float(np.clip(g("V", 100), 0, 100) / 100.0)
+    lkey = next((k for k in fl if k.lower() == "l"), None)
+    r.loop_mode = {1: "avg", 2: "stretch"}.get(fl[lkey], "concat") if lkey else "concat"
+    r.reverse = g("R", 0) == 1
+    r.normalize = float(np.clip(fl["P"], 0, 100) / 100.0) if "P" in fl else 1.0
+    r.env_shape = float(np.clip(_ci(fl, "es") or 0, -100, 100)) / 100.0
+    r.force_voiced = g("FV", 0) == 1
+    r.formant_width = ((g("fw", 0) or 0) / 100.0) * 0.1
+    glob = float(np.clip(_ci(fl, "fst") or 0, -100, 100)) / 100.0
+    r.formant_strength = tuple(float(np.clip(glob + ((_ci(fl, "fst" + c) or 0) / 100.0), -1.0, 1.0)) for c in "abcd")
+    # flags that exist in the reference but are not on the device path yet: refuse, never ignore
+    for k in UNSUPPORTED_FLAGS:
+        v = _ci(fl, k) if k == "pd" else g(k, 0)
+        if v:
+            raise NotImplementedError(f"flag '{k}' is not implemented on the device path yet (SURVEY.md §8 f)")
+    g("st", 0) / 100.0                                                 # keeps the reference's TypeError on a bare 'st'
+    return r
+
+
+# ---------------------------------------------------------------------------------------------
+# planning
+# ---------------------------------------------------------------------------------------------
+def segment_indices(r: Request, sr: int, ylen: int, hop: int = HOP) -> dict:
+    """Cut points (SillySampler.py:453-487): int() truncation, // hop, negative cutoff relative to the
+    offset, R1 mirrors the window."""
+    total = ylen / sr
+    a0 = r.offset
+    b0 = (r.offset - r.cutoff) if r.cutoff < 0 else (total - r.cutoff)
+    if r.reverse:
+        L = b0 - a0
+        off = total - b0
+        cut = total - (off + L)
+    else:
+        off, cut = r.offset, r.cutoff
+    s0 = int(off * sr)
+    s1 = s0 + int(r.consonant * sr)
+    s2 = int(((off - cut) if cut < 0 else (total - cut)) * sr)
+    return {"start_sample": s0, "consonant_sample": s1, "end_sample": s2,
+            "start_frame": s0 // hop, "consonant_frame": s1 // hop, "end_frame": s2 // hop}
+
+
+def _clip_slice(a: int, b: int, n: int):
+    """Python slice semantics of x[a:b] on length n -> (start, stop) with stop >= start."""
+    s = slice(a, b).indices(n)
+    return s[0], max(s[0], s[1])
+
+
+class Taps:
+    """Sparse frame combinations: out[t] = sum_k w[t,k] * src[idx[t,k]] (k < 2 here).  ``f64`` says the
+    reference holds this frame in float64 (lerps / cross-fades) rather than float32 (copies, L1 mean)."""
+
+    def __init__(self, idx, w, f64):
+        self.idx = np.asarray(idx, dtype=np.int64).reshape(-1, 2)
+        self.w = np.asarray(w, dtype=np.float64).reshape(-1, 2)
+        self.f64 = bool(f64)
+
+    @staticmethod
+    def copy(rows):
+        rows = np.asarray(rows, dtype=np.int64)
+        return Taps(np.stack([rows, rows], 1), np.stack([np.ones(len(rows)), np.zeros(len(rows))], 1), False)
+
+    def __len__(self):
+        return self.idx.shape[0]
+
+    def __getitem__(self, sl):
+        return Taps(self.idx[sl], self.w[sl], self.f64)
+
+    @staticmethod
+    def concat(parts):
+        parts = [p for p in parts]
+        return Taps(np.concatenate([p.idx for p in parts]), np.concatenate([p.w for p in parts]),
+                    any(p.f64 for p in parts if len(p)))
+
+
+def _interp_taps(n_old: int, x_old: np.ndarray, x_new: np.ndarray):
+    """np.interp(x_new, x_old, y) as (j, j+1, 1-c, c) with c = (x - x_j)/(x_{j+1} - x_j)."""
+    j = np.clip(np.searchsorted(x_old, x_new, side="right") - 1, 0, max(n_old - 2, 0))
+    if n_old == 1:
+        z = np.zeros(len(x_new), dtype=np.int64)
+        return z, z, np.ones(len(x_new)), np.zeros(len(x_new))
+    c = (x_new - x_old[j]) / (x_old[j + 1] - x_old[j])
+    c = np.where(x_new == x_old[j], 0.0, c)
+    last = x_new >= x_old[-1]
+    j = np.where(last, n_old - 2, j)
+    c = np.where(last, 1.0, c)
+    return j, j + 1, 1.0 - c, c
+
+
+def _loop_frames(tail: Taps, want: int, mode: str) -> Taps:
+    """Tail frames extended to ``want`` frames (SillySampler.py:631-696), on the index level."""
+    n = len(tail)
+    if n >= want:
+        return tail[:want]
+    reps, rem = want // n, want % n                     # ZeroDivisionError on an empty tail, like the reference
+    rows = tail.idx[:, 0]
+    if mode == "stretch":
+        n_new = int(n * (want / n))
+        jo, j1, w0, w1 = _interp_taps(n, np.linspace(0, 1, n), np.linspace(0, 1, n_new))
+        return Taps(np.stack([rows[jo], rows[j1]], 1), np.stack([w0, w1], 1), True)
+    if mode == "avg":
+        tile = Taps(np.stack([rows, rows[::-1]], 1), np.full((n, 2), 0.5), False)
+        return Taps.concat([tile] * reps + ([tile[:rem]] if rem else []))
+    chain = [tail]
+    for _ in range(reps - 1):
+        prev = chain[-1]                                   # always a fresh, pure copy of the tail
+        k = min(8, n // 2)
+        if k == 0:
+            # numpy: prev[:, -0:] is ALL of prev and the fades are empty -> the reference's multiply fails
+            raise ValueError("operands could not be broadcast together with shapes (%d,) (0,)" % n)
+        up, dn = np.linspace(0, 1, k), np.linspace(1, 0, k)
+        mixed = Taps(np.stack([prev.idx[len(prev) - k:, 0], tail.idx[:k, 0]], 1), np.stack([dn, up], 1), True)
+        chain[-1] = Taps.concat([prev[:len(prev) - k], mixed, tail[k:]])
+        chain.append(tail)
+    if rem:
+        last, prev = tail[:rem], chain[-1]
+        k = min(8, rem // 2)
+        if k > 0:
+            up, dn = np.linspace(0, 1, k), np.linspace(1, 0, k)
+            mixed = Taps(np.stack([prev.idx[len(prev) - k:, 0], last.idx[:k, 0]], 1), np.stack([dn, up], 1), True)
+            chain[-1] = Taps.concat([prev[:len(prev) - k], mixed, last[k:]])
+        else:
+            chain[-1] = Taps.concat([prev, last])
+    return Taps.concat(chain)
+
+
+def _prefix_positions(n: int, pre_len: int, factor: float):
+    pre_new = max(1, int(round(pre_len * factor)))
+    idx = np.arange(pre_new + (n - pre_len), dtype=np.float64)
+    return np.where(idx < pre_new, idx / factor, (idx - pre_new) + pre_len)
+
+
+def _lin_interp(x, y, q, fill="extrapolate"):
+    """The reference's interp1d (GOOFER.py:173-239) for small host-side tracks."""
+    x, y, q = np.asarray(x), np.asarray(y), np.asarray(q)
+    if x.size == 1:
+        return np.full_like(q, y[0], dtype=y.dtype)
+    sl = (y[1] - y[0]) / (x[1] - x[0] + 1e-10)
+    sr_ = (y[-1] - y[-2]) / (x[-1] - x[-2] + 1e-10)
+    out = np.interp(q, x, y)
+    lo, hi = q < x[0], q > x[-1]
+    if lo.any():
+        out[lo] = y[0] + sl * (q[lo] - x[0])
+    if hi.any():
+        out[hi] = y[-1] + sr_ * (q[hi] - x[-1])
+    return out
+
+
+def gauss_taps(sigma: float, truncate: float = 4.0):
+    r = int(truncate * sigma + 0.5)
+    t = np.arange(-r, r + 1)
+    k = np.exp(-0.5 * (t / sigma) ** 2)
+    return k / k.sum()
+
+
+def _gauss_track(x, sigma):
+    """gaussian_filter1d of a short 1-D track (numpy 'reflect' padding), fp64."""
+    k = gauss_taps(sigma)
+    r = (k.size - 1) // 2
+    return np.convolve(np.pad(np.asarray(x), (r, r), mode="reflect"), k, mode="valid")
+
+
+def _sanitize_track(track, T, sr, min_hz, sigma_frames=4):
+    """SillySampler.py:264-283 incl. its aliasing: when ``track`` is already fp32 and long enough, the
+    out-of-range repair edits the caller's array in place (those repaired values reach synthesize)."""
+    max_hz = sr * 0.48
+    x = np.asarray(track, dtype=np.float32)
+    x = np.pad(x, (0, T - len(x)), mode="edge") if len(x) < T else x[:T]
+    bad = (~np.isfinite(x)) | (x < min_hz) | (x > max_hz)
+    if bad.any():
+        good = np.where(~bad)[0]
+        if good.size:
+            x[bad] = _lin_interp(good.astype(np.float32), x[~bad], np.where(bad)[0].astype(np.float32))
+        else:
+            x = np.full_like(x, 300.0)
+    return _gauss_track(x, sigma_frames).astype(np.float32)
+
+
+@dataclass
+class NotePlan:
+    req: Request
+    seg: dict
+    sr: int
+    hop: int
+    # edited source rows: rows [row_lo, row_hi) of the (possibly reversed) source envelope
+    row_lo: int = 0
+    row_hi: int = 0
+    n_src_rows: int = 0
+    # output frames: 4 taps into the edited rows (relative to row_lo)
+    tap_idx: np.ndarray = None     # int32 [T, 4]
+    tap_w: np.ndarray = None       # float64 [T, 4]
+    env_f64: bool = False
+    formants: np.ndarray = None    # float64 [T, 4] tracks handed to synthesize (after the in-place repair)
+    fst_tracks: np.ndarray = None  # float32 [T, 4] sanitised + smoothed tracks of the formant-strength gain
+    # samples
+    n_out: int = 0
+    n_pre: int = 0
+    tail_len: int = 0
+    want_samples: int = 0
+    vel_factor: float = 1.0
+    vel_active: bool = False
+    n_before_vel: int = 0
+    extra: dict = field(default_factory=dict)
+
+
+def plan_note(req: Request, sr: int, ylen: int, n_src_frames: int, formants_src: dict, hop: int = HOP) -> NotePlan:
+    """Everything ``resample`` decides before touching an array (SillySampler.py:449-833)."""
+    seg = segment_indices(req, sr, ylen, hop)
+    p = NotePlan(req=req, seg=seg, sr=sr, hop=hop, n_src_rows=n_src_frames)
+    T_src = n_src_frames
+    f0a, f0b = _clip_slice(seg["start_frame"], seg["consonant_frame"], T_src)
+    f1a, f1b = _clip_slice(seg["consonant_frame"], seg["end_frame"], T_src)
+    pre = Taps.copy(np.arange(f0a, f0b))
+    tail = Taps.copy(np.arange(f1a, f1b))
+    want_f = int(np.ceil(req.length * sr / hop))
+    tail_l = _loop_frames(tail, want_f, req.loop_mode)
+    stage1 = Taps.concat([pre, tail_l])
+    T_target = len(stage1)
+
+    # samples
+    s0a, s0b = _clip_slice(seg["start_sample"], seg["consonant_sample"], ylen)
+    s1a, s1b = _clip_slice(seg["consonant_sample"], seg["end_sample"], ylen)
+    p.n_pre, p.tail_len = s0b - s0a, s1b - s1a
+    p.want_samples = int(req.length * sr)
+    if p.tail_len < p.want_samples and p.tail_len == 0:
+        raise ZeroDivisionError("integer division or modulo by zero")      # SillySampler.py:704
+    p.extra["s_pre"], p.extra["s_tail"] = s0a, s1a
+    p.n_before_vel = p.n_pre + p.want_samples
+
+    # formant tracks (tiny host arrays): slice, loop, pad/trim to the frame count   :714-763
+    fm = {}
+    for k in sorted(formants_src):
+        src = np.asarray(formants_src[k])
+        if req.reverse:
+            src = src[::-1]
+        pre_t = src[slice(seg["start_frame"], seg["consonant_frame"])]
+        tr = np.asarray(src[slice(seg["consonant_frame"], seg["end_frame"])], dtype=np.float32)
+        if tr.size == 0:
+            lp = np.zeros(want_f, dtype=np.float32)
+        elif req.loop_mode == "stretch":
+            factor = want_f / float(tr.size)
+            if factor == 1.0:
+                lp = tr.copy()
+            else:
+                n_new = int(tr.size * factor)
+                lp = _lin_interp(np.linspace(0, 1, tr.size), tr, np.linspace(0, 1, n_new)).astype(np.float32)
+        else:
+            reps, rem = want_f // tr.size, want_f % tr.size
+            tile = (tr + tr[::-1]) * 0.5 if req.loop_mode == "avg" else tr
+            lp = np.tile(tile, reps)
+            if rem > 0:
+                lp = np.concatenate([lp, tile[:rem]])
+            lp = lp.astype(np.float32)
+        f = np.concatenate([pre_t, lp])
+        fm[k] = np.pad(f, (0, T_target - len(f)), mode="edge") if len(f) < T_target else f[:T_target]
+
+    # velocity prefix stretch   :765-788
+    vel = float(2.0 ** (1.0 - (req.velocity / 100.0)))
+    n_pre_f = len(pre)
+    final = stage1
+    if abs(vel - 1.0) > 1e-6 and n_pre_f > 1 and p.n_pre > 1:
+        n1 = len(stage1)
+        pos = _prefix_positions(n1, n_pre_f, vel)
+        jo, j1, w0, w1 = _interp_taps(n1, np.arange(n1, dtype=np.float64), pos)
+        idx = np.concatenate([stage1.idx[jo], stage1.idx[j1]], axis=1)
+        w = np.concatenate([stage1.w[jo] * w0[:, None], stage1.w[j1] * w1[:, None]], axis=1)
+        p.tap_idx, p.tap_w, p.env_f64 = idx, w, True
+        Tn = len(pos)
+        for k in list(fm):
+            f = _lin_interp(np.arange(len(fm[k]), dtype=np.float64), np.asarray(fm[k], dtype=np.float64),
+                            _prefix_positions(len(fm[k]), n_pre_f, vel)) if len(fm[k]) > 1 else np.asarray(fm[k], dtype=np.float64)
+            fm[k] = np.pad(f, (0, Tn - len(f)), mode="edge") if len(f) < Tn else f[:Tn]
+        p.vel_active, p.vel_factor = True, vel
+        pre_new = max(1, int(round(p.n_pre * vel)))
+        p.n_out = pre_new + (p.n_before_vel - p.n_pre)
+    else:
+        z = np.zeros((len(final), 2))
+        p.tap_idx = np.concatenate([final.idx, final.idx], axis=1)
+        p.tap_w = np.concatenate([final.w, z], axis=1)
+        p.env_f64 = final.f64
+        p.n_out = p.n_before_vel
+    T_env = p.tap_idx.shape[0]
+
+    # canon + formant-strength tracks   :791-806 (canon uses the PRE-velocity frame count)
+    canon = {}
+    for k, v in fm.items():
+        a = np.asarray(v, dtype=np.float32)
+        canon["F%d" % int(k)] = np.pad(a, (0, T_target - len(a)), mode="edge") if len(a) < T_target else a[:T_target]
+    tracks = [_sanitize_track(canon.get(nm, np.zeros(T_env)), T_env, sr, lo)
+              for nm, lo in (("F1", 120.0), ("F2", 300.0), ("F3", 1500.0), ("F4", 2000.0))]
+    p.fst_tracks = np.stack(tracks, axis=1).astype(np.float32)
+    F = np.zeros((T_env, 4), dtype=np.float64)
+    for c in range(4):
+        a = np.asarray(canon.get("F%d" % (c + 1), np.zeros(1)), dtype=np.float64)
+        F[:, c] = a[:T_env] if a.size >= T_env else (np.zeros(T_env) if a.size == 0 else np.pad(a, (0, T_env - a.size), mode="edge"))
+    p.formants = F
+
+    # edited-row window
+    used = p.tap_idx[p.tap_w != 0.0] if p.tap_idx.size else np.zeros(0, dtype=np.int64)
+    p.row_lo = int(used.min()) if used.size else 0
+    p.row_hi = int(used.max()) + 1 if used.size else 0
+    return p

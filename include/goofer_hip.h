@@ -76,6 +76,56 @@ typedef struct {
     float *mix;                 /* [total_samples] (harm*V + bre*B + uv*U)*volume, may be NULL */
 } goofer_batch;
 
+/* One note's assembly plan (host-computed scalars, SillySampler.py:449-855).  "Logical" source rows /
+ * samples are those of the feature arrays after the optional R1 reversal. */
+typedef struct {
+    int64_t knot_off;        /* first fp16 element of the note's source knot rows, [n_src_rows x K]      */
+    int64_t edit_off;        /* first row of this note in the edited-row scratch                          */
+    int64_t tap_off;         /* first row of this note in tap_idx / tap_w                                 */
+    int64_t env_off;         /* first output envelope row (== fst_tracks row)                             */
+    int64_t src_sample_off;  /* first element of the note's source voicing mask                           */
+    int64_t out_sample_off;  /* first output sample                                                       */
+    int64_t ylen;            /* source length in samples                                                  */
+    int64_t bend_off;        /* first element of the note's pitch-bend array (cents, fp32)                */
+    double es_amount;        /* sharpen amount 5*|es|                                                     */
+    double vel_factor;       /* 2^(1 - velocity/100)                                                      */
+    double pitch_m;          /* MIDI note number                                                          */
+    double pitch_t;          /* 't' flag / 100, added after bend/100 + pitch_m                            */
+    double tick_dt;          /* 60 / (tempo * 96) seconds per pitch-bend tick                             */
+    double fst[4];           /* formant-strength values (python floats in the reference)                  */
+    int32_t K, lerp_plan, n_src_rows, reverse;
+    int32_t row_lo, n_edit;  /* edited window: logical rows [row_lo, row_lo + n_edit)                     */
+    int32_t tilt;            /* br tilt table index or -1                                                 */
+    int32_t es_mode;         /* 0 off, 1 smooth, 2 sharpen                                                */
+    int32_t es_taps_off, es_radius;
+    int32_t fw_plan;         /* fw plan index or -1                                                       */
+    int32_t n_out_rows, env_f64;
+    int32_t n_out, n_pre, s_pre, s_tail, tail_len, want_samples, n_before_vel, pre_new;
+    int32_t vel_active, force_voiced, n_bend, reserved;
+} goofer_note_plan;
+
+/* A batch of note assemblies.  All pointers are device memory. */
+typedef struct {
+    int32_t n_notes, n_bins, ld, sr, max_K, reserved;
+    int64_t total_edit_rows, total_out_rows, total_samples;
+    const goofer_note_plan *notes;   /* [n_notes] */
+    const uint16_t *knots;           /* fp16 log-knot values, per note [n_src_rows x K]                   */
+    const int32_t *lerp_idx;         /* [n_lerp_plans x n_bins] 2-tap lerp plans (GOOFER.py:84-90)        */
+    const float *lerp_w0, *lerp_w1;
+    const float *tilts;              /* [n_tilts x n_bins] br tilt curves (SillySampler.py:506-510)       */
+    const double *es_taps;           /* concatenated Gaussian taps of the es flag                          */
+    const int32_t *fw_lo, *fw_hi;    /* [n_fw x n_bins] fw plans (SillySampler.py:555-564)                */
+    const double *fw_frac;
+    const int32_t *tap_idx;          /* [total_out_rows x 4] logical source rows                           */
+    const double *tap_w;             /* [total_out_rows x 4]                                               */
+    const float *fst_tracks;         /* [total_out_rows x 4] sanitised + smoothed F1..F4 (Hz)              */
+    const float *mask_src;           /* source voicing masks, concatenated                                 */
+    const float *bend;               /* pitch-bend cents, concatenated                                     */
+    float *edit_rows;                /* scratch [total_edit_rows x ld] (NULL: handle-owned)                */
+    float *env_out;                  /* [total_out_rows x ld] assembled envelope                           */
+    float *f0_out, *mask_out;        /* [total_samples]                                                    */
+} goofer_assembly;
+
 /* ---- lifetime ------------------------------------------------------------------------------ */
 int goofer_create(int device_id, goofer_ctx **out);
 void goofer_destroy(goofer_ctx *ctx);
@@ -127,6 +177,11 @@ int goofer_knot_decode(goofer_ctx *ctx, const uint16_t *knots_f16, int K, const 
 /* gf.synthesize for a ragged batch (GOOFER.py:971-1220) + the V/B/U mix (SillySampler.py:1142-1151). */
 int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *batch, void *stream);
 
+/* SillySampler.resample up to (not including) the synthesize call: knot decode, br / es / fw on the source
+ * rows, slicing + loop modes + velocity stretch as a 4-tap frame gather, formant-strength gain, per-sample
+ * voicing mask and pitch curve (SillySampler.py:449-855).  Outputs feed goofer_synth_batch directly. */
+int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *assembly, void *stream);
+
 /* ---- measurement / test hooks --------------------------------------------------------------- */
 
 /* HIP-event timing of every stage of goofer_synth_batch on the caller's stream: begin() arms up to
@@ -139,6 +194,8 @@ const char *goofer_profile_stage_name(int stage);
 /* Copy a plan table (0 window, 1 freqs, 2 boost, 3 bright_harm, 4 bright_breath, 5 pulse peak) or an
  * intermediate of the last synth batch to HOST memory; return element count / byte size. Tests only. */
 int goofer_debug_table(goofer_ctx *ctx, int which, float *host_out, int capacity);
+/* sizeof of the ABI structs (0 note_params, 1 batch, 2 note_plan, 3 assembly) so bindings can verify layout */
+int goofer_sizeof(int which);
 int64_t goofer_debug_fetch(goofer_ctx *ctx, int which, void *host_out, int64_t capacity_bytes);
 
 #ifdef __cplusplus

@@ -29,8 +29,10 @@ def test_binding_covers_header_and_struct_layout():
     assert set(_declared()) <= set(_lib.EXPORTS)
     lib = _lib.load()
     assert lib.goofer_version().startswith(b"goofer_hip")
-    assert _lib.NOTE_PARAMS.itemsize == 88
-    assert ctypes.sizeof(_lib.Batch) == 4 * 4 + 3 * 8 + 9 * 8 + 8 + 8 + 5 * 8
+    assert _lib.NOTE_PARAMS.itemsize == lib.goofer_sizeof(0) == 88
+    assert ctypes.sizeof(_lib.Batch) == lib.goofer_sizeof(1)
+    assert _lib.NOTE_PLAN.itemsize == lib.goofer_sizeof(2)
+    assert ctypes.sizeof(_lib.Assembly) == lib.goofer_sizeof(3)
 
 
 def test_no_cpu_fallback_without_gpu():

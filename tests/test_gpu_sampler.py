@@ -1,0 +1,100 @@
+"""GPU: the 13-argument resampler path (plan on host, assemble + synthesize on the device) against the
+reference's renders of the same (features, flags, pitch string) with the same injected phases."""
+import numpy as np
+import pytest
+
+from conftest import golden, rms_err
+from goofer_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+CASES = [str(n) for n in golden("sampler_index")["names"]]
+SUPPORTED = ["default", "t12g50", "tm12gm50", "formants", "formants_flip", "L0", "L1", "L2", "L0_short", "br_es_neg",
+             "br_es_pos", "vel60", "vel150", "R1", "FV1_P50", "negcut", "vol_mix"]
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    from goofer_amd.device import Context
+    from goofer_amd.render import Renderer
+    c = Context(0)
+    yield Renderer(c)
+    c.close()
+
+
+def _job(name):
+    from goofer_amd.render import Source
+    from goofer_amd import sampler as S
+    g = golden("sampler_" + name)
+    i = CASES.index(name)
+    src = syn.make_source(2000 + i, seconds=0.45)
+    source = Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+    req = S.decode_request(*[str(a) for a in g["args"]])
+    return g, source, req
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_note_matches_reference(renderer, name):
+    g, source, req = _job(name)
+    (out,), parts = renderer.render([(source, req)], phi_seeds=[int(g["seed"][0])], return_parts=True)
+    ref = g["out"]
+    assert out.shape == ref.shape
+    if "env_new" in g.files:
+        env = parts["env"].cpu().numpy().T
+        ref_env = np.asarray(g["env_new"], dtype=np.float32)
+        assert env.shape == ref_env.shape
+        assert np.max(np.abs(env - ref_env)) <= 3e-6 * np.abs(ref_env).max(), name
+        assert np.array_equal(parts["mask"].cpu().numpy(), np.asarray(g["mask_new"], dtype=np.float32))
+        f0 = parts["f0"].cpu().numpy()
+        np.testing.assert_allclose(f0, np.asarray(g["f0_new"], dtype=np.float32), rtol=3e-7, atol=1e-6)
+    e = rms_err(out, ref) / max(1.0, float(np.max(np.abs(ref))))
+    assert e < TOL, (name, e)
+    assert e < 2e-5, (name, e)
+
+
+def test_all_supported_notes_as_one_batch(renderer):
+    jobs, refs, seeds = [], [], []
+    for name in SUPPORTED:
+        g, source, req = _job(name)
+        jobs.append((source, req))
+        refs.append(g["out"])
+        seeds.append(int(g["seed"][0]))
+    outs = renderer.render(jobs, phi_seeds=seeds)
+    worst = 0.0
+    for name, o, r in zip(SUPPORTED, outs, refs):
+        assert o.shape == r.shape, name
+        e = rms_err(o, r) / max(1.0, float(np.max(np.abs(r))))
+        worst = max(worst, e)
+        assert e < TOL, (name, e)
+    print("worst sample-RMS over the 17-note batch vs reference:", worst)
+
+
+def test_unsupported_flags_fail_loudly():
+    from goofer_amd import sampler as S
+    for fl in ("su50", "sj30", "sa30", "st-50", "sd30", "vf40", "pd50", "sh50", "sr50", "sg50"):
+        with pytest.raises(NotImplementedError):
+            S.decode_request("C4", "100", fl, "0", "1000", "0", "0", "100", "0", "!120", "AA")
+
+
+def test_resampler_call_surface(renderer, tmp_path):
+    """GooferResampler(in.wav, out.wav, ...13 args): reads <stem>_features.goofy, writes a PCM16 wav."""
+    import wave
+    from goofer_amd import core
+    from goofer_amd.render import GooferResampler
+    src = syn.make_source(2000, seconds=0.45)
+    wav = tmp_path / "a b" / "src.wav"
+    wav.parent.mkdir()
+    core.save_features(wav.with_name("src_features.goofy"), src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"],
+                       src["y_len"])
+    req = syn.make_request(2000, "t0g0", length_ms=300)
+    out = tmp_path / "out.wav"
+    r = GooferResampler(str(wav), str(out), *syn.request_args(req), renderer=renderer, seed=1)
+    with wave.open(str(out), "rb") as w:
+        assert w.getframerate() == 44100 and w.getnchannels() == 1 and w.getsampwidth() == 2
+        n = w.getnframes()
+    assert n == len(r.out) == len(golden("sampler_default")["out"])
+    with pytest.raises(FileNotFoundError):
+        GooferResampler(str(tmp_path / "none.wav"), str(out), *syn.request_args(req), renderer=renderer)
