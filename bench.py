@@ -38,7 +38,7 @@ def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int) ->
         "ola_harm": 4 * n_fft * F + 4 * N, "ola_breath": 4 * n_fft * F + 4 * N, "ola_unvoiced": 4 * n_fft * F + 4 * N,
         "harm_shape": (16 * B + 4 * B) * F,          # S in+out, env in
         "noise_spectra": (16 * B + 4 * B) * F,       # two spectra out, env in (+4B when phi is injected)
-        "gauss_env": 8 * B * F, "warp_env": 8 * B * F,
+        "gauss_env": 8 * B * F, "warp_env": 8 * B * F, "assemble": 12 * B * F + 12 * N,
         "phase_inc": 12 * N, "pulse_onsets": 12 * N, "pulse_place": 4 * N,
         "mask_short": 4 * N / 4 + 8 * N / 4, "stem_gains": 24 * N, "apply_gain": 28 * N, "setup_maps": 8 * N + 12 * F,
     }
@@ -46,29 +46,31 @@ def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int) ->
 
 
 def cpu_baseline(wl, hop, budget_s=15.0, min_notes=4):
-    """Oracle (CPU port of the reference path, oracle/) on the same notes, single thread, bounded."""
+    """Oracle (CPU port of the reference path, oracle/) on the same notes — the full render the reference does
+    per note: decode features, assemble, synthesize, mix — single thread, bounded sample."""
     from oracle import goofer_ref as R
+    from oracle import sampler_ref as SR
+    from goofer_amd import synthetic as syn
     R._native()
     frames = 0
-    t0 = time.perf_counter()
     done = 0
-    for j in range(len(wl.notes)):
-        h = wl.host_note(j)
-        T = 1 + h["n"] // hop
-        phi = np.random.default_rng(h["phi_seed"]).uniform(0.0, 2.0 * np.pi, size=(h["env"].shape[0], T)).astype(np.float32)
-        t1 = time.perf_counter()
-        R.synthesize(h["env"], h["f0"], h["mask"], np.empty(h["n"], bool), wl.geo["sr"], n_fft=wl.geo["n_fft"],
-                     hop_length=hop, formants=h["formants"], phi=phi, **h["kw"])
-        frames += T
-        done += 1
-        if j == 0:
-            t0 = t1                       # exclude the one-off table/native-lib warm-up before note 0
+    t0 = time.perf_counter()
+    for j, (src, req, phi_seed) in enumerate(wl.raw):
+        feats = (src["env_pack"], src["f0"].copy(), src["mask"].copy(), {k: v.copy() for k, v in src["formants"].items()},
+                 src["sr"], src["y_len"])
+        params = SR.decode_request(*syn.request_args(req))
+        if j == 1:
+            t0 = time.perf_counter()          # note 0 warms tables / the native lib and is not counted
+        out = SR.render(feats, params, seed=phi_seed, n_fft=wl.geo["n_fft"], hop=hop)
+        if j >= 1:
+            frames += 1 + len(out) // hop
+            done += 1
         if done >= min_notes and time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
     return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{done} notes of the same workload ({frames} frames) through oracle/goofer_ref.synthesize "
-                      f"(numpy + gcc -O2 loops standing in for numba), injected phases, {dt:.1f} s",
+            "sample": f"{done} notes of the same workload ({frames} frames) through oracle/sampler_ref.render (numpy + "
+                      f"gcc -O2 loops standing in for numba): knot decode, assembly, synthesize, mix; {dt:.1f} s",
             "host_cpus": os.cpu_count()}
 
 
@@ -96,13 +98,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from goofer_amd.device import Context
-    from goofer_amd.workload import SynthWorkload
+    from goofer_amd.workload import SamplerWorkload
 
     from goofer_amd.shard import note_range, reduce_timing
 
     ctx = Context(local)
     ids = note_range(rank, world, args.notes)
-    wl = SynthWorkload(ctx, args.config, ids)
+    wl = SamplerWorkload(ctx, args.config, ids)
     geo = wl.geo
     B, hop, n_fft, sr = geo["n_fft"] // 2 + 1, geo["hop"], geo["n_fft"], geo["sr"]
 
@@ -115,14 +117,19 @@ def main():
         wl.step()
     barrier()
     ctx.profile_begin(args.steps)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        ev[k][0].record()                 # torch's current stream is the stream the library launches on
         wl.step()
+        ev[k][1].record()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
     elapsed = t1 - t0
     prof = ctx.profile_end()
+    step_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    prof["ms"]["assemble"] = max(0.0, (step_ms - sum(prof["ms"].values()) / max(1, prof["steps"]))) * max(1, prof["steps"])
     elapsed, frames_total = reduce_timing(elapsed, wl.frames, device="cuda")
 
     if rank == 0:
@@ -145,8 +152,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.config}: {args.notes} notes/GPU x ~1.1 s, sr {sr}, n_fft {n_fft}, "
                                    f"hop {hop} ({1e3 * hop / sr:.1f} ms); per-note flags {wl_flags(args.config)}; one step = "
-                                   "goofer_synth_batch (gf.synthesize + V/B/U mix) on assembled features resident in HBM, "
-                                   "on-device Philox phases; assembly-side flags (fw, fst*) are not applied in this workload",
+                                   "goofer_assemble_batch + goofer_synth_batch (SillySampler.resample + gf.synthesize + V/B/U mix) "
+                                   "from .goofy features and host-made plans resident in HBM, on-device Philox phases",
                        "notes_per_gpu": args.notes, "frames_per_gpu": wl.frames, "samples_per_gpu": wl.samples,
                        "sharding": "independent notes, no data-path collective"},
             "stage_ms": per,

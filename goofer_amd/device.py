@@ -192,8 +192,26 @@ class Context:
         return r
 
     # -- the batch ------------------------------------------------------------------------------
+    def device_offsets(self, env_lengths, sample_lengths, params: np.ndarray):
+        """Upload the CSR offsets and the per-note parameter array once (reused by every step of a resident batch)."""
+        params = self._c_params(params)
+        s_off = self.offsets(sample_lengths)
+        f_off = self.offsets(self.frame_counts(sample_lengths))
+        e_off = self.offsets(env_lengths)
+        return {"s_off": s_off, "f_off": f_off, "e_off": e_off, "d_s": self.tensor(s_off), "d_f": self.tensor(f_off),
+                "d_e": self.tensor(e_off), "d_par": self.tensor(params.view(np.uint8))}
+
+    def _c_params(self, params: np.ndarray) -> np.ndarray:
+        if params.dtype != _lib.NOTE_PARAMS or params.dtype.itemsize != _lib.NOTE_PARAMS.itemsize:
+            # numpy re-packs structured dtypes on concatenate/promotion: force the C layout back
+            fixed = np.zeros(params.shape, dtype=_lib.NOTE_PARAMS)
+            for name in _lib.NOTE_PARAMS.names:
+                fixed[name] = params[name]
+            params = fixed
+        return np.ascontiguousarray(params)
+
     def synth_batch(self, env, env_lengths, f0, mask, sample_lengths, params: np.ndarray, formants=None, phi=None,
-                    seed: int = 0, transition_sigma: float = 100.0, want_rec=True, want_mix=True):
+                    seed: int = 0, transition_sigma: float = 100.0, want_rec=True, want_mix=True, offsets=None):
         """Run goofer_synth_batch.
 
         env fp32 [R_total, n_bins] ld-strided device tensor; env_lengths rows per note;
@@ -203,20 +221,11 @@ class Context:
         """
         nb = self.n_bins
         n = len(sample_lengths)
-        if params.dtype != _lib.NOTE_PARAMS or params.dtype.itemsize != _lib.NOTE_PARAMS.itemsize:
-            # numpy re-packs structured dtypes on concatenate/promotion: force the C layout back
-            fixed = np.zeros(params.shape, dtype=_lib.NOTE_PARAMS)
-            for name in _lib.NOTE_PARAMS.names:
-                fixed[name] = params[name]
-            params = fixed
-        params = np.ascontiguousarray(params)
-        s_off = self.offsets(sample_lengths)
-        f_off = self.offsets(self.frame_counts(sample_lengths))
-        e_off = self.offsets(env_lengths)
+        o = offsets or self.device_offsets(env_lengths, sample_lengths, params)
+        s_off, f_off, e_off = o["s_off"], o["f_off"], o["e_off"]
+        d_s, d_f, d_e, d_par = o["d_s"], o["d_f"], o["d_e"], o["d_par"]
         N, F, R = int(s_off[-1]), int(f_off[-1]), int(e_off[-1])
         assert env.shape == (R, nb) and f0.numel() == N and mask.numel() == N and params.shape == (n,)
-        d_s, d_f, d_e = self.tensor(s_off), self.tensor(f_off), self.tensor(e_off)
-        d_par = self.tensor(params.view(np.uint8))
         out = {k: torch.empty(N, dtype=torch.float32, device=self.device) for k in ("harm", "uv", "bre")}
         if want_rec:
             out["rec"] = torch.empty(N, dtype=torch.float32, device=self.device)

@@ -76,9 +76,31 @@ class Renderer:
         out.wav); with ``return_parts`` also a dict of device-side intermediates for tests.
         ``phi_seeds``: per-note seeds for INJECTED phases (parity with a seeded reference run); otherwise the
         device draws phases from Philox keyed by ``seed`` and the note index."""
-        ctx = self.ctx
         if not jobs:
             return []
+        prep = self.prepare(jobs, phi_seeds=phi_seeds)
+        out = self.run(prep, seed=seed)
+        torch.cuda.synchronize(self.ctx.device)
+        mix = out["mix"].cpu().numpy()
+        offs = prep["sample_off"]
+        res = [mix[offs[i]:offs[i + 1]] for i in range(len(jobs))]
+        if return_parts:
+            parts = {"env": prep["env"], "f0": prep["f0"], "mask": prep["mask"], "env_off": prep["env_off"], "sample_off": offs,
+                     "plans": prep["plans"], "stems": out}
+            return res, parts
+        return res
+
+    def run(self, prep, seed: int = 0):
+        """The device work of one batch: goofer_assemble_batch then goofer_synth_batch (asynchronous)."""
+        ctx = self.ctx
+        ctx._check(ctx.lib.goofer_assemble_batch(ctx.h, C.byref(prep["assembly"]), ctx._stream()))
+        return ctx.synth_batch(prep["env"], prep["env_lens"], prep["f0"], prep["mask"], prep["lens"], prep["params"],
+                               formants=prep["formants"], phi=prep["phi"], seed=seed, want_rec=False, want_mix=True,
+                               offsets=prep["offsets"])
+
+    def prepare(self, jobs, phi_seeds=None):
+        """Plan every note on the host and make the batch resident in HBM (plans, tables, sources)."""
+        ctx = self.ctx
         sr, n_fft = jobs[0][0].sr, jobs[0][0].n_fft
         if any(j[0].sr != sr or j[0].n_fft != n_fft for j in jobs):
             raise ValueError("one batch must share sr / n_fft")
@@ -189,9 +211,7 @@ class Renderer:
                           fw_hi=ptr(d["fw_hi"]), fw_frac=ptr(d["fw_frac"]), tap_idx=ptr(d["tap_idx"]), tap_w=ptr(d["tap_w"]),
                           fst_tracks=ptr(d["fst_tracks"]), mask_src=ptr(d["mask_src"]), bend=ptr(d["bend"]), edit_rows=None,
                           env_out=env.data_ptr(), f0_out=f0.data_ptr(), mask_out=mask.data_ptr())
-        ctx._check(ctx.lib.goofer_assemble_batch(ctx.h, C.byref(a), ctx._stream()))
-
-        # synthesize + mix
+        # per-note synthesize parameters
         par = default_params(n)
         for i, (_, req) in enumerate(jobs):
             par[i]["formant_shift"] = req.formant_shift
@@ -209,17 +229,14 @@ class Renderer:
                 T = 1 + p.n_out // self.hop
                 mats.append(np.random.default_rng(sd).uniform(0.0, 2.0 * np.pi, size=(B, T)).astype(np.float32).T)
             phi = ctx.rows_from(np.concatenate(mats))
-        out = ctx.synth_batch(env, env_lens, f0, mask, lens, par, formants=ctx.tensor(np.concatenate(F_cat)), phi=phi,
-                              seed=seed, want_rec=False, want_mix=True)
+        offsets = ctx.device_offsets(env_lens, lens, par)
+        frames = int(sum(ctx.frame_counts(lens)))
+        ctx.reserve(frames, int(sum(lens)), n)
         torch.cuda.synchronize(ctx.device)
-        mix = out["mix"].cpu().numpy()
-        offs = np.concatenate([[0], np.cumsum(lens)])
-        res = [mix[offs[i]:offs[i + 1]] for i in range(n)]
-        if return_parts:
-            eo = np.concatenate([[0], np.cumsum(env_lens)])
-            parts = {"env": env, "f0": f0, "mask": mask, "env_off": eo, "sample_off": offs, "plans": plans, "stems": out, "keep": d}
-            return res, parts
-        return res
+        return {"assembly": a, "keep": d, "env": env, "f0": f0, "mask": mask, "params": par, "lens": lens, "env_lens": env_lens,
+                "formants": ctx.tensor(np.concatenate(F_cat)), "phi": phi, "plans": plans, "offsets": offsets,
+                "sample_off": np.concatenate([[0], np.cumsum(lens)]), "env_off": np.concatenate([[0], np.cumsum(env_lens)]),
+                "frames": frames, "samples": int(sum(lens)), "edit_rows": e_off}
 
 
 # ---------------------------------------------------------------------------------------------

@@ -139,3 +139,30 @@ class SynthWorkload:
         return {"env": env, "f0": nt["f0"].astype(np.float64), "mask": nt["mask"], "n": nt["n"],
                 "formants": {k + 1: nt["formants"][:, k] for k in range(4)}, "kw": kw, "params": p,
                 "phi_seed": nt["phi_seed"]}
+
+
+class SamplerWorkload:
+    """BASELINE config N as the reference would see it: ``.goofy`` features + the 13-argument request per note.
+    Planning happens once on the host; plans, tables and sources stay resident in HBM; ``step()`` is the
+    device work of one render of the whole batch (assemble + synthesize + mix)."""
+
+    def __init__(self, ctx: Context, config: int, note_ids):
+        from .render import Renderer, Source
+        from . import sampler as S
+        self.geo = syn.config_geometry(config)
+        self.config = config
+        self.ctx = ctx
+        self.renderer = Renderer(ctx, hop=self.geo["hop"])
+        self.raw = []
+        jobs = []
+        for i in note_ids:
+            src, req, phi_seed = syn.config_note(config, int(i))
+            self.raw.append((src, req, phi_seed))
+            jobs.append((Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]),
+                         S.decode_request(*syn.request_args(req))))
+        self.prep = self.renderer.prepare(jobs)
+        self.frames, self.samples = self.prep["frames"], self.prep["samples"]
+        self.notes = jobs
+
+    def step(self):
+        return self.renderer.run(self.prep, seed=0)
