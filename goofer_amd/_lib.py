@@ -89,6 +89,8 @@ EXPORTS = {
     "goofer_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "goofer_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "goofer_profile_stage_name": (C.c_char_p, [C.c_int]),
+    "goofer_profile_stage_name_ex": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "goofer_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
 }
 
 _lib = None

@@ -33,6 +33,11 @@ int launch_noise_spectra(goofer_ctx *, float2 *, float2 *, int, int64_t, const i
                          hipStream_t);
 int launch_mask_short(goofer_ctx *, const float *, const int64_t *, int, int64_t, const double *, int, double *, hipStream_t);
 int launch_assemble(goofer_ctx *, const goofer_assembly *, int *, int *, hipStream_t);
+int launch_ola3_gains(goofer_ctx *, const float *, const float *, const float *, const float *, const double *, const int64_t *,
+                      const int64_t *, int, int64_t, const goofer_note_params *, double *, float *, float *, float *, float *, hipStream_t);
+int launch_harm_frames(goofer_ctx *, const float *, const goofer_batch *, const float *, const int *, const int64_t *, float *, float *,
+                       hipStream_t);
+int launch_noise_frames(goofer_ctx *, const goofer_batch *, const float *, const int *, const int64_t *, float *, float *, hipStream_t);
 int launch_stem_gains(goofer_ctx *, float *, float *, float *, const double *, const int64_t *, int, int64_t,
                       const goofer_note_params *, float *, double *, hipStream_t);
 int launch_apply_gain(goofer_ctx *, float *, float *, float *, float *, float *, const int64_t *, int, int64_t,
@@ -114,7 +119,7 @@ static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t sampl
     add(64);                                      // overflow flag
     add(samples * sizeof(float));                 // pulse
     add(3 * frames * ldc * sizeof(float2));       // S_h, S_uv, S_br
-    add(frames * (size_t)p.n_fft * sizeof(float));  // windowed time frames
+    add(3 * frames * (size_t)p.n_fft * sizeof(float));  // windowed time frames (three stems in the fused path)
     add(2 * frames * ld * sizeof(float));         // env_h, env_n
     add((samples / 4 + notes + 16) * sizeof(double));  // smoothed decimated mask
     add(2 * notes * sizeof(float) + 64);          // note_mag, note_peak
@@ -324,8 +329,7 @@ int64_t goofer_debug_fetch(goofer_ctx *ctx, int which, void *host_out, int64_t c
 
 static const char *const PROF_NAMES[PROF_STAGES] = {
     "setup_maps", "gauss_env", "warp_env", "phase_inc", "pulse_onsets", "pulse_place", "rfft_frames", "harm_shape",
-    "irfft_harm", "ola_harm", "noise_spectra", "irfft_breath", "ola_breath", "irfft_unvoiced", "ola_unvoiced",
-    "mask_short", "stem_gains", "apply_gain"};
+    "irfft_harm", "noise_spectra", "irfft_breath", "irfft_unvoiced", "mask_short", "ola3_gains", "apply_gain", "", "", ""};
 
 // Per-stage timing of goofer_synth_batch with HIP events recorded on the caller's stream (so the
 // numbers are what that stream really executed).  begin(max_steps) arms it; every synth batch then
@@ -365,6 +369,24 @@ int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages)
 }
 
 const char *goofer_profile_stage_name(int stage) { return stage >= 0 && stage < PROF_STAGES ? PROF_NAMES[stage] : ""; }
+
+static const char *const PROF_NAMES_FUSED[PROF_STAGES] = {
+    "setup_maps", "", "", "phase_inc", "pulse_onsets", "pulse_place", "harm_frames", "", "", "noise_frames", "", "",
+    "mask_short", "ola3_gains", "apply_gain", "", "", ""};
+
+const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage)
+{
+    if (stage < 0 || stage >= PROF_STAGES) return "";
+    return (ctx && ctx->fused) ? PROF_NAMES_FUSED[stage] : PROF_NAMES[stage];
+}
+
+/* options: "fused" = 1 (default) fused per-frame kernels, 0 one kernel per reference step (A/B parity) */
+int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
+{
+    if (!ctx || !name) return GOOFER_EINVAL;
+    if (!strcmp(name, "fused")) { ctx->fused = value != 0; return GOOFER_OK; }
+    return goofer_fail(ctx, GOOFER_EINVAL, "unknown option %s", name);
+}
 
 int goofer_sizeof(int which)
 {
@@ -538,12 +560,14 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     float2 *S_uv = a.take<float2>((size_t)F * ldc);
     float2 *S_br = a.take<float2>((size_t)F * ldc);
     float *frames = a.take<float>((size_t)F * p.n_fft);
+    float *frames_u = a.take<float>((size_t)F * p.n_fft);
+    float *frames_b = a.take<float>((size_t)F * p.n_fft);
     float *env_h = a.take<float>((size_t)F * ld);
     float *env_n = a.take<float>((size_t)F * ld);
     double *short_s = a.take<double>(N / 4 + n + 16);
     float *note_mag = a.take<float>(2 * (size_t)n + 16);
     double *note_steps = a.take<double>(2 * (size_t)n + 16);
-    if (!frame_note || !row_src || !f0s || !inc || !onsets || !onset_idx || !onset_cnt || !ovf || !pulse || !S_h || !S_uv || !S_br || !frames ||
+    if (!frames_u || !frames_b || !frame_note || !row_src || !f0s || !inc || !onsets || !onset_idx || !onset_cnt || !ovf || !pulse || !S_h || !S_uv || !S_br || !frames ||
         !env_h || !env_n || !short_s || !note_mag || !note_steps)
         return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     float *note_peak = note_mag + n;
@@ -592,9 +616,10 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     hipLaunchKernelGGL(k_scale_f0, dim3(sb), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s);
     LAUNCH_CHECK(ctx);
     MARK();   // 1: noise envelope = sigma-1.75 blur of the un-warped rows (GOOFER.py:993)
-    if ((rc = launch_gauss_bins(ctx, b->env, env_n, F, p.n_bins, ld, p.blur175, 7, row_src, st))) return rc;
+    if (!ctx->fused && (rc = launch_gauss_bins(ctx, b->env, env_n, F, p.n_bins, ld, p.blur175, 7, row_src, st))) return rc;
     MARK();   // 2: harmonic envelope = formant-anchored + uniform warp
-    if ((rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, st)))
+    if (!ctx->fused &&
+        (rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, st)))
         return rc;
     MARK();   // 3..5: pulse train
     if ((rc = launch_phase_inc(ctx, f0s, 1.0f, N, inc, st))) return rc;
@@ -602,34 +627,45 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, inc, b->sample_off, n, (onset_t *)onsets, onset_idx, onset_cnt, ovf, st))) return rc;
     MARK();
     if ((rc = launch_pulse_place(ctx, (onset_t *)onsets, onset_cnt, b->sample_off, n, N, pulse, st))) return rc;
-    MARK();   // 6: framewise rFFT of the pulse train
-    if ((rc = launch_rfft_frames_mapped(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, st))) return rc;
-    MARK();   // 7
-    if ((rc = launch_harm_shape(ctx, S_h, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, env_h, ld, b->params,
-                                note_mag, st)))
-        return rc;
-    MARK();   // 8, 9
-    if ((rc = launch_irfft_frames(ctx, S_h, ldc, F, frames, st))) return rc;
-    MARK();
-    if ((rc = launch_ola_gather(ctx, frames, b->sample_off, b->frame_off, n, N, b->harm, note_mag, st))) return rc;
-    MARK();   // 10: aperiodic spectra
-    if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, env_n, b->phi, ld,
-                                   b->params, b->seed, st)))
-        return rc;
-    MARK();   // 11..14
-    if ((rc = launch_irfft_frames(ctx, S_br, ldc, F, frames, st))) return rc;
-    MARK();
-    if ((rc = launch_ola_gather(ctx, frames, b->sample_off, b->frame_off, n, N, b->bre, nullptr, st))) return rc;
-    MARK();
-    if ((rc = launch_irfft_frames(ctx, S_uv, ldc, F, frames, st))) return rc;
-    MARK();
-    if ((rc = launch_ola_gather(ctx, frames, b->sample_off, b->frame_off, n, N, b->uv, nullptr, st))) return rc;
-    MARK();   // 15..17: gains, peak normalisation, mix
+    // spectra -> windowed time frames of the three stems
+    if (ctx->fused) {
+        MARK();   // 6: harm_frames = rFFT + warp + shape + irFFT (envelope stages 1, 2 folded in)
+        if ((rc = launch_harm_frames(ctx, pulse, b, f0s, frame_note, row_src, frames, note_mag, st))) return rc;
+        MARK();   // 7
+        MARK();   // 8
+        MARK();   // 9: noise_frames = blur + spectra + 2 irFFT
+        if ((rc = launch_noise_frames(ctx, b, f0s, frame_note, row_src, frames_u, frames_b, st))) return rc;
+        MARK();   // 10
+        MARK();   // 11
+    } else {
+        MARK();   // 6: framewise rFFT of the pulse train
+        if ((rc = launch_rfft_frames_mapped(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, st))) return rc;
+        MARK();   // 7
+        if ((rc = launch_harm_shape(ctx, S_h, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, env_h, ld, b->params,
+                                    note_mag, st)))
+            return rc;
+        MARK();   // 8
+        if ((rc = launch_irfft_frames(ctx, S_h, ldc, F, frames, st))) return rc;
+        MARK();   // 9: aperiodic spectra
+        if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, env_n, b->phi, ld,
+                                       b->params, b->seed, st)))
+            return rc;
+        MARK();   // 10, 11
+        if ((rc = launch_irfft_frames(ctx, S_br, ldc, F, frames_b, st))) return rc;
+        MARK();
+        if ((rc = launch_irfft_frames(ctx, S_uv, ldc, F, frames_u, st))) return rc;
+    }
+    MARK();   // 12: decimated + smoothed voicing mask
     if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, short_s, st))) return rc;
-    MARK();
-    if ((rc = launch_stem_gains(ctx, b->harm, b->uv, b->bre, short_s, b->sample_off, n, N, b->params, note_peak, note_steps, st))) return rc;
-    MARK();
+    MARK();   // 13: overlap-add of the three stems + gains + per-note peak, one pass
+    if ((rc = launch_ola3_gains(ctx, frames, frames_u, frames_b, note_mag, short_s, b->sample_off, b->frame_off, n, N, b->params,
+                                note_steps, b->harm, b->uv, b->bre, note_peak, st)))
+        return rc;
+    MARK();   // 14: gain, reconstruct, mix
     if ((rc = launch_apply_gain(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, N, b->params, note_peak, st))) return rc;
+    MARK();   // 15..17 unused
+    MARK();
+    MARK();
     MARK();   // end
 #undef MARK
     if (pev) ctx->prof_steps++;

@@ -9,7 +9,7 @@
 //   k_noise_spectra  random-phase noise stems                          GOOFER.py:1148-1173
 #include <hip/hip_fp16.h>
 
-#include "common.h"
+#include "binops_core.h"
 
 constexpr int ROWS_PER_BLOCK = 4;   // one wave per row, 256-thread workgroups
 
@@ -55,84 +55,6 @@ int launch_gauss_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows
 }
 
 // ---------------------------------------------------------------------------------------------
-// numpy's binary_search_with_guess (numpy/_core/src/multiarray/compiled_base.c) restated for the
-// short anchor arrays of warp_env_by_formants: np.interp is called there with a possibly
-// NON-monotone xp (anchors are not sorted, GOOFER.py:855-870), so the index it returns depends on
-// the guess carried over from the previous (ascending) query.  We reproduce that exactly.
-__device__ __forceinline__ int np_search_guess(double key, const double *arr, int len, int guess)
-{
-    if (key > arr[len - 1]) return len;
-    if (key < arr[0]) return -1;
-    if (len <= 4) {
-        int i = 1;
-        while (i < len && key >= arr[i]) ++i;
-        return i - 1;
-    }
-    if (guess > len - 3) guess = len - 3;
-    if (guess < 1) guess = 1;
-    int imin = 0, imax = len;
-    if (key < arr[guess]) {
-        if (key < arr[guess - 1]) {
-            imax = guess - 1;   // (the LIKELY_IN_CACHE_SIZE=8 refinement can never trigger for len <= 6)
-        } else {
-            return guess - 1;
-        }
-    } else {
-        if (key < arr[guess + 1]) return guess;
-        if (key < arr[guess + 2]) return guess + 1;
-        imin = guess + 2;
-    }
-    while (imin < imax) {
-        int imid = imin + ((imax - imin) >> 1);
-        if (key >= arr[imid]) imin = imid + 1; else imax = imid;
-    }
-    return imin - 1;
-}
-
-// np.interp value for index j (arr_interp inner body), xp/fp short arrays
-__device__ __forceinline__ double np_interp_eval(double x, int j, const double *xp, const double *fp, int len)
-{
-    if (j == -1) return fp[0];
-    if (j == len) return fp[len - 1];
-    if (j == len - 1) return fp[j];
-    if (x == xp[j]) return fp[j];
-    double slope = (fp[j + 1] - fp[j]) * fast_rcp(xp[j + 1] - xp[j]);
-    double v = slope * (x - xp[j]) + fp[j];
-    if (isnan(v)) {
-        v = slope * (x - xp[j + 1]) + fp[j + 1];
-        if (isnan(v) && fp[j] == fp[j + 1]) v = fp[j];
-    }
-    return v;
-}
-
-// linear interpolation of an fp32 row sampled on the uniform grid b*step, at x in [0, nyq]
-// (np.interp with sorted xp: largest j with xp[j] <= x), plus gf.interp1d's linear extrapolation.
-// The index is exact (multiply estimate, compare fix-up against the true grid); the slope uses
-// inv_step = 1/step instead of a division (grid spacing is exactly `step`: b*step is exact in fp64).
-__device__ __forceinline__ double row_interp(const float *r, int n_bins, double step, double inv_step, double nyq, double x)
-{
-    if (x < 0.0) {
-        double sl = (double)(r[1] - r[0]) / (step + 1e-10);           // fp32 difference, like the reference
-        return (double)r[0] + sl * (x - 0.0);
-    }
-    if (x > nyq) {
-        double xl = (double)(n_bins - 2) * step;
-        double sl = (double)(r[n_bins - 1] - r[n_bins - 2]) / (nyq - xl + 1e-10);
-        return (double)r[n_bins - 1] + sl * (x - nyq);
-    }
-    int j = (int)(x * inv_step);
-    if (j > n_bins - 1) j = n_bins - 1;
-    // grid point q is q*step, except the last which linspace pins to nyq
-    if (j + 1 <= n_bins - 1 && (j + 1 >= n_bins - 1 ? nyq : (double)(j + 1) * step) <= x) ++j;
-    if (j > 0 && (j >= n_bins - 1 ? nyq : (double)j * step) > x) --j;
-    if (j >= n_bins - 1) return (double)r[n_bins - 1];
-    const double xj = (double)j * step;
-    const double r0 = (double)r[j];
-    if (x == xj) return r0;
-    const double slope = ((double)r[j + 1] - r0) * inv_step;
-    return slope * (x - xj) + r0;
-}
-
 // Per-row formant-anchored warp then uniform warp.  f_shift == nullptr skips the first stage,
 // ratio == 1 the second; each stage rounds to fp32 (np.zeros_like(env) in the reference).
 // rows may be addressed through row_map (source row per output row), or identity when nullptr.
@@ -166,90 +88,7 @@ __global__ __launch_bounds__(256) void k_warp_bins(const float *__restrict__ in,
         for (int i = 0; i < 4; ++i) fs[i] = f_shift_global[i];
         warp = true;   // the caller decides (gf.synthesize tests any(shift != 1))
     }
-    const double step = nyq / (double)(n_bins - 1);
-    const double inv_step = fast_rcp(step);
-    float *cur = ra, *nxt = rb;
-
-    if (warp && formants) {
-        // anchors: (0,0), valid (shifted -> orig), (nyq, nyq)      GOOFER.py:850-865
-        double dst[6], sp[6];
-        int len = 0;
-        dst[len] = 0.0; sp[len] = 0.0; ++len;
-        for (int i = 0; i < 4; ++i) {
-            double fo = formants[src * 4 + i];
-            double fsft = fo * fs[i];
-            if (fo > 50.0 && fo < nyq && fsft > 50.0) { dst[len] = fsft; sp[len] = fo; ++len; }
-        }
-        dst[len] = nyq; sp[len] = nyq; ++len;
-
-        bool sorted = true;
-        for (int k = 1; k < len; ++k) sorted &= dst[k - 1] <= dst[k];
-        if (sorted || len <= 4) {
-            // monotone anchors (or numpy's guess-free linear search): the answer does not depend on the
-            // guess chain — index = last anchor <= x, found with a few compares, bins strided over lanes
-            for (int b = lane; b < n_bins; b += WAVE) {
-                const double x = b >= n_bins - 1 ? nyq : (double)b * step;
-                int j = np_search_guess(x, dst, len, 1);
-                if (len > 4) {
-                    j = 0;
-                    for (int k = 1; k < len; ++k) j += dst[k] <= x;
-                }
-                const double wf = np_interp_eval(x, j, dst, sp, len);
-                nxt[b] = (float)row_interp(cur, n_bins, step, inv_step, nyq, wf);
-            }
-        } else {
-        // Resolve np.interp's guess chain over the ascending bin frequencies.  The clamped guess
-        // takes at most 3 values (1..len-3), so each bin is a map state->state; lanes own
-        // contiguous chunks, compose their maps, scan across the wave, then replay.
-        const int per = (n_bins + WAVE - 1) / WAVE;
-        const int b0 = lane * per;
-        auto clampg = [&](int g) { int hi = len - 3; if (g > hi) g = hi; if (g < 1) g = 1; return g; };
-        int m1 = 1, m2 = 2, m3 = 3;                 // composed map of this lane's chunk: state s -> m_s
-        for (int q = 0; q < per; ++q) {
-            int b = b0 + q;
-            if (b >= n_bins) break;
-            double x = b >= n_bins - 1 ? nyq : (double)b * step;
-            m1 = clampg(np_search_guess(x, dst, len, m1));
-            m2 = clampg(np_search_guess(x, dst, len, m2));
-            m3 = clampg(np_search_guess(x, dst, len, m3));
-        }
-        // inclusive scan of map composition (earlier lanes apply first)
-        for (int off = 1; off < WAVE; off <<= 1) {
-            int p1 = __shfl_up(m1, off, WAVE), p2 = __shfl_up(m2, off, WAVE), p3 = __shfl_up(m3, off, WAVE);
-            if (lane >= off) {
-                int a1 = p1 == 1 ? m1 : (p1 == 2 ? m2 : m3);
-                int a2 = p2 == 1 ? m1 : (p2 == 2 ? m2 : m3);
-                int a3 = p3 == 1 ? m1 : (p3 == 2 ? m2 : m3);
-                m1 = a1; m2 = a2; m3 = a3;
-            }
-        }
-        // state entering this lane's chunk = inclusive result of lane-1 applied to the initial guess
-        int incoming = __shfl_up(m1, 1, WAVE);       // initial j = 0 clamps to state 1
-        int guess = lane == 0 ? 0 : incoming;
-        for (int q = 0; q < per; ++q) {
-            int b = b0 + q;
-            if (b >= n_bins) break;
-            double x = b >= n_bins - 1 ? nyq : (double)b * step;
-            int j = np_search_guess(x, dst, len, guess);
-            guess = j;
-            double wf = np_interp_eval(x, j, dst, sp, len);
-            nxt[b] = (float)row_interp(cur, n_bins, step, inv_step, nyq, wf);
-        }
-        }
-        wave_lds_sync();
-        float *t = cur; cur = nxt; nxt = t;
-    }
-    if (ratio != 1.0) {
-        const double inv_ratio = fast_rcp(ratio);
-        for (int b = lane; b < n_bins; b += WAVE) {
-            double x = b >= n_bins - 1 ? nyq : (double)b * step;
-            double q = x * inv_ratio;
-            q = q < 0.0 ? 0.0 : (q > nyq ? nyq : q);
-            nxt[b] = (float)row_interp(cur, n_bins, step, inv_step, nyq, q);
-        }
-        wave_lds_sync();
-        float *t = cur; cur = nxt; nxt = t;
-    }
+    float *cur = warp_row(ra, rb, n_bins, nyq, formants ? formants + src * 4 : nullptr, fs, warp, ratio, lane, src);
     for (int b = lane; b < n_bins; b += WAVE) out[row * ld + b] = cur[b];
 }
 
@@ -299,37 +138,6 @@ int launch_knot_decode(goofer_ctx *ctx, const uint16_t *knots, int K, int64_t ro
 }
 
 // ---------------------------------------------------------------------------------------------
-// frame -> per-frame picks of the per-sample arrays: x[::hop] edge-padded to T (GOOFER.py:1104-1106)
-__device__ __forceinline__ int64_t pick_index(int64_t t, int64_t n, int hop)
-{
-    int64_t cnt = (n + hop - 1) / hop;            // len(x[::hop])
-    if (cnt <= 0) return 0;
-    int64_t q = t < cnt ? t : cnt - 1;
-    return q * hop;
-}
-
-__device__ __forceinline__ float hp_mask(float freq, float f0f)
-{
-    float z = (freq - f0f) / 5.0f;
-    z = fminf(fmaxf(z, -60.0f), 60.0f);
-    return 1.0f / (1.0f + expf(-z));
-}
-
-// 5-tap sigma=0.5 blur of a complex row held in LDS (reflect padded), complex128 accumulate
-__device__ __forceinline__ float2 blur5(const float2 *r, int k, int n_bins, const double *t5)
-{
-    double re = 0.0, im = 0.0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        int q = k + j - 2;
-        q = q < 0 ? -q : (q >= n_bins ? 2 * (n_bins - 1) - q : q);
-        float2 v = r[q];
-        re += t5[j] * (double)v.x;
-        im += t5[j] * (double)v.y;
-    }
-    return make_float2((float)re, (float)im);
-}
-
 // In place on S: optional high-pass, per-note max(|S| + 1e-8), then * env * boost, and on voiced
 // frames * brightness followed by the 5-tap blur.  The 1/max normalisation commutes with the
 // (linear) rest of the chain and is applied after the overlap-add.
@@ -399,23 +207,6 @@ int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Philox-4x32-10 keyed by (seed), counter (frame, bin): uniform phase in [0, 2 pi) when no phase
-// matrix is injected.
-__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t ctr_hi, uint32_t ctr_lo)
-{
-    uint32_t c0 = ctr_lo, c1 = (uint32_t)ctr_hi, c2 = (uint32_t)(ctr_hi >> 32), c3 = 0x9E3779B9u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return c0;
-}
-
 // S_uv = U * env_noise ; S_br = (U * env_noise) * HP, brightened + blurred on voiced frames.
 __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv, float2 *__restrict__ S_br, int ldc,
                                                        int64_t total_frames, const int *__restrict__ frame_note,

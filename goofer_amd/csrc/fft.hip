@@ -9,157 +9,7 @@
 // Stockham autosort FFT (lane holds M/64 points; first radix-(M/64) pass in registers straight from
 // global memory, then two radix-8 passes exchanged through a padded per-wave LDS buffer) followed by
 // the even/odd split that recovers the n_fft/2+1 real-input bins.  No MFMA: ~5 flop/B, HBM-bound.
-#include "common.h"
-
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
-
-// In-register forward DFTs (exp(-2 pi i nk/R)), natural-order output, decimation in frequency.
-template <int R> struct dft;
-
-template <> struct dft<2> {
-    __device__ __forceinline__ static void run(float2 *v)
-    {
-        float2 a = v[0], b = v[1];
-        v[0] = cadd(a, b);
-        v[1] = csub(a, b);
-    }
-};
-
-template <> struct dft<4> {
-    __device__ __forceinline__ static void run(float2 *v)
-    {
-        float2 a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]);
-        float2 a2 = cadd(v[1], v[3]), a3 = mul_mi(csub(v[1], v[3]));
-        v[0] = cadd(a0, a2);
-        v[2] = csub(a0, a2);
-        v[1] = cadd(a1, a3);
-        v[3] = csub(a1, a3);
-    }
-};
-
-template <> struct dft<8> {
-    __device__ __forceinline__ static void run(float2 *v)
-    {
-        const float h = 0.70710678118654752440f;
-        float2 e[4], o[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            e[n] = cadd(v[n], v[n + 4]);
-            o[n] = csub(v[n], v[n + 4]);
-        }
-        o[1] = make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));   // * W8^1 = (1-i)/sqrt2
-        o[2] = mul_mi(o[2]);                                               // * W8^2 = -i
-        o[3] = make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));  // * W8^3 = (-1-i)/sqrt2
-        dft<4>::run(e);
-        dft<4>::run(o);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            v[2 * m] = e[m];
-            v[2 * m + 1] = o[m];
-        }
-    }
-};
-
-template <> struct dft<16> {
-    __device__ __forceinline__ static void run(float2 *v)
-    {
-        // W16^n, n = 0..7
-        const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
-        const float2 w[8] = {{1.f, 0.f}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.f, -1.f}, {-s1, -c1}, {-h, -h}, {-c1, -s1}};
-        float2 e[8], o[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            e[n] = cadd(v[n], v[n + 8]);
-            o[n] = cmul(csub(v[n], v[n + 8]), w[n]);
-        }
-        dft<8>::run(e);
-        dft<8>::run(o);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            v[2 * m] = e[m];
-            v[2 * m + 1] = o[m];
-        }
-    }
-};
-
-__host__ __device__ __forceinline__ constexpr int lds_pad(int i) { return i + (i >> 5); }
-
-template <int M> struct fft_cfg {
-    static constexpr int R = M / 64;           // points per lane == first-pass radix
-    static constexpr int BUF = M + (M >> 5);   // padded float2 slots per wave
-};
-
-// Radix-8 Stockham pass over the per-wave LDS buffer.  NS = product of the radices already applied.
-// Reads x[b + t*M/8], writes y[(b/NS)*NS*8 + b%NS + t*NS]; all reads precede all writes.
-template <int M, int NS>
-__device__ __forceinline__ void radix8_pass(float2 *buf, const float2 *tw, int lane)
-{
-    constexpr int NB = M / 8;                       // butterflies in this pass
-    constexpr int PER = (NB + WAVE - 1) / WAVE;     // per lane
-    float2 v[PER][8];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        int b = lane + WAVE * u;
-        if (NB >= WAVE || b < NB) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) v[u][t] = buf[lds_pad(b + t * NB)];
-        }
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        int b = lane + WAVE * u;
-        if (NB >= WAVE || b < NB) {
-            int k = b % NS;
-            // twiddle exp(-2 pi i t k / (8 NS)) = tw[t * k * (M / (8 NS))]
-            constexpr int STEP = M / (8 * NS);
-#pragma unroll
-            for (int t = 1; t < 8; ++t) v[u][t] = cmul(v[u][t], tw[(t * k * STEP) & (M - 1)]);
-            dft<8>::run(v[u]);
-            int j0 = (b / NS) * NS * 8 + k;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) buf[lds_pad(j0 + t * NS)] = v[u][t];
-        }
-    }
-    wave_lds_sync();
-}
-
-// Complex forward FFT of size M for one wave.  `v` holds x[lane + 64 t], t < R on entry; the result
-// is left in natural order in `buf` (padded).
-template <int M>
-__device__ __forceinline__ void wave_fft(float2 *v, float2 *buf, const float2 *tw, int lane)
-{
-    constexpr int R = fft_cfg<M>::R;
-    dft<R>::run(v);                       // pass 0: NS = 1, no twiddle, y[lane*R + t]
-#pragma unroll
-    for (int t = 0; t < R; ++t) buf[lds_pad(lane * R + t)] = v[t];
-    wave_lds_sync();
-    radix8_pass<M, R>(buf, tw, lane);
-    radix8_pass<M, R * 8>(buf, tw, lane);
-    static_assert(R * 64 == M, "M must be 64 * first radix");
-}
-
-template <int M>
-__device__ __forceinline__ void load_tables(float2 *tw, float2 *twh, float *win, const float2 *g_tw,
-                                            const float2 *g_twh, const float *g_win)
-{
-    for (int i = threadIdx.x; i < M; i += blockDim.x) tw[i] = g_tw[i];
-    for (int i = threadIdx.x; i < M / 2 + 1; i += blockDim.x) twh[i] = g_twh[i];
-    for (int i = threadIdx.x; i < 2 * M; i += blockDim.x) win[i] = g_win[i];
-    __syncthreads();
-}
-
-constexpr int FRAMES_PER_BLOCK = 32;   // contiguous frames per workgroup: overlapping reads stay in L1/L2
-constexpr int WAVES_PER_BLOCK = 4;
-
-template <int M> constexpr size_t fft_lds_bytes()
-{
-    return sizeof(float2) * (M + M / 2 + 1 + WAVES_PER_BLOCK * fft_cfg<M>::BUF) + sizeof(float) * 2 * M + 16;
-}
+#include "fft_core.h"
 
 // ---------------------------------------------------------------------------------------------
 template <int M>

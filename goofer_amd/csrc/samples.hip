@@ -179,6 +179,73 @@ __global__ __launch_bounds__(256) void k_stem_gains(float *__restrict__ harm, fl
         atomic_max_pos(note_peak + lo, fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])));
 }
 
+// Overlap-add of the three stems + mask upsample + stem gains + per-note peak in ONE pass over the samples
+// (k_ola_gather x3 + k_stem_gains): each output sample gathers its covering windowed frames of the three
+// stems in ascending frame order (the reference's fp32 accumulation order), normalises by the summed
+// squared window, then applies the gains.  Saves one full write + read of the three stems.
+__global__ __launch_bounds__(256) void k_ola3_gains(const float *__restrict__ fr_h, const float *__restrict__ fr_u,
+                                                    const float *__restrict__ fr_b, const float *__restrict__ win_sq,
+                                                    const float *__restrict__ note_mag, const double *__restrict__ short_s,
+                                                    const int64_t *__restrict__ sample_off, const int64_t *__restrict__ frame_off,
+                                                    int n_notes, int64_t total_samples, int n_fft, int hop,
+                                                    const goofer_note_params *__restrict__ params, const double *__restrict__ steps,
+                                                    float *__restrict__ harm, float *__restrict__ uv, float *__restrict__ bre,
+                                                    float *__restrict__ note_peak)
+{
+    __shared__ int s_pair[2];
+    __shared__ float s_red[4];
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    int lo_n, hi_n;
+    block_note_range(sample_off, n_notes, g0, total_samples, s_pair, lo_n, hi_n);
+    const int64_t g = g0 + threadIdx.x;
+    const bool live = g < total_samples;
+
+    auto body = [&](int note) -> float {
+        const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+        const int64_t i = g - base;
+        const int64_t fbase = frame_off[note];
+        const int64_t T = frame_off[note + 1] - fbase;
+        float h = 0.f, u = 0.f, b = 0.f;
+        if (i < (int64_t)hop * (T - 1)) {
+            const int64_t p = i + n_fft / 2;
+            int64_t lo = p - n_fft + 1;
+            lo = lo <= 0 ? 0 : (lo + hop - 1) / hop;
+            int64_t hi = p / hop;
+            if (hi > T - 1) hi = T - 1;
+            float ws = 0.f;
+            for (int64_t fr = lo; fr <= hi; ++fr) {
+                const int j = (int)(p - fr * hop);
+                const int64_t at = (fbase + fr) * n_fft + j;
+                h += fr_h[at];
+                u += fr_u[at];
+                b += fr_b[at];
+                ws += win_sq[j];
+            }
+            if (ws > 1e-9f) { h /= ws; u /= ws; b /= ws; }
+            h = h / note_mag[note];
+        }
+        const int64_t ns = (n + MASK_DS - 1) / MASK_DS;
+        const float ms = smooth_mask_at(short_s + short_base(sample_off, note), ns, i, n, steps[2 * note], steps[2 * note + 1]);
+        b = (b * ms) * params[note].breath_strength;
+        u = (u * (1.0f - ms)) * params[note].uv_strength;
+        harm[g] = h;
+        uv[g] = u;
+        bre[g] = b;
+        return fabsf((h + u) + b);
+    };
+    if (lo_n == hi_n) {
+        float pk = live ? body(lo_n) : 0.f;
+        pk = wave_max(pk);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = pk;
+        __syncthreads();
+        if (threadIdx.x == 0) atomic_max_pos(note_peak + lo_n, fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])));
+    } else if (live) {
+        int note = lo_n;
+        while (sample_off[note + 1] <= g) ++note;
+        atomic_max_pos(note_peak + note, body(note));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_apply_gain(float *__restrict__ harm, float *__restrict__ uv, float *__restrict__ bre,
                                                     float *__restrict__ rec, float *__restrict__ mix,
                                                     const int64_t *__restrict__ sample_off, int n_notes, int64_t total_samples,
@@ -269,6 +336,22 @@ int launch_apply_gain(goofer_ctx *ctx, float *harm, float *uv, float *bre, float
     if (total_samples <= 0) return GOOFER_OK;
     hipLaunchKernelGGL(k_apply_gain, dim3((unsigned)((total_samples + 1023) / 1024)), dim3(256), 0, st, harm, uv, bre, rec, mix,
                        sample_off, n_notes, total_samples, params, note_peak);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+int launch_ola3_gains(goofer_ctx *ctx, const float *fr_h, const float *fr_u, const float *fr_b, const float *note_mag,
+                      const double *short_s, const int64_t *sample_off, const int64_t *frame_off, int n_notes, int64_t total_samples,
+                      const goofer_note_params *params, double *steps, float *harm, float *uv, float *bre, float *note_peak,
+                      hipStream_t st)
+{
+    if (total_samples <= 0) return GOOFER_OK;
+    const goofer_plan_t &p = ctx->plan;
+    hipLaunchKernelGGL(k_note_steps, dim3((n_notes + 255) / 256), dim3(256), 0, st, sample_off, n_notes, steps);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_ola3_gains, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, st, fr_h, fr_u, fr_b, p.win_sq,
+                       note_mag, short_s, sample_off, frame_off, n_notes, total_samples, p.n_fft, p.hop, params, steps, harm, uv, bre,
+                       note_peak);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

@@ -112,8 +112,11 @@ class Context:
         k = self.lib.goofer_profile_end(self.h, ms.ctypes.data_as(C.c_void_p), 18)
         if k < 0:
             self._check(k)
-        names = [self.lib.goofer_profile_stage_name(i).decode() for i in range(18)]
-        return {"steps": k, "ms": dict(zip(names, ms.tolist()))}
+        names = [self.lib.goofer_profile_stage_name_ex(self.h, i).decode() for i in range(18)]
+        return {"steps": k, "ms": {nm: v for nm, v in zip(names, ms.tolist()) if nm}}
+
+    def set_option(self, name: str, value: int):
+        self._check(self.lib.goofer_set_option(self.h, name.encode(), int(value)))
 
     # -- CSR helpers ---------------------------------------------------------------------------
     def offsets(self, lengths):
@@ -126,11 +129,11 @@ class Context:
         return [1 + int(n) // hop for n in sample_lengths]
 
     # -- single-kernel entry points -------------------------------------------------------------
-    def rfft_frames(self, x, sample_off, frame_off, total_frames: int):
+    def rfft_frames(self, x, sample_off, frame_off, total_frames: int, out=None):
         """x fp32 [N_total] -> complex64 [F_total, n_bins] (gf.stft per note)."""
         nb = self.n_bins
         ldc = nb + 1
-        S = torch.empty((total_frames, ldc), dtype=torch.complex64, device=self.device)
+        S = out if out is not None else torch.empty((total_frames, ldc), dtype=torch.complex64, device=self.device)
         self._check(self.lib.goofer_rfft_frames(self.h, _ptr(x), _ptr(sample_off), _ptr(frame_off), sample_off.numel() - 1,
                                                 total_frames, _ptr(S), ldc, self._stream()))
         return S[:, :nb]

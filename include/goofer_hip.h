@@ -190,6 +190,10 @@ int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *assembly, void
 int goofer_profile_begin(goofer_ctx *ctx, int max_steps);
 int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages);
 const char *goofer_profile_stage_name(int stage);
+const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage);   /* names of the active (fused/modular) path */
+
+/* Options: "fused" 1 (default) = fused per-frame kernels; 0 = one kernel per reference step (A/B parity runs). */
+int goofer_set_option(goofer_ctx *ctx, const char *name, int value);
 
 /* Copy a plan table (0 window, 1 freqs, 2 boost, 3 bright_harm, 4 bright_breath, 5 pulse peak) or an
  * intermediate of the last synth batch to HOST memory; return element count / byte size. Tests only. */

@@ -143,3 +143,19 @@ def test_batch_equals_single_notes_bitwise(ctx):
             b = one[key].cpu().numpy()
             assert np.array_equal(a, b), (i, key)
         o += lens[i]
+
+
+def test_fused_path_equals_modular_path(ctx):
+    """The fused per-frame kernels and the one-kernel-per-step path are the same arithmetic."""
+    from goofer_amd.workload import SynthWorkload
+    wl = SynthWorkload(ctx, 3, [0, 1, 2, 3, 4, 5])
+    ctx.set_option("fused", 1)
+    a = wl.step(want_rec=True)
+    torch.cuda.synchronize()
+    a = {k: a[k].cpu().numpy() for k in ("harm", "uv", "bre", "rec", "mix")}
+    ctx.set_option("fused", 0)
+    b = wl.step(want_rec=True)
+    torch.cuda.synchronize()
+    ctx.set_option("fused", 1)
+    for k in a:
+        assert rms_err(a[k], b[k].cpu().numpy()) < 1e-7, k
