@@ -1,0 +1,203 @@
+"""Resampler front end: the reference's CLI and port-8572 HTTP protocol (SillySampler.py:1187-1275).
+
+  python -m goofer_amd.cli in.wav out.wav pitch velocity flags offset length consonant cutoff volume
+                           modulation !tempo pitch_string          -> render one note, exit 0 / 1
+  python -m goofer_amd.cli                                          -> HTTP server on port 8572
+
+HTTP: ``POST /`` with the 13 arguments joined by single spaces (wav paths may contain spaces) answers
+``200`` (empty) when ``out.wav`` is written or ``500 text/plain`` ``An error occurred.\\n<traceback>``;
+``GET`` answers ``200`` (liveness probe).  Unlike the reference, which renders each request inline in its
+thread, requests that arrive within a few milliseconds are rendered as ONE GPU batch (``BatchCollector``);
+a request that fails (bad flags, missing features, ...) is isolated and does not fail its batch-mates.
+"""
+from __future__ import annotations
+
+import logging
+import sys
+import threading
+import traceback
+from http.server import BaseHTTPRequestHandler, HTTPServer
+from pathlib import Path
+from socketserver import ThreadingMixIn
+
+import numpy as np
+
+from . import sampler as S
+
+HELP = (
+    "Usage:\n"
+    "  SillySampler.py in.wav out.wav pitch velocity flags\n"
+    "           offset(ms) length(ms) consonant(ms) cutoff(ms)\n"
+    "           volume(%) modulation(%) !tempo pitch_string\n\n"
+    "Example:\n"
+    "  SillySampler.py in.wav out.wav C4 100 g0 0 1000 0 700 100 0 !120 AA"
+)
+
+
+class _Pending:
+    __slots__ = ("args", "done", "error")
+
+    def __init__(self, args):
+        self.args, self.done, self.error = args, threading.Event(), None
+
+
+class BatchCollector:
+    """Gathers concurrent render requests and runs them as one device batch."""
+
+    def __init__(self, renderer=None, window_s: float = 0.005, max_batch: int = 4096):
+        self._renderer = renderer
+        self.window_s, self.max_batch = window_s, max_batch
+        self._lock = threading.Condition()
+        self._queue = []
+        self._stop = False
+        self._thread = threading.Thread(target=self._loop, name="goofer-batch", daemon=True)
+        self._thread.start()
+        self.batches = []           # sizes of the batches rendered (observability / tests)
+
+    @property
+    def renderer(self):
+        if self._renderer is None:
+            from .render import Renderer
+            self._renderer = Renderer()
+        return self._renderer
+
+    def submit(self, args) -> None:
+        """Blocks until the note is written; raises what the render raised."""
+        p = _Pending(list(args))
+        with self._lock:
+            self._queue.append(p)
+            self._lock.notify_all()
+        p.done.wait()
+        if p.error is not None:
+            raise p.error
+
+    def close(self):
+        with self._lock:
+            self._stop = True
+            self._lock.notify_all()
+        self._thread.join(5)
+
+    def _loop(self):
+        while True:
+            with self._lock:
+                while not self._queue and not self._stop:
+                    self._lock.wait()
+                if self._stop and not self._queue:
+                    return
+                self._lock.wait(self.window_s)            # let a burst accumulate
+                batch, self._queue = self._queue[:self.max_batch], self._queue[self.max_batch:]
+            self._render(batch)
+
+    def _render(self, batch):
+        from . import core
+        from .render import Source, write_wav
+        jobs, owners = [], []
+        for p in batch:                                    # per-note decode / feature load: errors stay per note
+            try:
+                if len(p.args) < 13:
+                    raise TypeError(f"Expected 13 arguments but got {len(p.args)}")
+                in_file, out_file = Path(p.args[0]), Path(p.args[1])
+                req = S.decode_request(*p.args[2:13])
+                feat = in_file.with_name(f"{in_file.stem}_features.goofy")
+                if not feat.exists():
+                    raise FileNotFoundError(f"{feat} not found (feature extraction from raw audio needs Praat)")
+                env, f0, mask, forms, sr, ylen = core.load_features(feat)
+                jobs.append((Source.from_pack(env, f0, mask, forms, sr, ylen), req))
+                owners.append((p, out_file, sr))
+            except Exception as e:      # noqa: BLE001 - reported to the client as a 500
+                p.error = e
+                p.done.set()
+        groups = {}
+        for j, (job, own) in enumerate(zip(jobs, owners)):
+            groups.setdefault((job[0].sr, job[0].n_fft), []).append(j)
+        for idxs in groups.values():
+            try:
+                outs = self.renderer.render([jobs[j] for j in idxs], seed=int(np.random.SeedSequence().generate_state(1)[0]))
+                results = dict(zip(idxs, outs))
+                errors = {}
+            except Exception:           # noqa: BLE001 - isolate the offender by rendering one by one
+                results, errors = {}, {}
+                for j in idxs:
+                    try:
+                        results[j] = self.renderer.render([jobs[j]])[0]
+                    except Exception as e:   # noqa: BLE001
+                        errors[j] = e
+            self.batches.append(len(idxs))
+            for j in idxs:
+                p, out_file, sr = owners[j]
+                try:
+                    if j in errors:
+                        raise errors[j]
+                    logging.info(f"Writing {out_file}")
+                    write_wav(out_file, results[j], sr)
+                except Exception as e:  # noqa: BLE001
+                    p.error = e
+                p.done.set()
+
+
+class ThreadedHTTPServer(ThreadingMixIn, HTTPServer):
+    daemon_threads = True
+
+
+def make_handler(collector: BatchCollector):
+    class RequestHandler(BaseHTTPRequestHandler):
+        def log_message(self, fmt, *a):                    # keep stdout quiet like the reference's logging level
+            logging.debug(fmt % a)
+
+        def do_GET(self):
+            self.send_response(200)
+            self.end_headers()
+
+        def do_POST(self):
+            body = self.rfile.read(int(self.headers["Content-Length"])).decode("utf-8")
+            try:
+                collector.submit(S.split_arguments(body))
+            except Exception:           # noqa: BLE001
+                self.send_response(500)
+                self.send_header("Content-type", "text/plain")
+                self.end_headers()
+                self.wfile.write(f"An error occurred.\n{traceback.format_exc()}".encode("utf-8"))
+                return
+            self.send_response(200)
+            self.end_headers()
+
+    return RequestHandler
+
+
+def serve(port: int = 8572, collector: BatchCollector | None = None, host: str = ""):
+    collector = collector or BatchCollector()
+    httpd = ThreadedHTTPServer((host, port), make_handler(collector))
+    return httpd, collector
+
+
+def main(argv=None) -> int:
+    logging.basicConfig(format="%(message)s", level=logging.INFO)
+    argv = list(sys.argv[1:] if argv is None else argv)
+    logging.info(f"SillySampler {S.VERSION} (goofer_amd / MI355X)")
+    if not argv:
+        httpd, _ = serve()
+        print("Starting HTTP server on port 8572...")
+        httpd.serve_forever()
+        return 0
+    logging.info(f"Args: {argv} (count={len(argv)})")
+    try:
+        if all(Path(a).suffix.lower() == ".goofy" for a in argv):
+            raise NotImplementedError("the Tk voicing editor is out of scope for the GPU backend")
+        if len(argv) == 1 and Path(argv[0]).exists():
+            raise NotImplementedError("folder feature extraction needs Praat (f0 / formant tracks); run the reference's extractor")
+        if len(argv) < 13:
+            raise TypeError(f"Expected 13 arguments but got {len(argv)}")
+        from .render import GooferResampler
+        GooferResampler(*argv[:13])
+    except TypeError as e:
+        logging.error("Argument parsing failed: %s", str(e))
+        logging.error(HELP)
+        return 1
+    except Exception:                   # noqa: BLE001
+        logging.exception("Failed to render")
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

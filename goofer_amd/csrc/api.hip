@@ -27,10 +27,11 @@ int launch_warp_bins(goofer_ctx *, const float *, float *, int64_t, int, int, co
 int launch_knot_decode(goofer_ctx *, const uint16_t *, int, int64_t, const int *, const float *, const float *, float *, int, int,
                        hipStream_t);
 int launch_harm_shape(goofer_ctx *, float2 *, int, int64_t, const int *, const int64_t *, const int64_t *, const float *,
-                      const float *, const float *, int, const goofer_note_params *, float *, hipStream_t);
+                      const float *, const float *, int, const goofer_note_params *, float *, const int64_t *, const double *,
+                      hipStream_t);
 int launch_noise_spectra(goofer_ctx *, float2 *, float2 *, int, int64_t, const int *, const int64_t *, const int64_t *,
                          const float *, const float *, const float *, const float *, int, const goofer_note_params *, uint64_t,
-                         hipStream_t);
+                         const int64_t *, hipStream_t);
 int launch_mask_short(goofer_ctx *, const float *, const int64_t *, int, int64_t, const double *, int, double *, hipStream_t);
 int launch_assemble(goofer_ctx *, const goofer_assembly *, int *, int *, hipStream_t);
 int launch_ola3_gains(goofer_ctx *, const float *, const float *, const float *, const float *, const double *, const int64_t *,
@@ -328,7 +329,7 @@ int64_t goofer_debug_fetch(goofer_ctx *ctx, int which, void *host_out, int64_t c
 }
 
 static const char *const PROF_NAMES[PROF_STAGES] = {
-    "setup_maps", "gauss_env", "warp_env", "phase_inc", "pulse_onsets", "pulse_place", "rfft_frames", "harm_shape",
+    "setup_maps", "", "", "phase_inc", "pulse_onsets", "pulse_place", "rfft_frames", "harm_shape",
     "irfft_harm", "noise_spectra", "irfft_breath", "irfft_unvoiced", "mask_short", "ola3_gains", "apply_gain", "", "", ""};
 
 // Per-stage timing of goofer_synth_batch with HIP events recorded on the caller's stream (so the
@@ -616,11 +617,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     hipLaunchKernelGGL(k_scale_f0, dim3(sb), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s);
     LAUNCH_CHECK(ctx);
     MARK();   // 1: noise envelope = sigma-1.75 blur of the un-warped rows (GOOFER.py:993)
-    if (!ctx->fused && (rc = launch_gauss_bins(ctx, b->env, env_n, F, p.n_bins, ld, p.blur175, 7, row_src, st))) return rc;
+    // (folded into k_noise_spectra / k_harm_shape: the standalone envelope kernels remain as C-ABI entry points)
     MARK();   // 2: harmonic envelope = formant-anchored + uniform warp
-    if (!ctx->fused &&
-        (rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, st)))
-        return rc;
+
     MARK();   // 3..5: pulse train
     if ((rc = launch_phase_inc(ctx, f0s, 1.0f, N, inc, st))) return rc;
     MARK();
@@ -641,14 +640,14 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         MARK();   // 6: framewise rFFT of the pulse train
         if ((rc = launch_rfft_frames_mapped(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, st))) return rc;
         MARK();   // 7
-        if ((rc = launch_harm_shape(ctx, S_h, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, env_h, ld, b->params,
-                                    note_mag, st)))
+        if ((rc = launch_harm_shape(ctx, S_h, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, b->env, ld, b->params,
+                                    note_mag, row_src, b->formants, st)))
             return rc;
         MARK();   // 8
         if ((rc = launch_irfft_frames(ctx, S_h, ldc, F, frames, st))) return rc;
         MARK();   // 9: aperiodic spectra
-        if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, env_n, b->phi, ld,
-                                       b->params, b->seed, st)))
+        if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, b->env, b->phi,
+                                       ld, b->params, b->seed, row_src, st)))
             return rc;
         MARK();   // 10, 11
         if ((rc = launch_irfft_frames(ctx, S_br, ldc, F, frames_b, st))) return rc;

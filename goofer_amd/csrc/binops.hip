@@ -148,14 +148,18 @@ __global__ __launch_bounds__(256) void k_harm_shape(float2 *__restrict__ S, int 
                                                     const goofer_note_params *__restrict__ params, float *__restrict__ note_mag,
                                                     const float *__restrict__ freqs, const float *__restrict__ boost,
                                                     const float *__restrict__ bright, const double *__restrict__ taps5,
-                                                    int n_bins, int hop)
+                                                    int n_bins, int hop, const int64_t *__restrict__ row_src,
+                                                    const double *__restrict__ formants, double nyq)
 {
+    // env is either the already-warped [frames x ld] matrix (row_src == nullptr) or the source rows, in which
+    // case the formant-anchored + uniform warp (GOOFER.py:1004-1017) runs here on the LDS row.
     extern __shared__ __align__(16) unsigned char smem[];
-    float2 *s_rows = reinterpret_cast<float2 *>(smem);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t f = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
     if (f >= total_frames) return;
-    float2 *r = s_rows + wave * n_bins;
+    const int rowf = (n_bins + 1) & ~1;                           // floats per fp32 row (even)
+    float2 *r = reinterpret_cast<float2 *>(smem) + (size_t)wave * (n_bins + rowf);
+    float *ra = reinterpret_cast<float *>(r + n_bins), *rb = ra + rowf;
     const int note = frame_note[f];
     const goofer_note_params p = params[note];
     const int64_t t = f - frame_off[note];
@@ -169,6 +173,19 @@ __global__ __launch_bounds__(256) void k_harm_shape(float2 *__restrict__ S, int 
 
     float2 *row = S + f * (int64_t)ldc;
     const float *er = env + f * (int64_t)ld;
+    if (row_src) {
+        const int64_t src = row_src[f];
+        const float *sr_ = env + src * (int64_t)ld;
+        for (int b = lane; b < n_bins; b += WAVE) ra[b] = sr_[b];
+        wave_lds_sync();
+        double fs[4];
+        bool warp = false;
+        for (int k = 0; k < 4; ++k) {
+            fs[k] = p.f_shift[k];
+            warp |= fs[k] != 1.0;
+        }
+        er = warp_row(ra, rb, n_bins, nyq, formants ? formants + src * 4 : nullptr, fs, warp, (double)p.formant_shift, lane, 0);
+    }
     float mx = 0.f;
     for (int k = lane; k < n_bins; k += WAVE) {
         float2 s = row[k];
@@ -195,13 +212,16 @@ __global__ __launch_bounds__(256) void k_harm_shape(float2 *__restrict__ S, int 
 
 int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames, const int *frame_note, const int64_t *frame_off,
                       const int64_t *sample_off, const float *f0, const float *mask, const float *env, int ld,
-                      const goofer_note_params *params, float *note_mag, hipStream_t st)
+                      const goofer_note_params *params, float *note_mag, const int64_t *row_src, const double *formants,
+                      hipStream_t st)
 {
     if (total_frames <= 0) return GOOFER_OK;
     const goofer_plan_t &pl = ctx->plan;
+    const int rowf = (pl.n_bins + 1) & ~1;
     hipLaunchKernelGGL(k_harm_shape, dim3((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256),
-                       sizeof(float2) * ROWS_PER_BLOCK * pl.n_bins, st, S, ldc, total_frames, frame_note, frame_off, sample_off, f0,
-                       mask, env, ld, params, note_mag, pl.freqs, pl.boost, pl.bright_h, pl.blur5, pl.n_bins, pl.hop);
+                       sizeof(float2) * ROWS_PER_BLOCK * (pl.n_bins + rowf), st, S, ldc, total_frames, frame_note, frame_off,
+                       sample_off, f0, mask, env, ld, params, note_mag, pl.freqs, pl.boost, pl.bright_h, pl.blur5, pl.n_bins, pl.hop,
+                       row_src, formants, (double)pl.sr / 2.0);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
@@ -215,14 +235,18 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
                                                        const float *__restrict__ env_noise, const float *__restrict__ phi, int ld,
                                                        const goofer_note_params *__restrict__ params, uint64_t seed,
                                                        const float *__restrict__ freqs, const float *__restrict__ bright,
-                                                       const double *__restrict__ taps5, int n_bins, int hop)
+                                                       const double *__restrict__ taps5, int n_bins, int hop,
+                                                       const int64_t *__restrict__ row_src, const double *__restrict__ taps175)
 {
+    // env_noise is either the already-blurred [frames x ld] matrix (row_src == nullptr) or the source rows, in
+    // which case the sigma-1.75 bin blur (GOOFER.py:993) runs here from the LDS row.
     extern __shared__ __align__(16) unsigned char smem[];
-    float2 *s_rows = reinterpret_cast<float2 *>(smem);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t f = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
     if (f >= total_frames) return;
-    float2 *r = s_rows + wave * n_bins;
+    const int rowf = (n_bins + 1) & ~1;
+    float2 *r = reinterpret_cast<float2 *>(smem) + (size_t)wave * (n_bins + rowf / 2 + 1);
+    float *ra = reinterpret_cast<float *>(r + n_bins);
     const int note = frame_note[f];
     const goofer_note_params p = params[note];
     const int64_t t = f - frame_off[note];
@@ -237,6 +261,11 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
     const float *er = env_noise + f * (int64_t)ld;
     float2 *ru = S_uv + f * (int64_t)ldc;
     float2 *rb = S_br + f * (int64_t)ldc;
+    if (row_src) {
+        const float *sr_ = env_noise + row_src[f] * (int64_t)ld;
+        for (int b = lane; b < n_bins; b += WAVE) ra[b] = sr_[b];
+        wave_lds_sync();
+    }
     for (int k = lane; k < n_bins; k += WAVE) {
         float ph;
         if (phi) {
@@ -247,7 +276,19 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
             ph = (float)(u >> 8) * (6.283185307179586f / 16777216.0f);
         }
         float c = cosf(ph), s = sinf(ph);
-        float e = er[k];
+        float e;
+        if (row_src) {
+            double acc = 0.0;
+            if (k >= 7 && k + 7 < n_bins) {
+#pragma unroll
+                for (int j = 0; j < 15; ++j) acc += taps175[j] * (double)ra[k + j - 7];
+            } else {
+                for (int j = 0; j < 15; ++j) acc += taps175[j] * (double)ra[reflect_index(k + j - 7, n_bins)];
+            }
+            e = (float)acc;
+        } else {
+            e = er[k];
+        }
         float2 u = make_float2(c * e, s * e);
         ru[k] = u;
         float h = hp_mask(freqs[k], f0f);
@@ -266,13 +307,15 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
 int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, int64_t total_frames, const int *frame_note,
                          const int64_t *frame_off, const int64_t *sample_off, const float *f0, const float *mask,
                          const float *env_noise, const float *phi, int ld, const goofer_note_params *params, uint64_t seed,
-                         hipStream_t st)
+                         const int64_t *row_src, hipStream_t st)
 {
     if (total_frames <= 0) return GOOFER_OK;
     const goofer_plan_t &pl = ctx->plan;
+    const int rowf = (pl.n_bins + 1) & ~1;
     hipLaunchKernelGGL(k_noise_spectra, dim3((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256),
-                       sizeof(float2) * ROWS_PER_BLOCK * pl.n_bins, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,
-                       sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins, pl.hop);
+                       sizeof(float2) * ROWS_PER_BLOCK * (pl.n_bins + rowf / 2 + 1), st, S_uv, S_br, ldc, total_frames, frame_note,
+                       frame_off, sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins,
+                       pl.hop, row_src, pl.blur175);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

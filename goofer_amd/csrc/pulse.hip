@@ -233,24 +233,93 @@ __global__ __launch_bounds__(64) void k_onset_finish(const float *__restrict__ f
     }
 }
 
+// One workgroup = 1024 consecutive samples (4 per thread).  When the tile lies inside one note (almost
+// always) the onsets that can touch it — first onset whose running end_max passes the tile start, up to
+// the last onset starting inside the tile — are staged once in LDS; every sample then scans that short
+// list in ascending onset order (the reference's accumulation order).  Other tiles (note boundaries, or
+// more onsets than the LDS list holds) take the per-sample search of the compact list in global memory.
+#define PP_SPT 4
+#define PP_MAXON 512
+
+__device__ __forceinline__ float pulse_value(const onset_t &o, int j, const float *__restrict__ peak)
+{
+    const int d = j - o.i;
+    if (d < 0 || d >= o.T0) return 0.f;
+    const float raw = lf_raw(d, o.T0, o.T);
+    const double m = (double)peak[o.T0];
+    return m > 0.0 ? (float)((double)raw / m) : raw;
+}
+
 __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__ onsets, const int32_t *__restrict__ onset_cnt,
                                                      const float *__restrict__ peak, const int64_t *__restrict__ sample_off,
                                                      int n_notes, int64_t total_samples, float *__restrict__ pulse)
 {
     __shared__ int s_pair[2];
-    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
-    int lo_n, hi_n;
-    block_note_range(sample_off, n_notes, g0, total_samples, s_pair, lo_n, hi_n);
-    const int64_t g = g0 + threadIdx.x;
-    if (g >= total_samples) return;
-
-    auto body = [&](int note) {
+    __shared__ int s_rng[2];
+    __shared__ onset_t s_on[PP_MAXON];
+    const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x * PP_SPT);
+    if (threadIdx.x == 0) {
+        s_pair[0] = csr_find(sample_off, n_notes, g0);
+        int64_t gl = g0 + (int64_t)blockDim.x * PP_SPT - 1;
+        if (gl > total_samples - 1) gl = total_samples - 1;
+        s_pair[1] = csr_find(sample_off, n_notes, gl);
+        s_rng[0] = 0;
+        s_rng[1] = -1;
+        if (s_pair[0] == s_pair[1]) {
+            const int note = s_pair[0];
+            const int64_t base = sample_off[note];
+            const onset_t *ol = onsets + (base / 2 + 16 * (int64_t)note);
+            const int cnt = onset_cnt[note];
+            const int32_t j_lo = (int32_t)(g0 - base), j_hi = (int32_t)(gl - base);
+            int lo = -1, hi = cnt;                      // last onset with i <= j_hi
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (ol[mid].i <= j_hi) lo = mid; else hi = mid;
+            }
+            const int last = lo;
+            lo = -1; hi = cnt;                          // first onset with end_max > j_lo (end_max is monotone)
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (ol[mid].end_max > j_lo) hi = mid; else lo = mid;
+            }
+            s_rng[0] = hi;
+            s_rng[1] = last;
+        }
+    }
+    __syncthreads();
+    const int lo_n = __builtin_amdgcn_readfirstlane(s_pair[0]), hi_n = __builtin_amdgcn_readfirstlane(s_pair[1]);
+    const int k0 = __builtin_amdgcn_readfirstlane(s_rng[0]), k1 = __builtin_amdgcn_readfirstlane(s_rng[1]);
+    const int nk = k1 - k0 + 1;
+    if (lo_n == hi_n && nk <= PP_MAXON) {
+        const int64_t base = sample_off[lo_n];
+        const onset_t *ol = onsets + (base / 2 + 16 * (int64_t)lo_n);
+        for (int k = threadIdx.x; k < nk; k += blockDim.x) s_on[k] = ol[k0 + k];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PP_SPT; ++u) {
+            const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;      // coalesced: stride blockDim between a thread's samples
+            if (g >= total_samples) break;
+            const int32_t j = (int32_t)(g - base);
+            float acc = 0.f;
+            for (int k = 0; k < nk; ++k) {
+                if (s_on[k].i > j) break;                                        // sorted by onset sample
+                acc += pulse_value(s_on[k], j, peak);
+            }
+            pulse[g] = acc;
+        }
+        return;
+    }
+    for (int u = 0; u < PP_SPT; ++u) {
+        const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
+        if (g >= total_samples) break;
+        int note = lo_n;
+        while (sample_off[note + 1] <= g) ++note;
         const int64_t base = sample_off[note];
         const int32_t j = (int32_t)(g - base);
         const onset_t *ol = onsets + (base / 2 + 16 * (int64_t)note);
         const int cnt = onset_cnt[note];
         float acc = 0.f;
-        int lo = -1, hi = cnt;   // last onset with i <= j:  ol[lo].i <= j < ol[hi].i
+        int lo = -1, hi = cnt;   // last onset with i <= j
         while (hi - lo > 1) {
             int mid = (lo + hi) >> 1;
             if (ol[mid].i <= j) lo = mid; else hi = mid;
@@ -258,25 +327,9 @@ __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__
         if (lo >= 0) {
             int first = lo;
             while (first > 0 && ol[first - 1].end_max > j) --first;
-            for (int k = first; k <= lo; ++k) {
-                onset_t o = ol[k];
-                int d = j - o.i;
-                if (d < o.T0) {
-                    float raw = lf_raw(d, o.T0, o.T);
-                    double m = (double)peak[o.T0];
-                    float v = m > 0.0 ? (float)((double)raw / m) : raw;
-                    acc += v;
-                }
-            }
+            for (int k = first; k <= lo; ++k) acc += pulse_value(ol[k], j, peak);
         }
         pulse[g] = acc;
-    };
-    if (lo_n == hi_n) {
-        body(lo_n);
-    } else {
-        int note = lo_n;
-        while (sample_off[note + 1] <= g) ++note;
-        body(note);
     }
 }
 
@@ -319,7 +372,7 @@ int launch_pulse_place(goofer_ctx *ctx, const onset_t *onsets, const int32_t *on
                        int64_t total_samples, float *pulse, hipStream_t st)
 {
     if (total_samples <= 0) return GOOFER_OK;
-    hipLaunchKernelGGL(k_pulse_place, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, st, onsets, onset_cnt,
+    hipLaunchKernelGGL(k_pulse_place, dim3((unsigned)((total_samples + 1023) / 1024)), dim3(256), 0, st, onsets, onset_cnt,
                        ctx->plan.pulse_peak, sample_off, n_notes, total_samples, pulse);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;

@@ -1,0 +1,79 @@
+"""Resampler front end: CLI exit codes (CPU) and the port-8572 HTTP protocol with batching (GPU)."""
+import http.client
+import threading
+import wave
+
+import numpy as np
+import pytest
+
+from goofer_amd import cli
+from goofer_amd import sampler as S
+from goofer_amd import synthetic as syn
+
+
+def test_cli_argument_errors_exit_1(caplog):
+    assert cli.main(["a.wav", "b.wav", "C4"]) == 1            # < 13 args -> TypeError -> help, exit 1
+    assert "Expected 13 arguments but got 3" in caplog.text
+    assert cli.main(["x_features.goofy"]) == 1                # editor mode: out of scope, loud
+    # a bare flag letter crashes the flag arithmetic with TypeError exactly like the reference
+    assert cli.main(["a.wav", "b.wav", "C4", "100", "g", "0", "1000", "0", "0", "100", "0", "!120", "AA"]) == 1
+
+
+def test_split_arguments_keeps_spaces_in_paths():
+    from conftest import golden
+    g = golden("flags_pitch")
+    assert S.split_arguments(str(g["split_in"][0])) == [str(v) for v in g["split_out"]]      # the reference's own answer
+    with pytest.raises(ValueError):
+        S.split_arguments("only_one.wav C4 100 g0 0 1000 0 700 100 0 !120 AA")
+
+
+@pytest.mark.gpu
+def test_http_server_batches_concurrent_requests(tmp_path):
+    torch = pytest.importorskip("torch")
+    from goofer_amd import core
+    from goofer_amd.device import Context
+    from goofer_amd.render import Renderer
+    ctx = Context(0)
+    collector = cli.BatchCollector(Renderer(ctx), window_s=0.25)
+    httpd, _ = cli.serve(0, collector, host="127.0.0.1")
+    port = httpd.server_address[1]
+    th = threading.Thread(target=httpd.serve_forever, daemon=True)
+    th.start()
+    try:
+        bodies = []
+        for i in range(6):
+            src = syn.make_source(100 + i, seconds=0.4)
+            wav = tmp_path / f"s{i}.wav"
+            core.save_features(wav.with_name(f"s{i}_features.goofy"), src["env_pack"], src["f0"], src["mask"], src["formants"],
+                               src["sr"], src["y_len"])
+            req = syn.make_request(100 + i, ["t0g0", "g30", "L1", "fa20fb-10", "br30", "V80B10"][i], length_ms=200 + 40 * i)
+            bodies.append(" ".join([str(wav), str(tmp_path / f"o{i}.wav")] + syn.request_args(req)))
+        bodies.append(" ".join([str(tmp_path / "missing.wav"), str(tmp_path / "bad.wav")] + syn.request_args(req)))   # no features
+        status = [None] * len(bodies)
+        text = [None] * len(bodies)
+
+        def post(k):
+            c = http.client.HTTPConnection("127.0.0.1", port, timeout=120)
+            c.request("POST", "/", body=bodies[k].encode("utf-8"))
+            r = c.getresponse()
+            status[k], text[k] = r.status, r.read().decode()
+            c.close()
+
+        ts = [threading.Thread(target=post, args=(k,)) for k in range(len(bodies))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(180)
+        assert status[:6] == [200] * 6 and all(t == "" for t in text[:6])
+        assert status[6] == 500 and text[6].startswith("An error occurred.\n") and "FileNotFoundError" in text[6]
+        assert max(collector.batches) >= 2                    # concurrent requests shared a device batch
+        for i in range(6):
+            with wave.open(str(tmp_path / f"o{i}.wav"), "rb") as w:
+                assert w.getframerate() == 44100 and w.getnframes() == int(0.1 * 44100) + int((0.2 + 0.04 * i) * 44100)
+        c = http.client.HTTPConnection("127.0.0.1", port, timeout=30)
+        c.request("GET", "/")
+        assert c.getresponse().status == 200
+    finally:
+        httpd.shutdown()
+        collector.close()
+        ctx.close()

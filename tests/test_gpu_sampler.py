@@ -98,3 +98,35 @@ def test_resampler_call_surface(renderer, tmp_path):
     assert n == len(r.out) == len(golden("sampler_default")["out"])
     with pytest.raises(FileNotFoundError):
         GooferResampler(str(tmp_path / "none.wav"), str(out), *syn.request_args(req), renderer=renderer)
+
+
+@pytest.mark.parametrize("config,ids", [(4, [0, 1, 2, 5, 7]), (5, [0, 1, 2]), (2, [0, 1, 2, 3]), (3, [0, 1])])
+def test_baseline_config_notes_vs_oracle(config, ids):
+    """Notes of the BASELINE configs (incl. 96 kHz / n_fft 2048 / hop 96 with br+es, and L0/L1/L2 with random
+    lengths) rendered as one batch vs the CPU oracle's full render, same injected phases."""
+    from goofer_amd.device import Context
+    from goofer_amd.render import Renderer, Source
+    from goofer_amd import sampler as S
+    from oracle import sampler_ref as SR
+    geo = syn.config_geometry(config)
+    ctx = Context(0)
+    try:
+        r = Renderer(ctx, hop=geo["hop"])
+        jobs, refs, seeds = [], [], []
+        for i in ids:
+            src, req, phi_seed = syn.config_note(config, i)
+            if config == 5:
+                req = dict(req, length="300")             # keep the CPU oracle quick at 1001 frames/s
+            jobs.append((Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]),
+                         S.decode_request(*syn.request_args(req))))
+            feats = (src["env_pack"], src["f0"].copy(), src["mask"].copy(), {k: v.copy() for k, v in src["formants"].items()},
+                     src["sr"], src["y_len"])
+            refs.append(SR.render(feats, SR.decode_request(*syn.request_args(req)), seed=phi_seed, n_fft=geo["n_fft"], hop=geo["hop"]))
+            seeds.append(phi_seed)
+        outs = r.render(jobs, phi_seeds=seeds)
+        for i, o, ref in zip(ids, outs, refs):
+            assert o.shape == ref.shape
+            e = rms_err(o, ref) / max(1.0, float(np.max(np.abs(ref))))
+            assert e < 2e-5, (config, i, e)
+    finally:
+        ctx.close()
