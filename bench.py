@@ -48,6 +48,25 @@ def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int) ->
     return float(table[stage])
 
 
+STAGE_KERNEL = {"rfft_frames": "void k_rfft_frames<512>", "rfft_frames_standalone": "void k_rfft_frames<512>",
+                "irfft_harm": "void k_irfft_frames<512>", "harm_shape": "k_harm_shape", "noise_spectra": "k_noise_spectra",
+                "ola3_gains": "k_ola3_gains", "apply_gain": "k_apply_gain", "pulse_onsets": "k_pulse_onsets",
+                "pulse_place": "k_pulse_place", "mask_short": "k_mask_short", "phase_inc": "k_phase_inc"}
+
+
+def pmc_traffic(stage, frames):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json), with the
+    gfx950 FETCH_SIZE correction; None when no matching measurement exists for this workload size."""
+    try:
+        d = json.load(open(os.path.join(HERE, "profiles", "r01_pmc_traffic.json")))
+        k = d["kernels"][STAGE_KERNEL[stage]]
+        if d["_meta"]["frames"] != frames:
+            return None
+        return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(wl, hop, budget_s=15.0, min_notes=4):
     """Oracle (CPU port of the reference path, oracle/) on the same notes — the full render the reference does
     per note: decode features, assemble, synthesize, mix — single thread, bounded sample."""
@@ -162,7 +181,7 @@ def main():
             ms = per[stage]
             a = stage_alg_bytes(stage, wl.frames, wl.samples, B, hop, n_fft) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             return {"kernel": stage, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": a / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms,
+                    "frac": a / HBM_PEAK_GBS, "traffic": pmc_traffic(stage, wl.frames), "ms_per_launch": ms,
                     "alg_bytes_per_launch": stage_alg_bytes(stage, wl.frames, wl.samples, B, hop, n_fft)}
 
         line = {
