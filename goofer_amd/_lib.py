@@ -82,6 +82,12 @@ EXPORTS = {
     "goofer_knot_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                      C.c_void_p]),
     "goofer_synth_batch": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_void_p]),
+    "goofer_mag_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "goofer_gauss_bins_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                                        C.c_int, C.c_void_p]),
+    "goofer_knot_fit_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
+    "goofer_knot_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goofer_debug_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "goofer_debug_fetch": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "goofer_sizeof": (C.c_int, [C.c_int]),

@@ -132,6 +132,88 @@ def gaussian_taps(sigma, truncate=4.0):
     return k / k.sum()
 
 
+# -- analysis: the half of extract_features that is not Praat (GOOFER.py:940-969, 97-147) ------------------
+def make_mel_knots(sr, n_fft, K):
+    """(bin freqs fp32, mel-spaced knot Hz fp32) — the codec's knot grid (GOOFER.py:77-82)."""
+    from .synthetic import mel_knots_hz
+    return np.fft.rfftfreq(n_fft, 1.0 / sr).astype(np.float32), mel_knots_hz(sr, K)
+
+
+def compress_env_to_knots(env_spec, sr, n_fft, eps=1e-2, K_start=32, K_step=16, K_max=192, smooth_sigma_bins=0.5, ctx=None,
+                          _rows=None):
+    """Smallest mel-knot count whose 2-tap lerp reproduces the (sigma 0.5 blurred) envelope to < eps max relative
+    error on <= 256 probe frames; knots sampled at the nearest bin, log, fp16.  Blur, error metric and knot
+    gather run on the device; the loop over the 9 candidate K is host logic."""
+    c = _ctx(sr, n_fft, n_fft // 4, ctx)
+    rows = _rows if _rows is not None else c.rows_from(np.asarray(env_spec, dtype=np.float32).T)
+    T, nb = rows.shape
+    taps = gaussian_taps(smooth_sigma_bins) if smooth_sigma_bins > 0 and int(4.0 * smooth_sigma_bins + 0.5) > 0 else np.ones(1)
+    env2 = c.gauss_bins_f64(rows, taps)
+    probe = c.tensor(np.linspace(0, T - 1, min(256, T), dtype=int).astype(np.int64))
+    res = sr / n_fft
+    chosen = None
+    for K in list(range(K_start, K_max + 1, K_step)) + [None]:
+        last = K is None
+        _, hz = make_mel_knots(sr, n_fft, K_max if last else K)
+        at = np.clip(np.round(hz / res).astype(int), 0, nb - 1).astype(np.int32)
+        d_at = c.tensor(at)
+        if not last and not (c.knot_fit_error(env2, probe, d_at, hz) < eps):
+            continue
+        vals = c.knot_gather(env2, d_at).cpu().numpy().T
+        chosen = {"mode": "knots", "knot_vals_log": np.ascontiguousarray(vals), "hz_knots": hz.astype(np.float32),
+                  "n_bins": int(nb), "n_fft": int(n_fft), "sr": int(sr)}
+        break
+    return chosen
+
+
+def envelope_features(y, sr, n_fft=1024, hop_length=256, ctx=None):
+    """(env_spec fp64 [bins, T], env_knots) = |stft| + 1e-8 -> sigma-2 bin blur -> knot encode (GOOFER.py:942-946, 968)."""
+    c = _ctx(sr, n_fft, hop_length, ctx)
+    y = np.asarray(y, dtype=np.float32)
+    n = len(y)
+    T = 1 + n // hop_length
+    S = c.rfft_frames(c.tensor(y), c.tensor(np.array([0, n], dtype=np.int64)), c.tensor(np.array([0, T], dtype=np.int64)), T)
+    env_rows = c.gauss_bins_f64(c.mag_rows(S), gaussian_taps(2.0))
+    env_spec = np.ascontiguousarray(env_rows.cpu().numpy().T)
+    rows32 = c.rows(T, c.n_bins)
+    rows32.copy_(env_rows.to(torch.float32))                  # to_compute(env_spec)
+    return env_spec, compress_env_to_knots(None, sr, n_fft, ctx=c, _rows=rows32)
+
+
+def extract_features(y, sr, n_fft=1024, hop_length=256, f0_min=75, f0_max=600, f0_merge_range=2, pitch_tracker=None, ctx=None):
+    """gf.extract_features (GOOFER.py:940-969).  The envelope half runs on the GPU; f0 and formant tracks come from
+    ``pitch_tracker(y, sr, hop_length, n_frames) -> (f0_track [frames], formants {1..5: [frames]})`` because the
+    reference computes them with Praat (third-party, unpinned: SURVEY §8 c) — without one this raises."""
+    if pitch_tracker is None:
+        raise NotImplementedError("f0 / formant tracking needs Praat in the reference; pass pitch_tracker= to supply the tracks")
+    env_spec, env_knots = envelope_features(y, sr, n_fft, hop_length, ctx=ctx)
+    n_frames = env_spec.shape[1]
+    f0_track, formants = pitch_tracker(np.asarray(y), sr, hop_length, n_frames)
+    f0_track = np.nan_to_num(np.asarray(f0_track, dtype=np.float64))
+    i, nfr = 0, len(f0_track)                                  # fix_f0_gaps(max_gap): bridge short zero runs (GOOFER.py:415-435)
+    fixed = f0_track.copy()
+    while i < nfr:
+        if fixed[i] == 0.0:
+            a = i
+            while i < nfr and fixed[i] == 0.0:
+                i += 1
+            gap = i - a
+            if a > 0 and i < nfr and gap <= f0_merge_range:
+                for j in range(gap):
+                    r = (j + 1) / (gap + 1)
+                    fixed[a + j] = fixed[a - 1] * (1 - r) + fixed[i] * r
+        else:
+            i += 1
+    t_f0 = np.linspace(0, len(y) / sr, num=len(fixed))
+    t_s = np.linspace(0, len(y) / sr, num=len(y))
+    inside = (t_s >= t_f0[0]) & (t_s <= t_f0[-1])
+    f0_interp = np.zeros(len(y))
+    f0_interp[inside] = np.interp(t_s[inside], t_f0, fixed)
+    f0_interp = np.clip(f0_interp, 1e-5, 2000)
+    voicing_mask = (f0_interp > f0_min).astype(float)
+    return env_spec, f0_interp, voicing_mask, formants, env_knots
+
+
 # -- synthesize --------------------------------------------------------------------------------------
 def _fit(x, T):
     x = np.asarray(x, dtype=np.float64)

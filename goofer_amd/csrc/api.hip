@@ -34,6 +34,11 @@ int launch_noise_spectra(goofer_ctx *, float2 *, float2 *, int, int64_t, const i
                          const int64_t *, hipStream_t);
 int launch_mask_short(goofer_ctx *, const float *, const int64_t *, int, int64_t, const double *, int, double *, hipStream_t);
 int launch_assemble(goofer_ctx *, const goofer_assembly *, int *, int *, hipStream_t);
+int launch_mag_rows(goofer_ctx *, const float2 *, int, int64_t, int, float *, int, hipStream_t);
+int launch_gauss_rows64(goofer_ctx *, const float *, int, double *, int, int64_t, int, const double *, int, hipStream_t);
+int launch_knot_error(goofer_ctx *, const double *, int, const int64_t *, int, int, const int *, int, const int *, const float *,
+                      const float *, unsigned long long *, hipStream_t);
+int launch_knot_gather(goofer_ctx *, const double *, int, int64_t, const int *, int, uint16_t *, hipStream_t);
 int launch_ola3_gains(goofer_ctx *, const float *, const float *, const float *, const float *, const double *, const int64_t *,
                       const int64_t *, int, int64_t, const goofer_note_params *, double *, float *, float *, float *, float *, hipStream_t);
 int launch_harm_frames(goofer_ctx *, const float *, const goofer_batch *, const float *, const int *, const int64_t *, float *, float *,
@@ -507,6 +512,77 @@ int goofer_knot_decode(goofer_ctx *ctx, const uint16_t *knots_f16, int K, const 
     HIP_TRY(ctx, hipMemcpyAsync(d_w1, w1.data(), n_bins * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));   // the host vectors die at return
     return launch_knot_decode(ctx, knots_f16, K, rows, d_idx, d_w0, d_w1, env, n_bins, ld, st);
+}
+
+static void knot_lerp_plan(const goofer_plan_t &p, const float *hz_knots, int K, int n_bins, std::vector<int> &idx,
+                           std::vector<float> &w0, std::vector<float> &w1)
+{
+    // 2-tap lerp plan, fp32 arithmetic like precompute_interp_matrix (GOOFER.py:84-90)
+    idx.resize(n_bins); w0.resize(n_bins); w1.resize(n_bins);
+    double val = 1.0 / ((double)p.n_fft * (1.0 / (double)p.sr));
+    for (int b = 0; b < n_bins; ++b) {
+        float f = (float)((double)b * val);
+        int i = (int)(std::upper_bound(hz_knots, hz_knots + K, f) - hz_knots) - 1;   // searchsorted(side='right') - 1
+        i = std::min(std::max(i, 0), K - 2);
+        float x0 = hz_knots[i], x1 = hz_knots[i + 1];
+        float den = std::max(x1 - x0, 1e-12f);
+        float b1 = (f - x0) / den;
+        idx[b] = i; w1[b] = b1; w0[b] = 1.0f - b1;
+    }
+}
+
+int goofer_mag_rows(goofer_ctx *ctx, const float *S, int ldc, int64_t rows, int n_bins, float *mag, int ld, void *stream)
+{
+    if (!ctx) return GOOFER_EINVAL;
+    if (ldc < n_bins || ld < n_bins) return goofer_fail(ctx, GOOFER_EINVAL, "bad strides");
+    return launch_mag_rows(ctx, (const float2 *)S, ldc, rows, n_bins, mag, ld, (hipStream_t)stream);
+}
+
+int goofer_gauss_bins_f64(goofer_ctx *ctx, const float *in, int ld, double *out, int ld64, int64_t rows, int n_bins,
+                          const double *taps, int radius, void *stream)
+{
+    if (!ctx) return GOOFER_EINVAL;
+    if (radius < 0 || radius > 4096 || ld < n_bins || ld64 < n_bins) return goofer_fail(ctx, GOOFER_EINVAL, "bad gauss geometry");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_small(ctx, 65536);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->small, taps, (2 * radius + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+    return launch_gauss_rows64(ctx, in, ld, out, ld64, rows, n_bins, (const double *)ctx->small, radius, st);
+}
+
+int goofer_knot_fit_error(goofer_ctx *ctx, const double *env, int ld64, const int64_t *probe_rows, int n_probe, int n_bins,
+                          const int32_t *knot_bin, int K, const float *hz_knots, double *max_rel_err, void *stream)
+{
+    NEED_PLAN(ctx);
+    if (K < 2 || K > 4096 || !max_rel_err) return goofer_fail(ctx, GOOFER_EINVAL, "bad knot count %d", K);
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int> idx;
+    std::vector<float> w0, w1;
+    knot_lerp_plan(ctx->plan, hz_knots, K, n_bins, idx, w0, w1);
+    int rc = ensure_small(ctx, 65536);
+    if (rc) return rc;
+    if ((size_t)n_bins * 12 + 64 > 32768) return goofer_fail(ctx, GOOFER_EINVAL, "n_bins too large");
+    char *d = (char *)ctx->small;
+    int *d_idx = (int *)d;
+    float *d_w0 = (float *)(d + 4 * (size_t)n_bins), *d_w1 = (float *)(d + 8 * (size_t)n_bins);
+    unsigned long long *d_err = (unsigned long long *)(d + 32768);
+    HIP_TRY(ctx, hipMemcpyAsync(d_idx, idx.data(), n_bins * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_w0, w0.data(), n_bins * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_w1, w1.data(), n_bins * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(d_err, 0, sizeof(unsigned long long), st));
+    if ((rc = launch_knot_error(ctx, env, ld64, probe_rows, n_probe, n_bins, knot_bin, K, d_idx, d_w0, d_w1, d_err, st))) return rc;
+    unsigned long long bits = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&bits, d_err, sizeof(bits), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    memcpy(max_rel_err, &bits, sizeof(double));
+    return GOOFER_OK;
+}
+
+int goofer_knot_gather(goofer_ctx *ctx, const double *env, int ld64, int64_t rows, const int32_t *knot_bin, int K,
+                       uint16_t *knots_f16, void *stream)
+{
+    if (!ctx) return GOOFER_EINVAL;
+    return launch_knot_gather(ctx, env, ld64, rows, knot_bin, K, knots_f16, (hipStream_t)stream);
 }
 
 int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *asmb, void *stream)

@@ -169,6 +169,38 @@ class Context:
                                               float(ratio), self._stream()))
         return out
 
+    # -- analysis (GOOFER.py:942-946, 97-147) -----------------------------------------------------
+    def mag_rows(self, S):
+        """complex64 [R, >=n_bins] -> |S| + 1e-8 as fp32 rows."""
+        R, nb = S.shape
+        out = self.rows(R, nb)
+        self._check(self.lib.goofer_mag_rows(self.h, _ptr(S), S.stride(0), R, nb, _ptr(out), out.stride(0), self._stream()))
+        return out
+
+    def gauss_bins_f64(self, rows, taps: np.ndarray):
+        """fp32 rows -> fp64 rows (the reference's gaussian_filter1d returns float64)."""
+        taps = np.ascontiguousarray(taps, dtype=np.float64)
+        R, nb = rows.shape
+        ld64 = (nb + 1) & ~1
+        out = torch.empty((R, ld64), dtype=torch.float64, device=self.device)[:, :nb]
+        self._check(self.lib.goofer_gauss_bins_f64(self.h, _ptr(rows), rows.stride(0), _ptr(out), ld64, R, nb,
+                                                   taps.ctypes.data_as(C.c_void_p), (taps.size - 1) // 2, self._stream()))
+        return out
+
+    def knot_fit_error(self, env64, probe_rows, knot_bin, hz_knots: np.ndarray) -> float:
+        hz = np.ascontiguousarray(hz_knots, dtype=np.float32)
+        err = C.c_double(0.0)
+        self._check(self.lib.goofer_knot_fit_error(self.h, _ptr(env64), env64.stride(0), _ptr(probe_rows), probe_rows.numel(),
+                                                   env64.shape[1], _ptr(knot_bin), hz.size, hz.ctypes.data_as(C.c_void_p),
+                                                   C.byref(err), self._stream()))
+        return float(err.value)
+
+    def knot_gather(self, env64, knot_bin):
+        R, K = env64.shape[0], knot_bin.numel()
+        out = torch.empty((R, K), dtype=torch.float16, device=self.device)
+        self._check(self.lib.goofer_knot_gather(self.h, _ptr(env64), env64.stride(0), R, _ptr(knot_bin), K, _ptr(out), self._stream()))
+        return out
+
     def knot_decode(self, knots_f16, hz_knots: np.ndarray):
         """knots fp16 [rows, K] -> env fp32 [rows, n_bins] (view of an ld-strided buffer)."""
         hz = np.ascontiguousarray(hz_knots, dtype=np.float32)

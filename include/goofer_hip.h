@@ -172,6 +172,26 @@ int goofer_warp_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows,
 int goofer_knot_decode(goofer_ctx *ctx, const uint16_t *knots_f16, int K, const float *hz_knots,
                        int64_t rows, float *env, int n_bins, int ld, void *stream);
 
+/* ---- analysis half that does not need Praat (GOOFER.py:942-946, 97-147) -------------------------------- */
+
+/* mag = abs(S) + 1e-8 per row (fp32).  S [rows x ldc] complex64 -> mag [rows x ld]. */
+int goofer_mag_rows(goofer_ctx *ctx, const float *S, int ldc, int64_t rows, int n_bins, float *mag, int ld, void *stream);
+
+/* gaussian_filter1d(axis=bins) with the reference's fp64 result kept: in fp32 [rows x ld] -> out fp64 [rows x ld64];
+ * taps fp64 [2*radius+1] in HOST memory. */
+int goofer_gauss_bins_f64(goofer_ctx *ctx, const float *in, int ld, double *out, int ld64, int64_t rows, int n_bins,
+                          const double *taps, int radius, void *stream);
+
+/* One candidate of compress_env_to_knots' search: max over the probe rows and all bins of
+ * abs(exp(lerp(log knots)) - env) / (env + 1e-8), with knots = log(max(env, 1e-8)) sampled at knot_bin (all device
+ * arrays; hz_knots fp32 [K] in HOST memory defines the lerp).  *max_rel_err is written on the host (synchronises). */
+int goofer_knot_fit_error(goofer_ctx *ctx, const double *env, int ld64, const int64_t *probe_rows, int n_probe, int n_bins,
+                          const int32_t *knot_bin, int K, const float *hz_knots, double *max_rel_err, void *stream);
+
+/* knot_vals_log = log(max(env, 1e-8))[knot_bin] as fp16, [rows x K] (frames-major). */
+int goofer_knot_gather(goofer_ctx *ctx, const double *env, int ld64, int64_t rows, const int32_t *knot_bin, int K,
+                       uint16_t *knots_f16, void *stream);
+
 /* ---- the hot path --------------------------------------------------------------------------- */
 
 /* gf.synthesize for a ragged batch (GOOFER.py:971-1220) + the V/B/U mix (SillySampler.py:1142-1151). */

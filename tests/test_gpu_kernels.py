@@ -191,3 +191,26 @@ def test_knot_decode(ctx):
     out = core.decode_env_from_knots(pack, ctx=ctx)
     assert out.dtype == np.float32 and out.shape == g["decoded"].shape
     np.testing.assert_allclose(out, g["decoded"], rtol=1e-6)
+
+
+def test_analysis_envelope_and_knot_encode(ctx):
+    """|stft| + 1e-8 -> sigma 2 blur -> sigma 0.5 blur -> K search -> fp16 knots, against the reference."""
+    from goofer_amd import core
+    g = golden("knots")
+    env, pack = core.envelope_features(g["an_x"], 44100, ctx=ctx)
+    assert env.dtype == np.float64 and env.shape == g["an_env"].shape
+    np.testing.assert_allclose(env, g["an_env"], rtol=2e-6, atol=1e-9)
+    assert np.array_equal(pack["hz_knots"], g["an_hz_knots"])                  # same K chosen
+    a, b = pack["knot_vals_log"].astype(np.float32), g["an_knot_vals_log"].astype(np.float32)
+    assert pack["knot_vals_log"].dtype == np.float16 and a.shape == b.shape
+    assert np.mean(a == b) > 0.995 and np.max(np.abs(a - b)) <= 0.008          # <= 1 fp16 ulp on rare rounding ties
+    # a smooth envelope picks a small K, exactly like the reference
+    p2 = core.compress_env_to_knots(g["sm_env"], 44100, 1024, ctx=ctx)
+    assert np.array_equal(p2["hz_knots"], g["sm_hz_knots"])
+    a, b = p2["knot_vals_log"].astype(np.float32), g["sm_knot_vals_log"].astype(np.float32)
+    assert np.mean(a == b) > 0.995 and np.max(np.abs(a - b)) <= 0.008
+    with pytest.raises(NotImplementedError):
+        core.extract_features(g["an_x"], 44100, ctx=ctx)
+    out = core.extract_features(g["an_x"], 44100, ctx=ctx,
+                                pitch_tracker=lambda y, sr, hop, T: (np.full(T, 220.0), {k: [500.0 * k] * T for k in range(1, 6)}))
+    assert out[1].shape == (len(g["an_x"]),) and out[2].min() == 1.0 and out[4]["mode"] == "knots"
