@@ -12,13 +12,15 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgoofer_hip.so")
 
-# numpy mirror of goofer_note_params (C layout, 88 bytes)
+# numpy mirror of goofer_note_params (C layout, 104 bytes; checked against goofer_sizeof)
 NOTE_PARAMS = np.dtype({
     "names": ["pitch_shift", "formant_shift", "f_shift", "uv_strength", "breath_strength", "normalize",
-              "apply_brightness", "cut_below_f0", "mix_harm", "mix_breath", "mix_unvoiced", "volume", "seed"],
-    "formats": ["<f4", "<f4", ("<f8", 4), "<f4", "<f4", "<f4", "<i4", "<i4", "<f4", "<f4", "<f4", "<f4", ("<u4", 2)],
-    "offsets": [0, 4, 8, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76],
-    "itemsize": 88,
+              "apply_brightness", "cut_below_f0", "mix_harm", "mix_breath", "mix_unvoiced", "volume", "seed",
+              "f0_jitter", "vol_jitter_harm", "vol_jitter_breath", "subharm_weight"],
+    "formats": ["<f4", "<f4", ("<f8", 4), "<f4", "<f4", "<f4", "<i4", "<i4", "<f4", "<f4", "<f4", "<f4", ("<u4", 2),
+                "<f4", "<f4", "<f4", "<f4"],
+    "offsets": [0, 4, 8, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 84, 88, 92, 96],
+    "itemsize": 104,
 })
 
 
@@ -58,6 +60,8 @@ class Batch(C.Structure):
         ("env", C.c_void_p), ("formants", C.c_void_p), ("f0", C.c_void_p), ("mask", C.c_void_p),
         ("phi", C.c_void_p), ("params", C.c_void_p), ("seed", C.c_uint64),
         ("transition_sigma", C.c_float), ("reserved2", C.c_float),
+        ("noise_f0", C.c_void_p), ("noise_vol_h", C.c_void_p), ("noise_vol_b", C.c_void_p),
+        ("f0_jitter_sigma", C.c_float), ("vol_jitter_sigma", C.c_float),
         ("harm", C.c_void_p), ("uv", C.c_void_p), ("bre", C.c_void_p), ("rec", C.c_void_p), ("mix", C.c_void_p),
     ]
 

@@ -20,7 +20,7 @@ from .device import Context, default_context, default_params, row_stride
 DSTORAGE = np.float16
 DCOMPUTE = np.float32
 
-_UNSUPPORTED = ("f0_jitter", "volume_jitter", "add_subharm", "roughness_on")
+_UNSUPPORTED = ("add_subharm", "roughness_on")
 
 
 def _ctx(sr, n_fft, hop, ctx=None) -> Context:
@@ -232,6 +232,13 @@ def note_params_from_kwargs(n=1, **kw):
     p["normalize"] = kw.get("normalize", 1.0)
     p["apply_brightness"] = int(bool(kw.get("apply_brightness", True)))
     p["cut_below_f0"] = int(bool(kw.get("cut_subharm_below_f0", True)))
+    if kw.get("f0_jitter"):
+        p["f0_jitter"] = kw.get("f0_jitter_strength", 1.5)
+    if kw.get("volume_jitter"):
+        if kw.get("volume_vibrato"):
+            raise NotImplementedError("volume_vibrato is not on the device path yet")
+        p["vol_jitter_harm"] = kw.get("volume_jitter_strength_harm", 50)
+        p["vol_jitter_breath"] = kw.get("volume_jitter_strength_breath", 100)
     return p
 
 
@@ -267,7 +274,11 @@ def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=
         d_phi = c.rows_from(np.asarray(phi, dtype=np.float32).T)
     if seed is None:
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
+    # jitter flags draw from the legacy global np.random stream in the reference's order: f0, harm volume, breath volume
+    noise_f0 = c.tensor(np.random.randn(n)) if kw.get("f0_jitter") else None
+    noise_vol = (c.tensor(np.random.randn(n)), c.tensor(np.random.randn(n))) if kw.get("volume_jitter") else None
     out = c.synth_batch(d_env, [T_env], c.tensor(f0[:n]), c.tensor(mask[:n]), [n], params, formants=c.tensor(F),
                         phi=d_phi, seed=seed, transition_sigma=float(kw.get("noise_transition_smoothness", 100)),
-                        want_mix=False)
+                        want_mix=False, noise_f0=noise_f0, noise_vol=noise_vol,
+                        f0_jitter_speed=float(kw.get("f0_jitter_speed", 100)), vol_jitter_speed=float(kw.get("volume_jitter_speed", 150)))
     return tuple(out[k].cpu().numpy() for k in ("rec", "harm", "uv", "bre"))

@@ -41,6 +41,16 @@ int launch_knot_error(goofer_ctx *, const double *, int, const int64_t *, int, i
 int launch_knot_gather(goofer_ctx *, const double *, int, int64_t, const int *, int, uint16_t *, hipStream_t);
 int launch_ola3_gains(goofer_ctx *, const float *, const float *, const float *, const float *, const double *, const int64_t *,
                       const int64_t *, int, int64_t, const goofer_note_params *, double *, float *, float *, float *, float *, hipStream_t);
+template <typename Tin>
+int launch_gauss_samples(goofer_ctx *, const Tin *, const int64_t *, int, int64_t, const double *, int, const unsigned char *, double *,
+                         hipStream_t);
+int launch_note_absmax(goofer_ctx *, const double *, const int64_t *, int, int64_t, const unsigned char *, unsigned long long *,
+                       hipStream_t);
+int launch_f0_jitter(goofer_ctx *, float *, const float *, const double *, const unsigned long long *, const int64_t *, int, int64_t,
+                     const goofer_note_params *, hipStream_t);
+int launch_volume_jitter(goofer_ctx *, float *, float *, const double *, const double *, const double *, const unsigned long long *,
+                         const unsigned long long *, const int64_t *, int, int64_t, const goofer_note_params *, hipStream_t);
+int launch_stem_peak(goofer_ctx *, const float *, const float *, const float *, const int64_t *, int, int64_t, float *, hipStream_t);
 int launch_harm_frames(goofer_ctx *, const float *, const goofer_batch *, const float *, const int *, const int64_t *, float *, float *,
                        hipStream_t);
 int launch_noise_frames(goofer_ctx *, const goofer_batch *, const float *, const int *, const int64_t *, float *, float *, hipStream_t);
@@ -93,6 +103,35 @@ __global__ void k_scale_f0(const float *__restrict__ f0, const int64_t *__restri
         while (sample_off[note + 1] <= g) ++note;
         out[g] = f0[g] * params[note].pitch_shift;
     }
+}
+
+static void gauss_taps_host(double sigma, std::vector<double> &taps, int &radius);
+static int ensure_small(goofer_ctx *ctx, size_t bytes);
+
+__global__ void k_note_flags(const goofer_note_params *__restrict__ params, int n_notes, unsigned char *__restrict__ on_f0,
+                             unsigned char *__restrict__ on_vol)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_notes) return;
+    on_f0[i] = params[i].f0_jitter > 0.f;
+    on_vol[i] = params[i].vol_jitter_harm > 0.f || params[i].vol_jitter_breath > 0.f;
+}
+
+// taps of a sample-axis Gaussian, uploaded into the handle's small buffer at `slot` (3 slots of 16 KiB after 64 KiB)
+static int upload_jitter_taps(goofer_ctx *ctx, double sigma, int slot, const double **d_taps, int *radius, hipStream_t st)
+{
+    std::vector<double> taps;
+    int r;
+    gauss_taps_host(sigma, taps, r);
+    if (r > 1000) return goofer_fail(ctx, GOOFER_EINVAL, "jitter sigma %g too large", sigma);
+    int rc = ensure_small(ctx, 65536 + 3 * 16384);
+    if (rc) return rc;
+    double *dst = (double *)((char *)ctx->small + 65536 + (size_t)slot * 16384);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, taps.data(), taps.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    *d_taps = dst;
+    *radius = r;
+    return GOOFER_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -621,7 +660,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     const int64_t F = b->total_frames, N = b->total_samples;
     const int n = b->n_notes, ld = b->ld, ldc = p.n_bins + 1;
 
-    int rc = ensure_scratch(ctx, scratch_need(p, F, N, n) + (size_t)F * (ld - ((p.n_bins + 3) & ~3)) * 2 * sizeof(float));
+    const bool jit_f0 = b->noise_f0 != nullptr, jit_vol = b->noise_vol_h != nullptr && b->noise_vol_b != nullptr;
+    const size_t jit_bytes = (jit_f0 || jit_vol) ? (3 * (size_t)N * sizeof(double) + 3 * 256 * (size_t)n + 8192) : 0;
+    int rc = ensure_scratch(ctx, scratch_need(p, F, N, n) + (size_t)F * (ld - ((p.n_bins + 3) & ~3)) * 2 * sizeof(float) + jit_bytes);
     if (rc) return rc;
     arena a{(char *)ctx->scratch, ctx->scratch_bytes, 0};
     int *frame_note = a.take<int>(F);
@@ -648,6 +689,15 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         !env_h || !env_n || !short_s || !note_mag || !note_steps)
         return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     float *note_peak = note_mag + n;
+    double *jit_a = nullptr, *jit_b = nullptr, *jit_c = nullptr;
+    unsigned long long *jit_max = nullptr;
+    unsigned char *on_f0 = nullptr, *on_vol = nullptr;
+    if (jit_f0 || jit_vol) {
+        jit_a = a.take<double>(N); jit_b = a.take<double>(N); jit_c = a.take<double>(N);
+        jit_max = a.take<unsigned long long>(3 * (size_t)n + 16);
+        on_f0 = a.take<unsigned char>(n + 16); on_vol = a.take<unsigned char>(n + 16);
+        if (!jit_a || !jit_b || !jit_c || !jit_max || !on_f0 || !on_vol) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
+    }
     {
         const void *ptrs[] = {frame_note, row_src, f0s, pulse, S_h, S_uv, S_br, frames, env_h, env_n, short_s, note_mag, note_peak, onset_cnt};
         size_t bytes[] = {F * sizeof(int), F * sizeof(int64_t), N * sizeof(float), N * sizeof(float), (size_t)F * ldc * sizeof(float2),
@@ -692,6 +742,18 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_scale_f0, dim3(sb), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s);
     LAUNCH_CHECK(ctx);
+    if (jit_f0 || jit_vol) {
+        hipLaunchKernelGGL(k_note_flags, dim3((n + 255) / 256), dim3(256), 0, st, b->params, n, on_f0, on_vol);
+        LAUNCH_CHECK(ctx);
+        HIP_TRY(ctx, hipMemsetAsync(jit_max, 0, 3 * (size_t)n * sizeof(unsigned long long), st));
+    }
+    if (jit_f0) {   // 'sh': f0 *= 1 + (jitter - 1) * mask, after pitch_shift and before the pulse train (GOOFER.py:1069-1071)
+        const double *d_t; int r;
+        if ((rc = upload_jitter_taps(ctx, (double)b->f0_jitter_sigma, 0, &d_t, &r, st))) return rc;
+        if ((rc = launch_gauss_samples<double>(ctx, b->noise_f0, b->sample_off, n, N, d_t, r, on_f0, jit_a, st))) return rc;
+        if ((rc = launch_note_absmax(ctx, jit_a, b->sample_off, n, N, on_f0, jit_max, st))) return rc;
+        if ((rc = launch_f0_jitter(ctx, f0s, b->mask, jit_a, jit_max, b->sample_off, n, N, b->params, st))) return rc;
+    }
     MARK();   // 1: noise envelope = sigma-1.75 blur of the un-warped rows (GOOFER.py:993)
     // (folded into k_noise_spectra / k_harm_shape: the standalone envelope kernels remain as C-ABI entry points)
     MARK();   // 2: harmonic envelope = formant-anchored + uniform warp
@@ -736,6 +798,21 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     if ((rc = launch_ola3_gains(ctx, frames, frames_u, frames_b, note_mag, short_s, b->sample_off, b->frame_off, n, N, b->params,
                                 note_steps, b->harm, b->uv, b->bre, note_peak, st)))
         return rc;
+    if (jit_vol) {  // 'sr': volume jitter on harm / breath, then the peak is taken again (GOOFER.py:1185-1193)
+        const double *d_t, *d_t20; int r, r20;
+        if ((rc = upload_jitter_taps(ctx, (double)b->vol_jitter_sigma, 1, &d_t, &r, st))) return rc;
+        if ((rc = upload_jitter_taps(ctx, 20.0, 2, &d_t20, &r20, st))) return rc;
+        if ((rc = launch_gauss_samples<double>(ctx, b->noise_vol_h, b->sample_off, n, N, d_t, r, on_vol, jit_a, st))) return rc;
+        if ((rc = launch_gauss_samples<double>(ctx, b->noise_vol_b, b->sample_off, n, N, d_t, r, on_vol, jit_b, st))) return rc;
+        if ((rc = launch_gauss_samples<float>(ctx, b->mask, b->sample_off, n, N, d_t20, r20, on_vol, jit_c, st))) return rc;
+        if ((rc = launch_note_absmax(ctx, jit_a, b->sample_off, n, N, on_vol, jit_max + n, st))) return rc;
+        if ((rc = launch_note_absmax(ctx, jit_b, b->sample_off, n, N, on_vol, jit_max + 2 * (size_t)n, st))) return rc;
+        if ((rc = launch_volume_jitter(ctx, b->harm, b->bre, jit_a, jit_b, jit_c, jit_max + n, jit_max + 2 * (size_t)n, b->sample_off, n,
+                                       N, b->params, st)))
+            return rc;
+        HIP_TRY(ctx, hipMemsetAsync(note_peak, 0, (size_t)n * sizeof(float), st));
+        if ((rc = launch_stem_peak(ctx, b->harm, b->uv, b->bre, b->sample_off, n, N, note_peak, st))) return rc;
+    }
     MARK();   // 14: gain, reconstruct, mix
     if ((rc = launch_apply_gain(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, N, b->params, note_peak, st))) return rc;
     MARK();   // 15..17 unused

@@ -305,6 +305,40 @@ __global__ __launch_bounds__(256) void k_apply_gain(float *__restrict__ harm, fl
     }
 }
 
+// per-note max |harm + uv + bre| (used when the volume jitter changes stems after the fused OLA/gain pass)
+__global__ __launch_bounds__(256) void k_stem_peak(const float *__restrict__ harm, const float *__restrict__ uv, const float *__restrict__ bre,
+                                                   const int64_t *__restrict__ sample_off, int n_notes, int64_t total,
+                                                   float *__restrict__ note_peak)
+{
+    __shared__ int s_pair[2];
+    __shared__ float s_red[4];
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    int lo, hi;
+    block_note_range(sample_off, n_notes, g0, total, s_pair, lo, hi);
+    const int64_t g = g0 + threadIdx.x;
+    float pk = g < total ? fabsf((harm[g] + uv[g]) + bre[g]) : 0.f;
+    if (lo == hi) {
+        pk = wave_max(pk);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = pk;
+        __syncthreads();
+        if (threadIdx.x == 0) atomic_max_pos(note_peak + lo, fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])));
+    } else if (g < total) {
+        int note = lo;
+        while (sample_off[note + 1] <= g) ++note;
+        atomic_max_pos(note_peak + note, pk);
+    }
+}
+
+int launch_stem_peak(goofer_ctx *ctx, const float *harm, const float *uv, const float *bre, const int64_t *sample_off, int n_notes,
+                     int64_t total, float *note_peak, hipStream_t st)
+{
+    if (total <= 0) return GOOFER_OK;
+    hipLaunchKernelGGL(k_stem_peak, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, harm, uv, bre, sample_off, n_notes, total,
+                       note_peak);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
 int launch_mask_short(goofer_ctx *ctx, const float *mask, const int64_t *sample_off, int n_notes, int64_t total_samples,
                       const double *d_taps, int radius, double *short_s, hipStream_t st)
 {

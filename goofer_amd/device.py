@@ -246,7 +246,8 @@ class Context:
         return np.ascontiguousarray(params)
 
     def synth_batch(self, env, env_lengths, f0, mask, sample_lengths, params: np.ndarray, formants=None, phi=None,
-                    seed: int = 0, transition_sigma: float = 100.0, want_rec=True, want_mix=True, offsets=None):
+                    seed: int = 0, transition_sigma: float = 100.0, want_rec=True, want_mix=True, offsets=None,
+                    noise_f0=None, noise_vol=None, f0_jitter_speed: float = 100.0, vol_jitter_speed: float = 150.0):
         """Run goofer_synth_batch.
 
         env fp32 [R_total, n_bins] ld-strided device tensor; env_lengths rows per note;
@@ -272,7 +273,12 @@ class Context:
                        sample_off=d_s.data_ptr(), frame_off=d_f.data_ptr(), env_off=d_e.data_ptr(), env=env.data_ptr(),
                        formants=formants.data_ptr() if formants is not None else None, f0=f0.data_ptr(),
                        mask=mask.data_ptr(), phi=phi.data_ptr() if phi is not None else None, params=d_par.data_ptr(),
-                       seed=seed, transition_sigma=float(transition_sigma), harm=out["harm"].data_ptr(),
+                       seed=seed, transition_sigma=float(transition_sigma),
+                       noise_f0=noise_f0.data_ptr() if noise_f0 is not None else None,
+                       noise_vol_h=noise_vol[0].data_ptr() if noise_vol is not None else None,
+                       noise_vol_b=noise_vol[1].data_ptr() if noise_vol is not None else None,
+                       f0_jitter_sigma=self.geom[0] / (f0_jitter_speed * 6), vol_jitter_sigma=self.geom[0] / (vol_jitter_speed * 6),
+                       harm=out["harm"].data_ptr(),
                        uv=out["uv"].data_ptr(), bre=out["bre"].data_ptr(),
                        rec=out["rec"].data_ptr() if want_rec else None, mix=out["mix"].data_ptr() if want_mix else None)
         self._check(self.lib.goofer_synth_batch(self.h, C.byref(b), self._stream()))

@@ -96,7 +96,7 @@ class Renderer:
         ctx._check(ctx.lib.goofer_assemble_batch(ctx.h, C.byref(prep["assembly"]), ctx._stream()))
         return ctx.synth_batch(prep["env"], prep["env_lens"], prep["f0"], prep["mask"], prep["lens"], prep["params"],
                                formants=prep["formants"], phi=prep["phi"], seed=seed, want_rec=False, want_mix=True,
-                               offsets=prep["offsets"])
+                               offsets=prep["offsets"], noise_f0=prep["noise_f0"], noise_vol=prep["noise_vol"])
 
     def prepare(self, jobs, phi_seeds=None):
         """Plan every note on the host and make the batch resident in HBM (plans, tables, sources)."""
@@ -220,7 +220,25 @@ class Renderer:
             par[i]["mix_harm"], par[i]["mix_breath"], par[i]["mix_unvoiced"] = req.harmonic_mix, req.breathiness_mix, req.unvoiced_mix
             par[i]["volume"] = req.volume
             par[i]["seed"] = [i & 0xFFFFFFFF, 0]
+            if req.f0_jitter:
+                par[i]["f0_jitter"] = req.f0_jitter_strength
+            if req.volume_jitter:
+                par[i]["vol_jitter_harm"] = req.volume_jitter_strength
+                par[i]["vol_jitter_breath"] = req.volume_jitter_strength * 2
         lens = [p.n_out for p in plans]
+        # sh / sr draws come from the legacy global np.random stream, note by note, in the reference's order
+        # (f0 jitter, harmonic volume, breath volume: GOOFER.py:666, 653)
+        noise_f0 = noise_vol = None
+        if any(r.f0_jitter for _, r in jobs) or any(r.volume_jitter for _, r in jobs):
+            nf, nh, nb = [], [], []
+            for (_, req), n_ in zip(jobs, lens):
+                nf.append(np.random.randn(n_) if req.f0_jitter else np.zeros(n_))
+                nh.append(np.random.randn(n_) if req.volume_jitter else np.zeros(n_))
+                nb.append(np.random.randn(n_) if req.volume_jitter else np.zeros(n_))
+            if any(r.f0_jitter for _, r in jobs):
+                noise_f0 = ctx.tensor(np.concatenate(nf))
+            if any(r.volume_jitter for _, r in jobs):
+                noise_vol = (ctx.tensor(np.concatenate(nh)), ctx.tensor(np.concatenate(nb)))
         env_lens = [p.tap_idx.shape[0] for p in plans]
         phi = None
         if phi_seeds is not None:
@@ -234,6 +252,7 @@ class Renderer:
         ctx.reserve(frames, int(sum(lens)), n)
         torch.cuda.synchronize(ctx.device)
         return {"assembly": a, "keep": d, "env": env, "f0": f0, "mask": mask, "params": par, "lens": lens, "env_lens": env_lens,
+                "noise_f0": noise_f0, "noise_vol": noise_vol,
                 "formants": ctx.tensor(np.concatenate(F_cat)), "phi": phi, "plans": plans, "offsets": offsets,
                 "sample_off": np.concatenate([[0], np.cumsum(lens)]), "env_off": np.concatenate([[0], np.cumsum(env_lens)]),
                 "frames": frames, "samples": int(sum(lens)), "edit_rows": e_off}

@@ -25,7 +25,7 @@ _FLAG = re.compile(r"([A-Za-z]{1,4})([+-]?\d+)?")
 _SEMI = {"C": 0, "C#": 1, "D": 2, "D#": 3, "E": 4, "F": 5, "F#": 6, "G": 7, "G#": 8, "A": 9, "A#": 10, "B": 11}
 
 # flags whose processing is not on the device yet (SURVEY.md §8 f): fail loudly instead of ignoring
-UNSUPPORTED_FLAGS = ("su", "sj", "sa", "st", "sd", "vf", "pd", "sh", "sr", "sg")
+UNSUPPORTED_FLAGS = ("su", "sj", "sa", "st", "sd", "vf", "pd", "sg")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -115,6 +115,10 @@ class Request:
     formant_width: float = 0.0
     formant_strength: tuple = (0.0, 0.0, 0.0, 0.0)
     use_editor: bool = False
+    f0_jitter: bool = False
+    f0_jitter_strength: float = 0.0
+    volume_jitter: bool = False
+    volume_jitter_strength: float = 0.0
 
 
 def decode_request(pitch, velocity, flags="", offset=0, length=1000, consonant=0, cutoff=0, volume=100,
@@ -129,6 +133,11 @@ def decode_request(pitch, velocity, flags="", offset=0, length=1000, consonant=0
     r.formant_shift = 1.0 + (g("g", 0) / 200.0)                       # TypeError on a bare 'g', like the reference
     r.brightness_env = (g("br", 0) + 100) / 100.0
     r.f_shift = tuple(1.0 + (g(k, 0) / 100.0) for k in ("fa", "fb", "fc", "fd"))
+    sh, sr_ = g("sh", None), g("sr", None)                              # roughness / harshness   :325-330
+    r.f0_jitter = sh is not None and sh > 0
+    r.f0_jitter_strength = (sh or 0) / 50.0
+    r.volume_jitter = sr_ is not None and sr_ > 0
+    r.volume_jitter_strength = (sr_ or 0) / 50.0
     r.breathiness_mix = (g("B", 0) + 100) / 100.0
     r.unvoiced_mix = (g("U", 0) + 100) / 100.0
     r.harmonic_mix = float(np.clip(g("V", 100), 0, 100) / 100.0)

@@ -46,7 +46,12 @@ typedef struct {
     int32_t cut_below_f0;       /* cut_subharm_below_f0, default 1                 GOOFER.py:1113 */
     float mix_harm, mix_breath, mix_unvoiced, volume;   /* V, (B+100)/100, (U+100)/100, volume */
     uint32_t seed[2];           /* per-note Philox key (lo, hi), XORed with the batch seed: a note's  */
-    uint32_t reserved;          /* noise never depends on where it sits in a batch                    */
+                                /* noise never depends on where it sits in a batch                    */
+    float f0_jitter;            /* 'sh': f0_jitter_strength, 0 = off              GOOFER.py:1069-1071 */
+    float vol_jitter_harm;      /* 'sr': volume_jitter_strength_harm, 0 = off     GOOFER.py:1185-1191 */
+    float vol_jitter_breath;    /*       volume_jitter_strength_breath                                */
+    float subharm_weight;       /* 'sg': +12 st pulse layer weight, 0 = off       GOOFER.py:1076-1097 */
+    uint32_t reserved;
 } goofer_note_params;
 
 /* One ragged batch of notes for goofer_synth_batch.  All pointers are device memory. */
@@ -71,6 +76,13 @@ typedef struct {
     uint64_t seed;              /* Philox key when phi == NULL */
     float transition_sigma;     /* noise_transition_smoothness of this call (default 100; the 'sa'  */
     float reserved2;            /* layer uses 1) — one value per batch            GOOFER.py:1179 */
+    /* jitter flags: standard-normal draws supplied by the caller (the reference takes them from the legacy  */
+    /* global np.random stream), [total_samples] fp64 each, NULL when no note of the batch uses the flag      */
+    const double *noise_f0;     /* for notes with f0_jitter > 0                   GOOFER.py:666        */
+    const double *noise_vol_h;  /* harmonic volume jitter draw                    GOOFER.py:653        */
+    const double *noise_vol_b;  /* breath volume jitter draw                                           */
+    float f0_jitter_sigma;      /* sr / (6 * f0_jitter_speed)  samples            GOOFER.py:667        */
+    float vol_jitter_sigma;     /* sr / (6 * volume_jitter_speed)                 GOOFER.py:654        */
     float *harm, *uv, *bre;     /* [total_samples] stems, gain-normalised like the reference   */
     float *rec;                 /* [total_samples] harm+uv+bre (reconstruct), may be NULL      */
     float *mix;                 /* [total_samples] (harm*V + bre*B + uv*U)*volume, may be NULL */

@@ -74,7 +74,7 @@ def test_all_supported_notes_as_one_batch(renderer):
 
 def test_unsupported_flags_fail_loudly():
     from goofer_amd import sampler as S
-    for fl in ("su50", "sj30", "sa30", "st-50", "sd30", "vf40", "pd50", "sh50", "sr50", "sg50"):
+    for fl in ("su50", "sj30", "sa30", "st-50", "sd30", "vf40", "pd50", "sg50"):
         with pytest.raises(NotImplementedError):
             S.decode_request("C4", "100", fl, "0", "1000", "0", "0", "100", "0", "!120", "AA")
 
@@ -130,3 +130,16 @@ def test_baseline_config_notes_vs_oracle(config, ids):
             assert e < 2e-5, (config, i, e)
     finally:
         ctx.close()
+
+
+def test_jitter_flags_sh_sr_match_reference(renderer):
+    """sh (f0 jitter) + sr (volume jitter): legacy-RNG draws seeded like the reference run."""
+    g, source, req = _job("sh50sr50")
+    seed, legacy = int(g["seed"][0]), int(g["seed"][1])
+    np.random.seed(legacy)
+    (out,) = renderer.render([(source, req)], phi_seeds=[seed])
+    ref = g["out"]
+    assert out.shape == ref.shape
+    e = rms_err(out, ref) / max(1.0, float(np.max(np.abs(ref))))
+    assert e < TOL, e
+    assert e < 2e-5, e

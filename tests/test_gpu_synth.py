@@ -159,3 +159,21 @@ def test_fused_path_equals_modular_path(ctx):
     ctx.set_option("fused", 1)
     for k in a:
         assert rms_err(a[k], b[k].cpu().numpy()) < 1e-7, k
+
+
+def test_synthesize_jitter_kwargs_vs_oracle(ctx):
+    """f0_jitter / volume_jitter kwargs of gf.synthesize: same legacy RNG stream on both sides."""
+    from goofer_amd import core
+    from oracle import goofer_ref as R
+    g = golden("synthesize")
+    c = _case(g, "plain")
+    kw = dict(f0_jitter=True, f0_jitter_strength=1.2, volume_jitter=True, volume_jitter_strength_harm=0.8,
+              volume_jitter_strength_breath=1.6)
+    np.random.seed(99)
+    ref = R.synthesize(c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"], n_fft=c["n_fft"], hop_length=c["hop"],
+                       formants=c["formants"], phi=c["phi"], **kw)
+    np.random.seed(99)
+    got = core.synthesize(c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"], n_fft=c["n_fft"], hop_length=c["hop"],
+                          formants=c["formants"], phi=c["phi"], ctx=ctx, **kw)
+    for a, b, key in zip(got, ref, ("rec", "harm", "uv", "bre")):
+        assert rms_err(a, b) < 2e-5, (key, rms_err(a, b))
