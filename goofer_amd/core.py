@@ -20,7 +20,7 @@ from .device import Context, default_context, default_params, row_stride
 DSTORAGE = np.float16
 DCOMPUTE = np.float32
 
-_UNSUPPORTED = ("add_subharm", "roughness_on")
+_UNSUPPORTED = ("roughness_on",)
 
 
 def _ctx(sr, n_fft, hop, ctx=None) -> Context:
@@ -239,7 +239,22 @@ def note_params_from_kwargs(n=1, **kw):
             raise NotImplementedError("volume_vibrato is not on the device path yet")
         p["vol_jitter_harm"] = kw.get("volume_jitter_strength_harm", 50)
         p["vol_jitter_breath"] = kw.get("volume_jitter_strength_breath", 100)
+    if kw.get("add_subharm"):
+        if kw.get("subharm_f0_jitter", 0) > 0.0:
+            raise NotImplementedError("subharm_f0_jitter is not on the device path yet")
+        if np.ndim(kw.get("subharm_semitones", -12)) != 0:
+            raise NotImplementedError("one sub-harmonic ratio per call on the device path")
+        p["subharm_weight"] = kw.get("subharm_weight", 0.5)
     return p
+
+
+def subharm_from_kwargs(kw):
+    """The call-level half of gf.synthesize's add_subharm arguments (GOOFER.py:979-980) for Context.synth_batch."""
+    if not kw.get("add_subharm"):
+        return None
+    return {"semitones": kw.get("subharm_semitones", -12), "vibrato": kw.get("subharm_vibrato", False),
+            "rate": kw.get("subharm_vibrato_rate", 6.0), "depth": kw.get("subharm_vibrato_depth", 0.1),
+            "delay": kw.get("subharm_vibrato_delay", 0.1)}
 
 
 def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=256, phi=None, seed=None, ctx=None, **kw):
@@ -280,5 +295,6 @@ def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=
     out = c.synth_batch(d_env, [T_env], c.tensor(f0[:n]), c.tensor(mask[:n]), [n], params, formants=c.tensor(F),
                         phi=d_phi, seed=seed, transition_sigma=float(kw.get("noise_transition_smoothness", 100)),
                         want_mix=False, noise_f0=noise_f0, noise_vol=noise_vol,
-                        f0_jitter_speed=float(kw.get("f0_jitter_speed", 100)), vol_jitter_speed=float(kw.get("volume_jitter_speed", 150)))
+                        f0_jitter_speed=float(kw.get("f0_jitter_speed", 100)), vol_jitter_speed=float(kw.get("volume_jitter_speed", 150)),
+                        subharm=subharm_from_kwargs(kw))
     return tuple(out[k].cpu().numpy() for k in ("rec", "harm", "uv", "bre"))

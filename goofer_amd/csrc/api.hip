@@ -21,6 +21,9 @@ int launch_phase_inc(goofer_ctx *, const float *, float, int64_t, double *, hipS
 int launch_pulse_onsets(goofer_ctx *, const float *, float, const double *, const int64_t *, int, onset_t *, int32_t *, int32_t *,
                         int32_t *, hipStream_t);
 int launch_pulse_place(goofer_ctx *, const onset_t *, const int32_t *, const int64_t *, int, int64_t, float *, hipStream_t);
+int launch_subharm(goofer_ctx *, const float *, const float *, const int64_t *, int, int64_t, const goofer_note_params *, double, int,
+                   double, double, double, float *, double *, onset_t *, int32_t *, int32_t *, int32_t *, const unsigned char *,
+                   double *, unsigned long long *, float *, hipStream_t);
 int launch_gauss_bins(goofer_ctx *, const float *, float *, int64_t, int, int, const double *, int, const int64_t *, hipStream_t);
 int launch_warp_bins(goofer_ctx *, const float *, float *, int64_t, int, int, const double *, const double *,
                      const goofer_note_params *, const int *, const int64_t *, double, hipStream_t);
@@ -107,6 +110,12 @@ __global__ void k_scale_f0(const float *__restrict__ f0, const int64_t *__restri
 
 static void gauss_taps_host(double sigma, std::vector<double> &taps, int &radius);
 static int ensure_small(goofer_ctx *ctx, size_t bytes);
+
+__global__ void k_note_sub_flags(const goofer_note_params *__restrict__ params, int n_notes, unsigned char *__restrict__ on_sub)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_notes) on_sub[i] = params[i].subharm_weight > 0.f;
+}
 
 __global__ void k_note_flags(const goofer_note_params *__restrict__ params, int n_notes, unsigned char *__restrict__ on_f0,
                              unsigned char *__restrict__ on_vol)
@@ -661,7 +670,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     const int n = b->n_notes, ld = b->ld, ldc = p.n_bins + 1;
 
     const bool jit_f0 = b->noise_f0 != nullptr, jit_vol = b->noise_vol_h != nullptr && b->noise_vol_b != nullptr;
-    const size_t jit_bytes = (jit_f0 || jit_vol) ? (3 * (size_t)N * sizeof(double) + 3 * 256 * (size_t)n + 8192) : 0;
+    const bool sub_on = b->subharm_ratio > 0.0;
+    const size_t jit_bytes = ((jit_f0 || jit_vol) ? (3 * (size_t)N * sizeof(double) + 3 * 256 * (size_t)n + 8192) : 0) +
+                             (sub_on ? ((size_t)N * (sizeof(double) + sizeof(float)) + 3 * 256 * (size_t)n + 8192) : 0);
     int rc = ensure_scratch(ctx, scratch_need(p, F, N, n) + (size_t)F * (ld - ((p.n_bins + 3) & ~3)) * 2 * sizeof(float) + jit_bytes);
     if (rc) return rc;
     arena a{(char *)ctx->scratch, ctx->scratch_bytes, 0};
@@ -697,6 +708,15 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         jit_max = a.take<unsigned long long>(3 * (size_t)n + 16);
         on_f0 = a.take<unsigned char>(n + 16); on_vol = a.take<unsigned char>(n + 16);
         if (!jit_a || !jit_b || !jit_c || !jit_max || !on_f0 || !on_vol) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
+    }
+    double *sub_buf = nullptr;
+    float *sub_fm = nullptr;
+    unsigned long long *sub_max = nullptr;
+    unsigned char *on_sub = nullptr;
+    if (sub_on) {
+        sub_buf = a.take<double>(N); sub_fm = a.take<float>(N);
+        sub_max = a.take<unsigned long long>(n + 16); on_sub = a.take<unsigned char>(n + 16);
+        if (!sub_buf || !sub_fm || !sub_max || !on_sub) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     }
     {
         const void *ptrs[] = {frame_note, row_src, f0s, pulse, S_h, S_uv, S_br, frames, env_h, env_n, short_s, note_mag, note_peak, onset_cnt};
@@ -764,6 +784,15 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, inc, b->sample_off, n, (onset_t *)onsets, onset_idx, onset_cnt, ovf, st))) return rc;
     MARK();
     if ((rc = launch_pulse_place(ctx, (onset_t *)onsets, onset_cnt, b->sample_off, n, N, pulse, st))) return rc;
+    if (sub_on) {   // 'sg': extra LF pulse layer at f0 * ratio with vibrato, added to the pulse train (GOOFER.py:1076-1097)
+        hipLaunchKernelGGL(k_note_sub_flags, dim3((n + 255) / 256), dim3(256), 0, st, b->params, n, on_sub);
+        LAUNCH_CHECK(ctx);
+        HIP_TRY(ctx, hipMemsetAsync(sub_max, 0, (size_t)n * sizeof(unsigned long long), st));
+        if ((rc = launch_subharm(ctx, f0s, b->mask, b->sample_off, n, N, b->params, b->subharm_ratio, b->subharm_vibrato,
+                                 b->subharm_vib_rate, b->subharm_vib_depth, b->subharm_vib_delay, sub_fm, inc, (onset_t *)onsets,
+                                 onset_idx, onset_cnt, ovf, on_sub, sub_buf, sub_max, pulse, st)))
+            return rc;
+    }
     // spectra -> windowed time frames of the three stems
     if (ctx->fused) {
         MARK();   // 6: harm_frames = rFFT + warp + shape + irFFT (envelope stages 1, 2 folded in)

@@ -94,14 +94,22 @@ struct onset_t {
 // Placement: a workgroup is 4 waves = 4 notes (one per SIMD of a CU), and the launcher pads the
 // dynamic LDS request so that only ceil(blocks/256) workgroups fit on a CU — otherwise the dispatcher
 // packs many of these latency-bound waves onto a few CUs and they time-slice one SIMD.
+// WRAP = true is the sub-harmonic layer's tracker (GOOFER.py:693-696): an event fires when the phase reaches 1
+// and the phase then drops by 1.0, so the partial sums after an event inside a block must be re-walked.
+template <bool WRAP>
 __global__ __launch_bounds__(256) void k_pulse_onsets(const double *__restrict__ inc, const int64_t *__restrict__ sample_off,
                                                       int n_notes, int32_t *__restrict__ onset_idx,
-                                                      int32_t *__restrict__ onset_cnt, int32_t *__restrict__ overflow)
+                                                      int32_t *__restrict__ onset_cnt, int32_t *__restrict__ overflow,
+                                                      const unsigned char *__restrict__ note_on)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int note = blockIdx.x * 4 + wv;
     if (note >= n_notes) return;                              // whole wave; no block barrier below
+    if (note_on && !note_on[note]) {
+        if (lane == 0) onset_cnt[note] = 0;
+        return;
+    }
     double (*tile)[OC] = reinterpret_cast<double (*)[OC]>(smem) + 2 * wv;
     const int64_t base = sample_off[note];
     const int64_t n = sample_off[note + 1] - base;
@@ -150,6 +158,29 @@ __global__ __launch_bounds__(256) void k_pulse_onsets(const double *__restrict__
             ps[0] = phase + x[0];
 #pragma unroll
             for (int k = 1; k < OB; ++k) ps[k] = ps[k - 1] + x[k];
+            if (WRAP) {
+                if (__any((ps[OB - 1] >= 1.0) || chunk_neg)) {
+                    const int32_t i0 = (int32_t)c0 + g * OB;
+                    double ph = phase;
+#pragma unroll
+                    for (int j = 0; j < OB; ++j) {
+                        ph += x[j];
+                        if (__any(ph >= 1.0)) {
+                            if (cnt < cap) {
+                                if (lane == 0) out[cnt] = i0 + j;
+                            } else if (lane == 0) {
+                                *overflow = 1;
+                            }
+                            ++cnt;
+                            ph -= 1.0;
+                        }
+                    }
+                    phase = ph;
+                } else {
+                    phase = ps[OB - 1];
+                }
+                return;
+            }
             phase = ps[OB - 1];
             if (__any((phase >= next_k) || chunk_neg)) {     // wave-uniform: every lane holds the same phase
                 const int32_t i0 = (int32_t)c0 + g * OB;
@@ -356,10 +387,12 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
         if (lds < need) lds = need;
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_pulse_onsets, dim3(blocks), dim3(256), lds, st, inc, sample_off, n_notes, onset_idx, onset_cnt, overflow);
+        hipLaunchKernelGGL(k_pulse_onsets<false>, dim3(blocks), dim3(256), lds, st, inc, sample_off, n_notes, onset_idx, onset_cnt,
+                           overflow, (const unsigned char *)nullptr);
         LAUNCH_CHECK(ctx);
     }
     hipLaunchKernelGGL(k_onset_finish, dim3(n_notes), dim3(64), 0, st, f0, sample_off, n_notes, (double)ctx->plan.sr, onset_idx,
@@ -387,4 +420,232 @@ int launch_pulse_train(goofer_ctx *ctx, const float *f0, float f0_scale, const i
     if ((rc = launch_phase_inc(ctx, f0, f0_scale, total_samples, inc, st))) return rc;
     if ((rc = launch_pulse_onsets(ctx, f0, f0_scale, inc, sample_off, n_notes, onsets, onset_idx, onset_cnt, overflow, st))) return rc;
     return launch_pulse_place(ctx, onsets, onset_cnt, sample_off, n_notes, total_samples, pulse, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sub-harmonic pulse layer ('sg' flag) — gf.add_subharms + apply_subharm_vibrato (GOOFER.py:672-766).
+//
+//   k_subharm_inc     vibrato'd f0 (fp32 like the reference's array) and the tracker increments sub_f0/sr
+//   k_pulse_onsets<true>  the wrapped phase tracker, exact sequential order
+//   k_subharm_finish  per event: T = 1/sub_f0, n = max(3, round_half_even(sr T)), fp32 peak of its LF pulse, end_max
+//   k_subharm_place   gather of the covering LF pulses (ascending events), * voicing mask, per-note max
+//   k_subharm_add     pulse += sub / max * weight
+// LF pulse here is lf_model_pulse (GOOFER.py:437-471) with Ra .02, Rg 1.7, Rk 1 on an fp32 time grid.
+struct sub_cfg {
+    double ratio;        // 2^(semitones/12)
+    double vib_rate, vib_depth;
+    int vib_on, vib_fade;   // fade = int(delay * sr)
+    double sr;
+};
+
+__device__ __forceinline__ float sub_lf_raw(int k, int n, double T)
+{
+    const double step = T / (double)n;
+    const float tk = (float)((double)k * step);               // np.linspace(..., endpoint=False, dtype=float32)
+    const double Tp = 0.02 * T;
+    const double Tc = Tp + 1.0 * (T - Tp);
+    if ((double)tk < Tp) {
+        const float a = 3.141592653589793f * tk;               // np.pi * t[mask1] stays fp32 (weak python scalar)
+        const double s = sin((double)a / (2.0 * Tp));
+        return (float)(s * s);
+    }
+    if ((double)tk < Tc) {
+        const double tau = ((double)tk - Tp) / (Tc - Tp);
+        return (float)(exp(-1.7 * tau) * cos(3.141592653589793 * tau / 2.0));
+    }
+    return 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_subharm_inc(const float *__restrict__ f0, const float *__restrict__ mask,
+                                                     const int64_t *__restrict__ sample_off, int n_notes, int64_t total,
+                                                     const goofer_note_params *__restrict__ params, sub_cfg c,
+                                                     float *__restrict__ fm, double *__restrict__ inc)
+{
+    __shared__ int s_pair[2];
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    int lo, hi;
+    block_note_range(sample_off, n_notes, g0, total, s_pair, lo, hi);
+    const int64_t g = g0 + threadIdx.x;
+    if (g >= total) return;
+    int note = lo;
+    while (sample_off[note + 1] <= g) ++note;
+    if (!(params[note].subharm_weight > 0.f)) { inc[g] = 0.0; fm[g] = 0.f; return; }
+    const int64_t base = sample_off[note], n = sample_off[note + 1] - base, i = g - base;
+    float f = f0[g];
+    if (c.vib_on && f > 0.f) {
+        double v = sin(((2.0 * 3.141592653589793) * c.vib_rate) * ((double)i / c.sr) + 0.0);
+        if (c.vib_fade < n && i < c.vib_fade) {
+            const double fade = c.vib_fade > 1 ? (i >= c.vib_fade - 1 ? 1.0 : (double)i * (1.0 / (double)(c.vib_fade - 1))) : 0.0;
+            v *= fade;
+        }
+        f = (float)((double)f * (1.0 + v * c.vib_depth));
+    }
+    fm[g] = f;
+    double a = 0.0;
+    if (mask[g] > 0.f && f > 0.f) {
+        const double sub = (double)f * c.ratio;
+        if (!(sub < 1e-2)) a = sub / c.sr;
+    }
+    inc[g] = a;
+}
+
+// The reference keeps one LF pulse per '{sub_f0:.2f}' key (GOOFER.py:716-724): an event reuses the pulse of the FIRST
+// event whose sub_f0 prints to the same two decimals.  keys = the note's slice of the increment buffer (free once
+// the tracker has run), holding each event's own sub_f0.
+__global__ __launch_bounds__(64) void k_subharm_finish(const float *__restrict__ fm, const int64_t *__restrict__ sample_off, int n_notes,
+                                                       sub_cfg c, const int32_t *__restrict__ onset_idx,
+                                                       const int32_t *__restrict__ onset_cnt, double *__restrict__ keys_all,
+                                                       onset_t *__restrict__ onsets)
+{
+    const int note = blockIdx.x, lane = threadIdx.x;
+    const int64_t base = sample_off[note];
+    const int64_t obase = base / 2 + 16 * (int64_t)note;
+    const int cnt = onset_cnt[note];
+    double *keys = keys_all + base;                              // cnt <= n/2 + 16 would not fit a tiny note: clamp below
+    const int64_t n_note = sample_off[note + 1] - base;
+    const int kcap = (int)(cnt < n_note ? cnt : n_note);
+    for (int k = lane; k < kcap; k += WAVE) keys[k] = (double)fm[base + onset_idx[obase + k]] * c.ratio;
+    __threadfence_block();
+    wave_lds_sync();
+    int32_t carry = 0;
+    for (int k0 = 0; k0 < cnt; k0 += WAVE) {
+        const int k = k0 + lane;
+        int32_t i = 0, n = 0, e = 0;
+        float peak = 0.f;
+        double T = 0.0;
+        if (k < cnt) {
+            i = onset_idx[obase + k];
+            double sub = (double)fm[base + i] * c.ratio;
+            if (k < kcap) {
+                const double key = rint(sub * 100.0);
+                for (int j = 0; j < k; ++j) {
+                    const double sj = keys[j];
+                    if (rint(sj * 100.0) == key) { sub = sj; break; }
+                }
+            }
+            T = 1.0 / sub;
+            long t0 = (long)rint(c.sr * T);
+            n = (int32_t)(t0 <= 3 ? 3 : t0);
+            for (int q = 0; q < n; ++q) peak = fmaxf(peak, fabsf(sub_lf_raw(q, n, T)));
+            e = i + n;
+        }
+        int32_t m = e;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            int32_t o = __shfl_up(m, off, WAVE);
+            if (lane >= off) m = o > m ? o : m;
+        }
+        m = m > carry ? m : carry;
+        if (k < cnt) {
+            onset_t o;
+            o.i = i; o.T0 = n; o.end_max = m; o.pad = __float_as_int(peak); o.T = T;
+            onsets[obase + k] = o;
+        }
+        carry = __shfl(m, WAVE - 1, WAVE);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_subharm_place(const onset_t *__restrict__ onsets, const int32_t *__restrict__ onset_cnt,
+                                                       const float *__restrict__ mask, const int64_t *__restrict__ sample_off,
+                                                       int n_notes, int64_t total, const goofer_note_params *__restrict__ params,
+                                                       double *__restrict__ sub, unsigned long long *__restrict__ max_bits)
+{
+    __shared__ int s_pair[2];
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    int lo_n, hi_n;
+    block_note_range(sample_off, n_notes, g0, total, s_pair, lo_n, hi_n);
+    const int64_t g = g0 + threadIdx.x;
+    if (g >= total) return;
+    int note = lo_n;
+    while (sample_off[note + 1] <= g) ++note;
+    if (!(params[note].subharm_weight > 0.f)) return;
+    const int64_t base = sample_off[note];
+    const int32_t j = (int32_t)(g - base);
+    const onset_t *ol = onsets + (base / 2 + 16 * (int64_t)note);
+    const int cnt = onset_cnt[note];
+    double acc = 0.0;
+    int lo = -1, hi = cnt;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (ol[mid].i <= j) lo = mid; else hi = mid;
+    }
+    if (lo >= 0) {
+        int first = lo;
+        while (first > 0 && ol[first - 1].end_max > j) --first;
+        for (int k = first; k <= lo; ++k) {
+            const onset_t o = ol[k];
+            const int d = j - o.i;
+            if (d < o.T0) {
+                const float pk = __int_as_float(o.pad);
+                float v = sub_lf_raw(d, o.T0, o.T);
+                if (pk > 0.f) v = v / pk;
+                acc += (double)v;
+            }
+        }
+    }
+    acc *= (double)mask[g];
+    sub[g] = acc;
+    const double m = fabs(acc);
+    if (m > 0.0) atomicMax(max_bits + note, (unsigned long long)__double_as_longlong(m));
+}
+
+__global__ __launch_bounds__(256) void k_subharm_add(float *__restrict__ pulse, const double *__restrict__ sub,
+                                                     const unsigned long long *__restrict__ max_bits,
+                                                     const int64_t *__restrict__ sample_off, int n_notes, int64_t total,
+                                                     const goofer_note_params *__restrict__ params)
+{
+    __shared__ int s_pair[2];
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    int lo, hi;
+    block_note_range(sample_off, n_notes, g0, total, s_pair, lo, hi);
+    const int64_t g = g0 + threadIdx.x;
+    if (g >= total) return;
+    int note = lo;
+    while (sample_off[note + 1] <= g) ++note;
+    const float w = params[note].subharm_weight;
+    if (!(w > 0.f)) return;
+    double v = sub[g];
+    const double mx = __longlong_as_double((long long)max_bits[note]);
+    if (mx > 1e-6) v /= mx;
+    v *= (double)w;
+    pulse[g] = (float)((double)pulse[g] + v);
+}
+
+int launch_subharm(goofer_ctx *ctx, const float *f0s, const float *mask, const int64_t *sample_off, int n_notes, int64_t total,
+                   const goofer_note_params *params, double ratio, int vib_on, double vib_rate, double vib_depth, double vib_delay,
+                   float *fm, double *inc, onset_t *onsets, int32_t *onset_idx, int32_t *onset_cnt, int32_t *overflow,
+                   const unsigned char *note_on, double *sub, unsigned long long *max_bits, float *pulse, hipStream_t st)
+{
+    if (total <= 0 || n_notes <= 0) return GOOFER_OK;
+    sub_cfg c;
+    c.ratio = ratio; c.vib_rate = vib_rate; c.vib_depth = vib_depth; c.vib_on = vib_on;
+    c.sr = (double)ctx->plan.sr;
+    c.vib_fade = (int)(vib_delay * c.sr);
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(k_subharm_inc, dim3(nb), dim3(256), 0, st, f0s, mask, sample_off, n_notes, total, params, c, fm, inc);
+    LAUNCH_CHECK(ctx);
+    {
+        const int blocks = (n_notes + 3) / 4;
+        const int per_cu = (blocks + 255) / 256;
+        size_t lds = (size_t)(160 * 1024) / per_cu;
+        lds = lds / 1024 * 1024;
+        const size_t need = 4 * 2 * OC * sizeof(double);
+        if (lds < need) lds = need;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_pulse_onsets<true>, dim3(blocks), dim3(256), lds, st, inc, sample_off, n_notes, onset_idx, onset_cnt, overflow,
+                           note_on);
+        LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(k_subharm_finish, dim3(n_notes), dim3(64), 0, st, fm, sample_off, n_notes, c, onset_idx, onset_cnt, inc, onsets);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_subharm_place, dim3(nb), dim3(256), 0, st, onsets, onset_cnt, mask, sample_off, n_notes, total, params, sub,
+                       max_bits);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_subharm_add, dim3(nb), dim3(256), 0, st, pulse, sub, max_bits, sample_off, n_notes, total, params);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
 }

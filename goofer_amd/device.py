@@ -247,8 +247,12 @@ class Context:
 
     def synth_batch(self, env, env_lengths, f0, mask, sample_lengths, params: np.ndarray, formants=None, phi=None,
                     seed: int = 0, transition_sigma: float = 100.0, want_rec=True, want_mix=True, offsets=None,
-                    noise_f0=None, noise_vol=None, f0_jitter_speed: float = 100.0, vol_jitter_speed: float = 150.0):
+                    noise_f0=None, noise_vol=None, f0_jitter_speed: float = 100.0, vol_jitter_speed: float = 150.0,
+                    subharm=None):
         """Run goofer_synth_batch.
+
+        ``subharm`` = dict(semitones, vibrato, rate, depth, delay) switches the sub-harmonic pulse layer on for the
+        notes whose params.subharm_weight > 0 (gf.synthesize's add_subharm, GOOFER.py:1076-1097).
 
         env fp32 [R_total, n_bins] ld-strided device tensor; env_lengths rows per note;
         f0 / mask fp32 [N_total]; sample_lengths per note; params structured array (NOTE_PARAMS);
@@ -278,6 +282,11 @@ class Context:
                        noise_vol_h=noise_vol[0].data_ptr() if noise_vol is not None else None,
                        noise_vol_b=noise_vol[1].data_ptr() if noise_vol is not None else None,
                        f0_jitter_sigma=self.geom[0] / (f0_jitter_speed * 6), vol_jitter_sigma=self.geom[0] / (vol_jitter_speed * 6),
+                       subharm_ratio=2.0 ** (float(subharm["semitones"]) / 12.0) if subharm else 0.0,
+                       subharm_vib_rate=float(subharm.get("rate", 6.0)) if subharm else 0.0,
+                       subharm_vib_depth=float(subharm.get("depth", 0.1)) if subharm else 0.0,
+                       subharm_vib_delay=float(subharm.get("delay", 0.1)) if subharm else 0.0,
+                       subharm_vibrato=int(bool(subharm.get("vibrato", False))) if subharm else 0,
                        harm=out["harm"].data_ptr(),
                        uv=out["uv"].data_ptr(), bre=out["bre"].data_ptr(),
                        rec=out["rec"].data_ptr() if want_rec else None, mix=out["mix"].data_ptr() if want_mix else None)

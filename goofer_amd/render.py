@@ -96,7 +96,8 @@ class Renderer:
         ctx._check(ctx.lib.goofer_assemble_batch(ctx.h, C.byref(prep["assembly"]), ctx._stream()))
         return ctx.synth_batch(prep["env"], prep["env_lens"], prep["f0"], prep["mask"], prep["lens"], prep["params"],
                                formants=prep["formants"], phi=prep["phi"], seed=seed, want_rec=False, want_mix=True,
-                               offsets=prep["offsets"], noise_f0=prep["noise_f0"], noise_vol=prep["noise_vol"])
+                               offsets=prep["offsets"], noise_f0=prep["noise_f0"], noise_vol=prep["noise_vol"],
+                               subharm=S.SUBHARM if prep["subharm"] else None)
 
     def prepare(self, jobs, phi_seeds=None):
         """Plan every note on the host and make the batch resident in HBM (plans, tables, sources)."""
@@ -225,6 +226,8 @@ class Renderer:
             if req.volume_jitter:
                 par[i]["vol_jitter_harm"] = req.volume_jitter_strength
                 par[i]["vol_jitter_breath"] = req.volume_jitter_strength * 2
+            if req.add_subharm:
+                par[i]["subharm_weight"] = req.subharm_weight
         lens = [p.n_out for p in plans]
         # sh / sr draws come from the legacy global np.random stream, note by note, in the reference's order
         # (f0 jitter, harmonic volume, breath volume: GOOFER.py:666, 653)
@@ -252,7 +255,7 @@ class Renderer:
         ctx.reserve(frames, int(sum(lens)), n)
         torch.cuda.synchronize(ctx.device)
         return {"assembly": a, "keep": d, "env": env, "f0": f0, "mask": mask, "params": par, "lens": lens, "env_lens": env_lens,
-                "noise_f0": noise_f0, "noise_vol": noise_vol,
+                "noise_f0": noise_f0, "noise_vol": noise_vol, "subharm": any(r.add_subharm for _, r in jobs),
                 "formants": ctx.tensor(np.concatenate(F_cat)), "phi": phi, "plans": plans, "offsets": offsets,
                 "sample_off": np.concatenate([[0], np.cumsum(lens)]), "env_off": np.concatenate([[0], np.cumsum(env_lens)]),
                 "frames": frames, "samples": int(sum(lens)), "edit_rows": e_off}

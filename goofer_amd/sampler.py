@@ -25,7 +25,9 @@ _FLAG = re.compile(r"([A-Za-z]{1,4})([+-]?\d+)?")
 _SEMI = {"C": 0, "C#": 1, "D": 2, "D#": 3, "E": 4, "F": 5, "F#": 6, "G": 7, "G#": 8, "A": 9, "A#": 10, "B": 11}
 
 # flags whose processing is not on the device yet (SURVEY.md §8 f): fail loudly instead of ignoring
-UNSUPPORTED_FLAGS = ("su", "sj", "sa", "st", "sd", "vf", "pd", "sg")
+UNSUPPORTED_FLAGS = ("su", "sj", "sa", "st", "sd", "vf", "pd")
+# the resampler's fixed sub-harmonic layer settings (SillySampler.py:1027-1033)
+SUBHARM = {"semitones": 12, "vibrato": True, "rate": 75, "depth": 3, "delay": 0.01}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -119,6 +121,8 @@ class Request:
     f0_jitter_strength: float = 0.0
     volume_jitter: bool = False
     volume_jitter_strength: float = 0.0
+    add_subharm: bool = False
+    subharm_weight: float = 0.0
 
 
 def decode_request(pitch, velocity, flags="", offset=0, length=1000, consonant=0, cutoff=0, volume=100,
@@ -138,6 +142,9 @@ def decode_request(pitch, velocity, flags="", offset=0, length=1000, consonant=0
     r.f0_jitter_strength = (sh or 0) / 50.0
     r.volume_jitter = sr_ is not None and sr_ > 0
     r.volume_jitter_strength = (sr_ or 0) / 50.0
+    sg = g("sg", 0)                                                     # sub-harmonic pulse layer  :364-366
+    r.subharm_weight = (sg / 100.0) * 1.5
+    r.add_subharm = sg > 0
     r.breathiness_mix = (g("B", 0) + 100) / 100.0
     r.unvoiced_mix = (g("U", 0) + 100) / 100.0
     r.harmonic_mix = float(np.clip(g("V", 100), 0, 100) / 100.0)

@@ -83,6 +83,13 @@ typedef struct {
     const double *noise_vol_b;  /* breath volume jitter draw                                           */
     float f0_jitter_sigma;      /* sr / (6 * f0_jitter_speed)  samples            GOOFER.py:667        */
     float vol_jitter_sigma;     /* sr / (6 * volume_jitter_speed)                 GOOFER.py:654        */
+    /* sub-harmonic pulse layer ('sg'): notes with params.subharm_weight > 0         GOOFER.py:1076-1097  */
+    double subharm_ratio;       /* 2^(subharm_semitones / 12); 0 disables the layer for the batch         */
+    double subharm_vib_rate;    /* Hz                                              GOOFER.py:748-766       */
+    double subharm_vib_depth;
+    double subharm_vib_delay;   /* seconds of linear fade-in                                              */
+    int32_t subharm_vibrato;    /* 0 / 1                                                                  */
+    int32_t reserved3;
     float *harm, *uv, *bre;     /* [total_samples] stems, gain-normalised like the reference   */
     float *rec;                 /* [total_samples] harm+uv+bre (reconstruct), may be NULL      */
     float *mix;                 /* [total_samples] (harm*V + bre*B + uv*U)*volume, may be NULL */

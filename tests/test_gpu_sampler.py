@@ -74,7 +74,7 @@ def test_all_supported_notes_as_one_batch(renderer):
 
 def test_unsupported_flags_fail_loudly():
     from goofer_amd import sampler as S
-    for fl in ("su50", "sj30", "sa30", "st-50", "sd30", "vf40", "pd50", "sg50"):
+    for fl in ("su50", "sj30", "sa30", "st-50", "sd30", "vf40", "pd50"):
         with pytest.raises(NotImplementedError):
             S.decode_request("C4", "100", fl, "0", "1000", "0", "0", "100", "0", "!120", "AA")
 
@@ -143,3 +143,24 @@ def test_jitter_flags_sh_sr_match_reference(renderer):
     e = rms_err(out, ref) / max(1.0, float(np.max(np.abs(ref))))
     assert e < TOL, e
     assert e < 2e-5, e
+
+
+def test_subharm_flag_sg_matches_reference(renderer):
+    """sg: vibrato'd sub-harmonic LF pulse layer added to the pulse train (SillySampler.py:364-366, GOOFER.py:1076-1097)."""
+    g, source, req = _job("sg50")
+    assert req.add_subharm and abs(req.subharm_weight - 0.75) < 1e-12
+    (out,) = renderer.render([(source, req)], phi_seeds=[int(g["seed"][0])])
+    ref = g["out"]
+    assert out.shape == ref.shape
+    e = rms_err(out, ref) / max(1.0, float(np.max(np.abs(ref))))
+    assert e < TOL, e
+
+
+def test_subharm_mixed_batch(renderer):
+    """A note with sg next to notes without it: the layer touches only its own note."""
+    g, source, req = _job("sg50")
+    g0, source0, req0 = _job("default")
+    seeds = [int(g0["seed"][0]), int(g["seed"][0]), int(g0["seed"][0])]
+    outs = renderer.render([(source0, req0), (source, req), (source0, req0)], phi_seeds=seeds)
+    for o, r in zip(outs, (g0["out"], g["out"], g0["out"])):
+        assert rms_err(o, r) / max(1.0, float(np.max(np.abs(r)))) < TOL

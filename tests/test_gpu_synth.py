@@ -177,3 +177,24 @@ def test_synthesize_jitter_kwargs_vs_oracle(ctx):
                           formants=c["formants"], phi=c["phi"], ctx=ctx, **kw)
     for a, b, key in zip(got, ref, ("rec", "harm", "uv", "bre")):
         assert rms_err(a, b) < 2e-5, (key, rms_err(a, b))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(add_subharm=True),                                                         # defaults: -12 st, weight .5, no vibrato
+    dict(add_subharm=True, subharm_semitones=7, subharm_weight=1.2, subharm_vibrato=True, subharm_vibrato_rate=40.0,
+         subharm_vibrato_depth=0.6, subharm_vibrato_delay=0.05, pitch_shift=1.3),
+])
+def test_synthesize_subharm_kwargs_vs_oracle(ctx, kw):
+    """add_subharm kwargs of gf.synthesize (GOOFER.py:1076-1097) against the oracle's restatement."""
+    from goofer_amd import core
+    from oracle import goofer_ref as R
+    g = golden("synthesize")
+    c = _case(g, "plain")
+    args = (c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"])
+    ref = R.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=c["phi"], **kw)
+    got = core.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=c["phi"], ctx=ctx, **kw)
+    plain = core.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=c["phi"], ctx=ctx,
+                            pitch_shift=kw.get("pitch_shift", 1.0))
+    assert rms_err(got[1], plain[1]) > 1e-3                     # the layer is audible, not a no-op
+    for a, b, key in zip(got, ref, ("rec", "harm", "uv", "bre")):
+        assert rms_err(a, b) < 2e-5, (key, rms_err(a, b))
