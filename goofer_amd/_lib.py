@@ -35,6 +35,20 @@ NOTE_PLAN = np.dtype([
     ("n_out_rows", "<i4"), ("env_f64", "<i4"), ("n_out", "<i4"), ("n_pre", "<i4"), ("s_pre", "<i4"), ("s_tail", "<i4"),
     ("tail_len", "<i4"), ("want_samples", "<i4"), ("n_before_vel", "<i4"), ("pre_new", "<i4"), ("vel_active", "<i4"),
     ("force_voiced", "<i4"), ("n_bend", "<i4"), ("reserved", "<i4"),
+    ("fry_hz", "<f8"), ("fry_dir", "<i4"), ("fry_const_lo", "<i4"), ("fry_const_hi", "<i4"), ("fry_glide_lo", "<i4"),
+    ("fry_glide_hi", "<i4"), ("fry_a", "<i4"), ("fry_b", "<i4"), ("fry_fade", "<i4"), ("pd_on", "<i4"), ("reserved4", "<i4"),
+    ("pd_base", "<f8"),
+], align=True)
+
+# goofer_onepole_job / goofer_post_note
+ONEPOLE_JOB = np.dtype([
+    ("src_off", "<i8"), ("dst_off", "<i8"), ("f0_off", "<i8"), ("n", "<i4"), ("order", "<i4"), ("highpass", "<i4"),
+    ("f0_mode", "<i4"), ("cutoff_factor", "<f4"), ("reserved", "<i4"),
+], align=True)
+POST_NOTE = np.dtype([
+    ("su_off", "<i8"), ("sj_off", "<i8"), ("sa_off", "<i8"), ("su_gain", "<f4"), ("sj_mix", "<f4"), ("sa_mix", "<f4"),
+    ("sd_strength", "<f4"), ("tension", "<f4"), ("pitch_dyn", "<f4"), ("fry_a", "<i4"), ("fry_b", "<i4"), ("fry_fade", "<i4"),
+    ("reserved", "<i4"),
 ], align=True)
 
 
@@ -48,6 +62,18 @@ class Assembly(C.Structure):
         ("tilts", C.c_void_p), ("es_taps", C.c_void_p), ("fw_lo", C.c_void_p), ("fw_hi", C.c_void_p), ("fw_frac", C.c_void_p),
         ("tap_idx", C.c_void_p), ("tap_w", C.c_void_p), ("fst_tracks", C.c_void_p), ("mask_src", C.c_void_p), ("bend", C.c_void_p),
         ("edit_rows", C.c_void_p), ("env_out", C.c_void_p), ("f0_out", C.c_void_p), ("mask_out", C.c_void_p),
+        ("bend_out", C.c_void_p), ("any_fry", C.c_int32), ("reserved5", C.c_int32),
+    ]
+
+
+class Post(C.Structure):
+    """goofer_post"""
+    _fields_ = [
+        ("n_notes", C.c_int32), ("reserved", C.c_int32), ("total_samples", C.c_int64),
+        ("sample_off", C.c_void_p), ("sample_off_host", C.c_void_p), ("params", C.c_void_p), ("notes", C.c_void_p),
+        ("f0", C.c_void_p), ("mask", C.c_void_p), ("bend", C.c_void_p),
+        ("harm", C.c_void_p), ("uv", C.c_void_p), ("bre", C.c_void_p), ("su_harm", C.c_void_p), ("sj_harm", C.c_void_p),
+        ("sa_uv", C.c_void_p), ("sa_bre", C.c_void_p), ("mix", C.c_void_p),
     ]
 
 
@@ -97,6 +123,8 @@ EXPORTS = {
     "goofer_debug_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "goofer_debug_fetch": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "goofer_sizeof": (C.c_int, [C.c_int]),
+    "goofer_onepole_cascade": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "goofer_post_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "goofer_assemble_batch": (C.c_int, [C.c_void_p, C.POINTER(Assembly), C.c_void_p]),
     "goofer_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "goofer_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),

@@ -53,6 +53,23 @@ int launch_f0_jitter(goofer_ctx *, float *, const float *, const double *, const
                      const goofer_note_params *, hipStream_t);
 int launch_volume_jitter(goofer_ctx *, float *, float *, const double *, const double *, const double *, const unsigned long long *,
                          const unsigned long long *, const int64_t *, int, int64_t, const goofer_note_params *, hipStream_t);
+int launch_onepole(goofer_ctx *, const float *, float *, const float *, const goofer_onepole_job *, int, hipStream_t);
+int launch_post_layers(goofer_ctx *, float *, const float *, const float *, const goofer_post_note *, const int64_t *, int, int64_t,
+                       hipStream_t);
+int launch_post_fry(goofer_ctx *, float *, float *, const float *, const float *, const goofer_post_note *, const int64_t *, int, int64_t,
+                    hipStream_t);
+int launch_post_sd(goofer_ctx *, float *, const double *, const goofer_post_note *, const int64_t *, int, int64_t, hipStream_t);
+int launch_note_sumsq(goofer_ctx *, const float *, const float *, const goofer_post_note *, const int64_t *, int, int64_t, double *,
+                      hipStream_t);
+int launch_post_tension(goofer_ctx *, float *, float *, const float *, const goofer_post_note *, const int64_t *, int, int64_t,
+                        hipStream_t);
+int launch_post_scale(goofer_ctx *, float *, float *, const double *, const double *, const goofer_post_note *, const int64_t *, int,
+                      int64_t, hipStream_t);
+int launch_post_mix(goofer_ctx *, const float *, const float *, const float *, const float *, const float *, const double *,
+                    const goofer_post_note *, const unsigned char *, const goofer_note_params *, const int64_t *, int, int64_t, float *,
+                    hipStream_t);
+int launch_dyn_gain(goofer_ctx *, const double *, const double *, const unsigned char *, double *, const goofer_post_note *,
+                    const int64_t *, int, int64_t, double *, hipStream_t);
 int launch_stem_peak(goofer_ctx *, const float *, const float *, const float *, const int64_t *, int, int64_t, float *, hipStream_t);
 int launch_harm_frames(goofer_ctx *, const float *, const goofer_batch *, const float *, const int *, const int64_t *, float *, float *,
                        hipStream_t);
@@ -449,6 +466,9 @@ int goofer_sizeof(int which)
     case 1: return (int)sizeof(goofer_batch);
     case 2: return (int)sizeof(goofer_note_plan);
     case 3: return (int)sizeof(goofer_assembly);
+    case 4: return (int)sizeof(goofer_onepole_job);
+    case 5: return (int)sizeof(goofer_post_note);
+    case 6: return (int)sizeof(goofer_post);
     }
     return -1;
 }
@@ -638,6 +658,7 @@ int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *asmb, void *st
     if (!ctx || !asmb) return GOOFER_EINVAL;
     if (asmb->n_notes <= 0) return GOOFER_OK;
     if (asmb->ld < asmb->n_bins || asmb->max_K < 2 || asmb->max_K > 4096) return goofer_fail(ctx, GOOFER_EINVAL, "bad assembly geometry");
+    if (asmb->any_fry && ctx->plan.hop <= 0) return goofer_fail(ctx, GOOFER_EINVAL, "the fry envelope warp needs goofer_plan first");
     hipStream_t st = (hipStream_t)stream;
     goofer_assembly a = *asmb;
     size_t map_bytes = ((size_t)(a.total_edit_rows + a.total_out_rows) * sizeof(int) + 511) & ~(size_t)255;
@@ -656,6 +677,171 @@ int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *asmb, void *st
     int *map_out = map_edit + a.total_edit_rows;
     if (!a.edit_rows) a.edit_rows = (float *)((char *)ctx->asm_scratch + map_bytes);
     return launch_assemble(ctx, &a, map_edit, map_out, st);
+}
+
+int goofer_onepole_cascade(goofer_ctx *ctx, const float *src, float *dst, const float *f0, const goofer_onepole_job *jobs, int n_jobs,
+                           void *stream)
+{
+    NEED_PLAN(ctx);
+    if (!src || !dst || !f0 || !jobs) return goofer_fail(ctx, GOOFER_EINVAL, "null pointer");
+    return launch_onepole(ctx, src, dst, f0, jobs, n_jobs, (hipStream_t)stream);
+}
+
+// The post chain of one batch.  Host work: turn the per-note flags into job lists for the cascade kernel and upload
+// them with the note table; everything per sample runs on the device, in the reference's order.
+int goofer_post_batch(goofer_ctx *ctx, const goofer_post *p, void *stream)
+{
+    NEED_PLAN(ctx);
+    if (!p || !p->notes || !p->sample_off || !p->sample_off_host || !p->harm || !p->uv || !p->bre || !p->mix || !p->f0 || !p->mask ||
+        !p->params)
+        return goofer_fail(ctx, GOOFER_EINVAL, "null pointer in goofer_post");
+    const int n = p->n_notes;
+    const int64_t N = p->total_samples;
+    if (n <= 0 || N <= 0) return GOOFER_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const double sr = (double)ctx->plan.sr;
+
+    enum { J_SU, J_SJ, J_FRY_H, J_FRY_B, J_ST_H, J_ST_B, J_ST_HP, J_LISTS };
+    std::vector<goofer_onepole_job> jobs[J_LISTS];
+    std::vector<unsigned char> on_any(n, 0), on_sd(n, 0), on_pd(n, 0);
+    bool any = false, any_layers = false, any_fry = false, any_sd = false, any_st = false, any_pd = false;
+    for (int i = 0; i < n; ++i) {
+        const goofer_post_note &q = p->notes[i];
+        const int64_t off = p->sample_off_host[i];
+        const int64_t len = p->sample_off_host[i + 1] - off;
+        if (len <= 0) continue;
+        if (len > INT32_MAX) return goofer_fail(ctx, GOOFER_EINVAL, "note too long");
+        auto job = [&](int64_t so, int64_t d_o, int order, int hp, int mode, double cf) {
+            goofer_onepole_job j;
+            j.src_off = so; j.dst_off = d_o; j.f0_off = off; j.n = (int32_t)len; j.order = order; j.highpass = hp; j.f0_mode = mode;
+            j.cutoff_factor = (float)cf; j.reserved = 0;
+            return j;
+        };
+        bool on = false;
+        if (q.su_off >= 0) {
+            if (!p->su_harm) return goofer_fail(ctx, GOOFER_EINVAL, "su_off set but su_harm is null");
+            jobs[J_SU].push_back(job(q.su_off, q.su_off, 12, 1, 1, 1.0));                  // two chained order-6 calls :1051-1058
+            on = any_layers = true;
+        }
+        if (q.sj_off >= 0) {
+            if (!p->sj_harm) return goofer_fail(ctx, GOOFER_EINVAL, "sj_off set but sj_harm is null");
+            jobs[J_SJ].push_back(job(q.sj_off, q.sj_off, 12, 1, 1, 1.0));                  // :1078-1080
+            on = any_layers = true;
+        }
+        if (q.fry_a < q.fry_b) {
+            jobs[J_FRY_H].push_back(job(off, off, 6, 1, 2, 200.0));                        // :1090-1095
+            jobs[J_FRY_B].push_back(job(off, off, 6, 1, 2, 200.0));
+            on = any_fry = true;
+        }
+        if (q.sd_strength > 0.f) { on_sd[i] = 1; on = any_sd = true; }
+        if (q.tension != 0.f) {
+            const double t = fabs((double)q.tension);
+            if (q.tension < 0.f) {
+                long o = lrint(1.0 + t * 4.0);                                              // np.round: half to even   :1120-1121
+                o = o < 1 ? 1 : (o > 6 ? 6 : o);
+                jobs[J_ST_H].push_back(job(off, off, (int)o, 0, 0, 2.0 - t * 0.75));
+                jobs[J_ST_B].push_back(job(off, off, 4, 1, 0, t));
+            } else {
+                jobs[J_ST_HP].push_back(job(off, off, 4, 1, 0, t * 4.0));                  // :1129
+                jobs[J_ST_B].push_back(job(off, off, 6, 0, 0, (2.0 - t) / 0.5));           // :1133-1134
+            }
+            on = any_st = true;
+        }
+        if (q.sa_off >= 0) {
+            if (!p->sa_uv || !p->sa_bre) return goofer_fail(ctx, GOOFER_EINVAL, "sa_off set but sa_uv / sa_bre is null");
+            on = true;
+        }
+        if (q.pitch_dyn != 0.f) {
+            if (!p->bend) return goofer_fail(ctx, GOOFER_EINVAL, "pitch_dyn set but bend is null");
+            on_pd[i] = 1;
+            on = any_pd = true;
+        }
+        on_any[i] = on;
+        any |= on;
+    }
+    if (!any) return GOOFER_OK;
+
+    // staging blob: note table | job lists | flags | taps
+    std::vector<double> taps20, taps_pd;
+    int r20 = 0, r_pd = 0;
+    if (any_sd) gauss_taps_host(20.0, taps20, r20);                                         // :1109
+    if (any_pd) gauss_taps_host((double)std::max(1, (int)(0.010 * sr)), taps_pd, r_pd);     // :865-866, 880
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t o_notes = 0, o_jobs[J_LISTS], o_any, o_sd, o_pd, o_t20, o_tpd, blob = al((size_t)n * sizeof(goofer_post_note));
+    for (int k = 0; k < J_LISTS; ++k) { o_jobs[k] = blob; blob += al(jobs[k].size() * sizeof(goofer_onepole_job)); }
+    o_any = blob; blob += al(n);
+    o_sd = blob; blob += al(n);
+    o_pd = blob; blob += al(n);
+    o_t20 = blob; blob += al(taps20.size() * sizeof(double));
+    o_tpd = blob; blob += al(taps_pd.size() * sizeof(double));
+    std::vector<unsigned char> host(blob, 0);
+    memcpy(host.data() + o_notes, p->notes, (size_t)n * sizeof(goofer_post_note));
+    for (int k = 0; k < J_LISTS; ++k)
+        if (!jobs[k].empty()) memcpy(host.data() + o_jobs[k], jobs[k].data(), jobs[k].size() * sizeof(goofer_onepole_job));
+    memcpy(host.data() + o_any, on_any.data(), n);
+    memcpy(host.data() + o_sd, on_sd.data(), n);
+    memcpy(host.data() + o_pd, on_pd.data(), n);
+    if (!taps20.empty()) memcpy(host.data() + o_t20, taps20.data(), taps20.size() * sizeof(double));
+    if (!taps_pd.empty()) memcpy(host.data() + o_tpd, taps_pd.data(), taps_pd.size() * sizeof(double));
+
+    const bool need_tmp = any_fry || any_st;
+    const bool need_d = any_sd || any_pd;
+    size_t need = blob + 4096 + (need_tmp ? 2 * al((size_t)N * sizeof(float)) : 0) +
+                  (need_d ? 2 * al((size_t)N * sizeof(double)) : 0) + (any_pd ? al((size_t)N * sizeof(double)) : 0) +
+                  4 * al((size_t)n * sizeof(double));
+    int rc = ensure_scratch(ctx, need);
+    if (rc) return rc;
+    arena a{(char *)ctx->scratch, ctx->scratch_bytes, 0};
+    unsigned char *d_blob = a.take<unsigned char>(blob);
+    float *tmpA = need_tmp ? a.take<float>(N) : nullptr, *tmpB = need_tmp ? a.take<float>(N) : nullptr;
+    double *tmpD1 = need_d ? a.take<double>(N) : nullptr, *tmpD2 = need_d ? a.take<double>(N) : nullptr;
+    double *dyn = any_pd ? a.take<double>(N) : nullptr;
+    double *sums = a.take<double>(2 * (size_t)n), *ref = a.take<double>(n);
+    if (!d_blob || !sums || !ref || (need_tmp && (!tmpA || !tmpB)) || (need_d && (!tmpD1 || !tmpD2)) || (any_pd && !dyn))
+        return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
+    HIP_TRY(ctx, hipMemcpyAsync(d_blob, host.data(), blob, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));                   // the staging vector dies with this call
+    const goofer_post_note *d_notes = (const goofer_post_note *)(d_blob + o_notes);
+    auto d_jobs = [&](int k) { return (const goofer_onepole_job *)(d_blob + o_jobs[k]); };
+    const unsigned char *d_any = d_blob + o_any, *d_sd = d_blob + o_sd, *d_pd = d_blob + o_pd;
+    const double *d_t20 = (const double *)(d_blob + o_t20), *d_tpd = (const double *)(d_blob + o_tpd);
+
+    // su / sj layers
+    if (any_layers) {
+        if ((rc = launch_onepole(ctx, p->su_harm, p->su_harm, p->f0, d_jobs(J_SU), (int)jobs[J_SU].size(), st))) return rc;
+        if ((rc = launch_onepole(ctx, p->sj_harm, p->sj_harm, p->f0, d_jobs(J_SJ), (int)jobs[J_SJ].size(), st))) return rc;
+        if ((rc = launch_post_layers(ctx, p->harm, p->su_harm, p->sj_harm, d_notes, p->sample_off, n, N, st))) return rc;
+    }
+    // fry part 2
+    if (any_fry) {
+        if ((rc = launch_onepole(ctx, p->harm, tmpA, p->f0, d_jobs(J_FRY_H), (int)jobs[J_FRY_H].size(), st))) return rc;
+        if ((rc = launch_onepole(ctx, p->bre, tmpB, p->f0, d_jobs(J_FRY_B), (int)jobs[J_FRY_B].size(), st))) return rc;
+        if ((rc = launch_post_fry(ctx, p->harm, p->bre, tmpA, tmpB, d_notes, p->sample_off, n, N, st))) return rc;
+    }
+    // sd dryness
+    if (any_sd) {
+        if ((rc = launch_gauss_samples<float>(ctx, p->mask, p->sample_off, n, N, d_t20, r20, d_sd, tmpD1, st))) return rc;
+        if ((rc = launch_post_sd(ctx, p->bre, tmpD1, d_notes, p->sample_off, n, N, st))) return rc;
+    }
+    // st tension
+    if (any_st) {
+        HIP_TRY(ctx, hipMemsetAsync(sums, 0, 2 * (size_t)n * sizeof(double), st));
+        if ((rc = launch_note_sumsq(ctx, p->harm, p->bre, d_notes, p->sample_off, n, N, sums, st))) return rc;
+        if ((rc = launch_onepole(ctx, p->harm, tmpA, p->f0, d_jobs(J_ST_HP), (int)jobs[J_ST_HP].size(), st))) return rc;
+        if ((rc = launch_onepole(ctx, p->harm, p->harm, p->f0, d_jobs(J_ST_H), (int)jobs[J_ST_H].size(), st))) return rc;
+        if ((rc = launch_onepole(ctx, p->bre, p->bre, p->f0, d_jobs(J_ST_B), (int)jobs[J_ST_B].size(), st))) return rc;
+        if ((rc = launch_post_tension(ctx, p->harm, p->bre, tmpA, d_notes, p->sample_off, n, N, st))) return rc;
+        if ((rc = launch_note_sumsq(ctx, p->harm, p->bre, d_notes, p->sample_off, n, N, sums + n, st))) return rc;
+        if ((rc = launch_post_scale(ctx, p->harm, p->bre, sums, sums + n, d_notes, p->sample_off, n, N, st))) return rc;
+    }
+    // pd gain curve
+    if (any_pd) {
+        if ((rc = launch_gauss_samples<float>(ctx, p->bend, p->sample_off, n, N, d_tpd, r_pd, d_pd, tmpD1, st))) return rc;
+        if ((rc = launch_gauss_samples<float>(ctx, p->mask, p->sample_off, n, N, d_tpd, r_pd, d_pd, tmpD2, st))) return rc;
+        if ((rc = launch_dyn_gain(ctx, tmpD1, tmpD2, d_pd, ref, d_notes, p->sample_off, n, N, dyn, st))) return rc;
+    }
+    return launch_post_mix(ctx, p->harm, p->uv, p->bre, p->sa_uv, p->sa_bre, dyn, d_notes, d_any, p->params, p->sample_off, n, N,
+                           p->mix, st);
 }
 
 int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)

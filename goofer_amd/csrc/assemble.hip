@@ -231,7 +231,76 @@ __global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a
     }
     const double hz = 440.0 * exp2((midi - 69.0) / 12.0);
     a.mask_out[g] = (float)mk;
-    a.f0_out[g] = (float)(mk * hz);
+    double f0 = mk * hz;
+    if (p.pd_on && a.bend_out) a.bend_out[g] = (float)(midi - p.pd_base);                    // 'pd' bend in semitones   :861-863
+    // vocal fry part 1: f0 pulled to fry_hz over a constant stretch plus a linear glide       :883-934
+    if (p.fry_dir != 0) {
+        const double base_hz = p.fry_hz * (mk > 0.0 ? 1.0 : 0.0);
+        if (i >= p.fry_const_lo && i < p.fry_const_hi) {
+            f0 = base_hz;
+        } else if (i >= p.fry_glide_lo && i < p.fry_glide_hi) {
+            const int m = p.fry_glide_hi - p.fry_glide_lo, k = (int)(i - p.fry_glide_lo);
+            double w;                                         // np.linspace(0, 1, m) or np.linspace(1, 0, m), endpoint pinned
+            if (p.fry_dir > 0) w = m > 1 ? (k == m - 1 ? 1.0 : (double)k * (1.0 / (double)(m - 1))) : 0.0;
+            else w = m > 1 ? (k == m - 1 ? 0.0 : (double)k * (-1.0 / (double)(m - 1)) + 1.0) : 1.0;
+            f0 = (1.0 - w) * base_hz + w * f0;
+        }
+    }
+    a.f0_out[g] = (float)f0;
+}
+
+// vocal fry part 1b: frames under the fry mask get their bin axis squeezed by 1 - 0.08 w   SillySampler.py:966-994
+__device__ __forceinline__ float plan_fry_mask(const goofer_note_plan &p, int64_t i)
+{
+    const int a = p.fry_a, b = p.fry_b, fade = p.fry_fade;
+    if (i < a || i >= b) return 0.f;
+    float v = 1.0f;
+    if (fade > 0) {
+        const int a1 = b < a + fade ? b : a + fade;
+        if (i < a1) {
+            const int m = a1 - a, k = (int)(i - a);
+            const double w = m > 1 ? (k == m - 1 ? 1.0 : (double)k * (1.0 / (double)(m - 1))) : 0.0;
+            v = (float)((double)v * w);
+        }
+        const int b0 = a > b - fade ? a : b - fade;
+        if (i >= b0) {
+            const int m = b - b0, k = (int)(i - b0);
+            const double w = m > 1 ? (k == m - 1 ? 0.0 : (double)k * (-1.0 / (double)(m - 1)) + 1.0) : 1.0;
+            v = (float)((double)v * w);
+        }
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_env_fry(const goofer_assembly a, int64_t total_out_rows, const int *__restrict__ row_note, int hop)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int B = a.n_bins;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t orow = (int64_t)blockIdx.x * A_ROWS + wave;
+    if (orow >= total_out_rows) return;
+    const int note = row_note[orow];
+    const goofer_note_plan p = a.notes[note];
+    if (p.fry_a >= p.fry_b || p.n_out <= 0) return;
+    const int64_t j = orow - p.env_off;
+    int64_t c = j * hop + hop / 2;
+    if (c > p.n_out - 1) c = p.n_out - 1;
+    const float w = plan_fry_mask(p, c);
+    if (!(w > 1e-6f)) return;
+    const double sc = 1.0 - (double)w * (1.0 - 0.92);
+    if (fabs(sc - 1.0) < 1e-6) return;
+    float *row = reinterpret_cast<float *>(smem) + (size_t)wave * ((B + 3) & ~3);
+    float *g = a.env_out + orow * (int64_t)a.ld;
+    for (int b = lane; b < B; b += WAVE) row[b] = g[b];
+    wave_lds_sync();
+    for (int b = lane; b < B; b += WAVE) {
+        double src = (double)b / sc;
+        src = src < 0.0 ? 0.0 : (src > (double)(B - 1) ? (double)(B - 1) : src);
+        const int lo = (int)floor(src);
+        const int hi = lo + 1 < B - 1 ? lo + 1 : B - 1;
+        const double fr = src - (double)lo;
+        g[b] = (float)((1.0 - fr) * (double)row[lo] + fr * (double)row[hi]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -268,6 +337,12 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         hipLaunchKernelGGL(k_env_loop, dim3((unsigned)((a->total_out_rows + A_ROWS - 1) / A_ROWS)), dim3(256), 0, st, *a,
                            a->total_out_rows, row_note_out);
         LAUNCH_CHECK(ctx);
+        if (a->any_fry) {
+            size_t lds = (size_t)A_ROWS * ((B + 3) & ~3) * sizeof(float);
+            hipLaunchKernelGGL(k_env_fry, dim3((unsigned)((a->total_out_rows + A_ROWS - 1) / A_ROWS)), dim3(256), lds, st, *a,
+                               a->total_out_rows, row_note_out, ctx->plan.hop);
+            LAUNCH_CHECK(ctx);
+        }
     }
     if (a->total_samples > 0) {
         hipLaunchKernelGGL(k_sample_assemble, dim3((unsigned)((a->total_samples + 255) / 256)), dim3(256), 0, st, *a, a->total_samples);

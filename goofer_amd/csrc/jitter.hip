@@ -10,7 +10,7 @@
 // each wave stages its window in LDS so every input sample is fetched once per 64 outputs.
 #include "common.h"
 
-#define GS_MAXR 1024          // radius limit (sigma <= 256)
+#define GS_MAXR 1920          // radius limit (sigma <= 480): taps + window must fit 64 KB of LDS
 
 template <typename Tin>
 __global__ __launch_bounds__(256) void k_gauss_samples(const Tin *__restrict__ in, const int64_t *__restrict__ sample_off, int n_notes,

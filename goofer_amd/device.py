@@ -226,6 +226,22 @@ class Context:
         r.copy_(torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)))
         return r
 
+    def onepole_cascade(self, x, f0, cutoff_factor: float, order: int = 4, btype: str = "lowpass", f0_mode: int = 0, lengths=None):
+        """dynamic_butter_filter (SillySampler.py:95-174) on fp32 device signals: every note of ``lengths`` (default:
+        the whole array as one note) is filtered with the same settings.  Returns a new tensor."""
+        n_total = x.numel()
+        lengths = [n_total] if lengths is None else list(lengths)
+        off = self.offsets(lengths)
+        jobs = np.zeros(len(lengths), dtype=_lib.ONEPOLE_JOB)
+        jobs["src_off"] = jobs["dst_off"] = jobs["f0_off"] = off[:-1]
+        jobs["n"], jobs["order"], jobs["highpass"] = lengths, order, int(btype != "lowpass")
+        jobs["f0_mode"], jobs["cutoff_factor"] = f0_mode, cutoff_factor
+        d_jobs = self.tensor(jobs.view(np.uint8))
+        y = torch.empty_like(x)
+        self._check(self.lib.goofer_onepole_cascade(self.h, _ptr(x), _ptr(y), _ptr(f0), _ptr(d_jobs), len(lengths), self._stream()))
+        y._keep = d_jobs
+        return y
+
     # -- the batch ------------------------------------------------------------------------------
     def device_offsets(self, env_lengths, sample_lengths, params: np.ndarray):
         """Upload the CSR offsets and the per-note parameter array once (reused by every step of a resident batch)."""

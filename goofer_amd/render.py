@@ -94,10 +94,81 @@ class Renderer:
         """The device work of one batch: goofer_assemble_batch then goofer_synth_batch (asynchronous)."""
         ctx = self.ctx
         ctx._check(ctx.lib.goofer_assemble_batch(ctx.h, C.byref(prep["assembly"]), ctx._stream()))
-        return ctx.synth_batch(prep["env"], prep["env_lens"], prep["f0"], prep["mask"], prep["lens"], prep["params"],
-                               formants=prep["formants"], phi=prep["phi"], seed=seed, want_rec=False, want_mix=True,
-                               offsets=prep["offsets"], noise_f0=prep["noise_f0"], noise_vol=prep["noise_vol"],
-                               subharm=S.SUBHARM if prep["subharm"] else None)
+        out = ctx.synth_batch(prep["env"], prep["env_lens"], prep["f0"], prep["mask"], prep["lens"], prep["params"],
+                              formants=prep["formants"], phi=prep["phi"], seed=seed, want_rec=False, want_mix=True,
+                              offsets=prep["offsets"], noise_f0=prep["noise_f0"], noise_vol=prep["noise_vol"],
+                              subharm=S.SUBHARM if prep["subharm"] else None)
+        if prep["post"] is not None:
+            self._post_chain(prep, out, seed)
+        return out
+
+    # -- sample-domain post chain (SillySampler.py:1037-1182) ------------------------------------------------------
+    def _subset(self, prep, idxs):
+        """The assembled inputs of the notes ``idxs`` as their own ragged batch (views when that is every note)."""
+        ctx = self.ctx
+        n = len(prep["lens"])
+        if list(idxs) == list(range(n)):
+            return {"env": prep["env"], "f0": prep["f0"], "mask": prep["mask"], "formants": prep["formants"], "phi": prep["phi"]}
+        so, eo = prep["sample_off"], prep["env_off"]
+        fo = np.concatenate([[0], np.cumsum(ctx.frame_counts(prep["lens"]))])
+        cat = lambda t, off: torch.cat([t[int(off[i]):int(off[i + 1])] for i in idxs])
+        env = ctx.rows(int(sum(eo[i + 1] - eo[i] for i in idxs)), ctx.n_bins)
+        env.copy_(cat(prep["env"], eo))
+        phi = None
+        if prep["phi"] is not None:
+            phi = ctx.rows(int(sum(fo[i + 1] - fo[i] for i in idxs)), ctx.n_bins)
+            phi.copy_(cat(prep["phi"], fo))
+        return {"env": env, "f0": cat(prep["f0"], so), "mask": cat(prep["mask"], so), "formants": cat(prep["formants"], eo), "phi": phi}
+
+    def _extra_synth(self, prep, idxs, seed, edit=None, **kw):
+        """One more gf.synthesize call for the notes ``idxs`` (the su / sj / sa layers re-enter the synth)."""
+        sub = self._subset(prep, idxs)
+        par = prep["params"][list(idxs)].copy()
+        for k in ("f0_jitter", "vol_jitter_harm", "vol_jitter_breath", "subharm_weight"):
+            par[k] = 0                                          # the layer calls pass none of the jitter / sg arguments
+        if edit is not None:
+            edit(sub, par)
+        lens, env_lens = [prep["lens"][i] for i in idxs], [prep["env_lens"][i] for i in idxs]
+        out = self.ctx.synth_batch(sub["env"], env_lens, sub["f0"], sub["mask"], lens, par, formants=sub["formants"], phi=sub["phi"],
+                                   seed=seed, want_rec=False, want_mix=False, **kw)
+        out["_sub"] = sub
+        return out, np.concatenate([[0], np.cumsum(lens)])
+
+    def _post_chain(self, prep, out, seed):
+        ctx, post, jobs = self.ctx, prep["post"].copy(), prep["jobs"]
+        n = len(jobs)
+        extra = {}
+        su = [i for i, (_, r) in enumerate(jobs) if r.subharm_gain > 0.0]
+        sj = [i for i, (_, r) in enumerate(jobs) if r.growl_mix > 0.0]
+        sa = [i for i, (_, r) in enumerate(jobs) if r.aperiodic_mix > 0.0]
+        if su:                                                  # f0 * 0.5 == pitch_shift 0.5 on the fp32 f0          :1038-1049
+            def half(sub, par):
+                par["pitch_shift"] = 0.5
+            extra["su"], off = self._extra_synth(prep, su, seed, edit=half)
+            post["su_off"][su] = off[:-1]
+        if sj:
+            scale = ctx.tensor(np.concatenate([prep["growl"][i] for i in sj]))
+            def growl(sub, par):
+                sub["f0"] = (sub["f0"].double() * scale).float()
+            extra["sj"], off = self._extra_synth(prep, sj, seed, edit=growl)
+            post["sj_off"][sj] = off[:-1]
+        if sa:                                                  # all-voiced, full-strength noise, transition sigma 1   :1153-1168
+            def whisper(sub, par):
+                sub["mask"] = torch.ones_like(sub["mask"])
+                par["uv_strength"], par["breath_strength"] = 1.0, 1.0
+            extra["sa"], off = self._extra_synth(prep, sa, seed ^ 0x5A5A5A5A, edit=whisper, transition_sigma=1.0)
+            post["sa_off"][sa] = off[:-1]
+        s_host = np.ascontiguousarray(prep["offsets"]["s_off"], dtype=np.int64)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        g = lambda k, s: extra[k][s] if k in extra else None
+        P = _lib.Post(n_notes=n, total_samples=int(s_host[-1]), sample_off=prep["offsets"]["d_s"].data_ptr(),
+                      sample_off_host=s_host.ctypes.data, params=prep["offsets"]["d_par"].data_ptr(), notes=post.ctypes.data,
+                      f0=prep["f0"].data_ptr(), mask=prep["mask"].data_ptr(), bend=ptr(prep["bend_out"]),
+                      harm=out["harm"].data_ptr(), uv=out["uv"].data_ptr(), bre=out["bre"].data_ptr(),
+                      su_harm=ptr(g("su", "harm")), sj_harm=ptr(g("sj", "harm")), sa_uv=ptr(g("sa", "uv")), sa_bre=ptr(g("sa", "bre")),
+                      mix=out["mix"].data_ptr())
+        ctx._check(ctx.lib.goofer_post_batch(ctx.h, C.byref(P), ctx._stream()))
+        out["_keep_post"] = (extra, post, s_host)
 
     def prepare(self, jobs, phi_seeds=None):
         """Plan every note on the host and make the batch resident in HBM (plans, tables, sources)."""
@@ -170,6 +241,12 @@ class Renderer:
             tc = req.flags.get("t", 0)
             q["pitch_t"] = (tc / 100.0) if tc else 0.0
             q["tick_dt"] = 60.0 / (req.tempo * 96.0)
+            fx = p.extra
+            q["fry_hz"], q["fry_dir"] = req.fry_hz, fx["fry_dir"]
+            q["fry_const_lo"], q["fry_const_hi"] = fx["fry_const"]
+            q["fry_glide_lo"], q["fry_glide_hi"] = fx["fry_glide"]
+            (q["fry_a"], q["fry_b"]), q["fry_fade"] = fx["fry_mask"], fx["fry_fade"]
+            q["pd_on"], q["pd_base"] = int(req.pitch_dyn != 0.0), req.pitch_m + ((req.flags.get("t", 0) or 0) / 100.0)
             knots_cat.append(np.ascontiguousarray(src.knots.T))
             mask_cat.append(src.mask[:src.ylen])
             bend_cat.append(req.bend)
@@ -205,13 +282,17 @@ class Renderer:
         f0 = torch.empty(o_off, dtype=torch.float32, device=ctx.device)
         mask = torch.empty(o_off, dtype=torch.float32, device=ctx.device)
         ptr = lambda t: t.data_ptr() if t is not None else None
+        any_pd = any(r.pitch_dyn != 0.0 for _, r in jobs)
+        any_fry = any(pl.extra["fry_mask"][1] > pl.extra["fry_mask"][0] for pl in plans)
+        bend_out = torch.zeros(o_off, dtype=torch.float32, device=ctx.device) if any_pd else None
         a = _lib.Assembly(n_notes=n, n_bins=B, ld=ld, sr=sr, max_K=int(max(s.knots.shape[0] for s, _ in jobs)),
                           total_edit_rows=e_off, total_out_rows=t_off, total_samples=o_off,
                           notes=ptr(d["notes"]), knots=ptr(d["knots"]), lerp_idx=ptr(d["lerp_idx"]), lerp_w0=ptr(d["lerp_w0"]),
                           lerp_w1=ptr(d["lerp_w1"]), tilts=ptr(d["tilts"]), es_taps=ptr(d["es_taps"]), fw_lo=ptr(d["fw_lo"]),
                           fw_hi=ptr(d["fw_hi"]), fw_frac=ptr(d["fw_frac"]), tap_idx=ptr(d["tap_idx"]), tap_w=ptr(d["tap_w"]),
                           fst_tracks=ptr(d["fst_tracks"]), mask_src=ptr(d["mask_src"]), bend=ptr(d["bend"]), edit_rows=None,
-                          env_out=env.data_ptr(), f0_out=f0.data_ptr(), mask_out=mask.data_ptr())
+                          env_out=env.data_ptr(), f0_out=f0.data_ptr(), mask_out=mask.data_ptr(), bend_out=ptr(bend_out),
+                          any_fry=int(any_fry))
         # per-note synthesize parameters
         par = default_params(n)
         for i, (_, req) in enumerate(jobs):
@@ -242,6 +323,19 @@ class Renderer:
                 noise_f0 = ctx.tensor(np.concatenate(nf))
             if any(r.volume_jitter for _, r in jobs):
                 noise_vol = (ctx.tensor(np.concatenate(nh)), ctx.tensor(np.concatenate(nb)))
+        # sample-domain post chain: per-note table (offsets into the extra synth calls are filled in by run())
+        post = np.zeros(n, dtype=_lib.POST_NOTE)
+        growl = {}
+        for i, ((_, req), pl) in enumerate(zip(jobs, plans)):
+            post[i]["su_off"] = post[i]["sj_off"] = post[i]["sa_off"] = -1
+            post[i]["su_gain"], post[i]["sj_mix"], post[i]["sa_mix"] = req.subharm_gain, req.growl_mix, req.aperiodic_mix
+            post[i]["sd_strength"], post[i]["tension"], post[i]["pitch_dyn"] = req.sd_strength, req.tension, req.pitch_dyn
+            (post[i]["fry_a"], post[i]["fry_b"]), post[i]["fry_fade"] = pl.extra["fry_mask"], pl.extra["fry_fade"]
+            if req.growl_mix > 0.0:                            # 'sj': f0 * 0.5 * 2^N(0, mix^2), a fresh generator per call  :1063-1065
+                rng = np.random.default_rng(phi_seeds[i]) if phi_seeds is not None else np.random.default_rng()
+                growl[i] = 0.5 * (2.0 ** rng.normal(loc=0.0, scale=req.growl_mix ** 2, size=pl.n_out))
+        has_post = any(r.subharm_gain > 0 or r.growl_mix > 0 or r.aperiodic_mix > 0 or r.sd_strength > 0 or r.tension != 0
+                       or r.pitch_dyn != 0 for _, r in jobs) or any_fry
         env_lens = [p.tap_idx.shape[0] for p in plans]
         phi = None
         if phi_seeds is not None:
@@ -256,6 +350,7 @@ class Renderer:
         torch.cuda.synchronize(ctx.device)
         return {"assembly": a, "keep": d, "env": env, "f0": f0, "mask": mask, "params": par, "lens": lens, "env_lens": env_lens,
                 "noise_f0": noise_f0, "noise_vol": noise_vol, "subharm": any(r.add_subharm for _, r in jobs),
+                "post": post if has_post else None, "growl": growl, "bend_out": bend_out, "jobs": jobs,
                 "formants": ctx.tensor(np.concatenate(F_cat)), "phi": phi, "plans": plans, "offsets": offsets,
                 "sample_off": np.concatenate([[0], np.cumsum(lens)]), "env_off": np.concatenate([[0], np.cumsum(env_lens)]),
                 "frames": frames, "samples": int(sum(lens)), "edit_rows": e_off}

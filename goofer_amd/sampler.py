@@ -24,8 +24,6 @@ _NOTE = re.compile(r"([A-G]#?)(-?\d+)")
 _FLAG = re.compile(r"([A-Za-z]{1,4})([+-]?\d+)?")
 _SEMI = {"C": 0, "C#": 1, "D": 2, "D#": 3, "E": 4, "F": 5, "F#": 6, "G": 7, "G#": 8, "A": 9, "A#": 10, "B": 11}
 
-# flags whose processing is not on the device yet (SURVEY.md §8 f): fail loudly instead of ignoring
-UNSUPPORTED_FLAGS = ("su", "sj", "sa", "st", "sd", "vf", "pd")
 # the resampler's fixed sub-harmonic layer settings (SillySampler.py:1027-1033)
 SUBHARM = {"semitones": 12, "vibrato": True, "rate": 75, "depth": 3, "delay": 0.01}
 
@@ -123,6 +121,15 @@ class Request:
     volume_jitter_strength: float = 0.0
     add_subharm: bool = False
     subharm_weight: float = 0.0
+    sd_strength: float = 0.0
+    tension: float = 0.0
+    growl_mix: float = 0.0
+    aperiodic_mix: float = 0.0
+    subharm_gain: float = 0.0
+    pitch_dyn: float = 0.0
+    fry: float = 0.0          # vf, clipped to [-100, 100]
+    fry_hz: float = 50.0      # vh
+    fry_glide: float = 15.0   # vl
 
 
 def decode_request(pitch, velocity, flags="", offset=0, length=1000, consonant=0, cutoff=0, volume=100,
@@ -157,12 +164,16 @@ def decode_request(pitch, velocity, flags="", offset=0, length=1000, consonant=0
     r.formant_width = ((g("fw", 0) or 0) / 100.0) * 0.1
     glob = float(np.clip(_ci(fl, "fst") or 0, -100, 100)) / 100.0
     r.formant_strength = tuple(float(np.clip(glob + ((_ci(fl, "fst" + c) or 0) / 100.0), -1.0, 1.0)) for c in "abcd")
-    # flags that exist in the reference but are not on the device path yet: refuse, never ignore
-    for k in UNSUPPORTED_FLAGS:
-        v = _ci(fl, k) if k == "pd" else g(k, 0)
-        if v:
-            raise NotImplementedError(f"flag '{k}' is not implemented on the device path yet (SURVEY.md §8 f)")
-    g("st", 0) / 100.0                                                 # keeps the reference's TypeError on a bare 'st'
+    # sample-domain post chain                                                         :332-334, 360-393, 884-888
+    r.sd_strength = float(g("sd", None) or 0)
+    r.tension = g("st", 0) / 100.0                                     # TypeError on a bare 'st', like the reference
+    r.growl_mix = float(np.clip(g("sj", 0) or 0, 0, 100) / 100.0)
+    r.aperiodic_mix = float(np.clip(g("sa", 0) or 0, 0, 100) / 100.0)
+    r.subharm_gain = float(np.clip(g("su", 0) or 0, 0, 100) / 100.0)
+    r.pitch_dyn = float(int(np.clip(_ci(fl, "pd") or 0, -100, 100))) / 100.0
+    r.fry = float(np.clip(float(g("vf", 0)), -100.0, 100.0))
+    r.fry_hz = max(1.0, float(g("vh", 50)))
+    r.fry_glide = float(np.clip(float(g("vl", 15)), 0.0, 100.0))
     return r
 
 
@@ -447,4 +458,32 @@ def plan_note(req: Request, sr: int, ylen: int, n_src_frames: int, formants_src:
     used = p.tap_idx[p.tap_w != 0.0] if p.tap_idx.size else np.zeros(0, dtype=np.int64)
     p.row_lo = int(used.min()) if used.size else 0
     p.row_hi = int(used.max()) + 1 if used.size else 0
+    p.extra.update(fry_plan(req, sr, p.n_out))
     return p
+
+
+def fry_plan(req: Request, sr: int, n: int) -> dict:
+    """Sample ranges of the vocal-fry edit (SillySampler.py:883-955): where f0 is pinned to ``vh`` Hz, where it
+    glides back, and the fry mask's support and fade.  Integer arithmetic, bit-exact with the reference."""
+    out = {"fry_dir": 0, "fry_const": (0, 0), "fry_glide": (0, 0), "fry_mask": (0, 0), "fry_fade": 0}
+    vf = req.fry
+    if vf == 0:
+        return out
+    L = int(round(n * (abs(vf) / 100.0)))
+    if L > 0:
+        gl = int(np.clip(int(round(L * (req.fry_glide / 100.0))), 0, L))
+        cl = L - gl
+        out["fry_dir"] = 1 if vf > 0 else -1
+        if vf > 0:
+            out["fry_const"], out["fry_glide"] = (0, cl), (cl, L)
+        else:
+            st = n - L
+            out["fry_glide"], out["fry_const"] = (st, st + gl), (st + gl, n)
+    mid = n // 2
+    if vf > 0:
+        a, b = 0, max(0, min(n, int(round(mid * (vf / 100.0)))))
+    else:
+        a, b = max(0, n - int(round((n - mid) * (abs(vf) / 100.0)))), n
+    if b > a:
+        out["fry_mask"], out["fry_fade"] = (a, b), int(0.01 * sr)
+    return out

@@ -121,6 +121,16 @@ typedef struct {
     int32_t n_out_rows, env_f64;
     int32_t n_out, n_pre, s_pre, s_tail, tail_len, want_samples, n_before_vel, pre_new;
     int32_t vel_active, force_voiced, n_bend, reserved;
+    /* vocal fry ('vf' / 'vh' / 'vl', SillySampler.py:883-997); all ranges in output samples          */
+    double fry_hz;           /* 'vh' base frequency (>= 1)                                                */
+    int32_t fry_dir;         /* 0 off, +1 fry from the start, -1 fry towards the end                      */
+    int32_t fry_const_lo, fry_const_hi;   /* f0 = fry_hz * (mask > 0)                                     */
+    int32_t fry_glide_lo, fry_glide_hi;   /* f0 = (1 - w) * fry_hz * (mask > 0) + w * f0, w linspace      */
+    int32_t fry_a, fry_b, fry_fade;       /* fry mask = 1 on [a, b) with linear fades of fry_fade samples */
+    /* pitch dynamics ('pd', SillySampler.py:857-881)                                                     */
+    int32_t pd_on;           /* write midi_curve - pd_base (fp32) to goofer_assembly.bend_out             */
+    int32_t reserved4;
+    double pd_base;          /* pitch_m + t/100                                                           */
 } goofer_note_plan;
 
 /* A batch of note assemblies.  All pointers are device memory. */
@@ -143,7 +153,51 @@ typedef struct {
     float *edit_rows;                /* scratch [total_edit_rows x ld] (NULL: handle-owned)                */
     float *env_out;                  /* [total_out_rows x ld] assembled envelope                           */
     float *f0_out, *mask_out;        /* [total_samples]                                                    */
+    float *bend_out;                 /* [total_samples] pitch-bend semitones of the 'pd' notes, or NULL    */
+    int32_t any_fry, reserved5;      /* some note has fry_a < fry_b: run the envelope fry warp             */
 } goofer_assembly;
+
+/* One time-varying one-pole cascade (dynamic_butter_filter, SillySampler.py:95-174): `order` sections of
+ * y = y' + a (x - y') (low-pass) or y = a (y' + x - x') (high-pass), each restarted from zero, the per-sample
+ * coefficient following cutoff_factor * (5-tap box-smoothed f0 reference), clamped to [60|20 Hz, 0.45 sr]. */
+typedef struct {
+    int64_t src_off, dst_off;   /* element offsets into src / dst (equal offsets with src == dst: in place)  */
+    int64_t f0_off;             /* element offset of the note's f0 reference                                 */
+    int32_t n;                  /* samples                                                                   */
+    int32_t order;              /* 1..12 (two chained order-6 calls are one order-12 cascade)                */
+    int32_t highpass;           /* 0 low-pass, 1 high-pass                                                   */
+    int32_t f0_mode;            /* 0: f0, 1: max(f0, 120), 2: ones (cutoff_factor is then the cutoff in Hz)  */
+    float cutoff_factor;
+    int32_t reserved;
+} goofer_onepole_job;
+
+/* Per-note settings of the sample-domain post chain (SillySampler.py:1037-1182). */
+typedef struct {
+    int64_t su_off, sj_off, sa_off;  /* first sample of the note in su_harm / sj_harm / sa_uv+sa_bre, -1: flag off */
+    float su_gain;              /* 'su' / 100                                              :1037-1059        */
+    float sj_mix;               /* 'sj' / 100                                              :1061-1081        */
+    float sa_mix;               /* 'sa' / 100                                              :1153-1172        */
+    float sd_strength;          /* 'sd' value                                              :1101-1112        */
+    float tension;              /* 'st' / 100, in [-1, 1]                                  :1114-1140        */
+    float pitch_dyn;            /* 'pd' / 100                                              :857-881, 1174-1182 */
+    int32_t fry_a, fry_b, fry_fade;   /* fry mask range (see goofer_note_plan); a >= b: off :1083-1099       */
+    int32_t reserved;
+} goofer_post_note;
+
+typedef struct {
+    int32_t n_notes, reserved;
+    int64_t total_samples;
+    const int64_t *sample_off;          /* [n_notes+1] device                                                */
+    const int64_t *sample_off_host;     /* [n_notes+1] the same offsets in HOST memory                       */
+    const goofer_note_params *params;   /* [n_notes] device (mix_harm / mix_breath / mix_unvoiced / volume)  */
+    const goofer_post_note *notes;      /* [n_notes] HOST memory: the library builds its job lists from it   */
+    const float *f0, *mask;             /* [total_samples] assembled f0 / voicing mask                       */
+    const float *bend;                  /* [total_samples] goofer_assembly.bend_out, NULL without 'pd'       */
+    float *harm, *uv, *bre;             /* [total_samples] stems of the main synth call, edited in place     */
+    float *su_harm, *sj_harm;           /* harmonic stems of the extra synth calls (compact, filtered in place) */
+    const float *sa_uv, *sa_bre;        /* noise stems of the all-voiced 'sa' synth call (compact)           */
+    float *mix;                         /* [total_samples] out; only notes with some post flag are rewritten */
+} goofer_post;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 int goofer_create(int device_id, goofer_ctx **out);
@@ -220,6 +274,14 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *batch, void *stream)
  * rows, slicing + loop modes + velocity stretch as a 4-tap frame gather, formant-strength gain, per-sample
  * voicing mask and pitch curve (SillySampler.py:449-855).  Outputs feed goofer_synth_batch directly. */
 int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *assembly, void *stream);
+
+/* dynamic_butter_filter (SillySampler.py:95-174) for a list of jobs (device array): src -> dst, fp32. */
+int goofer_onepole_cascade(goofer_ctx *ctx, const float *src, float *dst, const float *f0, const goofer_onepole_job *jobs,
+                           int n_jobs, void *stream);
+
+/* The sample-domain post chain after the synth calls (SillySampler.py:1037-1182): su / sj layers, fry blend,
+ * sd dryness, st tension, V/B/U mix, sa whisper blend, pd gain.  Notes without any of these keep their mix. */
+int goofer_post_batch(goofer_ctx *ctx, const goofer_post *post, void *stream);
 
 /* ---- measurement / test hooks --------------------------------------------------------------- */
 

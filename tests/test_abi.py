@@ -33,6 +33,9 @@ def test_binding_covers_header_and_struct_layout():
     assert ctypes.sizeof(_lib.Batch) == lib.goofer_sizeof(1)
     assert _lib.NOTE_PLAN.itemsize == lib.goofer_sizeof(2)
     assert ctypes.sizeof(_lib.Assembly) == lib.goofer_sizeof(3)
+    assert _lib.ONEPOLE_JOB.itemsize == lib.goofer_sizeof(4)
+    assert _lib.POST_NOTE.itemsize == lib.goofer_sizeof(5)
+    assert ctypes.sizeof(_lib.Post) == lib.goofer_sizeof(6)
 
 
 def test_no_cpu_fallback_without_gpu():

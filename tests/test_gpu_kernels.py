@@ -214,3 +214,28 @@ def test_analysis_envelope_and_knot_encode(ctx):
     out = core.extract_features(g["an_x"], 44100, ctx=ctx,
                                 pitch_tracker=lambda y, sr, hop, T: (np.full(T, 220.0), {k: [500.0 * k] * T for k in range(1, 6)}))
     assert out[1].shape == (len(g["an_x"]),) and out[2].min() == 1.0 and out[4]["mode"] == "knots"
+
+
+def test_onepole_cascade_vs_reference(ctx):
+    """K10: time-varying one-pole cascades as an affine scan, against the reference's sequential fp32 loops."""
+    g = golden("post_chain")
+    ctx.plan(44100, 1024, 256)
+    x, f0 = ctx.tensor(g["x"]), ctx.tensor(g["f0"])
+    for i in range(4):
+        cf, order, hp = g[f"dyn_args_{i}"]
+        y = ctx.onepole_cascade(x, f0, float(cf), int(order), "highpass" if hp else "lowpass").cpu().numpy()
+        ref = g[f"dyn_{i}"]
+        assert y.dtype == np.float32 and y.shape == ref.shape
+        scale = max(1e-6, float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))))
+        assert rms_err(y, ref) / scale < 2e-6, (i, rms_err(y, ref) / scale)
+    # several notes in one launch, lengths that are not tile multiples, in/out of the oracle's restatement
+    from oracle import sampler_ref as SR
+    lens = [1, 7, 2049, 2943]
+    xs, fs = g["x"][:sum(lens)], g["f0"][:sum(lens)]
+    y = ctx.onepole_cascade(ctx.tensor(xs), ctx.tensor(fs), 1.0, 12, "highpass", f0_mode=1, lengths=lens).cpu().numpy()
+    o = 0
+    for n in lens:
+        ref = SR.dynamic_filter(xs[o:o + n], np.maximum(fs[o:o + n], 120.0), 44100, 1.0, order=6, btype="highpass")
+        ref = SR.dynamic_filter(ref, np.maximum(fs[o:o + n], 120.0), 44100, 1.0, order=6, btype="highpass")
+        assert np.max(np.abs(y[o:o + n] - ref)) < 1e-6 * max(1.0, float(np.max(np.abs(ref)))), n
+        o += n

@@ -72,11 +72,34 @@ def test_all_supported_notes_as_one_batch(renderer):
     print("worst sample-RMS over the 17-note batch vs reference:", worst)
 
 
-def test_unsupported_flags_fail_loudly():
-    from goofer_amd import sampler as S
-    for fl in ("su50", "sj30", "sa30", "st-50", "sd30", "vf40", "pd50"):
-        with pytest.raises(NotImplementedError):
-            S.decode_request("C4", "100", fl, "0", "1000", "0", "0", "100", "0", "!120", "AA")
+POST = ["su50", "sj30", "sa30", "st50", "stm50", "sd30", "vf40", "vfm40", "pd50", "pdm50"]
+
+
+@pytest.mark.parametrize("name", POST)
+def test_post_chain_flags_match_reference(renderer, name):
+    """su / sj / sa layers, st tension, sd dryness, vf fry, pd pitch dynamics (SillySampler.py:857-997, 1037-1182)."""
+    g, source, req = _job(name)
+    np.random.seed(int(g["seed"][1]))
+    (out,) = renderer.render([(source, req)], phi_seeds=[int(g["seed"][0])])
+    ref = g["out"]
+    assert out.shape == ref.shape
+    e = rms_err(out, ref) / max(1.0, float(np.max(np.abs(ref))))
+    assert e < TOL, e
+
+
+def test_post_chain_mixed_batch(renderer):
+    """Every post flag in one ragged batch next to plain notes: the extra synth calls run on sub-batches."""
+    names = ["default", "su50", "sj30", "L1", "sa30", "stm50", "vfm40", "pd50", "st50", "sd30"]
+    jobs, seeds, refs = [], [], []
+    for nm in names:
+        g, source, req = _job(nm)
+        jobs.append((source, req))
+        seeds.append(int(g["seed"][0]))
+        refs.append(g["out"])
+    outs = renderer.render(jobs, phi_seeds=seeds)
+    for nm, o, r in zip(names, outs, refs):
+        assert o.shape == r.shape, nm
+        assert rms_err(o, r) / max(1.0, float(np.max(np.abs(r)))) < TOL, nm
 
 
 def test_resampler_call_surface(renderer, tmp_path):
