@@ -85,11 +85,11 @@ class Batch(C.Structure):
         ("sample_off", C.c_void_p), ("frame_off", C.c_void_p), ("env_off", C.c_void_p),
         ("env", C.c_void_p), ("formants", C.c_void_p), ("f0", C.c_void_p), ("mask", C.c_void_p),
         ("phi", C.c_void_p), ("params", C.c_void_p), ("seed", C.c_uint64),
-        ("transition_sigma", C.c_float), ("reserved2", C.c_float),
+        ("transition_sigma", C.c_float), ("vol_jitter_speed", C.c_float),
         ("noise_f0", C.c_void_p), ("noise_vol_h", C.c_void_p), ("noise_vol_b", C.c_void_p),
         ("f0_jitter_sigma", C.c_float), ("vol_jitter_sigma", C.c_float),
         ("subharm_ratio", C.c_double), ("subharm_vib_rate", C.c_double), ("subharm_vib_depth", C.c_double),
-        ("subharm_vib_delay", C.c_double), ("subharm_vibrato", C.c_int32), ("reserved3", C.c_int32),
+        ("subharm_vib_delay", C.c_double), ("subharm_vibrato", C.c_int32), ("volume_vibrato", C.c_int32),
         ("harm", C.c_void_p), ("uv", C.c_void_p), ("bre", C.c_void_p), ("rec", C.c_void_p), ("mix", C.c_void_p),
     ]
 

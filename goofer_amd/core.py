@@ -235,8 +235,6 @@ def note_params_from_kwargs(n=1, **kw):
     if kw.get("f0_jitter"):
         p["f0_jitter"] = kw.get("f0_jitter_strength", 1.5)
     if kw.get("volume_jitter"):
-        if kw.get("volume_vibrato"):
-            raise NotImplementedError("volume_vibrato is not on the device path yet")
         p["vol_jitter_harm"] = kw.get("volume_jitter_strength_harm", 50)
         p["vol_jitter_breath"] = kw.get("volume_jitter_strength_breath", 100)
     if kw.get("add_subharm"):
@@ -291,10 +289,11 @@ def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
     # jitter flags draw from the legacy global np.random stream in the reference's order: f0, harm volume, breath volume
     noise_f0 = c.tensor(np.random.randn(n)) if kw.get("f0_jitter") else None
-    noise_vol = (c.tensor(np.random.randn(n)), c.tensor(np.random.randn(n))) if kw.get("volume_jitter") else None
+    vib = bool(kw.get("volume_jitter") and kw.get("volume_vibrato"))          # the sinusoid variant draws nothing
+    noise_vol = (c.tensor(np.random.randn(n)), c.tensor(np.random.randn(n))) if kw.get("volume_jitter") and not vib else None
     out = c.synth_batch(d_env, [T_env], c.tensor(f0[:n]), c.tensor(mask[:n]), [n], params, formants=c.tensor(F),
                         phi=d_phi, seed=seed, transition_sigma=float(kw.get("noise_transition_smoothness", 100)),
                         want_mix=False, noise_f0=noise_f0, noise_vol=noise_vol,
                         f0_jitter_speed=float(kw.get("f0_jitter_speed", 100)), vol_jitter_speed=float(kw.get("volume_jitter_speed", 150)),
-                        subharm=subharm_from_kwargs(kw))
+                        subharm=subharm_from_kwargs(kw), volume_vibrato=vib)
     return tuple(out[k].cpu().numpy() for k in ("rec", "harm", "uv", "bre"))

@@ -52,7 +52,7 @@ int launch_note_absmax(goofer_ctx *, const double *, const int64_t *, int, int64
 int launch_f0_jitter(goofer_ctx *, float *, const float *, const double *, const unsigned long long *, const int64_t *, int, int64_t,
                      const goofer_note_params *, hipStream_t);
 int launch_volume_jitter(goofer_ctx *, float *, float *, const double *, const double *, const double *, const unsigned long long *,
-                         const unsigned long long *, const int64_t *, int, int64_t, const goofer_note_params *, hipStream_t);
+                         const unsigned long long *, const int64_t *, int, int64_t, const goofer_note_params *, int, double, hipStream_t);
 int launch_onepole(goofer_ctx *, const float *, float *, const float *, const goofer_onepole_job *, int, hipStream_t);
 int launch_post_layers(goofer_ctx *, float *, const float *, const float *, const goofer_post_note *, const int64_t *, int, int64_t,
                        hipStream_t);
@@ -855,7 +855,8 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     const int64_t F = b->total_frames, N = b->total_samples;
     const int n = b->n_notes, ld = b->ld, ldc = p.n_bins + 1;
 
-    const bool jit_f0 = b->noise_f0 != nullptr, jit_vol = b->noise_vol_h != nullptr && b->noise_vol_b != nullptr;
+    const bool jit_f0 = b->noise_f0 != nullptr, vol_vib = b->volume_vibrato != 0,
+               jit_vol = vol_vib || (b->noise_vol_h != nullptr && b->noise_vol_b != nullptr);
     const bool sub_on = b->subharm_ratio > 0.0;
     const size_t jit_bytes = ((jit_f0 || jit_vol) ? (3 * (size_t)N * sizeof(double) + 3 * 256 * (size_t)n + 8192) : 0) +
                              (sub_on ? ((size_t)N * (sizeof(double) + sizeof(float)) + 3 * 256 * (size_t)n + 8192) : 0);
@@ -1014,16 +1015,18 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                                 note_steps, b->harm, b->uv, b->bre, note_peak, st)))
         return rc;
     if (jit_vol) {  // 'sr': volume jitter on harm / breath, then the peak is taken again (GOOFER.py:1185-1193)
-        const double *d_t, *d_t20; int r, r20;
-        if ((rc = upload_jitter_taps(ctx, (double)b->vol_jitter_sigma, 1, &d_t, &r, st))) return rc;
+        const double *d_t = nullptr, *d_t20; int r = 0, r20;
+        if (!vol_vib && (rc = upload_jitter_taps(ctx, (double)b->vol_jitter_sigma, 1, &d_t, &r, st))) return rc;
         if ((rc = upload_jitter_taps(ctx, 20.0, 2, &d_t20, &r20, st))) return rc;
-        if ((rc = launch_gauss_samples<double>(ctx, b->noise_vol_h, b->sample_off, n, N, d_t, r, on_vol, jit_a, st))) return rc;
-        if ((rc = launch_gauss_samples<double>(ctx, b->noise_vol_b, b->sample_off, n, N, d_t, r, on_vol, jit_b, st))) return rc;
+        if (!vol_vib) {
+            if ((rc = launch_gauss_samples<double>(ctx, b->noise_vol_h, b->sample_off, n, N, d_t, r, on_vol, jit_a, st))) return rc;
+            if ((rc = launch_gauss_samples<double>(ctx, b->noise_vol_b, b->sample_off, n, N, d_t, r, on_vol, jit_b, st))) return rc;
+            if ((rc = launch_note_absmax(ctx, jit_a, b->sample_off, n, N, on_vol, jit_max + n, st))) return rc;
+            if ((rc = launch_note_absmax(ctx, jit_b, b->sample_off, n, N, on_vol, jit_max + 2 * (size_t)n, st))) return rc;
+        }
         if ((rc = launch_gauss_samples<float>(ctx, b->mask, b->sample_off, n, N, d_t20, r20, on_vol, jit_c, st))) return rc;
-        if ((rc = launch_note_absmax(ctx, jit_a, b->sample_off, n, N, on_vol, jit_max + n, st))) return rc;
-        if ((rc = launch_note_absmax(ctx, jit_b, b->sample_off, n, N, on_vol, jit_max + 2 * (size_t)n, st))) return rc;
         if ((rc = launch_volume_jitter(ctx, b->harm, b->bre, jit_a, jit_b, jit_c, jit_max + n, jit_max + 2 * (size_t)n, b->sample_off, n,
-                                       N, b->params, st)))
+                                       N, b->params, vol_vib ? 1 : 0, (double)b->vol_jitter_speed, st)))
             return rc;
         HIP_TRY(ctx, hipMemsetAsync(note_peak, 0, (size_t)n * sizeof(float), st));
         if ((rc = launch_stem_peak(ctx, b->harm, b->uv, b->bre, b->sample_off, n, N, note_peak, st))) return rc;

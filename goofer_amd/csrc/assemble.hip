@@ -43,12 +43,18 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
     const __half *kn = reinterpret_cast<const __half *>(a.knots) + p.knot_off + (int64_t)phys * p.K;
     for (int k = lane; k < p.K; k += WAVE) kv[k] = __half2float(kn[k]);
     wave_lds_sync();
-    const int *li = a.lerp_idx + (int64_t)p.lerp_plan * B;
-    const float *l0 = a.lerp_w0 + (int64_t)p.lerp_plan * B, *l1 = a.lerp_w1 + (int64_t)p.lerp_plan * B;
+    const bool dense = p.lerp_plan < 0;                       // 'full' mode source: the rows are the fp16 envelope itself
+    const int *li = dense ? nullptr : a.lerp_idx + (int64_t)p.lerp_plan * B;
+    const float *l0 = dense ? nullptr : a.lerp_w0 + (int64_t)p.lerp_plan * B, *l1 = dense ? nullptr : a.lerp_w1 + (int64_t)p.lerp_plan * B;
     const float *tilt = p.tilt >= 0 ? a.tilts + (int64_t)p.tilt * B : nullptr;
     for (int b = lane; b < B; b += WAVE) {
-        int i = li[b];
-        float v = expf(l0[b] * kv[i] + l1[b] * kv[i + 1]);
+        float v;
+        if (dense) {
+            v = kv[b];
+        } else {
+            int i = li[b];
+            v = expf(l0[b] * kv[i] + l1[b] * kv[i + 1]);
+        }
         if (tilt) v *= tilt[b];                               // 2. br: env *= tilt (fp32)   :513-515
         row[b] = v;
     }
@@ -326,6 +332,10 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
                            a->total_edit_rows, 0, row_note_edit);
         LAUNCH_CHECK(ctx);
         size_t lds = (size_t)A_ROWS * ((3 * B + a->max_K + 3) & ~3) * sizeof(float);
+        if (lds > 64 * 1024) {
+            if (lds > 160 * 1024) return goofer_fail(ctx, GOOFER_EINVAL, "envelope rows too wide for the edit kernel's LDS staging");
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_env_edit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
         hipLaunchKernelGGL(k_env_edit, dim3((unsigned)((a->total_edit_rows + A_ROWS - 1) / A_ROWS)), dim3(256), lds, st, *a,
                            a->total_edit_rows, row_note_edit);
         LAUNCH_CHECK(ctx);

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void k_volume_jitter(float *__restrict__ harm,
                                                        const double *__restrict__ nb, const double *__restrict__ vjm,
                                                        const unsigned long long *__restrict__ max_h,
                                                        const unsigned long long *__restrict__ max_b, const int64_t *__restrict__ sample_off,
-                                                       int n_notes, int64_t total, const goofer_note_params *__restrict__ params)
+                                                       int n_notes, int64_t total, const goofer_note_params *__restrict__ params,
+                                                       int vibrato, double speed, double sr)
 {
     __shared__ int s_pair[2];
     const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
@@ -117,8 +118,18 @@ __global__ __launch_bounds__(256) void k_volume_jitter(float *__restrict__ harm,
     while (sample_off[note + 1] <= g) ++note;
     const float sh = params[note].vol_jitter_harm, sb = params[note].vol_jitter_breath;
     if (!(sh > 0.f) && !(sb > 0.f)) return;
-    const double jh = 1.0 + (nh[g] / __longlong_as_double((long long)max_h[note])) * (double)sh;
-    const double jb = 1.0 + (nb[g] / __longlong_as_double((long long)max_b[note])) * (double)sb;
+    double jh, jb;
+    if (vibrato) {   // volume_vibrato: zero-phase sinusoid, 0.1 s fade-in, clip [0.5, 1.5]   GOOFER.py:643-660
+        const int64_t i = g - sample_off[note], n = sample_off[note + 1] - sample_off[note];
+        double z = sin(((2.0 * 3.141592653589793) * speed) * ((double)i / sr) + 0.0);
+        const int fade = (int)(0.1 * sr);
+        if (fade < n && i < fade) z *= fade > 1 ? (i == fade - 1 ? 1.0 : (double)i * (1.0 / (double)(fade - 1))) : 0.0;
+        jh = fmin(fmax(1.0 + z * (double)sh, 0.5), 1.5);
+        jb = fmin(fmax(1.0 + z * (double)sb, 0.5), 1.5);
+    } else {
+        jh = 1.0 + (nh[g] / __longlong_as_double((long long)max_h[note])) * (double)sh;
+        jb = 1.0 + (nb[g] / __longlong_as_double((long long)max_b[note])) * (double)sb;
+    }
     const double m = vjm[g];
     harm[g] = (float)((double)harm[g] * (1.0 + (jh - 1.0) * m));
     bre[g] = (float)((double)bre[g] * (1.0 + (jb - 1.0) * m));
@@ -163,11 +174,11 @@ int launch_f0_jitter(goofer_ctx *ctx, float *f0, const float *mask, const double
 
 int launch_volume_jitter(goofer_ctx *ctx, float *harm, float *bre, const double *nh, const double *nb, const double *vjm,
                          const unsigned long long *max_h, const unsigned long long *max_b, const int64_t *sample_off, int n_notes,
-                         int64_t total, const goofer_note_params *params, hipStream_t st)
+                         int64_t total, const goofer_note_params *params, int vibrato, double speed, hipStream_t st)
 {
     if (total <= 0) return GOOFER_OK;
     hipLaunchKernelGGL(k_volume_jitter, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, harm, bre, nh, nb, vjm, max_h, max_b,
-                       sample_off, n_notes, total, params);
+                       sample_off, n_notes, total, params, vibrato, speed, (double)ctx->plan.sr);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

@@ -264,7 +264,7 @@ class Context:
     def synth_batch(self, env, env_lengths, f0, mask, sample_lengths, params: np.ndarray, formants=None, phi=None,
                     seed: int = 0, transition_sigma: float = 100.0, want_rec=True, want_mix=True, offsets=None,
                     noise_f0=None, noise_vol=None, f0_jitter_speed: float = 100.0, vol_jitter_speed: float = 150.0,
-                    subharm=None):
+                    subharm=None, volume_vibrato: bool = False):
         """Run goofer_synth_batch.
 
         ``subharm`` = dict(semitones, vibrato, rate, depth, delay) switches the sub-harmonic pulse layer on for the
@@ -298,6 +298,7 @@ class Context:
                        noise_vol_h=noise_vol[0].data_ptr() if noise_vol is not None else None,
                        noise_vol_b=noise_vol[1].data_ptr() if noise_vol is not None else None,
                        f0_jitter_sigma=self.geom[0] / (f0_jitter_speed * 6), vol_jitter_sigma=self.geom[0] / (vol_jitter_speed * 6),
+                       vol_jitter_speed=float(vol_jitter_speed), volume_vibrato=int(bool(volume_vibrato)),
                        subharm_ratio=2.0 ** (float(subharm["semitones"]) / 12.0) if subharm else 0.0,
                        subharm_vib_rate=float(subharm.get("rate", 6.0)) if subharm else 0.0,
                        subharm_vib_depth=float(subharm.get("depth", 0.1)) if subharm else 0.0,

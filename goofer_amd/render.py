@@ -21,7 +21,8 @@ from .device import Context, default_context, default_params, row_stride
 
 @dataclass
 class Source:
-    """Features of one voicebank sample, as stored in ``<stem>_features.goofy`` (knots mode)."""
+    """Features of one voicebank sample, as stored in ``<stem>_features.goofy`` (knots mode, or the dense 'full'
+    mode: then ``knots`` is the fp16 envelope itself, K = bins, and ``hz_knots`` is None)."""
     knots: np.ndarray        # fp16 [K, T] log-envelope knot values (reference layout)
     hz_knots: np.ndarray     # fp32 [K]
     mask: np.ndarray         # fp32 [ylen] voicing mask
@@ -33,7 +34,11 @@ class Source:
     @staticmethod
     def from_pack(env_pack, f0, mask, formants, sr, ylen):
         if not (isinstance(env_pack, dict) and env_pack.get("mode") == "knots"):
-            raise NotImplementedError("dense ('full' mode) feature files are not on the device path yet")
+            env = np.asarray(env_pack)                        # dense [bins, T]: stored fp16, computed fp32 (GOOFER.py:306-333)
+            if env.ndim != 2:
+                raise ValueError("features must be a knots dict or a [bins, T] envelope")
+            return Source(env.astype(np.float16), None, np.asarray(mask, dtype=np.float32), formants, int(sr), int(ylen),
+                          2 * env.shape[0] - 2)
         return Source(np.asarray(env_pack["knot_vals_log"], dtype=np.float16), np.asarray(env_pack["hz_knots"], dtype=np.float32),
                       np.asarray(mask, dtype=np.float32), formants, int(sr), int(ylen), int(env_pack["n_fft"]))
 
@@ -192,12 +197,18 @@ class Renderer:
         k_off = e_off = t_off = s_off = o_off = b_off = 0
         for i, ((src, req), p) in enumerate(zip(jobs, plans)):
             K = src.knots.shape[0]
-            key = (K, src.hz_knots.tobytes())
-            if key not in lerp_keys:
-                lerp_keys[key] = len(lerp_tabs)
-                lerp_tabs.append(_lerp_plan(sr, n_fft, src.hz_knots))
+            if src.hz_knots is None:                           # dense source: rows are the envelope, no lerp plan
+                if K != B:
+                    raise ValueError("dense envelope has %d bins, the plan has %d" % (K, B))
+                lp = -1
+            else:
+                key = (K, src.hz_knots.tobytes())
+                if key not in lerp_keys:
+                    lerp_keys[key] = len(lerp_tabs)
+                    lerp_tabs.append(_lerp_plan(sr, n_fft, src.hz_knots))
+                lp = lerp_keys[key]
             q = P[i]
-            q["knot_off"], q["K"], q["lerp_plan"], q["n_src_rows"] = k_off, K, lerp_keys[key], src.knots.shape[1]
+            q["knot_off"], q["K"], q["lerp_plan"], q["n_src_rows"] = k_off, K, lp, src.knots.shape[1]
             q["reverse"] = int(req.reverse)
             q["row_lo"], q["n_edit"], q["edit_off"] = p.row_lo, p.row_hi - p.row_lo, e_off
             q["tilt"] = -1

@@ -75,7 +75,8 @@ typedef struct {
     const goofer_note_params *params;  /* [n_notes] */
     uint64_t seed;              /* Philox key when phi == NULL */
     float transition_sigma;     /* noise_transition_smoothness of this call (default 100; the 'sa'  */
-    float reserved2;            /* layer uses 1) — one value per batch            GOOFER.py:1179 */
+    float vol_jitter_speed;     /* layer uses 1) — one value per batch            GOOFER.py:1179 */
+                                /* vol_jitter_speed: Hz of the volume_vibrato sinusoid (see volume_vibrato)       */
     /* jitter flags: standard-normal draws supplied by the caller (the reference takes them from the legacy  */
     /* global np.random stream), [total_samples] fp64 each, NULL when no note of the batch uses the flag      */
     const double *noise_f0;     /* for notes with f0_jitter > 0                   GOOFER.py:666        */
@@ -89,7 +90,7 @@ typedef struct {
     double subharm_vib_depth;
     double subharm_vib_delay;   /* seconds of linear fade-in                                              */
     int32_t subharm_vibrato;    /* 0 / 1                                                                  */
-    int32_t reserved3;
+    int32_t volume_vibrato;     /* 1: the volume jitter is a sinusoid, no noise draws needed  GOOFER.py:643-652  */
     float *harm, *uv, *bre;     /* [total_samples] stems, gain-normalised like the reference   */
     float *rec;                 /* [total_samples] harm+uv+bre (reconstruct), may be NULL      */
     float *mix;                 /* [total_samples] (harm*V + bre*B + uv*U)*volume, may be NULL */

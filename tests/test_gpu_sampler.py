@@ -187,3 +187,32 @@ def test_subharm_mixed_batch(renderer):
     outs = renderer.render([(source0, req0), (source, req), (source0, req0)], phi_seeds=seeds)
     for o, r in zip(outs, (g0["out"], g["out"], g0["out"])):
         assert rms_err(o, r) / max(1.0, float(np.max(np.abs(r)))) < TOL
+
+
+def test_dense_feature_source_vs_oracle(renderer):
+    """'full' mode .goofy (dense fp16 envelope, GOOFER.py:306-333) next to a knots-mode source in one batch."""
+    from goofer_amd.render import Source
+    from goofer_amd import sampler as S
+    from oracle import goofer_ref as R, sampler_ref as SR
+    jobs, refs, seeds = [], [], []
+    for i, flags in enumerate(("br30es40fw20", "g-30L1")):
+        src = syn.make_source(3100 + i, seconds=0.4)
+        env16 = R.decode_env_from_knots(src["env_pack"]).astype(np.float16)
+        args = ("D4", "100", flags, "20", "450", "60", "40", "100", "0", "!120", "AA#3#AF")
+        jobs.append((Source.from_pack(env16, src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]),
+                     S.decode_request(*args)))
+        feats = (env16.astype(np.float32), src["f0"].copy(), src["mask"].copy(), {k: v.copy() for k, v in src["formants"].items()},
+                 src["sr"], src["y_len"])
+        refs.append(SR.render(feats, SR.decode_request(*args), seed=700 + i))
+        seeds.append(700 + i)
+    src = syn.make_source(3102, seconds=0.4)
+    args = ("C4", "100", "t0g0", "20", "450", "60", "40", "100", "0", "!120", "AA")
+    jobs.append((Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]),
+                 S.decode_request(*args)))
+    refs.append(SR.render((src["env_pack"], src["f0"].copy(), src["mask"].copy(), {k: v.copy() for k, v in src["formants"].items()},
+                           src["sr"], src["y_len"]), SR.decode_request(*args), seed=702))
+    seeds.append(702)
+    outs = renderer.render(jobs, phi_seeds=seeds)
+    for o, ref in zip(outs, refs):
+        assert o.shape == ref.shape
+        assert rms_err(o, ref) / max(1.0, float(np.max(np.abs(ref)))) < 2e-5

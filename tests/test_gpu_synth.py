@@ -161,14 +161,15 @@ def test_fused_path_equals_modular_path(ctx):
         assert rms_err(a[k], b[k].cpu().numpy()) < 1e-7, k
 
 
-def test_synthesize_jitter_kwargs_vs_oracle(ctx):
-    """f0_jitter / volume_jitter kwargs of gf.synthesize: same legacy RNG stream on both sides."""
+@pytest.mark.parametrize("vibrato", [False, True])
+def test_synthesize_jitter_kwargs_vs_oracle(ctx, vibrato):
+    """f0_jitter / volume_jitter (noise or volume_vibrato sinusoid) kwargs of gf.synthesize: same legacy RNG stream on both sides."""
     from goofer_amd import core
     from oracle import goofer_ref as R
     g = golden("synthesize")
     c = _case(g, "plain")
     kw = dict(f0_jitter=True, f0_jitter_strength=1.2, volume_jitter=True, volume_jitter_strength_harm=0.8,
-              volume_jitter_strength_breath=1.6)
+              volume_jitter_strength_breath=1.6, volume_vibrato=vibrato, volume_jitter_speed=150 if not vibrato else 9.0)
     np.random.seed(99)
     ref = R.synthesize(c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"], n_fft=c["n_fft"], hop_length=c["hop"],
                        formants=c["formants"], phi=c["phi"], **kw)
