@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void k_warp_bins(const float *__restrict__ in,
                                                    double ratio_global, double nyq)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double s_seg[ROWS_PER_BLOCK][WARP_SEG_DOUBLES];
     float *s_all = reinterpret_cast<float *>(smem);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void k_warp_bins(const float *__restrict__ in,
         for (int i = 0; i < 4; ++i) fs[i] = f_shift_global[i];
         warp = true;   // the caller decides (gf.synthesize tests any(shift != 1))
     }
-    float *cur = warp_row(ra, rb, n_bins, nyq, formants ? formants + src * 4 : nullptr, fs, warp, ratio, lane, src);
+    float *cur = warp_row(ra, rb, n_bins, nyq, formants ? formants + src * 4 : nullptr, fs, warp, ratio, lane, s_seg[wave]);
     for (int b = lane; b < n_bins; b += WAVE) out[row * ld + b] = cur[b];
 }
 
@@ -141,6 +142,7 @@ int launch_knot_decode(goofer_ctx *ctx, const uint16_t *knots, int K, int64_t ro
 // In place on S: optional high-pass, per-note max(|S| + 1e-8), then * env * boost, and on voiced
 // frames * brightness followed by the 5-tap blur.  The 1/max normalisation commutes with the
 // (linear) rest of the chain and is applied after the overlap-add.
+template <int ITERS>
 __global__ __launch_bounds__(256) void k_harm_shape(float2 *__restrict__ S, int ldc, int64_t total_frames,
                                                     const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
                                                     const int64_t *__restrict__ sample_off, const float *__restrict__ f0,
@@ -153,13 +155,33 @@ __global__ __launch_bounds__(256) void k_harm_shape(float2 *__restrict__ S, int 
 {
     // env is either the already-warped [frames x ld] matrix (row_src == nullptr) or the source rows, in which
     // case the formant-anchored + uniform warp (GOOFER.py:1004-1017) runs here on the LDS row.
+    // Latency plan: the frame index is made wave-uniform so every per-note scalar is a scalar load (its own
+    // counter), and all of the row's vector loads (spectrum, envelope, tables) are issued before the first wait.
     extern __shared__ __align__(16) unsigned char smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double s_seg[ROWS_PER_BLOCK][WARP_SEG_DOUBLES];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int64_t f = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
     if (f >= total_frames) return;
     const int rowf = (n_bins + 1) & ~1;                           // floats per fp32 row (even)
     float2 *r = reinterpret_cast<float2 *>(smem) + (size_t)wave * (n_bins + rowf);
     float *ra = reinterpret_cast<float *>(r + n_bins), *rb = ra + rowf;
+
+    float2 *row = S + f * (int64_t)ldc;
+    float2 sv[ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int k = lane + WAVE * i;
+        sv[i] = k < n_bins ? row[k] : make_float2(0.f, 0.f);
+    }
+    const int64_t src = row_src ? row_src[f] : f;
+    const float *er = env + src * (int64_t)ld;
+    float ev[ITERS], fq[ITERS], bo[ITERS], br[ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int k = lane + WAVE * i;
+        const int kc = k < n_bins ? k : n_bins - 1;
+        ev[i] = er[kc]; fq[i] = freqs[kc]; bo[i] = boost[kc]; br[i] = bright[kc];
+    }
     const int note = frame_note[f];
     const goofer_note_params p = params[note];
     const int64_t t = f - frame_off[note];
@@ -171,42 +193,52 @@ __global__ __launch_bounds__(256) void k_harm_shape(float2 *__restrict__ S, int 
 #pragma unroll
     for (int j = 0; j < 5; ++j) t5[j] = taps5[j];
 
-    float2 *row = S + f * (int64_t)ldc;
-    const float *er = env + f * (int64_t)ld;
+    const float *eg = nullptr;                       // LDS row of the warped envelope, or registers when no warp ran
     if (row_src) {
-        const int64_t src = row_src[f];
-        const float *sr_ = env + src * (int64_t)ld;
-        for (int b = lane; b < n_bins; b += WAVE) ra[b] = sr_[b];
-        wave_lds_sync();
         double fs[4];
         bool warp = false;
         for (int k = 0; k < 4; ++k) {
             fs[k] = p.f_shift[k];
             warp |= fs[k] != 1.0;
         }
-        er = warp_row(ra, rb, n_bins, nyq, formants ? formants + src * 4 : nullptr, fs, warp, (double)p.formant_shift, lane, 0);
+        if ((warp && formants) || p.formant_shift != 1.0f) {
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) {
+                const int k = lane + WAVE * i;
+                if (k < n_bins) ra[k] = ev[i];
+            }
+            wave_lds_sync();
+            eg = warp_row(ra, rb, n_bins, nyq, formants ? formants + src * 4 : nullptr, fs, warp, (double)p.formant_shift, lane,
+                          s_seg[wave]);
+        }
     }
     float mx = 0.f;
-    for (int k = lane; k < n_bins; k += WAVE) {
-        float2 s = row[k];
-        if (p.cut_below_f0) {
-            float h = hp_mask(freqs[k], f0f);
-            s.x *= h; s.y *= h;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int k = lane + WAVE * i;
+        if (k < n_bins) {
+            float2 s = sv[i];
+            if (p.cut_below_f0) {
+                float h = hp_mask(fq[i], f0f);
+                s.x *= h; s.y *= h;
+            }
+            mx = fmaxf(mx, hypotf(s.x, s.y) + 1e-8f);
+            const float g = eg ? eg[k] : ev[i];
+            s.x = (s.x * g) * bo[i];
+            s.y = (s.y * g) * bo[i];
+            if (voiced) { s.x *= br[i]; s.y *= br[i]; r[k] = s; }
+            else row[k] = s;
         }
-        mx = fmaxf(mx, hypotf(s.x, s.y) + 1e-8f);
-        float g = er[k];
-        s.x = (s.x * g) * boost[k];
-        s.y = (s.y * g) * boost[k];
-        if (voiced) { s.x *= bright[k]; s.y *= bright[k]; }
-        r[k] = s;
     }
     mx = wave_max(mx);
     if (lane == 0) atomic_max_pos(note_mag + note, mx);
     if (voiced) {
         wave_lds_sync();
-        for (int k = lane; k < n_bins; k += WAVE) row[k] = blur5(r, k, n_bins, t5);
-    } else {
-        for (int k = lane; k < n_bins; k += WAVE) row[k] = r[k];
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int k = lane + WAVE * i;
+            if (k < n_bins) row[k] = blur5(r, k, n_bins, t5);
+        }
     }
 }
 
@@ -218,16 +250,26 @@ int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames,
     if (total_frames <= 0) return GOOFER_OK;
     const goofer_plan_t &pl = ctx->plan;
     const int rowf = (pl.n_bins + 1) & ~1;
-    hipLaunchKernelGGL(k_harm_shape, dim3((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256),
-                       sizeof(float2) * ROWS_PER_BLOCK * (pl.n_bins + rowf), st, S, ldc, total_frames, frame_note, frame_off,
-                       sample_off, f0, mask, env, ld, params, note_mag, pl.freqs, pl.boost, pl.bright_h, pl.blur5, pl.n_bins, pl.hop,
-                       row_src, formants, (double)pl.sr / 2.0);
+    const dim3 grid((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    const size_t lds = sizeof(float2) * ROWS_PER_BLOCK * (pl.n_bins + rowf);
+#define HARM_SHAPE(IT)                                                                                                             \
+    hipLaunchKernelGGL(k_harm_shape<IT>, grid, dim3(256), lds, st, S, ldc, total_frames, frame_note, frame_off, sample_off, f0,   \
+                       mask, env, ld, params, note_mag, pl.freqs, pl.boost, pl.bright_h, pl.blur5, pl.n_bins, pl.hop, row_src,    \
+                       formants, (double)pl.sr / 2.0)
+    switch ((pl.n_bins + WAVE - 1) / WAVE) {
+    case 5: HARM_SHAPE(5); break;
+    case 9: HARM_SHAPE(9); break;
+    case 17: HARM_SHAPE(17); break;
+    default: return goofer_fail(ctx, GOOFER_EINVAL, "unsupported bin count %d", pl.n_bins);
+    }
+#undef HARM_SHAPE
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // S_uv = U * env_noise ; S_br = (U * env_noise) * HP, brightened + blurred on voiced frames.
+template <int ITERS>
 __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv, float2 *__restrict__ S_br, int ldc,
                                                        int64_t total_frames, const int *__restrict__ frame_note,
                                                        const int64_t *__restrict__ frame_off, const int64_t *__restrict__ sample_off,
@@ -241,12 +283,23 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
     // env_noise is either the already-blurred [frames x ld] matrix (row_src == nullptr) or the source rows, in
     // which case the sigma-1.75 bin blur (GOOFER.py:993) runs here from the LDS row.
     extern __shared__ __align__(16) unsigned char smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int64_t f = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
     if (f >= total_frames) return;
     const int rowf = (n_bins + 1) & ~1;
     float2 *r = reinterpret_cast<float2 *>(smem) + (size_t)wave * (n_bins + rowf / 2 + 1);
     float *ra = reinterpret_cast<float *>(r + n_bins);
+
+    const int64_t src = row_src ? row_src[f] : f;
+    const float *er = env_noise + src * (int64_t)ld;
+    float ev[ITERS], fq[ITERS], br[ITERS], ph[ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int k = lane + WAVE * i;
+        const int kc = k < n_bins ? k : n_bins - 1;
+        ev[i] = er[kc]; fq[i] = freqs[kc]; br[i] = bright[kc];
+        ph[i] = phi ? phi[f * (int64_t)ld + kc] : 0.f;
+    }
     const int note = frame_note[f];
     const goofer_note_params p = params[note];
     const int64_t t = f - frame_off[note];
@@ -258,24 +311,34 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
 #pragma unroll
     for (int j = 0; j < 5; ++j) t5[j] = taps5[j];
 
-    const float *er = env_noise + f * (int64_t)ld;
     float2 *ru = S_uv + f * (int64_t)ldc;
     float2 *rb = S_br + f * (int64_t)ldc;
     if (row_src) {
-        const float *sr_ = env_noise + row_src[f] * (int64_t)ld;
-        for (int b = lane; b < n_bins; b += WAVE) ra[b] = sr_[b];
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int k = lane + WAVE * i;
+            if (k < n_bins) ra[k] = ev[i];
+        }
         wave_lds_sync();
     }
-    for (int k = lane; k < n_bins; k += WAVE) {
-        float ph;
+    const uint64_t key = seed ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
+    uint4 rnd = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int k = lane + WAVE * i;
+        if (k >= n_bins) continue;
+        float c, s;
         if (phi) {
-            ph = phi[f * (int64_t)ld + k];
+            c = cosf(ph[i]);
+            s = sinf(ph[i]);
         } else {
-            uint64_t key = seed ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
-            uint32_t u = philox_u32(key, (uint64_t)t, (uint32_t)k);
-            ph = (float)(u >> 8) * (6.283185307179586f / 16777216.0f);
+            // one Philox-4x32-10 block feeds four bins of this lane (bins lane+64i, i = 4q..4q+3)
+            if ((i & 3) == 0) rnd = philox_4x32(key, (uint64_t)t, (uint32_t)(lane + WAVE * (i >> 2)));
+            const uint32_t u = (i & 3) == 0 ? rnd.x : ((i & 3) == 1 ? rnd.y : ((i & 3) == 2 ? rnd.z : rnd.w));
+            const float rev = (float)(u >> 8) * (1.0f / 16777216.0f);      // phase / 2 pi, uniform in [0, 1)
+            c = __builtin_amdgcn_cosf(rev);
+            s = __builtin_amdgcn_sinf(rev);
         }
-        float c = cosf(ph), s = sinf(ph);
         float e;
         if (row_src) {
             double acc = 0.0;
@@ -287,20 +350,22 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
             }
             e = (float)acc;
         } else {
-            e = er[k];
+            e = ev[i];
         }
-        float2 u = make_float2(c * e, s * e);
-        ru[k] = u;
-        float h = hp_mask(freqs[k], f0f);
-        float2 b = make_float2(u.x * h, u.y * h);
-        if (voiced) { b.x *= bright[k]; b.y *= bright[k]; }
-        r[k] = b;
+        float2 u2 = make_float2(c * e, s * e);
+        ru[k] = u2;
+        float h = hp_mask(fq[i], f0f);
+        float2 b = make_float2(u2.x * h, u2.y * h);
+        if (voiced) { b.x *= br[i]; b.y *= br[i]; r[k] = b; }
+        else rb[k] = b;
     }
     if (voiced) {
         wave_lds_sync();
-        for (int k = lane; k < n_bins; k += WAVE) rb[k] = blur5(r, k, n_bins, t5);
-    } else {
-        for (int k = lane; k < n_bins; k += WAVE) rb[k] = r[k];
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int k = lane + WAVE * i;
+            if (k < n_bins) rb[k] = blur5(r, k, n_bins, t5);
+        }
     }
 }
 
@@ -312,10 +377,19 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
     if (total_frames <= 0) return GOOFER_OK;
     const goofer_plan_t &pl = ctx->plan;
     const int rowf = (pl.n_bins + 1) & ~1;
-    hipLaunchKernelGGL(k_noise_spectra, dim3((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256),
-                       sizeof(float2) * ROWS_PER_BLOCK * (pl.n_bins + rowf / 2 + 1), st, S_uv, S_br, ldc, total_frames, frame_note,
-                       frame_off, sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins,
-                       pl.hop, row_src, pl.blur175);
+    const dim3 grid((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    const size_t lds = sizeof(float2) * ROWS_PER_BLOCK * (pl.n_bins + rowf / 2 + 1);
+#define NOISE_SPECTRA(IT)                                                                                                          \
+    hipLaunchKernelGGL(k_noise_spectra<IT>, grid, dim3(256), lds, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,        \
+                       sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins, pl.hop, \
+                       row_src, pl.blur175)
+    switch ((pl.n_bins + WAVE - 1) / WAVE) {
+    case 5: NOISE_SPECTRA(5); break;
+    case 9: NOISE_SPECTRA(9); break;
+    case 17: NOISE_SPECTRA(17); break;
+    default: return goofer_fail(ctx, GOOFER_EINVAL, "unsupported bin count %d", pl.n_bins);
+    }
+#undef NOISE_SPECTRA
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

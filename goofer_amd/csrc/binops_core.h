@@ -84,9 +84,13 @@ __device__ __forceinline__ double row_interp(const float *r, int n_bins, double 
 
 // Formant-anchored warp (if `warp` and formants given) then uniform warp (if ratio != 1) of the fp32 row in
 // `ra`, ping-ponging with `rb` (both LDS, n_bins floats).  Returns the buffer holding the result.
+// `seg` = 18 doubles of per-wave LDS: the sorted-anchor path parks (x_k, y_k, slope_k) there so the per-bin
+// segment lookup is three LDS reads instead of a select chain over register arrays.
 // GOOFER.py:840-875, 618-627; each stage rounds to fp32 like the reference.
+constexpr int WARP_SEG_DOUBLES = 18;
+
 __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, double nyq, const double *formants, const double *fs,
-                                           bool warp, double ratio, int lane, int64_t src)
+                                           bool warp, double ratio, int lane, double *seg)
 {
     const double step = nyq / (double)(n_bins - 1);
     const double inv_step = fast_rcp(step);
@@ -107,17 +111,41 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, dou
         bool sorted = true;
         for (int k = 1; k < len; ++k) sorted &= dst[k - 1] <= dst[k];
         if (sorted || len <= 4) {
-            // monotone anchors (or numpy's guess-free linear search): the answer does not depend on the
-            // guess chain — index = last anchor <= x, found with a few compares, bins strided over lanes
-            for (int b = lane; b < n_bins; b += WAVE) {
-                const double x = b >= n_bins - 1 ? nyq : (double)b * step;
-                int j = np_search_guess(x, dst, len, 1);
-                if (len > 4) {
-                    j = 0;
-                    for (int k = 1; k < len; ++k) j += dst[k] <= x;
+            // monotone anchors (or numpy's guess-free linear search for len <= 4): the answer does not depend on the
+            // guess chain — index = number of anchors (after the first) that are <= x
+            if (lane < len) {
+                // lane k owns segment k: slope as np.interp computes it; the last anchor evaluates to its own value
+                double xk = 0.0, yk = 0.0, xn = 0.0, yn = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    if (k == lane) { xk = dst[k]; yk = sp[k]; }
+                    if (k == lane + 1 && k < len) { xn = dst[k]; yn = sp[k]; }
                 }
-                const double wf = np_interp_eval(x, j, dst, sp, len);
-                nxt[b] = (float)row_interp(cur, n_bins, step, inv_step, nyq, wf);
+                const double sl = lane < len - 1 ? (yn - yk) * fast_rcp(xn - xk) : 0.0;
+                seg[3 * lane] = xk; seg[3 * lane + 1] = yk; seg[3 * lane + 2] = sl;
+            }
+            wave_lds_sync();
+            const double d1 = dst[1], d2 = len > 2 ? dst[2] : 0.0, d3 = len > 3 ? dst[3] : 0.0, d4 = len > 4 ? dst[4] : 0.0,
+                         d5 = len > 5 ? dst[5] : 0.0;
+            if (sorted) {
+                for (int b = lane; b < n_bins; b += WAVE) {
+                    const double x = b >= n_bins - 1 ? nyq : (double)b * step;
+                    int j = (d1 <= x);
+                    j += (len > 2) & (d2 <= x);
+                    j += (len > 3) & (d3 <= x);
+                    j += (len > 4) & (d4 <= x);
+                    j += (len > 5) & (d5 <= x);
+                    const double xj = seg[3 * j], yj = seg[3 * j + 1], sl = seg[3 * j + 2];
+                    const double wf = x == xj ? yj : sl * (x - xj) + yj;
+                    nxt[b] = (float)row_interp(cur, n_bins, step, inv_step, nyq, wf);
+                }
+            } else {
+                for (int b = lane; b < n_bins; b += WAVE) {
+                    const double x = b >= n_bins - 1 ? nyq : (double)b * step;
+                    const int j = np_search_guess(x, dst, len, 1);
+                    const double wf = np_interp_eval(x, j, dst, sp, len);
+                    nxt[b] = (float)row_interp(cur, n_bins, step, inv_step, nyq, wf);
+                }
             }
         } else {
         // Resolve np.interp's guess chain over the ascending bin frequencies.  The clamped guess
@@ -206,9 +234,10 @@ __device__ __forceinline__ float2 blur5(const float2 *r, int k, int n_bins, cons
     return make_float2((float)re, (float)im);
 }
 
-// Philox-4x32-10 keyed by (seed), counter (frame, bin): uniform phase in [0, 2 pi) when no phase
-// matrix is injected.
-__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t ctr_hi, uint32_t ctr_lo)
+// Philox-4x32-10 keyed by (seed), counter (frame, slot): four 32-bit words per block.  The phase of bin k comes
+// from slot (k & 63) + 64 * (k >> 8), word (k >> 6) & 3, so a lane that owns bins lane, lane+64, ... needs one
+// block per four of its bins; philox_u32 is the same mapping evaluated for a single bin.
+__device__ __forceinline__ uint4 philox_4x32(uint64_t seed, uint64_t ctr_hi, uint32_t ctr_lo)
 {
     uint32_t c0 = ctr_lo, c1 = (uint32_t)ctr_hi, c2 = (uint32_t)(ctr_hi >> 32), c3 = 0x9E3779B9u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -220,6 +249,12 @@ __device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t ctr_hi, u
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return c0;
+    return make_uint4(c0, c1, c2, c3);
 }
 
+__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t frame, uint32_t bin)
+{
+    const uint4 v = philox_4x32(seed, frame, (bin & 63u) + 64u * (bin >> 8));
+    const uint32_t w = (bin >> 6) & 3u;
+    return w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w));
+}

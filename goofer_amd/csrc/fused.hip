@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256, 3) void k_harm_frames(const float *__restrict_
     using C = fz_cfg<M>;
     constexpr int R = fft_cfg<M>::R, B = C::B;
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double s_seg[4][WARP_SEG_DOUBLES];
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float2 *twh = tw + M;
     float2 *wbase = twh + (M / 2 + 1);
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, 3) void k_harm_frames(const float *__restrict_
             fs[k] = p.f_shift[k];
             warp |= fs[k] != 1.0;
         }
-        const float *cur = warp_row(ra, rb, B, nyq, formants ? formants + q.src * 4 : nullptr, fs, warp, (double)p.formant_shift, lane, 0);
+        const float *cur = warp_row(ra, rb, B, nyq, formants ? formants + q.src * 4 : nullptr, fs, warp, (double)p.formant_shift, lane, s_seg[wave]);
         float eh[C::PER];
 #pragma unroll
         for (int r = 0; r < C::PER; ++r) {
@@ -218,14 +219,17 @@ __global__ __launch_bounds__(256, 3) void k_noise_frames(const float *__restrict
             int k = lane + WAVE * r;
             uv2[r] = make_float2(0.f, 0.f);
             if (k < B) {
-                float ph;
+                float c, s;
                 if (phi) {
-                    ph = phi[f * (int64_t)ld + k];
+                    const float ph = phi[f * (int64_t)ld + k];
+                    c = cosf(ph);
+                    s = sinf(ph);
                 } else {
-                    uint32_t u = philox_u32(key, (uint64_t)q.t, (uint32_t)k);
-                    ph = (float)(u >> 8) * (6.283185307179586f / 16777216.0f);
+                    const uint32_t u = philox_u32(key, (uint64_t)q.t, (uint32_t)k);
+                    const float rev = (float)(u >> 8) * (1.0f / 16777216.0f);
+                    c = __builtin_amdgcn_cosf(rev);
+                    s = __builtin_amdgcn_sinf(rev);
                 }
-                float c = cosf(ph), s = sinf(ph);
                 uv2[r] = make_float2(c * en[r], s * en[r]);
                 float h = hp_mask(freqs[k], q.f0f);
                 float2 bb = make_float2(uv2[r].x * h, uv2[r].y * h);
@@ -271,7 +275,7 @@ static int harm_impl(goofer_ctx *ctx, const float *pulse, const goofer_batch *b,
     const goofer_plan_t &p = ctx->plan;
     static bool attr = false;
     if (!attr) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_harm_frames<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_harm_frames<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         attr = true;
     }
     unsigned blocks = (unsigned)((b->total_frames + FZ_FRAMES - 1) / FZ_FRAMES);
