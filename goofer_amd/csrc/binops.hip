@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_harm_shape(float2 *__restrict__ S, int 
                 float h = hp_mask(fq[i], f0f);
                 s.x *= h; s.y *= h;
             }
-            mx = fmaxf(mx, hypotf(s.x, s.y) + 1e-8f);
+            mx = fmaxf(mx, cabs_fast(s) + 1e-8f);
             const float g = eg ? eg[k] : ev[i];
             s.x = (s.x * g) * bo[i];
             s.y = (s.y * g) * bo[i];

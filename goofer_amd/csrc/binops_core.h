@@ -56,8 +56,9 @@ __device__ __forceinline__ double np_interp_eval(double x, int j, const double *
 
 // linear interpolation of an fp32 row sampled on the uniform grid b*step, at x in [0, nyq]
 // (np.interp with sorted xp: largest j with xp[j] <= x), plus gf.interp1d's linear extrapolation.
-// The index is exact (multiply estimate, compare fix-up against the true grid); the slope uses
-// inv_step = 1/step instead of a division (grid spacing is exactly `step`: b*step is exact in fp64).
+// Index: multiply estimate, then the exact residual d = x - j*step (one fma, so its sign is exact) moves j by at
+// most one; d is also the reference's (x - xp[j]) to within an ulp of xp[j].  The slope uses inv_step = 1/step
+// instead of a division (the grid spacing is exactly `step`).
 __device__ __forceinline__ double row_interp(const float *r, int n_bins, double step, double inv_step, double nyq, double x)
 {
     if (x < 0.0) {
@@ -70,16 +71,13 @@ __device__ __forceinline__ double row_interp(const float *r, int n_bins, double 
         return (double)r[n_bins - 1] + sl * (x - nyq);
     }
     int j = (int)(x * inv_step);
-    if (j > n_bins - 1) j = n_bins - 1;
-    // grid point q is q*step, except the last which linspace pins to nyq
-    if (j + 1 <= n_bins - 1 && (j + 1 >= n_bins - 1 ? nyq : (double)(j + 1) * step) <= x) ++j;
-    if (j > 0 && (j >= n_bins - 1 ? nyq : (double)j * step) > x) --j;
-    if (j >= n_bins - 1) return (double)r[n_bins - 1];
-    const double xj = (double)j * step;
+    double d = fma(-(double)j, step, x);
+    if (d < 0.0) { --j; d += step; }
+    else if (d >= step) { ++j; d -= step; }
+    if (j >= n_bins - 1 || x >= nyq) return (double)r[n_bins - 1];   // linspace pins the last grid point to nyq
     const double r0 = (double)r[j];
-    if (x == xj) return r0;
     const double slope = ((double)r[j + 1] - r0) * inv_step;
-    return slope * (x - xj) + r0;
+    return slope * d + r0;
 }
 
 // Formant-anchored warp (if `warp` and formants given) then uniform warp (if ratio != 1) of the fp32 row in
@@ -212,26 +210,37 @@ __device__ __forceinline__ int64_t pick_index(int64_t t, int64_t n, int hop)
     return q * hop;
 }
 
+// 1 / (1 + exp(-clip((f - f0) / 5, -60, 60)))   GOOFER.py:1110-1111.  Hardware exp2 / rcp (1 ulp) and a multiply by
+// 0.2f stand in for the reference's exp and two divisions: <= 3e-6 relative on the mask, far inside the bound.
 __device__ __forceinline__ float hp_mask(float freq, float f0f)
 {
-    float z = (freq - f0f) / 5.0f;
+    float z = (freq - f0f) * 0.2f;
     z = fminf(fmaxf(z, -60.0f), 60.0f);
-    return 1.0f / (1.0f + expf(-z));
+    const float e = __builtin_amdgcn_exp2f(z * -1.4426950408889634f);
+    return __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-// 5-tap sigma=0.5 blur of a complex row held in LDS (reflect padded), complex128 accumulate
+// |s| for the per-note max(abs(S) + 1e-8): plain sqrt (no overflow risk at these magnitudes)
+__device__ __forceinline__ float cabs_fast(float2 s) { return __builtin_amdgcn_sqrtf(s.x * s.x + s.y * s.y); }
+
+// 5-tap sigma=0.5 blur of a complex row held in LDS (reflect padded).  The reference accumulates in complex128 and
+// rounds to complex64; here the five products are fp32 FMAs in the same tap order (<= 2e-7 relative).
 __device__ __forceinline__ float2 blur5(const float2 *r, int k, int n_bins, const double *t5)
 {
-    double re = 0.0, im = 0.0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        int q = k + j - 2;
-        q = q < 0 ? -q : (q >= n_bins ? 2 * (n_bins - 1) - q : q);
-        float2 v = r[q];
-        re += t5[j] * (double)v.x;
-        im += t5[j] * (double)v.y;
+    const float t0 = (float)t5[0], t1 = (float)t5[1], t2 = (float)t5[2], t3 = (float)t5[3], t4 = (float)t5[4];
+    float2 v0, v1, v2, v3, v4;
+    if (k >= 2 && k + 2 < n_bins) {
+        v0 = r[k - 2]; v1 = r[k - 1]; v2 = r[k]; v3 = r[k + 1]; v4 = r[k + 2];
+    } else {
+        auto at = [&](int q) { return r[q < 0 ? -q : (q >= n_bins ? 2 * (n_bins - 1) - q : q)]; };
+        v0 = at(k - 2); v1 = at(k - 1); v2 = at(k); v3 = at(k + 1); v4 = at(k + 2);
     }
-    return make_float2((float)re, (float)im);
+    float re = t0 * v0.x, im = t0 * v0.y;
+    re = fmaf(t1, v1.x, re); im = fmaf(t1, v1.y, im);
+    re = fmaf(t2, v2.x, re); im = fmaf(t2, v2.y, im);
+    re = fmaf(t3, v3.x, re); im = fmaf(t3, v3.y, im);
+    re = fmaf(t4, v4.x, re); im = fmaf(t4, v4.y, im);
+    return make_float2(re, im);
 }
 
 // Philox-4x32-10 keyed by (seed), counter (frame, slot): four 32-bit words per block.  The phase of bin k comes

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 3) void k_harm_frames(const float *__restrict_
                     float h = hp_mask(freqs[k], q.f0f);
                     s.x *= h; s.y *= h;
                 }
-                mx = fmaxf(mx, hypotf(s.x, s.y) + 1e-8f);
+                mx = fmaxf(mx, cabs_fast(s) + 1e-8f);
                 s.x = (s.x * eh[r]) * boost[k];
                 s.y = (s.y * eh[r]) * boost[k];
                 if (q.voiced) { s.x *= bright[k]; s.y *= bright[k]; }

@@ -1,7 +1,8 @@
 """Per-stage HIP-event times of the default bench workload (config 3, 1024 notes), one line per stage.
 Usage (on the GPU box): python scripts/stage_times.py [notes] [steps]"""
+import os
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from goofer_amd.device import Context
 from goofer_amd.workload import SamplerWorkload
