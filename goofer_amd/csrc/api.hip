@@ -70,6 +70,9 @@ int launch_post_mix(goofer_ctx *, const float *, const float *, const float *, c
                     hipStream_t);
 int launch_dyn_gain(goofer_ctx *, const double *, const double *, const unsigned char *, double *, const goofer_post_note *,
                     const int64_t *, int, int64_t, double *, hipStream_t);
+int launch_irfft_ola3(goofer_ctx *, const float2 *, const float2 *, const float2 *, int, int64_t, const int *, const int64_t *,
+                      const int64_t *, int, const float *, const double *, double *, const goofer_note_params *, float *, float *, float *,
+                      float *, hipStream_t);
 int launch_stem_peak(goofer_ctx *, const float *, const float *, const float *, const int64_t *, int, int64_t, float *, hipStream_t);
 int launch_harm_frames(goofer_ctx *, const float *, const goofer_batch *, const float *, const int *, const int64_t *, float *, float *,
                        hipStream_t);
@@ -445,10 +448,15 @@ static const char *const PROF_NAMES_FUSED[PROF_STAGES] = {
     "setup_maps", "", "", "phase_inc", "pulse_onsets", "pulse_place", "harm_frames", "", "", "noise_frames", "", "",
     "mask_short", "ola3_gains", "apply_gain", "", "", ""};
 
+static const char *const PROF_NAMES_OLA[PROF_STAGES] = {
+    "setup_maps", "", "", "phase_inc", "pulse_onsets", "pulse_place", "rfft_frames", "harm_shape",
+    "", "noise_spectra", "", "", "mask_short", "irfft_ola3", "apply_gain", "", "", ""};
+
 const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage)
 {
     if (stage < 0 || stage >= PROF_STAGES) return "";
-    return (ctx && ctx->fused) ? PROF_NAMES_FUSED[stage] : PROF_NAMES[stage];
+    if (ctx && ctx->fused) return PROF_NAMES_FUSED[stage];
+    return (ctx && ctx->ola_fused) ? PROF_NAMES_OLA[stage] : PROF_NAMES[stage];
 }
 
 /* options: "fused" = 1 (default) fused per-frame kernels, 0 one kernel per reference step (A/B parity) */
@@ -456,6 +464,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return GOOFER_EINVAL;
     if (!strcmp(name, "fused")) { ctx->fused = value != 0; return GOOFER_OK; }
+    if (!strcmp(name, "fused_ola")) { ctx->ola_fused = value != 0; return GOOFER_OK; }
     return goofer_fail(ctx, GOOFER_EINVAL, "unknown option %s", name);
 }
 
@@ -942,6 +951,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         ++stage;                                                     \
     } while (0)
 
+    const bool ola_one = ctx->ola_fused && !ctx->fused && (p.hop % 2 == 0);
     unsigned fb = (unsigned)((F + 255) / 256), sb = (unsigned)((N + 255) / 256);
     MARK();   // 0: setup
     if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, st))) return rc;
@@ -998,21 +1008,25 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                                     note_mag, row_src, b->formants, st)))
             return rc;
         MARK();   // 8
-        if ((rc = launch_irfft_frames(ctx, S_h, ldc, F, frames, st))) return rc;
+        if (!ola_one && (rc = launch_irfft_frames(ctx, S_h, ldc, F, frames, st))) return rc;
         MARK();   // 9: aperiodic spectra
         if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, b->env, b->phi,
                                        ld, b->params, b->seed, row_src, st)))
             return rc;
         MARK();   // 10, 11
-        if ((rc = launch_irfft_frames(ctx, S_br, ldc, F, frames_b, st))) return rc;
+        if (!ola_one && (rc = launch_irfft_frames(ctx, S_br, ldc, F, frames_b, st))) return rc;
         MARK();
-        if ((rc = launch_irfft_frames(ctx, S_uv, ldc, F, frames_u, st))) return rc;
+        if (!ola_one && (rc = launch_irfft_frames(ctx, S_uv, ldc, F, frames_u, st))) return rc;
     }
     MARK();   // 12: decimated + smoothed voicing mask
     if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, short_s, st))) return rc;
-    MARK();   // 13: overlap-add of the three stems + gains + per-note peak, one pass
-    if ((rc = launch_ola3_gains(ctx, frames, frames_u, frames_b, note_mag, short_s, b->sample_off, b->frame_off, n, N, b->params,
-                                note_steps, b->harm, b->uv, b->bre, note_peak, st)))
+    MARK();   // 13: (irFFT of the three stems +) overlap-add + gains + per-note peak, one pass
+    if (ola_one) {
+        if ((rc = launch_irfft_ola3(ctx, S_h, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, n, note_mag, short_s,
+                                    note_steps, b->params, b->harm, b->uv, b->bre, note_peak, st)))
+            return rc;
+    } else if ((rc = launch_ola3_gains(ctx, frames, frames_u, frames_b, note_mag, short_s, b->sample_off, b->frame_off, n, N,
+                                       b->params, note_steps, b->harm, b->uv, b->bre, note_peak, st)))
         return rc;
     if (jit_vol) {  // 'sr': volume jitter on harm / breath, then the peak is taken again (GOOFER.py:1185-1193)
         const double *d_t = nullptr, *d_t20; int r = 0, r20;

@@ -40,6 +40,7 @@ struct goofer_ctx {
     // device pointers of the last synth batch's intermediates (goofer_debug_fetch; tests only)
     const void *dbg_ptr[16] = {nullptr};
     size_t dbg_bytes[16] = {0};
+    bool ola_fused = true;        // irFFT x3 + overlap-add + gains in one kernel (k_irfft_ola3); false: separate irFFT launches + k_ola3_gains
     bool fused = false;           // opt-in fused per-frame kernels (fused.hip); default: one kernel per reference step
     // per-stage HIP-event timing of goofer_synth_batch (goofer_profile_begin/end)
     bool prof_on = false;

@@ -4,7 +4,7 @@
 //   k_stem_gains   lerp-upsample the smoothed mask, scale the three stems, per-note peak
 //                                                                    GOOFER.py:563-567, 1179-1193, 1210
 //   k_apply_gain   gain = (1/peak)^normalize, reconstruct, V/B/U mix GOOFER.py:1208-1218, SillySampler.py:1142-1151
-#include "common.h"
+#include "fft_core.h"
 
 #define MASK_DS 4
 
@@ -244,6 +244,223 @@ __global__ __launch_bounds__(256) void k_ola3_gains(const float *__restrict__ fr
         while (sample_off[note + 1] <= g) ++note;
         atomic_max_pos(note_peak + note, body(note));
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// irFFT of the three stems + overlap-add + gains + per-note peak in one pass over the spectra (replaces three
+// k_irfft_frames launches and k_ola3_gains: the windowed frames never go to HBM).
+//
+// A wave walks `run` consecutive frames of the concatenated frame axis in order.  Per stem it keeps a ring of
+// n_fft accumulators in LDS indexed by (padded sample position mod n_fft): frame t adds its windowed samples to
+// positions [t hop, t hop + n_fft); the last `hop` of them are first contributions and are stored, the rest are
+// added — so every output sample receives its covering frames in ascending frame order, the reference's fp32
+// order (GOOFER.py:379-385).  After frame t, hop t is complete: it is normalised by the summed squared window,
+// scaled by the stem gains and written.  A run that starts inside a note first replays the `halo` preceding
+// frames (accumulate only); the wave that owns a note's last frame also flushes the hops behind it and the
+// zero-filled tail (GOOFER.py:402-413).
+template <int M>
+__global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S_h, const float2 *__restrict__ S_u,
+                                                    const float2 *__restrict__ S_b, int ldc, int64_t total_frames,
+                                                    const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
+                                                    const int64_t *__restrict__ sample_off, int hop, int run, int halo,
+                                                    const float *__restrict__ note_mag, const double *__restrict__ short_s,
+                                                    const double *__restrict__ steps, const goofer_note_params *__restrict__ params,
+                                                    float *__restrict__ harm, float *__restrict__ uv, float *__restrict__ bre,
+                                                    float *__restrict__ note_peak, const float2 *__restrict__ g_tw,
+                                                    const float2 *__restrict__ g_twh, const float *__restrict__ g_win)
+{
+    constexpr int R = fft_cfg<M>::R, NF = 2 * M, BUF = fft_cfg<M>::BUF;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *tw = reinterpret_cast<float2 *>(smem);
+    float2 *twh = tw + M;
+    float2 *bufs = twh + (M / 2 + 1);
+    float *win = reinterpret_cast<float *>(bufs + WAVES_PER_BLOCK * BUF);
+    float *rings = win + NF;
+    load_tables<M>(tw, twh, win, g_tw, g_twh, g_win);
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float2 *buf = bufs + wave * BUF;
+    float *ring = rings + (size_t)wave * 3 * NF;
+    const int64_t f0 = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + wave) * run;
+    if (f0 >= total_frames) return;                          // no block barrier below
+    const int64_t f1 = f0 + run < total_frames ? f0 + run : total_frames;
+    const float inv_m = 1.0f / (float)M;
+
+    int64_t fs = f0;
+    {
+        const int nt = frame_note[f0];
+        const int64_t t0 = f0 - frame_off[nt];
+        fs = f0 - (t0 < halo ? t0 : halo);
+    }
+
+    // spectrum rows of the next (frame, stem) job are fetched while the current one is transformed
+    float2 nk[R], nm[R];
+    auto fetch = [&](int64_t f, int stem) {
+        const float2 *row = (stem == 0 ? S_h : (stem == 1 ? S_u : S_b)) + f * (int64_t)ldc;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int k = lane + WAVE * r;
+            nk[r] = row[k];
+            nm[r] = row[M - k];
+        }
+    };
+    fetch(fs, 0);
+
+    int note = -1;
+    int64_t base = 0, n = 0, fbase = 0, T = 0, ns = 0, out_len = 0;
+    float mag = 1.f, g_b = 0.f, g_u = 0.f, pk = 0.f;
+    double step_n = 0.0, step_s = 0.0;
+    const double *ss = nullptr;
+
+    // finished hop h of the current note -> gains -> stems; also used for the flush hops and the zero tail
+    auto emit = [&](int64_t h) {
+        for (int j = lane; j < hop; j += WAVE) {
+            const int64_t p = h * hop + j;
+            const int64_t i = p - M;
+            if (i < 0 || i >= n) continue;
+            float vh = 0.f, vu = 0.f, vb = 0.f;
+            if (i < out_len) {
+                int64_t lo = p - NF + 1;
+                lo = lo <= 0 ? 0 : (lo + hop - 1) / hop;
+                int64_t hi = p / hop;
+                if (hi > T - 1) hi = T - 1;
+                float ws = 0.f;
+                for (int64_t fr = lo; fr <= hi; ++fr) {
+                    const float w = win[(int)(p - fr * hop)];
+                    ws += w * w;
+                }
+                const int q = (int)(p & (NF - 1));
+                vh = ring[q]; vu = ring[NF + q]; vb = ring[2 * NF + q];
+                if (ws > 1e-9f) { vh /= ws; vu /= ws; vb /= ws; }
+                vh = vh / mag;
+            }
+            const float ms = smooth_mask_at(ss, ns, i, n, step_n, step_s);
+            vb = (vb * ms) * g_b;
+            vu = (vu * (1.0f - ms)) * g_u;
+            harm[base + i] = vh;
+            uv[base + i] = vu;
+            bre[base + i] = vb;
+            pk = fmaxf(pk, fabsf((vh + vu) + vb));
+        }
+    };
+
+    for (int64_t f = fs; f < f1; ++f) {
+        const int nt = frame_note[f];
+        if (nt != note) {
+            if (note >= 0) {
+                const float m = wave_max(pk);
+                if (lane == 0) atomic_max_pos(note_peak + note, m);
+            }
+            note = nt;
+            pk = 0.f;
+            base = sample_off[note];
+            n = sample_off[note + 1] - base;
+            fbase = frame_off[note];
+            T = frame_off[note + 1] - fbase;
+            ns = (n + MASK_DS - 1) / MASK_DS;
+            out_len = (int64_t)hop * (T - 1);
+            mag = note_mag[note];
+            g_b = params[note].breath_strength;
+            g_u = params[note].uv_strength;
+            step_n = steps[2 * note];
+            step_s = steps[2 * note + 1];
+            ss = short_s + short_base(sample_off, note);
+        }
+        const int64_t t = f - fbase;
+#pragma unroll
+        for (int stem = 0; stem < 3; ++stem) {
+            float2 v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int k = lane + WAVE * r;
+                float2 xk = nk[r], xm = nm[r];
+                if (k == 0) { xk.y = 0.f; xm.y = 0.f; }       // irfft ignores Im of DC and Nyquist
+                const float2 wc = (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y);
+                const float2 A = make_float2(xk.x + xm.x, xk.y - xm.y);
+                const float2 D = make_float2(xk.x - xm.x, xk.y + xm.y);
+                const float2 Cc = cmul(wc, D);
+                v[r] = make_float2(0.5f * (A.x - Cc.y), -0.5f * (A.y + Cc.x));
+            }
+            // next job's rows: same frame next stem, or the next frame's first stem
+            if (stem < 2) fetch(f, stem + 1);
+            else if (f + 1 < f1) fetch(f + 1, 0);
+            wave_fft<M>(v, buf, tw, lane);
+            float *rg = ring + stem * NF;
+            const int shift = (int)((t * hop) & (NF - 1));
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int m = lane + WAVE * r;
+                const float2 z = buf[lds_pad(m)];
+                const float a = (z.x * inv_m) * win[2 * m], b = (-z.y * inv_m) * win[2 * m + 1];
+                const int q = (2 * m + shift) & (NF - 1);
+                float2 *slot = reinterpret_cast<float2 *>(rg + q);
+                if (t == 0 || 2 * m >= NF - hop) {
+                    *slot = make_float2(a, b);                // first contribution: y starts from zero
+                } else {
+                    float2 o = *slot;
+                    *slot = make_float2(o.x + a, o.y + b);
+                }
+            }
+            wave_lds_sync();
+        }
+        if (f >= f0) {
+            emit(t);
+            if (t == T - 1) {
+                const int64_t h_last = (out_len + M - 1) / hop;   // last hop holding a sample below out_len
+                for (int64_t h = T; h <= h_last; ++h) emit(h);
+                // zero-filled tail [out_len, n) not covered by the hops above
+                for (int64_t h = h_last + 1; h * hop - M < n; ++h) emit(h);
+            }
+        }
+        wave_lds_sync();
+    }
+    if (note >= 0) {
+        const float m = wave_max(pk);
+        if (lane == 0) atomic_max_pos(note_peak + note, m);
+    }
+}
+
+template <int M>
+static int irfft_ola3_impl(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u, const float2 *S_b, int ldc, int64_t total_frames,
+                           const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, const float *note_mag,
+                           const double *short_s, const double *steps, const goofer_note_params *params, float *harm, float *uv,
+                           float *bre, float *note_peak, hipStream_t st)
+{
+    const goofer_plan_t &p = ctx->plan;
+    const int halo = (p.n_fft + p.hop - 1) / p.hop - 1;
+    const int run = halo <= 4 ? 32 : 8 * halo;
+    const size_t lds = sizeof(float2) * (M + M / 2 + 1 + WAVES_PER_BLOCK * fft_cfg<M>::BUF) + sizeof(float) * 2 * M +
+                       sizeof(float) * WAVES_PER_BLOCK * 3 * 2 * M + 16;
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_irfft_ola3<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const int64_t runs = (total_frames + run - 1) / run;
+    hipLaunchKernelGGL(k_irfft_ola3<M>, dim3((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), dim3(256), lds, st, S_h, S_u,
+                       S_b, ldc, total_frames, frame_note, frame_off, sample_off, p.hop, run, halo, note_mag, short_s, steps, params,
+                       harm, uv, bre, note_peak, p.tw_full, p.tw_half, p.window);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+// note_steps must have run (launch_note_steps) before this
+int launch_irfft_ola3(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u, const float2 *S_b, int ldc, int64_t total_frames,
+                      const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, int n_notes, const float *note_mag,
+                      const double *short_s, double *steps, const goofer_note_params *params, float *harm, float *uv, float *bre,
+                      float *note_peak, hipStream_t st)
+{
+    if (total_frames <= 0) return GOOFER_OK;
+    const goofer_plan_t &p = ctx->plan;
+    if (p.hop & 1) return goofer_fail(ctx, GOOFER_EINVAL, "the fused overlap-add needs an even hop");
+    hipLaunchKernelGGL(k_note_steps, dim3((n_notes + 255) / 256), dim3(256), 0, st, sample_off, n_notes, steps);
+    LAUNCH_CHECK(ctx);
+    switch (p.n_fft) {
+    case 512: return irfft_ola3_impl<256>(ctx, S_h, S_u, S_b, ldc, total_frames, frame_note, frame_off, sample_off, note_mag, short_s, steps, params, harm, uv, bre, note_peak, st);
+    case 1024: return irfft_ola3_impl<512>(ctx, S_h, S_u, S_b, ldc, total_frames, frame_note, frame_off, sample_off, note_mag, short_s, steps, params, harm, uv, bre, note_peak, st);
+    case 2048: return irfft_ola3_impl<1024>(ctx, S_h, S_u, S_b, ldc, total_frames, frame_note, frame_off, sample_off, note_mag, short_s, steps, params, harm, uv, bre, note_peak, st);
+    }
+    return goofer_fail(ctx, GOOFER_EINVAL, "unsupported n_fft %d", p.n_fft);
 }
 
 __global__ __launch_bounds__(256) void k_apply_gain(float *__restrict__ harm, float *__restrict__ uv, float *__restrict__ bre,

@@ -199,3 +199,23 @@ def test_synthesize_subharm_kwargs_vs_oracle(ctx, kw):
     assert rms_err(got[1], plain[1]) > 1e-3                     # the layer is audible, not a no-op
     for a, b, key in zip(got, ref, ("rec", "harm", "uv", "bre")):
         assert rms_err(a, b) < 2e-5, (key, rms_err(a, b))
+
+
+@pytest.mark.parametrize("config,ids", [(3, [0, 1, 2, 3, 4, 5, 6]), (4, [0, 1, 2, 5, 7, 9]), (5, [0, 1])])
+def test_fused_overlap_add_equals_separate_kernels(ctx, config, ids):
+    """k_irfft_ola3 (irFFT x3 + OLA + gains in one kernel, runs with replayed halo frames) must produce the bits
+    of the separate irFFT launches + k_ola3_gains: same products, same ascending-frame accumulation order."""
+    from goofer_amd.workload import SynthWorkload
+    wl = SynthWorkload(ctx, config, ids)
+    try:
+        ctx.set_option("fused_ola", 1)
+        a = wl.step(want_rec=True)
+        torch.cuda.synchronize()
+        a = {k: a[k].cpu().numpy() for k in ("harm", "uv", "bre", "rec", "mix")}
+        ctx.set_option("fused_ola", 0)
+        b = wl.step(want_rec=True)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_option("fused_ola", 1)
+    for k in a:
+        assert np.array_equal(a[k], b[k].cpu().numpy()), k
