@@ -14,6 +14,8 @@ int launch_frame_note(goofer_ctx *, const int64_t *, int, int64_t, int *, hipStr
 int launch_rfft_frames_mapped(goofer_ctx *, const float *, const int64_t *, const int64_t *, const int *, int64_t, float2 *, int,
                               hipStream_t);
 int launch_pulse_peak(goofer_ctx *, float *, double, hipStream_t);
+size_t pulse_shape_table_floats();
+int launch_pulse_shape_table(goofer_ctx *, float *, const float *, double, hipStream_t);
 struct onset_t;
 int launch_pulse_train(goofer_ctx *, const float *, float, const int64_t *, int, int64_t, float *, double *, onset_t *, int32_t *,
                        int32_t *, int32_t *, hipStream_t);
@@ -35,7 +37,7 @@ int launch_harm_shape(goofer_ctx *, float2 *, int, int64_t, const int *, const i
 int launch_noise_spectra(goofer_ctx *, float2 *, float2 *, int, int64_t, const int *, const int64_t *, const int64_t *,
                          const float *, const float *, const float *, const float *, int, const goofer_note_params *, uint64_t,
                          const int64_t *, hipStream_t);
-int launch_mask_short(goofer_ctx *, const float *, const int64_t *, int, int64_t, const double *, int, double *, hipStream_t);
+int launch_mask_short(goofer_ctx *, const float *, const int64_t *, int, int64_t, const double *, int, double, double *, hipStream_t);
 int launch_assemble(goofer_ctx *, const goofer_assembly *, int *, int *, hipStream_t);
 int launch_mag_rows(goofer_ctx *, const float2 *, int, int64_t, int, float *, int, hipStream_t);
 int launch_gauss_rows64(goofer_ctx *, const float *, int, double *, int, int64_t, int, const double *, int, hipStream_t);
@@ -110,21 +112,30 @@ __global__ void k_row_src(const int64_t *__restrict__ frame_off, const int64_t *
     row_src[f] = env_off[note] + t;
 }
 
-__global__ void k_scale_f0(const float *__restrict__ f0, const int64_t *__restrict__ sample_off, int n_notes, int64_t total,
-                           const goofer_note_params *__restrict__ params, float *__restrict__ out)
+// f0 *= pitch_shift (GOOFER.py:995), fp32.  1024 samples per workgroup, 16-byte accesses when the tile sits in one note.
+__global__ __launch_bounds__(256) void k_scale_f0(const float *__restrict__ f0, const int64_t *__restrict__ sample_off, int n_notes,
+                                                  int64_t total, const goofer_note_params *__restrict__ params, float *__restrict__ out)
 {
     __shared__ int s_pair[2];
-    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t g0 = (int64_t)blockIdx.x * 1024;
+    int64_t gl = g0 + 1023;
+    if (gl > total - 1) gl = total - 1;
     int lo, hi;
-    block_note_range(sample_off, n_notes, g0, total, s_pair, lo, hi);
-    const int64_t g = g0 + threadIdx.x;
+    block_note_range_last(sample_off, n_notes, g0, gl, s_pair, lo, hi);
+    const int64_t g = g0 + (int64_t)threadIdx.x * 4;
     if (g >= total) return;
-    if (lo == hi) {
-        out[g] = f0[g] * params[lo].pitch_shift;
-    } else {
-        int note = lo;
-        while (sample_off[note + 1] <= g) ++note;
-        out[g] = f0[g] * params[note].pitch_shift;
+    const bool vec = (((uintptr_t)f0 | (uintptr_t)out) & 15) == 0;
+    if (lo == hi && g + 4 <= total && vec) {
+        const float ps = params[lo].pitch_shift;
+        float4 v = *reinterpret_cast<const float4 *>(f0 + g);
+        v.x *= ps; v.y *= ps; v.z *= ps; v.w *= ps;
+        *reinterpret_cast<float4 *>(out + g) = v;
+        return;
+    }
+    int note = lo;
+    for (int k = 0; k < 4 && g + k < total; ++k) {
+        while (sample_off[note + 1] <= g + k) ++note;
+        out[g + k] = f0[g + k] * params[note].pitch_shift;
     }
 }
 
@@ -271,7 +282,7 @@ template <typename T> static int upload(goofer_ctx *ctx, T **dst, const std::vec
 
 static void free_plan(goofer_plan_t &p)
 {
-    void *ptrs[] = {p.window, p.win_sq, p.freqs, p.boost, p.bright_h, p.bright_b, p.tw_full, p.tw_half, p.pulse_peak, p.blur5, p.blur175};
+    void *ptrs[] = {p.window, p.win_sq, p.freqs, p.boost, p.bright_h, p.bright_b, p.tw_full, p.tw_half, p.pulse_peak, p.pulse_shape, p.blur5, p.blur175};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     p = goofer_plan_t();
@@ -363,6 +374,8 @@ int goofer_plan(goofer_ctx *ctx, int sr, int n_fft, int hop)
     HIP_TRY(ctx, hipMalloc((void **)&p.pulse_peak, 8193 * sizeof(float)));
     p.sr = sr; p.n_fft = n_fft; p.hop = hop; p.n_bins = B;
     if ((rc = launch_pulse_peak(ctx, p.pulse_peak, (double)sr, 0))) return rc;
+    HIP_TRY(ctx, hipMalloc((void **)&p.pulse_shape, pulse_shape_table_floats() * sizeof(float)));
+    if ((rc = launch_pulse_shape_table(ctx, p.pulse_shape, p.pulse_peak, (double)sr, 0))) return rc;
     HIP_TRY(ctx, hipDeviceSynchronize());
     return GOOFER_OK;
 }
@@ -935,6 +948,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         HIP_TRY(ctx, hipMemcpy(ctx->mask_taps, mtaps.data(), mtaps.size() * sizeof(double), hipMemcpyHostToDevice));
         ctx->mask_taps_sigma = b->transition_sigma;
         ctx->mask_taps_radius = mrad;
+        double acc = 0.0;
+        for (double tv : mtaps) acc += tv * 1.0;
+        ctx->mask_taps_sum = acc;
     }
     const double *d_mtaps = ctx->mask_taps;
     const int mrad = ctx->mask_taps_radius;
@@ -952,12 +968,12 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     } while (0)
 
     const bool ola_one = ctx->ola_fused && !ctx->fused && (p.hop % 2 == 0);
-    unsigned fb = (unsigned)((F + 255) / 256), sb = (unsigned)((N + 255) / 256);
+    unsigned fb = (unsigned)((F + 255) / 256);
     MARK();   // 0: setup
     if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, st))) return rc;
     hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, st, b->frame_off, b->env_off, frame_note, F, row_src);
     LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_scale_f0, dim3(sb), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s);
+    hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s);
     LAUNCH_CHECK(ctx);
     if (jit_f0 || jit_vol) {
         hipLaunchKernelGGL(k_note_flags, dim3((n + 255) / 256), dim3(256), 0, st, b->params, n, on_f0, on_vol);
@@ -1019,7 +1035,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if (!ola_one && (rc = launch_irfft_frames(ctx, S_uv, ldc, F, frames_u, st))) return rc;
     }
     MARK();   // 12: decimated + smoothed voicing mask
-    if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, short_s, st))) return rc;
+    if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
     MARK();   // 13: (irFFT of the three stems +) overlap-add + gains + per-note peak, one pass
     if (ola_one) {
         if ((rc = launch_irfft_ola3(ctx, S_h, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, n, note_mag, short_s,

@@ -10,6 +10,7 @@
 
 #define WAVE 64
 #define PROF_STAGES 18
+#define PULSE_TAB_MAX 2048     // pulse lengths served from the shape table (f0 >= sr/2048); longer ones are evaluated on the fly
 
 struct goofer_plan_t {
     int sr = 0, n_fft = 0, hop = 0, n_bins = 0;
@@ -22,6 +23,7 @@ struct goofer_plan_t {
     float2 *tw_full = nullptr;    // [n_fft/2]   exp(-2 pi i k / (n_fft/2))
     float2 *tw_half = nullptr;    // [n_fft/4+1] exp(-2 pi i k / n_fft)
     float *pulse_peak = nullptr;  // [8193] 1/peak-normaliser of the LF shape per T0 (fp64 math)
+    float *pulse_shape = nullptr; // normalised LF pulses for T0 = 3..PULSE_TAB_MAX back to back (row T0 at T0(T0-1)/2 - 3)
     double *blur5 = nullptr;      // [5] sigma=0.5 taps (brightness blur)         GOOFER.py:1143
     double *blur175 = nullptr;    // [15] sigma=1.75 taps                         GOOFER.py:993
 };
@@ -49,6 +51,7 @@ struct goofer_ctx {
     double *mask_taps = nullptr;  // device taps of the voicing-mask smoother, cached per sigma
     float mask_taps_sigma = -1.f;
     int mask_taps_radius = 0;
+    double mask_taps_sum = 0.0;   // running fp64 sum of the taps in tap order (the FIR's answer on a window of ones)
 };
 
 int goofer_fail(goofer_ctx *ctx, int code, const char *fmt, ...);
@@ -92,22 +95,52 @@ __device__ __forceinline__ int csr_find(const int64_t *__restrict__ off, int n, 
     return lo;
 }
 
+// Wave-cooperative version of csr_find for any non-decreasing key(k), k in [0, n]: all 64 lanes probe 64 evenly
+// spaced positions per round (one round of dependent loads narrows the range 64x: 2 rounds for 4096 notes instead
+// of 12 serial steps).  Every lane of the calling wave must be active; every lane gets the result.
+template <typename Key>
+__device__ __forceinline__ int wave_find(int n, int64_t g, int lane, Key key)
+{
+    int lo = 0, hi = n;                                      // invariant key(lo) <= g < key(hi)
+    while (hi - lo > 1) {
+        const int step = (hi - lo + 63) >> 6;
+        const int p = lo + (lane + 1) * step;
+        const bool le = p < hi && key(p) <= g;
+        const int c = __popcll(__ballot(le));                // probes <= g form a prefix (keys are sorted)
+        const int nhi = lo + (c + 1) * step;
+        lo += c * step;
+        if (nhi < hi) hi = nhi;
+    }
+    return lo;
+}
+
 // Kernels that tile the concatenated sample axis call this first: it finds the notes of the block's
 // first and last sample.  When they coincide (almost always: a note is ~190 blocks long) the caller
 // runs its body with that index held in an SGPR, so every per-note load behind it (offsets, params,
-// constants) is a scalar load instead of a chain of dependent per-lane vector loads.
-__device__ __forceinline__ void block_note_range(const int64_t *__restrict__ off, int n_notes, int64_t g0, int64_t total,
-                                                 int *s_pair, int &lo, int &hi)
+// constants) is a scalar load instead of a chain of dependent per-lane vector loads.  The search itself is
+// done by the first wave cooperatively (the serial binary search used to cost ~20 dependent loads per block,
+// which bounded the short elementwise kernels).  Workgroups must be at least one full wave.
+__device__ __forceinline__ void block_note_range_last(const int64_t *__restrict__ off, int n_notes, int64_t g0, int64_t gl,
+                                                      int *s_pair, int &lo, int &hi)
 {
-    if (threadIdx.x == 0) {
-        s_pair[0] = csr_find(off, n_notes, g0);
-        int64_t gl = g0 + blockDim.x - 1;
-        if (gl > total - 1) gl = total - 1;
-        s_pair[1] = csr_find(off, n_notes, gl);
+    if (threadIdx.x < WAVE) {
+        const int lane = threadIdx.x;
+        auto key = [&](int k) { return off[k]; };
+        const int a = wave_find(n_notes, g0, lane, key);
+        const int b = wave_find(n_notes, gl, lane, key);
+        if (lane == 0) { s_pair[0] = a; s_pair[1] = b; }
     }
     __syncthreads();
     lo = __builtin_amdgcn_readfirstlane(s_pair[0]);
     hi = __builtin_amdgcn_readfirstlane(s_pair[1]);
+}
+
+__device__ __forceinline__ void block_note_range(const int64_t *__restrict__ off, int n_notes, int64_t g0, int64_t total,
+                                                 int *s_pair, int &lo, int &hi)
+{
+    int64_t gl = g0 + blockDim.x - 1;
+    if (gl > total - 1) gl = total - 1;
+    block_note_range_last(off, n_notes, g0, gl, s_pair, lo, hi);
 }
 
 __device__ __forceinline__ void wave_lds_sync()

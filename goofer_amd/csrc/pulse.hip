@@ -53,9 +53,35 @@ __global__ __launch_bounds__(256) void k_pulse_peak(float *__restrict__ peak, do
     if (threadIdx.x == 0) peak[T0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// The normalised pulse of length T0, tabulated at the nominal period T = T0/sr.  The LF shape depends on the period
+// only through ratios (ti/Tp = k / (Ra T0), tau = (k/T0 - Ra) / (Rk (1 - Ra))), so an onset's true period
+// 1/f0 moves the fp64 value by ~1e-11 relative (the 1e-12 guards) — below fp32 resolution except on rare ties.
+__device__ __forceinline__ int64_t pulse_tab_row(int T0) { return (int64_t)T0 * (T0 - 1) / 2 - 3; }
+
+__global__ __launch_bounds__(256) void k_pulse_shape_table(float *__restrict__ tab, const float *__restrict__ peak, double sr)
+{
+    const int T0 = blockIdx.x + 3;
+    const double T = (double)T0 / sr;
+    const double m = (double)peak[T0];
+    float *row = tab + pulse_tab_row(T0);
+    for (int k = threadIdx.x; k < T0; k += blockDim.x) {
+        const float raw = lf_raw(k, T0, T);
+        row[k] = m > 0.0 ? (float)((double)raw / m) : raw;
+    }
+}
+
 int launch_pulse_peak(goofer_ctx *ctx, float *peak, double sr, hipStream_t st)
 {
     hipLaunchKernelGGL(k_pulse_peak, dim3(8193), dim3(256), 0, st, peak, sr);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+size_t pulse_shape_table_floats() { return (size_t)((int64_t)(PULSE_TAB_MAX + 1) * PULSE_TAB_MAX / 2 - 3); }
+
+int launch_pulse_shape_table(goofer_ctx *ctx, float *tab, const float *peak, double sr, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pulse_shape_table, dim3(PULSE_TAB_MAX - 2), dim3(256), 0, st, tab, peak, sr);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
@@ -272,54 +298,59 @@ __global__ __launch_bounds__(64) void k_onset_finish(const float *__restrict__ f
 #define PP_SPT 4
 #define PP_MAXON 512
 
-__device__ __forceinline__ float pulse_value(const onset_t &o, int j, const float *__restrict__ peak)
+__device__ __forceinline__ float pulse_value(const onset_t &o, int j, const float *__restrict__ peak, const float *__restrict__ tab)
 {
     const int d = j - o.i;
     if (d < 0 || d >= o.T0) return 0.f;
+    if (o.T0 <= PULSE_TAB_MAX) return tab[pulse_tab_row(o.T0) + d];
     const float raw = lf_raw(d, o.T0, o.T);
     const double m = (double)peak[o.T0];
     return m > 0.0 ? (float)((double)raw / m) : raw;
 }
 
 __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__ onsets, const int32_t *__restrict__ onset_cnt,
-                                                     const float *__restrict__ peak, const int64_t *__restrict__ sample_off,
-                                                     int n_notes, int64_t total_samples, float *__restrict__ pulse)
+                                                     const float *__restrict__ peak, const float *__restrict__ tab,
+                                                     const int64_t *__restrict__ sample_off, int n_notes, int64_t total_samples,
+                                                     float *__restrict__ pulse)
 {
     __shared__ int s_pair[2];
     __shared__ int s_rng[2];
     __shared__ onset_t s_on[PP_MAXON];
     const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x * PP_SPT);
+    int64_t gl = g0 + (int64_t)blockDim.x * PP_SPT - 1;
+    if (gl > total_samples - 1) gl = total_samples - 1;
     if (threadIdx.x == 0) {
-        s_pair[0] = csr_find(sample_off, n_notes, g0);
-        int64_t gl = g0 + (int64_t)blockDim.x * PP_SPT - 1;
-        if (gl > total_samples - 1) gl = total_samples - 1;
-        s_pair[1] = csr_find(sample_off, n_notes, gl);
         s_rng[0] = 0;
-        s_rng[1] = -1;
-        if (s_pair[0] == s_pair[1]) {
-            const int note = s_pair[0];
-            const int64_t base = sample_off[note];
-            const onset_t *ol = onsets + (base / 2 + 16 * (int64_t)note);
-            const int cnt = onset_cnt[note];
-            const int32_t j_lo = (int32_t)(g0 - base), j_hi = (int32_t)(gl - base);
-            int lo = -1, hi = cnt;                      // last onset with i <= j_hi
-            while (hi - lo > 1) {
-                int mid = (lo + hi) >> 1;
-                if (ol[mid].i <= j_hi) lo = mid; else hi = mid;
-            }
-            const int last = lo;
-            lo = -1; hi = cnt;                          // first onset with end_max > j_lo (end_max is monotone)
-            while (hi - lo > 1) {
-                int mid = (lo + hi) >> 1;
-                if (ol[mid].end_max > j_lo) hi = mid; else lo = mid;
-            }
-            s_rng[0] = hi;
-            s_rng[1] = last;
-        }
+        s_rng[1] = 0;
     }
-    __syncthreads();
-    const int lo_n = __builtin_amdgcn_readfirstlane(s_pair[0]), hi_n = __builtin_amdgcn_readfirstlane(s_pair[1]);
-    const int k0 = __builtin_amdgcn_readfirstlane(s_rng[0]), k1 = __builtin_amdgcn_readfirstlane(s_rng[1]);
+    int lo_n, hi_n;
+    block_note_range_last(sample_off, n_notes, g0, gl, s_pair, lo_n, hi_n);
+    int k0 = 0, k1 = -1;
+    if (lo_n == hi_n) {
+        // onsets that can touch the tile: [first with end_max > j_lo (end_max is monotone), last with i <= j_hi].  Both
+        // are counts over the sorted list, taken by the whole workgroup at once instead of two serial binary searches.
+        const int64_t base = sample_off[lo_n];
+        const onset_t *ol = onsets + (base / 2 + 16 * (int64_t)lo_n);
+        const int cnt = onset_cnt[lo_n];
+        const int32_t j_lo = (int32_t)(g0 - base), j_hi = (int32_t)(gl - base);
+        int c_first = 0, c_last = 0;
+        for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
+            c_first += ol[k].end_max <= j_lo;
+            c_last += ol[k].i <= j_hi;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            c_first += __shfl_xor(c_first, o, 64);
+            c_last += __shfl_xor(c_last, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&s_rng[0], c_first);
+            atomicAdd(&s_rng[1], c_last);
+        }
+        __syncthreads();
+        k0 = __builtin_amdgcn_readfirstlane(s_rng[0]);
+        k1 = __builtin_amdgcn_readfirstlane(s_rng[1]) - 1;
+    }
     const int nk = k1 - k0 + 1;
     if (lo_n == hi_n && nk <= PP_MAXON) {
         const int64_t base = sample_off[lo_n];
@@ -334,7 +365,7 @@ __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__
             float acc = 0.f;
             for (int k = 0; k < nk; ++k) {
                 if (s_on[k].i > j) break;                                        // sorted by onset sample
-                acc += pulse_value(s_on[k], j, peak);
+                acc += pulse_value(s_on[k], j, peak, tab);
             }
             pulse[g] = acc;
         }
@@ -358,7 +389,7 @@ __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__
         if (lo >= 0) {
             int first = lo;
             while (first > 0 && ol[first - 1].end_max > j) --first;
-            for (int k = first; k <= lo; ++k) acc += pulse_value(ol[k], j, peak);
+            for (int k = first; k <= lo; ++k) acc += pulse_value(ol[k], j, peak, tab);
         }
         pulse[g] = acc;
     }
@@ -406,7 +437,7 @@ int launch_pulse_place(goofer_ctx *ctx, const onset_t *onsets, const int32_t *on
 {
     if (total_samples <= 0) return GOOFER_OK;
     hipLaunchKernelGGL(k_pulse_place, dim3((unsigned)((total_samples + 1023) / 1024)), dim3(256), 0, st, onsets, onset_cnt,
-                       ctx->plan.pulse_peak, sample_off, n_notes, total_samples, pulse);
+                       ctx->plan.pulse_peak, ctx->plan.pulse_shape, sample_off, n_notes, total_samples, pulse);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

@@ -18,53 +18,77 @@ __device__ __forceinline__ int64_t short_base(const int64_t *sample_off, int not
 
 __global__ __launch_bounds__(256) void k_mask_short(const float *__restrict__ mask, const int64_t *__restrict__ sample_off,
                                                     int n_notes, int64_t total_short, const double *__restrict__ taps, int radius,
-                                                    double *__restrict__ short_s)
+                                                    double *__restrict__ short_s, double tap_sum)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double *s_taps = reinterpret_cast<double *>(smem);
-    float *s_win = reinterpret_cast<float *>(s_taps + (2 * radius + 1)) + (threadIdx.x >> 6) * MS_MAXWIN;
-    __shared__ int s_lo;
+    float *s_all = reinterpret_cast<float *>(s_taps + (2 * radius + 1));          // 4 * MS_MAXWIN floats
+    __shared__ int s_lo[2];
     for (int i = threadIdx.x; i < 2 * radius + 1; i += blockDim.x) s_taps[i] = taps[i];
     const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
-    if (threadIdx.x == 0) {
-        int lo = 0, hi = n_notes;      // largest note with short_base(note) <= g0
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (short_base(sample_off, mid) <= g0) lo = mid; else hi = mid;
-        }
-        s_lo = lo;
+    if (threadIdx.x < WAVE) {                               // largest note with short_base(note) <= g, first wave cooperatively
+        auto key = [&](int k) { return short_base(sample_off, k); };
+        int64_t gl = g0 + blockDim.x - 1;
+        if (gl > total_short - 1) gl = total_short - 1;
+        const int a = wave_find(n_notes, g0, (int)threadIdx.x, key);
+        const int b = wave_find(n_notes, gl, (int)threadIdx.x, key);
+        if (threadIdx.x == 0) { s_lo[0] = a; s_lo[1] = b; }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t g = g0 + threadIdx.x;
-    int note = s_lo;
-    while (note + 1 < n_notes && short_base(sample_off, note + 1) <= g) ++note;
-    const int64_t q = g - short_base(sample_off, note);
-    const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
-    const int64_t ns = (n + MASK_DS - 1) / MASK_DS;
-    const bool live = g < total_short && q < ns;
-    const float *m = mask + base;
+    const int n_lo = __builtin_amdgcn_readfirstlane(s_lo[0]), n_hi = __builtin_amdgcn_readfirstlane(s_lo[1]);
 
-    // wave-level staging: valid when every lane of the wave sits in the same note
-    const int note0 = __shfl(note, 0, WAVE);
-    const int64_t q0 = __shfl((long long)q, 0, WAVE);
-    const bool same = __all(note == note0) && (2 * radius + WAVE <= MS_MAXWIN);
-    if (same) {
-        const int win = WAVE + 2 * radius;
-        for (int w = lane; w < win; w += WAVE) {
+    // Block-level staging: the 256 + 2r decimated mask values of the tile are fetched once for all four waves.
+    // A wave whose own 64 + 2r window is all zeros (ones) answers 0 (the running sum of the taps: the same
+    // additions in the same order) without the 2r+1-tap loop — voicing masks are 0/1 almost everywhere.
+    if (n_lo == n_hi && 2 * radius + (int)blockDim.x <= 4 * MS_MAXWIN) {
+        const int note = n_lo;
+        const int64_t sb = short_base(sample_off, note);
+        const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+        const int64_t ns = (n + MASK_DS - 1) / MASK_DS;
+        const int64_t q0 = g0 - sb;
+        const float *m = mask + base;
+        const int win = (int)blockDim.x + 2 * radius;
+        for (int w = threadIdx.x; w < win; w += blockDim.x) {
             const int64_t idx = reflect_index(q0 - radius + w, ns);
-            s_win[w] = ns > 0 ? m[MASK_DS * idx] : 0.f;
+            s_all[w] = ns > 0 ? m[MASK_DS * idx] : 0.f;
         }
-        wave_lds_sync();
+        __syncthreads();
+        const int64_t q = g - sb;
+        const bool live = g < total_short && q < ns;
+        const float *x0 = s_all + wv * WAVE;                 // this wave's window: 64 + 2r values
+        bool all0 = true, all1 = true;
+        for (int w = lane; w < WAVE + 2 * radius; w += WAVE) {
+            const float v = x0[w];
+            all0 &= v == 0.0f;
+            all1 &= v == 1.0f;
+        }
+        if (__all(all0)) {
+            if (live) short_s[g] = 0.0;
+            return;
+        }
+        if (__all(all1)) {
+            if (live) short_s[g] = tap_sum;
+            return;
+        }
         if (live) {
             double acc = 0.0;
-            const float *x = s_win + (int)(q - q0);
+            const float *x = x0 + lane;
             for (int j = 0; j <= 2 * radius; ++j) acc += s_taps[j] * (double)x[j];
             short_s[g] = acc;
         }
         return;
     }
-    if (!live) return;
+    __syncthreads();
+    if (g >= total_short) return;
+    int note = n_lo;
+    while (note + 1 < n_notes && short_base(sample_off, note + 1) <= g) ++note;
+    const int64_t q = g - short_base(sample_off, note);
+    const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+    const int64_t ns = (n + MASK_DS - 1) / MASK_DS;
+    if (q >= ns) return;
+    const float *m = mask + base;
     double acc = 0.0;
     for (int j = 0; j <= 2 * radius; ++j) acc += s_taps[j] * (double)m[MASK_DS * reflect_index(q + j - radius, ns)];
     short_s[g] = acc;
@@ -125,15 +149,11 @@ __global__ __launch_bounds__(256) void k_stem_gains(float *__restrict__ harm, fl
     __shared__ float s_red[4];
     const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x * SPT);
     int lo, hi;
-    if (threadIdx.x == 0) {
-        s_pair[0] = csr_find(sample_off, n_notes, g0);
+    {
         int64_t gl = g0 + (int64_t)blockDim.x * SPT - 1;
         if (gl > total_samples - 1) gl = total_samples - 1;
-        s_pair[1] = csr_find(sample_off, n_notes, gl);
+        block_note_range_last(sample_off, n_notes, g0, gl, s_pair, lo, hi);
     }
-    __syncthreads();
-    lo = __builtin_amdgcn_readfirstlane(s_pair[0]);
-    hi = __builtin_amdgcn_readfirstlane(s_pair[1]);
     const int64_t g = g0 + (int64_t)threadIdx.x * SPT;
 
     auto one = [&](int note, int64_t gi, float h, float u_in, float b_in, float &u_out, float &b_out) -> float {
@@ -470,14 +490,12 @@ __global__ __launch_bounds__(256) void k_apply_gain(float *__restrict__ harm, fl
 {
     __shared__ int s_pair[2];
     const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x * SPT);
-    if (threadIdx.x == 0) {
-        s_pair[0] = csr_find(sample_off, n_notes, g0);
+    int lo, hi;
+    {
         int64_t gl = g0 + (int64_t)blockDim.x * SPT - 1;
         if (gl > total_samples - 1) gl = total_samples - 1;
-        s_pair[1] = csr_find(sample_off, n_notes, gl);
+        block_note_range_last(sample_off, n_notes, g0, gl, s_pair, lo, hi);
     }
-    __syncthreads();
-    const int lo = __builtin_amdgcn_readfirstlane(s_pair[0]), hi = __builtin_amdgcn_readfirstlane(s_pair[1]);
     const int64_t g = g0 + (int64_t)threadIdx.x * SPT;
     if (g >= total_samples) return;
 
@@ -557,13 +575,13 @@ int launch_stem_peak(goofer_ctx *ctx, const float *harm, const float *uv, const 
 }
 
 int launch_mask_short(goofer_ctx *ctx, const float *mask, const int64_t *sample_off, int n_notes, int64_t total_samples,
-                      const double *d_taps, int radius, double *short_s, hipStream_t st)
+                      const double *d_taps, int radius, double tap_sum, double *short_s, hipStream_t st)
 {
     int64_t total_short = total_samples / MASK_DS + n_notes;
     if (total_short <= 0) return GOOFER_OK;
     hipLaunchKernelGGL(k_mask_short, dim3((unsigned)((total_short + 255) / 256)), dim3(256),
                        sizeof(double) * (2 * radius + 1) + sizeof(float) * 4 * MS_MAXWIN, st, mask, sample_off, n_notes, total_short,
-                       d_taps, radius, short_s);
+                       d_taps, radius, short_s, tap_sum);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
