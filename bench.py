@@ -37,6 +37,7 @@ def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int) ->
         "rfft_frames": fft, "rfft_frames_standalone": fft, "irfft_harm": fft, "irfft_breath": fft, "irfft_unvoiced": fft,
         "ola_harm": 4 * n_fft * F + 4 * N, "ola_breath": 4 * n_fft * F + 4 * N, "ola_unvoiced": 4 * n_fft * F + 4 * N,
         "ola3_gains": 3 * 4 * n_fft * F + 12 * N,     # three windowed-frame buffers in, three stems out
+        "irfft_ola3": 3 * 8 * B * F + 12 * N,         # three spectra in, three stems out (frames stay in LDS)
         "harm_shape": (16 * B + 4 * B) * F,          # S in+out, env in
         "noise_spectra": (16 * B + 4 * B) * F,       # two spectra out, env in (+4B when phi is injected)
         "gauss_env": 8 * B * F, "warp_env": 8 * B * F, "assemble": 12 * B * F + 12 * N,
@@ -50,7 +51,7 @@ def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int) ->
 
 STAGE_KERNEL = {"rfft_frames": "void k_rfft_frames<512>", "rfft_frames_standalone": "void k_rfft_frames<512>",
                 "irfft_harm": "void k_irfft_frames<512>", "harm_shape": "k_harm_shape", "noise_spectra": "k_noise_spectra",
-                "ola3_gains": "k_ola3_gains", "apply_gain": "k_apply_gain", "pulse_onsets": "k_pulse_onsets",
+                "ola3_gains": "k_ola3_gains", "irfft_ola3": "void k_irfft_ola3<512>", "apply_gain": "k_apply_gain", "pulse_onsets": "k_pulse_onsets",
                 "pulse_place": "k_pulse_place", "mask_short": "k_mask_short", "phase_inc": "k_phase_inc"}
 
 

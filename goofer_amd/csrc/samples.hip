@@ -123,6 +123,31 @@ __device__ __forceinline__ float smooth_mask_at(const double *__restrict__ ss, i
     return (float)(slope * (x - xj) + s0);
 }
 
+// 32-bit flavour for the hot kernels (note lengths are far below 2^31): same comparisons, half the integer work
+__device__ __forceinline__ double lin01_f32_i(int i, int num, double step)
+{
+    if (num <= 1) return 0.0;
+    if (i >= num - 1) return 1.0;
+    return (double)(float)((double)i * step);
+}
+
+__device__ __forceinline__ float smooth_mask_at32(const double *__restrict__ ss, int ns, int i, int n, double step_n, double step_s)
+{
+    if (ns <= 1) return (float)ss[0];
+    const double x = lin01_f32_i(i, n, step_n);
+    int j = (int)(x * (double)(ns - 1));
+    if (j > ns - 1) j = ns - 1;
+    if (j < 0) j = 0;
+    while (j + 1 <= ns - 1 && lin01_f32_i(j + 1, ns, step_s) <= x) ++j;
+    while (j > 0 && lin01_f32_i(j, ns, step_s) > x) --j;
+    if (j >= ns - 1) return (float)ss[ns - 1];
+    const double xj = lin01_f32_i(j, ns, step_s);
+    if (x == xj) return (float)ss[j];
+    const double s0 = ss[j], s1 = ss[j + 1];
+    const double slope = (s1 - s0) * fast_rcp(lin01_f32_i(j + 1, ns, step_s) - xj);
+    return (float)(slope * (x - xj) + s0);
+}
+
 // per-note constants of the mask upsampler: 1/(n-1) and 1/(ns-1) as true divisions (numpy's linspace step)
 __global__ void k_note_steps(const int64_t *__restrict__ sample_off, int n_notes, double *__restrict__ steps)
 {
@@ -327,34 +352,63 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
     fetch(fs, 0);
 
     int note = -1;
-    int64_t base = 0, n = 0, fbase = 0, T = 0, ns = 0, out_len = 0;
+    int64_t base = 0, fbase = 0;
+    int n = 0, T = 0, ns = 0, out_len = 0;
     float mag = 1.f, g_b = 0.f, g_u = 0.f, pk = 0.f;
     double step_n = 0.0, step_s = 0.0;
     const double *ss = nullptr;
 
+    // per-lane constants of the output stage for its samples j = lane + 64 u of a hop: how many earlier frames
+    // cover position j, and the summed squared window when all of them exist (interior hops)
+    constexpr int SLOTS = 8;                                  // hop <= 512; larger hops recompute per sample
+    int back_u[SLOTS];
+    float ws_u[SLOTS];
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const int j = lane + WAVE * u;
+        back_u[u] = 0;
+        ws_u[u] = 0.f;
+        if (j < hop) {
+            const int back = (NF - 1 - j) / hop;
+            back_u[u] = back;
+            float ws = 0.f;
+            for (int q = back; q >= 0; --q) {                 // ascending frame order = descending offset
+                const float w = win[j + q * hop];
+                ws += w * w;
+            }
+            ws_u[u] = ws;
+        }
+    }
+
     // finished hop h of the current note -> gains -> stems; also used for the flush hops and the zero tail
-    auto emit = [&](int64_t h) {
-        for (int j = lane; j < hop; j += WAVE) {
-            const int64_t p = h * hop + j;
-            const int64_t i = p - M;
+    auto emit = [&](int h) {
+        const int p0 = h * hop - M;                           // output index of the hop's first sample
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            const int j = lane + WAVE * u;
+            if (j >= hop) break;
+            const int i = p0 + j;
             if (i < 0 || i >= n) continue;
             float vh = 0.f, vu = 0.f, vb = 0.f;
             if (i < out_len) {
-                int64_t lo = p - NF + 1;
-                lo = lo <= 0 ? 0 : (lo + hop - 1) / hop;
-                int64_t hi = p / hop;
-                if (hi > T - 1) hi = T - 1;
-                float ws = 0.f;
-                for (int64_t fr = lo; fr <= hi; ++fr) {
-                    const float w = win[(int)(p - fr * hop)];
-                    ws += w * w;
+                const int back = back_u[u];
+                float ws;
+                if (h - back >= 0 && h <= T - 1) {
+                    ws = ws_u[u];
+                } else {
+                    const int lo = h - back < 0 ? 0 : h - back, hi = h > T - 1 ? T - 1 : h;
+                    ws = 0.f;
+                    for (int fr = lo; fr <= hi; ++fr) {
+                        const float w = win[j + (h - fr) * hop];
+                        ws += w * w;
+                    }
                 }
-                const int q = (int)(p & (NF - 1));
+                const int q = (h * hop + j) & (NF - 1);
                 vh = ring[q]; vu = ring[NF + q]; vb = ring[2 * NF + q];
                 if (ws > 1e-9f) { vh /= ws; vu /= ws; vb /= ws; }
                 vh = vh / mag;
             }
-            const float ms = smooth_mask_at(ss, ns, i, n, step_n, step_s);
+            const float ms = smooth_mask_at32(ss, ns, i, n, step_n, step_s);
             vb = (vb * ms) * g_b;
             vu = (vu * (1.0f - ms)) * g_u;
             harm[base + i] = vh;
@@ -363,6 +417,34 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
             pk = fmaxf(pk, fabsf((vh + vu) + vb));
         }
     };
+    auto emit_any = [&](int h) {                              // hops wider than the cached slots
+        for (int j = lane; j < hop; j += WAVE) {
+            const int i = h * hop + j - M;
+            if (i < 0 || i >= n) continue;
+            float vh = 0.f, vu = 0.f, vb = 0.f;
+            if (i < out_len) {
+                const int back = (NF - 1 - j) / hop;
+                const int lo = h - back < 0 ? 0 : h - back, hi = h > T - 1 ? T - 1 : h;
+                float ws = 0.f;
+                for (int fr = lo; fr <= hi; ++fr) {
+                    const float w = win[j + (h - fr) * hop];
+                    ws += w * w;
+                }
+                const int q = (h * hop + j) & (NF - 1);
+                vh = ring[q]; vu = ring[NF + q]; vb = ring[2 * NF + q];
+                if (ws > 1e-9f) { vh /= ws; vu /= ws; vb /= ws; }
+                vh = vh / mag;
+            }
+            const float ms = smooth_mask_at32(ss, ns, i, n, step_n, step_s);
+            vb = (vb * ms) * g_b;
+            vu = (vu * (1.0f - ms)) * g_u;
+            harm[base + i] = vh;
+            uv[base + i] = vu;
+            bre[base + i] = vb;
+            pk = fmaxf(pk, fabsf((vh + vu) + vb));
+        }
+    };
+    const bool slots_ok = hop <= WAVE * SLOTS;
 
     for (int64_t f = fs; f < f1; ++f) {
         const int nt = frame_note[f];
@@ -374,11 +456,11 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
             note = nt;
             pk = 0.f;
             base = sample_off[note];
-            n = sample_off[note + 1] - base;
+            n = (int)(sample_off[note + 1] - base);
             fbase = frame_off[note];
-            T = frame_off[note + 1] - fbase;
+            T = (int)(frame_off[note + 1] - fbase);
             ns = (n + MASK_DS - 1) / MASK_DS;
-            out_len = (int64_t)hop * (T - 1);
+            out_len = hop * (T - 1);
             mag = note_mag[note];
             g_b = params[note].breath_strength;
             g_u = params[note].uv_strength;
@@ -386,7 +468,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
             step_s = steps[2 * note + 1];
             ss = short_s + short_base(sample_off, note);
         }
-        const int64_t t = f - fbase;
+        const int t = (int)(f - fbase);
 #pragma unroll
         for (int stem = 0; stem < 3; ++stem) {
             float2 v[R];
@@ -406,7 +488,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
             else if (f + 1 < f1) fetch(f + 1, 0);
             wave_fft<M>(v, buf, tw, lane);
             float *rg = ring + stem * NF;
-            const int shift = (int)((t * hop) & (NF - 1));
+            const int shift = (t * hop) & (NF - 1);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int m = lane + WAVE * r;
@@ -424,12 +506,12 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
             wave_lds_sync();
         }
         if (f >= f0) {
-            emit(t);
+            if (slots_ok) emit(t); else emit_any(t);
             if (t == T - 1) {
-                const int64_t h_last = (out_len + M - 1) / hop;   // last hop holding a sample below out_len
-                for (int64_t h = T; h <= h_last; ++h) emit(h);
-                // zero-filled tail [out_len, n) not covered by the hops above
-                for (int64_t h = h_last + 1; h * hop - M < n; ++h) emit(h);
+                // the hops behind the last frame (up to the one holding sample out_len - 1), then the zero-filled tail
+                for (int h = T; h * hop - M < n; ++h) {
+                    if (slots_ok) emit(h); else emit_any(h);
+                }
             }
         }
         wave_lds_sync();
