@@ -162,36 +162,13 @@ __device__ __forceinline__ double mask_src(const float *__restrict__ m, const go
 __device__ __forceinline__ double mask_stage1(const float *__restrict__ m, const goofer_note_plan &p, int64_t q)
 {
     if (q < p.n_pre) return mask_src(m, p, p.s_pre + q);
-    int64_t k = q - p.n_pre;
-    if (p.tail_len < p.want_samples) k = k % p.tail_len;
-    return mask_src(m, p, p.s_tail + k);
+    uint32_t k = (uint32_t)(q - p.n_pre);                    // lengths are int32 in the plan: 32-bit modulo, not the 64-bit emulation
+    if (p.tail_len < p.want_samples) k = k % (uint32_t)p.tail_len;
+    return mask_src(m, p, p.s_tail + (int64_t)k);
 }
 
-__global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a, int64_t total_samples)
+__device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, const goofer_note_plan &p, int64_t g)
 {
-    __shared__ int s_pair[2];
-    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
-    if (threadIdx.x == 0) {
-        // notes own [out_sample_off, out_sample_off + n_out): find by binary search over the plan array
-        auto find = [&](int64_t g) {
-            int lo = 0, hi = a.n_notes;
-            while (hi - lo > 1) {
-                int mid = (lo + hi) >> 1;
-                if (a.notes[mid].out_sample_off <= g) lo = mid; else hi = mid;
-            }
-            return lo;
-        };
-        s_pair[0] = find(g0);
-        int64_t gl = g0 + blockDim.x - 1;
-        if (gl > total_samples - 1) gl = total_samples - 1;
-        s_pair[1] = find(gl);
-    }
-    __syncthreads();
-    const int64_t g = g0 + threadIdx.x;
-    if (g >= total_samples) return;
-    int note = s_pair[0];
-    while (note + 1 < a.n_notes && a.notes[note + 1].out_sample_off <= g) ++note;
-    const goofer_note_plan p = a.notes[note];
     const int64_t i = g - p.out_sample_off;
     const float *m = a.mask_src + p.src_sample_off;
 
@@ -223,7 +200,7 @@ __global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a
     if (p.n_bend == 1) {
         midi = semi(0);
     } else {
-        int64_t j = (int64_t)floor(tsec / p.tick_dt);
+        int64_t j = (int64_t)(tsec * fast_rcp(p.tick_dt));   // estimate; the two loops below settle it on the true tick grid
         if (j > p.n_bend - 1) j = p.n_bend - 1;
         while (j + 1 <= p.n_bend - 1 && (double)(j + 1) * p.tick_dt <= tsec) ++j;
         while (j > 0 && (double)j * p.tick_dt > tsec) --j;
@@ -253,6 +230,33 @@ __global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a
         }
     }
     a.f0_out[g] = (float)f0;
+}
+
+
+__global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a, int64_t total_samples)
+{
+    __shared__ int s_pair[2];
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    if (threadIdx.x < WAVE) {
+        // notes own [out_sample_off, out_sample_off + n_out): first wave searches the plan array cooperatively
+        auto key = [&](int k) { return a.notes[k].out_sample_off; };
+        int64_t gl = g0 + blockDim.x - 1;
+        if (gl > total_samples - 1) gl = total_samples - 1;
+        const int lo = wave_find(a.n_notes, g0, (int)threadIdx.x, key);
+        const int hi = wave_find(a.n_notes, gl, (int)threadIdx.x, key);
+        if (threadIdx.x == 0) { s_pair[0] = lo; s_pair[1] = hi; }
+    }
+    __syncthreads();
+    const int64_t g = g0 + threadIdx.x;
+    if (g >= total_samples) return;
+    const int n_lo = __builtin_amdgcn_readfirstlane(s_pair[0]), n_hi = __builtin_amdgcn_readfirstlane(s_pair[1]);
+    if (n_lo == n_hi) {
+        sample_assemble_one(a, a.notes[n_lo], g);            // uniform note: the 300-byte plan comes in through scalar loads
+    } else {
+        int note = n_lo;
+        while (note + 1 < a.n_notes && a.notes[note + 1].out_sample_off <= g) ++note;
+        sample_assemble_one(a, a.notes[note], g);
+    }
 }
 
 // vocal fry part 1b: frames under the fry mask get their bin axis squeezed by 1 - 0.08 w   SillySampler.py:966-994

@@ -138,13 +138,22 @@ __device__ __forceinline__ float smooth_mask_at32(const double *__restrict__ ss,
     int j = (int)(x * (double)(ns - 1));
     if (j > ns - 1) j = ns - 1;
     if (j < 0) j = 0;
-    while (j + 1 <= ns - 1 && lin01_f32_i(j + 1, ns, step_s) <= x) ++j;
-    while (j > 0 && lin01_f32_i(j, ns, step_s) > x) --j;
+    // the estimate is within one knot of the answer (both grids are fp32 roundings of k / (num - 1)): one step
+    // either way replaces the search loops of smooth_mask_at
+    double xj = lin01_f32_i(j, ns, step_s), xn = lin01_f32_i(j + 1, ns, step_s);
+    if (j + 1 <= ns - 1 && xn <= x) {
+        ++j;
+        xj = xn;
+        xn = lin01_f32_i(j + 1, ns, step_s);
+    } else if (j > 0 && xj > x) {
+        --j;
+        xn = xj;
+        xj = lin01_f32_i(j, ns, step_s);
+    }
     if (j >= ns - 1) return (float)ss[ns - 1];
-    const double xj = lin01_f32_i(j, ns, step_s);
     if (x == xj) return (float)ss[j];
     const double s0 = ss[j], s1 = ss[j + 1];
-    const double slope = (s1 - s0) * fast_rcp(lin01_f32_i(j + 1, ns, step_s) - xj);
+    const double slope = (s1 - s0) * fast_rcp(xn - xj);
     return (float)(slope * (x - xj) + s0);
 }
 
