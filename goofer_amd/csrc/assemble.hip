@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
 __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64_t total_out_rows, const int *__restrict__ row_note)
 {
     const int B = a.n_bins;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // uniform row: scalar plan / tap loads
     const int64_t orow = (int64_t)blockIdx.x * A_ROWS + wave;
     if (orow >= total_out_rows) return;
     const int note = row_note[orow];
@@ -121,12 +121,16 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
     double sv[4];
     bool on[4];
     const float nyq = (float)((double)a.sr * 0.5);
-    const float sig[4] = {100.0f, 200.0f, 350.0f, 500.0f};
+    // 1/sigma and -0.5*log2(e): the bell exp(-0.5 ((f - F)/sigma)^2) through the hardware exp2 (<= 1e-6 relative on
+    // the gain where the bell is not negligible) instead of an IEEE division and libm expf per bin and formant
+    const float isig[4] = {1.0f / 100.0f, 1.0f / 200.0f, 1.0f / 350.0f, 1.0f / 500.0f};
+    float gk[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         sv[k] = p.fst[k];
         Fk[k] = a.fst_tracks[(p.env_off + t) * 4 + k];
         on[k] = !(fabs(sv[k]) < 1e-6) && isfinite(Fk[k]) && !(Fk[k] <= 50.0f) && !(Fk[k] >= nyq);
+        gk[k] = (float)((1.0 + sv[k]) - 1.0);                // python-float (gain - 1.0), weak-cast to fp32
     }
     const double fstep = ((double)a.sr / 2.0) / (double)(B - 1);
     float *out = a.env_out + orow * (int64_t)a.ld;
@@ -140,10 +144,9 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (on[k]) {
-                float z = (fb - Fk[k]) / sig[k];
-                float wt = expf(-0.5f * (z * z));
-                float gk = (float)((1.0 + sv[k]) - 1.0);            // python-float (gain - 1.0), weak-cast to fp32
-                gain *= 1.0f + gk * wt;
+                const float z = (fb - Fk[k]) * isig[k];
+                const float wt = __builtin_amdgcn_exp2f((z * z) * -0.72134752044448170368f);
+                gain *= 1.0f + gk[k] * wt;
             }
         }
         out[b] = p.env_f64 ? (float)(v * (double)gain) : ((float)v) * gain;
@@ -191,12 +194,12 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
     }
 
     // pitch curve: bend cents/100 + MIDI (+t), ticks of 60/(tempo*96) s, clamped linear interpolation
-    const float *bend = a.bend + p.bend_off;
+    const double *bend = a.bend + p.bend_off;                // MIDI semitones per tick, built on the host like the reference
     double tsec = (double)i / (double)a.sr;
     const double t_last = (double)(p.n_bend - 1) * p.tick_dt;
     tsec = tsec < 0.0 ? 0.0 : (tsec > t_last ? t_last : tsec);
     double midi;
-    auto semi = [&](int64_t k) { return ((double)bend[k] / 100.0 + p.pitch_m) + p.pitch_t; };   // two adds, like the reference
+    auto semi = [&](int64_t k) { return bend[k]; };
     if (p.n_bend == 1) {
         midi = semi(0);
     } else {
@@ -209,7 +212,7 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
         } else {
             double y0 = semi(j), y1 = semi(j + 1);
             double x0 = (double)j * p.tick_dt, x1 = (double)(j + 1) * p.tick_dt;
-            midi = tsec == x0 ? y0 : ((y1 - y0) / (x1 - x0)) * (tsec - x0) + y0;
+            midi = tsec == x0 ? y0 : ((y1 - y0) * fast_rcp(x1 - x0)) * (tsec - x0) + y0;
         }
     }
     const double hz = 440.0 * exp2((midi - 69.0) / 12.0);

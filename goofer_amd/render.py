@@ -260,7 +260,10 @@ class Renderer:
             q["pd_on"], q["pd_base"] = int(req.pitch_dyn != 0.0), req.pitch_m + ((req.flags.get("t", 0) or 0) / 100.0)
             knots_cat.append(np.ascontiguousarray(src.knots.T))
             mask_cat.append(src.mask[:src.ylen])
-            bend_cat.append(req.bend)
+            semis = req.bend.astype(np.float64) / 100.0 + req.pitch_m      # SillySampler.py:838-846
+            if tc:
+                semis = semis + (tc / 100.0)
+            bend_cat.append(semis)
             tapi_cat.append(p.tap_idx)
             tapw_cat.append(p.tap_w)
             fst_cat.append(p.fst_tracks)
@@ -287,7 +290,7 @@ class Renderer:
             tap_idx=ctx.tensor(np.concatenate(tapi_cat).astype(np.int32)), tap_w=ctx.tensor(np.concatenate(tapw_cat)),
             fst_tracks=ctx.tensor(np.concatenate(fst_cat).astype(np.float32)),
             mask_src=ctx.tensor(np.concatenate(mask_cat).astype(np.float32)),
-            bend=ctx.tensor(np.concatenate(bend_cat).astype(np.float32)),
+            bend=ctx.tensor(np.concatenate(bend_cat).astype(np.float64)),
         )
         env = ctx.rows(t_off, B)
         f0 = torch.empty(o_off, dtype=torch.float32, device=ctx.device)

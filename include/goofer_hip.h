@@ -106,7 +106,7 @@ typedef struct {
     int64_t src_sample_off;  /* first element of the note's source voicing mask                           */
     int64_t out_sample_off;  /* first output sample                                                       */
     int64_t ylen;            /* source length in samples                                                  */
-    int64_t bend_off;        /* first element of the note's pitch-bend array (cents, fp32)                */
+    int64_t bend_off;        /* first element of the note's pitch curve in goofer_assembly.bend           */
     double es_amount;        /* sharpen amount 5*|es|                                                     */
     double vel_factor;       /* 2^(1 - velocity/100)                                                      */
     double pitch_m;          /* MIDI note number                                                          */
@@ -150,7 +150,8 @@ typedef struct {
     const double *tap_w;             /* [total_out_rows x 4]                                               */
     const float *fst_tracks;         /* [total_out_rows x 4] sanitised + smoothed F1..F4 (Hz)              */
     const float *mask_src;           /* source voicing masks, concatenated                                 */
-    const float *bend;               /* pitch-bend cents, concatenated                                     */
+    const double *bend;              /* pitch curve per tick in MIDI semitones, concatenated: bend/100 + pitch_m */
+                                     /* (+ t/100), fp64 like the reference builds it (SillySampler.py:838-846)    */
     float *edit_rows;                /* scratch [total_edit_rows x ld] (NULL: handle-owned)                */
     float *env_out;                  /* [total_out_rows x ld] assembled envelope                           */
     float *f0_out, *mask_out;        /* [total_samples]                                                    */
