@@ -50,16 +50,20 @@ def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int) ->
 
 
 STAGE_KERNEL = {"rfft_frames": "void k_rfft_frames<512>", "rfft_frames_standalone": "void k_rfft_frames<512>",
-                "irfft_harm": "void k_irfft_frames<512>", "harm_shape": "k_harm_shape", "noise_spectra": "k_noise_spectra",
-                "ola3_gains": "k_ola3_gains", "irfft_ola3": "void k_irfft_ola3<512>", "apply_gain": "k_apply_gain", "pulse_onsets": "k_pulse_onsets",
-                "pulse_place": "k_pulse_place", "mask_short": "k_mask_short", "phase_inc": "k_phase_inc"}
+                "irfft_harm": "void k_irfft_frames<512>", "harm_shape": "void k_harm_shape<9>",
+                "noise_spectra": "void k_noise_spectra<9>", "ola3_gains": "k_ola3_gains", "irfft_ola3": "void k_irfft_ola3<512>",
+                "apply_gain": "k_apply_gain", "pulse_onsets": "void k_pulse_onsets<false>", "pulse_place": "k_pulse_place",
+                "mask_short": "k_mask_short", "phase_inc": "k_phase_inc", "setup_maps": "k_scale_f0"}
+
+
+PMC_FILE = "r01c_pmc_traffic.json"      # committed rocprofv3 counter passes of this same command (scripts/collect_profiles.sh)
 
 
 def pmc_traffic(stage, frames):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json), with the
     gfx950 FETCH_SIZE correction; None when no matching measurement exists for this workload size."""
     try:
-        d = json.load(open(os.path.join(HERE, "profiles", "r01_pmc_traffic.json")))
+        d = json.load(open(os.path.join(HERE, "profiles", PMC_FILE)))
         k = d["kernels"][STAGE_KERNEL[stage]]
         if d["_meta"]["frames"] != frames:
             return None

@@ -1,0 +1,35 @@
+"""Fold the rocprofv3 outputs of scripts/collect_profiles.sh into the small files committed under profiles/:
+<tag>_bench.json, <tag>_kernel_stats.csv, <tag>_pmc_traffic.json (per-kernel mean FETCH_SIZE / WRITE_SIZE in KB)."""
+import csv, glob, json, os, shutil, sys, collections
+
+out, tag = sys.argv[1], sys.argv[2]
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "profiles_" + tag)
+os.makedirs(dst, exist_ok=True)
+line = open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1]
+bench = json.loads(line)
+json.dump(bench, open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
+stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+
+
+def short(name):
+    return name.split("(")[0].strip()
+
+
+res = collections.defaultdict(dict)
+for which, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    vals = collections.defaultdict(list)
+    for fn in glob.glob(os.path.join(out, which, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(fn)):
+            if row["Counter_Name"] == key:
+                vals[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    for k, v in vals.items():
+        res[k][key + "_KB"] = sum(v) / len(v)
+        res[k]["launches_sampled"] = len(v)
+meta = {"workload": bench["config"]["workload"], "frames": bench["config"]["frames_per_gpu"], "samples": bench["config"]["samples_per_gpu"],
+        "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (only --kernel-trace beside them); per-launch means in KB",
+        "correction": "gfx950: FETCH_SIZE reports half of a coalesced streaming read (MI355X_MICROARCH.md, HBM) -> bytes = (2*FETCH + WRITE)*1024"}
+json.dump({"_meta": meta, "kernels": {k: v for k, v in sorted(res.items()) if k.startswith(("k_", "void k_"))}},
+          open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
+print("wrote", os.listdir(dst))
