@@ -210,16 +210,45 @@ __global__ __launch_bounds__(256) void k_pulse_onsets(const double *__restrict__
             phase = ps[OB - 1];
             if (__any((phase >= next_k) || chunk_neg)) {     // wave-uniform: every lane holds the same phase
                 const int32_t i0 = (int32_t)c0 + g * OB;
-#pragma unroll
-                for (int j = 0; j < OB; ++j) {
-                    while (__any(ps[j] >= next_k)) {
-                        if (cnt < cap) {
-                            if (lane == 0) out[cnt] = i0 + j;
-                        } else if (lane == 0) {
-                            *overflow = 1;
+                auto record = [&](int j) {
+                    if (cnt < cap) {
+                        if (lane == 0) out[cnt] = i0 + j;
+                    } else if (lane == 0) {
+                        *overflow = 1;
+                    }
+                    ++cnt;
+                    next_k += 1.0;
+                };
+                if (!chunk_neg) {
+                    // increments >= 0: the partial sums are monotone, so the first sample that reaches next_k is found
+                    // by a 4-step bisection of wave-uniform compares (the reference's while loop records the same
+                    // sample again while the phase still covers the next integer)
+                    static_assert(OB == 16, "bisection below is written for 16-sample walk blocks");
+                    while (__any(phase >= next_k)) {
+                        int j;
+                        if (__any(ps[7] >= next_k)) {
+                            if (__any(ps[3] >= next_k)) {
+                                if (__any(ps[1] >= next_k)) j = __any(ps[0] >= next_k) ? 0 : 1;
+                                else j = __any(ps[2] >= next_k) ? 2 : 3;
+                            } else {
+                                if (__any(ps[5] >= next_k)) j = __any(ps[4] >= next_k) ? 4 : 5;
+                                else j = __any(ps[6] >= next_k) ? 6 : 7;
+                            }
+                        } else {
+                            if (__any(ps[11] >= next_k)) {
+                                if (__any(ps[9] >= next_k)) j = __any(ps[8] >= next_k) ? 8 : 9;
+                                else j = __any(ps[10] >= next_k) ? 10 : 11;
+                            } else {
+                                if (__any(ps[13] >= next_k)) j = __any(ps[12] >= next_k) ? 12 : 13;
+                                else j = __any(ps[14] >= next_k) ? 14 : 15;
+                            }
                         }
-                        ++cnt;
-                        next_k += 1.0;
+                        record(j);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < OB; ++j) {
+                        while (__any(ps[j] >= next_k)) record(j);
                     }
                 }
             }
