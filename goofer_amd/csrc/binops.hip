@@ -323,6 +323,9 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
     }
     const uint64_t key = seed ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
     uint4 rnd = make_uint4(0, 0, 0, 0);
+    float t175[15];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) t175[j] = (float)taps175[j];
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
         const int k = lane + WAVE * i;
@@ -341,14 +344,18 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
         }
         float e;
         if (row_src) {
-            double acc = 0.0;
+            // sigma-1.75 blur of the envelope row (GOOFER.py:993): the reference accumulates in fp64 and the product with
+            // the unit phasor is rounded to complex64; fp32 FMAs in tap order stay within ~2e-7 relative
+            float acc;
             if (k >= 7 && k + 7 < n_bins) {
+                acc = t175[0] * ra[k - 7];
 #pragma unroll
-                for (int j = 0; j < 15; ++j) acc += taps175[j] * (double)ra[k + j - 7];
+                for (int j = 1; j < 15; ++j) acc = fmaf(t175[j], ra[k + j - 7], acc);
             } else {
-                for (int j = 0; j < 15; ++j) acc += taps175[j] * (double)ra[reflect_index(k + j - 7, n_bins)];
+                acc = t175[0] * ra[reflect_index(k - 7, n_bins)];
+                for (int j = 1; j < 15; ++j) acc = fmaf(t175[j], ra[reflect_index(k + j - 7, n_bins)], acc);
             }
-            e = (float)acc;
+            e = acc;
         } else {
             e = ev[i];
         }

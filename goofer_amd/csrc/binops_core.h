@@ -243,7 +243,8 @@ __device__ __forceinline__ float2 blur5(const float2 *r, int k, int n_bins, cons
     return make_float2(re, im);
 }
 
-// Philox-4x32-10 keyed by (seed), counter (frame, slot): four 32-bit words per block.  The phase of bin k comes
+// Philox-4x32 with 7 rounds (the Crush-resistant minimum of the Random123 paper; its 32-bit multiplies run at quarter
+// rate here and only feed noise phases) keyed by (seed), counter (frame, slot): four 32-bit words per block.  The phase of bin k comes
 // from slot (k & 63) + 64 * (k >> 8), word (k >> 6) & 3, so a lane that owns bins lane, lane+64, ... needs one
 // block per four of its bins; philox_u32 is the same mapping evaluated for a single bin.
 __device__ __forceinline__ uint4 philox_4x32(uint64_t seed, uint64_t ctr_hi, uint32_t ctr_lo)
@@ -251,7 +252,7 @@ __device__ __forceinline__ uint4 philox_4x32(uint64_t seed, uint64_t ctr_hi, uin
     uint32_t c0 = ctr_lo, c1 = (uint32_t)ctr_hi, c2 = (uint32_t)(ctr_hi >> 32), c3 = 0x9E3779B9u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < 7; ++i) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
         uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;

@@ -197,17 +197,19 @@ __global__ __launch_bounds__(256, 3) void k_noise_frames(const float *__restrict
 #pragma unroll
         for (int r = 0; r < C::PER; ++r) {
             int b = lane + WAVE * r;
-            double acc = 0.0;
+            float acc = 0.f;                                   // fp32 FMAs in tap order, like k_noise_spectra
             if (b < B) {
                 if (b >= 7 && b + 7 < B) {
+                    acc = (float)t15[0] * ra[b - 7];
 #pragma unroll
-                    for (int j = 0; j < 15; ++j) acc += t15[j] * (double)ra[b + j - 7];
+                    for (int j = 1; j < 15; ++j) acc = fmaf((float)t15[j], ra[b + j - 7], acc);
                 } else {
+                    acc = (float)t15[0] * ra[reflect_index(b - 7, B)];
 #pragma unroll
-                    for (int j = 0; j < 15; ++j) acc += t15[j] * (double)ra[reflect_index(b + j - 7, B)];
+                    for (int j = 1; j < 15; ++j) acc = fmaf((float)t15[j], ra[reflect_index(b + j - 7, B)], acc);
                 }
             }
-            en[r] = (float)acc;
+            en[r] = acc;
         }
         wave_lds_sync();                                       // row dead, fbuf free
 
