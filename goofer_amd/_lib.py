@@ -84,7 +84,7 @@ class Batch(C.Structure):
         ("total_frames", C.c_int64), ("total_samples", C.c_int64), ("total_env_rows", C.c_int64),
         ("sample_off", C.c_void_p), ("frame_off", C.c_void_p), ("env_off", C.c_void_p),
         ("env", C.c_void_p), ("formants", C.c_void_p), ("f0", C.c_void_p), ("mask", C.c_void_p),
-        ("phi", C.c_void_p), ("params", C.c_void_p), ("seed", C.c_uint64),
+        ("phi", C.c_void_p), ("env_noise", C.c_void_p), ("params", C.c_void_p), ("seed", C.c_uint64),
         ("transition_sigma", C.c_float), ("vol_jitter_speed", C.c_float),
         ("noise_f0", C.c_void_p), ("noise_vol_h", C.c_void_p), ("noise_vol_b", C.c_void_p),
         ("f0_jitter_sigma", C.c_float), ("vol_jitter_sigma", C.c_float),
@@ -123,6 +123,7 @@ EXPORTS = {
     "goofer_debug_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "goofer_debug_fetch": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "goofer_sizeof": (C.c_int, [C.c_int]),
+    "goofer_stretch_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "goofer_onepole_cascade": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "goofer_post_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "goofer_assemble_batch": (C.c_int, [C.c_void_p, C.POINTER(Assembly), C.c_void_p]),

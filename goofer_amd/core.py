@@ -255,6 +255,66 @@ def subharm_from_kwargs(kw):
             "delay": kw.get("subharm_vibrato_delay", 0.1)}
 
 
+def _stretch(c, x, a, b, factor):
+    """concat(x[:a], stretch_feature(x[a:b], factor), x[b:]) along axis 0 of a device array (GOOFER.py:1019-1057)."""
+    n = x.shape[0]
+    a, b, _ = slice(a, b).indices(n)
+    b = max(a, b)
+    if b - a == 0:
+        raise ValueError("x cannot be empty")                   # what gf.interp1d raises for an empty stretch region
+    mid = c.stretch_rows(x[a:b], int((b - a) * factor))
+    if x.dim() == 1:
+        return torch.cat([x[:a], mid, x[b:]])
+    out = c.rows(a + mid.shape[0] + (n - b), x.shape[1])
+    out[:a].copy_(x[:a])
+    out[a:a + mid.shape[0]].copy_(mid)
+    out[a + mid.shape[0]:].copy_(x[b:])
+    return out
+
+
+def _synthesize_stretched(c, d_env, f0, mask, F, params, sr, hop, phi, seed, kw):
+    """gf.synthesize with stretch_factor != 1 (GOOFER.py:1019-1067): the warped envelope and the blurred noise envelope
+    are made first, then both, f0 (already scaled by pitch_shift) and the mask are resampled along time, and the
+    synth runs on the stretched features with its in-kernel warps and blur switched off."""
+    factor = float(kw["stretch_factor"])
+    f_shift = [kw.get("F%d_shift" % i, 1.0) for i in (1, 2, 3, 4)]
+    fs = float(kw.get("formant_shift", 1.0))
+    env_n = c.gauss_bins(d_env, gaussian_taps(1.75))
+    env_h = d_env
+    if any(v != 1.0 for v in f_shift) or fs != 1.0:
+        env_h = c.warp_bins(d_env, c.tensor(F), f_shift if any(v != 1.0 for v in f_shift) else None, fs)
+    f0 = (f0 * np.float32(kw.get("pitch_shift", 1.0))).astype(np.float32) if kw.get("pitch_shift", 1.0) != 1.0 else f0
+    d_f0, d_mask = c.tensor(f0), c.tensor(mask)
+    s0, s1 = kw.get("start_sec"), kw.get("end_sec")
+    if s0 is not None and s1 is not None:
+        a, b = int(s0 * sr), int(s1 * sr)
+        fa, fb = int((s0 * sr) / hop), int((s1 * sr) / hop)
+    else:
+        a, b, fa, fb = 0, None, 0, None
+    d_f0, d_mask = _stretch(c, d_f0, a, b, factor), _stretch(c, d_mask, a, b, factor)
+    env_h, env_n = _stretch(c, env_h, fa, fb, factor), _stretch(c, env_n, fa, fb, factor)
+    n = int(d_f0.numel())
+    if n == 0:
+        z = np.zeros(0, dtype=np.float32)
+        return z, z.copy(), z.copy(), z.copy()
+    params = params.copy()
+    params["pitch_shift"], params["formant_shift"], params["f_shift"] = 1.0, 1.0, [1.0, 1.0, 1.0, 1.0]
+    d_phi = None
+    if phi is not None:
+        d_phi = c.rows_from(np.asarray(phi, dtype=np.float32).T)
+    if seed is None:
+        seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
+    noise_f0 = c.tensor(np.random.randn(n)) if kw.get("f0_jitter") else None
+    vib = bool(kw.get("volume_jitter") and kw.get("volume_vibrato"))
+    noise_vol = (c.tensor(np.random.randn(n)), c.tensor(np.random.randn(n))) if kw.get("volume_jitter") and not vib else None
+    out = c.synth_batch(env_h, [env_h.shape[0]], d_f0, d_mask, [n], params, formants=None, phi=d_phi, seed=seed,
+                        transition_sigma=float(kw.get("noise_transition_smoothness", 100)), want_mix=False,
+                        noise_f0=noise_f0, noise_vol=noise_vol, f0_jitter_speed=float(kw.get("f0_jitter_speed", 100)),
+                        vol_jitter_speed=float(kw.get("volume_jitter_speed", 150)), subharm=subharm_from_kwargs(kw),
+                        volume_vibrato=vib, env_noise=env_n)
+    return tuple(out[k].cpu().numpy() for k in ("rec", "harm", "uv", "bre"))
+
+
 def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=256, phi=None, seed=None, ctx=None, **kw):
     """gf.synthesize for one note on the GPU -> (reconstruct, harmonic, aper_uv, aper_bre), fp32.
 
@@ -264,8 +324,6 @@ def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=
     for k in _UNSUPPORTED:
         if kw.get(k):
             raise NotImplementedError(f"{k} is not on the device path yet (SURVEY.md §8 f)")
-    if kw.get("stretch_factor", 1.0) != 1.0:
-        raise NotImplementedError("stretch_factor != 1 is not on the device path yet")
     c = _ctx(sr, n_fft, hop_length, ctx)
     if isinstance(env_spec, dict) and env_spec.get("mode") == "knots":
         env_spec = decode_env_from_knots(env_spec, ctx=c)
@@ -282,6 +340,8 @@ def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=
     F = np.stack([_fit(fm[i], T_env) for i in (1, 2, 3, 4)], axis=1)           # [T_env, 4] fp64
     params = note_params_from_kwargs(1, **kw)
     d_env = c.rows_from(env.T)
+    if kw.get("stretch_factor", 1.0) != 1.0:
+        return _synthesize_stretched(c, d_env, f0, mask, F, params, sr, hop_length, phi, seed, kw)
     d_phi = None
     if phi is not None:
         d_phi = c.rows_from(np.asarray(phi, dtype=np.float32).T)

@@ -36,7 +36,7 @@ int launch_harm_shape(goofer_ctx *, float2 *, int, int64_t, const int *, const i
                       hipStream_t);
 int launch_noise_spectra(goofer_ctx *, float2 *, float2 *, int, int64_t, const int *, const int64_t *, const int64_t *,
                          const float *, const float *, const float *, const float *, int, const goofer_note_params *, uint64_t,
-                         const int64_t *, hipStream_t);
+                         const int64_t *, bool, hipStream_t);
 int launch_mask_short(goofer_ctx *, const float *, const int64_t *, int, int64_t, const double *, int, double, double *, hipStream_t);
 int launch_assemble(goofer_ctx *, const goofer_assembly *, int *, int *, hipStream_t);
 int launch_mag_rows(goofer_ctx *, const float2 *, int, int64_t, int, float *, int, hipStream_t);
@@ -75,6 +75,8 @@ int launch_dyn_gain(goofer_ctx *, const double *, const double *, const unsigned
 int launch_irfft_ola3(goofer_ctx *, const float2 *, const float2 *, const float2 *, int, int64_t, const int *, const int64_t *,
                       const int64_t *, int, const float *, const double *, double *, const goofer_note_params *, float *, float *, float *,
                       float *, hipStream_t);
+int launch_lerp_axis0(goofer_ctx *, const float *, int64_t, int64_t, float *, int64_t, int64_t, int, hipStream_t);
+int launch_lerp_1d(goofer_ctx *, const float *, int64_t, float *, int64_t, hipStream_t);
 int launch_stem_peak(goofer_ctx *, const float *, const float *, const float *, const int64_t *, int, int64_t, float *, hipStream_t);
 int launch_harm_frames(goofer_ctx *, const float *, const goofer_batch *, const float *, const int *, const int64_t *, float *, float *,
                        hipStream_t);
@@ -701,6 +703,15 @@ int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *asmb, void *st
     return launch_assemble(ctx, &a, map_edit, map_out, st);
 }
 
+int goofer_stretch_rows(goofer_ctx *ctx, const float *in, int64_t ld_in, int64_t rows_in, float *out, int64_t ld_out, int64_t rows_out,
+                        int n_cols, void *stream)
+{
+    if (!ctx) return GOOFER_EINVAL;
+    if (!in || !out) return goofer_fail(ctx, GOOFER_EINVAL, "null pointer");
+    if (n_cols == 1 && ld_in == 1 && ld_out == 1) return launch_lerp_1d(ctx, in, rows_in, out, rows_out, (hipStream_t)stream);
+    return launch_lerp_axis0(ctx, in, ld_in, rows_in, out, ld_out, rows_out, n_cols, (hipStream_t)stream);
+}
+
 int goofer_onepole_cascade(goofer_ctx *ctx, const float *src, float *dst, const float *f0, const goofer_onepole_job *jobs, int n_jobs,
                            void *stream)
 {
@@ -967,7 +978,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         ++stage;                                                     \
     } while (0)
 
-    const bool ola_one = ctx->ola_fused && !ctx->fused && (p.hop % 2 == 0);
+    const bool ola_one = ctx->ola_fused && !(ctx->fused && !b->env_noise) && (p.hop % 2 == 0);
     unsigned fb = (unsigned)((F + 255) / 256);
     MARK();   // 0: setup
     if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, st))) return rc;
@@ -1007,7 +1018,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
             return rc;
     }
     // spectra -> windowed time frames of the three stems
-    if (ctx->fused) {
+    if (ctx->fused && !b->env_noise) {
         MARK();   // 6: harm_frames = rFFT + warp + shape + irFFT (envelope stages 1, 2 folded in)
         if ((rc = launch_harm_frames(ctx, pulse, b, f0s, frame_note, row_src, frames, note_mag, st))) return rc;
         MARK();   // 7
@@ -1026,8 +1037,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         MARK();   // 8
         if (!ola_one && (rc = launch_irfft_frames(ctx, S_h, ldc, F, frames, st))) return rc;
         MARK();   // 9: aperiodic spectra
-        if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, b->env, b->phi,
-                                       ld, b->params, b->seed, row_src, st)))
+        if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
+                                       b->env_noise ? b->env_noise : b->env, b->phi, ld, b->params, b->seed, row_src,
+                                       b->env_noise != nullptr, st)))
             return rc;
         MARK();   // 10, 11
         if (!ola_one && (rc = launch_irfft_frames(ctx, S_br, ldc, F, frames_b, st))) return rc;

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
 
     float2 *ru = S_uv + f * (int64_t)ldc;
     float2 *rb = S_br + f * (int64_t)ldc;
-    if (row_src) {
+    if (row_src && taps175) {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
             const int k = lane + WAVE * i;
@@ -323,9 +323,10 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
     }
     const uint64_t key = seed ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
     uint4 rnd = make_uint4(0, 0, 0, 0);
+    const bool do_blur = row_src && taps175;                 // taps175 == nullptr: the rows are the noise envelope already
     float t175[15];
 #pragma unroll
-    for (int j = 0; j < 15; ++j) t175[j] = (float)taps175[j];
+    for (int j = 0; j < 15; ++j) t175[j] = do_blur ? (float)taps175[j] : 0.f;
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
         const int k = lane + WAVE * i;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
             s = __builtin_amdgcn_sinf(rev);
         }
         float e;
-        if (row_src) {
+        if (do_blur) {
             // sigma-1.75 blur of the envelope row (GOOFER.py:993): the reference accumulates in fp64 and the product with
             // the unit phasor is rounded to complex64; fp32 FMAs in tap order stay within ~2e-7 relative
             float acc;
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
 int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, int64_t total_frames, const int *frame_note,
                          const int64_t *frame_off, const int64_t *sample_off, const float *f0, const float *mask,
                          const float *env_noise, const float *phi, int ld, const goofer_note_params *params, uint64_t seed,
-                         const int64_t *row_src, hipStream_t st)
+                         const int64_t *row_src, bool preblurred, hipStream_t st)
 {
     if (total_frames <= 0) return GOOFER_OK;
     const goofer_plan_t &pl = ctx->plan;
@@ -389,7 +390,7 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
 #define NOISE_SPECTRA(IT)                                                                                                          \
     hipLaunchKernelGGL(k_noise_spectra<IT>, grid, dim3(256), lds, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,        \
                        sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins, pl.hop, \
-                       row_src, pl.blur175)
+                       row_src, preblurred ? (const double *)nullptr : pl.blur175)
     switch ((pl.n_bins + WAVE - 1) / WAVE) {
     case 5: NOISE_SPECTRA(5); break;
     case 9: NOISE_SPECTRA(9); break;

@@ -226,6 +226,17 @@ class Context:
         r.copy_(torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)))
         return r
 
+    def stretch_rows(self, x, rows_out: int):
+        """gf.stretch_feature along axis 0 (GOOFER.py:597-616): a 1-D fp32 tensor, or an ld-strided [rows, bins] view."""
+        if x.dim() == 1:
+            y = torch.empty(rows_out, dtype=torch.float32, device=self.device)
+            self._check(self.lib.goofer_stretch_rows(self.h, _ptr(x), 1, x.numel(), _ptr(y), 1, rows_out, 1, self._stream()))
+            return y
+        y = self.rows(rows_out, x.shape[1])
+        self._check(self.lib.goofer_stretch_rows(self.h, _ptr(x), x.stride(0), x.shape[0], _ptr(y), y.stride(0), rows_out, x.shape[1],
+                                                 self._stream()))
+        return y
+
     def onepole_cascade(self, x, f0, cutoff_factor: float, order: int = 4, btype: str = "lowpass", f0_mode: int = 0, lengths=None):
         """dynamic_butter_filter (SillySampler.py:95-174) on fp32 device signals: every note of ``lengths`` (default:
         the whole array as one note) is filtered with the same settings.  Returns a new tensor."""
@@ -264,7 +275,7 @@ class Context:
     def synth_batch(self, env, env_lengths, f0, mask, sample_lengths, params: np.ndarray, formants=None, phi=None,
                     seed: int = 0, transition_sigma: float = 100.0, want_rec=True, want_mix=True, offsets=None,
                     noise_f0=None, noise_vol=None, f0_jitter_speed: float = 100.0, vol_jitter_speed: float = 150.0,
-                    subharm=None, volume_vibrato: bool = False):
+                    subharm=None, volume_vibrato: bool = False, env_noise=None):
         """Run goofer_synth_batch.
 
         ``subharm`` = dict(semitones, vibrato, rate, depth, delay) switches the sub-harmonic pulse layer on for the
@@ -289,10 +300,13 @@ class Context:
             out["mix"] = torch.empty(N, dtype=torch.float32, device=self.device)
         if phi is not None:
             assert phi.shape == (F, nb) and phi.stride(0) == env.stride(0)
+        if env_noise is not None:                            # pre-blurred noise envelope rows (gf.synthesize's time stretch)
+            assert env_noise.shape == env.shape and env_noise.stride(0) == env.stride(0)
         b = _lib.Batch(n_notes=n, n_bins=nb, ld=env.stride(0), total_frames=F, total_samples=N, total_env_rows=R,
                        sample_off=d_s.data_ptr(), frame_off=d_f.data_ptr(), env_off=d_e.data_ptr(), env=env.data_ptr(),
                        formants=formants.data_ptr() if formants is not None else None, f0=f0.data_ptr(),
-                       mask=mask.data_ptr(), phi=phi.data_ptr() if phi is not None else None, params=d_par.data_ptr(),
+                       mask=mask.data_ptr(), phi=phi.data_ptr() if phi is not None else None,
+                       env_noise=env_noise.data_ptr() if env_noise is not None else None, params=d_par.data_ptr(),
                        seed=seed, transition_sigma=float(transition_sigma),
                        noise_f0=noise_f0.data_ptr() if noise_f0 is not None else None,
                        noise_vol_h=noise_vol[0].data_ptr() if noise_vol is not None else None,

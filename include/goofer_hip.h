@@ -72,6 +72,9 @@ typedef struct {
     const float *f0;            /* [total_samples] Hz, 0 where unvoiced                        */
     const float *mask;          /* [total_samples] voicing mask                                */
     const float *phi;           /* [total_frames x ld] random phases, or NULL: on-device Philox */
+    const float *env_noise;     /* [total_env_rows x ld] noise envelope (sigma-1.75 blur of env along bins,    */
+                                /* GOOFER.py:993) when the caller has it already — gf.synthesize's time stretch  */
+                                /* resamples it separately from the warped env — else NULL: blurred in-kernel    */
     const goofer_note_params *params;  /* [n_notes] */
     uint64_t seed;              /* Philox key when phi == NULL */
     float transition_sigma;     /* noise_transition_smoothness of this call (default 100; the 'sa'  */
@@ -276,6 +279,11 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *batch, void *stream)
  * rows, slicing + loop modes + velocity stretch as a 4-tap frame gather, formant-strength gain, per-sample
  * voicing mask and pitch curve (SillySampler.py:449-855).  Outputs feed goofer_synth_batch directly. */
 int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *assembly, void *stream);
+
+/* gf.stretch_feature (GOOFER.py:597-616): np.interp(linspace(0,1,rows_out), linspace(0,1,rows_in), column) along
+ * axis 0 of a [rows x n_cols] fp32 matrix with row strides ld_in / ld_out (n_cols = 1, ld = 1: a 1-D array). */
+int goofer_stretch_rows(goofer_ctx *ctx, const float *in, int64_t ld_in, int64_t rows_in, float *out, int64_t ld_out,
+                        int64_t rows_out, int n_cols, void *stream);
 
 /* dynamic_butter_filter (SillySampler.py:95-174) for a list of jobs (device array): src -> dst, fp32. */
 int goofer_onepole_cascade(goofer_ctx *ctx, const float *src, float *dst, const float *f0, const goofer_onepole_job *jobs,

@@ -219,3 +219,28 @@ def test_fused_overlap_add_equals_separate_kernels(ctx, config, ids):
         ctx.set_option("fused_ola", 1)
     for k in a:
         assert np.array_equal(a[k], b[k].cpu().numpy()), k
+
+
+@pytest.mark.parametrize("kw", [
+    dict(stretch_factor=1.3),
+    dict(stretch_factor=0.7, start_sec=0.05, end_sec=0.2, pitch_shift=1.2, formant_shift=1.1, F2_shift=1.15),
+])
+def test_synthesize_stretch_vs_oracle(ctx, kw):
+    """stretch_factor / start_sec / end_sec of gf.synthesize (GOOFER.py:1019-1067): envelope rows, f0 and mask resampled
+    along time on the device after the warps and the noise-envelope blur, like the reference orders them."""
+    from goofer_amd import core
+    from oracle import goofer_ref as R
+    g = golden("synthesize")
+    c = _case(g, "plain")
+    n_new = len(R.stretch_feature(c["f0"], kw["stretch_factor"])) if "start_sec" not in kw else None
+    if n_new is None:
+        a, b = int(kw["start_sec"] * c["sr"]), int(kw["end_sec"] * c["sr"])
+        n_new = a + int((b - a) * kw["stretch_factor"]) + (len(c["f0"]) - b)
+    T = 1 + n_new // c["hop"]
+    phi = np.random.default_rng(5).uniform(0.0, 2.0 * np.pi, size=(c["env"].shape[0], T)).astype(np.float32)
+    args = (c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"])
+    ref = R.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=phi, **kw)
+    got = core.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=phi, ctx=ctx, **kw)
+    assert len(got[0]) == n_new == len(ref[0])
+    for a_, b_, key in zip(got, ref, ("rec", "harm", "uv", "bre")):
+        assert rms_err(a_, b_) < 2e-5, (key, rms_err(a_, b_))
