@@ -72,6 +72,31 @@ def pmc_traffic(stage, frames):
         return None
 
 
+def pcie_leg(wl, step_s):
+    """What a host that hands over numpy buffers pays on top of `value` (never part of it): H2D of everything
+    Renderer.prepare made resident (knots, masks, pitch curves, plans, taps, formant tracks) and D2H of the mix,
+    through pinned staging buffers, timed with events around the copies."""
+    import torch
+    dev = [t for t in wl.prep["keep"].values() if t is not None] + [wl.prep["formants"]]
+    host = [t.cpu().pin_memory() for t in dev]
+    out = wl.step()
+    mix_host = torch.empty(out["mix"].shape, dtype=out["mix"].dtype).pin_memory()
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    for h, d in zip(host, dev):
+        d.copy_(h, non_blocking=True)
+    e[1].record()
+    mix_host.copy_(out["mix"], non_blocking=True)
+    e[2].record()
+    torch.cuda.synchronize()
+    h2d_ms, d2h_ms = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+    h2d_b, d2h_b = sum(h.numel() * h.element_size() for h in host), mix_host.numel() * mix_host.element_size()
+    tot = step_s + (h2d_ms + d2h_ms) * 1e-3
+    return {"h2d_ms": h2d_ms, "d2h_ms": d2h_ms, "h2d_bytes": h2d_b, "d2h_bytes": d2h_b,
+            "frames_per_s": wl.frames / tot, "note": "serial copies + compute, pinned host buffers; not the headline value"}
+
+
 def cpu_baseline(wl, hop, budget_s=15.0, min_notes=4):
     """Oracle (CPU port of the reference path, oracle/) on the same notes — the full render the reference does
     per note: decode features, assemble, synthesize, mix — single thread, bounded sample."""
@@ -205,6 +230,8 @@ def main():
             # in-pipeline launch when the active path has a standalone rFFT stage, else the entry-point timing
             "roofline_fft": roof("rfft_frames" if per.get("rfft_frames", 0) > 0 else "rfft_frames_standalone"),
         }
+        if world == 1:
+            line["pcie_inclusive"] = pcie_leg(wl, elapsed / args.steps)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, hop)
         print(json.dumps(line))

@@ -244,3 +244,50 @@ def test_synthesize_stretch_vs_oracle(ctx, kw):
     assert len(got[0]) == n_new == len(ref[0])
     for a_, b_, key in zip(got, ref, ("rec", "harm", "uv", "bre")):
         assert rms_err(a_, b_) < 2e-5, (key, rms_err(a_, b_))
+
+
+def test_fused_overlap_add_tiny_and_ragged_notes(ctx):
+    """Note lengths around the hop / window sizes (1 sample .. a few frames), all in one batch: the fused
+    irFFT + overlap-add kernel against the separate kernels, bit for bit, and against the oracle for one of them."""
+    from goofer_amd.device import default_params
+    from oracle import goofer_ref as R
+    ctx.plan(44100, 1024, 256)
+    rng = np.random.default_rng(11)
+    lens = [1, 7, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 3000, 2, 4097]
+    nb = 513
+    envs, f0s, masks, env_len = [], [], [], []
+    for n in lens:
+        T = 1 + n // 256
+        rows = T + int(rng.integers(0, 3)) - 1                        # fewer / equal / more envelope rows than frames
+        rows = max(1, rows)
+        envs.append((1.0 + rng.random((rows, nb))).astype(np.float32))
+        env_len.append(rows)
+        m = (rng.random(n) > 0.3).astype(np.float32)
+        masks.append(m)
+        f0s.append((200.0 + 50.0 * rng.random(n)).astype(np.float32) * m)
+    par = default_params(len(lens))
+    args = (ctx.rows_from(np.concatenate(envs)), env_len, ctx.tensor(np.concatenate(f0s)), ctx.tensor(np.concatenate(masks)), lens, par)
+    try:
+        ctx.set_option("fused_ola", 1)
+        a = ctx.synth_batch(*args, seed=5)
+        torch.cuda.synchronize()
+        a = {k: a[k].cpu().numpy() for k in ("harm", "uv", "bre", "mix")}
+        ctx.set_option("fused_ola", 0)
+        b = ctx.synth_batch(*args, seed=5)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_option("fused_ola", 1)
+    for k in a:
+        assert np.array_equal(a[k], b[k].cpu().numpy()), k
+        assert np.all(np.isfinite(a[k])), k
+    # one short note against the oracle with injected phases
+    i = lens.index(1025)
+    o = int(np.sum(lens[:i]))
+    n = lens[i]
+    T = 1 + n // 256
+    phi = rng.uniform(0.0, 2.0 * np.pi, size=(nb, T)).astype(np.float32)
+    ref = R.synthesize(envs[i].T, f0s[i], masks[i], np.empty(n, bool), 44100, phi=phi)
+    one = ctx.synth_batch(ctx.rows_from(envs[i]), [env_len[i]], ctx.tensor(f0s[i]), ctx.tensor(masks[i]), [n], par[i:i + 1],
+                          phi=ctx.rows_from(phi.T))
+    for key, r in zip(("rec", "harm", "uv", "bre"), ref):
+        assert rms_err(one[key].cpu().numpy(), r) < 2e-5, key
