@@ -27,26 +27,23 @@ __global__ __launch_bounds__(256) void k_rfft_frames(const float *__restrict__ x
     float *win = reinterpret_cast<float *>(bufs + WAVES_PER_BLOCK * fft_cfg<M>::BUF);
     load_tables<M>(tw, twh, win, g_tw, g_twh, g_win);
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2 *buf = bufs + wave * fft_cfg<M>::BUF;
     const int64_t f_begin = (int64_t)blockIdx.x * FRAMES_PER_BLOCK;
 
-    for (int i = wave; i < FRAMES_PER_BLOCK; i += WAVES_PER_BLOCK) {
-        const int64_t f = f_begin + i;
-        if (f >= total_frames) break;                 // wave-uniform
+    // raw sample pairs of a frame (reflect-padded at the note ends); the next frame's are in flight during the FFT
+    auto fetch = [&](int64_t f, float2 (&raw)[R]) {
         const int note = frame_note[f];
         const int64_t base = sample_off[note];
         const int64_t n = sample_off[note + 1] - base;
         const int64_t t = f - frame_off[note];
         const int64_t start = t * hop - M;            // first sample of the frame, un-padded coordinates
         const float *xs = x + base;
-
-        float2 v[R];
         if (start >= 0 && start + 2 * M <= n) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 int m = lane + WAVE * r;
-                v[r] = make_float2(xs[start + 2 * m] * win[2 * m], xs[start + 2 * m + 1] * win[2 * m + 1]);
+                raw[r] = make_float2(xs[start + 2 * m], xs[start + 2 * m + 1]);
             }
         } else {
 #pragma unroll
@@ -54,9 +51,23 @@ __global__ __launch_bounds__(256) void k_rfft_frames(const float *__restrict__ x
                 int m = lane + WAVE * r;
                 float a = n > 0 ? xs[reflect_index(start + 2 * m, n)] : 0.f;
                 float b = n > 0 ? xs[reflect_index(start + 2 * m + 1, n)] : 0.f;
-                v[r] = make_float2(a * win[2 * m], b * win[2 * m + 1]);
+                raw[r] = make_float2(a, b);
             }
         }
+    };
+    float2 nx[R];
+    if (f_begin + wave < total_frames) fetch(f_begin + wave, nx);
+
+    for (int i = wave; i < FRAMES_PER_BLOCK; i += WAVES_PER_BLOCK) {
+        const int64_t f = f_begin + i;
+        if (f >= total_frames) break;                 // wave-uniform
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int m = lane + WAVE * r;
+            v[r] = make_float2(nx[r].x * win[2 * m], nx[r].y * win[2 * m + 1]);
+        }
+        if (i + WAVES_PER_BLOCK < FRAMES_PER_BLOCK && f + WAVES_PER_BLOCK < total_frames) fetch(f + WAVES_PER_BLOCK, nx);
         wave_fft<M>(v, buf, tw, lane);
 
         // even/odd split: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 e^{-i pi k/M} (Z[k] - conj Z[M-k])
