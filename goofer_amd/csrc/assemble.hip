@@ -236,29 +236,38 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
 }
 
 
+#define SA_SPT 4   // samples per thread, strided by the workgroup so loads and stores stay coalesced
+
 __global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a, int64_t total_samples)
 {
     __shared__ int s_pair[2];
-    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x * SA_SPT);
     if (threadIdx.x < WAVE) {
         // notes own [out_sample_off, out_sample_off + n_out): first wave searches the plan array cooperatively
         auto key = [&](int k) { return a.notes[k].out_sample_off; };
-        int64_t gl = g0 + blockDim.x - 1;
+        int64_t gl = g0 + (int64_t)blockDim.x * SA_SPT - 1;
         if (gl > total_samples - 1) gl = total_samples - 1;
         const int lo = wave_find(a.n_notes, g0, (int)threadIdx.x, key);
         const int hi = wave_find(a.n_notes, gl, (int)threadIdx.x, key);
         if (threadIdx.x == 0) { s_pair[0] = lo; s_pair[1] = hi; }
     }
     __syncthreads();
-    const int64_t g = g0 + threadIdx.x;
-    if (g >= total_samples) return;
     const int n_lo = __builtin_amdgcn_readfirstlane(s_pair[0]), n_hi = __builtin_amdgcn_readfirstlane(s_pair[1]);
     if (n_lo == n_hi) {
-        sample_assemble_one(a, a.notes[n_lo], g);            // uniform note: the 300-byte plan comes in through scalar loads
+        const goofer_note_plan &p = a.notes[n_lo];           // uniform note: the 300-byte plan comes in through scalar loads
+#pragma unroll
+        for (int u = 0; u < SA_SPT; ++u) {
+            const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
+            if (g < total_samples) sample_assemble_one(a, p, g);
+        }
     } else {
-        int note = n_lo;
-        while (note + 1 < a.n_notes && a.notes[note + 1].out_sample_off <= g) ++note;
-        sample_assemble_one(a, a.notes[note], g);
+        for (int u = 0; u < SA_SPT; ++u) {
+            const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
+            if (g >= total_samples) break;
+            int note = n_lo;
+            while (note + 1 < a.n_notes && a.notes[note + 1].out_sample_off <= g) ++note;
+            sample_assemble_one(a, a.notes[note], g);
+        }
     }
 }
 
@@ -362,7 +371,8 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         }
     }
     if (a->total_samples > 0) {
-        hipLaunchKernelGGL(k_sample_assemble, dim3((unsigned)((a->total_samples + 255) / 256)), dim3(256), 0, st, *a, a->total_samples);
+        hipLaunchKernelGGL(k_sample_assemble, dim3((unsigned)((a->total_samples + 256 * SA_SPT - 1) / (256 * SA_SPT))), dim3(256), 0, st, *a,
+                           a->total_samples);
         LAUNCH_CHECK(ctx);
     }
     return GOOFER_OK;
