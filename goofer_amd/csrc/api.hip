@@ -320,6 +320,13 @@ void goofer_destroy(goofer_ctx *ctx)
     if (ctx->mask_taps) (void)hipFree(ctx->mask_taps);
     for (int i = 0; i < ctx->prof_cap * (PROF_STAGES + 1); ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
     free(ctx->prof_ev);
+    for (int i = 0; ctx->prof_side && i < ctx->prof_cap * 4; ++i) (void)hipEventDestroy(ctx->prof_side[i]);
+    free(ctx->prof_side);
+    for (int i = 0; ctx->prof_main2 && i < ctx->prof_cap * 2; ++i) (void)hipEventDestroy(ctx->prof_main2[i]);
+    free(ctx->prof_main2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     delete ctx;
 }
 
@@ -429,9 +436,17 @@ int goofer_profile_begin(goofer_ctx *ctx, int max_steps)
     if (ctx->prof_cap < max_steps) {
         for (int i = 0; i < ctx->prof_cap * (PROF_STAGES + 1); ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
         free(ctx->prof_ev);
+        for (int i = 0; ctx->prof_side && i < ctx->prof_cap * 4; ++i) (void)hipEventDestroy(ctx->prof_side[i]);
+        free(ctx->prof_side);
+        for (int i = 0; ctx->prof_main2 && i < ctx->prof_cap * 2; ++i) (void)hipEventDestroy(ctx->prof_main2[i]);
+        free(ctx->prof_main2);
         ctx->prof_ev = (hipEvent_t *)calloc((size_t)max_steps * (PROF_STAGES + 1), sizeof(hipEvent_t));
-        if (!ctx->prof_ev) return goofer_fail(ctx, GOOFER_ENOMEM, "event pool");
+        ctx->prof_side = (hipEvent_t *)calloc((size_t)max_steps * 4, sizeof(hipEvent_t));
+        ctx->prof_main2 = (hipEvent_t *)calloc((size_t)max_steps * 2, sizeof(hipEvent_t));
+        if (!ctx->prof_ev || !ctx->prof_side || !ctx->prof_main2) return goofer_fail(ctx, GOOFER_ENOMEM, "event pool");
         for (int i = 0; i < max_steps * (PROF_STAGES + 1); ++i) HIP_TRY(ctx, hipEventCreate(&ctx->prof_ev[i]));
+        for (int i = 0; i < max_steps * 4; ++i) HIP_TRY(ctx, hipEventCreate(&ctx->prof_side[i]));
+        for (int i = 0; i < max_steps * 2; ++i) HIP_TRY(ctx, hipEventCreate(&ctx->prof_main2[i]));
         ctx->prof_cap = max_steps;
     }
     ctx->prof_steps = 0;
@@ -449,7 +464,15 @@ int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages)
         for (int k = 0; k < ctx->prof_steps; ++k) {
             hipEvent_t *e = ctx->prof_ev + (size_t)k * (PROF_STAGES + 1);
             float ms = 0.f;
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, e[s], e[s + 1]));
+            if (ctx->prof_side_used && s >= 3 && s <= 5) {              // the pulse chain ran on the side stream
+                hipEvent_t *q = ctx->prof_side + (size_t)k * 4;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, q[s - 3], q[s - 2]));
+            } else if (ctx->prof_side_used && (s == 9 || s == 12)) {    // launched beside it on the caller's stream
+                hipEvent_t *q = ctx->prof_main2 + (size_t)k * 2;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, s == 9 ? e[5] : q[0], s == 9 ? q[0] : q[1]));
+            } else {
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, e[s], e[s + 1]));
+            }
             acc += ms;
         }
         ms_per_stage[s] = acc;
@@ -480,6 +503,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!ctx || !name) return GOOFER_EINVAL;
     if (!strcmp(name, "fused")) { ctx->fused = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "fused_ola")) { ctx->ola_fused = value != 0; return GOOFER_OK; }
+    if (!strcmp(name, "overlap")) { ctx->overlap = value != 0; return GOOFER_OK; }
     return goofer_fail(ctx, GOOFER_EINVAL, "unknown option %s", name);
 }
 
@@ -972,6 +996,10 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     hipEvent_t *pev = nullptr;
     if (ctx->prof_on && ctx->prof_steps < ctx->prof_cap) pev = ctx->prof_ev + (size_t)ctx->prof_steps * (PROF_STAGES + 1);
     int stage = 0;
+#define MARK_AT(k)                                                   \
+    do {                                                             \
+        if (pev) HIP_TRY(ctx, hipEventRecord(ctx->prof_main2[(size_t)ctx->prof_steps * 2 + ((k) == 9 ? 0 : 1)], st)); \
+    } while (0)
 #define MARK()                                                       \
     do {                                                             \
         if (pev) HIP_TRY(ctx, hipEventRecord(pev[stage], st));       \
@@ -998,16 +1026,52 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if ((rc = launch_note_absmax(ctx, jit_a, b->sample_off, n, N, on_f0, jit_max, st))) return rc;
         if ((rc = launch_f0_jitter(ctx, f0s, b->mask, jit_a, jit_max, b->sample_off, n, N, b->params, st))) return rc;
     }
+    // The pulse walk is one latency-bound wave per SIMD: it goes to a side stream FIRST (so its workgroups are resident
+    // from the start), and the aperiodic branch — noise spectra, mask smoothing, which depend only on the maps and
+    // the scaled f0 — fills the rest of the machine from the caller's stream meanwhile.
+    const bool side_on = ctx->overlap && ola_one && !sub_on;
+    hipEvent_t *sev = nullptr;
+    hipStream_t pst = st;                                     // stream of the pulse chain
+    if (side_on) {
+        if (!ctx->side) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        if (pev) sev = ctx->prof_side + (size_t)ctx->prof_steps * 4;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        pst = ctx->side;
+        ctx->prof_side_used = true;
+    } else if (pev) {
+        ctx->prof_side_used = false;
+    }
     MARK();   // 1: noise envelope = sigma-1.75 blur of the un-warped rows (GOOFER.py:993)
     // (folded into k_noise_spectra / k_harm_shape: the standalone envelope kernels remain as C-ABI entry points)
     MARK();   // 2: harmonic envelope = formant-anchored + uniform warp
 
     MARK();   // 3..5: pulse train
-    if ((rc = launch_phase_inc(ctx, f0s, 1.0f, N, inc, st))) return rc;
+    if (sev) HIP_TRY(ctx, hipEventRecord(sev[0], pst));
+    if ((rc = launch_phase_inc(ctx, f0s, 1.0f, N, inc, pst))) return rc;
     MARK();
-    if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, inc, b->sample_off, n, (onset_t *)onsets, onset_idx, onset_cnt, ovf, st))) return rc;
+    if (sev) HIP_TRY(ctx, hipEventRecord(sev[1], pst));
+    if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, inc, b->sample_off, n, (onset_t *)onsets, onset_idx, onset_cnt, ovf, pst))) return rc;
     MARK();
-    if ((rc = launch_pulse_place(ctx, (onset_t *)onsets, onset_cnt, b->sample_off, n, N, pulse, st))) return rc;
+    if (sev) HIP_TRY(ctx, hipEventRecord(sev[2], pst));
+    if ((rc = launch_pulse_place(ctx, (onset_t *)onsets, onset_cnt, b->sample_off, n, N, pulse, pst))) return rc;
+    if (side_on) {
+        if (sev) HIP_TRY(ctx, hipEventRecord(sev[3], pst));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, pst));
+        // meanwhile, on the caller's stream
+        if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
+                                       b->env_noise ? b->env_noise : b->env, b->phi, ld, b->params, b->seed, row_src,
+                                       b->env_noise != nullptr, st)))
+            return rc;
+        MARK_AT(9);
+        if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
+        MARK_AT(12);
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+    }
     if (sub_on) {   // 'sg': extra LF pulse layer at f0 * ratio with vibrato, added to the pulse train (GOOFER.py:1076-1097)
         hipLaunchKernelGGL(k_note_sub_flags, dim3((n + 255) / 256), dim3(256), 0, st, b->params, n, on_sub);
         LAUNCH_CHECK(ctx);
@@ -1037,9 +1101,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         MARK();   // 8
         if (!ola_one && (rc = launch_irfft_frames(ctx, S_h, ldc, F, frames, st))) return rc;
         MARK();   // 9: aperiodic spectra
-        if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
-                                       b->env_noise ? b->env_noise : b->env, b->phi, ld, b->params, b->seed, row_src,
-                                       b->env_noise != nullptr, st)))
+        if (!side_on && (rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
+                                                   b->env_noise ? b->env_noise : b->env, b->phi, ld, b->params, b->seed, row_src,
+                                                   b->env_noise != nullptr, st)))
             return rc;
         MARK();   // 10, 11
         if (!ola_one && (rc = launch_irfft_frames(ctx, S_br, ldc, F, frames_b, st))) return rc;
@@ -1047,7 +1111,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if (!ola_one && (rc = launch_irfft_frames(ctx, S_uv, ldc, F, frames_u, st))) return rc;
     }
     MARK();   // 12: decimated + smoothed voicing mask
-    if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
+    if (!side_on && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
     MARK();   // 13: (irFFT of the three stems +) overlap-add + gains + per-note peak, one pass
     if (ola_one) {
         if ((rc = launch_irfft_ola3(ctx, S_h, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, n, note_mag, short_s,

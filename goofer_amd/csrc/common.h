@@ -42,6 +42,12 @@ struct goofer_ctx {
     // device pointers of the last synth batch's intermediates (goofer_debug_fetch; tests only)
     const void *dbg_ptr[16] = {nullptr};
     size_t dbg_bytes[16] = {0};
+    bool overlap = true;          // noise spectra + mask smoothing on a side stream, beside the latency-bound pulse walk
+    hipStream_t side = nullptr;   // created on first use
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t *prof_side = nullptr;    // [prof_cap][4]: boundaries of the pulse chain on the side stream
+    hipEvent_t *prof_main2 = nullptr;   // [prof_cap][2]: ends of noise_spectra / mask_short when they run beside it
+    bool prof_side_used = false;
     bool ola_fused = true;        // irFFT x3 + overlap-add + gains in one kernel (k_irfft_ola3); false: separate irFFT launches + k_ola3_gains
     bool fused = false;           // opt-in fused per-frame kernels (fused.hip); default: one kernel per reference step
     // per-stage HIP-event timing of goofer_synth_batch (goofer_profile_begin/end)

@@ -129,6 +129,9 @@ __global__ __launch_bounds__(256) void k_pulse_onsets(const double *__restrict__
                                                       const unsigned char *__restrict__ note_on)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    // this wave is one long dependent chain: when another kernel shares the SIMD (the side stream's noise spectra),
+    // let the arbiter issue it first
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int note = blockIdx.x * 4 + wv;
     if (note >= n_notes) return;                              // whole wave; no block barrier below
@@ -442,6 +445,8 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
         const int blocks = (n_notes + 3) / 4;
         const int per_cu = (blocks + 255) / 256;              // MI355X: 256 CUs, 160 KiB LDS each
         size_t lds = (size_t)(160 * 1024) / per_cu;
+        if (lds > 96 * 1024) lds = 96 * 1024;                 // still one workgroup per CU, and 64 KiB left for a kernel
+                                                              // running beside the walk on the side stream
         lds = lds / 1024 * 1024;
         const size_t need = 4 * 2 * OC * sizeof(double);      // 32 KiB actually used
         if (lds < need) lds = need;

@@ -291,3 +291,23 @@ def test_fused_overlap_add_tiny_and_ragged_notes(ctx):
                           phi=ctx.rows_from(phi.T))
     for key, r in zip(("rec", "harm", "uv", "bre"), ref):
         assert rms_err(one[key].cpu().numpy(), r) < 2e-5, key
+
+
+def test_side_stream_overlap_equals_single_stream(ctx):
+    """Noise spectra + mask smoothing on the library's side stream (default) vs everything on the caller's stream."""
+    from goofer_amd.workload import SynthWorkload
+    wl = SynthWorkload(ctx, 3, list(range(12)))
+    try:
+        ctx.set_option("overlap", 1)
+        outs = []
+        for _ in range(3):                                     # back-to-back calls reuse the scratch arena
+            a = wl.step(want_rec=True)
+        torch.cuda.synchronize()
+        a = {k: a[k].cpu().numpy() for k in ("harm", "uv", "bre", "rec", "mix")}
+        ctx.set_option("overlap", 0)
+        b = wl.step(want_rec=True)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_option("overlap", 1)
+    for k in a:
+        assert np.array_equal(a[k], b[k].cpu().numpy()), k
