@@ -44,7 +44,7 @@ def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int) ->
         # fused frame kernels: unique pulse samples + env row in, windowed frame(s) out
         "harm_frames": (4 * hop + 4 * B + 4 * n_fft) * F, "noise_frames": (4 * B + 8 * n_fft) * F,
         "phase_inc": 12 * N, "pulse_onsets": 12 * N, "pulse_place": 4 * N,
-        "mask_short": 4 * N / 4 + 8 * N / 4, "stem_gains": 24 * N, "apply_gain": 28 * N, "setup_maps": 8 * N + 12 * F,
+        "mask_short": 4 * N / 4 + 8 * N / 4, "stem_gains": 24 * N, "apply_gain": 16 * N,   # three stems in, the mix out (mix_only) "setup_maps": 8 * N + 12 * F,
     }
     return float(table[stage])
 

@@ -80,7 +80,7 @@ class Post(C.Structure):
 class Batch(C.Structure):
     """goofer_batch"""
     _fields_ = [
-        ("n_notes", C.c_int32), ("n_bins", C.c_int32), ("ld", C.c_int32), ("reserved", C.c_int32),
+        ("n_notes", C.c_int32), ("n_bins", C.c_int32), ("ld", C.c_int32), ("mix_only", C.c_int32),
         ("total_frames", C.c_int64), ("total_samples", C.c_int64), ("total_env_rows", C.c_int64),
         ("sample_off", C.c_void_p), ("frame_off", C.c_void_p), ("env_off", C.c_void_p),
         ("env", C.c_void_p), ("formants", C.c_void_p), ("f0", C.c_void_p), ("mask", C.c_void_p),

@@ -84,7 +84,7 @@ int launch_noise_frames(goofer_ctx *, const goofer_batch *, const float *, const
 int launch_stem_gains(goofer_ctx *, float *, float *, float *, const double *, const int64_t *, int, int64_t,
                       const goofer_note_params *, float *, double *, hipStream_t);
 int launch_apply_gain(goofer_ctx *, float *, float *, float *, float *, float *, const int64_t *, int, int64_t,
-                      const goofer_note_params *, const float *, hipStream_t);
+                      const goofer_note_params *, const float *, bool, hipStream_t);
 
 static const size_t ONSET_BYTES = 24;
 
@@ -1138,7 +1138,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if ((rc = launch_stem_peak(ctx, b->harm, b->uv, b->bre, b->sample_off, n, N, note_peak, st))) return rc;
     }
     MARK();   // 14: gain, reconstruct, mix
-    if ((rc = launch_apply_gain(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, N, b->params, note_peak, st))) return rc;
+    if ((rc = launch_apply_gain(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, N, b->params, note_peak,
+                                !(b->mix_only && (b->mix || b->rec)), st)))
+        return rc;
     MARK();   // 15..17 unused
     MARK();
     MARK();

@@ -577,7 +577,8 @@ int launch_irfft_ola3(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u, con
 __global__ __launch_bounds__(256) void k_apply_gain(float *__restrict__ harm, float *__restrict__ uv, float *__restrict__ bre,
                                                     float *__restrict__ rec, float *__restrict__ mix,
                                                     const int64_t *__restrict__ sample_off, int n_notes, int64_t total_samples,
-                                                    const goofer_note_params *__restrict__ params, const float *__restrict__ note_peak)
+                                                    const goofer_note_params *__restrict__ params, const float *__restrict__ note_peak,
+                                                    int write_stems)
 {
     __shared__ int s_pair[2];
     const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x * SPT);
@@ -607,9 +608,11 @@ __global__ __launch_bounds__(256) void k_apply_gain(float *__restrict__ harm, fl
         h.x *= gain; h.y *= gain; h.z *= gain; h.w *= gain;
         u.x *= gain; u.y *= gain; u.z *= gain; u.w *= gain;
         b.x *= gain; b.y *= gain; b.z *= gain; b.w *= gain;
-        *reinterpret_cast<float4 *>(harm + g) = h;
-        *reinterpret_cast<float4 *>(uv + g) = u;
-        *reinterpret_cast<float4 *>(bre + g) = b;
+        if (write_stems) {
+            *reinterpret_cast<float4 *>(harm + g) = h;
+            *reinterpret_cast<float4 *>(uv + g) = u;
+            *reinterpret_cast<float4 *>(bre + g) = b;
+        }
         if (rec) *reinterpret_cast<float4 *>(rec + g) = make_float4(comb.x * gain, comb.y * gain, comb.z * gain, comb.w * gain);
         if (mix)
             *reinterpret_cast<float4 *>(mix + g) = make_float4(mixdown(lo, h.x, u.x, b.x), mixdown(lo, h.y, u.y, b.y),
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(256) void k_apply_gain(float *__restrict__ harm, fl
         float h = harm[gi], u = uv[gi], b = bre[gi];
         const float comb = (h + u) + b;
         h *= gain; u *= gain; b *= gain;
-        harm[gi] = h; uv[gi] = u; bre[gi] = b;
+        if (write_stems) { harm[gi] = h; uv[gi] = u; bre[gi] = b; }
         if (rec) rec[gi] = comb * gain;
         if (mix) mix[gi] = mixdown(note, h, u, b);
     }
@@ -691,11 +694,12 @@ int launch_stem_gains(goofer_ctx *ctx, float *harm, float *uv, float *bre, const
 }
 
 int launch_apply_gain(goofer_ctx *ctx, float *harm, float *uv, float *bre, float *rec, float *mix, const int64_t *sample_off,
-                      int n_notes, int64_t total_samples, const goofer_note_params *params, const float *note_peak, hipStream_t st)
+                      int n_notes, int64_t total_samples, const goofer_note_params *params, const float *note_peak, bool write_stems,
+                      hipStream_t st)
 {
     if (total_samples <= 0) return GOOFER_OK;
     hipLaunchKernelGGL(k_apply_gain, dim3((unsigned)((total_samples + 1023) / 1024)), dim3(256), 0, st, harm, uv, bre, rec, mix,
-                       sample_off, n_notes, total_samples, params, note_peak);
+                       sample_off, n_notes, total_samples, params, note_peak, write_stems ? 1 : 0);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

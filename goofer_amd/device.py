@@ -275,7 +275,7 @@ class Context:
     def synth_batch(self, env, env_lengths, f0, mask, sample_lengths, params: np.ndarray, formants=None, phi=None,
                     seed: int = 0, transition_sigma: float = 100.0, want_rec=True, want_mix=True, offsets=None,
                     noise_f0=None, noise_vol=None, f0_jitter_speed: float = 100.0, vol_jitter_speed: float = 150.0,
-                    subharm=None, volume_vibrato: bool = False, env_noise=None):
+                    subharm=None, volume_vibrato: bool = False, env_noise=None, mix_only: bool = False):
         """Run goofer_synth_batch.
 
         ``subharm`` = dict(semitones, vibrato, rate, depth, delay) switches the sub-harmonic pulse layer on for the
@@ -302,7 +302,7 @@ class Context:
             assert phi.shape == (F, nb) and phi.stride(0) == env.stride(0)
         if env_noise is not None:                            # pre-blurred noise envelope rows (gf.synthesize's time stretch)
             assert env_noise.shape == env.shape and env_noise.stride(0) == env.stride(0)
-        b = _lib.Batch(n_notes=n, n_bins=nb, ld=env.stride(0), total_frames=F, total_samples=N, total_env_rows=R,
+        b = _lib.Batch(n_notes=n, n_bins=nb, ld=env.stride(0), mix_only=int(bool(mix_only and want_mix)), total_frames=F, total_samples=N, total_env_rows=R,
                        sample_off=d_s.data_ptr(), frame_off=d_f.data_ptr(), env_off=d_e.data_ptr(), env=env.data_ptr(),
                        formants=formants.data_ptr() if formants is not None else None, f0=f0.data_ptr(),
                        mask=mask.data_ptr(), phi=phi.data_ptr() if phi is not None else None,

@@ -84,7 +84,7 @@ class Renderer:
         if not jobs:
             return []
         prep = self.prepare(jobs, phi_seeds=phi_seeds)
-        out = self.run(prep, seed=seed)
+        out = self.run(prep, seed=seed, keep_stems=return_parts)
         torch.cuda.synchronize(self.ctx.device)
         mix = out["mix"].cpu().numpy()
         offs = prep["sample_off"]
@@ -95,14 +95,15 @@ class Renderer:
             return res, parts
         return res
 
-    def run(self, prep, seed: int = 0):
+    def run(self, prep, seed: int = 0, keep_stems: bool = False):
         """The device work of one batch: goofer_assemble_batch then goofer_synth_batch (asynchronous)."""
         ctx = self.ctx
         ctx._check(ctx.lib.goofer_assemble_batch(ctx.h, C.byref(prep["assembly"]), ctx._stream()))
         out = ctx.synth_batch(prep["env"], prep["env_lens"], prep["f0"], prep["mask"], prep["lens"], prep["params"],
                               formants=prep["formants"], phi=prep["phi"], seed=seed, want_rec=False, want_mix=True,
                               offsets=prep["offsets"], noise_f0=prep["noise_f0"], noise_vol=prep["noise_vol"],
-                              subharm=S.SUBHARM if prep["subharm"] else None)
+                              subharm=S.SUBHARM if prep["subharm"] else None,
+                              mix_only=prep["post"] is None and not keep_stems)
         if prep["post"] is not None:
             self._post_chain(prep, out, seed)
         return out
