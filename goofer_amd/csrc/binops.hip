@@ -143,7 +143,7 @@ int launch_knot_decode(goofer_ctx *ctx, const uint16_t *knots, int K, int64_t ro
 // frames * brightness followed by the 5-tap blur.  The 1/max normalisation commutes with the
 // (linear) rest of the chain and is applied after the overlap-add.
 template <int ITERS>
-__global__ __launch_bounds__(256) void k_harm_shape(float2 *__restrict__ S, int ldc, int64_t total_frames,
+__global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *__restrict__ S, int ldc, int64_t total_frames,
                                                     const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
                                                     const int64_t *__restrict__ sample_off, const float *__restrict__ f0,
                                                     const float *__restrict__ mask, const float *__restrict__ env, int ld,
