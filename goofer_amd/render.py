@@ -95,10 +95,15 @@ class Renderer:
             return res, parts
         return res
 
+    def assemble(self, prep):
+        """goofer_assemble_batch alone (asynchronous): envelope rows, f0 and voicing mask of the batch."""
+        ctx = self.ctx
+        ctx._check(ctx.lib.goofer_assemble_batch(ctx.h, C.byref(prep["assembly"]), ctx._stream()))
+
     def run(self, prep, seed: int = 0, keep_stems: bool = False):
         """The device work of one batch: goofer_assemble_batch then goofer_synth_batch (asynchronous)."""
         ctx = self.ctx
-        ctx._check(ctx.lib.goofer_assemble_batch(ctx.h, C.byref(prep["assembly"]), ctx._stream()))
+        self.assemble(prep)
         out = ctx.synth_batch(prep["env"], prep["env_lens"], prep["f0"], prep["mask"], prep["lens"], prep["params"],
                               formants=prep["formants"], phi=prep["phi"], seed=seed, want_rec=False, want_mix=True,
                               offsets=prep["offsets"], noise_f0=prep["noise_f0"], noise_vol=prep["noise_vol"],

@@ -27,4 +27,4 @@ for k, v in st["ms"].items():
     if v > 0:
         print(f"{k:16s} {v / st['steps']:.3f} ms")
         tot += v / st["steps"]
-print(f"{'synth sum':16s} {tot:.3f} ms;  step (assemble + synth) {t0.elapsed_time(t1) / steps:.3f} ms")
+print(f"sum of synth stages (two streams, they overlap) {tot:.3f} ms;  step (assemble + synth, wall) {t0.elapsed_time(t1) / steps:.3f} ms")
