@@ -131,9 +131,21 @@ __device__ __forceinline__ double lin01_f32_i(int i, int num, double step)
     return (double)(float)((double)i * step);
 }
 
-__device__ __forceinline__ float smooth_mask_at32(const double *__restrict__ ss, int ns, int i, int n, double step_n, double step_s)
+__device__ __forceinline__ float smooth_mask_at32(const double *__restrict__ ss, int ns, int i, int n, double step_n, double step_s,
+                                                  float knots_per_sample)
 {
     if (ns <= 1) return (float)ss[0];
+    // Almost everywhere the smoothed mask is flat (0, or the tap sum): when the four knots around a cheap index
+    // estimate (good to +-1) are equal, any of the candidate intervals interpolates to exactly that value
+    // (slope 0), and the exact index search below is not needed.
+    {
+        int je = (int)((float)i * knots_per_sample);
+        je = je < 1 ? 1 : (je > ns - 3 ? ns - 3 : je);
+        if (ns >= 4) {
+            const double a = ss[je - 1], b = ss[je], c = ss[je + 1], d = ss[je + 2];
+            if (a == b && b == c && c == d) return (float)b;
+        }
+    }
     const double x = lin01_f32_i(i, n, step_n);
     int j = (int)(x * (double)(ns - 1));
     if (j > ns - 1) j = ns - 1;
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
     int note = -1;
     int64_t base = 0, fbase = 0;
     int n = 0, T = 0, ns = 0, out_len = 0;
-    float mag = 1.f, g_b = 0.f, g_u = 0.f, pk = 0.f;
+    float mag = 1.f, g_b = 0.f, g_u = 0.f, pk = 0.f, kps = 0.f;
     double step_n = 0.0, step_s = 0.0;
     const double *ss = nullptr;
 
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
                 if (ws > 1e-9f) { vh /= ws; vu /= ws; vb /= ws; }
                 vh = vh / mag;
             }
-            const float ms = smooth_mask_at32(ss, ns, i, n, step_n, step_s);
+            const float ms = smooth_mask_at32(ss, ns, i, n, step_n, step_s, kps);
             vb = (vb * ms) * g_b;
             vu = (vu * (1.0f - ms)) * g_u;
             harm[base + i] = vh;
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
                 if (ws > 1e-9f) { vh /= ws; vu /= ws; vb /= ws; }
                 vh = vh / mag;
             }
-            const float ms = smooth_mask_at32(ss, ns, i, n, step_n, step_s);
+            const float ms = smooth_mask_at32(ss, ns, i, n, step_n, step_s, kps);
             vb = (vb * ms) * g_b;
             vu = (vu * (1.0f - ms)) * g_u;
             harm[base + i] = vh;
@@ -475,6 +487,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
             g_u = params[note].uv_strength;
             step_n = steps[2 * note];
             step_s = steps[2 * note + 1];
+            kps = n > 1 ? (float)(ns - 1) / (float)(n - 1) : 0.f;
             ss = short_s + short_base(sample_off, note);
         }
         const int t = (int)(f - fbase);
