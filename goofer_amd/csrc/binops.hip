@@ -353,8 +353,11 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
 #pragma unroll
                 for (int j = 1; j < 15; ++j) acc = fmaf(t175[j], ra[k + j - 7], acc);
             } else {
-                acc = t175[0] * ra[reflect_index(k - 7, n_bins)];
-                for (int j = 1; j < 15; ++j) acc = fmaf(t175[j], ra[reflect_index(k + j - 7, n_bins)], acc);
+                // single reflection is enough for a 7-bin reach; the general periodic map costs a 64-bit modulo
+                auto refl = [&](int q) { return q < 0 ? -q : (q >= n_bins ? 2 * (n_bins - 1) - q : q); };   // n_bins >= 257 (goofer_plan)
+                acc = t175[0] * ra[refl(k - 7)];
+#pragma unroll
+                for (int j = 1; j < 15; ++j) acc = fmaf(t175[j], ra[refl(k + j - 7)], acc);
             }
             e = acc;
         } else {

@@ -219,10 +219,10 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, dou
 // frame -> per-frame picks of the per-sample arrays: x[::hop] edge-padded to T (GOOFER.py:1104-1106)
 __device__ __forceinline__ int64_t pick_index(int64_t t, int64_t n, int hop)
 {
-    int64_t cnt = (n + hop - 1) / hop;            // len(x[::hop])
-    if (cnt <= 0) return 0;
-    int64_t q = t < cnt ? t : cnt - 1;
-    return q * hop;
+    if (n <= 0) return 0;
+    const int64_t at = t * hop;
+    if (at < n) return at;                        // t < len(x[::hop]): the usual case, no division
+    return ((n - 1) / hop) * hop;                 // edge-padded: the last pick
 }
 
 // 1 / (1 + exp(-clip((f - f0) / 5, -60, 60)))   GOOFER.py:1110-1111.  Hardware exp2 / rcp (1 ulp) and a multiply by

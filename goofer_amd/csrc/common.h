@@ -84,7 +84,9 @@ int goofer_fail(goofer_ctx *ctx, int code, const char *fmt, ...);
 __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n)
 {
     if (n <= 1) return 0;
-    int64_t period = 2 * (n - 1);
+    if (i >= 0 && i < n) return i;                           // in range: the usual case
+    const int64_t period = 2 * (n - 1);
+    if (i > -n && i < period) return i < 0 ? -i : period - i;   // one reflection, no 64-bit modulo (it costs ~100 instructions)
     int64_t m = i % period;
     if (m < 0) m += period;
     return m < n ? m : period - m;
