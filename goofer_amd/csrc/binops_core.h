@@ -38,6 +38,46 @@ __device__ __forceinline__ int np_search_guess(double key, const double *arr, in
     return imin - 1;
 }
 
+// np_search_guess as a table: for the short anchor arrays (len <= 6) the result depends on the key only through the six
+// comparisons key >= arr[k]; NP_SEARCH_TAB[len][mask][guess] is the function above evaluated on that bit mask (valid
+// for arr[0] <= key <= arr[len-1], which holds for the bin frequencies: arr[0] = 0, arr[len-1] = nyquist).
+struct np_search_tab_t {
+    signed char v[7][64][4];
+};
+constexpr int np_search_from_mask(unsigned m, int len, int guess)
+{
+    if (len <= 4) {
+        int i = 1;
+        while (i < len && ((m >> i) & 1u)) ++i;
+        return i - 1;
+    }
+    if (guess > len - 3) guess = len - 3;
+    if (guess < 1) guess = 1;
+    int imin = 0, imax = len;
+    if (!((m >> guess) & 1u)) {
+        if (!((m >> (guess - 1)) & 1u)) imax = guess - 1;
+        else return guess - 1;
+    } else {
+        if (!((m >> (guess + 1)) & 1u)) return guess;
+        if (!((m >> (guess + 2)) & 1u)) return guess + 1;
+        imin = guess + 2;
+    }
+    while (imin < imax) {
+        int imid = imin + ((imax - imin) >> 1);
+        if ((m >> imid) & 1u) imin = imid + 1; else imax = imid;
+    }
+    return imin - 1;
+}
+constexpr np_search_tab_t make_np_search_tab()
+{
+    np_search_tab_t t{};
+    for (int len = 2; len <= 6; ++len)
+        for (unsigned m = 0; m < 64; ++m)
+            for (int g = 0; g < 4; ++g) t.v[len][m][g] = (signed char)np_search_from_mask(m, len, g);
+    return t;
+}
+static __constant__ np_search_tab_t NP_SEARCH_TAB = make_np_search_tab();
+
 // np.interp value for index j (arr_interp inner body), xp/fp short arrays
 __device__ __forceinline__ double np_interp_eval(double x, int j, const double *xp, const double *fp, int len)
 {
@@ -159,39 +199,68 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, dou
         // Resolve np.interp's guess chain over the ascending bin frequencies.  The clamped guess
         // takes at most 3 values (1..len-3), so each bin is a map state->state; lanes own
         // contiguous chunks, compose their maps, scan across the wave, then replay.
+        // The anchors are parked in LDS first: the searches index them with run-time values, which on
+        // register arrays turns into long select chains (crossing formants are common: F1*1.3 vs F2*0.8).
+        if (lane < len) {
+            double xk = 0.0, yk = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (k == lane) { xk = dst[k]; yk = sp[k]; }
+            seg[lane] = xk;
+            seg[6 + lane] = yk;
+        }
+        wave_lds_sync();
+        const double *xp = seg, *fp = seg + 6;                // run-time indexed copies (np_interp_eval)
         const int per = (n_bins + WAVE - 1) / WAVE;
         const int b0 = lane * per;
+        const double a1 = dst[1], a2 = dst[2], a3 = dst[3], a4 = dst[4], a5 = len > 5 ? dst[5] : 0.0;   // len is 5 or 6 here
+        auto cmp_mask = [&](double x) {
+            unsigned m = 1u;                                  // x >= arr[0] = 0
+            m |= (unsigned)(x >= a1) << 1;
+            m |= (unsigned)(x >= a2) << 2;
+            m |= (unsigned)(x >= a3) << 3;
+            m |= (unsigned)(x >= a4) << 4;
+            m |= (unsigned)((len > 5) & (x >= a5)) << 5;
+            return m;
+        };
         auto clampg = [&](int g) { int hi = len - 3; if (g > hi) g = hi; if (g < 1) g = 1; return g; };
+        // lane m keeps the table row of comparison mask m (four results, one per guess, packed in a dword); a bin's row
+        // is then one cross-lane read away
+        const uint32_t my_row = reinterpret_cast<const uint32_t *>(NP_SEARCH_TAB.v[len])[lane];
+        auto lookup = [&](unsigned mask, int g) { return (int)(signed char)((__shfl((int)my_row, (int)mask, WAVE) >> (8 * g)) & 0xff); };
         int m1 = 1, m2 = 2, m3 = 3;                 // composed map of this lane's chunk: state s -> m_s
         for (int q = 0; q < per; ++q) {
             int b = b0 + q;
-            if (b >= n_bins) break;
             double x = b >= n_bins - 1 ? nyq : (double)b * step;
-            m1 = clampg(np_search_guess(x, dst, len, m1));
-            m2 = clampg(np_search_guess(x, dst, len, m2));
-            m3 = clampg(np_search_guess(x, dst, len, m3));
+            const int row = __shfl((int)my_row, (int)cmp_mask(x), WAVE);          // every lane takes part in the exchange
+            if (b < n_bins) {
+                m1 = clampg((int)(signed char)((row >> (8 * m1)) & 0xff));
+                m2 = clampg((int)(signed char)((row >> (8 * m2)) & 0xff));
+                m3 = clampg((int)(signed char)((row >> (8 * m3)) & 0xff));
+            }
         }
         // inclusive scan of map composition (earlier lanes apply first)
         for (int off = 1; off < WAVE; off <<= 1) {
             int p1 = __shfl_up(m1, off, WAVE), p2 = __shfl_up(m2, off, WAVE), p3 = __shfl_up(m3, off, WAVE);
             if (lane >= off) {
-                int a1 = p1 == 1 ? m1 : (p1 == 2 ? m2 : m3);
-                int a2 = p2 == 1 ? m1 : (p2 == 2 ? m2 : m3);
-                int a3 = p3 == 1 ? m1 : (p3 == 2 ? m2 : m3);
-                m1 = a1; m2 = a2; m3 = a3;
+                int a1_ = p1 == 1 ? m1 : (p1 == 2 ? m2 : m3);
+                int a2_ = p2 == 1 ? m1 : (p2 == 2 ? m2 : m3);
+                int a3_ = p3 == 1 ? m1 : (p3 == 2 ? m2 : m3);
+                m1 = a1_; m2 = a2_; m3 = a3_;
             }
         }
         // state entering this lane's chunk = inclusive result of lane-1 applied to the initial guess
         int incoming = __shfl_up(m1, 1, WAVE);       // initial j = 0 clamps to state 1
-        int guess = lane == 0 ? 0 : incoming;
+        int guess = lane == 0 ? 1 : incoming;
         for (int q = 0; q < per; ++q) {
             int b = b0 + q;
-            if (b >= n_bins) break;
             double x = b >= n_bins - 1 ? nyq : (double)b * step;
-            int j = np_search_guess(x, dst, len, guess);
-            guess = j;
-            double wf = np_interp_eval(x, j, dst, sp, len);
-            nxt[b] = (float)row_interp(cur, n_bins, step, inv_step, nyq, wf);
+            const int j = lookup(cmp_mask(x), guess);
+            if (b < n_bins) {
+                guess = clampg(j);
+                double wf = np_interp_eval(x, j, xp, fp, len);
+                nxt[b] = (float)row_interp(cur, n_bins, step, inv_step, nyq, wf);
+            }
         }
         }
         wave_lds_sync();
