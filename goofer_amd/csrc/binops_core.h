@@ -206,8 +206,13 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, dou
 #pragma unroll
             for (int k = 0; k < 6; ++k)
                 if (k == lane) { xk = dst[k]; yk = sp[k]; }
+            double xn = 0.0, yn = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (k == lane + 1 && k < len) { xn = dst[k]; yn = sp[k]; }
             seg[lane] = xk;
             seg[6 + lane] = yk;
+            seg[12 + lane] = lane < len - 1 ? (yn - yk) * fast_rcp(xn - xk) : 0.0;   // np.interp's slope of segment `lane`
         }
         wave_lds_sync();
         const double *xp = seg, *fp = seg + 6;                // run-time indexed copies (np_interp_eval)
@@ -258,7 +263,15 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, dou
             const int j = lookup(cmp_mask(x), guess);
             if (b < n_bins) {
                 guess = clampg(j);
-                double wf = np_interp_eval(x, j, xp, fp, len);
+                // np_interp_eval with the slope read from the per-segment table (0 <= j <= len - 1 for these keys)
+                double wf;
+                if (j >= len - 1) {
+                    wf = fp[len - 1];
+                } else {
+                    const double xj = xp[j], yj = fp[j];
+                    wf = x == xj ? yj : seg[12 + j] * (x - xj) + yj;
+                    if (isnan(wf)) wf = np_interp_eval(x, j, xp, fp, len);
+                }
                 nxt[b] = (float)row_interp(cur, n_bins, step, inv_step, nyq, wf);
             }
         }
