@@ -116,8 +116,10 @@ __global__ void k_row_src(const int64_t *__restrict__ frame_off, const int64_t *
 
 // f0 *= pitch_shift (GOOFER.py:995), fp32.  1024 samples per workgroup, 16-byte accesses when the tile sits in one note.
 __global__ __launch_bounds__(256) void k_scale_f0(const float *__restrict__ f0, const int64_t *__restrict__ sample_off, int n_notes,
-                                                  int64_t total, const goofer_note_params *__restrict__ params, float *__restrict__ out)
+                                                  int64_t total, const goofer_note_params *__restrict__ params, float *__restrict__ out,
+                                                  double *__restrict__ inc, double sr)
 {
+    // inc != nullptr: also the pulse tracker's increments (double)f0 / sr (GOOFER.py:491), saving k_phase_inc its pass
     __shared__ int s_pair[2];
     const int64_t g0 = (int64_t)blockIdx.x * 1024;
     int64_t gl = g0 + 1023;
@@ -132,12 +134,19 @@ __global__ __launch_bounds__(256) void k_scale_f0(const float *__restrict__ f0, 
         float4 v = *reinterpret_cast<const float4 *>(f0 + g);
         v.x *= ps; v.y *= ps; v.z *= ps; v.w *= ps;
         *reinterpret_cast<float4 *>(out + g) = v;
+        if (inc) {
+            double2 *io = reinterpret_cast<double2 *>(inc + g);
+            io[0] = make_double2((double)v.x / sr, (double)v.y / sr);
+            io[1] = make_double2((double)v.z / sr, (double)v.w / sr);
+        }
         return;
     }
     int note = lo;
     for (int k = 0; k < 4 && g + k < total; ++k) {
         while (sample_off[note + 1] <= g + k) ++note;
-        out[g + k] = f0[g + k] * params[note].pitch_shift;
+        const float v = f0[g + k] * params[note].pitch_shift;
+        out[g + k] = v;
+        if (inc) inc[g + k] = (double)v / sr;
     }
 }
 
@@ -1012,7 +1021,8 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, st))) return rc;
     hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, st, b->frame_off, b->env_off, frame_note, F, row_src);
     LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s);
+    hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s,
+                       jit_f0 ? (double *)nullptr : inc, (double)p.sr);     // jittered f0: increments after the jitter, below
     LAUNCH_CHECK(ctx);
     if (jit_f0 || jit_vol) {
         hipLaunchKernelGGL(k_note_flags, dim3((n + 255) / 256), dim3(256), 0, st, b->params, n, on_f0, on_vol);
@@ -1052,7 +1062,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
 
     MARK();   // 3..5: pulse train
     if (sev) HIP_TRY(ctx, hipEventRecord(sev[0], pst));
-    if ((rc = launch_phase_inc(ctx, f0s, 1.0f, N, inc, pst))) return rc;
+    if (jit_f0 && (rc = launch_phase_inc(ctx, f0s, 1.0f, N, inc, pst))) return rc;
     MARK();
     if (sev) HIP_TRY(ctx, hipEventRecord(sev[1], pst));
     if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, inc, b->sample_off, n, (onset_t *)onsets, onset_idx, onset_cnt, ovf, pst))) return rc;
