@@ -181,8 +181,10 @@ class Renderer:
         ctx._check(ctx.lib.goofer_post_batch(ctx.h, C.byref(P), ctx._stream()))
         out["_keep_post"] = (extra, post, s_host)
 
-    def prepare(self, jobs, phi_seeds=None):
-        """Plan every note on the host and make the batch resident in HBM (plans, tables, sources)."""
+    def prepare(self, jobs, phi_seeds=None, note_ids=None):
+        """Plan every note on the host and make the batch resident in HBM (plans, tables, sources).
+        ``note_ids`` key the on-device noise phases (default: the position in ``jobs``), so a note can render to the
+        same bits whatever batch or rank it lands in."""
         ctx = self.ctx
         sr, n_fft = jobs[0][0].sr, jobs[0][0].n_fft
         if any(j[0].sr != sr or j[0].n_fft != n_fft for j in jobs):
@@ -321,7 +323,8 @@ class Renderer:
             par[i]["normalize"] = req.normalize
             par[i]["mix_harm"], par[i]["mix_breath"], par[i]["mix_unvoiced"] = req.harmonic_mix, req.breathiness_mix, req.unvoiced_mix
             par[i]["volume"] = req.volume
-            par[i]["seed"] = [i & 0xFFFFFFFF, 0]
+            nid = int(note_ids[i]) if note_ids is not None else i      # Philox stream of the note: its id, not its batch position
+            par[i]["seed"] = [nid & 0xFFFFFFFF, (nid >> 32) & 0xFFFFFFFF]
             if req.f0_jitter:
                 par[i]["f0_jitter"] = req.f0_jitter_strength
             if req.volume_jitter:

@@ -160,7 +160,7 @@ class SamplerWorkload:
             self.raw.append((src, req, phi_seed))
             jobs.append((Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]),
                          S.decode_request(*syn.request_args(req))))
-        self.prep = self.renderer.prepare(jobs)
+        self.prep = self.renderer.prepare(jobs, note_ids=[int(i) for i in note_ids])
         self.frames, self.samples = self.prep["frames"], self.prep["samples"]
         self.notes = jobs
 
