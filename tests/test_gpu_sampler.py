@@ -216,3 +216,51 @@ def test_dense_feature_source_vs_oracle(renderer):
     for o, ref in zip(outs, refs):
         assert o.shape == ref.shape
         assert rms_err(o, ref) / max(1.0, float(np.max(np.abs(ref)))) < 2e-5
+
+
+def _random_flags(rng):
+    """A random subset of the reference's flag vocabulary with in-range values (SillySampler.py:307-410)."""
+    pool = {
+        "g": lambda: int(rng.integers(-80, 81)), "t": lambda: int(rng.integers(-300, 301)), "br": lambda: int(rng.integers(-60, 61)),
+        "es": lambda: int(rng.integers(-80, 81)), "fw": lambda: int(rng.integers(-80, 81)), "fa": lambda: int(rng.integers(-30, 31)),
+        "fb": lambda: int(rng.integers(-30, 31)), "fc": lambda: int(rng.integers(-20, 21)), "fd": lambda: int(rng.integers(-20, 21)),
+        "fst": lambda: int(rng.integers(-60, 61)), "fsta": lambda: int(rng.integers(-40, 41)), "fstc": lambda: int(rng.integers(-40, 41)),
+        "V": lambda: int(rng.integers(40, 101)), "B": lambda: int(rng.integers(-50, 51)), "U": lambda: int(rng.integers(-50, 51)),
+        "P": lambda: int(rng.integers(0, 101)), "L": lambda: int(rng.integers(0, 3)), "R": lambda: int(rng.integers(0, 2)),
+        "FV": lambda: int(rng.integers(0, 2)), "sh": lambda: int(rng.integers(10, 80)), "sr": lambda: int(rng.integers(10, 80)),
+        "sg": lambda: int(rng.integers(10, 80)), "su": lambda: int(rng.integers(10, 80)), "sj": lambda: int(rng.integers(10, 60)),
+        "sa": lambda: int(rng.integers(10, 60)), "st": lambda: int(rng.integers(-80, 81)), "sd": lambda: int(rng.integers(10, 60)),
+        "vf": lambda: int(rng.integers(-60, 61)), "vh": lambda: int(rng.integers(30, 80)), "vl": lambda: int(rng.integers(0, 60)),
+        "pd": lambda: int(rng.integers(-80, 81)),
+    }
+    keys = list(pool)
+    chosen = rng.choice(len(keys), size=int(rng.integers(3, 9)), replace=False)
+    return "".join(f"{keys[i]}{pool[keys[i]]()}" for i in sorted(chosen))
+
+
+@pytest.mark.parametrize("case", range(48))
+def test_random_flag_combinations_vs_oracle(renderer, case):
+    """Flag interactions: random subsets of the whole vocabulary (assembly edits, jitter / sub-harmonic layers, post chain
+    together), one note at a time so the legacy-RNG draw order matches, against the oracle's full render."""
+    from goofer_amd.render import Source
+    from goofer_amd import sampler as S
+    from oracle import sampler_ref as SR
+    rng = np.random.default_rng(9000 + case)
+    src = syn.make_source(4000 + case, seconds=float(rng.uniform(0.3, 0.6)))
+    flags = _random_flags(rng)
+    pitch = ["A3", "C4", "E4", "G#4", "D5"][int(rng.integers(0, 5))]
+    args = (pitch, str(int(rng.choice([60, 100, 140]))), flags, str(int(rng.integers(0, 60))), str(int(rng.integers(200, 700))),
+            str(int(rng.integers(0, 120))), str(int(rng.choice([-200, 30, 80]))), str(int(rng.integers(50, 121))), "0",
+            "!" + str(int(rng.choice([90, 120, 150]))), ["AA", "AA#5#AF#3#/+", "B7CPCV#2#Cb"][int(rng.integers(0, 3))])
+    feats = (src["env_pack"], src["f0"].copy(), src["mask"].copy(), {k: v.copy() for k, v in src["formants"].items()},
+             src["sr"], src["y_len"])
+    seed = 800 + case
+    np.random.seed(77 + case)
+    ref = SR.render(feats, SR.decode_request(*args), seed=seed)
+    source = Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+    np.random.seed(77 + case)
+    (out,) = renderer.render([(source, S.decode_request(*args))], phi_seeds=[seed])
+    assert out.shape == ref.shape, (flags, out.shape, ref.shape)
+    assert np.all(np.isfinite(out)), flags
+    e = rms_err(out, ref) / max(1.0, float(np.max(np.abs(ref))))
+    assert e < TOL, (flags, args, e)
