@@ -64,3 +64,23 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "from . import oracle" not in src and "/root/reference" not in src, f
+
+
+def test_c_host_example_compiles_and_links(tmp_path):
+    """examples/c_host.c is a torch-free C99 host for the ABI: it must compile with plain gcc against include/ and link
+    against the built library (it runs only where an MI355X is visible)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "goofer_amd", "libgoofer_hip.so")
+    if not os.path.exists(lib) or shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("needs the built library, gcc and the ROCm headers")
+    out = tmp_path / "c_host"
+    cmd = ["gcc", "-std=c99", "-Wall", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "examples", "c_host.c"),
+           "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", "-L" + os.path.join(root, "goofer_amd"), "-lgoofer_hip",
+           "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + os.path.join(root, "goofer_amd"), "-Wl,-rpath,/opt/rocm/lib",
+           "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out.exists()
