@@ -239,3 +239,23 @@ def test_onepole_cascade_vs_reference(ctx):
         ref = SR.dynamic_filter(ref, np.maximum(fs[o:o + n], 120.0), 44100, 1.0, order=6, btype="highpass")
         assert np.max(np.abs(y[o:o + n] - ref)) < 1e-6 * max(1.0, float(np.max(np.abs(ref)))), n
         o += n
+
+
+def test_stretch_rows_vs_oracle(ctx):
+    """goofer_stretch_rows = gf.stretch_feature (np.interp on normalised coordinates) for 1-D arrays and row matrices,
+    growing and shrinking, including the single-knot and single-output corner cases."""
+    from oracle import goofer_ref as R
+    ctx.plan(44100, 1024, 256)
+    rng = np.random.default_rng(21)
+    for n_in, factor in ((1000, 1.37), (1000, 0.41), (70001, 1.003), (5, 3.2), (1, 4.0), (3, 0.34)):
+        x = rng.standard_normal(n_in).astype(np.float32)
+        ref = R.stretch_feature(x, factor)
+        got = ctx.stretch_rows(ctx.tensor(x), len(ref)).cpu().numpy()
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref.astype(np.float32))) <= 1e-6 * max(1.0, float(np.max(np.abs(ref)))) if len(ref) else True
+    for T, factor in ((37, 1.6), (200, 0.55), (2, 2.5)):
+        M = rng.random((ctx.n_bins, T)).astype(np.float32)
+        ref = R.stretch_feature(M, factor)                          # [bins, T']
+        got = ctx.stretch_rows(ctx.rows_from(M.T), ref.shape[1]).cpu().numpy().T
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref.astype(np.float32))) <= 1e-6
