@@ -123,6 +123,7 @@ EXPORTS = {
     "goofer_debug_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "goofer_debug_fetch": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "goofer_sizeof": (C.c_int, [C.c_int]),
+    "goofer_gauss_rows_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goofer_stretch_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "goofer_onepole_cascade": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "goofer_post_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

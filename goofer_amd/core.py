@@ -133,6 +133,150 @@ def gaussian_taps(sigma, truncate=4.0):
 
 
 # -- analysis: the half of extract_features that is not Praat (GOOFER.py:940-969, 97-147) ------------------
+# -- small numeric helpers the reference exposes at module level (SillySampler.py / SillyEditor.py call them) ---------
+def to_compute(x):
+    return np.asarray(x, dtype=np.float32)                      # GOOFER.py:72
+
+
+def hz_to_mel(hz):
+    return 2595.0 * np.log10(1.0 + hz / 700.0)                  # GOOFER.py:74
+
+
+def mel_to_hz(m):
+    return 700.0 * (10 ** (m / 2595.0) - 1.0)                   # GOOFER.py:75
+
+
+def rms(x):
+    return float(np.sqrt(np.mean(np.square(x)) + 1e-12))        # GOOFER.py:170-171 (a scalar reduction: host)
+
+
+def gaussian_filter1d(input_array, sigma, axis=-1, truncate=4.0, ctx=None):
+    """gf.gaussian_filter1d (GOOFER.py:241-261) on the device: numpy-'reflect' padding, fp64 accumulate in tap order,
+    every 1-D line along ``axis`` filtered independently.  Returns float64 (complex128 for complex input)."""
+    arr = np.asarray(input_array)
+    if arr.size == 0 or arr.shape[axis] == 0 or sigma <= 0.0:
+        return arr.copy()
+    radius = int(truncate * sigma + 0.5)
+    if radius <= 0:
+        return arr.copy()
+    if np.iscomplexobj(arr):
+        return (gaussian_filter1d(arr.real, sigma, axis, truncate, ctx) +
+                1j * gaussian_filter1d(arr.imag, sigma, axis, truncate, ctx))
+    c = ctx or default_context()
+    moved = np.moveaxis(arr, axis, -1)
+    lines = np.ascontiguousarray(moved, dtype=np.float64).reshape(-1, moved.shape[-1])
+    out = c.gauss_rows_f64(c.tensor(lines), gaussian_taps(sigma, truncate)).cpu().numpy()
+    return np.moveaxis(out.reshape(moved.shape), -1, axis)
+
+
+def gaussian_filter(input_array, sigma, ctx=None):
+    """gf.gaussian_filter (GOOFER.py:263-285): separable, sigma a float or a (rows, cols) pair."""
+    arr = np.asarray(input_array)
+    if arr.ndim != 2:
+        raise ValueError("gaussian_filter expects a 2D array.")
+    if arr.size == 0 or arr.shape[0] == 0 or arr.shape[1] == 0:
+        return arr.copy()
+    if isinstance(sigma, (list, tuple)):
+        if len(sigma) != 2:
+            raise ValueError("sigma must be a float or a 2-tuple for 2D arrays.")
+        s0, s1 = (max(float(v), 0.0) for v in sigma)
+    else:
+        s0 = s1 = max(float(sigma), 0.0)
+    out = arr
+    if s0 > 0.0:
+        out = gaussian_filter1d(out, s0, axis=0, ctx=ctx)
+    if s1 > 0.0:
+        out = gaussian_filter1d(out, s1, axis=1, ctx=ctx)
+    return out
+
+
+def interp1d(x, y, kind="linear", fill_value="extrapolate"):
+    """gf.interp1d (GOOFER.py:173-239): a callable linear interpolant with linear extrapolation (edge slopes carry the
+    reference's +1e-10) or a constant fill.  A host-side convenience, like the reference's; the hot path does its
+    interpolations in the kernels."""
+    if kind != "linear":
+        raise ValueError("Only 'linear' interpolation is supported.")
+    x, y = np.asarray(x), np.asarray(y)
+    if len(x) == 0:
+        raise ValueError("x cannot be empty")
+    if fill_value != "extrapolate":
+        try:
+            fill = float(fill_value)
+        except (TypeError, ValueError):
+            raise ValueError("fill_value must be 'extrapolate' or a number")
+    if len(x) == 1:
+        def one(q):
+            q = np.asarray(q)
+            if fill_value == "extrapolate":
+                return np.full_like(q, y[0], dtype=y.dtype)
+            out = np.full_like(q, fill)
+            out[np.isclose(q, x[0])] = y[0]
+            return out
+        return one
+    left = (y[1] - y[0]) / (x[1] - x[0] + 1e-10)
+    right = (y[-1] - y[-2]) / (x[-1] - x[-2] + 1e-10)
+
+    def f(q):
+        q = np.asarray(q)
+        if fill_value != "extrapolate":
+            inside = (q >= x[0]) & (q <= x[-1])
+            out = np.empty_like(q)
+            if np.any(inside):
+                out[inside] = np.interp(q[inside], x, y)
+            out[~inside] = fill
+            return out
+        out = np.interp(q, x, y)
+        lo, hi = q < x[0], q > x[-1]
+        if np.any(lo):
+            out[lo] = y[0] + left * (q[lo] - x[0])
+        if np.any(hi):
+            out[hi] = y[-1] + right * (q[hi] - x[-1])
+        return out
+    return f
+
+
+def stretch_feature(feature, stretch, kind="linear", ctx=None):
+    """gf.stretch_feature (GOOFER.py:597-616) on the device (fp32 rows in, fp64 math, fp32 out like the synth uses it)."""
+    feature = np.asarray(feature)
+    if stretch == 1.0:
+        return feature.copy()
+    if kind != "linear":
+        raise ValueError("Only 'linear' interpolation is supported.")
+    c = ctx or default_context()
+    n_new = int(feature.shape[-1] * stretch)
+    if feature.ndim == 1:
+        if len(feature) == 0:
+            raise ValueError("x cannot be empty")
+        return c.stretch_rows(c.tensor(feature.astype(np.float32)), n_new).cpu().numpy().astype(np.float64)
+    if feature.ndim == 2:
+        if feature.shape[1] == 0:
+            raise ValueError("x cannot be empty")
+        rows = torch.empty((feature.shape[1], feature.shape[0]), dtype=torch.float32, device=c.device)
+        rows.copy_(torch.as_tensor(np.ascontiguousarray(feature.T, dtype=np.float32)))
+        return c.stretch_rows(rows, n_new).cpu().numpy().T.astype(np.float64)
+    raise ValueError("Only 1D or 2D features are supported.")
+
+
+def create_volume_jitter(length, sr, speed=6.0, strength=0.1, seed=None, vibrato=False, ctx=None):
+    """gf.create_volume_jitter (GOOFER.py:638-660): a sinusoid with a 0.1 s fade-in (vibrato) or smoothed legacy-RNG noise
+    (the Gaussian FIR of sigma = sr / (6 speed) runs on the device), as 1 + x * strength."""
+    if seed is not None:
+        np.random.seed(seed)
+    t = np.arange(length) / sr
+    if vibrato:
+        phase = np.random.uniform(0, 2 * np.pi) if seed is not None else 0
+        noise = np.sin(2 * np.pi * speed * t + phase)
+        fade = int(0.1 * sr)
+        if fade < length:
+            noise[:fade] *= np.linspace(0, 1, fade)
+    else:
+        noise = np.random.randn(len(t))
+        noise = gaussian_filter1d(noise, sigma=sr / (speed * 6), ctx=ctx)
+        noise /= np.max(np.abs(noise) + 1e-6)
+    envelope = 1.0 + noise * strength
+    return np.clip(envelope, 0.5, 1.5) if vibrato else envelope
+
+
 def make_mel_knots(sr, n_fft, K):
     """(bin freqs fp32, mel-spaced knot Hz fp32) — the codec's knot grid (GOOFER.py:77-82)."""
     from .synthetic import mel_knots_hz

@@ -745,6 +745,21 @@ int goofer_stretch_rows(goofer_ctx *ctx, const float *in, int64_t ld_in, int64_t
     return launch_lerp_axis0(ctx, in, ld_in, rows_in, out, ld_out, rows_out, n_cols, (hipStream_t)stream);
 }
 
+int goofer_gauss_rows_f64(goofer_ctx *ctx, const double *in, const int64_t *row_off, int n_rows, int64_t total, const double *taps,
+                          int radius, double *out, void *stream)
+{
+    if (!ctx) return GOOFER_EINVAL;
+    if (!in || !out || !row_off || !taps) return goofer_fail(ctx, GOOFER_EINVAL, "null pointer");
+    if (radius < 0 || radius > 1920) return goofer_fail(ctx, GOOFER_EINVAL, "gaussian radius %d outside [0, 1920]", radius);
+    if (n_rows <= 0 || total <= 0) return GOOFER_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_small(ctx, 65536 + 3 * 16384);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->small, taps, (2 * radius + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));                   // the caller's taps buffer may be transient
+    return launch_gauss_samples<double>(ctx, in, row_off, n_rows, total, (const double *)ctx->small, radius, nullptr, out, st);
+}
+
 int goofer_onepole_cascade(goofer_ctx *ctx, const float *src, float *dst, const float *f0, const goofer_onepole_job *jobs, int n_jobs,
                            void *stream)
 {

@@ -226,6 +226,16 @@ class Context:
         r.copy_(torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)))
         return r
 
+    def gauss_rows_f64(self, x, taps: np.ndarray):
+        """gf.gaussian_filter1d along the last axis of an fp64 [rows, L] device tensor (each row its own reflect padding)."""
+        taps = np.ascontiguousarray(taps, dtype=np.float64)
+        rows, L = x.shape
+        off = self.tensor(np.arange(rows + 1, dtype=np.int64) * L)
+        out = torch.empty_like(x)
+        self._check(self.lib.goofer_gauss_rows_f64(self.h, _ptr(x), _ptr(off), rows, rows * L, taps.ctypes.data_as(C.c_void_p),
+                                                   (taps.size - 1) // 2, _ptr(out), self._stream()))
+        return out
+
     def stretch_rows(self, x, rows_out: int):
         """gf.stretch_feature along axis 0 (GOOFER.py:597-616): a 1-D fp32 tensor, or an ld-strided [rows, bins] view."""
         if x.dim() == 1:

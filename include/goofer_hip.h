@@ -286,6 +286,11 @@ int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *assembly, void
 int goofer_stretch_rows(goofer_ctx *ctx, const float *in, int64_t ld_in, int64_t rows_in, float *out, int64_t ld_out,
                         int64_t rows_out, int n_cols, void *stream);
 
+/* gf.gaussian_filter1d along the last axis of ragged fp64 rows (GOOFER.py:241-261: numpy 'reflect' padding, fp64
+ * accumulate in tap order): row r is in[row_off[r] .. row_off[r+1]) (device CSR); taps are HOST memory, 2*radius+1. */
+int goofer_gauss_rows_f64(goofer_ctx *ctx, const double *in, const int64_t *row_off, int n_rows, int64_t total, const double *taps,
+                          int radius, double *out, void *stream);
+
 /* dynamic_butter_filter (SillySampler.py:95-174) for a list of jobs (device array): src -> dst, fp32. */
 int goofer_onepole_cascade(goofer_ctx *ctx, const float *src, float *dst, const float *f0, const goofer_onepole_job *jobs,
                            int n_jobs, void *stream);

@@ -259,3 +259,36 @@ def test_stretch_rows_vs_oracle(ctx):
         got = ctx.stretch_rows(ctx.rows_from(M.T), ref.shape[1]).cpu().numpy().T
         assert got.shape == ref.shape
         assert np.max(np.abs(got - ref.astype(np.float32))) <= 1e-6
+
+
+def test_module_level_helpers_vs_oracle(ctx):
+    """gf.gaussian_filter1d / gaussian_filter / stretch_feature / create_volume_jitter as the reference exposes them
+    (SillySampler.py and SillyEditor.py call them on the module)."""
+    from goofer_amd import core
+    from oracle import goofer_ref as R
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal(5000)
+    for sigma in (0.5, 2.0, 20.0, 73.5):
+        a, b = core.gaussian_filter1d(x, sigma, ctx=ctx), R.gauss1d(x, sigma)
+        assert a.dtype == np.float64 and a.shape == b.shape and np.max(np.abs(a - b)) < 1e-13
+    short = rng.standard_normal(7)                                   # radius larger than the array: multiple reflections
+    assert np.max(np.abs(core.gaussian_filter1d(short, 3.0, ctx=ctx) - R.gauss1d(short, 3.0))) < 1e-13
+    M = rng.random((33, 40))
+    for axis in (0, 1):
+        assert np.max(np.abs(core.gaussian_filter1d(M, 1.75, axis=axis, ctx=ctx) - R.gauss1d(M, 1.75, axis=axis))) < 1e-13
+    assert np.max(np.abs(core.gaussian_filter(M, (0.5, 0), ctx=ctx) - R.gauss2d(M, (0.5, 0)))) < 1e-13
+    Z = M[:, :20] + 1j * M[:, 20:]
+    assert np.max(np.abs(core.gaussian_filter1d(Z, 0.5, axis=0, ctx=ctx) - R.gauss1d(Z, 0.5, axis=0))) < 1e-13
+    assert core.gaussian_filter1d(x, 0.0, ctx=ctx) is not x and np.array_equal(core.gaussian_filter1d(x, 0.0, ctx=ctx), x)
+    f = rng.random(300).astype(np.float32)
+    assert np.max(np.abs(core.stretch_feature(f, 1.7, ctx=ctx) - R.stretch_feature(f, 1.7))) < 1e-6
+    E = rng.random((513, 21)).astype(np.float32)
+    assert np.max(np.abs(core.stretch_feature(E, 0.6, ctx=ctx) - R.stretch_feature(E, 0.6))) < 1e-6
+    np.random.seed(5)
+    a = core.create_volume_jitter(4000, 44100, speed=150, strength=0.8, ctx=ctx)
+    np.random.seed(5)
+    b = R.volume_jitter_curve(4000, 44100, speed=150.0, strength=0.8)
+    assert np.max(np.abs(a - b)) < 1e-12
+    assert np.array_equal(core.create_volume_jitter(4000, 44100, speed=150.0, strength=0.15, vibrato=True, ctx=ctx),
+                          R.volume_jitter_curve(4000, 44100, speed=150.0, strength=0.15, vibrato=True))
+    assert abs(core.rms(x) - R.rms(x)) < 1e-15

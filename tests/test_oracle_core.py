@@ -197,3 +197,19 @@ def test_goofy_files(tmp_path):
     assert np.array_equal(env2, g2["env"]) and np.array_equal(f02, g2["f0"])
     for k in (1, 2, 3, 4):
         assert np.array_equal(forms2[k], g2["formant_%d" % k])
+
+
+def test_product_interp1d_matches_oracle_interpolant():
+    """goofer_amd.core.interp1d (host helper of the reference's module surface) against the oracle's LinInterp."""
+    from goofer_amd import core
+    rng = np.random.default_rng(4)
+    x = np.sort(rng.random(12)) * 10
+    y = rng.standard_normal(12)
+    q = np.linspace(-3, 14, 101)
+    assert np.array_equal(core.interp1d(x, y)(q), R.LinInterp(x, y)(q))
+    assert np.array_equal(core.interp1d(x, y, fill_value=0.5)(q), R.LinInterp(x, y, fill=0.5)(q))
+    assert np.array_equal(core.interp1d([2.0], [7.0])(q), R.LinInterp([2.0], np.array([7.0]))(q))
+    with pytest.raises(ValueError):
+        core.interp1d([], [])
+    with pytest.raises(ValueError):
+        core.interp1d(x, y, kind="cubic")
