@@ -84,3 +84,12 @@ def test_c_host_example_compiles_and_links(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert out.exists()
+
+
+def test_core_exposes_the_reference_module_surface():
+    """Every GOOFER.py name that SillySampler.py / SillyEditor.py / test.py reach through `gf.` (SURVEY §8 b)."""
+    from goofer_amd import core
+    for name in ("extract_features", "synthesize", "save_features", "load_features", "decode_env_from_knots", "interp1d",
+                 "gaussian_filter1d", "gaussian_filter", "stretch_feature", "create_volume_jitter", "rms", "pulse_train_numba",
+                 "stft", "istft", "compress_env_to_knots", "make_mel_knots", "formants_to_int_keys", "to_compute"):
+        assert callable(getattr(core, name)), name
