@@ -182,3 +182,24 @@ def config_note(config: int, i: int) -> tuple:
         length = float(np.exp(rng.uniform(np.log(100.0), np.log(3000.0))))
     req = make_request(1000 + i, config_flags(config, i), length_ms=round(length))
     return src, req, 5000 + i
+
+
+def random_flags(rng) -> str:
+    """A random subset (3-8 flags) of the reference's flag vocabulary with in-range values (SillySampler.py:307-410):
+    used by the flag-interaction fixtures (tests/golden/make_golden.py) and the fuzz tests."""
+    pool = {
+        "g": lambda: int(rng.integers(-80, 81)), "t": lambda: int(rng.integers(-300, 301)), "br": lambda: int(rng.integers(-60, 61)),
+        "es": lambda: int(rng.integers(-80, 81)), "fw": lambda: int(rng.integers(-80, 81)), "fa": lambda: int(rng.integers(-30, 31)),
+        "fb": lambda: int(rng.integers(-30, 31)), "fc": lambda: int(rng.integers(-20, 21)), "fd": lambda: int(rng.integers(-20, 21)),
+        "fst": lambda: int(rng.integers(-60, 61)), "fsta": lambda: int(rng.integers(-40, 41)), "fstc": lambda: int(rng.integers(-40, 41)),
+        "V": lambda: int(rng.integers(40, 101)), "B": lambda: int(rng.integers(-50, 51)), "U": lambda: int(rng.integers(-50, 51)),
+        "P": lambda: int(rng.integers(0, 101)), "L": lambda: int(rng.integers(0, 3)), "R": lambda: int(rng.integers(0, 2)),
+        "FV": lambda: int(rng.integers(0, 2)), "sh": lambda: int(rng.integers(10, 80)), "sr": lambda: int(rng.integers(10, 80)),
+        "sg": lambda: int(rng.integers(10, 80)), "su": lambda: int(rng.integers(10, 80)), "sj": lambda: int(rng.integers(10, 60)),
+        "sa": lambda: int(rng.integers(10, 60)), "st": lambda: int(rng.integers(-80, 81)), "sd": lambda: int(rng.integers(10, 60)),
+        "vf": lambda: int(rng.integers(-60, 61)), "vh": lambda: int(rng.integers(30, 80)), "vl": lambda: int(rng.integers(0, 60)),
+        "pd": lambda: int(rng.integers(-80, 81)),
+    }
+    keys = list(pool)
+    chosen = rng.choice(len(keys), size=int(rng.integers(3, 9)), replace=False)
+    return "".join(f"{keys[i]}{pool[keys[i]]()}" for i in sorted(chosen))

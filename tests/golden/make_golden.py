@@ -504,6 +504,32 @@ def gen_sampler():
     save("sampler_index", names=np.array(index))
 
 
+N_COMBOS = 16
+
+
+def gen_sampler_combos():
+    """Flag interactions pinned by the reference itself: 16 random subsets of the whole flag vocabulary (assembly edits,
+    jitter / sub-harmonic layers and the post chain together), rendered by the real GooferResampler."""
+    names = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for i in range(N_COMBOS):
+            rng = np.random.default_rng(7700 + i)
+            flags = syn.random_flags(rng)
+            src = syn.make_source(5000 + i, seconds=float(rng.uniform(0.3, 0.55)))
+            req = syn.make_request(5000 + i, flags, length_ms=float(rng.integers(200, 700)), offset_ms=float(rng.integers(0, 60)),
+                                   consonant_ms=float(rng.integers(0, 120)), cutoff_ms=float(rng.choice([-200, 30, 80])),
+                                   velocity=float(rng.choice([60, 100, 140])), volume=float(rng.integers(50, 121)),
+                                   tempo=float(rng.choice([90, 120, 150])))
+            seed = 6500 + i
+            out, sr, cap, _ = _run_sampler(src, req, seed, tmp, legacy_seed=4500 + i)
+            name = "combo_%02d" % i
+            save(name, out=out, seed=np.array([seed, 4500 + i, 5000 + i]), args=np.array(syn.request_args(req)),
+                 seconds=np.array([src["y_len"] / src["sr"]]), n_calls=np.array([len(cap.calls)]))
+            names.append(name)
+            print(name, flags, "synth calls:", len(cap.calls), flush=True)
+    save("combo_index", names=np.array(names))
+
+
 def gen_index_plans():
     """Loop-mode / slicing index plans, bit-exact: feed env[b,t] = t and mask[n] = n so the
     assembled arrays spell out which source frame / sample every output position came from."""
@@ -598,7 +624,10 @@ def gen_post_chain():
     save("post_chain", **out)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 1:
+    for which in sys.argv[1:]:                         # regenerate only the named groups, e.g. `make_golden.py sampler_combos`
+        globals()["gen_" + which]()
+elif __name__ == "__main__":
     gen_tables()
     gen_stft_istft()
     gen_pulse()
@@ -612,5 +641,6 @@ if __name__ == "__main__":
     gen_post_chain()
     gen_index_plans()
     gen_sampler()
+    gen_sampler_combos()
     total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE))
     print("total fixture bytes: %.1f MB" % (total / 1e6))

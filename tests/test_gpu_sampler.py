@@ -218,24 +218,7 @@ def test_dense_feature_source_vs_oracle(renderer):
         assert rms_err(o, ref) / max(1.0, float(np.max(np.abs(ref)))) < 2e-5
 
 
-def _random_flags(rng):
-    """A random subset of the reference's flag vocabulary with in-range values (SillySampler.py:307-410)."""
-    pool = {
-        "g": lambda: int(rng.integers(-80, 81)), "t": lambda: int(rng.integers(-300, 301)), "br": lambda: int(rng.integers(-60, 61)),
-        "es": lambda: int(rng.integers(-80, 81)), "fw": lambda: int(rng.integers(-80, 81)), "fa": lambda: int(rng.integers(-30, 31)),
-        "fb": lambda: int(rng.integers(-30, 31)), "fc": lambda: int(rng.integers(-20, 21)), "fd": lambda: int(rng.integers(-20, 21)),
-        "fst": lambda: int(rng.integers(-60, 61)), "fsta": lambda: int(rng.integers(-40, 41)), "fstc": lambda: int(rng.integers(-40, 41)),
-        "V": lambda: int(rng.integers(40, 101)), "B": lambda: int(rng.integers(-50, 51)), "U": lambda: int(rng.integers(-50, 51)),
-        "P": lambda: int(rng.integers(0, 101)), "L": lambda: int(rng.integers(0, 3)), "R": lambda: int(rng.integers(0, 2)),
-        "FV": lambda: int(rng.integers(0, 2)), "sh": lambda: int(rng.integers(10, 80)), "sr": lambda: int(rng.integers(10, 80)),
-        "sg": lambda: int(rng.integers(10, 80)), "su": lambda: int(rng.integers(10, 80)), "sj": lambda: int(rng.integers(10, 60)),
-        "sa": lambda: int(rng.integers(10, 60)), "st": lambda: int(rng.integers(-80, 81)), "sd": lambda: int(rng.integers(10, 60)),
-        "vf": lambda: int(rng.integers(-60, 61)), "vh": lambda: int(rng.integers(30, 80)), "vl": lambda: int(rng.integers(0, 60)),
-        "pd": lambda: int(rng.integers(-80, 81)),
-    }
-    keys = list(pool)
-    chosen = rng.choice(len(keys), size=int(rng.integers(3, 9)), replace=False)
-    return "".join(f"{keys[i]}{pool[keys[i]]()}" for i in sorted(chosen))
+_random_flags = syn.random_flags
 
 
 @pytest.mark.parametrize("case", range(48))
@@ -264,3 +247,28 @@ def test_random_flag_combinations_vs_oracle(renderer, case):
     assert np.all(np.isfinite(out)), flags
     e = rms_err(out, ref) / max(1.0, float(np.max(np.abs(ref))))
     assert e < TOL, (flags, args, e)
+
+
+COMBOS = [str(n) for n in golden("combo_index")["names"]]
+
+
+@pytest.mark.parametrize("name", COMBOS)
+def test_flag_combinations_match_reference(renderer, name):
+    """The same 16 random flag subsets the reference rendered (tests/golden/combo_*.npz), on the device."""
+    from goofer_amd.render import Source
+    from goofer_amd import sampler as S
+    g = golden(name)
+    i = COMBOS.index(name)
+    rng = np.random.default_rng(7700 + i)
+    flags = syn.random_flags(rng)
+    src = syn.make_source(5000 + i, seconds=float(rng.uniform(0.3, 0.55)))
+    args = [str(a) for a in g["args"]]
+    assert args[2] == flags
+    seed, legacy, _ = (int(v) for v in g["seed"])
+    source = Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+    np.random.seed(legacy)
+    (out,) = renderer.render([(source, S.decode_request(*args))], phi_seeds=[seed])
+    ref = g["out"]
+    assert out.shape == ref.shape
+    e = rms_err(out, ref) / max(1.0, float(np.max(np.abs(ref))))
+    assert e < TOL, (flags, e)

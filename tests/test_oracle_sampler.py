@@ -138,3 +138,32 @@ def test_render_against_reference(name):
             assert rms_err(got, g[key]) < 3e-6, (name, key)
     scale = max(1.0, float(np.max(np.abs(ref))))
     assert rms_err(out, ref) < 1e-5 * scale, (name, rms_err(out, ref), scale)
+
+
+COMBOS = [str(n) for n in golden("combo_index")["names"]]
+
+
+def _combo(name):
+    """The source of a flag-interaction fixture, rebuilt with the generator's own draws (make_golden.gen_sampler_combos)."""
+    g = golden(name)
+    i = COMBOS.index(name)
+    rng = np.random.default_rng(7700 + i)
+    flags = syn.random_flags(rng)
+    src = syn.make_source(5000 + i, seconds=float(rng.uniform(0.3, 0.55)))
+    args = [str(a) for a in g["args"]]
+    assert args[2] == flags and abs(src["y_len"] / src["sr"] - float(g["seconds"][0])) < 1e-9
+    return g, src, args
+
+
+@pytest.mark.parametrize("name", COMBOS)
+def test_flag_combinations_against_reference(name):
+    """Random subsets of the whole flag vocabulary rendered by the reference itself: the oracle must follow it through
+    every interaction (assembly edits + jitter / sub-harmonic layers + post chain in one note)."""
+    g, src, args = _combo(name)
+    seed, legacy, _ = (int(v) for v in g["seed"])
+    np.random.seed(legacy)
+    out = S.render(_features(src), S.decode_request(*args), seed=seed)
+    ref = g["out"]
+    assert out.shape == ref.shape
+    scale = max(1.0, float(np.max(np.abs(ref))))
+    assert rms_err(out, ref) < 1e-5 * scale, (name, args[2], rms_err(out, ref), scale)
