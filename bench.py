@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--notes", type=int, default=1024, help="notes per GPU (weak scaling)")
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (1-based)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="also time the optional ragged gather of finished audio to rank 0 "
+                    "(RCCL over xGMI; never part of `value`)")
     args = ap.parse_args()
 
     import torch
@@ -208,6 +210,19 @@ def main():
     rfft_ms = e0.elapsed_time(e1) / args.steps
     del xin, Sout
 
+    gather_ms = None
+    if args.gather:
+        from goofer_amd.shard import gather_audio
+        out = wl.step()
+        barrier()
+        g0 = time.perf_counter()
+        got = gather_audio(out["mix"], wl.prep["lens"], dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:
+            assert sum(int(a.numel()) for a, _ in got) == world * wl.samples
+        del got
+
     if rank == 0:
         value = frames_total * args.steps / elapsed
         steps = max(1, prof["steps"])
@@ -238,6 +253,9 @@ def main():
             # in-pipeline launch when the active path has a standalone rFFT stage, else the entry-point timing
             "roofline_fft": roof("rfft_frames" if per.get("rfft_frames", 0) > 0 else "rfft_frames_standalone"),
         }
+        if gather_ms is not None:
+            line["gather_to_rank0"] = {"ms": gather_ms, "bytes": 4 * wl.samples * (world - 1), "note": "ragged gather of the finished "
+                                       "notes (goofer_amd.shard.gather_audio), outside the timed steps"}
         if world == 1:
             line["pcie_inclusive"] = pcie_leg(wl, elapsed / args.steps)
         if world == 1 and not args.no_cpu_baseline:

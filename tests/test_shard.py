@@ -75,3 +75,39 @@ def test_gloo_two_ranks_reduce_timing():
     assert ids0 == [0, 1, 2] and ids1 == [3, 4, 5]
     assert t0 == t1 == 1.5                       # MAX over ranks
     assert tot0 == tot1 == f0 + f1               # SUM of frames
+
+
+def _gather_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lens = [5, 3] if rank == 0 else [2, 7, 4]                     # ragged notes, different counts per rank
+    mix = torch.arange(sum(lens), dtype=torch.float32) + 100.0 * rank
+    got = shard.gather_audio(mix, lens, dst=0)
+    if rank == 0:
+        q.put([(a.tolist(), l) for a, l in got])
+    else:
+        assert got is None
+        q.put(None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_two_ranks_gather_finished_audio():
+    """The optional ragged gather of finished notes to one rank (what RCCL does over xGMI on the GPU box)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    got = next(r for r in res if r is not None)
+    assert got[0] == ([float(v) for v in range(8)], [5, 3])
+    assert got[1] == ([100.0 + v for v in range(13)], [2, 7, 4])
