@@ -16,10 +16,10 @@ LIB_PATH = os.path.join(HERE, "libgoofer_hip.so")
 NOTE_PARAMS = np.dtype({
     "names": ["pitch_shift", "formant_shift", "f_shift", "uv_strength", "breath_strength", "normalize",
               "apply_brightness", "cut_below_f0", "mix_harm", "mix_breath", "mix_unvoiced", "volume", "seed",
-              "f0_jitter", "vol_jitter_harm", "vol_jitter_breath", "subharm_weight"],
+              "f0_jitter", "vol_jitter_harm", "vol_jitter_breath", "subharm_weight", "subharm_f0_jitter"],
     "formats": ["<f4", "<f4", ("<f8", 4), "<f4", "<f4", "<f4", "<i4", "<i4", "<f4", "<f4", "<f4", "<f4", ("<u4", 2),
-                "<f4", "<f4", "<f4", "<f4"],
-    "offsets": [0, 4, 8, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 84, 88, 92, 96],
+                "<f4", "<f4", "<f4", "<f4", "<f4"],
+    "offsets": [0, 4, 8, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 84, 88, 92, 96, 100],
     "itemsize": 104,
 })
 
@@ -86,7 +86,7 @@ class Batch(C.Structure):
         ("env", C.c_void_p), ("formants", C.c_void_p), ("f0", C.c_void_p), ("mask", C.c_void_p),
         ("phi", C.c_void_p), ("env_noise", C.c_void_p), ("params", C.c_void_p), ("seed", C.c_uint64),
         ("transition_sigma", C.c_float), ("vol_jitter_speed", C.c_float),
-        ("noise_f0", C.c_void_p), ("noise_vol_h", C.c_void_p), ("noise_vol_b", C.c_void_p),
+        ("noise_f0", C.c_void_p), ("noise_vol_h", C.c_void_p), ("noise_vol_b", C.c_void_p), ("noise_subharm", C.c_void_p),
         ("f0_jitter_sigma", C.c_float), ("vol_jitter_sigma", C.c_float),
         ("subharm_ratio", C.c_double), ("subharm_vib_rate", C.c_double), ("subharm_vib_depth", C.c_double),
         ("subharm_vib_delay", C.c_double), ("subharm_vibrato", C.c_int32), ("volume_vibrato", C.c_int32),

@@ -383,7 +383,7 @@ def note_params_from_kwargs(n=1, **kw):
         p["vol_jitter_breath"] = kw.get("volume_jitter_strength_breath", 100)
     if kw.get("add_subharm"):
         if kw.get("subharm_f0_jitter", 0) > 0.0:
-            raise NotImplementedError("subharm_f0_jitter is not on the device path yet")
+            p["subharm_f0_jitter"] = kw["subharm_f0_jitter"]
         if np.ndim(kw.get("subharm_semitones", -12)) != 0:
             raise NotImplementedError("one sub-harmonic ratio per call on the device path")
         p["subharm_weight"] = kw.get("subharm_weight", 0.5)
@@ -449,13 +449,14 @@ def _synthesize_stretched(c, d_env, f0, mask, F, params, sr, hop, phi, seed, kw)
     if seed is None:
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
     noise_f0 = c.tensor(np.random.randn(n)) if kw.get("f0_jitter") else None
+    noise_sub = c.tensor(np.random.randn(n)) if kw.get("add_subharm") and kw.get("subharm_f0_jitter", 0) > 0.0 else None
     vib = bool(kw.get("volume_jitter") and kw.get("volume_vibrato"))
     noise_vol = (c.tensor(np.random.randn(n)), c.tensor(np.random.randn(n))) if kw.get("volume_jitter") and not vib else None
     out = c.synth_batch(env_h, [env_h.shape[0]], d_f0, d_mask, [n], params, formants=None, phi=d_phi, seed=seed,
                         transition_sigma=float(kw.get("noise_transition_smoothness", 100)), want_mix=False,
                         noise_f0=noise_f0, noise_vol=noise_vol, f0_jitter_speed=float(kw.get("f0_jitter_speed", 100)),
                         vol_jitter_speed=float(kw.get("volume_jitter_speed", 150)), subharm=subharm_from_kwargs(kw),
-                        volume_vibrato=vib, env_noise=env_n)
+                        volume_vibrato=vib, env_noise=env_n, noise_subharm=noise_sub)
     return tuple(out[k].cpu().numpy() for k in ("rec", "harm", "uv", "bre"))
 
 
@@ -493,11 +494,12 @@ def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=
         seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
     # jitter flags draw from the legacy global np.random stream in the reference's order: f0, harm volume, breath volume
     noise_f0 = c.tensor(np.random.randn(n)) if kw.get("f0_jitter") else None
+    noise_sub = c.tensor(np.random.randn(n)) if kw.get("add_subharm") and kw.get("subharm_f0_jitter", 0) > 0.0 else None
     vib = bool(kw.get("volume_jitter") and kw.get("volume_vibrato"))          # the sinusoid variant draws nothing
     noise_vol = (c.tensor(np.random.randn(n)), c.tensor(np.random.randn(n))) if kw.get("volume_jitter") and not vib else None
     out = c.synth_batch(d_env, [T_env], c.tensor(f0[:n]), c.tensor(mask[:n]), [n], params, formants=c.tensor(F),
                         phi=d_phi, seed=seed, transition_sigma=float(kw.get("noise_transition_smoothness", 100)),
                         want_mix=False, noise_f0=noise_f0, noise_vol=noise_vol,
                         f0_jitter_speed=float(kw.get("f0_jitter_speed", 100)), vol_jitter_speed=float(kw.get("volume_jitter_speed", 150)),
-                        subharm=subharm_from_kwargs(kw), volume_vibrato=vib)
+                        subharm=subharm_from_kwargs(kw), volume_vibrato=vib, noise_subharm=noise_sub)
     return tuple(out[k].cpu().numpy() for k in ("rec", "harm", "uv", "bre"))

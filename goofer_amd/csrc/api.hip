@@ -52,7 +52,7 @@ int launch_gauss_samples(goofer_ctx *, const Tin *, const int64_t *, int, int64_
 int launch_note_absmax(goofer_ctx *, const double *, const int64_t *, int, int64_t, const unsigned char *, unsigned long long *,
                        hipStream_t);
 int launch_f0_jitter(goofer_ctx *, float *, const float *, const double *, const unsigned long long *, const int64_t *, int, int64_t,
-                     const goofer_note_params *, hipStream_t);
+                     const goofer_note_params *, int, hipStream_t);
 int launch_volume_jitter(goofer_ctx *, float *, float *, const double *, const double *, const double *, const unsigned long long *,
                          const unsigned long long *, const int64_t *, int, int64_t, const goofer_note_params *, int, double, hipStream_t);
 int launch_onepole(goofer_ctx *, const float *, float *, const float *, const goofer_onepole_job *, int, hipStream_t);
@@ -153,10 +153,14 @@ __global__ __launch_bounds__(256) void k_scale_f0(const float *__restrict__ f0, 
 static void gauss_taps_host(double sigma, std::vector<double> &taps, int &radius);
 static int ensure_small(goofer_ctx *ctx, size_t bytes);
 
-__global__ void k_note_sub_flags(const goofer_note_params *__restrict__ params, int n_notes, unsigned char *__restrict__ on_sub)
+__global__ void k_note_sub_flags(const goofer_note_params *__restrict__ params, int n_notes, unsigned char *__restrict__ on_sub,
+                                 unsigned char *__restrict__ on_subj)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_notes) on_sub[i] = params[i].subharm_weight > 0.f;
+    if (i < n_notes) {
+        on_sub[i] = params[i].subharm_weight > 0.f;
+        on_subj[i] = params[i].subharm_weight > 0.f && params[i].subharm_f0_jitter > 0.f;
+    }
 }
 
 __global__ void k_note_flags(const goofer_note_params *__restrict__ params, int n_notes, unsigned char *__restrict__ on_f0,
@@ -939,7 +943,8 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     const bool jit_f0 = b->noise_f0 != nullptr, vol_vib = b->volume_vibrato != 0,
                jit_vol = vol_vib || (b->noise_vol_h != nullptr && b->noise_vol_b != nullptr);
     const bool sub_on = b->subharm_ratio > 0.0;
-    const size_t jit_bytes = ((jit_f0 || jit_vol) ? (3 * (size_t)N * sizeof(double) + 3 * 256 * (size_t)n + 8192) : 0) +
+    const bool sub_jit = sub_on && b->noise_subharm != nullptr;
+    const size_t jit_bytes = ((jit_f0 || jit_vol || sub_jit) ? (3 * (size_t)N * sizeof(double) + 3 * 256 * (size_t)n + 8192) : 0) +
                              (sub_on ? ((size_t)N * (sizeof(double) + sizeof(float)) + 3 * 256 * (size_t)n + 8192) : 0);
     int rc = ensure_scratch(ctx, scratch_need(p, F, N, n) + (size_t)F * (ld - ((p.n_bins + 3) & ~3)) * 2 * sizeof(float) + jit_bytes);
     if (rc) return rc;
@@ -971,7 +976,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     double *jit_a = nullptr, *jit_b = nullptr, *jit_c = nullptr;
     unsigned long long *jit_max = nullptr;
     unsigned char *on_f0 = nullptr, *on_vol = nullptr;
-    if (jit_f0 || jit_vol) {
+    if (jit_f0 || jit_vol || sub_jit) {
         jit_a = a.take<double>(N); jit_b = a.take<double>(N); jit_c = a.take<double>(N);
         jit_max = a.take<unsigned long long>(3 * (size_t)n + 16);
         on_f0 = a.take<unsigned char>(n + 16); on_vol = a.take<unsigned char>(n + 16);
@@ -980,11 +985,12 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     double *sub_buf = nullptr;
     float *sub_fm = nullptr;
     unsigned long long *sub_max = nullptr;
-    unsigned char *on_sub = nullptr;
+    unsigned char *on_sub = nullptr, *on_subj = nullptr;
     if (sub_on) {
         sub_buf = a.take<double>(N); sub_fm = a.take<float>(N);
         sub_max = a.take<unsigned long long>(n + 16); on_sub = a.take<unsigned char>(n + 16);
-        if (!sub_buf || !sub_fm || !sub_max || !on_sub) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
+        on_subj = a.take<unsigned char>(n + 16);
+        if (!sub_buf || !sub_fm || !sub_max || !on_sub || !on_subj) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     }
     {
         const void *ptrs[] = {frame_note, row_src, f0s, pulse, S_h, S_uv, S_br, frames, env_h, env_n, short_s, note_mag, note_peak, onset_cnt};
@@ -1049,7 +1055,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if ((rc = upload_jitter_taps(ctx, (double)b->f0_jitter_sigma, 0, &d_t, &r, st))) return rc;
         if ((rc = launch_gauss_samples<double>(ctx, b->noise_f0, b->sample_off, n, N, d_t, r, on_f0, jit_a, st))) return rc;
         if ((rc = launch_note_absmax(ctx, jit_a, b->sample_off, n, N, on_f0, jit_max, st))) return rc;
-        if ((rc = launch_f0_jitter(ctx, f0s, b->mask, jit_a, jit_max, b->sample_off, n, N, b->params, st))) return rc;
+        if ((rc = launch_f0_jitter(ctx, f0s, b->mask, jit_a, jit_max, b->sample_off, n, N, b->params, 0, st))) return rc;
     }
     // The pulse walk is one latency-bound wave per SIMD: it goes to a side stream FIRST (so its workgroups are resident
     // from the start), and the aperiodic branch — noise spectra, mask smoothing, which depend only on the maps and
@@ -1098,9 +1104,17 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     }
     if (sub_on) {   // 'sg': extra LF pulse layer at f0 * ratio with vibrato, added to the pulse train (GOOFER.py:1076-1097)
-        hipLaunchKernelGGL(k_note_sub_flags, dim3((n + 255) / 256), dim3(256), 0, st, b->params, n, on_sub);
+        hipLaunchKernelGGL(k_note_sub_flags, dim3((n + 255) / 256), dim3(256), 0, st, b->params, n, on_sub, on_subj);
         LAUNCH_CHECK(ctx);
         HIP_TRY(ctx, hipMemsetAsync(sub_max, 0, (size_t)n * sizeof(unsigned long long), st));
+        if (sub_jit) {   // subharm_f0_jitter: f0 (the array itself, as in the reference) *= 1 + (jitter - 1) * mask   :1078-1080
+            const double *d_t; int r;
+            if ((rc = upload_jitter_taps(ctx, (double)b->f0_jitter_sigma, 0, &d_t, &r, st))) return rc;
+            HIP_TRY(ctx, hipMemsetAsync(jit_max, 0, (size_t)n * sizeof(unsigned long long), st));
+            if ((rc = launch_gauss_samples<double>(ctx, b->noise_subharm, b->sample_off, n, N, d_t, r, on_subj, jit_a, st))) return rc;
+            if ((rc = launch_note_absmax(ctx, jit_a, b->sample_off, n, N, on_subj, jit_max, st))) return rc;
+            if ((rc = launch_f0_jitter(ctx, f0s, b->mask, jit_a, jit_max, b->sample_off, n, N, b->params, 1, st))) return rc;
+        }
         if ((rc = launch_subharm(ctx, f0s, b->mask, b->sample_off, n, N, b->params, b->subharm_ratio, b->subharm_vibrato,
                                  b->subharm_vib_rate, b->subharm_vib_depth, b->subharm_vib_delay, sub_fm, inc, (onset_t *)onsets,
                                  onset_idx, onset_cnt, ovf, on_sub, sub_buf, sub_max, pulse, st)))

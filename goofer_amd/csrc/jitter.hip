@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_note_absmax(const double *__restrict__ 
 // f0 (fp32, in place) *= 1 + ((1 + noise/max*strength) - 1) * mask, evaluated in fp64 then rounded to fp32
 __global__ __launch_bounds__(256) void k_f0_jitter(float *__restrict__ f0, const float *__restrict__ mask, const double *__restrict__ noise_s,
                                                    const unsigned long long *__restrict__ max_bits, const int64_t *__restrict__ sample_off,
-                                                   int n_notes, int64_t total, const goofer_note_params *__restrict__ params)
+                                                   int n_notes, int64_t total, const goofer_note_params *__restrict__ params, int which)
 {
     __shared__ int s_pair[2];
     const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void k_f0_jitter(float *__restrict__ f0, const
     if (g >= total) return;
     int note = lo;
     while (sample_off[note + 1] <= g) ++note;
-    const float strength = params[note].f0_jitter;
+    const float strength = which == 0 ? params[note].f0_jitter                                    // :1071 / :1080
+                                      : (params[note].subharm_weight > 0.f ? params[note].subharm_f0_jitter : 0.f);
     if (!(strength > 0.f)) return;
     const double mx = __longlong_as_double((long long)max_bits[note]);
     const double jit = 1.0 + (noise_s[g] / mx) * (double)strength;
@@ -163,11 +164,11 @@ int launch_note_absmax(goofer_ctx *ctx, const double *x, const int64_t *sample_o
 }
 
 int launch_f0_jitter(goofer_ctx *ctx, float *f0, const float *mask, const double *noise_s, const unsigned long long *max_bits,
-                     const int64_t *sample_off, int n_notes, int64_t total, const goofer_note_params *params, hipStream_t st)
+                     const int64_t *sample_off, int n_notes, int64_t total, const goofer_note_params *params, int which, hipStream_t st)
 {
     if (total <= 0) return GOOFER_OK;
     hipLaunchKernelGGL(k_f0_jitter, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, f0, mask, noise_s, max_bits, sample_off,
-                       n_notes, total, params);
+                       n_notes, total, params, which);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

@@ -285,7 +285,7 @@ class Context:
     def synth_batch(self, env, env_lengths, f0, mask, sample_lengths, params: np.ndarray, formants=None, phi=None,
                     seed: int = 0, transition_sigma: float = 100.0, want_rec=True, want_mix=True, offsets=None,
                     noise_f0=None, noise_vol=None, f0_jitter_speed: float = 100.0, vol_jitter_speed: float = 150.0,
-                    subharm=None, volume_vibrato: bool = False, env_noise=None, mix_only: bool = False):
+                    subharm=None, volume_vibrato: bool = False, env_noise=None, mix_only: bool = False, noise_subharm=None):
         """Run goofer_synth_batch.
 
         ``subharm`` = dict(semitones, vibrato, rate, depth, delay) switches the sub-harmonic pulse layer on for the
@@ -321,6 +321,7 @@ class Context:
                        noise_f0=noise_f0.data_ptr() if noise_f0 is not None else None,
                        noise_vol_h=noise_vol[0].data_ptr() if noise_vol is not None else None,
                        noise_vol_b=noise_vol[1].data_ptr() if noise_vol is not None else None,
+                       noise_subharm=noise_subharm.data_ptr() if noise_subharm is not None else None,
                        f0_jitter_sigma=self.geom[0] / (f0_jitter_speed * 6), vol_jitter_sigma=self.geom[0] / (vol_jitter_speed * 6),
                        vol_jitter_speed=float(vol_jitter_speed), volume_vibrato=int(bool(volume_vibrato)),
                        subharm_ratio=2.0 ** (float(subharm["semitones"]) / 12.0) if subharm else 0.0,

@@ -51,7 +51,8 @@ typedef struct {
     float vol_jitter_harm;      /* 'sr': volume_jitter_strength_harm, 0 = off     GOOFER.py:1185-1191 */
     float vol_jitter_breath;    /*       volume_jitter_strength_breath                                */
     float subharm_weight;       /* 'sg': +12 st pulse layer weight, 0 = off       GOOFER.py:1076-1097 */
-    uint32_t reserved;
+    float subharm_f0_jitter;    /* jitter of the f0 the sub-harmonic layer tracks; applied IN PLACE after the pulse   */
+                                /* train, so the later per-frame f0 picks see it too (the reference's aliasing) :1078-1080 */
 } goofer_note_params;
 
 /* One ragged batch of notes for goofer_synth_batch.  All pointers are device memory. */
@@ -86,6 +87,7 @@ typedef struct {
     const double *noise_f0;     /* for notes with f0_jitter > 0                   GOOFER.py:666        */
     const double *noise_vol_h;  /* harmonic volume jitter draw                    GOOFER.py:653        */
     const double *noise_vol_b;  /* breath volume jitter draw                                           */
+    const double *noise_subharm;/* draw of subharm_f0_jitter (between the f0 and the volume draws), or NULL  :1079   */
     float f0_jitter_sigma;      /* sr / (6 * f0_jitter_speed)  samples            GOOFER.py:667        */
     float vol_jitter_sigma;     /* sr / (6 * volume_jitter_speed)                 GOOFER.py:654        */
     /* sub-harmonic pulse layer ('sg'): notes with params.subharm_weight > 0         GOOFER.py:1076-1097  */

@@ -184,6 +184,9 @@ def test_synthesize_jitter_kwargs_vs_oracle(ctx, vibrato):
     dict(add_subharm=True),                                                         # defaults: -12 st, weight .5, no vibrato
     dict(add_subharm=True, subharm_semitones=7, subharm_weight=1.2, subharm_vibrato=True, subharm_vibrato_rate=40.0,
          subharm_vibrato_depth=0.6, subharm_vibrato_delay=0.05, pitch_shift=1.3),
+    # subharm_f0_jitter jitters f0_interp itself (alias) after the pulse train: the HP cutoffs of both branches follow it
+    dict(add_subharm=True, subharm_f0_jitter=0.8, f0_jitter=True, f0_jitter_strength=0.5, volume_jitter=True,
+         volume_jitter_strength_harm=0.4, volume_jitter_strength_breath=0.7),
 ])
 def test_synthesize_subharm_kwargs_vs_oracle(ctx, kw):
     """add_subharm kwargs of gf.synthesize (GOOFER.py:1076-1097) against the oracle's restatement."""
@@ -192,7 +195,9 @@ def test_synthesize_subharm_kwargs_vs_oracle(ctx, kw):
     g = golden("synthesize")
     c = _case(g, "plain")
     args = (c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"])
+    np.random.seed(41)
     ref = R.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=c["phi"], **kw)
+    np.random.seed(41)
     got = core.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=c["phi"], ctx=ctx, **kw)
     plain = core.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=c["phi"], ctx=ctx,
                             pitch_shift=kw.get("pitch_shift", 1.0))
