@@ -23,8 +23,8 @@ int launch_phase_inc(goofer_ctx *, const float *, float, int64_t, double *, hipS
 int launch_pulse_onsets(goofer_ctx *, const float *, float, const double *, const int64_t *, int, onset_t *, int32_t *, int32_t *,
                         int32_t *, hipStream_t);
 int launch_pulse_place(goofer_ctx *, const onset_t *, const int32_t *, const int64_t *, int, int64_t, float *, hipStream_t);
-int launch_subharm(goofer_ctx *, const float *, const float *, const int64_t *, int, int64_t, const goofer_note_params *, double, int,
-                   double, double, double, float *, double *, onset_t *, int32_t *, int32_t *, int32_t *, const unsigned char *,
+int launch_subharm(goofer_ctx *, const float *, const float *, const int64_t *, int, int64_t, const goofer_note_params *, const double *, int,
+                   int, double, double, double, float *, double *, onset_t *, int32_t *, int32_t *, int32_t *, const unsigned char *,
                    double *, unsigned long long *, float *, hipStream_t);
 int launch_gauss_bins(goofer_ctx *, const float *, float *, int64_t, int, int, const double *, int, const int64_t *, hipStream_t);
 int launch_warp_bins(goofer_ctx *, const float *, float *, int64_t, int, int, const double *, const double *,
@@ -1115,7 +1115,10 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
             if ((rc = launch_note_absmax(ctx, jit_a, b->sample_off, n, N, on_subj, jit_max, st))) return rc;
             if ((rc = launch_f0_jitter(ctx, f0s, b->mask, jit_a, jit_max, b->sample_off, n, N, b->params, 1, st))) return rc;
         }
-        if ((rc = launch_subharm(ctx, f0s, b->mask, b->sample_off, n, N, b->params, b->subharm_ratio, b->subharm_vibrato,
+        double ratios[4] = {b->subharm_ratio, b->subharm_more[0], b->subharm_more[1], b->subharm_more[2]};
+        int n_ratios = 1;
+        while (n_ratios < 4 && ratios[n_ratios] > 0.0) ++n_ratios;
+        if ((rc = launch_subharm(ctx, f0s, b->mask, b->sample_off, n, N, b->params, ratios, n_ratios, b->subharm_vibrato,
                                  b->subharm_vib_rate, b->subharm_vib_depth, b->subharm_vib_delay, sub_fm, inc, (onset_t *)onsets,
                                  onset_idx, onset_cnt, ovf, on_sub, sub_buf, sub_max, pulse, st)))
             return rc;

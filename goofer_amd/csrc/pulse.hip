@@ -613,8 +613,11 @@ __global__ __launch_bounds__(64) void k_subharm_finish(const float *__restrict__
 __global__ __launch_bounds__(256) void k_subharm_place(const onset_t *__restrict__ onsets, const int32_t *__restrict__ onset_cnt,
                                                        const float *__restrict__ mask, const int64_t *__restrict__ sample_off,
                                                        int n_notes, int64_t total, const goofer_note_params *__restrict__ params,
-                                                       double *__restrict__ sub, unsigned long long *__restrict__ max_bits)
+                                                       double *__restrict__ sub, unsigned long long *__restrict__ max_bits,
+                                                       int accumulate, int last)
 {
+    // several ratios (a list of subharm_semitones): each has its own event list; the pulses of all of them are summed
+    // (accumulate), and the voicing mask and the joint maximum are applied once, after the last one
     __shared__ int s_pair[2];
     const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
     int lo_n, hi_n;
@@ -648,10 +651,13 @@ __global__ __launch_bounds__(256) void k_subharm_place(const onset_t *__restrict
             }
         }
     }
-    acc *= (double)mask[g];
+    if (accumulate) acc += sub[g];
+    if (last) acc *= (double)mask[g];
     sub[g] = acc;
-    const double m = fabs(acc);
-    if (m > 0.0) atomicMax(max_bits + note, (unsigned long long)__double_as_longlong(m));
+    if (last) {
+        const double m = fabs(acc);
+        if (m > 0.0) atomicMax(max_bits + note, (unsigned long long)__double_as_longlong(m));
+    }
 }
 
 __global__ __launch_bounds__(256) void k_subharm_add(float *__restrict__ pulse, const double *__restrict__ sub,
@@ -677,39 +683,42 @@ __global__ __launch_bounds__(256) void k_subharm_add(float *__restrict__ pulse, 
 }
 
 int launch_subharm(goofer_ctx *ctx, const float *f0s, const float *mask, const int64_t *sample_off, int n_notes, int64_t total,
-                   const goofer_note_params *params, double ratio, int vib_on, double vib_rate, double vib_depth, double vib_delay,
-                   float *fm, double *inc, onset_t *onsets, int32_t *onset_idx, int32_t *onset_cnt, int32_t *overflow,
-                   const unsigned char *note_on, double *sub, unsigned long long *max_bits, float *pulse, hipStream_t st)
+                   const goofer_note_params *params, const double *ratios, int n_ratios, int vib_on, double vib_rate, double vib_depth,
+                   double vib_delay, float *fm, double *inc, onset_t *onsets, int32_t *onset_idx, int32_t *onset_cnt,
+                   int32_t *overflow, const unsigned char *note_on, double *sub, unsigned long long *max_bits, float *pulse,
+                   hipStream_t st)
 {
-    if (total <= 0 || n_notes <= 0) return GOOFER_OK;
-    sub_cfg c;
-    c.ratio = ratio; c.vib_rate = vib_rate; c.vib_depth = vib_depth; c.vib_on = vib_on;
-    c.sr = (double)ctx->plan.sr;
-    c.vib_fade = (int)(vib_delay * c.sr);
+    if (total <= 0 || n_notes <= 0 || n_ratios <= 0) return GOOFER_OK;
     const unsigned nb = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(k_subharm_inc, dim3(nb), dim3(256), 0, st, f0s, mask, sample_off, n_notes, total, params, c, fm, inc);
-    LAUNCH_CHECK(ctx);
-    {
-        const int blocks = (n_notes + 3) / 4;
-        const int per_cu = (blocks + 255) / 256;
-        size_t lds = (size_t)(160 * 1024) / per_cu;
-        lds = lds / 1024 * 1024;
-        const size_t need = 4 * 2 * OC * sizeof(double);
-        if (lds < need) lds = need;
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+    for (int ri = 0; ri < n_ratios; ++ri) {
+        sub_cfg c;
+        c.ratio = ratios[ri]; c.vib_rate = vib_rate; c.vib_depth = vib_depth; c.vib_on = vib_on;
+        c.sr = (double)ctx->plan.sr;
+        c.vib_fade = (int)(vib_delay * c.sr);
+        hipLaunchKernelGGL(k_subharm_inc, dim3(nb), dim3(256), 0, st, f0s, mask, sample_off, n_notes, total, params, c, fm, inc);
+        LAUNCH_CHECK(ctx);
+        {
+            const int blocks = (n_notes + 3) / 4;
+            const int per_cu = (blocks + 255) / 256;
+            size_t lds = (size_t)(160 * 1024) / per_cu;
+            lds = lds / 1024 * 1024;
+            const size_t need = 4 * 2 * OC * sizeof(double);
+            if (lds < need) lds = need;
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_pulse_onsets<true>, dim3(blocks), dim3(256), lds, st, inc, sample_off, n_notes, onset_idx, onset_cnt,
+                               overflow, note_on);
+            LAUNCH_CHECK(ctx);
         }
-        hipLaunchKernelGGL(k_pulse_onsets<true>, dim3(blocks), dim3(256), lds, st, inc, sample_off, n_notes, onset_idx, onset_cnt, overflow,
-                           note_on);
+        hipLaunchKernelGGL(k_subharm_finish, dim3(n_notes), dim3(64), 0, st, fm, sample_off, n_notes, c, onset_idx, onset_cnt, inc, onsets);
+        LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(k_subharm_place, dim3(nb), dim3(256), 0, st, onsets, onset_cnt, mask, sample_off, n_notes, total, params, sub,
+                           max_bits, ri > 0 ? 1 : 0, ri == n_ratios - 1 ? 1 : 0);
         LAUNCH_CHECK(ctx);
     }
-    hipLaunchKernelGGL(k_subharm_finish, dim3(n_notes), dim3(64), 0, st, fm, sample_off, n_notes, c, onset_idx, onset_cnt, inc, onsets);
-    LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_subharm_place, dim3(nb), dim3(256), 0, st, onsets, onset_cnt, mask, sample_off, n_notes, total, params, sub,
-                       max_bits);
-    LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_subharm_add, dim3(nb), dim3(256), 0, st, pulse, sub, max_bits, sample_off, n_notes, total, params);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;

@@ -184,6 +184,9 @@ def test_synthesize_jitter_kwargs_vs_oracle(ctx, vibrato):
     dict(add_subharm=True),                                                         # defaults: -12 st, weight .5, no vibrato
     dict(add_subharm=True, subharm_semitones=7, subharm_weight=1.2, subharm_vibrato=True, subharm_vibrato_rate=40.0,
          subharm_vibrato_depth=0.6, subharm_vibrato_delay=0.05, pitch_shift=1.3),
+    # a list of ratios: one phase tracker each, pulses summed before the joint max-normalisation (GOOFER.py:672-736)
+    dict(add_subharm=True, subharm_semitones=[-12, 7, 12], subharm_weight=0.9, subharm_vibrato=True, subharm_vibrato_rate=20.0,
+         subharm_vibrato_depth=0.2, subharm_vibrato_delay=0.02),
     # subharm_f0_jitter jitters f0_interp itself (alias) after the pulse train: the HP cutoffs of both branches follow it
     dict(add_subharm=True, subharm_f0_jitter=0.8, f0_jitter=True, f0_jitter_strength=0.5, volume_jitter=True,
          volume_jitter_strength_harm=0.4, volume_jitter_strength_breath=0.7),
