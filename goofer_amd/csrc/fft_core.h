@@ -138,6 +138,34 @@ __device__ __forceinline__ void wave_fft(float2 *v, float2 *buf, const float2 *t
     static_assert(R * 64 == M, "M must be 64 * first radix");
 }
 
+// Same transform with the last pass left in registers (M >= 512).  In that pass NS = M/8, so butterfly b = lane + 64 u
+// produces y[b + t M/8], t < 8 — exactly the points m = lane + 64 r (r = u + t M/512) this lane consumes next when the
+// consumer works on m = lane + 64 r.  Saves the write, the exchange and the read back of the whole frame.
+template <int M>
+__device__ __forceinline__ void wave_fft_keep(float2 *v, float2 *buf, const float2 *tw, int lane, float2 *out)
+{
+    static_assert(M >= 512, "the last pass needs at least 64 butterflies");
+    constexpr int R = fft_cfg<M>::R, NB = M / 8, PER = NB / WAVE;
+    dft<R>::run(v);
+#pragma unroll
+    for (int t = 0; t < R; ++t) buf[lds_pad(lane * R + t)] = v[t];
+    wave_lds_sync();
+    radix8_pass<M, R>(buf, tw, lane);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int b = lane + WAVE * u;
+        float2 x[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = buf[lds_pad(b + t * NB)];
+#pragma unroll
+        for (int t = 1; t < 8; ++t) x[t] = cmul(x[t], tw[(t * b) & (M - 1)]);    // NS = M/8: exp(-2 pi i t b / M)
+        dft<8>::run(x);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) out[u + PER * t] = x[t];
+    }
+    wave_lds_sync();
+}
+
 template <int M>
 __device__ __forceinline__ void load_tables(float2 *tw, float2 *twh, float *win, const float2 *g_tw,
                                             const float2 *g_twh, const float *g_win)

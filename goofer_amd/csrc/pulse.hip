@@ -4,8 +4,9 @@
 // (`total_phase += f0[i]/sr`, GOOFER.py:491-493): re-associating it moves onsets by a sample
 // (SURVEY.md §7.3-1).  So the work is split three ways:
 //   k_phase_inc     fully parallel: inc[i] = (double)f0[i] / sr  (true IEEE division)
-//   k_pulse_onsets  one LANE per note walks its increments in order (fp64 add + compare only) and
-//                   emits a compact onset list (sample, T0, period, running max of sample+T0)
+//   k_pulse_onsets_scan  one WAVE per note walks its increments in order (nothing but the dependent fp64 adds) and
+//                   extracts the onset samples from the partial sums chunk by chunk, in parallel; k_onset_finish
+//                   completes the onset list (sample, T0, period, running max of sample+T0)
 //   k_pulse_place   fully parallel gather: every output sample sums, in ascending onset order, the
 //                   LF shapes that cover it — no atomics, same fp32 accumulation order as the
 //                   reference's `pulse[j] += cache[k]`
@@ -105,25 +106,21 @@ struct onset_t {
 // the memory side be fully parallel: the wave fetches 512-sample chunks of increments with coalesced
 // vector loads (next chunk prefetched into registers while the current one is walked), parks them in
 // LDS, and reads them back as uniform 16-byte broadcasts.  A lone wave issues roughly one instruction
-// per 4 cycles whatever its kind, so the hot loop is kept minimal: per 16 samples 8 LDS reads, 16
-// dependent v_add_f64, one compare and one branch.  The 16 partial sums ARE the reference's
-// sequential phases (same additions, same order: GOOFER.py:491), so onsets are bit-exact.
-// Increments are >= 0 in practice, so a block of 16 can only contain an onset if its last partial
-// sum reaches next_k; the per-sample checks (the reference's `while`) run only then, and only record
-// the sample index.  A negative increment anywhere in the chunk (found in parallel at fetch time)
-// forces the per-sample checks for every block of that chunk.  Zero padding of the last chunk adds
-// +0.0, which leaves the phase unchanged.  T0, the period and the look-back bound of every onset are
-// filled in afterwards, in parallel, by k_onset_finish.
+// per 4 cycles whatever its kind, so the hot loop is kept minimal.  The 16 partial sums of a block ARE
+// the reference's sequential phases (same additions, same order: GOOFER.py:491), so events are
+// bit-exact.  Zero padding of the last chunk adds +0.0, which leaves the phase unchanged.
 #define OC 512   // samples per chunk (64 lanes x 8)
 #define OB 16    // samples per walk block
 
 // Placement: a workgroup is 4 waves = 4 notes (one per SIMD of a CU), and the launcher pads the
 // dynamic LDS request so that only ceil(blocks/256) workgroups fit on a CU — otherwise the dispatcher
 // packs many of these latency-bound waves onto a few CUs and they time-slice one SIMD.
-// WRAP = true is the sub-harmonic layer's tracker (GOOFER.py:693-696): an event fires when the phase reaches 1
-// and the phase then drops by 1.0, so the partial sums after an event inside a block must be re-walked.
-template <bool WRAP>
-__global__ __launch_bounds__(256) void k_pulse_onsets(const double *__restrict__ inc, const int64_t *__restrict__ sample_off,
+//
+// k_pulse_onsets_wrap is the sub-harmonic layer's tracker (GOOFER.py:693-696): an event fires when the phase reaches 1
+// and the phase then drops by 1.0, so the events feed back into the chain.  Increments are >= 0 in practice, so a
+// block of 16 can only hold an event if its last partial sum reaches 1; only then (or when the chunk holds a negative
+// increment, found in parallel at fetch time) is the block re-walked sample by sample.
+__global__ __launch_bounds__(256) void k_pulse_onsets_wrap(const double *__restrict__ inc, const int64_t *__restrict__ sample_off,
                                                       int n_notes, int32_t *__restrict__ onset_idx,
                                                       int32_t *__restrict__ onset_cnt, int32_t *__restrict__ overflow,
                                                       const unsigned char *__restrict__ note_on)
@@ -146,8 +143,27 @@ __global__ __launch_bounds__(256) void k_pulse_onsets(const double *__restrict__
     const int32_t cap = (int32_t)((sample_off[note + 1] / 2 + 16 * (int64_t)(note + 1)) - obase);
     const double *__restrict__ a = inc + base;
     int32_t *__restrict__ out = onset_idx + obase;
-    double phase = 0.0, next_k = 1.0;
+    double phase = 0.0;
     int32_t cnt = 0;
+    // Event samples are parked in a 64-entry LDS queue and written out once per chunk as one coalesced store, issued
+    // right after the next prefetch: a global store from inside the walk would sit in vmcnt and stall the wave for
+    // its acknowledgement at the next chunk boundary.
+    int32_t *queue = reinterpret_cast<int32_t *>(smem + 4 * 2 * OC * sizeof(double)) + WAVE * wv;
+    int pend = 0;
+    auto flush = [&]() {
+        const int32_t at = cnt - pend + lane;
+        if (lane < pend && at < cap) out[at] = queue[lane];
+        pend = 0;
+    };
+    auto push = [&](int32_t idx) {
+        if (lane == 0) queue[pend] = idx;
+        ++pend;
+        ++cnt;
+        if (pend == WAVE) {
+            wave_lds_sync();
+            flush();
+        }
+    };
 
     double r[8];
     // NOTE the branch is wave-uniform on purpose: a per-lane if/else writing the same registers makes
@@ -179,6 +195,7 @@ __global__ __launch_bounds__(256) void k_pulse_onsets(const double *__restrict__
         const bool chunk_neg = __any(r_neg);
         wave_lds_sync();
         if (c0 + OC < n) fetch(c0 + OC);                    // in flight during the walk below
+        flush();                                            // the previous chunk's onsets
         const int64_t left = n - c0;
         const int blocks = left >= OC ? OC / OB : (int)((left + OB - 1) / OB);
         // one walk block from registers: chain, group test, rare per-sample checks
@@ -187,73 +204,20 @@ __global__ __launch_bounds__(256) void k_pulse_onsets(const double *__restrict__
             ps[0] = phase + x[0];
 #pragma unroll
             for (int k = 1; k < OB; ++k) ps[k] = ps[k - 1] + x[k];
-            if (WRAP) {
-                if (__any((ps[OB - 1] >= 1.0) || chunk_neg)) {
-                    const int32_t i0 = (int32_t)c0 + g * OB;
-                    double ph = phase;
-#pragma unroll
-                    for (int j = 0; j < OB; ++j) {
-                        ph += x[j];
-                        if (__any(ph >= 1.0)) {
-                            if (cnt < cap) {
-                                if (lane == 0) out[cnt] = i0 + j;
-                            } else if (lane == 0) {
-                                *overflow = 1;
-                            }
-                            ++cnt;
-                            ph -= 1.0;
-                        }
-                    }
-                    phase = ph;
-                } else {
-                    phase = ps[OB - 1];
-                }
-                return;
-            }
-            phase = ps[OB - 1];
-            if (__any((phase >= next_k) || chunk_neg)) {     // wave-uniform: every lane holds the same phase
+            if (__any((ps[OB - 1] >= 1.0) || chunk_neg)) {
                 const int32_t i0 = (int32_t)c0 + g * OB;
-                auto record = [&](int j) {
-                    if (cnt < cap) {
-                        if (lane == 0) out[cnt] = i0 + j;
-                    } else if (lane == 0) {
-                        *overflow = 1;
-                    }
-                    ++cnt;
-                    next_k += 1.0;
-                };
-                if (!chunk_neg) {
-                    // increments >= 0: the partial sums are monotone, so the first sample that reaches next_k is found
-                    // by a 4-step bisection of wave-uniform compares (the reference's while loop records the same
-                    // sample again while the phase still covers the next integer)
-                    static_assert(OB == 16, "bisection below is written for 16-sample walk blocks");
-                    while (__any(phase >= next_k)) {
-                        int j;
-                        if (__any(ps[7] >= next_k)) {
-                            if (__any(ps[3] >= next_k)) {
-                                if (__any(ps[1] >= next_k)) j = __any(ps[0] >= next_k) ? 0 : 1;
-                                else j = __any(ps[2] >= next_k) ? 2 : 3;
-                            } else {
-                                if (__any(ps[5] >= next_k)) j = __any(ps[4] >= next_k) ? 4 : 5;
-                                else j = __any(ps[6] >= next_k) ? 6 : 7;
-                            }
-                        } else {
-                            if (__any(ps[11] >= next_k)) {
-                                if (__any(ps[9] >= next_k)) j = __any(ps[8] >= next_k) ? 8 : 9;
-                                else j = __any(ps[10] >= next_k) ? 10 : 11;
-                            } else {
-                                if (__any(ps[13] >= next_k)) j = __any(ps[12] >= next_k) ? 12 : 13;
-                                else j = __any(ps[14] >= next_k) ? 14 : 15;
-                            }
-                        }
-                        record(j);
-                    }
-                } else {
+                double ph = phase;
 #pragma unroll
-                    for (int j = 0; j < OB; ++j) {
-                        while (__any(ps[j] >= next_k)) record(j);
+                for (int j = 0; j < OB; ++j) {
+                    ph += x[j];
+                    if (__any(ph >= 1.0)) {
+                        push(i0 + j);
+                        ph -= 1.0;
                     }
                 }
+                phase = ph;
+            } else {
+                phase = ps[OB - 1];
             }
         };
         auto load = [&](double (&x)[OB], int g) {
@@ -274,7 +238,154 @@ __global__ __launch_bounds__(256) void k_pulse_onsets(const double *__restrict__
             if (g + 1 < blocks) walk(xb, g + 1);
         }
     }
-    if (lane == 0) onset_cnt[note] = cnt < cap ? cnt : cap;
+    wave_lds_sync();
+    flush();
+    if (lane == 0) {
+        onset_cnt[note] = cnt < cap ? cnt : cap;
+        if (cnt > cap) *overflow = 1;
+    }
+}
+
+// Inclusive wave scans of non-negative int32 values on the DPP path (row shifts inside each 16-lane row, then the two
+// row broadcasts): ~8 VALU instructions instead of six LDS round trips.
+template <typename Op>
+__device__ __forceinline__ int32_t wave_scan_incl(int32_t x, Op op)
+{
+    x = op(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));   // row_shr:1
+    x = op(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));   // row_shr:2
+    x = op(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));   // row_shr:4
+    x = op(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));   // row_shr:8
+    x = op(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    x = op(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+// The plain (non-wrapping) accumulator of the pulse train, GOOFER.py:487-493, with the onset test taken off the
+// sequential chain.  After sample i the reference has recorded R_i = max(R_{i-1}, floor(phase_i)) onsets (its
+// `while phase >= next_k` loop, next_k = R + 1), so the onsets are a function of the partial sums alone.  The wave-
+// uniform walk therefore runs nothing but the dependent fp64 adds; on the way lane l keeps the phase in front of
+// sample 8l of the chunk (two v_cndmask per 8 samples, in the shadow of the adds).  The onsets of a finished chunk are
+// then extracted in parallel while the next chunk is already being walked: every lane replays its 8 additions from the
+// phase it kept — the same additions in the same order, so the same partial sums — takes floor, and a max-scan and a
+// sum-scan across the wave give each lane R in front of its samples and the slot of its first onset.  Negative
+// increments and several onsets at one sample need no special case.
+__global__ __launch_bounds__(256) void k_pulse_onsets_scan(const double *__restrict__ inc, const int64_t *__restrict__ sample_off,
+                                                           int n_notes, int32_t *__restrict__ onset_idx,
+                                                           int32_t *__restrict__ onset_cnt, int32_t *__restrict__ overflow)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __builtin_amdgcn_s_setprio(3);                            // see k_pulse_onsets_wrap
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int note = blockIdx.x * 4 + wv;
+    if (note >= n_notes) return;                              // whole wave; no block barrier below
+    double (*tile)[OC] = reinterpret_cast<double (*)[OC]>(smem) + 2 * wv;
+    const int64_t base = sample_off[note];
+    const int64_t n = sample_off[note + 1] - base;
+    const int64_t obase = base / 2 + 16 * (int64_t)note;
+    const int32_t cap = (int32_t)((sample_off[note + 1] / 2 + 16 * (int64_t)(note + 1)) - obase);
+    const double *__restrict__ a = inc + base;
+    int32_t *__restrict__ out = onset_idx + obase;
+    double phase = 0.0;
+    int32_t cnt = 0;                                          // onsets recorded so far == R
+
+    double r[8];
+    auto fetch = [&](int64_t c0) {                            // wave-uniform branch on purpose, see k_pulse_onsets_wrap
+        const int64_t s = c0 + (int64_t)lane * 8;
+        if (c0 + OC <= n) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] = a[s + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t i = s + k;
+                const double v = a[i < n ? i : n - 1];
+                r[k] = i < n ? v : 0.0;
+            }
+        }
+    };
+    // onsets of a walked chunk: t = its increments, p0 = this lane's phase in front of its 8 samples
+    auto emit = [&](const double *t, double p0, int32_t c0, int valid) {
+        int32_t m[8];
+        int32_t run = 0;
+        double acc = p0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = lane * 8 + k;
+            acc += t[i];
+            const int32_t f = i < valid ? (int32_t)acc : 0;   // trunc == floor wherever it can raise the running max
+            run = max(run, f);
+            m[k] = run;
+        }
+        const int32_t upto = wave_scan_incl(run, [](int32_t x, int32_t y) { return max(x, y); });
+        int32_t before = __shfl_up(upto, 1);
+        if (lane == 0) before = 0;
+        const int32_t start = max(cnt, before);               // R in front of this lane's first sample
+        const int32_t mine = max(run, start) - start;
+        const int32_t s = wave_scan_incl(mine, [](int32_t x, int32_t y) { return x + y; });
+        const int32_t tot = __builtin_amdgcn_readlane(s, WAVE - 1);
+        if (mine > 0) {
+            int32_t at = cnt + s - mine, prev = start;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int32_t c = max(prev, m[k]);
+                for (; prev < c; ++prev, ++at)
+                    if (at < cap) out[at] = c0 + lane * 8 + k;
+            }
+        }
+        cnt += tot;
+    };
+
+    fetch(0);
+    int buf = 0;
+    double kept = 0.0, kept_prev = 0.0;
+    for (int64_t c0 = 0; c0 < n; c0 += OC, buf ^= 1) {
+        double *t = tile[buf];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[lane * 8 + k] = r[k];
+        wave_lds_sync();
+        if (c0 + OC < n) fetch(c0 + OC);                    // in flight during the walk below
+        if (c0 > 0) emit(tile[buf ^ 1], kept_prev, (int32_t)(c0 - OC), OC);   // its stores complete during the walk as well
+        const int64_t left = n - c0;
+        // blocks are walked in pairs; a padded block adds +0.0 sixteen times and leaves the phase where it was
+        const int blocks = left >= OC ? OC / OB : (int)((left + 2 * OB - 1) / (2 * OB)) * 2;
+        auto walk = [&](const double (&x)[OB], int g) {
+            double ps[OB];
+            kept = lane == 2 * g ? phase : kept;
+            ps[0] = phase + x[0];
+#pragma unroll
+            for (int k = 1; k < OB; ++k) ps[k] = ps[k - 1] + x[k];
+            kept = lane == 2 * g + 1 ? ps[OB / 2 - 1] : kept;
+            phase = ps[OB - 1];
+        };
+        auto load = [&](double (&x)[OB], int g) {
+            const double *q = t + (g < blocks ? g : blocks - 1) * OB;
+#pragma unroll
+            for (int k = 0; k < OB; ++k) x[k] = q[k];
+        };
+        double xa[OB], xb[OB];
+        // lgkmcnt(0) here, once per chunk: a scalar load left pending on some path above makes the compiler treat the
+        // counter as out of order inside the loop and wait for *all* LDS reads in front of every block
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        load(xa, 0);
+#pragma unroll 1
+        for (int g = 0; g < blocks; g += 2) {
+            load(xb, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            walk(xa, g);
+            load(xa, g + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            walk(xb, g + 1);
+        }
+        kept_prev = kept;
+    }
+    if (n > 0) {
+        const int64_t c_last = (n - 1) / OC * OC;
+        emit(tile[buf ^ 1], kept_prev, (int32_t)c_last, (int)(n - c_last));
+    }
+    if (lane == 0) {
+        onset_cnt[note] = cnt < cap ? cnt : cap;
+        if (cnt > cap) *overflow = 1;
+    }
 }
 
 // One wave per note, lanes over onsets: T = 1/max(last_valid_f0, 1e-6) with last_valid_f0 the most
@@ -445,19 +556,18 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
         const int blocks = (n_notes + 3) / 4;
         const int per_cu = (blocks + 255) / 256;              // MI355X: 256 CUs, 160 KiB LDS each
         size_t lds = (size_t)(160 * 1024) / per_cu;
-        if (lds > 96 * 1024) lds = 96 * 1024;                 // still one workgroup per CU, and 64 KiB left for a kernel
-                                                              // running beside the walk on the side stream
+        if (lds > 81 * 1024) lds = 81 * 1024;                 // two of these cannot share a CU, and 79 KiB stay free for the
+                                                              // kernel running beside the walk (three noise-spectra workgroups)
         lds = lds / 1024 * 1024;
         const size_t need = 4 * 2 * OC * sizeof(double);      // 32 KiB actually used
         if (lds < need) lds = need;
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_pulse_onsets<false>, dim3(blocks), dim3(256), lds, st, inc, sample_off, n_notes, onset_idx, onset_cnt,
-                           overflow, (const unsigned char *)nullptr);
+        hipLaunchKernelGGL(k_pulse_onsets_scan, dim3(blocks), dim3(256), lds, st, inc, sample_off, n_notes, onset_idx, onset_cnt,
+                           overflow);
         LAUNCH_CHECK(ctx);
     }
     hipLaunchKernelGGL(k_onset_finish, dim3(n_notes), dim3(64), 0, st, f0, sample_off, n_notes, (double)ctx->plan.sr, onset_idx,
@@ -491,7 +601,7 @@ int launch_pulse_train(goofer_ctx *ctx, const float *f0, float f0_scale, const i
 // Sub-harmonic pulse layer ('sg' flag) — gf.add_subharms + apply_subharm_vibrato (GOOFER.py:672-766).
 //
 //   k_subharm_inc     vibrato'd f0 (fp32 like the reference's array) and the tracker increments sub_f0/sr
-//   k_pulse_onsets<true>  the wrapped phase tracker, exact sequential order
+//   k_pulse_onsets_wrap  the wrapped phase tracker, exact sequential order
 //   k_subharm_finish  per event: T = 1/sub_f0, n = max(3, round_half_even(sr T)), fp32 peak of its LF pulse, end_max
 //   k_subharm_place   gather of the covering LF pulses (ascending events), * voicing mask, per-note max
 //   k_subharm_add     pulse += sub / max * weight
@@ -702,14 +812,14 @@ int launch_subharm(goofer_ctx *ctx, const float *f0s, const float *mask, const i
             const int per_cu = (blocks + 255) / 256;
             size_t lds = (size_t)(160 * 1024) / per_cu;
             lds = lds / 1024 * 1024;
-            const size_t need = 4 * 2 * OC * sizeof(double);
+            const size_t need = 4 * 2 * OC * sizeof(double) + 4 * WAVE * sizeof(int32_t);
             if (lds < need) lds = need;
             static bool attr_set = false;
             if (!attr_set) {
-                HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets_wrap, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr_set = true;
             }
-            hipLaunchKernelGGL(k_pulse_onsets<true>, dim3(blocks), dim3(256), lds, st, inc, sample_off, n_notes, onset_idx, onset_cnt,
+            hipLaunchKernelGGL(k_pulse_onsets_wrap, dim3(blocks), dim3(256), lds, st, inc, sample_off, n_notes, onset_idx, onset_cnt,
                                overflow, note_on);
             LAUNCH_CHECK(ctx);
         }

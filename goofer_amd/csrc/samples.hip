@@ -4,9 +4,11 @@
 //   k_stem_gains   lerp-upsample the smoothed mask, scale the three stems, per-note peak
 //                                                                    GOOFER.py:563-567, 1179-1193, 1210
 //   k_apply_gain   gain = (1/peak)^normalize, reconstruct, V/B/U mix GOOFER.py:1208-1218, SillySampler.py:1142-1151
+#include <type_traits>
 #include "fft_core.h"
 
 #define MASK_DS 4
+#define KNOT_MARGIN 12   // knots staged per hop beyond hop / MASK_DS (k_irfft_ola3)
 
 // short-array slot of a note: floor(sample_off/4) + note  (capacity >= ceil(n/4))
 __device__ __forceinline__ int64_t short_base(const int64_t *sample_off, int note) { return sample_off[note] / MASK_DS + note; }
@@ -131,10 +133,12 @@ __device__ __forceinline__ double lin01_f32_i(int i, int num, double step)
     return (double)(float)((double)i * step);
 }
 
-__device__ __forceinline__ float smooth_mask_at32(const double *__restrict__ ss, int ns, int i, int n, double step_n, double step_s,
+// `knot(k)` returns smoothed-mask knot k: a global array, or the window of it a wave has staged in LDS
+template <typename Knot>
+__device__ __forceinline__ float smooth_mask_at32(Knot knot, int ns, int i, int n, double step_n, double step_s,
                                                   float knots_per_sample)
 {
-    if (ns <= 1) return (float)ss[0];
+    if (ns <= 1) return (float)knot(0);
     // Almost everywhere the smoothed mask is flat (0, or the tap sum): when the four knots around a cheap index
     // estimate (good to +-1) are equal, any of the candidate intervals interpolates to exactly that value
     // (slope 0), and the exact index search below is not needed.
@@ -142,7 +146,7 @@ __device__ __forceinline__ float smooth_mask_at32(const double *__restrict__ ss,
         int je = (int)((float)i * knots_per_sample);
         je = je < 1 ? 1 : (je > ns - 3 ? ns - 3 : je);
         if (ns >= 4) {
-            const double a = ss[je - 1], b = ss[je], c = ss[je + 1], d = ss[je + 2];
+            const double a = knot(je - 1), b = knot(je), c = knot(je + 1), d = knot(je + 2);
             if (a == b && b == c && c == d) return (float)b;
         }
     }
@@ -162,9 +166,9 @@ __device__ __forceinline__ float smooth_mask_at32(const double *__restrict__ ss,
         xn = xj;
         xj = lin01_f32_i(j, ns, step_s);
     }
-    if (j >= ns - 1) return (float)ss[ns - 1];
-    if (x == xj) return (float)ss[j];
-    const double s0 = ss[j], s1 = ss[j + 1];
+    if (j >= ns - 1) return (float)knot(ns - 1);
+    if (x == xj) return (float)knot(j);
+    const double s0 = knot(j), s1 = knot(j + 1);
     const double slope = (s1 - s0) * fast_rcp(xn - xj);
     return (float)(slope * (x - xj) + s0);
 }
@@ -342,6 +346,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
     float2 *bufs = twh + (M / 2 + 1);
     float *win = reinterpret_cast<float *>(bufs + WAVES_PER_BLOCK * BUF);
     float *rings = win + NF;
+    double *knots = reinterpret_cast<double *>(rings + (size_t)WAVES_PER_BLOCK * 3 * NF);
     load_tables<M>(tw, twh, win, g_tw, g_twh, g_win);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -400,45 +405,99 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
             ws_u[u] = ws;
         }
     }
-
-    // finished hop h of the current note -> gains -> stems; also used for the flush hops and the zero tail
-    auto emit = [&](int h) {
-        const int p0 = h * hop - M;                           // output index of the hop's first sample
+    // per-lane constants of the transform's two ends: the conj-trick twiddle of bin k and the synthesis window of
+    // sample pair m, k = m = lane + 64 r
+    float2 wc_r[R], win_r[R];
 #pragma unroll
-        for (int u = 0; u < SLOTS; ++u) {
+    for (int r = 0; r < R; ++r) {
+        const int k = lane + WAVE * r;
+        wc_r[r] = (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y);
+        win_r[r] = make_float2(win[2 * k], win[2 * k + 1]);
+    }
+
+    // The smoothed-mask knots a hop needs (hop / MASK_DS of them, plus the +-3 the exact index search may reach) are
+    // fetched lane-parallel a frame ahead and parked in LDS, so the output stage reads them with LDS latency instead of
+    // issuing dependent global loads per sample.
+    constexpr int KPL = (512 / MASK_DS + KNOT_MARGIN + WAVE - 1) / WAVE;
+    const int KN = hop / MASK_DS + KNOT_MARGIN;
+    double *kbuf = knots + (size_t)wave * KN;
+    double kn_r[KPL];
+    int kn_lo = 0;
+    const bool slots_ok = hop <= WAVE * SLOTS;
+    auto knots_fetch = [&](int h) {
+        int i0 = h * hop - M;
+        i0 = i0 < 0 ? 0 : i0;
+        int lo = (int)((float)i0 * kps) - 4;
+        lo = lo < 0 ? 0 : lo;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const int e = lane + WAVE * c;
+            const int k = lo + e < ns - 1 ? lo + e : ns - 1;
+            kn_r[c] = (e < KN && ns > 0) ? ss[k] : 0.0;
+        }
+        kn_lo = lo;
+    };
+    auto knots_park = [&]() {
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const int e = lane + WAVE * c;
+            if (e < KN) kbuf[e] = kn_r[c];
+        }
+        wave_lds_sync();
+    };
+
+    // finished hop h of the current note -> gains -> stems; also used for the flush hops and the zero tail.
+    // NS slots of 64 samples cover the hop; loads first, then the arithmetic, then the stores.
+    auto emit = [&](auto ns_tag, int h) {
+        constexpr int NS = decltype(ns_tag)::value;
+        const int p0 = h * hop - M;                           // output index of the hop's first sample
+        const int e_hi = KN - 1, lo = kn_lo;
+        auto knot = [&](int k) {
+            const int e = k - lo;
+            return kbuf[e < e_hi ? e : e_hi];
+        };
+        float vh[NS], vu[NS], vb[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int q = (h * hop + lane + WAVE * u) & (NF - 1);
+            vh[u] = ring[q];
+            vu[u] = ring[NF + q];
+            vb[u] = ring[2 * NF + q];
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
             const int j = lane + WAVE * u;
-            if (j >= hop) break;
             const int i = p0 + j;
-            if (i < 0 || i >= n) continue;
-            float vh = 0.f, vu = 0.f, vb = 0.f;
+            if (j >= hop || i < 0 || i >= n) continue;
+            float xh = 0.f, xu = 0.f, xb = 0.f;
             if (i < out_len) {
                 const int back = back_u[u];
                 float ws;
                 if (h - back >= 0 && h <= T - 1) {
                     ws = ws_u[u];
                 } else {
-                    const int lo = h - back < 0 ? 0 : h - back, hi = h > T - 1 ? T - 1 : h;
+                    const int flo = h - back < 0 ? 0 : h - back, fhi = h > T - 1 ? T - 1 : h;
                     ws = 0.f;
-                    for (int fr = lo; fr <= hi; ++fr) {
+                    for (int fr = flo; fr <= fhi; ++fr) {
                         const float w = win[j + (h - fr) * hop];
                         ws += w * w;
                     }
                 }
-                const int q = (h * hop + j) & (NF - 1);
-                vh = ring[q]; vu = ring[NF + q]; vb = ring[2 * NF + q];
-                if (ws > 1e-9f) { vh /= ws; vu /= ws; vb /= ws; }
-                vh = vh / mag;
+                xh = vh[u]; xu = vu[u]; xb = vb[u];
+                if (ws > 1e-9f) { xh /= ws; xu /= ws; xb /= ws; }
+                xh = xh / mag;
             }
-            const float ms = smooth_mask_at32(ss, ns, i, n, step_n, step_s, kps);
-            vb = (vb * ms) * g_b;
-            vu = (vu * (1.0f - ms)) * g_u;
-            harm[base + i] = vh;
-            uv[base + i] = vu;
-            bre[base + i] = vb;
-            pk = fmaxf(pk, fabsf((vh + vu) + vb));
+            const float ms = smooth_mask_at32(knot, ns, i, n, step_n, step_s, kps);
+            xb = (xb * ms) * g_b;
+            xu = (xu * (1.0f - ms)) * g_u;
+            harm[base + i] = xh;
+            uv[base + i] = xu;
+            bre[base + i] = xb;
+            pk = fmaxf(pk, fabsf((xh + xu) + xb));
         }
     };
     auto emit_any = [&](int h) {                              // hops wider than the cached slots
+        auto knot = [&](int k) { return ss[k]; };
         for (int j = lane; j < hop; j += WAVE) {
             const int i = h * hop + j - M;
             if (i < 0 || i >= n) continue;
@@ -456,7 +515,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
                 if (ws > 1e-9f) { vh /= ws; vu /= ws; vb /= ws; }
                 vh = vh / mag;
             }
-            const float ms = smooth_mask_at32(ss, ns, i, n, step_n, step_s, kps);
+            const float ms = smooth_mask_at32(knot, ns, i, n, step_n, step_s, kps);
             vb = (vb * ms) * g_b;
             vu = (vu * (1.0f - ms)) * g_u;
             harm[base + i] = vh;
@@ -465,7 +524,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
             pk = fmaxf(pk, fabsf((vh + vu) + vb));
         }
     };
-    const bool slots_ok = hop <= WAVE * SLOTS;
+    const int nslot = (hop + WAVE - 1) / WAVE;
 
     for (int64_t f = fs; f < f1; ++f) {
         const int nt = frame_note[f];
@@ -491,6 +550,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
             ss = short_s + short_base(sample_off, note);
         }
         const int t = (int)(f - fbase);
+        if (f >= f0 && slots_ok) knots_fetch(t);              // lands during the three transforms below
 #pragma unroll
         for (int stem = 0; stem < 3; ++stem) {
             float2 v[R];
@@ -499,41 +559,55 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
                 const int k = lane + WAVE * r;
                 float2 xk = nk[r], xm = nm[r];
                 if (k == 0) { xk.y = 0.f; xm.y = 0.f; }       // irfft ignores Im of DC and Nyquist
-                const float2 wc = (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y);
                 const float2 A = make_float2(xk.x + xm.x, xk.y - xm.y);
                 const float2 D = make_float2(xk.x - xm.x, xk.y + xm.y);
-                const float2 Cc = cmul(wc, D);
+                const float2 Cc = cmul(wc_r[r], D);
                 v[r] = make_float2(0.5f * (A.x - Cc.y), -0.5f * (A.y + Cc.x));
             }
             // next job's rows: same frame next stem, or the next frame's first stem
             if (stem < 2) fetch(f, stem + 1);
             else if (f + 1 < f1) fetch(f + 1, 0);
-            wave_fft<M>(v, buf, tw, lane);
             float *rg = ring + stem * NF;
             const int shift = (t * hop) & (NF - 1);
+            // all ring reads, then all ring writes: the R slots of a lane are distinct, and a branch-free body lets the
+            // LDS reads overlap instead of paying one round trip per slot
+            float2 z[R], o[R];
+            if constexpr (M >= 512) {
+                wave_fft_keep<M>(v, buf, tw, lane, z);        // the lane's output points stay in registers
+            } else {
+                wave_fft<M>(v, buf, tw, lane);
+#pragma unroll
+                for (int r = 0; r < R; ++r) z[r] = buf[lds_pad(lane + WAVE * r)];
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int m = lane + WAVE * r;
-                const float2 z = buf[lds_pad(m)];
-                const float a = (z.x * inv_m) * win[2 * m], b = (-z.y * inv_m) * win[2 * m + 1];
-                const int q = (2 * m + shift) & (NF - 1);
-                float2 *slot = reinterpret_cast<float2 *>(rg + q);
-                if (t == 0 || 2 * m >= NF - hop) {
-                    *slot = make_float2(a, b);                // first contribution: y starts from zero
-                } else {
-                    float2 o = *slot;
-                    *slot = make_float2(o.x + a, o.y + b);
-                }
+                o[r] = *reinterpret_cast<const float2 *>(rg + ((2 * m + shift) & (NF - 1)));
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int m = lane + WAVE * r;
+                const float a = (z[r].x * inv_m) * win_r[r].x, b = (-z[r].y * inv_m) * win_r[r].y;
+                const bool first = t == 0 || 2 * m >= NF - hop;   // first contribution: y starts from zero
+                *reinterpret_cast<float2 *>(rg + ((2 * m + shift) & (NF - 1))) =
+                    make_float2(first ? a : o[r].x + a, first ? b : o[r].y + b);
             }
             wave_lds_sync();
         }
         if (f >= f0) {
-            if (slots_ok) emit(t); else emit_any(t);
-            if (t == T - 1) {
-                // the hops behind the last frame (up to the one holding sample out_len - 1), then the zero-filled tail
-                for (int h = T; h * hop - M < n; ++h) {
-                    if (slots_ok) emit(h); else emit_any(h);
+            // hop t; behind a note's last frame also the hops up to the one holding sample out_len - 1 and the zero tail
+            for (int h = t;;) {
+                if (slots_ok) {
+                    knots_park();
+                    if (nslot <= 2) emit(std::integral_constant<int, 2>{}, h);
+                    else if (nslot <= 4) emit(std::integral_constant<int, 4>{}, h);
+                    else emit(std::integral_constant<int, 8>{}, h);
+                } else {
+                    emit_any(h);
                 }
+                ++h;
+                if (t != T - 1 || h * hop - M >= n) break;
+                if (slots_ok) knots_fetch(h);
             }
         }
         wave_lds_sync();
@@ -554,7 +628,8 @@ static int irfft_ola3_impl(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u
     const int halo = (p.n_fft + p.hop - 1) / p.hop - 1;
     const int run = halo <= 4 ? 32 : 8 * halo;
     const size_t lds = sizeof(float2) * (M + M / 2 + 1 + WAVES_PER_BLOCK * fft_cfg<M>::BUF) + sizeof(float) * 2 * M +
-                       sizeof(float) * WAVES_PER_BLOCK * 3 * 2 * M + 16;
+                       sizeof(float) * WAVES_PER_BLOCK * 3 * 2 * M + 16 +
+                       (p.hop <= 512 ? sizeof(double) * WAVES_PER_BLOCK * (p.hop / MASK_DS + KNOT_MARGIN) : 0);
     static bool attr = false;
     if (!attr) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_irfft_ola3<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -1,5 +1,6 @@
 """Per-stage HIP-event times of the default bench workload (config 3, 1024 notes), one line per stage.
-Usage (on the GPU box): python scripts/stage_times.py [notes] [steps]"""
+Usage (on the GPU box): python scripts/stage_times.py [notes] [steps] [--serial]
+--serial turns the side stream off (option "overlap" = 0), so every stage is timed alone on the chip."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,9 +8,13 @@ import torch
 from goofer_amd.device import Context
 from goofer_amd.workload import SamplerWorkload
 
-notes = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+serial = "--serial" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+notes = int(argv[0]) if len(argv) > 0 else 1024
+steps = int(argv[1]) if len(argv) > 1 else 10
 ctx = Context(0)
+if serial:
+    ctx.set_option("overlap", 0)
 wl = SamplerWorkload(ctx, 3, list(range(notes)))
 for _ in range(3):
     wl.step()

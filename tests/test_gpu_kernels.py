@@ -124,6 +124,34 @@ def test_pulse_train_many_random_notes_vs_oracle(ctx):
         o += n
 
 
+def test_pulse_train_negative_and_oversized_increments(ctx):
+    """R_i = max(R_{i-1}, floor(phase_i)): a falling phase records nothing until it passes the old maximum again, and an
+    increment above 1 records several onsets on one sample (the reference's `while`, GOOFER.py:492)."""
+    from oracle import goofer_ref as R
+    ctx.plan(44100, 1024, 256)
+    rng = np.random.default_rng(23)
+    f0s = []
+    for i in range(9):
+        n = int(rng.integers(700, 4000))
+        f = rng.uniform(150, 700) * np.ones(n)
+        for _ in range(4):
+            a = int(rng.integers(0, n - 60))
+            f[a:a + int(rng.integers(1, 60))] = -rng.uniform(100, 3000)       # phase runs backwards
+        for _ in range(3):
+            f[int(rng.integers(0, n))] = rng.uniform(50000, 140000)          # 1-3 onsets on one sample
+        if i == 0:
+            f[:] = -200.0                                                    # never reaches 1
+        f0s.append(f.astype(np.float32))
+    lens = [len(f) for f in f0s]
+    out = ctx.pulse_train(ctx.tensor(np.concatenate(f0s)), _off(ctx, lens)).cpu().numpy()
+    o = 0
+    for f, n in zip(f0s, lens):
+        ref = R.pulse_train(f, 44100)
+        assert np.max(np.abs(out[o:o + n] - ref)) < 4e-6
+        o += n
+    assert not out[:lens[0]].any()
+
+
 def test_gauss_bins(ctx):
     from goofer_amd.core import gaussian_taps
     g = golden("gauss")
