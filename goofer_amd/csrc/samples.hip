@@ -316,6 +316,16 @@ __global__ __launch_bounds__(256) void k_ola3_gains(const float *__restrict__ fr
     }
 }
 
+// x / d for a divisor whose correctly rounded reciprocal r = RN(1 / d) is at hand: q = RN(x r) is within an ulp,
+// the FMA residual x - q d is exact, and RN(q + residual r) is the correctly rounded quotient (Markstein 1990) —
+// for finite operands and a quotient in the normal range, which is where audio samples over a window sum live
+// (a zero stays a zero; a subnormal quotient may differ from the division in its last subnormal bit).
+__device__ __forceinline__ float div_by(float x, float d, float r)
+{
+    const float q = x * r;
+    return fmaf(fmaf(-q, d, x), r, q);
+}
+
 // ---------------------------------------------------------------------------------------------
 // irFFT of the three stems + overlap-add + gains + per-note peak in one pass over the spectra (replaces three
 // k_irfft_frames launches and k_ola3_gains: the windowed frames never go to HBM).
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(256) void k_ola3_gains(const float *__restrict__ fr
 // frames (accumulate only); the wave that owns a note's last frame also flushes the hops behind it and the
 // zero-filled tail (GOOFER.py:402-413).
 template <int M>
-__global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S_h, const float2 *__restrict__ S_u,
+__global__ __launch_bounds__(256, M <= 512 ? 2 : 1) void k_irfft_ola3(const float2 *__restrict__ S_h, const float2 *__restrict__ S_u,
                                                     const float2 *__restrict__ S_b, int ldc, int64_t total_frames,
                                                     const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
                                                     const int64_t *__restrict__ sample_off, int hop, int run, int halo,
@@ -380,45 +390,52 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
     int note = -1;
     int64_t base = 0, fbase = 0;
     int n = 0, T = 0, ns = 0, out_len = 0;
-    float mag = 1.f, g_b = 0.f, g_u = 0.f, pk = 0.f, kps = 0.f;
+    float mag = 1.f, rmag = 1.f, g_b = 0.f, g_u = 0.f, pk = 0.f, kps = 0.f;
     double step_n = 0.0, step_s = 0.0;
     const double *ss = nullptr;
 
-    // per-lane constants of the output stage for its samples j = lane + 64 u of a hop: how many earlier frames
-    // cover position j, and the summed squared window when all of them exist (interior hops)
-    constexpr int SLOTS = 8;                                  // hop <= 512; larger hops recompute per sample
-    int back_u[SLOTS];
-    float ws_u[SLOTS];
+    // per-lane constants of the output stage for its samples j = lane + 64 u of a hop: the summed squared window
+    // when all covering frames exist (interior hops), and its reciprocal
+    constexpr int SLOTS = M >= 1024 ? 8 : 4;                  // hop <= 64 SLOTS; larger hops recompute per sample.  Eight slots
+                                                              // in the 1024-point kernel would cost it its second wave per SIMD
+    float ws_u[SLOTS], rws_u[SLOTS];
+    const int max_back = (NF - 1) / hop;                      // every position of a hop >= max_back has all its frames
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
         const int j = lane + WAVE * u;
-        back_u[u] = 0;
         ws_u[u] = 0.f;
+        rws_u[u] = 0.f;
         if (j < hop) {
             const int back = (NF - 1 - j) / hop;
-            back_u[u] = back;
             float ws = 0.f;
             for (int q = back; q >= 0; --q) {                 // ascending frame order = descending offset
                 const float w = win[j + q * hop];
                 ws += w * w;
             }
             ws_u[u] = ws;
+            rws_u[u] = 1.0f / ws;
         }
     }
     // per-lane constants of the transform's two ends: the conj-trick twiddle of bin k and the synthesis window of
     // sample pair m, k = m = lane + 64 r
-    float2 wc_r[R], win_r[R];
+    // (kept in registers up to M = 512; the 2048-point frame has no registers to spare and re-reads them from LDS)
+    constexpr bool HOIST = M <= 512;
+    auto wc_of = [&](int k) { return (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y); };
+    // (z / M) * w == z * (w / M) exactly (M is a power of two), and the conjugate's sign rides along
+    auto win_of = [&](int k) { return make_float2(win[2 * k] * inv_m, -(win[2 * k + 1] * inv_m)); };
+    float2 wc_r[HOIST ? R : 1], win_r[HOIST ? R : 1];
+    if constexpr (HOIST) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int k = lane + WAVE * r;
-        wc_r[r] = (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y);
-        win_r[r] = make_float2(win[2 * k], win[2 * k + 1]);
+        for (int r = 0; r < R; ++r) {
+            wc_r[r] = wc_of(lane + WAVE * r);
+            win_r[r] = win_of(lane + WAVE * r);
+        }
     }
 
     // The smoothed-mask knots a hop needs (hop / MASK_DS of them, plus the +-3 the exact index search may reach) are
     // fetched lane-parallel a frame ahead and parked in LDS, so the output stage reads them with LDS latency instead of
     // issuing dependent global loads per sample.
-    constexpr int KPL = (512 / MASK_DS + KNOT_MARGIN + WAVE - 1) / WAVE;
+    constexpr int KPL = (WAVE * SLOTS / MASK_DS + KNOT_MARGIN + WAVE - 1) / WAVE;
     const int KN = hop / MASK_DS + KNOT_MARGIN;
     double *kbuf = knots + (size_t)wave * KN;
     double kn_r[KPL];
@@ -471,21 +488,23 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
             if (j >= hop || i < 0 || i >= n) continue;
             float xh = 0.f, xu = 0.f, xb = 0.f;
             if (i < out_len) {
-                const int back = back_u[u];
-                float ws;
-                if (h - back >= 0 && h <= T - 1) {
-                    ws = ws_u[u];
+                xh = vh[u]; xu = vu[u]; xb = vb[u];
+                if (h >= max_back && h <= T - 1) {
+                    // interior hop: the divisor is a per-lane constant; with r = RN(1 / ws) the quotient correction
+                    // q + fma(-q, ws, x) * r is the correctly rounded x / ws (Markstein) in three instructions
+                    const float ws = ws_u[u], rw = rws_u[u];
+                    if (ws > 1e-9f) { xh = div_by(xh, ws, rw); xu = div_by(xu, ws, rw); xb = div_by(xb, ws, rw); }
                 } else {
+                    const int back = (NF - 1 - j) / hop;
                     const int flo = h - back < 0 ? 0 : h - back, fhi = h > T - 1 ? T - 1 : h;
-                    ws = 0.f;
+                    float ws = 0.f;
                     for (int fr = flo; fr <= fhi; ++fr) {
                         const float w = win[j + (h - fr) * hop];
                         ws += w * w;
                     }
+                    if (ws > 1e-9f) { xh /= ws; xu /= ws; xb /= ws; }
                 }
-                xh = vh[u]; xu = vu[u]; xb = vb[u];
-                if (ws > 1e-9f) { xh /= ws; xu /= ws; xb /= ws; }
-                xh = xh / mag;
+                xh = div_by(xh, mag, rmag);
             }
             const float ms = smooth_mask_at32(knot, ns, i, n, step_n, step_s, kps);
             xb = (xb * ms) * g_b;
@@ -542,6 +561,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
             ns = (n + MASK_DS - 1) / MASK_DS;
             out_len = hop * (T - 1);
             mag = note_mag[note];
+            rmag = 1.0f / mag;
             g_b = params[note].breath_strength;
             g_u = params[note].uv_strength;
             step_n = steps[2 * note];
@@ -561,7 +581,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
                 if (k == 0) { xk.y = 0.f; xm.y = 0.f; }       // irfft ignores Im of DC and Nyquist
                 const float2 A = make_float2(xk.x + xm.x, xk.y - xm.y);
                 const float2 D = make_float2(xk.x - xm.x, xk.y + xm.y);
-                const float2 Cc = cmul(wc_r[r], D);
+                const float2 Cc = cmul(HOIST ? wc_r[HOIST ? r : 0] : wc_of(k), D);
                 v[r] = make_float2(0.5f * (A.x - Cc.y), -0.5f * (A.y + Cc.x));
             }
             // next job's rows: same frame next stem, or the next frame's first stem
@@ -587,7 +607,8 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int m = lane + WAVE * r;
-                const float a = (z[r].x * inv_m) * win_r[r].x, b = (-z[r].y * inv_m) * win_r[r].y;
+                const float2 wn = HOIST ? win_r[HOIST ? r : 0] : win_of(m);
+                const float a = z[r].x * wn.x, b = z[r].y * wn.y;
                 const bool first = t == 0 || 2 * m >= NF - hop;   // first contribution: y starts from zero
                 *reinterpret_cast<float2 *>(rg + ((2 * m + shift) & (NF - 1))) =
                     make_float2(first ? a : o[r].x + a, first ? b : o[r].y + b);
@@ -601,7 +622,7 @@ __global__ __launch_bounds__(256) void k_irfft_ola3(const float2 *__restrict__ S
                     knots_park();
                     if (nslot <= 2) emit(std::integral_constant<int, 2>{}, h);
                     else if (nslot <= 4) emit(std::integral_constant<int, 4>{}, h);
-                    else emit(std::integral_constant<int, 8>{}, h);
+                    else if constexpr (SLOTS >= 8) emit(std::integral_constant<int, 8>{}, h);
                 } else {
                     emit_any(h);
                 }
@@ -629,7 +650,7 @@ static int irfft_ola3_impl(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u
     const int run = halo <= 4 ? 32 : 8 * halo;
     const size_t lds = sizeof(float2) * (M + M / 2 + 1 + WAVES_PER_BLOCK * fft_cfg<M>::BUF) + sizeof(float) * 2 * M +
                        sizeof(float) * WAVES_PER_BLOCK * 3 * 2 * M + 16 +
-                       (p.hop <= 512 ? sizeof(double) * WAVES_PER_BLOCK * (p.hop / MASK_DS + KNOT_MARGIN) : 0);
+                       (p.hop <= (M >= 1024 ? 512 : 256) ? sizeof(double) * WAVES_PER_BLOCK * (p.hop / MASK_DS + KNOT_MARGIN) : 0);
     static bool attr = false;
     if (!attr) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_irfft_ola3<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

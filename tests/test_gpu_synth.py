@@ -254,6 +254,44 @@ def test_synthesize_stretch_vs_oracle(ctx, kw):
         assert rms_err(a_, b_) < 2e-5, (key, rms_err(a_, b_))
 
 
+@pytest.mark.parametrize("n_fft,hop", [(1024, 512), (1024, 128), (1024, 200), (512, 128), (512, 256), (2048, 512), (2048, 96),
+                                       (2048, 1024)])
+def test_fused_overlap_add_other_geometries(ctx, n_fft, hop):
+    """Every output-stage variant of k_irfft_ola3 (2, 4 or 8 slots of 64 samples per hop, the per-sample fallback for
+    wider hops, hops that are not a multiple of 64, all three transform sizes) against the separate kernels, bit for bit."""
+    from goofer_amd.device import default_params
+    ctx.plan(44100, n_fft, hop)
+    rng = np.random.default_rng(n_fft + hop)
+    lens = [1, hop - 1, hop, n_fft + 3, 5 * n_fft + 17, 9 * hop, 20000]
+    nb = n_fft // 2 + 1
+    envs, f0s, masks, env_len = [], [], [], []
+    for n in lens:
+        T = 1 + n // hop
+        envs.append((1.0 + rng.random((T, nb))).astype(np.float32))
+        env_len.append(T)
+        m = (rng.random(n) > 0.3).astype(np.float32)
+        m[n // 3:n // 2] = 1.0                                        # flat and transition stretches of the smoothed mask
+        masks.append(m)
+        f0s.append((200.0 + 50.0 * rng.random(n)).astype(np.float32) * m)
+    par = default_params(len(lens))
+    args = (ctx.rows_from(np.concatenate(envs)), env_len, ctx.tensor(np.concatenate(f0s)), ctx.tensor(np.concatenate(masks)), lens, par)
+    try:
+        ctx.set_option("fused_ola", 1)
+        a = ctx.synth_batch(*args, seed=9)
+        torch.cuda.synchronize()
+        a = {k: a[k].cpu().numpy() for k in ("harm", "uv", "bre", "mix")}
+        ctx.set_option("fused_ola", 0)
+        b = ctx.synth_batch(*args, seed=9)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_option("fused_ola", 1)
+        ctx.plan(44100, 1024, 256)
+    for k in a:
+        assert np.array_equal(a[k], b[k].cpu().numpy()), k
+        assert np.all(np.isfinite(a[k])), k
+    assert np.abs(a["mix"]).max() > 0
+
+
 def test_fused_overlap_add_tiny_and_ragged_notes(ctx):
     """Note lengths around the hop / window sizes (1 sample .. a few frames), all in one batch: the fused
     irFFT + overlap-add kernel against the separate kernels, bit for bit, and against the oracle for one of them."""
