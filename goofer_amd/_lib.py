@@ -128,6 +128,7 @@ EXPORTS = {
     "goofer_onepole_cascade": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "goofer_post_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "goofer_assemble_batch": (C.c_int, [C.c_void_p, C.POINTER(Assembly), C.c_void_p]),
+    "goofer_render_batch": (C.c_int, [C.c_void_p, C.POINTER(Assembly), C.POINTER(Batch), C.c_void_p]),
     "goofer_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "goofer_profile_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "goofer_profile_stage_name": (C.c_char_p, [C.c_int]),

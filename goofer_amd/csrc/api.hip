@@ -339,6 +339,9 @@ void goofer_destroy(goofer_ctx *ctx)
     free(ctx->prof_main2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_entry) (void)hipEventDestroy(ctx->ev_entry);
+    if (ctx->ev_f0) (void)hipEventDestroy(ctx->ev_f0);
+    if (ctx->ev_f0s) (void)hipEventDestroy(ctx->ev_f0s);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     delete ctx;
 }
@@ -929,6 +932,18 @@ int goofer_post_batch(goofer_ctx *ctx, const goofer_post *p, void *stream)
                            p->mix, st);
 }
 
+static int ensure_side_stream(goofer_ctx *ctx)
+{
+    if (ctx->side) return GOOFER_OK;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_entry, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_f0, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_f0s, hipEventDisableTiming));
+    return GOOFER_OK;
+}
+
 int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
 {
     NEED_PLAN(ctx);
@@ -1020,7 +1035,6 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     const double *d_mtaps = ctx->mask_taps;
     const int mrad = ctx->mask_taps_radius;
 
-    HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), st));
 
     hipEvent_t *pev = nullptr;
@@ -1038,13 +1052,31 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
 
     const bool ola_one = ctx->ola_fused && !(ctx->fused && !b->env_noise) && (p.hop % 2 == 0);
     unsigned fb = (unsigned)((F + 255) / 256);
+    // goofer_render_batch: the assembly recorded ev_f0 right after the f0 / mask kernel.  The pulse chain (f0 scaling,
+    // sequential walk, placement) then runs on the side stream from that point on, beside the envelope assembly and the
+    // map kernels, instead of starting when this call's first kernel is reached in stream order.
+    const bool side_on = ctx->overlap && ola_one && !sub_on;
+    const bool early = side_on && !jit_f0 && ctx->early_req && ctx->early_f0 == b->f0 && ctx->side != nullptr;
     MARK();   // 0: setup
+    if (early) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_entry, 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_f0, 0));
+        HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), ctx->side));
+        hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, ctx->side, b->f0, b->sample_off, n, N,
+                           b->params, f0s, inc, (double)p.sr);
+        LAUNCH_CHECK(ctx);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_f0s, ctx->side));
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), st));
+    }
     if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, st))) return rc;
     hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, st, b->frame_off, b->env_off, frame_note, F, row_src);
     LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s,
-                       jit_f0 ? (double *)nullptr : inc, (double)p.sr);     // jittered f0: increments after the jitter, below
-    LAUNCH_CHECK(ctx);
+    if (!early) {
+        hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s,
+                           jit_f0 ? (double *)nullptr : inc, (double)p.sr);     // jittered f0: increments after the jitter, below
+        LAUNCH_CHECK(ctx);
+    }
     if (jit_f0 || jit_vol) {
         hipLaunchKernelGGL(k_note_flags, dim3((n + 255) / 256), dim3(256), 0, st, b->params, n, on_f0, on_vol);
         LAUNCH_CHECK(ctx);
@@ -1060,18 +1092,16 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // The pulse walk is one latency-bound wave per SIMD: it goes to a side stream FIRST (so its workgroups are resident
     // from the start), and the aperiodic branch — noise spectra, mask smoothing, which depend only on the maps and
     // the scaled f0 — fills the rest of the machine from the caller's stream meanwhile.
-    const bool side_on = ctx->overlap && ola_one && !sub_on;
     hipEvent_t *sev = nullptr;
     hipStream_t pst = st;                                     // stream of the pulse chain
     if (side_on) {
-        if (!ctx->side) {
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        }
+        int rc2 = ensure_side_stream(ctx);
+        if (rc2) return rc2;
         if (pev) sev = ctx->prof_side + (size_t)ctx->prof_steps * 4;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        if (!early) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        }
         pst = ctx->side;
         ctx->prof_side_used = true;
     } else if (pev) {
@@ -1094,6 +1124,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if (sev) HIP_TRY(ctx, hipEventRecord(sev[3], pst));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, pst));
         // meanwhile, on the caller's stream
+        if (early) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_f0s, 0));   // the scaled f0 comes from the side stream
         if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
                                        b->env_noise ? b->env_noise : b->env, b->phi, ld, b->params, b->seed, row_src,
                                        b->env_noise != nullptr, st)))
@@ -1190,6 +1221,28 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
 #undef MARK
     if (pev) ctx->prof_steps++;
     return GOOFER_OK;
+}
+
+// SillySampler.resample end to end for one batch (SillySampler.py:698-1151 up to the post chain): assembly and synthesis as
+// one call.  Same kernels and results as goofer_assemble_batch followed by goofer_synth_batch; the difference is scheduling.
+// Because both descriptors are in hand at once, everything they point to is known to be enqueued before this call, so
+// the synthesis' pulse chain may start on the side stream as soon as the assembled f0 exists.
+int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *asmb, const goofer_batch *b, void *stream)
+{
+    NEED_PLAN(ctx);
+    if (!asmb || !b) return goofer_fail(ctx, GOOFER_EINVAL, "null descriptor");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (ctx->overlap && asmb->f0_out == b->f0 && asmb->n_notes > 0) {
+        if ((rc = ensure_side_stream(ctx))) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_entry, st));      // every input of either descriptor precedes this point
+        ctx->early_req = true;
+    }
+    rc = goofer_assemble_batch(ctx, asmb, stream);
+    if (!rc) rc = goofer_synth_batch(ctx, b, stream);
+    ctx->early_req = false;
+    ctx->early_f0 = nullptr;
+    return rc;
 }
 
 }  // extern "C"

@@ -343,6 +343,18 @@ __global__ void k_row_notes(const goofer_note_plan *__restrict__ notes, int n_no
 int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edit, int *row_note_out, hipStream_t st)
 {
     const int B = a->n_bins;
+    // f0 and voicing mask first: the pulse chain of the synthesis (a long sequential walk) depends on nothing else, and
+    // goofer_render_batch starts it on the side stream while the envelope kernels below are still running
+    ctx->early_f0 = nullptr;
+    if (a->total_samples > 0) {
+        hipLaunchKernelGGL(k_sample_assemble, dim3((unsigned)((a->total_samples + 256 * SA_SPT - 1) / (256 * SA_SPT))), dim3(256), 0, st, *a,
+                           a->total_samples);
+        LAUNCH_CHECK(ctx);
+        if (ctx->early_req && ctx->ev_f0) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_f0, st));
+            ctx->early_f0 = a->f0_out;
+        }
+    }
     if (a->total_edit_rows > 0) {
         hipLaunchKernelGGL(k_row_notes, dim3((unsigned)((a->total_edit_rows + 255) / 256)), dim3(256), 0, st, a->notes, a->n_notes,
                            a->total_edit_rows, 0, row_note_edit);
@@ -369,11 +381,6 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
                                a->total_out_rows, row_note_out, ctx->plan.hop);
             LAUNCH_CHECK(ctx);
         }
-    }
-    if (a->total_samples > 0) {
-        hipLaunchKernelGGL(k_sample_assemble, dim3((unsigned)((a->total_samples + 256 * SA_SPT - 1) / (256 * SA_SPT))), dim3(256), 0, st, *a,
-                           a->total_samples);
-        LAUNCH_CHECK(ctx);
     }
     return GOOFER_OK;
 }

@@ -45,6 +45,10 @@ struct goofer_ctx {
     bool overlap = true;          // noise spectra + mask smoothing on a side stream, beside the latency-bound pulse walk
     hipStream_t side = nullptr;   // created on first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // goofer_render_batch: the pulse chain forks as soon as the assembled f0 exists, not when the synthesis call starts
+    hipEvent_t ev_entry = nullptr, ev_f0 = nullptr, ev_f0s = nullptr;
+    bool early_req = false;           // set for the duration of one goofer_render_batch
+    const float *early_f0 = nullptr;  // f0 array ev_f0 stands for (null: no event recorded)
     hipEvent_t *prof_side = nullptr;    // [prof_cap][4]: boundaries of the pulse chain on the side stream
     hipEvent_t *prof_main2 = nullptr;   // [prof_cap][2]: ends of noise_spectra / mask_short when they run beside it
     bool prof_side_used = false;

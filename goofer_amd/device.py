@@ -285,8 +285,10 @@ class Context:
     def synth_batch(self, env, env_lengths, f0, mask, sample_lengths, params: np.ndarray, formants=None, phi=None,
                     seed: int = 0, transition_sigma: float = 100.0, want_rec=True, want_mix=True, offsets=None,
                     noise_f0=None, noise_vol=None, f0_jitter_speed: float = 100.0, vol_jitter_speed: float = 150.0,
-                    subharm=None, volume_vibrato: bool = False, env_noise=None, mix_only: bool = False, noise_subharm=None):
-        """Run goofer_synth_batch.
+                    subharm=None, volume_vibrato: bool = False, env_noise=None, mix_only: bool = False, noise_subharm=None,
+                    assembly=None):
+        """Run goofer_synth_batch — or, given the ``assembly`` descriptor that produces this batch's f0 / mask / env,
+        goofer_render_batch (assembly + synthesis as one call, the pulse chain forked as soon as f0 exists).
 
         ``subharm`` = dict(semitones, vibrato, rate, depth, delay) switches the sub-harmonic pulse layer on for the
         notes whose params.subharm_weight > 0 (gf.synthesize's add_subharm, GOOFER.py:1076-1097).
@@ -332,7 +334,10 @@ class Context:
                        harm=out["harm"].data_ptr(),
                        uv=out["uv"].data_ptr(), bre=out["bre"].data_ptr(),
                        rec=out["rec"].data_ptr() if want_rec else None, mix=out["mix"].data_ptr() if want_mix else None)
-        self._check(self.lib.goofer_synth_batch(self.h, C.byref(b), self._stream()))
+        if assembly is not None:
+            self._check(self.lib.goofer_render_batch(self.h, C.byref(assembly), C.byref(b), self._stream()))
+        else:
+            self._check(self.lib.goofer_synth_batch(self.h, C.byref(b), self._stream()))
         out["_keep"] = (d_s, d_f, d_e, d_par)   # keep device-side descriptors alive until the caller syncs
         out["sample_off"], out["frame_off"] = s_off, f_off
         return out

@@ -2,8 +2,8 @@
 
 ``Renderer.render(jobs)`` takes any number of (source features, 13-argument request) pairs, plans them on
 the host (``sampler.plan_note``: scalars, index plans, few-hundred-value tracks), uploads the plans and
-runs two C-ABI calls: ``goofer_assemble_batch`` (SillySampler.resample up to the synthesize call) and
-``goofer_synth_batch`` (gf.synthesize + V/B/U mix).  ``GooferResampler`` keeps the reference's
+runs ``goofer_render_batch``: ``goofer_assemble_batch`` (SillySampler.resample up to the synthesize call) and
+``goofer_synth_batch`` (gf.synthesize + V/B/U mix) as one call.  ``GooferResampler`` keeps the reference's
 construct-to-render, one-note call surface (SillySampler.py:285-413) on top of it.
 """
 from __future__ import annotations
@@ -100,15 +100,18 @@ class Renderer:
         ctx = self.ctx
         ctx._check(ctx.lib.goofer_assemble_batch(ctx.h, C.byref(prep["assembly"]), ctx._stream()))
 
-    def run(self, prep, seed: int = 0, keep_stems: bool = False):
-        """The device work of one batch: goofer_assemble_batch then goofer_synth_batch (asynchronous)."""
+    def run(self, prep, seed: int = 0, keep_stems: bool = False, split: bool = False):
+        """The device work of one batch (asynchronous): goofer_render_batch, i.e. assembly + synthesis as one call;
+        ``split=True`` issues goofer_assemble_batch and goofer_synth_batch separately (same results)."""
         ctx = self.ctx
-        self.assemble(prep)
+        if split:
+            self.assemble(prep)
         out = ctx.synth_batch(prep["env"], prep["env_lens"], prep["f0"], prep["mask"], prep["lens"], prep["params"],
                               formants=prep["formants"], phi=prep["phi"], seed=seed, want_rec=False, want_mix=True,
                               offsets=prep["offsets"], noise_f0=prep["noise_f0"], noise_vol=prep["noise_vol"],
                               subharm=S.SUBHARM if prep["subharm"] else None,
-                              mix_only=prep["post"] is None and not keep_stems)
+                              mix_only=prep["post"] is None and not keep_stems,
+                              assembly=None if split else prep["assembly"])
         if prep["post"] is not None:
             self._post_chain(prep, out, seed)
         return out

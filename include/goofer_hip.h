@@ -285,6 +285,14 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *batch, void *stream)
  * voicing mask and pitch curve (SillySampler.py:449-855).  Outputs feed goofer_synth_batch directly. */
 int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *assembly, void *stream);
 
+/* SillySampler.resample for one batch as ONE call (SillySampler.py:449-1151 without the post chain): exactly
+ * goofer_assemble_batch followed by goofer_synth_batch — same kernels, same results — for a batch whose
+ * assembly->f0_out is batch->f0.  With both descriptors in hand everything they point to must already be enqueued on
+ * `stream` (or complete) when the call is made; that lets the synthesis' pulse chain (f0 scaling, the sequential
+ * phase walk, pulse placement) start on the handle's side stream as soon as the assembled f0 exists, beside the
+ * envelope assembly, instead of when the synthesis' first kernel is reached in stream order. */
+int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *assembly, const goofer_batch *batch, void *stream);
+
 /* gf.stretch_feature (GOOFER.py:597-616): np.interp(linspace(0,1,rows_out), linspace(0,1,rows_in), column) along
  * axis 0 of a [rows x n_cols] fp32 matrix with row strides ld_in / ld_out (n_cols = 1, ld = 1: a 1-D array). */
 int goofer_stretch_rows(goofer_ctx *ctx, const float *in, int64_t ld_in, int64_t rows_in, float *out, int64_t ld_out,

@@ -155,6 +155,31 @@ def test_baseline_config_notes_vs_oracle(config, ids):
         ctx.close()
 
 
+@pytest.mark.parametrize("config", [3, 4])
+def test_render_batch_equals_separate_calls(config):
+    """goofer_render_batch (pulse chain forked as soon as the assembled f0 exists) against goofer_assemble_batch followed by
+    goofer_synth_batch, bit for bit, twice in a row (the second run re-uses the scratch arena the first one left)."""
+    from goofer_amd.device import Context
+    from goofer_amd.workload import SamplerWorkload
+    ctx = Context(0)
+    try:
+        wl = SamplerWorkload(ctx, config, list(range(24)))
+        r = wl.renderer
+        ref = r.run(wl.prep, seed=3, split=True)["mix"].clone()
+        torch.cuda.synchronize()
+        for _ in range(2):
+            got = r.run(wl.prep, seed=3)["mix"]
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref)
+        ctx.set_option("overlap", 0)
+        got = r.run(wl.prep, seed=3)["mix"]
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+        assert float(ref.abs().max()) > 0
+    finally:
+        ctx.close()
+
+
 def test_jitter_flags_sh_sr_match_reference(renderer):
     """sh (f0 jitter) + sr (volume jitter): legacy-RNG draws seeded like the reference run."""
     g, source, req = _job("sh50sr50")
