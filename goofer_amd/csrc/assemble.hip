@@ -154,39 +154,49 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
 }
 
 // ---------------------------------------------------------------------------------------------
-// source mask value at index q of the (possibly reversed) source, before tiling
-__device__ __forceinline__ double mask_src(const float *__restrict__ m, const goofer_note_plan &p, int64_t idx)
+// source mask value at index q of the (possibly reversed) source, before tiling.  Indices inside a note are 32-bit: the
+// plan's lengths are int32, and 64-bit integer arithmetic and int64 -> double conversions are several instructions each.
+__device__ __forceinline__ double mask_src(const float *__restrict__ m, const goofer_note_plan &p, int idx)
 {
     if (p.force_voiced) return 1.0;
-    return (double)m[p.reverse ? p.ylen - 1 - idx : idx];
+    return (double)m[p.reverse ? (int)p.ylen - 1 - idx : idx];
 }
 
 // mask of the assembled note BEFORE the velocity stretch, at index q in [0, n_before_vel)
-__device__ __forceinline__ double mask_stage1(const float *__restrict__ m, const goofer_note_plan &p, int64_t q)
+__device__ __forceinline__ double mask_stage1(const float *__restrict__ m, const goofer_note_plan &p, int q)
 {
     if (q < p.n_pre) return mask_src(m, p, p.s_pre + q);
-    uint32_t k = (uint32_t)(q - p.n_pre);                    // lengths are int32 in the plan: 32-bit modulo, not the 64-bit emulation
+    uint32_t k = (uint32_t)(q - p.n_pre);
     if (p.tail_len < p.want_samples) k = k % (uint32_t)p.tail_len;
-    return mask_src(m, p, p.s_tail + (int64_t)k);
+    return mask_src(m, p, p.s_tail + (int)k);
+}
+
+// x / d with r = RN(1 / d) at hand: q = RN(x r), the FMA residual x - q d is exact, and RN(q + residual r) is the
+// correctly rounded quotient (Markstein 1990) for operands and quotients in the normal range — three FMAs instead of
+// the dozen instructions of the IEEE division sequence.
+__device__ __forceinline__ double div_by(double x, double d, double r)
+{
+    const double q = x * r;
+    return fma(fma(-q, d, x), r, q);
 }
 
 __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, const goofer_note_plan &p, int64_t g)
 {
-    const int64_t i = g - p.out_sample_off;
+    const int i = (int)(g - p.out_sample_off);
     const float *m = a.mask_src + p.src_sample_off;
 
     // voicing mask: direct, or np.interp over the pre-velocity sequence at old_pos   :176-187, 787-788
     double mk;
     if (p.vel_active) {
-        double pos = i < p.pre_new ? (double)i / p.vel_factor : (double)(i - p.pre_new) + (double)p.n_pre;
-        int64_t n1 = p.n_before_vel;
-        int64_t j = (int64_t)floor(pos);
+        const double pos = i < p.pre_new ? (double)i / p.vel_factor : (double)(i - p.pre_new) + (double)p.n_pre;
+        const int n1 = p.n_before_vel;
+        int j = pos >= 2147483647.0 ? n1 - 1 : (int)floor(pos);
         if (j > n1 - 1) j = n1 - 1;
         if (j < 0) j = 0;
         if (j >= n1 - 1) {
             mk = mask_stage1(m, p, n1 - 1);
         } else {
-            double y0 = mask_stage1(m, p, j), y1 = mask_stage1(m, p, j + 1);
+            const double y0 = mask_stage1(m, p, j), y1 = mask_stage1(m, p, j + 1);
             mk = pos == (double)j ? y0 : (y1 - y0) * (pos - (double)j) + y0;
         }
     } else {
@@ -195,27 +205,27 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
 
     // pitch curve: bend cents/100 + MIDI (+t), ticks of 60/(tempo*96) s, clamped linear interpolation
     const double *bend = a.bend + p.bend_off;                // MIDI semitones per tick, built on the host like the reference
-    double tsec = (double)i / (double)a.sr;
+    const double sr = (double)a.sr;
+    double tsec = div_by((double)i, sr, 1.0 / sr);           // np.arange(n) / sr
     const double t_last = (double)(p.n_bend - 1) * p.tick_dt;
     tsec = tsec < 0.0 ? 0.0 : (tsec > t_last ? t_last : tsec);
     double midi;
-    auto semi = [&](int64_t k) { return bend[k]; };
     if (p.n_bend == 1) {
-        midi = semi(0);
+        midi = bend[0];
     } else {
-        int64_t j = (int64_t)(tsec * fast_rcp(p.tick_dt));   // estimate; the two loops below settle it on the true tick grid
+        int j = (int)(tsec * fast_rcp(p.tick_dt));           // estimate; the two loops below settle it on the true tick grid
         if (j > p.n_bend - 1) j = p.n_bend - 1;
         while (j + 1 <= p.n_bend - 1 && (double)(j + 1) * p.tick_dt <= tsec) ++j;
         while (j > 0 && (double)j * p.tick_dt > tsec) --j;
         if (j >= p.n_bend - 1) {
-            midi = semi(p.n_bend - 1);
+            midi = bend[p.n_bend - 1];
         } else {
-            double y0 = semi(j), y1 = semi(j + 1);
-            double x0 = (double)j * p.tick_dt, x1 = (double)(j + 1) * p.tick_dt;
+            const double y0 = bend[j], y1 = bend[j + 1];
+            const double x0 = (double)j * p.tick_dt, x1 = (double)(j + 1) * p.tick_dt;
             midi = tsec == x0 ? y0 : ((y1 - y0) * fast_rcp(x1 - x0)) * (tsec - x0) + y0;
         }
     }
-    const double hz = 440.0 * exp2((midi - 69.0) / 12.0);
+    const double hz = 440.0 * exp2(div_by(midi - 69.0, 12.0, 0.083333333333333329));   // RN(1/12)
     a.mask_out[g] = (float)mk;
     double f0 = mk * hz;
     if (p.pd_on && a.bend_out) a.bend_out[g] = (float)(midi - p.pd_base);                    // 'pd' bend in semitones   :861-863
@@ -225,7 +235,7 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
         if (i >= p.fry_const_lo && i < p.fry_const_hi) {
             f0 = base_hz;
         } else if (i >= p.fry_glide_lo && i < p.fry_glide_hi) {
-            const int m = p.fry_glide_hi - p.fry_glide_lo, k = (int)(i - p.fry_glide_lo);
+            const int m = p.fry_glide_hi - p.fry_glide_lo, k = i - p.fry_glide_lo;
             double w;                                         // np.linspace(0, 1, m) or np.linspace(1, 0, m), endpoint pinned
             if (p.fry_dir > 0) w = m > 1 ? (k == m - 1 ? 1.0 : (double)k * (1.0 / (double)(m - 1))) : 0.0;
             else w = m > 1 ? (k == m - 1 ? 0.0 : (double)k * (-1.0 / (double)(m - 1)) + 1.0) : 1.0;

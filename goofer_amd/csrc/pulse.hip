@@ -433,12 +433,12 @@ __global__ __launch_bounds__(64) void k_onset_finish(const float *__restrict__ f
     }
 }
 
-// One workgroup = 1024 consecutive samples (4 per thread).  When the tile lies inside one note (almost
+// One workgroup = 256 * PP_SPT consecutive samples.  When the tile lies inside one note (almost
 // always) the onsets that can touch it — first onset whose running end_max passes the tile start, up to
 // the last onset starting inside the tile — are staged once in LDS; every sample then scans that short
 // list in ascending onset order (the reference's accumulation order).  Other tiles (note boundaries, or
 // more onsets than the LDS list holds) take the per-sample search of the compact list in global memory.
-#define PP_SPT 4
+#define PP_SPT 8
 #define PP_MAXON 512
 
 __device__ __forceinline__ float pulse_value(const onset_t &o, int j, const float *__restrict__ peak, const float *__restrict__ tab)
@@ -500,17 +500,36 @@ __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__
         const onset_t *ol = onsets + (base / 2 + 16 * (int64_t)lo_n);
         for (int k = threadIdx.x; k < nk; k += blockDim.x) s_on[k] = ol[k0 + k];
         __syncthreads();
+        // a thread owns PP_SPT consecutive samples (16-byte stores): they share their covering onsets, so the short
+        // search — last onset starting at or before the fourth sample, back to the first whose running end_max passes
+        // the first sample — is paid once per PP_SPT outputs, and the sums run over those one to three onsets only
+        const int64_t g = g0 + (int64_t)threadIdx.x * PP_SPT;
+        if (g > gl) return;
+        const int32_t j = (int32_t)(g - base);
+        const int live = gl - g + 1 < PP_SPT ? (int)(gl - g + 1) : PP_SPT;
+        int lo = -1, hi = nk;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_on[mid].i <= j + live - 1) lo = mid; else hi = mid;
+        }
+        float acc[PP_SPT];
 #pragma unroll
-        for (int u = 0; u < PP_SPT; ++u) {
-            const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;      // coalesced: stride blockDim between a thread's samples
-            if (g >= total_samples) break;
-            const int32_t j = (int32_t)(g - base);
-            float acc = 0.f;
-            for (int k = 0; k < nk; ++k) {
-                if (s_on[k].i > j) break;                                        // sorted by onset sample
-                acc += pulse_value(s_on[k], j, peak, tab);
+        for (int e = 0; e < PP_SPT; ++e) acc[e] = 0.f;
+        if (lo >= 0) {
+            int first = lo;
+            while (first > 0 && s_on[first - 1].end_max > j) --first;
+            for (int k = first; k <= lo; ++k) {                                  // ascending onsets: the reference's order
+                const onset_t o = s_on[k];
+#pragma unroll
+                for (int e = 0; e < PP_SPT; ++e) acc[e] += pulse_value(o, j + e, peak, tab);
             }
-            pulse[g] = acc;
+        }
+        if (live == PP_SPT) {
+#pragma unroll
+            for (int e = 0; e < PP_SPT; e += 4)
+                *reinterpret_cast<float4 *>(pulse + g + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+        } else {
+            for (int e = 0; e < live; ++e) pulse[g + e] = acc[e];
         }
         return;
     }
@@ -580,7 +599,7 @@ int launch_pulse_place(goofer_ctx *ctx, const onset_t *onsets, const int32_t *on
                        int64_t total_samples, float *pulse, hipStream_t st)
 {
     if (total_samples <= 0) return GOOFER_OK;
-    hipLaunchKernelGGL(k_pulse_place, dim3((unsigned)((total_samples + 1023) / 1024)), dim3(256), 0, st, onsets, onset_cnt,
+    hipLaunchKernelGGL(k_pulse_place, dim3((unsigned)((total_samples + 256 * PP_SPT - 1) / (256 * PP_SPT))), dim3(256), 0, st, onsets, onset_cnt,
                        ctx->plan.pulse_peak, ctx->plan.pulse_shape, sample_off, n_notes, total_samples, pulse);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
