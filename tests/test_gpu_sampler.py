@@ -1,5 +1,7 @@
 """GPU: the 13-argument resampler path (plan on host, assemble + synthesize on the device) against the
 reference's renders of the same (features, flags, pitch string) with the same injected phases."""
+import os
+
 import numpy as np
 import pytest
 
@@ -246,7 +248,7 @@ def test_dense_feature_source_vs_oracle(renderer):
 _random_flags = syn.random_flags
 
 
-@pytest.mark.parametrize("case", range(48))
+@pytest.mark.parametrize("case", range(int(os.environ.get("GOOFER_FUZZ_CASES", "48"))))   # a soak run sets it to a few hundred
 def test_random_flag_combinations_vs_oracle(renderer, case):
     """Flag interactions: random subsets of the whole vocabulary (assembly edits, jitter / sub-harmonic layers, post chain
     together), one note at a time so the legacy-RNG draw order matches, against the oracle's full render."""
