@@ -12,15 +12,15 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgoofer_hip.so")
 
-# numpy mirror of goofer_note_params (C layout, 104 bytes; checked against goofer_sizeof)
+# numpy mirror of goofer_note_params (C layout, 112 bytes; checked against goofer_sizeof)
 NOTE_PARAMS = np.dtype({
     "names": ["pitch_shift", "formant_shift", "f_shift", "uv_strength", "breath_strength", "normalize",
               "apply_brightness", "cut_below_f0", "mix_harm", "mix_breath", "mix_unvoiced", "volume", "seed",
-              "f0_jitter", "vol_jitter_harm", "vol_jitter_breath", "subharm_weight", "subharm_f0_jitter"],
+              "vol_jitter_harm", "vol_jitter_breath", "subharm_weight", "f0_jitter", "subharm_f0_jitter"],
     "formats": ["<f4", "<f4", ("<f8", 4), "<f4", "<f4", "<f4", "<i4", "<i4", "<f4", "<f4", "<f4", "<f4", ("<u4", 2),
-                "<f4", "<f4", "<f4", "<f4", "<f4"],
-    "offsets": [0, 4, 8, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 84, 88, 92, 96, 100],
-    "itemsize": 104,
+                "<f4", "<f4", "<f4", "<f8", "<f8"],
+    "offsets": [0, 4, 8, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 84, 88, 92, 96, 104],
+    "itemsize": 112,
 })
 
 
@@ -63,6 +63,7 @@ class Assembly(C.Structure):
         ("tap_idx", C.c_void_p), ("tap_w", C.c_void_p), ("fst_tracks", C.c_void_p), ("mask_src", C.c_void_p), ("bend", C.c_void_p),
         ("edit_rows", C.c_void_p), ("env_out", C.c_void_p), ("f0_out", C.c_void_p), ("mask_out", C.c_void_p),
         ("bend_out", C.c_void_p), ("any_fry", C.c_int32), ("reserved5", C.c_int32),
+        ("f0_mul", C.c_void_p), ("f0_mul_out", C.c_void_p),
     ]
 
 

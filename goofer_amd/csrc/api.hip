@@ -159,7 +159,7 @@ __global__ void k_note_sub_flags(const goofer_note_params *__restrict__ params, 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_notes) {
         on_sub[i] = params[i].subharm_weight > 0.f;
-        on_subj[i] = params[i].subharm_weight > 0.f && params[i].subharm_f0_jitter > 0.f;
+        on_subj[i] = params[i].subharm_weight > 0.f && params[i].subharm_f0_jitter > 0.0;
     }
 }
 
@@ -168,7 +168,7 @@ __global__ void k_note_flags(const goofer_note_params *__restrict__ params, int 
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_notes) return;
-    on_f0[i] = params[i].f0_jitter > 0.f;
+    on_f0[i] = params[i].f0_jitter > 0.0;
     on_vol[i] = params[i].vol_jitter_harm > 0.f || params[i].vol_jitter_breath > 0.f;
 }
 

@@ -243,6 +243,7 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
         }
     }
     a.f0_out[g] = (float)f0;
+    if (a.f0_mul_out) a.f0_mul_out[g] = (float)(f0 * a.f0_mul[g]);                           // 'sj' layer f0, one rounding   :1065
 }
 
 

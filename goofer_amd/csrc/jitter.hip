@@ -94,11 +94,11 @@ __global__ __launch_bounds__(256) void k_f0_jitter(float *__restrict__ f0, const
     if (g >= total) return;
     int note = lo;
     while (sample_off[note + 1] <= g) ++note;
-    const float strength = which == 0 ? params[note].f0_jitter                                    // :1071 / :1080
-                                      : (params[note].subharm_weight > 0.f ? params[note].subharm_f0_jitter : 0.f);
-    if (!(strength > 0.f)) return;
+    const double strength = which == 0 ? params[note].f0_jitter                                   // :1071 / :1080
+                                       : (params[note].subharm_weight > 0.f ? params[note].subharm_f0_jitter : 0.0);
+    if (!(strength > 0.0)) return;
     const double mx = __longlong_as_double((long long)max_bits[note]);
-    const double jit = 1.0 + (noise_s[g] / mx) * (double)strength;
+    const double jit = 1.0 + (noise_s[g] / mx) * strength;     // python-float strength: fp64 like the reference
     f0[g] = (float)((double)f0[g] * (1.0 + ((jit - 1.0) * (double)mask[g])));
 }
 

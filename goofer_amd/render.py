@@ -161,9 +161,9 @@ class Renderer:
             extra["su"], off = self._extra_synth(prep, su, seed, edit=half)
             post["su_off"][su] = off[:-1]
         if sj:
-            scale = ctx.tensor(np.concatenate([prep["growl"][i] for i in sj]))
-            def growl(sub, par):
-                sub["f0"] = (sub["f0"].double() * scale).float()
+            so = prep["sample_off"]
+            def growl(sub, par):                                # f0_new * (0.5 * 2^noise), written by the assembly   :1065
+                sub["f0"] = torch.cat([prep["f0_growl"][int(so[i]):int(so[i + 1])] for i in sj])
             extra["sj"], off = self._extra_synth(prep, sj, seed, edit=growl)
             post["sj_off"][sj] = off[:-1]
         if sa:                                                  # all-voiced, full-strength noise, transition sigma 1   :1153-1168
@@ -360,6 +360,17 @@ class Renderer:
             if req.growl_mix > 0.0:                            # 'sj': f0 * 0.5 * 2^N(0, mix^2), a fresh generator per call  :1063-1065
                 rng = np.random.default_rng(phi_seeds[i]) if phi_seeds is not None else np.random.default_rng()
                 growl[i] = 0.5 * (2.0 ** rng.normal(loc=0.0, scale=req.growl_mix ** 2, size=pl.n_out))
+        f0_growl = None
+        if growl:
+            # the layer's f0 is the fp64 pitch curve times the factor, rounded to fp32 once (SillySampler.py:1065): the
+            # assembly kernel writes it next to f0 while it still holds the fp64 value
+            so = np.concatenate([[0], np.cumsum(lens)])
+            mul = np.ones(int(so[-1]), dtype=np.float64)
+            for i, gv in growl.items():
+                mul[int(so[i]):int(so[i + 1])] = gv
+            d["f0_mul"] = ctx.tensor(mul)
+            f0_growl = torch.zeros(int(so[-1]), dtype=torch.float32, device=ctx.device)
+            a.f0_mul, a.f0_mul_out = d["f0_mul"].data_ptr(), f0_growl.data_ptr()
         has_post = any(r.subharm_gain > 0 or r.growl_mix > 0 or r.aperiodic_mix > 0 or r.sd_strength > 0 or r.tension != 0
                        or r.pitch_dyn != 0 for _, r in jobs) or any_fry
         env_lens = [p.tap_idx.shape[0] for p in plans]
@@ -376,7 +387,7 @@ class Renderer:
         torch.cuda.synchronize(ctx.device)
         return {"assembly": a, "keep": d, "env": env, "f0": f0, "mask": mask, "params": par, "lens": lens, "env_lens": env_lens,
                 "noise_f0": noise_f0, "noise_vol": noise_vol, "subharm": any(r.add_subharm for _, r in jobs),
-                "post": post if has_post else None, "growl": growl, "bend_out": bend_out, "jobs": jobs,
+                "post": post if has_post else None, "growl": growl, "f0_growl": f0_growl, "bend_out": bend_out, "jobs": jobs,
                 "formants": ctx.tensor(np.concatenate(F_cat)), "phi": phi, "plans": plans, "offsets": offsets,
                 "sample_off": np.concatenate([[0], np.cumsum(lens)]), "env_off": np.concatenate([[0], np.cumsum(env_lens)]),
                 "frames": frames, "samples": int(sum(lens)), "edit_rows": e_off}

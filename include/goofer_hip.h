@@ -47,11 +47,13 @@ typedef struct {
     float mix_harm, mix_breath, mix_unvoiced, volume;   /* V, (B+100)/100, (U+100)/100, volume */
     uint32_t seed[2];           /* per-note Philox key (lo, hi), XORed with the batch seed: a note's  */
                                 /* noise never depends on where it sits in a batch                    */
-    float f0_jitter;            /* 'sh': f0_jitter_strength, 0 = off              GOOFER.py:1069-1071 */
     float vol_jitter_harm;      /* 'sr': volume_jitter_strength_harm, 0 = off     GOOFER.py:1185-1191 */
     float vol_jitter_breath;    /*       volume_jitter_strength_breath                                */
     float subharm_weight;       /* 'sg': +12 st pulse layer weight, 0 = off       GOOFER.py:1076-1097 */
-    float subharm_f0_jitter;    /* jitter of the f0 the sub-harmonic layer tracks; applied IN PLACE after the pulse   */
+    /* The two f0 jitter strengths are python floats in the reference and scale a factor that is rounded into the fp32 f0   */
+    /* the pulse onsets are derived from: they stay fp64 (an fp32 strength moves a fifth of the f0 samples by an ulp).    */
+    double f0_jitter;           /* 'sh': f0_jitter_strength, 0 = off              GOOFER.py:1069-1071 */
+    double subharm_f0_jitter;   /* jitter of the f0 the sub-harmonic layer tracks; applied IN PLACE after the pulse   */
                                 /* train, so the later per-frame f0 picks see it too (the reference's aliasing) :1078-1080 */
 } goofer_note_params;
 
@@ -165,6 +167,12 @@ typedef struct {
     float *f0_out, *mask_out;        /* [total_samples]                                                    */
     float *bend_out;                 /* [total_samples] pitch-bend semitones of the 'pd' notes, or NULL    */
     int32_t any_fry, reserved5;      /* some note has fry_a < fry_b: run the envelope fry warp             */
+    /* 'sj' growl layer (SillySampler.py:1061-1065): its f0 is f0_new * (0.5 * 2^noise) with f0_new still fp64, rounded */
+    /* to fp32 ONCE inside synthesize.  f0_mul [total_samples] fp64 factors (anything on notes without the layer) and   */
+    /* f0_mul_out [total_samples] = (float)(fp64 f0 * f0_mul), or both NULL.  Scaling the rounded f0_out instead moves    */
+    /* two thirds of the layer's f0 samples by an ulp, enough to flip a pulse onset in ~3 % of such notes.              */
+    const double *f0_mul;
+    float *f0_mul_out;
 } goofer_assembly;
 
 /* One time-varying one-pole cascade (dynamic_butter_filter, SillySampler.py:95-174): `order` sections of

@@ -29,7 +29,7 @@ def test_binding_covers_header_and_struct_layout():
     assert set(_declared()) <= set(_lib.EXPORTS)
     lib = _lib.load()
     assert lib.goofer_version().startswith(b"goofer_hip")
-    assert _lib.NOTE_PARAMS.itemsize == lib.goofer_sizeof(0) == 104
+    assert _lib.NOTE_PARAMS.itemsize == lib.goofer_sizeof(0) == 112
     assert ctypes.sizeof(_lib.Batch) == lib.goofer_sizeof(1)
     assert _lib.NOTE_PLAN.itemsize == lib.goofer_sizeof(2)
     assert ctypes.sizeof(_lib.Assembly) == lib.goofer_sizeof(3)

@@ -248,7 +248,10 @@ def test_dense_feature_source_vs_oracle(renderer):
 _random_flags = syn.random_flags
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("GOOFER_FUZZ_CASES", "48"))))   # a soak run sets it to a few hundred
+_FUZZ_FIRST = int(os.environ.get("GOOFER_FUZZ_FIRST", "0"))          # a soak run: GOOFER_FUZZ_FIRST=3000 GOOFER_FUZZ_CASES=9000
+
+
+@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + int(os.environ.get("GOOFER_FUZZ_CASES", "48"))))
 def test_random_flag_combinations_vs_oracle(renderer, case):
     """Flag interactions: random subsets of the whole vocabulary (assembly edits, jitter / sub-harmonic layers, post chain
     together), one note at a time so the legacy-RNG draw order matches, against the oracle's full render."""
