@@ -282,6 +282,34 @@ def test_random_flag_combinations_vs_oracle(renderer, case):
 COMBOS = [str(n) for n in golden("combo_index")["names"]]
 
 
+@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + max(4, int(os.environ.get("GOOFER_FUZZ_CASES", "48")) // 12)))
+def test_random_mixed_batch_equals_single_notes(renderer, case):
+    """Six notes with unrelated random flag strings (assembly edits, jitter / sub-harmonic layers, post chain) rendered as ONE
+    ragged batch against the same notes rendered one at a time: bit for bit.  The legacy-RNG draws are made note by note in
+    both modes, so one seed in front of either run gives every note the same noise."""
+    from goofer_amd.render import Source
+    from goofer_amd import sampler as S
+    rng = np.random.default_rng(50000 + case)
+    jobs, seeds = [], []
+    for k in range(6):
+        src = syn.make_source(60000 + 10 * case + k, seconds=float(rng.uniform(0.25, 0.5)))
+        flags = _random_flags(rng)
+        pitch = ["A3", "C4", "E4", "G#4", "D5"][int(rng.integers(0, 5))]
+        args = (pitch, str(int(rng.choice([60, 100, 140]))), flags, str(int(rng.integers(0, 60))), str(int(rng.integers(150, 500))),
+                str(int(rng.integers(0, 120))), str(int(rng.choice([-200, 30, 80]))), str(int(rng.integers(50, 121))), "0",
+                "!" + str(int(rng.choice([90, 120, 150]))), ["AA", "AA#5#AF#3#/+", "B7CPCV#2#Cb"][int(rng.integers(0, 3))])
+        jobs.append((Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]),
+                     S.decode_request(*args)))
+        seeds.append(7000 + 6 * case + k)
+    np.random.seed(case)
+    batch = renderer.render(jobs, phi_seeds=seeds)
+    np.random.seed(case)
+    for k, job in enumerate(jobs):
+        (one,) = renderer.render([job], phi_seeds=[seeds[k]])
+        assert one.shape == batch[k].shape
+        assert np.array_equal(one, batch[k]), (case, k, float(np.max(np.abs(one - batch[k]))))
+
+
 @pytest.mark.parametrize("name", COMBOS)
 def test_flag_combinations_match_reference(renderer, name):
     """The same 16 random flag subsets the reference rendered (tests/golden/combo_*.npz), on the device."""
