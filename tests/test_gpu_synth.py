@@ -4,6 +4,7 @@ Tolerance: BASELINE.json's north_star asks <= 1e-4 sample-RMS on identical (feat
 curve, injected phases); outputs are peak-normalised (|x| <= 1), so this is an absolute figure.
 """
 import json
+import os
 
 import numpy as np
 import pytest
@@ -207,6 +208,58 @@ def test_synthesize_subharm_kwargs_vs_oracle(ctx, kw):
     assert rms_err(got[1], plain[1]) > 1e-3                     # the layer is audible, not a no-op
     for a, b, key in zip(got, ref, ("rec", "harm", "uv", "bre")):
         assert rms_err(a, b) < 2e-5, (key, rms_err(a, b))
+
+
+_SOAK_FIRST = int(os.environ.get("GOOFER_FUZZ_FIRST", "0"))
+
+
+@pytest.mark.parametrize("case", range(_SOAK_FIRST, _SOAK_FIRST + max(12, int(os.environ.get("GOOFER_FUZZ_CASES", "48")) // 4)))
+def test_synthesize_random_kwargs_vs_oracle(ctx, case):
+    """gf.synthesize's keyword surface in random combinations (shifts, strengths, switches, jitter, sub-harmonic layer,
+    time stretch) against the oracle, same legacy RNG stream and injected phases on both sides."""
+    from goofer_amd import core
+    from oracle import goofer_ref as R
+    g = golden("synthesize")
+    c = _case(g, "plain")
+    rng = np.random.default_rng(31000 + case)
+    pick = lambda p: rng.random() < p
+    kw = {}
+    if pick(0.5): kw["pitch_shift"] = float(np.round(rng.uniform(0.6, 1.7), 3))
+    if pick(0.5): kw["formant_shift"] = float(np.round(rng.uniform(0.7, 1.4), 3))
+    for k in ("F1_shift", "F2_shift", "F3_shift", "F4_shift"):
+        if pick(0.4): kw[k] = float(np.round(rng.uniform(0.7, 1.4), 2))
+    if pick(0.5): kw["normalize"] = float(np.round(rng.uniform(0.0, 1.0), 2))
+    if pick(0.3): kw["breath_strength"] = float(np.round(rng.uniform(0.0, 0.5), 3))
+    if pick(0.3): kw["uv_strength"] = float(np.round(rng.uniform(0.0, 1.5), 3))
+    if pick(0.3): kw["apply_brightness"] = bool(pick(0.5))
+    if pick(0.3): kw["cut_subharm_below_f0"] = bool(pick(0.5))
+    if pick(0.4): kw.update(f0_jitter=True, f0_jitter_strength=float(np.round(rng.uniform(0.05, 1.5), 3)))
+    if pick(0.4):
+        kw.update(volume_jitter=True, volume_jitter_strength_harm=float(np.round(rng.uniform(0.1, 1.0), 3)),
+                  volume_jitter_strength_breath=float(np.round(rng.uniform(0.1, 2.0), 3)))
+        if pick(0.3): kw.update(volume_vibrato=True, volume_jitter_speed=float(np.round(rng.uniform(3.0, 12.0), 2)))
+    if pick(0.4):
+        kw.update(add_subharm=True, subharm_weight=float(np.round(rng.uniform(0.2, 1.2), 3)),
+                  subharm_semitones=[int(v) for v in rng.choice([-12, -5, 7, 12, 19], size=int(rng.integers(1, 4)), replace=False)])
+        if pick(0.5):
+            kw.update(subharm_vibrato=True, subharm_vibrato_rate=float(np.round(rng.uniform(4.0, 40.0), 2)),
+                      subharm_vibrato_depth=float(np.round(rng.uniform(0.05, 0.6), 3)),
+                      subharm_vibrato_delay=float(np.round(rng.uniform(0.0, 0.1), 3)))
+        if pick(0.3): kw["subharm_f0_jitter"] = float(np.round(rng.uniform(0.1, 1.0), 3))
+    phi = c["phi"]
+    if pick(0.25):
+        kw["stretch_factor"] = float(np.round(rng.uniform(0.6, 1.5), 2))
+        n_new = len(R.stretch_feature(c["f0"], kw["stretch_factor"]))
+        phi = np.random.default_rng(case).uniform(0.0, 2.0 * np.pi, size=(c["env"].shape[0], 1 + n_new // c["hop"])).astype(np.float32)
+    args = (c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"])
+    np.random.seed(300 + case)
+    ref = R.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=phi, **kw)
+    np.random.seed(300 + case)
+    got = core.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=phi, ctx=ctx, **kw)
+    for a, b, key in zip(got, ref, ("rec", "harm", "uv", "bre")):
+        assert a.shape == b.shape, (key, kw)
+        e = rms_err(a, b) / max(1.0, float(np.max(np.abs(b))))
+        assert e < 2e-5, (key, e, kw)
 
 
 @pytest.mark.parametrize("config,ids", [(3, [0, 1, 2, 3, 4, 5, 6]), (4, [0, 1, 2, 5, 7, 9]), (5, [0, 1])])
