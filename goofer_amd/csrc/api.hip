@@ -20,7 +20,7 @@ struct onset_t;
 int launch_pulse_train(goofer_ctx *, const float *, float, const int64_t *, int, int64_t, float *, double *, onset_t *, int32_t *,
                        int32_t *, int32_t *, hipStream_t);
 int launch_phase_inc(goofer_ctx *, const float *, float, int64_t, double *, hipStream_t);
-int launch_pulse_onsets(goofer_ctx *, const float *, float, const double *, const int64_t *, int, onset_t *, int32_t *, int32_t *,
+int launch_pulse_onsets(goofer_ctx *, const float *, float, const int64_t *, int, onset_t *, int32_t *, int32_t *,
                         int32_t *, hipStream_t);
 int launch_pulse_place(goofer_ctx *, const onset_t *, const int32_t *, const int64_t *, int, int64_t, float *, hipStream_t);
 int launch_subharm(goofer_ctx *, const float *, const float *, const int64_t *, int, int64_t, const goofer_note_params *, const double *, int,
@@ -1057,14 +1057,23 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // map kernels, instead of starting when this call's first kernel is reached in stream order.
     const bool side_on = ctx->overlap && ola_one && !sub_on;
     const bool early = side_on && !jit_f0 && ctx->early_req && ctx->early_f0 == b->f0 && ctx->side != nullptr;
+    // f0 * pitch_shift (GOOFER.py:995).  When the caller vouches that every pitch_shift is 1 (the resampler path: the pitch
+    // lives in the curve) and nothing jitters f0 in place, the input array IS the scaled f0 and the pass is skipped.
+    const bool f0_alias = b->unit_pitch_shift && !jit_f0 && !sub_jit;
+    if (f0_alias) {
+        f0s = const_cast<float *>(b->f0);
+        ctx->dbg_ptr[2] = f0s;
+    }
     MARK();   // 0: setup
     if (early) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_entry, 0));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_f0, 0));
         HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), ctx->side));
-        hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, ctx->side, b->f0, b->sample_off, n, N,
-                           b->params, f0s, inc, (double)p.sr);
-        LAUNCH_CHECK(ctx);
+        if (!f0_alias) {
+            hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, ctx->side, b->f0, b->sample_off, n, N,
+                               b->params, f0s, (double *)nullptr, (double)p.sr);
+            LAUNCH_CHECK(ctx);
+        }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_f0s, ctx->side));
     } else {
         HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), st));
@@ -1072,9 +1081,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, st))) return rc;
     hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, st, b->frame_off, b->env_off, frame_note, F, row_src);
     LAUNCH_CHECK(ctx);
-    if (!early) {
+    if (!early && !f0_alias) {
         hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s,
-                           jit_f0 ? (double *)nullptr : inc, (double)p.sr);     // jittered f0: increments after the jitter, below
+                           (double *)nullptr, (double)p.sr);            // the pulse walk divides by sr itself
         LAUNCH_CHECK(ctx);
     }
     if (jit_f0 || jit_vol) {
@@ -1113,10 +1122,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
 
     MARK();   // 3..5: pulse train
     if (sev) HIP_TRY(ctx, hipEventRecord(sev[0], pst));
-    if (jit_f0 && (rc = launch_phase_inc(ctx, f0s, 1.0f, N, inc, pst))) return rc;
     MARK();
     if (sev) HIP_TRY(ctx, hipEventRecord(sev[1], pst));
-    if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, inc, b->sample_off, n, (onset_t *)onsets, onset_idx, onset_cnt, ovf, pst))) return rc;
+    if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, b->sample_off, n, (onset_t *)onsets, onset_idx, onset_cnt, ovf, pst))) return rc;
     MARK();
     if (sev) HIP_TRY(ctx, hipEventRecord(sev[2], pst));
     if ((rc = launch_pulse_place(ctx, (onset_t *)onsets, onset_cnt, b->sample_off, n, N, pulse, pst))) return rc;

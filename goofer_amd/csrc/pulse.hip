@@ -3,7 +3,7 @@
 // The onset positions are a discontinuous function of a strictly sequential fp64 sum
 // (`total_phase += f0[i]/sr`, GOOFER.py:491-493): re-associating it moves onsets by a sample
 // (SURVEY.md §7.3-1).  So the work is split three ways:
-//   k_phase_inc     fully parallel: inc[i] = (double)f0[i] / sr  (true IEEE division)
+//   (k_phase_inc    inc[i] = (double)f0[i] / sr as a pass of its own: the sub-harmonic layer's tracker still uses one)
 //   k_pulse_onsets_scan  one WAVE per note walks its increments in order (nothing but the dependent fp64 adds) and
 //                   extracts the onset samples from the partial sums chunk by chunk, in parallel; k_onset_finish
 //                   completes the onset list (sample, T0, period, running max of sample+T0)
@@ -269,7 +269,7 @@ __device__ __forceinline__ int32_t wave_scan_incl(int32_t x, Op op)
 // phase it kept — the same additions in the same order, so the same partial sums — takes floor, and a max-scan and a
 // sum-scan across the wave give each lane R in front of its samples and the slot of its first onset.  Negative
 // increments and several onsets at one sample need no special case.
-__global__ __launch_bounds__(256) void k_pulse_onsets_scan(const double *__restrict__ inc, const int64_t *__restrict__ sample_off,
+__global__ __launch_bounds__(256) void k_pulse_onsets_scan(const float *__restrict__ f0, double sr, const int64_t *__restrict__ sample_off,
                                                            int n_notes, int32_t *__restrict__ onset_idx,
                                                            int32_t *__restrict__ onset_cnt, int32_t *__restrict__ overflow)
 {
@@ -283,12 +283,16 @@ __global__ __launch_bounds__(256) void k_pulse_onsets_scan(const double *__restr
     const int64_t n = sample_off[note + 1] - base;
     const int64_t obase = base / 2 + 16 * (int64_t)note;
     const int32_t cap = (int32_t)((sample_off[note + 1] / 2 + 16 * (int64_t)(note + 1)) - obase);
-    const double *__restrict__ a = inc + base;
+    // The increments f0[i] / sr (GOOFER.py:491) are formed here, in the parallel fetch stage, instead of by a pass of their
+    // own that writes 8 bytes per sample and reads them back.  With r = RN(1 / sr) the quotient correction
+    // q + fma(-q, sr, x) r is the correctly rounded x / sr (Markstein), i.e. the increment the reference divides out.
+    const float *__restrict__ a = f0 + base;
+    const double rsr = 1.0 / sr;
     int32_t *__restrict__ out = onset_idx + obase;
     double phase = 0.0;
     int32_t cnt = 0;                                          // onsets recorded so far == R
 
-    double r[8];
+    float r[8];
     auto fetch = [&](int64_t c0) {                            // wave-uniform branch on purpose, see k_pulse_onsets_wrap
         const int64_t s = c0 + (int64_t)lane * 8;
         if (c0 + OC <= n) {
@@ -298,8 +302,8 @@ __global__ __launch_bounds__(256) void k_pulse_onsets_scan(const double *__restr
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int64_t i = s + k;
-                const double v = a[i < n ? i : n - 1];
-                r[k] = i < n ? v : 0.0;
+                const float v = a[i < n ? i : n - 1];
+                r[k] = i < n ? v : 0.f;                       // 0 / sr = +0.0: the padding leaves the phase alone
             }
         }
     };
@@ -341,7 +345,10 @@ __global__ __launch_bounds__(256) void k_pulse_onsets_scan(const double *__restr
     for (int64_t c0 = 0; c0 < n; c0 += OC, buf ^= 1) {
         double *t = tile[buf];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[lane * 8 + k] = r[k];
+        for (int k = 0; k < 8; ++k) {
+            const double x = (double)r[k], q = x * rsr;
+            t[lane * 8 + k] = fma(fma(-q, sr, x), rsr, q);
+        }
         wave_lds_sync();
         if (c0 + OC < n) fetch(c0 + OC);                    // in flight during the walk below
         if (c0 > 0) emit(tile[buf ^ 1], kept_prev, (int32_t)(c0 - OC), OC);   // its stores complete during the walk as well
@@ -566,7 +573,7 @@ int launch_phase_inc(goofer_ctx *ctx, const float *f0, float f0_scale, int64_t t
     return GOOFER_OK;
 }
 
-int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const double *inc, const int64_t *sample_off,
+int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const int64_t *sample_off,
                         int n_notes, onset_t *onsets, int32_t *onset_idx, int32_t *onset_cnt, int32_t *overflow, hipStream_t st)
 {
     if (n_notes <= 0) return GOOFER_OK;
@@ -585,8 +592,8 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
             HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_pulse_onsets_scan, dim3(blocks), dim3(256), lds, st, inc, sample_off, n_notes, onset_idx, onset_cnt,
-                           overflow);
+        hipLaunchKernelGGL(k_pulse_onsets_scan, dim3(blocks), dim3(256), lds, st, f0, (double)ctx->plan.sr, sample_off, n_notes,
+                           onset_idx, onset_cnt, overflow);
         LAUNCH_CHECK(ctx);
     }
     hipLaunchKernelGGL(k_onset_finish, dim3(n_notes), dim3(64), 0, st, f0, sample_off, n_notes, (double)ctx->plan.sr, onset_idx,
@@ -611,8 +618,8 @@ int launch_pulse_train(goofer_ctx *ctx, const float *f0, float f0_scale, const i
 {
     if (total_samples <= 0 || n_notes <= 0) return GOOFER_OK;
     int rc;
-    if ((rc = launch_phase_inc(ctx, f0, f0_scale, total_samples, inc, st))) return rc;
-    if ((rc = launch_pulse_onsets(ctx, f0, f0_scale, inc, sample_off, n_notes, onsets, onset_idx, onset_cnt, overflow, st))) return rc;
+    (void)inc;                                                // the walk divides f0 by sr itself
+    if ((rc = launch_pulse_onsets(ctx, f0, f0_scale, sample_off, n_notes, onsets, onset_idx, onset_cnt, overflow, st))) return rc;
     return launch_pulse_place(ctx, onsets, onset_cnt, sample_off, n_notes, total_samples, pulse, st);
 }
 
