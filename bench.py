@@ -244,7 +244,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.config}: {args.notes} notes/GPU x ~1.1 s, sr {sr}, n_fft {n_fft}, "
                                    f"hop {hop} ({1e3 * hop / sr:.1f} ms); per-note flags {wl_flags(args.config)}; one step = "
-                                   "goofer_assemble_batch + goofer_synth_batch (SillySampler.resample + gf.synthesize + V/B/U mix) "
+                                   "goofer_render_batch = goofer_assemble_batch + goofer_synth_batch (SillySampler.resample + gf.synthesize + V/B/U mix) "
                                    "from .goofy features and host-made plans resident in HBM, on-device Philox phases",
                        "notes_per_gpu": args.notes, "frames_per_gpu": wl.frames, "samples_per_gpu": wl.samples,
                        "sharding": "independent notes, no data-path collective"},
