@@ -19,7 +19,6 @@ int launch_pulse_shape_table(goofer_ctx *, float *, const float *, double, hipSt
 struct onset_t;
 int launch_pulse_train(goofer_ctx *, const float *, float, const int64_t *, int, int64_t, float *, double *, onset_t *, int32_t *,
                        int32_t *, int32_t *, hipStream_t);
-int launch_phase_inc(goofer_ctx *, const float *, float, int64_t, double *, hipStream_t);
 int launch_pulse_onsets(goofer_ctx *, const float *, float, const int64_t *, int, onset_t *, int32_t *, int32_t *,
                         int32_t *, hipStream_t);
 int launch_pulse_place(goofer_ctx *, const onset_t *, const int32_t *, const int64_t *, int, int64_t, float *, hipStream_t);
@@ -116,10 +115,8 @@ __global__ void k_row_src(const int64_t *__restrict__ frame_off, const int64_t *
 
 // f0 *= pitch_shift (GOOFER.py:995), fp32.  1024 samples per workgroup, 16-byte accesses when the tile sits in one note.
 __global__ __launch_bounds__(256) void k_scale_f0(const float *__restrict__ f0, const int64_t *__restrict__ sample_off, int n_notes,
-                                                  int64_t total, const goofer_note_params *__restrict__ params, float *__restrict__ out,
-                                                  double *__restrict__ inc, double sr)
+                                                  int64_t total, const goofer_note_params *__restrict__ params, float *__restrict__ out)
 {
-    // inc != nullptr: also the pulse tracker's increments (double)f0 / sr (GOOFER.py:491), saving k_phase_inc its pass
     __shared__ int s_pair[2];
     const int64_t g0 = (int64_t)blockIdx.x * 1024;
     int64_t gl = g0 + 1023;
@@ -134,11 +131,6 @@ __global__ __launch_bounds__(256) void k_scale_f0(const float *__restrict__ f0, 
         float4 v = *reinterpret_cast<const float4 *>(f0 + g);
         v.x *= ps; v.y *= ps; v.z *= ps; v.w *= ps;
         *reinterpret_cast<float4 *>(out + g) = v;
-        if (inc) {
-            double2 *io = reinterpret_cast<double2 *>(inc + g);
-            io[0] = make_double2((double)v.x / sr, (double)v.y / sr);
-            io[1] = make_double2((double)v.z / sr, (double)v.w / sr);
-        }
         return;
     }
     int note = lo;
@@ -146,7 +138,6 @@ __global__ __launch_bounds__(256) void k_scale_f0(const float *__restrict__ f0, 
         while (sample_off[note + 1] <= g + k) ++note;
         const float v = f0[g + k] * params[note].pitch_shift;
         out[g + k] = v;
-        if (inc) inc[g + k] = (double)v / sr;
     }
 }
 
@@ -967,7 +958,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     int *frame_note = a.take<int>(F);
     int64_t *row_src = a.take<int64_t>(F);
     float *f0s = a.take<float>(N);
-    double *inc = a.take<double>(N);
+    double *inc = a.take<double>(N);                          // increments of the sub-harmonic trackers ('sg') only
     char *onsets = a.take<char>((N / 2 + 16 * (size_t)n + 16) * ONSET_BYTES);
     int32_t *onset_idx = a.take<int32_t>(N / 2 + 16 * (size_t)n + 16);
     int32_t *onset_cnt = a.take<int32_t>(n + 16);
@@ -1071,7 +1062,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), ctx->side));
         if (!f0_alias) {
             hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, ctx->side, b->f0, b->sample_off, n, N,
-                               b->params, f0s, (double *)nullptr, (double)p.sr);
+                               b->params, f0s);
             LAUNCH_CHECK(ctx);
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_f0s, ctx->side));
@@ -1082,8 +1073,8 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, st, b->frame_off, b->env_off, frame_note, F, row_src);
     LAUNCH_CHECK(ctx);
     if (!early && !f0_alias) {
-        hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params, f0s,
-                           (double *)nullptr, (double)p.sr);            // the pulse walk divides by sr itself
+        hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params,
+                           f0s);                                     // (the pulse walk divides by sr itself)
         LAUNCH_CHECK(ctx);
     }
     if (jit_f0 || jit_vol) {
