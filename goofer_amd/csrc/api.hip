@@ -748,7 +748,7 @@ int goofer_gauss_rows_f64(goofer_ctx *ctx, const double *in, const int64_t *row_
 {
     if (!ctx) return GOOFER_EINVAL;
     if (!in || !out || !row_off || !taps) return goofer_fail(ctx, GOOFER_EINVAL, "null pointer");
-    if (radius < 0 || radius > 1920) return goofer_fail(ctx, GOOFER_EINVAL, "gaussian radius %d outside [0, 1920]", radius);
+    if (radius < 0 || radius > 4096) return goofer_fail(ctx, GOOFER_EINVAL, "gaussian radius %d outside [0, 4096]", radius);
     if (n_rows <= 0 || total <= 0) return GOOFER_OK;
     hipStream_t st = (hipStream_t)stream;
     int rc = ensure_small(ctx, 65536 + 3 * 16384);

@@ -10,7 +10,8 @@
 // each wave stages its window in LDS so every input sample is fetched once per 64 outputs.
 #include "common.h"
 
-#define GS_MAXR 1920          // radius limit (sigma <= 480): taps + window must fit 64 KB of LDS
+#define GS_MAXR 4096          // radius limit (sigma <= 1024: the 'pd' smoothing of 10 ms at 96 kHz is sigma 960): taps + window
+                              // take 8 (4 r + 257) bytes of LDS, 133 KB at the limit
 
 template <typename Tin>
 __global__ __launch_bounds__(256) void k_gauss_samples(const Tin *__restrict__ in, const int64_t *__restrict__ sample_off, int n_notes,
@@ -141,8 +142,15 @@ int launch_gauss_samples(goofer_ctx *ctx, const Tin *in, const int64_t *sample_o
                          int radius, const unsigned char *note_on, double *out, hipStream_t st)
 {
     if (total <= 0) return GOOFER_OK;
-    if (radius > GS_MAXR) return goofer_fail(ctx, GOOFER_EINVAL, "jitter sigma too large");
+    if (radius > GS_MAXR) return goofer_fail(ctx, GOOFER_EINVAL, "gaussian radius %d above %d (sigma too large for the LDS window)", radius, GS_MAXR);
     size_t lds = sizeof(double) * ((2 * radius + 1) + (256 + 2 * radius));
+    if (lds > 64 * 1024) {
+        static bool attr = false;                             // one flag per instantiation (Tin)
+        if (!attr) {
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_gauss_samples<Tin>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));   // + 8 B static
+            attr = true;
+        }
+    }
     hipLaunchKernelGGL(k_gauss_samples<Tin>, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, st, in, sample_off, n_notes, total,
                        d_taps, radius, note_on, out);
     LAUNCH_CHECK(ctx);

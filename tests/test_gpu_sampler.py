@@ -313,6 +313,51 @@ def test_random_mixed_batch_equals_single_notes(renderer, case):
         assert np.array_equal(one, batch[k]), (case, k, float(np.max(np.abs(one - batch[k]))))
 
 
+GEOMS = [(96000, 2048, 96), (48000, 2048, 512), (22050, 512, 128)]
+
+
+@pytest.fixture(scope="module", params=GEOMS, ids=lambda g: "sr%d_nfft%d_hop%d" % g)
+def geo_renderer(request):
+    from goofer_amd.device import Context
+    from goofer_amd.render import Renderer
+    sr, n_fft, hop = request.param
+    c = Context(0)
+    yield request.param, Renderer(c, hop=hop)
+    c.close()
+
+
+@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + max(3, int(os.environ.get("GOOFER_FUZZ_CASES", "48")) // 16)))
+def test_random_flags_other_geometries_vs_oracle(geo_renderer, case):
+    """The random flag vocabulary at other sample rates / transform sizes / hops (the 2048-point and 512-point kernels, a hop
+    that is not a multiple of 64, eight output slots per hop) against the oracle's full render."""
+    from goofer_amd.render import Source
+    from goofer_amd import sampler as S
+    from oracle import sampler_ref as SR
+    (sr, n_fft, hop), renderer = geo_renderer
+    rng = np.random.default_rng(70000 + case)
+    src = syn.make_source(80000 + case, sr, n_fft, hop, seconds=float(rng.uniform(0.25, 0.4)))
+    flags = _random_flags(rng)
+    pitch = ["A3", "C4", "E4", "G#4", "D5"][int(rng.integers(0, 5))]
+    args = (pitch, str(int(rng.choice([60, 100, 140]))), flags, str(int(rng.integers(0, 40))), str(int(rng.integers(150, 400))),
+            str(int(rng.integers(0, 100))), str(int(rng.choice([-150, 30, 60]))), str(int(rng.integers(50, 121))), "0",
+            "!" + str(int(rng.choice([90, 120, 150]))), ["AA", "AA#5#AF#3#/+", "B7CPCV#2#Cb"][int(rng.integers(0, 3))])
+    feats = (src["env_pack"], src["f0"].copy(), src["mask"].copy(), {k: v.copy() for k, v in src["formants"].items()},
+             src["sr"], src["y_len"])
+    seed = 900 + case
+    np.random.seed(177 + case)
+    try:
+        ref = SR.render(feats, SR.decode_request(*args), seed=seed, n_fft=n_fft, hop=hop)
+    except (ValueError, ZeroDivisionError):
+        pytest.skip("a request the reference rejects (empty region)")
+    source = Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+    np.random.seed(177 + case)
+    (out,) = renderer.render([(source, S.decode_request(*args))], phi_seeds=[seed])
+    assert out.shape == ref.shape, (flags, out.shape, ref.shape)
+    assert np.all(np.isfinite(out)), flags
+    e = rms_err(out, ref) / max(1.0, float(np.max(np.abs(ref))))
+    assert e < TOL, (sr, n_fft, hop, flags, args, e)
+
+
 @pytest.mark.parametrize("name", COMBOS)
 def test_flag_combinations_match_reference(renderer, name):
     """The same 16 random flag subsets the reference rendered (tests/golden/combo_*.npz), on the device."""
