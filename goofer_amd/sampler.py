@@ -265,8 +265,12 @@ def _loop_frames(tail: Taps, want: int, mode: str) -> Taps:
         prev = chain[-1]                                   # always a fresh, pure copy of the tail
         k = min(8, n // 2)
         if k == 0:
-            # numpy: prev[:, -0:] is ALL of prev and the fades are empty -> the reference's multiply fails
-            raise ValueError("operands could not be broadcast together with shapes (%d,) (0,)" % n)
+            # a one-frame tail (n == 1): the reference's fades are empty, prev[:, -0:] is all of prev — ONE column, which
+            # broadcasts against the empty fade to an empty cross-fade — and prev[:, :-0] is empty as well, so the chunk is
+            # the tail itself (SillySampler.py:657-672 under numpy's slicing / broadcasting rules)
+            chain[-1] = tail
+            chain.append(tail)
+            continue
         up, dn = np.linspace(0, 1, k), np.linspace(1, 0, k)
         mixed = Taps(np.stack([prev.idx[len(prev) - k:, 0], tail.idx[:k, 0]], 1), np.stack([dn, up], 1), True)
         chain[-1] = Taps.concat([prev[:len(prev) - k], mixed, tail[k:]])

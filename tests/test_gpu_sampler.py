@@ -358,6 +358,44 @@ def test_random_flags_other_geometries_vs_oracle(geo_renderer, case):
     assert e < TOL, (sr, n_fft, hop, flags, args, e)
 
 
+@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + max(6, int(os.environ.get("GOOFER_FUZZ_CASES", "48")) // 8)))
+def test_random_extreme_requests_vs_oracle(renderer, case):
+    """The request arguments at their edges: notes of 5-120 ms (shorter than a window, a hop, a pitch-bend tick), no
+    consonant, negative and large cutoffs, velocities 0 and 200, extreme tempi, long pitch-bend strings with runs, notes far
+    above and below the source pitch — with random flags on top, against the oracle's full render."""
+    from goofer_amd.render import Source
+    from goofer_amd import sampler as S
+    from oracle import sampler_ref as SR
+    rng = np.random.default_rng(90000 + case)
+    src = syn.make_source(95000 + case, seconds=float(rng.uniform(0.15, 0.7)))
+    flags = _random_flags(rng) if rng.random() < 0.7 else ""
+    pitch = ["C2", "A2", "C4", "B5", "C7"][int(rng.integers(0, 5))]
+    bend = ["AA", "AA#50#", "/+/+/+#9#AAAA#3#gA", "B7CPCV#2#Cb" * 6, "AAABACADAEAFAGAH" * 4][int(rng.integers(0, 5))]
+    args = (pitch, str(int(rng.choice([0, 1, 100, 199, 200]))), flags, str(int(rng.choice([0, 1, 5, 30, 200]))),
+            str(int(rng.choice([5, 12, 40, 120, 2500]))), str(int(rng.choice([0, 1, 40, 300]))),
+            str(int(rng.choice([-400, -50, 0, 1, 50, 350]))), str(int(rng.choice([0, 1, 100, 200]))), "0",
+            "!" + str(int(rng.choice([20, 60, 120, 480]))), bend)
+    feats = (src["env_pack"], src["f0"].copy(), src["mask"].copy(), {k: v.copy() for k, v in src["formants"].items()},
+             src["sr"], src["y_len"])
+    seed = 1900 + case
+    np.random.seed(277 + case)
+    try:
+        ref = SR.render(feats, SR.decode_request(*args), seed=seed)
+    except (ValueError, ZeroDivisionError, IndexError) as e:
+        source = Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+        with pytest.raises((ValueError, ZeroDivisionError, IndexError)):       # the same request fails here as well
+            renderer.render([(source, S.decode_request(*args))], phi_seeds=[seed])
+        return
+    source = Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+    np.random.seed(277 + case)
+    (out,) = renderer.render([(source, S.decode_request(*args))], phi_seeds=[seed])
+    assert out.shape == ref.shape, (flags, args, out.shape, ref.shape)
+    assert np.all(np.isfinite(out)) == np.all(np.isfinite(ref)), (flags, args)
+    if np.all(np.isfinite(ref)):
+        e = rms_err(out, ref) / max(1.0, float(np.max(np.abs(ref))))
+        assert e < TOL, (flags, args, e)
+
+
 @pytest.mark.parametrize("name", COMBOS)
 def test_flag_combinations_match_reference(renderer, name):
     """The same 16 random flag subsets the reference rendered (tests/golden/combo_*.npz), on the device."""

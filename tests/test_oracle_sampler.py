@@ -115,6 +115,25 @@ def test_index_plans_bit_exact():
         assert np.array_equal(F, g[f"{tag}_formants"]), tag
 
 
+def test_concat_loop_of_short_tails_matches_numpy_semantics():
+    """The L0 (concat) loop for every short tail, including the one-frame tail whose fades are empty: under numpy's slicing /
+    broadcasting rules the reference then simply repeats the frame (found by the extreme-request soak).  The planner's
+    index-level plan must realise the oracle's array-level loop for tails of 1..20 frames."""
+    from goofer_amd import sampler as P
+    from oracle import sampler_ref as SR
+    rng = np.random.default_rng(4)
+    for n in range(1, 21):
+        tail = rng.random((5, n))
+        for want in (n, n + 1, 2 * n, 2 * n + 1, 3 * n + n // 2, 7 * n + 3, 61):
+            if want < n:
+                continue
+            ref = SR._loop_env_concat(tail, want) if want > n else tail[:, :want]
+            taps = P._loop_frames(P.Taps.copy(np.arange(n)), want, "concat")
+            got = taps.w[:, 0][None, :] * tail[:, taps.idx[:, 0]] + taps.w[:, 1][None, :] * tail[:, taps.idx[:, 1]]
+            assert got.shape == ref.shape, (n, want)
+            assert np.allclose(got, ref, rtol=0, atol=1e-15), (n, want)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_render_against_reference(name):
     g = golden("sampler_" + name)
