@@ -43,8 +43,10 @@ def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int) ->
         "gauss_env": 8 * B * F, "warp_env": 8 * B * F, "assemble": 12 * B * F + 12 * N,
         # fused frame kernels: unique pulse samples + env row in, windowed frame(s) out
         "harm_frames": (4 * hop + 4 * B + 4 * n_fft) * F, "noise_frames": (4 * B + 8 * n_fft) * F,
-        "phase_inc": 12 * N, "pulse_onsets": 12 * N, "pulse_place": 4 * N,
-        "mask_short": 4 * N / 4 + 8 * N / 4, "stem_gains": 24 * N, "apply_gain": 16 * N,   # three stems in, the mix out (mix_only) "setup_maps": 8 * N + 12 * F,
+        "phase_inc": 12 * N, "pulse_onsets": 4 * N, "pulse_place": 4 * N,     # the walk reads f0 and divides by sr itself
+        "mask_short": 4 * N / 4 + 8 * N / 4, "stem_gains": 24 * N,
+        "apply_gain": 16 * N,                         # three stems in, the mix out (mix_only)
+        "setup_maps": 8 * N + 12 * F,
     }
     return float(table[stage])
 
