@@ -100,13 +100,28 @@ int goofer_fail(goofer_ctx *ctx, int code, const char *fmt, ...)
 
 // ---------------------------------------------------------------------------------------------
 // small helper kernels of the batch driver
+// picks != nullptr: also the frame's picks of the per-sample arrays, x[::hop] edge-padded to the frame count
+// (GOOFER.py:1104-1106), as one (f0, mask) record per frame.  The shaping kernels then find them one dependent load
+// earlier (frame -> record) instead of three (frame -> note -> offsets -> sample).
 __global__ void k_row_src(const int64_t *__restrict__ frame_off, const int64_t *__restrict__ env_off,
-                          const int *__restrict__ frame_note, int64_t total_frames, int64_t *__restrict__ row_src)
+                          const int *__restrict__ frame_note, int64_t total_frames, int64_t *__restrict__ row_src,
+                          const int64_t *__restrict__ sample_off, const float *__restrict__ f0, const float *__restrict__ mask,
+                          int hop, float2 *__restrict__ picks)
 {
     int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= total_frames) return;
     int note = frame_note[f];
     int64_t t = f - frame_off[note];
+    if (picks) {
+        const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+        float2 pv = make_float2(0.f, 0.f);
+        if (n > 0) {
+            int64_t at = t * hop;
+            if (at >= n) at = ((n - 1) / hop) * hop;          // edge-padded: the last pick
+            pv = make_float2(f0[base + at], mask[base + at]);
+        }
+        picks[f] = pv;
+    }
     int64_t rows = env_off[note + 1] - env_off[note];
     if (t > rows - 1) t = rows - 1;     // edge-repeat (np.pad mode='edge'); truncation is implicit
     if (t < 0) t = 0;
@@ -202,6 +217,7 @@ static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t sampl
     auto add = [&](size_t bytes) { b += (bytes + 255) & ~(size_t)255; };
     add(frames * sizeof(int));                    // frame_note
     add(frames * sizeof(int64_t));                // row_src
+    add(frames * sizeof(float2));                 // per-frame (f0, mask) picks
     add(samples * sizeof(float));                 // f0 scaled
     add(samples * sizeof(double));                // phase increments
     add((samples / 2 + 16 * notes + 16) * ONSET_BYTES);
@@ -943,6 +959,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     if (b->n_bins != p.n_bins || b->ld < p.n_bins) return goofer_fail(ctx, GOOFER_EINVAL, "batch geometry does not match the plan");
     if (b->n_notes <= 0 || b->total_samples <= 0) return GOOFER_OK;
     hipStream_t st = (hipStream_t)stream;
+    ctx->frame_picks = nullptr;
     const int64_t F = b->total_frames, N = b->total_samples;
     const int n = b->n_notes, ld = b->ld, ldc = p.n_bins + 1;
 
@@ -957,6 +974,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     arena a{(char *)ctx->scratch, ctx->scratch_bytes, 0};
     int *frame_note = a.take<int>(F);
     int64_t *row_src = a.take<int64_t>(F);
+    float2 *picks = a.take<float2>(F);
     float *f0s = a.take<float>(N);
     double *inc = a.take<double>(N);                          // increments of the sub-harmonic trackers ('sg') only
     char *onsets = a.take<char>((N / 2 + 16 * (size_t)n + 16) * ONSET_BYTES);
@@ -975,7 +993,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     double *short_s = a.take<double>(N / 4 + n + 16);
     float *note_mag = a.take<float>(2 * (size_t)n + 16);
     double *note_steps = a.take<double>(2 * (size_t)n + 16);
-    if (!frames_u || !frames_b || !frame_note || !row_src || !f0s || !inc || !onsets || !onset_idx || !onset_cnt || !ovf || !pulse || !S_h || !S_uv || !S_br || !frames ||
+    if (!picks || !frames_u || !frames_b || !frame_note || !row_src || !f0s || !inc || !onsets || !onset_idx || !onset_cnt || !ovf || !pulse || !S_h || !S_uv || !S_br || !frames ||
         !env_h || !env_n || !short_s || !note_mag || !note_steps)
         return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     float *note_peak = note_mag + n;
@@ -1070,13 +1088,18 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), st));
     }
     if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, st))) return rc;
-    hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, st, b->frame_off, b->env_off, frame_note, F, row_src);
-    LAUNCH_CHECK(ctx);
     if (!early && !f0_alias) {
         hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params,
                            f0s);                                     // (the pulse walk divides by sr itself)
         LAUNCH_CHECK(ctx);
     }
+    // per-frame (f0, mask) picks ride on the map kernel when the scaled f0 is final at this point of the caller's stream:
+    // nothing jitters it in place later, and it is not being produced on the side stream
+    const bool picks_on = !jit_f0 && !sub_jit && !(early && !f0_alias);
+    ctx->frame_picks = picks_on ? picks : nullptr;
+    hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, st, b->frame_off, b->env_off, frame_note, F, row_src, b->sample_off,
+                       (const float *)f0s, b->mask, p.hop, picks_on ? picks : (float2 *)nullptr);
+    LAUNCH_CHECK(ctx);
     if (jit_f0 || jit_vol) {
         hipLaunchKernelGGL(k_note_flags, dim3((n + 255) / 256), dim3(256), 0, st, b->params, n, on_f0, on_vol);
         LAUNCH_CHECK(ctx);
@@ -1219,6 +1242,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     MARK();   // end
 #undef MARK
     if (pev) ctx->prof_steps++;
+    ctx->frame_picks = nullptr;
     return GOOFER_OK;
 }
 

@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
                                                     const float *__restrict__ freqs, const float *__restrict__ boost,
                                                     const float *__restrict__ bright, const double *__restrict__ taps5,
                                                     int n_bins, int hop, const int64_t *__restrict__ row_src,
-                                                    const double *__restrict__ formants, double nyq)
+                                                    const double *__restrict__ formants, double nyq,
+                                                    const float2 *__restrict__ picks)
 {
     // env is either the already-warped [frames x ld] matrix (row_src == nullptr) or the source rows, in which
     // case the formant-anchored + uniform warp (GOOFER.py:1004-1017) runs here on the LDS row.
@@ -184,11 +185,19 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
     }
     const int note = frame_note[f];
     const goofer_note_params p = params[note];
-    const int64_t t = f - frame_off[note];
-    const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
-    const int64_t pk = pick_index(t, n, hop);
-    const float f0f = n > 0 ? f0[base + pk] : 0.f;   // f0 already carries pitch_shift
-    const bool voiced = p.apply_brightness && n > 0 && mask[base + pk] > 0.f;
+    float f0f;                                       // f0 already carries pitch_shift
+    bool voiced;
+    if (picks) {                                     // (f0, mask) record of the frame, written by the map kernel
+        const float2 pv = picks[f];
+        f0f = pv.x;
+        voiced = p.apply_brightness && pv.y > 0.f;
+    } else {
+        const int64_t t = f - frame_off[note];
+        const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+        const int64_t pk = pick_index(t, n, hop);
+        f0f = n > 0 ? f0[base + pk] : 0.f;
+        voiced = p.apply_brightness && n > 0 && mask[base + pk] > 0.f;
+    }
     double t5[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) t5[j] = taps5[j];
@@ -255,7 +264,7 @@ int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames,
 #define HARM_SHAPE(IT)                                                                                                             \
     hipLaunchKernelGGL(k_harm_shape<IT>, grid, dim3(256), lds, st, S, ldc, total_frames, frame_note, frame_off, sample_off, f0,   \
                        mask, env, ld, params, note_mag, pl.freqs, pl.boost, pl.bright_h, pl.blur5, pl.n_bins, pl.hop, row_src,    \
-                       formants, (double)pl.sr / 2.0)
+                       formants, (double)pl.sr / 2.0, ctx->frame_picks)
     switch ((pl.n_bins + WAVE - 1) / WAVE) {
     case 5: HARM_SHAPE(5); break;
     case 9: HARM_SHAPE(9); break;
@@ -278,7 +287,8 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
                                                        const goofer_note_params *__restrict__ params, uint64_t seed,
                                                        const float *__restrict__ freqs, const float *__restrict__ bright,
                                                        const double *__restrict__ taps5, int n_bins, int hop,
-                                                       const int64_t *__restrict__ row_src, const double *__restrict__ taps175)
+                                                       const int64_t *__restrict__ row_src, const double *__restrict__ taps175,
+                                                       const float2 *__restrict__ picks)
 {
     // env_noise is either the already-blurred [frames x ld] matrix (row_src == nullptr) or the source rows, in
     // which case the sigma-1.75 bin blur (GOOFER.py:993) runs here from the LDS row.
@@ -303,10 +313,18 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
     const int note = frame_note[f];
     const goofer_note_params p = params[note];
     const int64_t t = f - frame_off[note];
-    const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
-    const int64_t pk = pick_index(t, n, hop);
-    const float f0f = n > 0 ? f0[base + pk] : 0.f;   // f0 already carries pitch_shift
-    const bool voiced = p.apply_brightness && n > 0 && mask[base + pk] > 0.f;
+    float f0f;                                       // f0 already carries pitch_shift
+    bool voiced;
+    if (picks) {                                     // (f0, mask) record of the frame, written by the map kernel
+        const float2 pv = picks[f];
+        f0f = pv.x;
+        voiced = p.apply_brightness && pv.y > 0.f;
+    } else {
+        const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+        const int64_t pk = pick_index(t, n, hop);
+        f0f = n > 0 ? f0[base + pk] : 0.f;
+        voiced = p.apply_brightness && n > 0 && mask[base + pk] > 0.f;
+    }
     double t5[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) t5[j] = taps5[j];
@@ -393,7 +411,7 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
 #define NOISE_SPECTRA(IT)                                                                                                          \
     hipLaunchKernelGGL(k_noise_spectra<IT>, grid, dim3(256), lds, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,        \
                        sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins, pl.hop, \
-                       row_src, preblurred ? (const double *)nullptr : pl.blur175)
+                       row_src, preblurred ? (const double *)nullptr : pl.blur175, ctx->frame_picks)
     switch ((pl.n_bins + WAVE - 1) / WAVE) {
     case 5: NOISE_SPECTRA(5); break;
     case 9: NOISE_SPECTRA(9); break;

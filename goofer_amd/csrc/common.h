@@ -47,6 +47,7 @@ struct goofer_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // goofer_render_batch: the pulse chain forks as soon as the assembled f0 exists, not when the synthesis call starts
     hipEvent_t ev_entry = nullptr, ev_f0 = nullptr, ev_f0s = nullptr;
+    const float2 *frame_picks = nullptr;   // per-frame (f0, mask) picks of the running goofer_synth_batch, or null
     bool early_req = false;           // set for the duration of one goofer_render_batch
     const float *early_f0 = nullptr;  // f0 array ev_f0 stands for (null: no event recorded)
     hipEvent_t *prof_side = nullptr;    // [prof_cap][4]: boundaries of the pulse chain on the side stream
