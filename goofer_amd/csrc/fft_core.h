@@ -8,54 +8,92 @@
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// Complex product in two packed instructions.  The compiler's own lowering of (ax bx - ay by, ax by + ay bx) builds the
+// swapped operand with two v_mov per product (a fifth of the vector instructions of a 512-point transform); VOP3P's op_sel
+// picks the halves directly:  t = (ax bx, ax by);  r = (-ay by + t.lo, ay bx + t.hi).
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    v2f_t va = {a.x, a.y}, vb = {b.x, b.y}, t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(va), "v"(vb));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(va), "v"(vb), "v"(t));
+    return make_float2(r.x, r.y);
+}
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
 
 // In-register forward DFTs (exp(-2 pi i nk/R)), natural-order output, decimation in frequency.
+// The butterflies work on native two-element vectors (clang ext_vector_type): complex add / subtract are one packed
+// instruction each, and the multiplications by -i and by (+-1 -+ i)/sqrt2 are element swaps + sign flips that the back end
+// folds into the op_sel / neg modifiers of the packed add that consumes them — written on {x, y} structs the SLP
+// vectoriser pairs unrelated scalars instead and spends a v_mov per element putting the pairs together.
+typedef v2f_t cplx;
+__device__ __forceinline__ cplx to_c(float2 a) { return cplx{a.x, a.y}; }
+__device__ __forceinline__ float2 to_f2(cplx a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ cplx c_mi(cplx a) { return cplx{a.y, -a.x}; }                 // a * (-i)
 template <int R> struct dft;
 
 template <> struct dft<2> {
     __device__ __forceinline__ static void run(float2 *v)
     {
-        float2 a = v[0], b = v[1];
-        v[0] = cadd(a, b);
-        v[1] = csub(a, b);
+        const cplx a = to_c(v[0]), b = to_c(v[1]);
+        v[0] = to_f2(a + b);
+        v[1] = to_f2(a - b);
     }
 };
+
+__device__ __forceinline__ void dft4_c(cplx *v)
+{
+    const cplx a0 = v[0] + v[2], a1 = v[0] - v[2];
+    const cplx a2 = v[1] + v[3], a3 = c_mi(v[1] - v[3]);
+    v[0] = a0 + a2;
+    v[2] = a0 - a2;
+    v[1] = a1 + a3;
+    v[3] = a1 - a3;
+}
 
 template <> struct dft<4> {
     __device__ __forceinline__ static void run(float2 *v)
     {
-        float2 a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]);
-        float2 a2 = cadd(v[1], v[3]), a3 = mul_mi(csub(v[1], v[3]));
-        v[0] = cadd(a0, a2);
-        v[2] = csub(a0, a2);
-        v[1] = cadd(a1, a3);
-        v[3] = csub(a1, a3);
+        cplx c[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) c[n] = to_c(v[n]);
+        dft4_c(c);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) v[n] = to_f2(c[n]);
     }
 };
+
+__device__ __forceinline__ void dft8_c(cplx *v)
+{
+    const float h = 0.70710678118654752440f;
+    cplx e[4], o[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        e[n] = v[n] + v[n + 4];
+        o[n] = v[n] - v[n + 4];
+    }
+    o[1] = (o[1] + c_mi(o[1])) * h;                           // * W8^1 = (1-i)/sqrt2 : (h (x + y), h (y - x))
+    o[2] = c_mi(o[2]);                                        // * W8^2 = -i
+    o[3] = (c_mi(o[3]) - o[3]) * h;                           // * W8^3 = (-1-i)/sqrt2 : (h (y - x), -h (x + y))
+    dft4_c(e);
+    dft4_c(o);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        v[2 * m] = e[m];
+        v[2 * m + 1] = o[m];
+    }
+}
 
 template <> struct dft<8> {
     __device__ __forceinline__ static void run(float2 *v)
     {
-        const float h = 0.70710678118654752440f;
-        float2 e[4], o[4];
+        cplx c[8];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            e[n] = cadd(v[n], v[n + 4]);
-            o[n] = csub(v[n], v[n + 4]);
-        }
-        o[1] = make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));   // * W8^1 = (1-i)/sqrt2
-        o[2] = mul_mi(o[2]);                                               // * W8^2 = -i
-        o[3] = make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));  // * W8^3 = (-1-i)/sqrt2
-        dft<4>::run(e);
-        dft<4>::run(o);
+        for (int n = 0; n < 8; ++n) c[n] = to_c(v[n]);
+        dft8_c(c);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            v[2 * m] = e[m];
-            v[2 * m + 1] = o[m];
-        }
+        for (int n = 0; n < 8; ++n) v[n] = to_f2(c[n]);
     }
 };
 
@@ -65,18 +103,18 @@ template <> struct dft<16> {
         // W16^n, n = 0..7
         const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
         const float2 w[8] = {{1.f, 0.f}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.f, -1.f}, {-s1, -c1}, {-h, -h}, {-c1, -s1}};
-        float2 e[8], o[8];
+        cplx e[8], o[8];
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
-            e[n] = cadd(v[n], v[n + 8]);
-            o[n] = cmul(csub(v[n], v[n + 8]), w[n]);
+            e[n] = to_c(v[n]) + to_c(v[n + 8]);
+            o[n] = to_c(cmul(to_f2(to_c(v[n]) - to_c(v[n + 8])), w[n]));
         }
-        dft<8>::run(e);
-        dft<8>::run(o);
+        dft8_c(e);
+        dft8_c(o);
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            v[2 * m] = e[m];
-            v[2 * m + 1] = o[m];
+            v[2 * m] = to_f2(e[m]);
+            v[2 * m + 1] = to_f2(o[m]);
         }
     }
 };
