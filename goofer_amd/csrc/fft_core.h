@@ -42,14 +42,30 @@ template <> struct dft<2> {
     }
 };
 
+// a + (-i) b and a - (-i) b as ONE packed add each: the swap of b's halves is op_sel, the sign a neg modifier
+__device__ __forceinline__ cplx cadd_mi(cplx a, cplx b)
+{
+    cplx r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));   // (ax + by, ay - bx)
+    return r;
+}
+__device__ __forceinline__ cplx csub_mi(cplx a, cplx b)
+{
+    cplx r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));   // (ax - by, ay + bx)
+    return r;
+}
+
+// ROT2: element 2 still has to be multiplied by -i (the W8^2 twiddle of the odd half of a radix-8 butterfly)
+template <bool ROT2>
 __device__ __forceinline__ void dft4_c(cplx *v)
 {
-    const cplx a0 = v[0] + v[2], a1 = v[0] - v[2];
-    const cplx a2 = v[1] + v[3], a3 = c_mi(v[1] - v[3]);
+    const cplx a0 = ROT2 ? cadd_mi(v[0], v[2]) : v[0] + v[2], a1 = ROT2 ? csub_mi(v[0], v[2]) : v[0] - v[2];
+    const cplx a2 = v[1] + v[3], d = v[1] - v[3];
     v[0] = a0 + a2;
     v[2] = a0 - a2;
-    v[1] = a1 + a3;
-    v[3] = a1 - a3;
+    v[1] = cadd_mi(a1, d);
+    v[3] = csub_mi(a1, d);
 }
 
 template <> struct dft<4> {
@@ -58,7 +74,7 @@ template <> struct dft<4> {
         cplx c[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) c[n] = to_c(v[n]);
-        dft4_c(c);
+        dft4_c<false>(c);
 #pragma unroll
         for (int n = 0; n < 4; ++n) v[n] = to_f2(c[n]);
     }
@@ -73,11 +89,10 @@ __device__ __forceinline__ void dft8_c(cplx *v)
         e[n] = v[n] + v[n + 4];
         o[n] = v[n] - v[n + 4];
     }
-    o[1] = (o[1] + c_mi(o[1])) * h;                           // * W8^1 = (1-i)/sqrt2 : (h (x + y), h (y - x))
-    o[2] = c_mi(o[2]);                                        // * W8^2 = -i
-    o[3] = (c_mi(o[3]) - o[3]) * h;                           // * W8^3 = (-1-i)/sqrt2 : (h (y - x), -h (x + y))
-    dft4_c(e);
-    dft4_c(o);
+    o[1] = cadd_mi(o[1], o[1]) * h;                           // * W8^1 = (1-i)/sqrt2 : (h (x + y), h (y - x))
+    o[3] = csub_mi(o[3], o[3]) * -h;                          // * W8^3 = (-1-i)/sqrt2 : (h (y - x), -h (x + y))
+    dft4_c<false>(e);
+    dft4_c<true>(o);                                          // * W8^2 = -i on o[2], folded into its first butterfly
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         v[2 * m] = e[m];
