@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_irfft_frames(const float2 *__restrict__
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float2 *buf = bufs + wave * fft_cfg<M>::BUF;
     const int64_t f_begin = (int64_t)blockIdx.x * FRAMES_PER_BLOCK;
-    const float inv_m = 1.0f / (float)M;
+    const float inv_m = 0.5f / (float)M;                    // 1/M of the transform and the 1/2 of the input stage (irfft_pre)
 
     for (int i = wave; i < FRAMES_PER_BLOCK; i += WAVES_PER_BLOCK) {
         const int64_t f = f_begin + i;
@@ -122,11 +122,8 @@ __global__ __launch_bounds__(256) void k_irfft_frames(const float2 *__restrict__
             float2 xm = row[M - k];
             if (k == 0) { xk.y = 0.f; xm.y = 0.f; }   // irfft ignores Im of DC and Nyquist
             float2 wc = (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y);
-            float2 A = make_float2(xk.x + xm.x, xk.y - xm.y);
-            float2 D = make_float2(xk.x - xm.x, xk.y + xm.y);
-            float2 C = cmul(wc, D);
             // Z = (A + i C)/2 ; inverse FFT = conj(FFT(conj Z))
-            v[r] = make_float2(0.5f * (A.x - C.y), -0.5f * (A.y + C.x));
+            v[r] = irfft_pre(xk, xm, wc);
         }
         wave_fft<M>(v, buf, tw, lane);
         float2 *out = reinterpret_cast<float2 *>(frames + f * (int64_t)(2 * M));

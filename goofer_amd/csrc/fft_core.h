@@ -56,6 +56,21 @@ __device__ __forceinline__ cplx csub_mi(cplx a, cplx b)
     return r;
 }
 
+// irFFT input stage for bin k (conj trick: a real 2M-point inverse as a complex M-point forward transform):
+//   A = X[k] + conj X[M-k],  D = X[k] - conj X[M-k],  C = wc D  (wc = conj of the half-bin twiddle),  point = conj(A + i C).
+// The factor 1/2 of Z = (A + i C)/2 is NOT applied: the transform is linear, callers fold 0.5 into their output scale
+// (exact, a power of two).  Five packed instructions.
+__device__ __forceinline__ float2 irfft_pre(float2 xk, float2 xm, float2 wc)
+{
+    const cplx k = to_c(xk), m = to_c(xm);
+    cplx A, D, r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(A) : "v"(k), "v"(m));                 // (kx + mx, ky - my)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(D) : "v"(k), "v"(m));                 // (kx - mx, ky + my)
+    const cplx C = to_c(cmul(wc, to_f2(D)));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(A), "v"(C));   // (Ax - Cy, -Ay - Cx)
+    return to_f2(r);
+}
+
 // ROT2: element 2 still has to be multiplied by -i (the W8^2 twiddle of the odd half of a radix-8 butterfly)
 template <bool ROT2>
 __device__ __forceinline__ void dft4_c(cplx *v)
@@ -251,10 +266,7 @@ __device__ __forceinline__ void irfft_load(float2 *v, const Spec &X, const float
         float2 xm = X(M - k);
         if (k == 0) { xk.y = 0.f; xm.y = 0.f; }
         float2 wc = (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y);
-        float2 A = make_float2(xk.x + xm.x, xk.y - xm.y);
-        float2 D = make_float2(xk.x - xm.x, xk.y + xm.y);
-        float2 C = cmul(wc, D);
-        v[r] = make_float2(0.5f * (A.x - C.y), -0.5f * (A.y + C.x));     // conj((A + iC)/2)
+        v[r] = irfft_pre(xk, xm, wc);                                     // conj(A + iC); the 1/2 rides on irfft_store's scale
     }
 }
 
@@ -263,7 +275,7 @@ template <int M>
 __device__ __forceinline__ void irfft_store(const float2 *buf, const float *win, float *frame, int lane)
 {
     constexpr int R = fft_cfg<M>::R;
-    const float inv_m = 1.0f / (float)M;
+    const float inv_m = 0.5f / (float)M;                    // 1/M of the transform and the 1/2 of the input stage
     float2 *out = reinterpret_cast<float2 *>(frame);
 #pragma unroll
     for (int r = 0; r < R; ++r) {

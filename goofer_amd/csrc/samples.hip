@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, M <= 512 ? 2 : 1) void k_irfft_ola3(const floa
     const int64_t f0 = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + wave) * run;
     if (f0 >= total_frames) return;                          // no block barrier below
     const int64_t f1 = f0 + run < total_frames ? f0 + run : total_frames;
-    const float inv_m = 1.0f / (float)M;
+    const float inv_m = 0.5f / (float)M;                     // 1/M of the transform and the 1/2 of the input stage (irfft_pre)
 
     int64_t fs = f0;
     {
@@ -579,10 +579,7 @@ __global__ __launch_bounds__(256, M <= 512 ? 2 : 1) void k_irfft_ola3(const floa
                 const int k = lane + WAVE * r;
                 float2 xk = nk[r], xm = nm[r];
                 if (k == 0) { xk.y = 0.f; xm.y = 0.f; }       // irfft ignores Im of DC and Nyquist
-                const float2 A = make_float2(xk.x + xm.x, xk.y - xm.y);
-                const float2 D = make_float2(xk.x - xm.x, xk.y + xm.y);
-                const float2 Cc = cmul(HOIST ? wc_r[HOIST ? r : 0] : wc_of(k), D);
-                v[r] = make_float2(0.5f * (A.x - Cc.y), -0.5f * (A.y + Cc.x));
+                v[r] = irfft_pre(xk, xm, HOIST ? wc_r[HOIST ? r : 0] : wc_of(k));
             }
             // next job's rows: same frame next stem, or the next frame's first stem
             if (stem < 2) fetch(f, stem + 1);
