@@ -234,6 +234,54 @@ __device__ __forceinline__ void wave_fft_keep(float2 *v, float2 *buf, const floa
     wave_lds_sync();
 }
 
+// The same with both passes' twiddles held in registers (M = 512: one butterfly per lane and pass, 2 x 7 twiddles that
+// depend on the lane only): a caller that transforms many frames loads them once and saves 14 LDS reads per transform.
+template <int M>
+__device__ __forceinline__ void fft_lane_twiddles(const float2 *tw, int lane, float2 *tw1, float2 *tw2)
+{
+    static_assert(M == 512, "one butterfly per lane and pass");
+    constexpr int R = fft_cfg<M>::R;
+    const int k1 = lane % R;                                  // pass 1: NS = R, twiddle exp(-2 pi i t k / (8 R))
+#pragma unroll
+    for (int t = 1; t < 8; ++t) {
+        tw1[t - 1] = tw[(t * k1 * (M / (8 * R))) & (M - 1)];
+        tw2[t - 1] = tw[(t * lane) & (M - 1)];                // last pass: NS = M/8, exp(-2 pi i t b / M)
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void wave_fft_keep_tw(float2 *v, float2 *buf, const float2 *tw1, const float2 *tw2, int lane, float2 *out)
+{
+    static_assert(M == 512, "one butterfly per lane and pass");
+    constexpr int R = fft_cfg<M>::R, NB = M / 8;
+    dft<R>::run(v);
+#pragma unroll
+    for (int t = 0; t < R; ++t) buf[lds_pad(lane * R + t)] = v[t];
+    wave_lds_sync();
+    {   // pass 1 (NS = R): reads x[b + t NB], writes y[(b / NS) NS 8 + b % NS + t NS]
+        float2 x[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = buf[lds_pad(lane + t * NB)];
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 1; t < 8; ++t) x[t] = cmul(x[t], tw1[t - 1]);
+        dft<8>::run(x);
+        const int j0 = (lane / R) * R * 8 + lane % R;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) buf[lds_pad(j0 + t * R)] = x[t];
+        wave_lds_sync();
+    }
+    float2 x[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = buf[lds_pad(lane + t * NB)];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) x[t] = cmul(x[t], tw2[t - 1]);
+    dft<8>::run(x);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) out[t] = x[t];
+    wave_lds_sync();
+}
+
 template <int M>
 __device__ __forceinline__ void load_tables(float2 *tw, float2 *twh, float *win, const float2 *g_tw,
                                             const float2 *g_twh, const float *g_win)

@@ -423,6 +423,8 @@ __global__ __launch_bounds__(256, M <= 512 ? 2 : 1) void k_irfft_ola3(const floa
     auto wc_of = [&](int k) { return (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y); };
     // (z / M) * w == z * (w / M) exactly (M is a power of two), and the conjugate's sign rides along
     auto win_of = [&](int k) { return make_float2(win[2 * k] * inv_m, -(win[2 * k + 1] * inv_m)); };
+    float2 tw1_r[7], tw2_r[7];                                // radix-8 pass twiddles of this lane (M == 512 only)
+    if constexpr (M == 512) fft_lane_twiddles<M>(tw, lane, tw1_r, tw2_r);
     float2 wc_r[HOIST ? R : 1], win_r[HOIST ? R : 1];
     if constexpr (HOIST) {
 #pragma unroll
@@ -589,7 +591,9 @@ __global__ __launch_bounds__(256, M <= 512 ? 2 : 1) void k_irfft_ola3(const floa
             // all ring reads, then all ring writes: the R slots of a lane are distinct, and a branch-free body lets the
             // LDS reads overlap instead of paying one round trip per slot
             float2 z[R], o[R];
-            if constexpr (M >= 512) {
+            if constexpr (M == 512) {
+                wave_fft_keep_tw<M>(v, buf, tw1_r, tw2_r, lane, z);   // twiddles and the lane's output points in registers
+            } else if constexpr (M >= 512) {
                 wave_fft_keep<M>(v, buf, tw, lane, z);        // the lane's output points stay in registers
             } else {
                 wave_fft<M>(v, buf, tw, lane);
