@@ -58,7 +58,7 @@ STAGE_KERNEL = {"rfft_frames": "void k_rfft_frames<512>", "rfft_frames_standalon
                 "mask_short": "k_mask_short", "phase_inc": "k_phase_inc", "setup_maps": "k_scale_f0"}
 
 
-PMC_FILE = "r01k_pmc_traffic.json"      # committed rocprofv3 counter passes of this same command (scripts/collect_profiles.sh)
+PMC_FILE = "r01l_pmc_traffic.json"      # committed rocprofv3 counter passes of this same command (scripts/collect_profiles.sh)
 
 
 def pmc_traffic(stage, frames):
