@@ -128,6 +128,8 @@ EXPORTS = {
     "goofer_gauss_rows_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "goofer_stretch_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "goofer_onepole_cascade": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "goofer_vocal_roughness": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "goofer_post_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "goofer_assemble_batch": (C.c_int, [C.c_void_p, C.POINTER(Assembly), C.c_void_p]),
     "goofer_render_batch": (C.c_int, [C.c_void_p, C.POINTER(Assembly), C.POINTER(Batch), C.c_void_p]),

@@ -20,7 +20,7 @@ from .device import Context, default_context, default_params, row_stride
 DSTORAGE = np.float16
 DCOMPUTE = np.float32
 
-_UNSUPPORTED = ("roughness_on",)
+_UNSUPPORTED = ()
 
 
 def _ctx(sr, n_fft, hop, ctx=None) -> Context:
@@ -416,6 +416,48 @@ def _stretch(c, x, a, b, factor):
     return out
 
 
+def _roughness_params(params, kw):
+    """roughness_on needs the stems BEFORE the peak gain (the gain is taken from the roughened sum, GOOFER.py:1195-1217): the
+    batch runs with normalize = 0 (gain 1) and `_finish` applies the reference's gain."""
+    if kw.get("roughness_on"):
+        params = params.copy()
+        params["normalize"] = 0.0
+    return params
+
+
+def _finish(c, out, d_mask, n, sr, kw):
+    """The tail of gf.synthesize.  Without roughness the batch call has produced everything.  With it: the roughness layer on
+    the device (only `reconstruct` hears it), then peak and gain like the reference."""
+    if not kw.get("roughness_on"):
+        return tuple(out[k].cpu().numpy() for k in ("rec", "harm", "uv", "bre"))
+    k_list = list(kw.get("rough_k_list", (2, 3, 4)))
+    h_list = kw.get("rough_h_list")
+    if h_list is None:
+        h_list = [0.45, 0.28, 0.18][:len(k_list)]
+        if len(h_list) < len(k_list):
+            extra = len(k_list) - len(h_list)
+            h_list += [h_list[-1] * 0.6 ** i for i in range(1, extra + 1)]
+    k_list, h_list = k_list[:len(h_list)], list(h_list)[:len(k_list)]          # zip() of the reference
+    alpha = float(kw.get("rough_alpha", 0.6))
+    d_f0 = c.tensor(c.debug_fetch("f0")[:n])                  # f0_interp as the synthesis left it (scaled, stretched, jittered)
+    noises = []
+    for idx in range(len(k_list)):                            # make_smooth_noise re-seeds the LEGACY global generator
+        np.random.seed(1337 + idx)
+        noises.append(np.random.randn(n).astype(np.float32).astype(np.float64))
+    sig_n = max(1.0, (float(kw.get("rough_noise_smooth_ms", 120.0)) * 0.001 * sr) / 6.0)
+    sig_a = max(1.0, (float(kw.get("rough_alpha_slew_ms", 120.0)) * 0.001 * sr) / 6.0)
+    nz = c.gauss_rows_f64(c.tensor(np.stack(noises)), gaussian_taps(sig_n)) if noises else None
+    a_track = (d_mask.float() * np.float32(alpha)).double().reshape(1, n)      # alpha * vmask in fp32, filtered in fp64
+    a_slew = c.gauss_rows_f64(a_track, gaussian_taps(sig_a)).reshape(n).float()
+    rough = c.vocal_roughness(out["harm"], d_f0, d_mask, nz, k_list, h_list, float(kw.get("rough_noise_amp", 0.6)),
+                              float(kw.get("rough_hp_fc", 320.0)), a_slew)
+    harm, uv, bre = (out[k].cpu().numpy() for k in ("harm", "uv", "bre"))
+    combined = rough.cpu().numpy() + uv + bre
+    peak = float(np.max(np.abs(combined)) + 1e-12)
+    gain = (1.0 / peak) ** float(np.clip(kw.get("normalize", 1.0), 0.0, 1.0))
+    return combined * np.float32(gain), harm * np.float32(gain), uv * np.float32(gain), bre * np.float32(gain)
+
+
 def _synthesize_stretched(c, d_env, f0, mask, F, params, sr, hop, phi, seed, kw):
     """gf.synthesize with stretch_factor != 1 (GOOFER.py:1019-1067): the warped envelope and the blurred noise envelope
     are made first, then both, f0 (already scaled by pitch_shift) and the mask are resampled along time, and the
@@ -441,7 +483,7 @@ def _synthesize_stretched(c, d_env, f0, mask, F, params, sr, hop, phi, seed, kw)
     if n == 0:
         z = np.zeros(0, dtype=np.float32)
         return z, z.copy(), z.copy(), z.copy()
-    params = params.copy()
+    params = _roughness_params(params, kw).copy()
     params["pitch_shift"], params["formant_shift"], params["f_shift"] = 1.0, 1.0, [1.0, 1.0, 1.0, 1.0]
     d_phi = None
     if phi is not None:
@@ -457,7 +499,7 @@ def _synthesize_stretched(c, d_env, f0, mask, F, params, sr, hop, phi, seed, kw)
                         noise_f0=noise_f0, noise_vol=noise_vol, f0_jitter_speed=float(kw.get("f0_jitter_speed", 100)),
                         vol_jitter_speed=float(kw.get("volume_jitter_speed", 150)), subharm=subharm_from_kwargs(kw),
                         volume_vibrato=vib, env_noise=env_n, noise_subharm=noise_sub)
-    return tuple(out[k].cpu().numpy() for k in ("rec", "harm", "uv", "bre"))
+    return _finish(c, out, d_mask, n, sr, kw)
 
 
 def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=256, phi=None, seed=None, ctx=None, **kw):
@@ -483,7 +525,7 @@ def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=
     T_env = env.shape[1]
     fm = formants_to_int_keys(kw.get("formants"))
     F = np.stack([_fit(fm[i], T_env) for i in (1, 2, 3, 4)], axis=1)           # [T_env, 4] fp64
-    params = note_params_from_kwargs(1, **kw)
+    params = _roughness_params(note_params_from_kwargs(1, **kw), kw)
     d_env = c.rows_from(env.T)
     if kw.get("stretch_factor", 1.0) != 1.0:
         return _synthesize_stretched(c, d_env, f0, mask, F, params, sr, hop_length, phi, seed, kw)
@@ -497,9 +539,10 @@ def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=
     noise_sub = c.tensor(np.random.randn(n)) if kw.get("add_subharm") and kw.get("subharm_f0_jitter", 0) > 0.0 else None
     vib = bool(kw.get("volume_jitter") and kw.get("volume_vibrato"))          # the sinusoid variant draws nothing
     noise_vol = (c.tensor(np.random.randn(n)), c.tensor(np.random.randn(n))) if kw.get("volume_jitter") and not vib else None
-    out = c.synth_batch(d_env, [T_env], c.tensor(f0[:n]), c.tensor(mask[:n]), [n], params, formants=c.tensor(F),
+    d_mask = c.tensor(mask[:n])
+    out = c.synth_batch(d_env, [T_env], c.tensor(f0[:n]), d_mask, [n], params, formants=c.tensor(F),
                         phi=d_phi, seed=seed, transition_sigma=float(kw.get("noise_transition_smoothness", 100)),
                         want_mix=False, noise_f0=noise_f0, noise_vol=noise_vol,
                         f0_jitter_speed=float(kw.get("f0_jitter_speed", 100)), vol_jitter_speed=float(kw.get("volume_jitter_speed", 150)),
                         subharm=subharm_from_kwargs(kw), volume_vibrato=vib, noise_subharm=noise_sub)
-    return tuple(out[k].cpu().numpy() for k in ("rec", "harm", "uv", "bre"))
+    return _finish(c, out, d_mask, n, sr, kw)

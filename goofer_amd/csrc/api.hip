@@ -74,6 +74,8 @@ int launch_dyn_gain(goofer_ctx *, const double *, const double *, const unsigned
 int launch_irfft_ola3(goofer_ctx *, const float2 *, const float2 *, const float2 *, int, int64_t, const int *, const int64_t *,
                       const int64_t *, int, const float *, const double *, double *, const goofer_note_params *, float *, float *, float *,
                       float *, hipStream_t);
+int launch_vocal_roughness(goofer_ctx *, const float *, const float *, const float *, const double *, int, const double *, const double *,
+                           double, double, const float *, const int64_t *, int, int64_t, float *, hipStream_t);
 int launch_lerp_axis0(goofer_ctx *, const float *, int64_t, int64_t, float *, int64_t, int64_t, int, hipStream_t);
 int launch_lerp_1d(goofer_ctx *, const float *, int64_t, float *, int64_t, hipStream_t);
 int launch_stem_peak(goofer_ctx *, const float *, const float *, const float *, const int64_t *, int, int64_t, float *, hipStream_t);
@@ -764,14 +766,28 @@ int goofer_gauss_rows_f64(goofer_ctx *ctx, const double *in, const int64_t *row_
 {
     if (!ctx) return GOOFER_EINVAL;
     if (!in || !out || !row_off || !taps) return goofer_fail(ctx, GOOFER_EINVAL, "null pointer");
-    if (radius < 0 || radius > 4096) return goofer_fail(ctx, GOOFER_EINVAL, "gaussian radius %d outside [0, 4096]", radius);
+    if (radius < 0 || radius > (1 << 22)) return goofer_fail(ctx, GOOFER_EINVAL, "gaussian radius %d outside [0, 2^22]", radius);
     if (n_rows <= 0 || total <= 0) return GOOFER_OK;
     hipStream_t st = (hipStream_t)stream;
-    int rc = ensure_small(ctx, 65536 + 3 * 16384);
+    // taps behind the fixed small areas (tables at 0, the three jitter tap slots at 64 KiB)
+    const size_t tap_off = 65536 + 3 * 16384, tap_bytes = (size_t)(2 * radius + 1) * sizeof(double);
+    int rc = ensure_small(ctx, tap_off + tap_bytes);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->small, taps, (2 * radius + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+    double *d_taps = (double *)((char *)ctx->small + tap_off);
+    HIP_TRY(ctx, hipMemcpyAsync(d_taps, taps, tap_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));                   // the caller's taps buffer may be transient
-    return launch_gauss_samples<double>(ctx, in, row_off, n_rows, total, (const double *)ctx->small, radius, nullptr, out, st);
+    return launch_gauss_samples<double>(ctx, in, row_off, n_rows, total, d_taps, radius, nullptr, out, st);
+}
+
+int goofer_vocal_roughness(goofer_ctx *ctx, const float *y, const float *f0, const float *mask, const double *noise_s, int n_k,
+                           const double *k_list, const double *h_list, double noise_amp, double hp_fc, const float *alpha_slewed,
+                           const int64_t *sample_off, int n_notes, int64_t total_samples, float *out, void *stream)
+{
+    NEED_PLAN(ctx);
+    if (!y || !f0 || !mask || !alpha_slewed || !sample_off || !out || (n_k > 0 && (!noise_s || !k_list || !h_list)))
+        return goofer_fail(ctx, GOOFER_EINVAL, "null pointer");
+    return launch_vocal_roughness(ctx, y, f0, mask, noise_s, n_k, k_list, h_list, noise_amp, hp_fc, alpha_slewed, sample_off, n_notes,
+                                  total_samples, out, (hipStream_t)stream);
 }
 
 int goofer_onepole_cascade(goofer_ctx *ctx, const float *src, float *dst, const float *f0, const goofer_onepole_job *jobs, int n_jobs,

@@ -10,8 +10,12 @@
 // each wave stages its window in LDS so every input sample is fetched once per 64 outputs.
 #include "common.h"
 
-#define GS_MAXR 4096          // radius limit (sigma <= 1024: the 'pd' smoothing of 10 ms at 96 kHz is sigma 960): taps + window
-                              // take 8 (4 r + 257) bytes of LDS, 133 KB at the limit
+
+// The taps are consumed GS_CHUNK at a time: a chunk of taps and the 256 + GS_CHUNK window values it meets are staged in LDS,
+// every thread adds its products in tap order, and the running sum stays in its register across chunks — the same additions
+// in the same order as one long FIR, for any radius (the 'pd' smoothing at 96 kHz is sigma 960, gf.synthesize's roughness
+// slew sigma 1920: radii of 3 840 and 7 680 taps).
+#define GS_CHUNK 2048
 
 template <typename Tin>
 __global__ __launch_bounds__(256) void k_gauss_samples(const Tin *__restrict__ in, const int64_t *__restrict__ sample_off, int n_notes,
@@ -19,10 +23,11 @@ __global__ __launch_bounds__(256) void k_gauss_samples(const Tin *__restrict__ i
                                                        const unsigned char *__restrict__ note_on, double *__restrict__ out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    double *s_taps = reinterpret_cast<double *>(smem);
-    double *s_win = s_taps + (2 * radius + 1);               // [256 + 2 radius]
+    double *s_taps = reinterpret_cast<double *>(smem);      // [chunk]
+    const int nt = 2 * radius + 1;
+    const int chunk = nt < GS_CHUNK ? nt : GS_CHUNK;
+    double *s_win = s_taps + chunk;                           // [256 + chunk]
     __shared__ int s_pair[2];
-    for (int i = threadIdx.x; i < 2 * radius + 1; i += blockDim.x) s_taps[i] = taps[i];
     const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
     int lo, hi;
     block_note_range(sample_off, n_notes, g0, total, s_pair, lo, hi);   // includes a __syncthreads
@@ -31,15 +36,21 @@ __global__ __launch_bounds__(256) void k_gauss_samples(const Tin *__restrict__ i
         if (note_on && !note_on[lo]) return;                  // whole block: nothing to do for this note
         const int64_t base = sample_off[lo], n = sample_off[lo + 1] - base;
         const int64_t i0 = g0 - base;
-        const int win = blockDim.x + 2 * radius;
-        for (int w = threadIdx.x; w < win; w += blockDim.x) s_win[w] = (double)in[base + reflect_index(i0 - radius + w, n)];
-        __syncthreads();
-        if (g < total) {
-            double acc = 0.0;
-            const double *x = s_win + threadIdx.x;
-            for (int j = 0; j <= 2 * radius; ++j) acc += s_taps[j] * x[j];
-            out[g] = acc;
+        double acc = 0.0;
+        for (int j0 = 0; j0 < nt; j0 += chunk) {
+            const int cn = nt - j0 < chunk ? nt - j0 : chunk;
+            for (int i = threadIdx.x; i < cn; i += blockDim.x) s_taps[i] = taps[j0 + i];
+            const int win = (int)blockDim.x + cn - 1;           // window values the chunk's taps meet for this tile
+            for (int w = threadIdx.x; w < win; w += blockDim.x)
+                s_win[w] = (double)in[base + reflect_index(i0 - radius + j0 + w, n)];
+            __syncthreads();
+            if (g < total) {
+                const double *x = s_win + threadIdx.x;
+                for (int j = 0; j < cn; ++j) acc += s_taps[j] * x[j];
+            }
+            __syncthreads();
         }
+        if (g < total) out[g] = acc;
         return;
     }
     if (g >= total) return;
@@ -48,7 +59,7 @@ __global__ __launch_bounds__(256) void k_gauss_samples(const Tin *__restrict__ i
     if (note_on && !note_on[note]) return;
     const int64_t base = sample_off[note], n = sample_off[note + 1] - base, i = g - base;
     double acc = 0.0;
-    for (int j = 0; j <= 2 * radius; ++j) acc += s_taps[j] * (double)in[base + reflect_index(i + j - radius, n)];
+    for (int j = 0; j < nt; ++j) acc += taps[j] * (double)in[base + reflect_index(i + j - radius, n)];
     out[g] = acc;
 }
 
@@ -142,15 +153,9 @@ int launch_gauss_samples(goofer_ctx *ctx, const Tin *in, const int64_t *sample_o
                          int radius, const unsigned char *note_on, double *out, hipStream_t st)
 {
     if (total <= 0) return GOOFER_OK;
-    if (radius > GS_MAXR) return goofer_fail(ctx, GOOFER_EINVAL, "gaussian radius %d above %d (sigma too large for the LDS window)", radius, GS_MAXR);
-    size_t lds = sizeof(double) * ((2 * radius + 1) + (256 + 2 * radius));
-    if (lds > 64 * 1024) {
-        static bool attr = false;                             // one flag per instantiation (Tin)
-        if (!attr) {
-            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_gauss_samples<Tin>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));   // + 8 B static
-            attr = true;
-        }
-    }
+    if (radius < 0) return goofer_fail(ctx, GOOFER_EINVAL, "negative gaussian radius");
+    const int nt = 2 * radius + 1, chunk = nt < GS_CHUNK ? nt : GS_CHUNK;
+    size_t lds = sizeof(double) * ((size_t)chunk + 256 + chunk);              // at most 36 KB
     hipLaunchKernelGGL(k_gauss_samples<Tin>, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, st, in, sample_off, n_notes, total,
                        d_taps, radius, note_on, out);
     LAUNCH_CHECK(ctx);

@@ -463,3 +463,78 @@ int launch_dyn_gain(goofer_ctx *ctx, const double *bend_s, const double *vmask_s
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// apply_vocal_roughness (GOOFER.py:901-940), the `roughness_on` layer of gf.synthesize: amplitude modulation of the
+// harmonic stem at f0/k (k = 2, 3, 4 ...) with noisy modulation rates, the difference high-passed and faded in by the
+// slewed voicing mask.  Two strictly sequential recurrences per note — the fp64 running sum of each modulator's
+// frequency (np.cumsum) and the one-pole high-pass with its python-float state — so one lane walks one note; notes run
+// side by side.  A rarely used switch (no caller of the resampler sets it): written for exactness, not speed.
+//   nz     [n_k][total] fp64 smoothed noises (make_smooth_noise: legacy RNG re-seeded 1337 + idx, fp32 draw, fp64 Gaussian)
+//   aslew  [total]      fp32 gaussian_filter1d(alpha * mask, sigma = alpha_slew_ms sr / 6000)
+struct rough_cfg {
+    int n_k;
+    double k[8];
+    float h[8];          // hk * float32 array: the weight is applied in fp32
+    double noise_amp, hp_a, sr;
+};
+
+__global__ __launch_bounds__(64) void k_vocal_roughness(const float *__restrict__ y, const float *__restrict__ f0,
+                                                        const float *__restrict__ mask, const double *__restrict__ nz,
+                                                        const float *__restrict__ aslew, const int64_t *__restrict__ sample_off,
+                                                        int n_notes, int64_t total, rough_cfg cfg, float *__restrict__ out)
+{
+    const int note = blockIdx.x * blockDim.x + threadIdx.x;
+    if (note >= n_notes) return;
+    const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+    double c[8];
+    for (int q = 0; q < 8; ++q) c[q] = 0.0;
+    double px = 0.0, py = 0.0;
+    const double two_pi = 2.0 * 3.14159265358979323846;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t g = base + i;
+        const float f = f0[g], vm = mask[g], yv = y[g];
+        float mod = 0.f;
+        for (int q = 0; q < cfg.n_k; ++q) {
+            const float fk = f / (float)cfg.k[q];                                   // f0 / float(k): fp32 array / python float
+            double fm = (double)fk * (1.0 + cfg.noise_amp * nz[(int64_t)q * total + g]);
+            fm = (fm > 0.0 ? fm : 0.0) * (double)vm;                                // np.maximum(f_mod, 0.0) * vmask
+            c[q] += fm;                                                             // np.cumsum, fp64, in order
+            const double ph = (two_pi * c[q]) / cfg.sr;
+            mod += cfg.h[q] * (float)cos(ph);                                       // mod_sum += hk * cos(phase).astype(f32)
+        }
+        const float ym = yv * (1.0f + mod);
+        const float ys = ym - yv;
+        const double xn = (double)ys;
+        const double yn = cfg.hp_a * (py + xn - px);                                // one_pole_highpass: python-float state
+        px = xn;
+        py = yn;
+        out[g] = yv + aslew[g] * (float)yn;
+    }
+}
+
+int launch_vocal_roughness(goofer_ctx *ctx, const float *y, const float *f0, const float *mask, const double *nz, int n_k,
+                           const double *k_list, const double *h_list, double noise_amp, double hp_fc, const float *aslew,
+                           const int64_t *sample_off, int n_notes, int64_t total, float *out, hipStream_t st)
+{
+    if (n_notes <= 0 || total <= 0) return GOOFER_OK;
+    if (n_k < 0 || n_k > 8) return goofer_fail(ctx, GOOFER_EINVAL, "%d roughness modulators (0..8 supported)", n_k);
+    rough_cfg cfg;
+    cfg.n_k = n_k;
+    for (int q = 0; q < 8; ++q) {
+        cfg.k[q] = q < n_k ? k_list[q] : 1.0;
+        cfg.h[q] = q < n_k ? (float)h_list[q] : 0.f;
+    }
+    cfg.noise_amp = noise_amp;
+    cfg.sr = (double)ctx->plan.sr;
+    if (hp_fc > 0.0) {
+        const double rc = 1.0 / (2.0 * 3.14159265358979323846 * hp_fc);
+        cfg.hp_a = rc / (rc + 1.0 / cfg.sr);
+    } else {
+        cfg.hp_a = 0.0;                                        // fc <= 0: one_pole_highpass returns zeros
+    }
+    hipLaunchKernelGGL(k_vocal_roughness, dim3((n_notes + 63) / 64), dim3(64), 0, st, y, f0, mask, nz, aslew, sample_off, n_notes,
+                       total, cfg, out);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}

@@ -236,6 +236,22 @@ class Context:
                                                    (taps.size - 1) // 2, _ptr(out), self._stream()))
         return out
 
+    def vocal_roughness(self, y, f0, mask, noise_s, k_list, h_list, noise_amp: float, hp_fc: float, alpha_slewed, lengths=None):
+        """apply_vocal_roughness (GOOFER.py:901-940) on fp32 device signals; ``noise_s`` fp64 [n_k, N] smoothed noises,
+        ``alpha_slewed`` fp32 [N].  Returns the roughened signal (a new tensor)."""
+        n_total = y.numel()
+        lengths = [n_total] if lengths is None else list(lengths)
+        off = self.tensor(self.offsets(lengths))
+        k = np.ascontiguousarray(k_list, dtype=np.float64)
+        h = np.ascontiguousarray(h_list, dtype=np.float64)
+        out = torch.empty_like(y)
+        self._check(self.lib.goofer_vocal_roughness(self.h, _ptr(y), _ptr(f0), _ptr(mask), _ptr(noise_s) if len(k) else None, len(k),
+                                                    k.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p), float(noise_amp),
+                                                    float(hp_fc), _ptr(alpha_slewed), _ptr(off), len(lengths), n_total, _ptr(out),
+                                                    self._stream()))
+        out._keep = off
+        return out
+
     def stretch_rows(self, x, rows_out: int):
         """gf.stretch_feature along axis 0 (GOOFER.py:597-616): a 1-D fp32 tensor, or an ld-strided [rows, bins] view."""
         if x.dim() == 1:

@@ -313,6 +313,14 @@ int goofer_stretch_rows(goofer_ctx *ctx, const float *in, int64_t ld_in, int64_t
 int goofer_gauss_rows_f64(goofer_ctx *ctx, const double *in, const int64_t *row_off, int n_rows, int64_t total, const double *taps,
                           int radius, double *out, void *stream);
 
+/* apply_vocal_roughness (GOOFER.py:901-940; gf.synthesize's roughness_on layer) for a ragged batch: out = y + alpha_slewed *
+ * highpass(y * (1 + sum_k h_k cos(2 pi cumsum(f_mod_k) / sr)) - y), f_mod_k = max(f0 / k * (1 + noise_amp * noise_k), 0) * mask.
+ * noise_s [n_k x total_samples] fp64 = the smoothed noises (make_smooth_noise), alpha_slewed [total_samples] fp32 = the slewed
+ * alpha * mask — both Gaussian filters of host draws / the mask (goofer_gauss_rows_f64); k_list / h_list are HOST arrays. */
+int goofer_vocal_roughness(goofer_ctx *ctx, const float *y, const float *f0, const float *mask, const double *noise_s, int n_k,
+                           const double *k_list, const double *h_list, double noise_amp, double hp_fc, const float *alpha_slewed,
+                           const int64_t *sample_off, int n_notes, int64_t total_samples, float *out, void *stream);
+
 /* dynamic_butter_filter (SillySampler.py:95-174) for a list of jobs (device array): src -> dst, fp32. */
 int goofer_onepole_cascade(goofer_ctx *ctx, const float *src, float *dst, const float *f0, const goofer_onepole_job *jobs,
                            int n_jobs, void *stream);

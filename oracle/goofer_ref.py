@@ -660,6 +660,59 @@ def _voiced_brighten(S, voiced_frames, curve):
     return S
 
 
+def smooth_noise(length, sr, smooth_ms, seed):
+    """make_smooth_noise (GOOFER.py:893-899): the LEGACY global generator is re-seeded, the fp32 draw is convolved with an fp64
+    Gaussian (fp64 result)."""
+    np.random.seed(seed)
+    n = np.random.randn(length).astype(F32)
+    return gauss1d(n, max(1.0, (smooth_ms * 0.001 * sr) / 6.0))
+
+
+def one_pole_highpass(x, sr, fc):
+    """GOOFER.py:878-892: python-float (fp64) state, fp32 stores."""
+    if fc <= 0:
+        return np.zeros_like(x)
+    rc = 1.0 / (2.0 * np.pi * fc)
+    a = rc / (rc + 1.0 / sr)
+    y = np.zeros_like(x, dtype=F32)
+    px = py = 0.0
+    for i in range(len(x)):
+        xn = float(x[i])
+        yn = a * (py + xn - px)
+        y[i] = yn
+        px, py = xn, yn
+    return y
+
+
+def vocal_roughness(y, f0, vmask, sr, k_list=(2, 3, 4), h_list=None, alpha=0.6, hp_fc=300.0, noise_amp=0.6,
+                    noise_smooth_ms=120.0, alpha_slew_ms=120.0):
+    """apply_vocal_roughness (GOOFER.py:901-940): sub-harmonic amplitude modulation at f0/k with noisy rates, the
+    difference high-passed and faded in by the slewed voicing mask."""
+    y = np.asarray(y, dtype=F32)
+    f0 = np.asarray(f0, dtype=F32)
+    vmask = np.asarray(vmask, dtype=F32)
+    N = len(y)
+    if h_list is None:
+        h_list = [0.45, 0.28, 0.18][:len(k_list)]
+        if len(h_list) < len(k_list):
+            extra = len(k_list) - len(h_list)
+            h_list += [h_list[-1] * 0.6 ** i for i in range(1, extra + 1)]
+    mod_sum = np.zeros(N, dtype=F32)
+    for idx, (k, hk) in enumerate(zip(k_list, h_list)):
+        nz = smooth_noise(N, sr, noise_smooth_ms, seed=1337 + idx)
+        f_mod = (f0 / float(k)) * (1.0 + noise_amp * nz)
+        f_mod = np.maximum(f_mod, 0.0) * vmask
+        phase = 2.0 * np.pi * np.cumsum(f_mod) / float(sr)
+        mod_sum += hk * np.cos(phase).astype(F32)
+    y_mod = y * (1.0 + mod_sum)
+    y_sub = y_mod - y
+    y_sub_hp = one_pole_highpass(y_sub, sr, hp_fc)
+    alpha_track = alpha * vmask
+    sigma = max(1.0, (alpha_slew_ms * 0.001 * sr) / 6.0)
+    alpha_slewed = gauss1d(alpha_track, sigma).astype(F32)
+    return y + alpha_slewed * y_sub_hp
+
+
 def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=256,
                stretch_factor=1.0, start_sec=None, end_sec=None, apply_brightness=True, normalize=1.0,
                uv_strength=0.75, breath_strength=0.1, noise_transition_smoothness=100,
@@ -671,6 +724,8 @@ def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=
                cut_subharm_below_f0=True, subharm_vibrato_rate=6.0, subharm_vibrato_depth=0.1,
                subharm_f0_jitter=0, subharm_vibrato_delay=0.1,
                F1_shift=1.0, F2_shift=1.0, F3_shift=1.0, F4_shift=1.0, formants=None,
+               roughness_on=False, rough_k_list=(2, 3, 4), rough_h_list=None, rough_alpha=0.6, rough_hp_fc=320.0,
+               rough_noise_amp=0.6, rough_noise_smooth_ms=120.0, rough_alpha_slew_ms=120.0,
                phi=None, rng=None, noise=None, return_parts=False, **_ignored):
     """Source-filter resynthesis (GOOFER.py:971-1220).
 
@@ -773,6 +828,9 @@ def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=
         bre *= 1.0 + (jb - 1.0) * vj
 
     combined = harmonic + uv + bre
+    if roughness_on:                                                   # GOOFER.py:1195-1206: only `combined` hears it
+        combined = vocal_roughness(harmonic, f0, vm, sr, rough_k_list, rough_h_list, rough_alpha, rough_hp_fc,
+                                   rough_noise_amp, rough_noise_smooth_ms, rough_alpha_slew_ms) + uv + bre
     peak = float(np.max(np.abs(combined)) + 1e-12)
     gain = (1.0 / peak) ** float(np.clip(normalize, 0.0, 1.0))
     harmonic *= gain

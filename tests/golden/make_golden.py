@@ -332,6 +332,32 @@ def gen_synthesize():
     save("synthesize", **out)
 
 
+def gen_synthesize_rough():
+    """gf.synthesize(roughness_on=True) (GOOFER.py:901-940, 1195-1206): defaults, and every rough_* argument moved."""
+    cases = [
+        ("default", dict(roughness_on=True)),
+        ("custom", dict(roughness_on=True, rough_k_list=(2, 5), rough_h_list=[0.5, 0.2], rough_alpha=0.8, rough_hp_fc=180.0,
+                        rough_noise_amp=0.3, rough_noise_smooth_ms=60.0, rough_alpha_slew_ms=40.0, normalize=0.5,
+                        pitch_shift=1.2)),
+        ("three_defaults_more_k", dict(roughness_on=True, rough_k_list=(2, 3, 4, 6))),
+    ]
+    src = syn.make_source(300, 44100, 1024, 256, seconds=0.30)
+    env = gf.decode_env_from_knots(src["env_pack"])
+    n = src["y_len"]
+    t = np.arange(n) / 44100
+    mask = src["mask"].copy()
+    f0 = (196.0 * 2 ** (0.3 * np.sin(2 * np.pi * 3.1 * t))) * mask
+    out = {"names": np.array([c[0] for c in cases]), "env": env, "f0": f0, "mask": mask,
+           "formants": np.stack([src["formants"][i] for i in (1, 2, 3, 4)], 0), "geo": np.array([44100, 1024, 256, 7000])}
+    for name, kw in cases:
+        _RNG_SEED[0] = 7000
+        rec, harm, uv, bre = gf.synthesize(env, f0.astype(np.float64), mask, np.empty(n, bool), 44100, n_fft=1024, hop_length=256,
+                                           formants=src["formants"], **kw)
+        _RNG_SEED[0] = None
+        out[f"{name}_rec"], out[f"{name}_harm"], out[f"{name}_uv"], out[f"{name}_bre"] = rec, harm, uv, bre
+    save("synthesize_rough", **out)
+
+
 # --------------------------------------------------------------------------------------------
 # sampler-level vectors (a13-a20)
 # --------------------------------------------------------------------------------------------
@@ -636,6 +662,7 @@ elif __name__ == "__main__":
     gen_knots()
     gen_warps()
     gen_synthesize()
+    gen_synthesize_rough()
     gen_flags_pitch()
     gen_goofy_file()
     gen_post_chain()

@@ -210,6 +210,21 @@ def test_synthesize_subharm_kwargs_vs_oracle(ctx, kw):
         assert rms_err(a, b) < 2e-5, (key, rms_err(a, b))
 
 
+@pytest.mark.parametrize("name", ["default", "custom", "three_defaults_more_k"])
+def test_synthesize_roughness_matches_reference(ctx, name):
+    """gf.synthesize(roughness_on=True) (apply_vocal_roughness, GOOFER.py:901-940) against the reference's own outputs."""
+    from goofer_amd import core
+    from test_oracle_core import ROUGH_KW, rough_case
+    g = golden("synthesize_rough")
+    c = rough_case(g)
+    got = core.synthesize(c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"], n_fft=c["n_fft"], hop_length=c["hop"],
+                          formants=c["formants"], phi=c["phi"], ctx=ctx, **ROUGH_KW[name])
+    for a, key in zip(got, ("rec", "harm", "uv", "bre")):
+        ref = g[f"{name}_{key}"]
+        assert a.dtype == np.float32 and a.shape == ref.shape
+        assert rms_err(a, ref) < 2e-5 * max(1.0, float(np.max(np.abs(ref)))), (name, key, rms_err(a, ref))
+
+
 _SOAK_FIRST = int(os.environ.get("GOOFER_FUZZ_FIRST", "0"))
 
 
@@ -246,6 +261,12 @@ def test_synthesize_random_kwargs_vs_oracle(ctx, case):
                       subharm_vibrato_depth=float(np.round(rng.uniform(0.05, 0.6), 3)),
                       subharm_vibrato_delay=float(np.round(rng.uniform(0.0, 0.1), 3)))
         if pick(0.3): kw["subharm_f0_jitter"] = float(np.round(rng.uniform(0.1, 1.0), 3))
+    if pick(0.25):
+        kw.update(roughness_on=True, rough_alpha=float(np.round(rng.uniform(0.2, 1.0), 2)),
+                  rough_hp_fc=float(np.round(rng.uniform(100.0, 500.0), 1)), rough_noise_amp=float(np.round(rng.uniform(0.0, 1.0), 2)),
+                  rough_noise_smooth_ms=float(np.round(rng.uniform(20.0, 200.0), 1)),
+                  rough_alpha_slew_ms=float(np.round(rng.uniform(10.0, 200.0), 1)))
+        if pick(0.5): kw["rough_k_list"] = tuple(int(v) for v in rng.choice([2, 3, 4, 5, 6], size=int(rng.integers(1, 5)), replace=False))
     phi = c["phi"]
     if pick(0.25):
         kw["stretch_factor"] = float(np.round(rng.uniform(0.6, 1.5), 2))

@@ -171,6 +171,39 @@ def test_synthesize_against_reference():
             assert rms_err(got, ref) < 2e-6 * max(1.0, float(np.max(np.abs(ref)))), (name, key, rms_err(got, ref))
 
 
+ROUGH_KW = {
+    "default": dict(roughness_on=True),
+    "custom": dict(roughness_on=True, rough_k_list=(2, 5), rough_h_list=[0.5, 0.2], rough_alpha=0.8, rough_hp_fc=180.0,
+                   rough_noise_amp=0.3, rough_noise_smooth_ms=60.0, rough_alpha_slew_ms=40.0, normalize=0.5, pitch_shift=1.2),
+    "three_defaults_more_k": dict(roughness_on=True, rough_k_list=(2, 3, 4, 6)),
+}
+
+
+def rough_case(g):
+    sr, n_fft, hop, seed = (int(v) for v in g["geo"])
+    env = g["env"]
+    T = 1 + len(g["f0"]) // hop
+    phi = np.random.default_rng(seed).uniform(0.0, 2.0 * np.pi, size=(env.shape[0], T)).astype(np.float32)
+    return dict(env=env, f0=g["f0"], mask=g["mask"], n=len(g["f0"]), sr=sr, n_fft=n_fft, hop=hop, phi=phi,
+                formants={i + 1: g["formants"][i] for i in range(4)})
+
+
+def test_vocal_roughness_against_reference():
+    """gf.synthesize(roughness_on=True): only `reconstruct` hears the roughness layer, the stems share its peak gain."""
+    g = golden("synthesize_rough")
+    c = rough_case(g)
+    for name in g["names"]:
+        out = R.synthesize(c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"], n_fft=c["n_fft"], hop_length=c["hop"],
+                           formants=c["formants"], phi=c["phi"], **ROUGH_KW[str(name)])
+        for got, key in zip(out, ("rec", "harm", "uv", "bre")):
+            ref = g[f"{name}_{key}"]
+            assert got.dtype == np.float32 and got.shape == ref.shape
+            assert rms_err(got, ref) < 2e-6 * max(1.0, float(np.max(np.abs(ref)))), (name, key, rms_err(got, ref))
+    plain = R.synthesize(c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"], n_fft=c["n_fft"], hop_length=c["hop"],
+                         formants=c["formants"], phi=c["phi"])
+    assert rms_err(plain[0], g["default_rec"]) > 1e-3          # the layer is audible
+
+
 def test_goofy_files(tmp_path):
     import os
     from conftest import GOLDEN
