@@ -384,8 +384,8 @@ def note_params_from_kwargs(n=1, **kw):
     if kw.get("add_subharm"):
         if kw.get("subharm_f0_jitter", 0) > 0.0:
             p["subharm_f0_jitter"] = kw["subharm_f0_jitter"]
-        if np.size(kw.get("subharm_semitones", -12)) > 4:
-            raise NotImplementedError("at most four sub-harmonic ratios per call on the device path")
+        if np.size(kw.get("subharm_semitones", -12)) > 16:
+            raise NotImplementedError("at most sixteen sub-harmonic ratios per call on the device path")
         p["subharm_weight"] = kw.get("subharm_weight", 0.5)
     return p
 

@@ -1184,9 +1184,11 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
             if ((rc = launch_note_absmax(ctx, jit_a, b->sample_off, n, N, on_subj, jit_max, st))) return rc;
             if ((rc = launch_f0_jitter(ctx, f0s, b->mask, jit_a, jit_max, b->sample_off, n, N, b->params, 1, st))) return rc;
         }
-        double ratios[4] = {b->subharm_ratio, b->subharm_more[0], b->subharm_more[1], b->subharm_more[2]};
+        double ratios[16];
+        ratios[0] = b->subharm_ratio;
+        for (int q = 0; q < 15; ++q) ratios[q + 1] = b->subharm_more[q];
         int n_ratios = 1;
-        while (n_ratios < 4 && ratios[n_ratios] > 0.0) ++n_ratios;
+        while (n_ratios < 16 && ratios[n_ratios] > 0.0) ++n_ratios;
         if ((rc = launch_subharm(ctx, f0s, b->mask, b->sample_off, n, N, b->params, ratios, n_ratios, b->subharm_vibrato,
                                  b->subharm_vib_rate, b->subharm_vib_depth, b->subharm_vib_delay, sub_fm, inc, (onset_t *)onsets,
                                  onset_idx, onset_cnt, ovf, on_sub, sub_buf, sub_max, pulse, st)))

@@ -342,7 +342,7 @@ class Context:
                        noise_subharm=noise_subharm.data_ptr() if noise_subharm is not None else None,
                        f0_jitter_sigma=self.geom[0] / (f0_jitter_speed * 6), vol_jitter_sigma=self.geom[0] / (vol_jitter_speed * 6),
                        vol_jitter_speed=float(vol_jitter_speed), volume_vibrato=int(bool(volume_vibrato)),
-                       subharm_ratio=_ratios(subharm)[0], subharm_more=(C.c_double * 3)(*_ratios(subharm)[1:4]),
+                       subharm_ratio=_ratios(subharm)[0], subharm_more=(C.c_double * 15)(*_ratios(subharm)[1:16]),
                        subharm_vib_rate=float(subharm.get("rate", 6.0)) if subharm else 0.0,
                        subharm_vib_depth=float(subharm.get("depth", 0.1)) if subharm else 0.0,
                        subharm_vib_delay=float(subharm.get("delay", 0.1)) if subharm else 0.0,
@@ -361,14 +361,14 @@ class Context:
 
 
 def _ratios(subharm):
-    """2^(st/12) for up to four sub-harmonic semitone offsets (a scalar or a list, like gf.add_subharms takes), 0-padded."""
+    """2^(st/12) for up to sixteen sub-harmonic semitone offsets (a scalar or a list, like gf.add_subharms takes), 0-padded."""
     if not subharm:
-        return [0.0, 0.0, 0.0, 0.0]
+        return [0.0] * 16
     st = np.atleast_1d(np.asarray(subharm["semitones"], dtype=np.float64))
-    if st.size > 4:
-        raise ValueError("at most four sub-harmonic ratios per call")
+    if st.size > 16:
+        raise ValueError("at most sixteen sub-harmonic ratios per call")
     r = [float(2.0 ** (v / 12.0)) for v in st]
-    return r + [0.0] * (4 - len(r))
+    return r + [0.0] * (16 - len(r))
 
 
 _default = {}

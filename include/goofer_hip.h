@@ -94,7 +94,7 @@ typedef struct {
     float vol_jitter_sigma;     /* sr / (6 * volume_jitter_speed)                 GOOFER.py:654        */
     /* sub-harmonic pulse layer ('sg'): notes with params.subharm_weight > 0         GOOFER.py:1076-1097  */
     double subharm_ratio;       /* 2^(subharm_semitones / 12); 0 disables the layer for the batch         */
-    double subharm_more[3];     /* further ratios when subharm_semitones is a list (0 = unused): one phase      */
+    double subharm_more[15];    /* further ratios when subharm_semitones is a list (0 = unused): one phase      */
                                 /* tracker each, pulses summed before the joint max-normalisation  :672-736     */
     double subharm_vib_rate;    /* Hz                                              GOOFER.py:748-766       */
     double subharm_vib_depth;

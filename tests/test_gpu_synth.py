@@ -188,6 +188,8 @@ def test_synthesize_jitter_kwargs_vs_oracle(ctx, vibrato):
     # a list of ratios: one phase tracker each, pulses summed before the joint max-normalisation (GOOFER.py:672-736)
     dict(add_subharm=True, subharm_semitones=[-12, 7, 12], subharm_weight=0.9, subharm_vibrato=True, subharm_vibrato_rate=20.0,
          subharm_vibrato_depth=0.2, subharm_vibrato_delay=0.02),
+    # six ratios (the struct takes sixteen)
+    dict(add_subharm=True, subharm_semitones=[-24, -12, -5, 7, 12, 19], subharm_weight=0.7),
     # subharm_f0_jitter jitters f0_interp itself (alias) after the pulse train: the HP cutoffs of both branches follow it
     dict(add_subharm=True, subharm_f0_jitter=0.8, f0_jitter=True, f0_jitter_strength=0.5, volume_jitter=True,
          volume_jitter_strength_harm=0.4, volume_jitter_strength_breath=0.7),
@@ -255,7 +257,7 @@ def test_synthesize_random_kwargs_vs_oracle(ctx, case):
         if pick(0.3): kw.update(volume_vibrato=True, volume_jitter_speed=float(np.round(rng.uniform(3.0, 12.0), 2)))
     if pick(0.4):
         kw.update(add_subharm=True, subharm_weight=float(np.round(rng.uniform(0.2, 1.2), 3)),
-                  subharm_semitones=[int(v) for v in rng.choice([-12, -5, 7, 12, 19], size=int(rng.integers(1, 4)), replace=False)])
+                  subharm_semitones=[int(v) for v in rng.choice([-24, -12, -5, 5, 7, 12, 19], size=int(rng.integers(1, 7)), replace=False)])
         if pick(0.5):
             kw.update(subharm_vibrato=True, subharm_vibrato_rate=float(np.round(rng.uniform(4.0, 40.0), 2)),
                       subharm_vibrato_depth=float(np.round(rng.uniform(0.05, 0.6), 3)),
