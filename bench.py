@@ -47,6 +47,9 @@ def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int) ->
         "mask_short": 4 * N / 4 + 8 * N / 4, "stem_gains": 24 * N,
         "apply_gain": 16 * N,                         # three stems in, the mix out (mix_only)
         "setup_maps": 8 * N + 12 * F,
+        # stem-split walkers (stems.hip): envelope row (+ unique pulse samples) in, finished samples out
+        "noise_stems": 4 * B * F + 8 * N, "harm_stem": (4 * hop + 4 * B) * F + 4 * N,
+        "note_finish": 16 * N,                        # three stems in, the mix out (mix_only)
     }
     return float(table[stage])
 
@@ -55,7 +58,8 @@ STAGE_KERNEL = {"rfft_frames": "void k_rfft_frames<512>", "rfft_frames_standalon
                 "irfft_harm": "void k_irfft_frames<512>", "harm_shape": "void k_harm_shape<9>",
                 "noise_spectra": "void k_noise_spectra<9>", "ola3_gains": "k_ola3_gains", "irfft_ola3": "void k_irfft_ola3<512>",
                 "apply_gain": "k_apply_gain", "pulse_onsets": "k_pulse_onsets_scan", "pulse_place": "k_pulse_place",
-                "mask_short": "k_mask_short", "phase_inc": "k_phase_inc", "setup_maps": "k_scale_f0"}
+                "mask_short": "k_mask_short", "phase_inc": "k_phase_inc", "setup_maps": "k_scale_f0",
+                "noise_stems": "void k_noise_stems<512>", "harm_stem": "void k_harm_stem<512>", "note_finish": "k_note_finish"}
 
 
 PMC_FILE = "r01l_pmc_traffic.json"      # committed rocprofv3 counter passes of this same command (scripts/collect_profiles.sh)
@@ -231,7 +235,7 @@ def main():
         per = {k: v / steps for k, v in prof["ms"].items()}              # ms per launch, this rank
         # the dominant kernel is picked among the stages that run alone on the chip: the event-bracketed times of the
         # forked stages (pulse chain on the side stream, noise spectra / mask smoothing beside it) include each other
-        shared = {"pulse_onsets", "pulse_place", "noise_spectra", "mask_short", "phase_inc", "setup_maps", "assemble"}
+        shared = {"pulse_onsets", "pulse_place", "noise_spectra", "noise_stems", "mask_short", "phase_inc", "setup_maps", "assemble"}
         solo = {k: v for k, v in per.items() if k not in shared} or per
         dom = max(solo, key=solo.get)
         per["rfft_frames_standalone"] = rfft_ms

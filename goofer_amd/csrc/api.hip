@@ -87,6 +87,18 @@ int launch_stem_gains(goofer_ctx *, float *, float *, float *, const double *, c
 int launch_apply_gain(goofer_ctx *, float *, float *, float *, float *, float *, const int64_t *, int, int64_t,
                       const goofer_note_params *, const float *, bool, hipStream_t);
 
+int launch_note_steps(goofer_ctx *, const int64_t *, int, double *, hipStream_t);
+bool stems_supported(const goofer_plan_t &);
+int launch_frame_picks(goofer_ctx *, const int64_t *, const int *, int64_t, const int64_t *, const float *, const float *, float2 *,
+                       hipStream_t);
+int launch_noise_stems(goofer_ctx *, const float *, int, const int64_t *, const float *, int64_t, const int *, const int64_t *,
+                       const int64_t *, const float2 *, const goofer_note_params *, uint64_t, bool, const double *, const double *, float *,
+                       float *, hipStream_t);
+int launch_harm_stem(goofer_ctx *, const float *, const float *, int, const int64_t *, const double *, int64_t, const int *,
+                     const int64_t *, const int64_t *, const float2 *, const goofer_note_params *, float *, float *, hipStream_t);
+int launch_note_finish(goofer_ctx *, float *, float *, float *, float *, float *, const int64_t *, int, const goofer_note_params *,
+                       const float *, float *, bool, hipStream_t);
+
 static const size_t ONSET_BYTES = 24;
 
 int goofer_fail(goofer_ctx *ctx, int code, const char *fmt, ...)
@@ -98,6 +110,40 @@ int goofer_fail(goofer_ctx *ctx, int code, const char *fmt, ...)
         va_end(ap);
     }
     return code;
+}
+
+static goofer_ctx::kernel_state *kstate_of(goofer_ctx *ctx, const void *fn)
+{
+    for (int i = 0; i < ctx->n_kstate; ++i)
+        if (ctx->kstate[i].fn == fn) return &ctx->kstate[i];
+    if (ctx->n_kstate >= 32) return nullptr;
+    goofer_ctx::kernel_state *k = &ctx->kstate[ctx->n_kstate++];
+    *k = {fn, 0, 0, false};
+    return k;
+}
+
+int kernel_allow_max_lds(goofer_ctx *ctx, const void *fn, int bytes)
+{
+    goofer_ctx::kernel_state *k = kstate_of(ctx, fn);
+    if (k && k->max_lds_set) return GOOFER_OK;
+    HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (k) k->max_lds_set = true;
+    return GOOFER_OK;
+}
+
+int kernel_resident_waves(goofer_ctx *ctx, const void *fn, size_t lds, int *waves)
+{
+    goofer_ctx::kernel_state *k = kstate_of(ctx, fn);
+    if (k && k->waves > 0 && k->lds == lds) {
+        *waves = k->waves;
+        return GOOFER_OK;
+    }
+    int cus = 0, per_cu = 0;
+    HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
+    *waves = (cus > 0 ? cus : 256) * (per_cu > 0 ? per_cu : 1) * 4;
+    if (k) { k->waves = *waves; k->lds = lds; }
+    return GOOFER_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,6 +451,8 @@ int goofer_plan(goofer_ctx *ctx, int sr, int n_fft, int hop)
     if ((rc = upload(ctx, &p.tw_half, twh))) return rc;
     if ((rc = upload(ctx, &p.blur5, t5))) return rc;
     if ((rc = upload(ctx, &p.blur175, t175))) return rc;
+    for (int j = 0; j < 5; ++j) p.taps5_f[j] = (float)t5[j];
+    for (int j = 0; j < 15; ++j) p.taps175_f[j] = (float)t175[j];
     HIP_TRY(ctx, hipMalloc((void **)&p.pulse_peak, 8193 * sizeof(float)));
     p.sr = sr; p.n_fft = n_fft; p.hop = hop; p.n_bins = B;
     if ((rc = launch_pulse_peak(ctx, p.pulse_peak, (double)sr, 0))) return rc;
@@ -492,9 +540,11 @@ int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages)
             if (ctx->prof_side_used && s >= 3 && s <= 5) {              // the pulse chain ran on the side stream
                 hipEvent_t *q = ctx->prof_side + (size_t)k * 4;
                 HIP_TRY(ctx, hipEventElapsedTime(&ms, q[s - 3], q[s - 2]));
-            } else if (ctx->prof_side_used && (s == 9 || s == 12)) {    // launched beside it on the caller's stream
+            } else if (ctx->prof_side_used && (s == (ctx->prof_stems ? 6 : 9) || s == (ctx->prof_stems ? 7 : 12))) {
+                // the two kernels launched beside it on the caller's stream, in launch order
                 hipEvent_t *q = ctx->prof_main2 + (size_t)k * 2;
-                HIP_TRY(ctx, hipEventElapsedTime(&ms, s == 9 ? e[5] : q[0], s == 9 ? q[0] : q[1]));
+                const bool first = s == (ctx->prof_stems ? 6 : 9);
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, first ? e[5] : q[0], first ? q[0] : q[1]));
             } else {
                 HIP_TRY(ctx, hipEventElapsedTime(&ms, e[s], e[s + 1]));
             }
@@ -511,6 +561,10 @@ static const char *const PROF_NAMES_FUSED[PROF_STAGES] = {
     "setup_maps", "", "", "phase_inc", "pulse_onsets", "pulse_place", "harm_frames", "", "", "noise_frames", "", "",
     "mask_short", "ola3_gains", "apply_gain", "", "", ""};
 
+static const char *const PROF_NAMES_STEMS[PROF_STAGES] = {
+    "setup_maps", "", "", "phase_inc", "pulse_onsets", "pulse_place", "mask_short", "noise_stems",
+    "", "harm_stem", "", "", "", "note_finish", "", "", "", ""};
+
 static const char *const PROF_NAMES_OLA[PROF_STAGES] = {
     "setup_maps", "", "", "phase_inc", "pulse_onsets", "pulse_place", "rfft_frames", "harm_shape",
     "", "noise_spectra", "", "", "mask_short", "irfft_ola3", "apply_gain", "", "", ""};
@@ -519,6 +573,7 @@ const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage)
 {
     if (stage < 0 || stage >= PROF_STAGES) return "";
     if (ctx && ctx->fused) return PROF_NAMES_FUSED[stage];
+    if (ctx && ctx->prof_stems) return PROF_NAMES_STEMS[stage];
     return (ctx && ctx->ola_fused) ? PROF_NAMES_OLA[stage] : PROF_NAMES[stage];
 }
 
@@ -529,6 +584,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "fused")) { ctx->fused = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "fused_ola")) { ctx->ola_fused = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "overlap")) { ctx->overlap = value != 0; return GOOFER_OK; }
+    if (!strcmp(name, "stems")) { ctx->stems = value != 0; return GOOFER_OK; }
     return goofer_fail(ctx, GOOFER_EINVAL, "unknown option %s", name);
 }
 
@@ -1065,9 +1121,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     hipEvent_t *pev = nullptr;
     if (ctx->prof_on && ctx->prof_steps < ctx->prof_cap) pev = ctx->prof_ev + (size_t)ctx->prof_steps * (PROF_STAGES + 1);
     int stage = 0;
-#define MARK_AT(k)                                                   \
+#define MARK_Q(q)                                                    \
     do {                                                             \
-        if (pev) HIP_TRY(ctx, hipEventRecord(ctx->prof_main2[(size_t)ctx->prof_steps * 2 + ((k) == 9 ? 0 : 1)], st)); \
+        if (pev) HIP_TRY(ctx, hipEventRecord(ctx->prof_main2[(size_t)ctx->prof_steps * 2 + (q)], st)); \
     } while (0)
 #define MARK()                                                       \
     do {                                                             \
@@ -1080,6 +1136,10 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // goofer_render_batch: the assembly recorded ev_f0 right after the f0 / mask kernel.  The pulse chain (f0 scaling,
     // sequential walk, placement) then runs on the side stream from that point on, beside the envelope assembly and the
     // map kernels, instead of starting when this call's first kernel is reached in stream order.
+    // Stem-split walkers (stems.hip): no spectra in HBM.  The legacy kernels stay for the other geometries, for the
+    // volume-jitter / sub-harmonic layers (which edit the stems or the pulse train between the steps) and as the A/B path.
+    const bool stem_path = ctx->stems && ola_one && !ctx->fused && stems_supported(p) && !sub_on && !jit_vol;
+    if (pev) ctx->prof_stems = stem_path;
     const bool side_on = ctx->overlap && ola_one && !sub_on;
     const bool early = side_on && !jit_f0 && ctx->early_req && ctx->early_f0 == b->f0 && ctx->side != nullptr;
     // f0 * pitch_shift (GOOFER.py:995).  When the caller vouches that every pitch_shift is 1 (the resampler path: the pitch
@@ -1128,6 +1188,21 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if ((rc = launch_note_absmax(ctx, jit_a, b->sample_off, n, N, on_f0, jit_max, st))) return rc;
         if ((rc = launch_f0_jitter(ctx, f0s, b->mask, jit_a, jit_max, b->sample_off, n, N, b->params, 0, st))) return rc;
     }
+    // aperiodic half of the stem-split path: smoothed mask knots, then the two noise stems straight to samples.  Needs the
+    // final scaled f0 (frame picks) and nothing of the pulse chain.
+    auto stems_aperiodic = [&]() -> int {
+        int r2;
+        if (!picks_on && (r2 = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return r2;
+        if ((r2 = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return r2;
+        if (side_on) MARK_Q(0);
+        if ((r2 = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return r2;
+        if ((r2 = launch_noise_stems(ctx, b->env_noise ? b->env_noise : b->env, ld, row_src, b->phi, F, frame_note, b->frame_off,
+                                     b->sample_off, picks, b->params, b->seed, b->env_noise != nullptr, short_s, note_steps, b->uv,
+                                     b->bre, st)))
+            return r2;
+        if (side_on) MARK_Q(1);
+        return GOOFER_OK;
+    };
     // The pulse walk is one latency-bound wave per SIMD: it goes to a side stream FIRST (so its workgroups are resident
     // from the start), and the aperiodic branch — noise spectra, mask smoothing, which depend only on the maps and
     // the scaled f0 — fills the rest of the machine from the caller's stream meanwhile.
@@ -1163,13 +1238,17 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, pst));
         // meanwhile, on the caller's stream
         if (early) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_f0s, 0));   // the scaled f0 comes from the side stream
-        if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
-                                       b->env_noise ? b->env_noise : b->env, b->phi, ld, b->params, b->seed, row_src,
-                                       b->env_noise != nullptr, st)))
-            return rc;
-        MARK_AT(9);
-        if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
-        MARK_AT(12);
+        if (stem_path) {
+            if ((rc = stems_aperiodic())) return rc;
+        } else {
+            if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
+                                           b->env_noise ? b->env_noise : b->env, b->phi, ld, b->params, b->seed, row_src,
+                                           b->env_noise != nullptr, st)))
+                return rc;
+            MARK_Q(0);
+            if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
+            MARK_Q(1);
+        }
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     }
     if (sub_on) {   // 'sg': extra LF pulse layer at f0 * ratio with vibrato, added to the pulse train (GOOFER.py:1076-1097)
@@ -1193,6 +1272,39 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                                  b->subharm_vib_rate, b->subharm_vib_depth, b->subharm_vib_delay, sub_fm, inc, (onset_t *)onsets,
                                  onset_idx, onset_cnt, ovf, on_sub, sub_buf, sub_max, pulse, st)))
             return rc;
+    }
+    if (stem_path) {
+        MARK();   // 6: mask_short, 7: noise_stems (here when nothing runs beside the pulse chain)
+        if (!side_on && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
+        MARK();
+        if (!side_on) {
+            if (!picks_on && (rc = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return rc;
+            if ((rc = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return rc;
+            if ((rc = launch_noise_stems(ctx, b->env_noise ? b->env_noise : b->env, ld, row_src, b->phi, F, frame_note, b->frame_off,
+                                         b->sample_off, picks, b->params, b->seed, b->env_noise != nullptr, short_s, note_steps, b->uv,
+                                         b->bre, st)))
+                return rc;
+        }
+        MARK();   // 8
+        MARK();   // 9: harm_stem = rFFT + shaping + irFFT + overlap-add of the harmonic stem
+        if ((rc = launch_harm_stem(ctx, pulse, b->env, ld, row_src, b->formants, F, frame_note, b->frame_off, b->sample_off, picks,
+                                   b->params, b->harm, note_mag, st)))
+            return rc;
+        MARK();   // 10..12
+        MARK();
+        MARK();
+        MARK();   // 13: harm / max|S|, peak, gain, reconstruct, mix
+        if ((rc = launch_note_finish(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, b->params, note_mag, note_peak,
+                                     !(b->mix_only && (b->mix || b->rec)), st)))
+            return rc;
+        MARK();   // 14..17 unused
+        MARK();
+        MARK();
+        MARK();
+        MARK();   // end
+        if (pev) ctx->prof_steps++;
+        ctx->frame_picks = nullptr;
+        return GOOFER_OK;
     }
     // spectra -> windowed time frames of the three stems
     if (ctx->fused && !b->env_noise) {

@@ -373,7 +373,7 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         size_t lds = (size_t)A_ROWS * ((3 * B + a->max_K + 3) & ~3) * sizeof(float);
         if (lds > 64 * 1024) {
             if (lds > 160 * 1024) return goofer_fail(ctx, GOOFER_EINVAL, "envelope rows too wide for the edit kernel's LDS staging");
-            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_env_edit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (int arc = kernel_allow_max_lds(ctx, (const void *)k_env_edit)) return arc;
         }
         hipLaunchKernelGGL(k_env_edit, dim3((unsigned)((a->total_edit_rows + A_ROWS - 1) / A_ROWS)), dim3(256), lds, st, *a,
                            a->total_edit_rows, row_note_edit);

@@ -26,6 +26,7 @@ struct goofer_plan_t {
     float *pulse_shape = nullptr; // normalised LF pulses for T0 = 3..PULSE_TAB_MAX back to back (row T0 at T0(T0-1)/2 - 3)
     double *blur5 = nullptr;      // [5] sigma=0.5 taps (brightness blur)         GOOFER.py:1143
     double *blur175 = nullptr;    // [15] sigma=1.75 taps                         GOOFER.py:993
+    float taps5_f[5] = {0}, taps175_f[15] = {0};   // the same taps rounded to fp32, host side (passed to kernels by value)
 };
 
 struct goofer_ctx {
@@ -55,6 +56,18 @@ struct goofer_ctx {
     bool prof_side_used = false;
     bool ola_fused = true;        // irFFT x3 + overlap-add + gains in one kernel (k_irfft_ola3); false: separate irFFT launches + k_ola3_gains
     bool fused = false;           // opt-in fused per-frame kernels (fused.hip); default: one kernel per reference step
+    bool stems = true;            // stem-split frame walkers (stems.hip) where the geometry allows (hop == n_fft / 4); false: the
+                                  // one-kernel-per-reference-step pipeline with the spectra in HBM (A/B parity path)
+    bool prof_stems = false;      // the last profiled batch ran the stem-split path (stage order differs)
+    // per-context kernel state: hipFuncSetAttribute is per device, and a handle belongs to one device, so what was set /
+    // queried is remembered here and never in process-wide statics
+    struct kernel_state {
+        const void *fn;
+        size_t lds;               // dynamic LDS the occupancy below was queried for
+        int waves;                // waves of this kernel the device holds at once (0: not queried)
+        bool max_lds_set;
+    } kstate[32] = {};
+    int n_kstate = 0;
     // per-stage HIP-event timing of goofer_synth_batch (goofer_profile_begin/end)
     bool prof_on = false;
     int prof_steps = 0, prof_cap = 0;
@@ -66,6 +79,10 @@ struct goofer_ctx {
 };
 
 int goofer_fail(goofer_ctx *ctx, int code, const char *fmt, ...);
+// opt a kernel in to the full 160 KiB of dynamic LDS on this handle's device (once per handle)
+int kernel_allow_max_lds(goofer_ctx *ctx, const void *fn, int bytes = 160 * 1024);
+// waves of `fn` (256-thread workgroups, `lds` bytes of dynamic LDS) resident on this handle's device at once
+int kernel_resident_waves(goofer_ctx *ctx, const void *fn, size_t lds, int *waves);
 
 #define HIP_TRY(ctx, call)                                                                       \
     do {                                                                                         \

@@ -275,11 +275,7 @@ static int harm_impl(goofer_ctx *ctx, const float *pulse, const goofer_batch *b,
                      const int64_t *row_src, float *frames, float *note_mag, hipStream_t st)
 {
     const goofer_plan_t &p = ctx->plan;
-    static bool attr = false;
-    if (!attr) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_harm_frames<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        attr = true;
-    }
+    if (int arc = kernel_allow_max_lds(ctx, (const void *)k_harm_frames<M>, 159 * 1024)   /* + 576 B static */) return arc;
     unsigned blocks = (unsigned)((b->total_frames + FZ_FRAMES - 1) / FZ_FRAMES);
     hipLaunchKernelGGL(k_harm_frames<M>, dim3(blocks), dim3(256), fz_cfg<M>::lds_bytes, st, pulse, b->env, b->ld, b->formants, f0s,
                        b->mask, b->sample_off, b->frame_off, frame_note, row_src, b->params, b->total_frames, frames, note_mag, p.hop,
@@ -293,11 +289,7 @@ static int noise_impl(goofer_ctx *ctx, const goofer_batch *b, const float *f0s, 
                       float *frames_uv, float *frames_br, hipStream_t st)
 {
     const goofer_plan_t &p = ctx->plan;
-    static bool attr = false;
-    if (!attr) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_noise_frames<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    if (int arc = kernel_allow_max_lds(ctx, (const void *)k_noise_frames<M>)) return arc;
     unsigned blocks = (unsigned)((b->total_frames + FZ_FRAMES - 1) / FZ_FRAMES);
     hipLaunchKernelGGL(k_noise_frames<M>, dim3(blocks), dim3(256), fz_cfg<M>::lds_bytes, st, b->env, b->ld, b->phi, f0s, b->mask,
                        b->sample_off, b->frame_off, frame_note, row_src, b->params, b->seed, b->total_frames, frames_uv, frames_br,

@@ -587,11 +587,7 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
         lds = lds / 1024 * 1024;
         const size_t need = 4 * 2 * OC * sizeof(double);      // 32 KiB actually used
         if (lds < need) lds = need;
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        if (int arc = kernel_allow_max_lds(ctx, (const void *)k_pulse_onsets_scan)) return arc;
         hipLaunchKernelGGL(k_pulse_onsets_scan, dim3(blocks), dim3(256), lds, st, f0, (double)ctx->plan.sr, sample_off, n_notes,
                            onset_idx, onset_cnt, overflow);
         LAUNCH_CHECK(ctx);
@@ -840,11 +836,7 @@ int launch_subharm(goofer_ctx *ctx, const float *f0s, const float *mask, const i
             lds = lds / 1024 * 1024;
             const size_t need = 4 * 2 * OC * sizeof(double) + 4 * WAVE * sizeof(int32_t);
             if (lds < need) lds = need;
-            static bool attr_set = false;
-            if (!attr_set) {
-                HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_pulse_onsets_wrap, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set = true;
-            }
+            if (int arc = kernel_allow_max_lds(ctx, (const void *)k_pulse_onsets_wrap)) return arc;
             hipLaunchKernelGGL(k_pulse_onsets_wrap, dim3(blocks), dim3(256), lds, st, inc, sample_off, n_notes, onset_idx, onset_cnt,
                                overflow, note_on);
             LAUNCH_CHECK(ctx);

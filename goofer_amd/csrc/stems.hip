@@ -1,0 +1,898 @@
+// Stem-split frame walkers of goofer_synth_batch for the reference's own geometry, hop == n_fft / 4 (gfx950).
+//
+// The one-kernel-per-reference-step pipeline keeps three [frames x bins] complex spectra in HBM between the framewise
+// rFFT, the shaping kernels and the inverse transforms (33 KB per frame, 7 GB per 1024-note step).  Here a wave walks a
+// run of consecutive frames and carries each frame from its inputs to finished samples:
+//
+//   k_noise_stems  sigma-1.75 blur of the envelope row -> random-phase spectra (unvoiced, breath) -> high-pass /
+//                  brightness / 5-tap blur -> 2 x irfft -> overlap-add -> stem gains      GOOFER.py:993, 1148-1183
+//   k_harm_stem    stft(pulse) -> high-pass -> per-note max -> envelope warps, * env * boost, brightness + blur
+//                  -> irfft -> overlap-add                                   GOOFER.py:1099-1146 (+ :840-875, 618-627)
+//   k_note_finish  harm / max|S|, per-note peak, gain, reconstruct, V/B/U mix    GOOFER.py:1121, 1208-1218,
+//                                                                                  SillySampler.py:1142-1151
+//
+// No spectrum and no windowed frame ever reaches HBM: per frame the walkers read one envelope row each and the pulse
+// samples, and write the three stems (12 KB per frame instead of ~62 KB).  The noise walker needs nothing from the
+// pulse chain, so it runs beside the latency-bound phase walk.
+//
+// Overlap-add in registers: with hop = n_fft / 4 a frame is R = n_fft / 128 groups of 64 sample pairs, lane l holding
+// pair l of every group, and frame t's group r lands on absolute group r + (R/4) t — the same lane for every frame.
+// The running sums of the R - R/4 groups still open therefore live in that lane's registers (no LDS ring); after frame t
+// its first R/4 groups are complete and leave as 8-byte stores.  Every output sample receives its covering frames in
+// ascending frame order, the reference's fp32 order (GOOFER.py:379-385), and every product / sum / quotient is the one
+// the separate kernels compute, so the results are bit-identical to that path (tested).
+#include "binops_core.h"
+#include "fft_core.h"
+#include "samples_core.h"
+
+typedef float2 __attribute__((aligned(4))) float2_u;   // stems start at arbitrary sample offsets: pair stores are 4-byte aligned
+
+struct stem_taps {
+    float t5[5];               // sigma = 0.5 taps of the brightness blur (GOOFER.py:1143), fp32
+    float t175[15];            // sigma = 1.75 taps of the noise-envelope blur (GOOFER.py:993), fp32
+};
+
+template <int M> struct stem_cfg {
+    static constexpr int R = M / 64;           // sample pairs (and FFT points) per lane
+    static constexpr int G = R / 4;            // 64-pair groups per hop
+    static constexpr int NF = 2 * M;
+    static constexpr int HOP = M / 2;
+    static constexpr int B = M + 1;
+    static constexpr int PER = R + 1;          // bins per lane: k = lane + 64 i; i == R is the Nyquist bin (lane 0 only)
+    static constexpr int ROWF = (B + 3) & ~3;  // floats of a staged fp32 row / bin table
+    static constexpr int ROWC = (B + 1) & ~1;  // float2 slots of a staged complex row
+    static constexpr int KN = HOP / MASK_DS + KNOT_MARGIN;
+    static constexpr int KPL = (KN + WAVE - 1) / WAVE;
+    static constexpr int NTAB = 3;             // per-bin tables staged per workgroup (frequencies, boost / brightness curves)
+    // per-wave LDS: the FFT exchange buffer (also the staged envelope rows and the complex row of the 5-tap blur, one after
+    // the other), a second complex row (the unvoiced spectrum waits there while the breath stem is transformed), the mask
+    // knots of a hop, the warp's segment table
+    static constexpr size_t wave_bytes = sizeof(float2) * (fft_cfg<M>::BUF + ROWC) + sizeof(double) * (KN + WARP_SEG_DOUBLES);
+    static constexpr size_t table_bytes = sizeof(float2) * (M + M / 2 + 2 + M) + sizeof(float) * (NF + NTAB * ROWF);
+    static constexpr size_t lds_bytes = table_bytes + WAVES_PER_BLOCK * wave_bytes;
+    static_assert(table_bytes % 16 == 0 && wave_bytes % 16 == 0, "16-byte aligned LDS carving");
+};
+
+// cmul(conj(a), b) in two packed instructions (see cmul in fft_core.h): the conjugation is a neg modifier
+__device__ __forceinline__ float2 cmul_conj(float2 a, float2 b)
+{
+    v2f_t va = {a.x, a.y}, vb = {b.x, b.y}, t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(va), "v"(vb));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(va), "v"(vb), "v"(t));
+    return make_float2(r.x, r.y);
+}
+
+// blur5 (binops_core.h) with the taps already rounded to fp32: the same five FMAs
+__device__ __forceinline__ float2 blur5f(const float2 *r, int k, int n_bins, const float (&t)[5])
+{
+    float2 v0, v1, v2, v3, v4;
+    if (k >= 2 && k + 2 < n_bins) {
+        v0 = r[k - 2]; v1 = r[k - 1]; v2 = r[k]; v3 = r[k + 1]; v4 = r[k + 2];
+    } else {
+        auto at = [&](int q) { return r[q < 0 ? -q : (q >= n_bins ? 2 * (n_bins - 1) - q : q)]; };
+        v0 = at(k - 2); v1 = at(k - 1); v2 = at(k); v3 = at(k + 1); v4 = at(k + 2);
+    }
+    float re = t[0] * v0.x, im = t[0] * v0.y;
+    re = fmaf(t[1], v1.x, re); im = fmaf(t[1], v1.y, im);
+    re = fmaf(t[2], v2.x, re); im = fmaf(t[2], v2.y, im);
+    re = fmaf(t[3], v3.x, re); im = fmaf(t[3], v3.y, im);
+    re = fmaf(t[4], v4.x, re); im = fmaf(t[4], v4.y, im);
+    return make_float2(re, im);
+}
+
+// Shared state of a walker wave: tables, per-lane constants, the note it is in.
+template <int M> struct walker {
+    using C = stem_cfg<M>;
+    static constexpr int R = C::R, G = C::G, NF = C::NF, HOP = C::HOP, B = C::B;
+    float2 *tw, *twh, *buf, *row2, *wsc;
+    float *win, *tab;
+    double *kbuf, *seg;
+    int lane;
+    float2 tw1_r[7], tw2_r[7];                 // radix-8 pass twiddles of this lane
+    float2 wc_r[R];                            // conj-trick twiddle of bin k = lane + 64 r
+    float ws_c[G][2], rws_c[G][2];             // summed squared window of this lane's hop samples (interior hops) and 1 / it
+    // note state (wave-uniform)
+    int note = -1, n = 0, T = 0, out_len = 0;
+    int64_t base = 0, fbase = 0;
+
+    __device__ __forceinline__ void init(unsigned char *smem, const float2 *g_tw, const float2 *g_twh, const float *g_win,
+                                         const float *t0, const float *t1, const float *t2)
+    {
+        tw = reinterpret_cast<float2 *>(smem);
+        twh = tw + M;
+        wsc = twh + (M / 2 + 2);
+        win = reinterpret_cast<float *>(wsc + M);
+        tab = win + NF;
+        for (int i = threadIdx.x; i < C::ROWF; i += blockDim.x) {
+            const int k = i < B ? i : B - 1;
+            tab[i] = t0[k];
+            tab[C::ROWF + i] = t1[k];
+            tab[2 * C::ROWF + i] = t2 ? t2[k] : 0.f;
+        }
+        {
+            // synthesis window of sample pair m with the transform's 1/M and the input stage's 1/2 folded in:
+            // (z / M) * w == z * (w / M) exactly (M is a power of two), and the conjugate's sign rides along
+            const float inv_m = 0.5f / (float)M;
+            for (int m = threadIdx.x; m < M; m += blockDim.x) wsc[m] = make_float2(g_win[2 * m] * inv_m, -(g_win[2 * m + 1] * inv_m));
+        }
+        load_tables<M>(tw, twh, win, g_tw, g_twh, g_win);      // ends with the block barrier
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        lane = threadIdx.x & 63;
+        unsigned char *per = smem + C::table_bytes + (size_t)wave * C::wave_bytes;
+        buf = reinterpret_cast<float2 *>(per);
+        row2 = buf + fft_cfg<M>::BUF;
+        kbuf = reinterpret_cast<double *>(row2 + C::ROWC);
+        seg = kbuf + C::KN;
+        fft_lane_twiddles<M>(tw, lane, tw1_r, tw2_r);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int k = lane + WAVE * r;
+            wc_r[r] = (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int j = 2 * (lane + WAVE * g) + c;
+                float ws = 0.f;
+                for (int q = (NF - 1 - j) / HOP; q >= 0; --q) {       // ascending frame order = descending offset
+                    const float w = win[j + q * HOP];
+                    ws += w * w;
+                }
+                ws_c[g][c] = ws;
+                rws_c[g][c] = 1.0f / ws;
+            }
+    }
+
+    // run of frames [f0, f1) of this wave; fs = first frame to transform (the halo in front of a run that starts inside a note)
+    __device__ __forceinline__ bool range(int64_t total_frames, int run, const int *frame_note, const int64_t *frame_off, int64_t &fs,
+                                          int64_t &f0, int64_t &f1)
+    {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        f0 = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + wave) * run;
+        if (f0 >= total_frames) return false;
+        f1 = f0 + run < total_frames ? f0 + run : total_frames;
+        const int64_t t0 = f0 - frame_off[frame_note[f0]];
+        constexpr int halo = NF / HOP - 1;
+        fs = f0 - (t0 < halo ? t0 : halo);
+        return true;
+    }
+
+    __device__ __forceinline__ void enter_note(int nt, const int64_t *frame_off, const int64_t *sample_off)
+    {
+        note = nt;
+        base = sample_off[nt];
+        n = (int)(sample_off[nt + 1] - base);
+        fbase = frame_off[nt];
+        T = (int)(frame_off[nt + 1] - fbase);
+        out_len = HOP * (T - 1);
+    }
+
+    // irFFT of a spectrum X[0..M] given this lane's bins x[r] = X[lane + 64 r] and their mirrors xm[r] = X[M - lane - 64 r],
+    // windowed and overlap-added into `carry`; out[g] = the finished groups of hop t.  `buf` must be free.
+    __device__ __forceinline__ void inverse_ola(const float2 (&x)[R], const float2 (&xm)[R], int t, float2 (&carry)[R - G],
+                                                float2 (&out)[G])
+    {
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float2 xk = x[r], xq = xm[r];
+            if (lane + WAVE * r == 0) { xk.y = 0.f; xq.y = 0.f; }     // irfft ignores Im of DC and Nyquist
+            v[r] = irfft_pre(xk, xq, wc_r[r]);
+        }
+        float2 z[R];
+        wave_fft_keep_tw<M>(v, buf, tw1_r, tw2_r, lane, z);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float2 wn = wsc[lane + WAVE * r];
+            const float a = z[r].x * wn.x, b = z[r].y * wn.y;
+            float2 s;
+            if (r < R - G && t != 0) s = make_float2(carry[r].x + a, carry[r].y + b);
+            else s = make_float2(a, b);                              // first contribution: y starts from zero
+            if (r < G) out[r] = s;
+            else carry[r - G] = s;                                   // slot r - G was consumed G steps ago
+        }
+    }
+
+    // the same from registers: the complex row goes through `buf` for the mirrored bins (x[R]: the Nyquist bin, lane 0)
+    __device__ __forceinline__ void inverse_ola_regs(const float2 (&x)[C::PER], int t, float2 (&carry)[R - G], float2 (&out)[G])
+    {
+#pragma unroll
+        for (int i = 0; i < R; ++i) buf[lane + WAVE * i] = x[i];
+        if (lane == 0) buf[M] = x[R];
+        wave_lds_sync();
+        float2 xk[R], xm[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            xk[r] = x[r];
+            xm[r] = buf[M - (lane + WAVE * r)];
+        }
+        wave_lds_sync();                                             // (compiler fence) the row is read before the transform reuses buf
+        inverse_ola(xk, xm, t, carry, out);
+    }
+
+    // and from a complex row already in LDS
+    __device__ __forceinline__ void inverse_ola_row(const float2 *row, int t, float2 (&carry)[R - G], float2 (&out)[G])
+    {
+        float2 xk[R], xm[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            xk[r] = row[lane + WAVE * r];
+            xm[r] = row[M - (lane + WAVE * r)];
+        }
+        wave_lds_sync();
+        inverse_ola(xk, xm, t, carry, out);
+    }
+
+    // overlap-add quotient of sample (g, c) of hop h: the per-lane constant for interior hops, the partial window sum at
+    // the ends of a note (GOOFER.py:385-389)
+    __device__ __forceinline__ float norm(float x, int h, int g, int c) const
+    {
+        constexpr int max_back = (NF - 1) / HOP;
+        if (h >= max_back && h <= T - 1) {
+            const float ws = ws_c[g][c];
+            return ws > 1e-9f ? div_by(x, ws, rws_c[g][c]) : x;
+        }
+        const int j = 2 * (lane + WAVE * g) + c;
+        const int back = (NF - 1 - j) / HOP;
+        const int flo = h - back < 0 ? 0 : h - back, fhi = h > T - 1 ? T - 1 : h;
+        float ws = 0.f;
+        for (int fr = flo; fr <= fhi; ++fr) {
+            const float w = win[j + (h - fr) * HOP];
+            ws += w * w;
+        }
+        return ws > 1e-9f ? x / ws : x;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict__ env, int ld, const int64_t *__restrict__ row_src,
+                                                        const float *__restrict__ phi, int64_t total_frames,
+                                                        const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
+                                                        const int64_t *__restrict__ sample_off, const float2 *__restrict__ picks,
+                                                        const goofer_note_params *__restrict__ params, uint64_t seed,
+                                                        const float *__restrict__ freqs, const float *__restrict__ bright,
+                                                        const stem_taps taps, int do_blur,
+                                                        const double *__restrict__ short_s, const double *__restrict__ steps,
+                                                        float *__restrict__ uv, float *__restrict__ bre, int run,
+                                                        const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twh,
+                                                        const float *__restrict__ g_win)
+{
+    using C = stem_cfg<M>;
+    constexpr int R = C::R, G = C::G, HOP = C::HOP, B = C::B, PER = C::PER, KN = C::KN, KPL = C::KPL, ROWF = C::ROWF;
+    static_assert(R == 8, "the row staging below moves two 16-byte pieces per lane");
+    extern __shared__ __align__(16) unsigned char smem[];
+    walker<M> w;
+    w.init(smem, g_tw, g_twh, g_win, freqs, bright, nullptr);
+    const int lane = w.lane;
+    const float *t_fq = w.tab, *t_br = w.tab + ROWF;
+    int64_t fs, f0, f1;
+    if (!w.range(total_frames, run, frame_note, frame_off, fs, f0, f1)) return;   // no block barrier below
+
+    // the next frame's envelope row is in flight while the current one is transformed: bins 8 lane .. 8 lane + 7 as two
+    // 16-byte loads, the Nyquist bin beside them
+    float4 ea, eb4;
+    float e_ny;
+    auto fetch = [&](int64_t f) {
+        const float *er = env + row_src[f] * (int64_t)ld;
+        ea = *reinterpret_cast<const float4 *>(er + 8 * lane);
+        eb4 = *reinterpret_cast<const float4 *>(er + 8 * lane + 4);
+        e_ny = er[B - 1];
+    };
+    fetch(fs);
+
+    float2 carry_u[R - G], carry_b[R - G];
+#pragma unroll
+    for (int r = 0; r < R - G; ++r) carry_u[r] = carry_b[r] = make_float2(0.f, 0.f);
+
+    // note scalars of the output stage
+    int ns = 0;
+    float g_b = 0.f, g_u = 0.f, kps = 0.f;
+    double step_n = 0.0, step_s = 0.0;
+    const double *ss = nullptr;
+    uint64_t key = 0;
+    int apply_bright = 0;
+
+    // The smoothed-mask knots a hop needs are fetched lane-parallel a frame ahead and parked in LDS, so the output stage
+    // reads them with LDS latency instead of issuing dependent global loads per sample.
+    double kn_r[KPL];
+    int kn_lo = 0;
+    auto knots_fetch = [&](int h) {
+        int i0 = h * HOP - M;
+        i0 = i0 < 0 ? 0 : i0;
+        int lo = (int)((float)i0 * kps) - 4;
+        lo = lo < 0 ? 0 : lo;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const int e = lane + WAVE * c;
+            const int k = lo + e < ns - 1 ? lo + e : ns - 1;
+            kn_r[c] = (e < KN && ns > 0) ? ss[k] : 0.0;
+        }
+        kn_lo = lo;
+    };
+    auto knots_park = [&]() {
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const int e = lane + WAVE * c;
+            if (e < KN) w.kbuf[e] = kn_r[c];
+        }
+        wave_lds_sync();
+    };
+    // finished hop h -> window-sum quotient -> mask upsample -> stem gains -> out (GOOFER.py:385-389, 1179-1183)
+    auto emit = [&](int h, const float2 (&eu)[G], const float2 (&eb)[G]) {
+        const int p0 = h * HOP - M;
+        const int e_hi = KN - 1, lo = kn_lo;
+        auto knot = [&](int k) {
+            const int e = k - lo;
+            return w.kbuf[e < e_hi ? e : e_hi];
+        };
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i0 = p0 + 2 * (lane + WAVE * g);
+            if (i0 < 0 || i0 >= w.n) continue;
+            float xu[2] = {eu[g].x, eu[g].y}, xb[2] = {eb[g].x, eb[g].y};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int i = i0 + c;
+                if (i < w.out_len) {
+                    xu[c] = w.norm(xu[c], h, g, c);
+                    xb[c] = w.norm(xb[c], h, g, c);
+                } else {
+                    xu[c] = 0.f;                                     // zero tail of istft (GOOFER.py:409-412)
+                    xb[c] = 0.f;
+                }
+                const float ms = smooth_mask_at32(knot, ns, i < w.n ? i : w.n - 1, w.n, step_n, step_s, kps);
+                xb[c] = (xb[c] * ms) * g_b;
+                xu[c] = (xu[c] * (1.0f - ms)) * g_u;
+            }
+            if (i0 + 1 < w.n) {
+                *reinterpret_cast<float2_u *>(uv + w.base + i0) = make_float2(xu[0], xu[1]);
+                *reinterpret_cast<float2_u *>(bre + w.base + i0) = make_float2(xb[0], xb[1]);
+            } else {
+                uv[w.base + i0] = xu[0];
+                bre[w.base + i0] = xb[0];
+            }
+        }
+    };
+
+    float *rp = reinterpret_cast<float *>(w.buf);             // staged fp32 rows (dead before the spectra use buf)
+    for (int64_t f = fs; f < f1; ++f) {
+        const int nt = frame_note[f];
+        if (nt != w.note) {
+            w.enter_note(nt, frame_off, sample_off);
+            const goofer_note_params &p = params[nt];
+            ns = (w.n + MASK_DS - 1) / MASK_DS;
+            g_b = p.breath_strength;
+            g_u = p.uv_strength;
+            step_n = steps[2 * nt];
+            step_s = steps[2 * nt + 1];
+            kps = w.n > 1 ? (float)(ns - 1) / (float)(w.n - 1) : 0.f;
+            ss = short_s + short_base(sample_off, nt);
+            key = seed ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
+            apply_bright = p.apply_brightness;
+        }
+        const int t = (int)(f - w.fbase);
+        const float2 pv = picks[f];                           // (f0, mask) of the frame: x[::hop] edge-padded (GOOFER.py:1104-1106)
+        const float f0f = pv.x;
+        const bool voiced = apply_bright && pv.y > 0.f;
+        if (f >= f0) knots_fetch(t);                          // lands during the two transforms below
+
+        // 1. noise envelope: sigma-1.75 blur of the un-warped row (GOOFER.py:993), fp32 FMAs in tap order.  A lane blurs its
+        //    eight consecutive bins from a 24-value window (its own eight, eight on either side from LDS), lane 63 also the
+        //    Nyquist bin; the blurred row then goes through LDS once more into the transform's layout k = lane + 64 i.
+        float ec[8] = {ea.x, ea.y, ea.z, ea.w, eb4.x, eb4.y, eb4.z, eb4.w};
+        float o9[9];
+        if (do_blur) {
+            *reinterpret_cast<float4 *>(rp + 8 + 8 * lane) = ea;
+            *reinterpret_cast<float4 *>(rp + 8 + 8 * lane + 4) = eb4;
+            wave_lds_sync();
+            float x[24];
+            {
+                const float4 l0 = *reinterpret_cast<const float4 *>(rp + 8 * lane), l1 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 4);
+                const float4 r0 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 16), r1 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 20);
+                x[0] = l0.x; x[1] = l0.y; x[2] = l0.z; x[3] = l0.w; x[4] = l1.x; x[5] = l1.y; x[6] = l1.z; x[7] = l1.w;
+                x[16] = r0.x; x[17] = r0.y; x[18] = r0.z; x[19] = r0.w; x[20] = r1.x; x[21] = r1.y; x[22] = r1.z; x[23] = r1.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[8 + j] = ec[j];
+            // numpy 'reflect' at the two ends of the row: bins -1..-7 are bins 1..7, bins 513..519 are bins 511..505
+#pragma unroll
+            for (int j = 1; j < 8; ++j) {
+                x[8 - j] = lane == 0 ? ec[j] : x[8 - j];
+                x[16 + j] = lane == 63 ? ec[8 - j] : x[16 + j];
+            }
+            x[16] = lane == 63 ? e_ny : x[16];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                float acc = taps.t175[0] * x[j + 1];
+#pragma unroll
+                for (int q = 1; q < 15; ++q) acc = fmaf(taps.t175[q], x[j + 1 + q], acc);
+                o9[j] = acc;
+            }
+            wave_lds_sync();
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o9[j] = ec[j];
+            o9[8] = e_ny;
+        }
+        *reinterpret_cast<float4 *>(rp + 8 * lane) = make_float4(o9[0], o9[1], o9[2], o9[3]);
+        *reinterpret_cast<float4 *>(rp + 8 * lane + 4) = make_float4(o9[4], o9[5], o9[6], o9[7]);
+        if (lane == 63) rp[B - 1] = o9[8];
+        wave_lds_sync();
+        float en[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) en[i] = rp[lane + WAVE * i < B ? lane + WAVE * i : B - 1];
+        wave_lds_sync();                                      // row dead: buf is free
+        if (f + 1 < f1) fetch(f + 1);
+
+        // 2. U * env_n (unvoiced spectrum, parked in row2) and U * env_n * HP (* brightness) (breath spectrum)  GOOFER.py:1148-1173
+        float2 sb[PER];
+        uint4 rnd = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int k = lane + WAVE * i;
+            sb[i] = make_float2(0.f, 0.f);
+            if (k >= B) continue;
+            float c, s;
+            if (phi) {
+                const float ph = phi[f * (int64_t)ld + k];
+                c = cosf(ph);
+                s = sinf(ph);
+            } else {
+                // one Philox block feeds four bins of this lane (bins lane + 64 i, i = 4q..4q+3)
+                if ((i & 3) == 0) rnd = philox_4x32(key, (uint64_t)t, (uint32_t)(lane + WAVE * (i >> 2)));
+                const uint32_t u = (i & 3) == 0 ? rnd.x : ((i & 3) == 1 ? rnd.y : ((i & 3) == 2 ? rnd.z : rnd.w));
+                const float rev = (float)(u >> 8) * (1.0f / 16777216.0f);      // phase / 2 pi, uniform in [0, 1)
+                c = __builtin_amdgcn_cosf(rev);
+                s = __builtin_amdgcn_sinf(rev);
+            }
+            const float2 su = make_float2(c * en[i], s * en[i]);
+            w.row2[k] = su;
+            const float h = hp_mask(t_fq[k], f0f);
+            sb[i] = make_float2(su.x * h, su.y * h);
+            if (voiced) {
+                const float b = t_br[k];
+                sb[i].x *= b; sb[i].y *= b;
+            }
+        }
+        if (voiced) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = lane + WAVE * i;
+                if (k < B) w.buf[k] = sb[i];
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = lane + WAVE * i;
+                if (k < B) sb[i] = blur5f(w.buf, k, B, taps.t5);
+            }
+            wave_lds_sync();
+        }
+
+        // 3. inverse transforms + overlap-add
+        float2 ob[G], ou[G];
+        w.inverse_ola_regs(sb, t, carry_b, ob);
+        w.inverse_ola_row(w.row2, t, carry_u, ou);
+
+        if (f >= f0) {
+            // hop t; behind a note's last frame also the hop still open in the registers and the zero tail
+            knots_park();
+            emit(t, ou, ob);
+            if (t == w.T - 1) {
+                for (int h = t + 1; h * HOP - M < w.n; ++h) {
+                    knots_fetch(h);
+                    knots_park();
+                    float2 fu[G], fb[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) { fu[g] = carry_u[g]; fb[g] = carry_b[g]; }
+                    emit(h, fu, fb);                          // h == T: the sums in the registers; beyond: zeros (i >= out_len)
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ pulse, const float *__restrict__ env, int ld,
+                                                      const int64_t *__restrict__ row_src, const double *__restrict__ formants,
+                                                      int64_t total_frames, const int *__restrict__ frame_note,
+                                                      const int64_t *__restrict__ frame_off, const int64_t *__restrict__ sample_off,
+                                                      const float2 *__restrict__ picks, const goofer_note_params *__restrict__ params,
+                                                      const float *__restrict__ freqs, const float *__restrict__ boost,
+                                                      const float *__restrict__ bright, const stem_taps taps, double nyq,
+                                                      float *__restrict__ harm, float *__restrict__ note_mag, int run,
+                                                      const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twh,
+                                                      const float *__restrict__ g_win)
+{
+    using C = stem_cfg<M>;
+    constexpr int R = C::R, G = C::G, HOP = C::HOP, B = C::B, PER = C::PER, ROWF = C::ROWF;
+    static_assert(R == 8, "the row staging below moves two 16-byte pieces per lane");
+    extern __shared__ __align__(16) unsigned char smem[];
+    walker<M> w;
+    w.init(smem, g_tw, g_twh, g_win, freqs, boost, bright);
+    const int lane = w.lane;
+    const float *t_fq = w.tab, *t_bo = w.tab + ROWF, *t_br = w.tab + 2 * ROWF;
+    int64_t fs, f0, f1;
+    if (!w.range(total_frames, run, frame_note, frame_off, fs, f0, f1)) return;   // no block barrier below
+
+    // raw sample pairs (reflect-padded at the note ends, GOOFER.py:358-360) and the envelope row of the next frame are in
+    // flight while the current frame is transformed
+    float2 raw[R];
+    float4 ea, eb4;
+    float e_ny;
+    auto fetch = [&](int64_t f) {
+        const int nt = frame_note[f];
+        const int64_t nb = sample_off[nt];
+        const int64_t nn = sample_off[nt + 1] - nb;
+        const int64_t start = (f - frame_off[nt]) * HOP - M;       // first sample of the frame, un-padded coordinates
+        const float *xs = pulse + nb;
+        if (start >= 0 && start + 2 * M <= nn) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int m = lane + WAVE * r;
+                raw[r] = make_float2(xs[start + 2 * m], xs[start + 2 * m + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int m = lane + WAVE * r;
+                const float a = nn > 0 ? xs[reflect_index(start + 2 * m, nn)] : 0.f;
+                const float b = nn > 0 ? xs[reflect_index(start + 2 * m + 1, nn)] : 0.f;
+                raw[r] = make_float2(a, b);
+            }
+        }
+        const float *er = env + row_src[f] * (int64_t)ld;
+        ea = *reinterpret_cast<const float4 *>(er + 8 * lane);
+        eb4 = *reinterpret_cast<const float4 *>(er + 8 * lane + 4);
+        e_ny = er[B - 1];
+    };
+    fetch(fs);
+
+    float2 carry[R - G];
+#pragma unroll
+    for (int r = 0; r < R - G; ++r) carry[r] = make_float2(0.f, 0.f);
+
+    bool warp = false, any_warp = false;
+    int apply_bright = 0, cut_below = 0;
+    double fsh[4] = {1.0, 1.0, 1.0, 1.0}, ratio = 1.0;
+
+    auto emit = [&](int h, const float2 (&e)[G]) {
+        const int p0 = h * HOP - M;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i0 = p0 + 2 * (lane + WAVE * g);
+            if (i0 < 0 || i0 >= w.n) continue;
+            float x[2] = {e[g].x, e[g].y};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) x[c] = i0 + c < w.out_len ? w.norm(x[c], h, g, c) : 0.f;
+            if (i0 + 1 < w.n) *reinterpret_cast<float2_u *>(harm + w.base + i0) = make_float2(x[0], x[1]);
+            else harm[w.base + i0] = x[0];
+        }
+    };
+
+    float *ra = reinterpret_cast<float *>(w.buf), *rb = ra + ROWF;   // envelope rows of the warp (2 ROWF floats <= BUF float2)
+    static_assert(2 * ROWF <= 2 * fft_cfg<M>::BUF, "two fp32 rows fit the exchange buffer");
+    for (int64_t f = fs; f < f1; ++f) {
+        const int nt = frame_note[f];
+        if (nt != w.note) {
+            w.enter_note(nt, frame_off, sample_off);
+            const goofer_note_params &p = params[nt];
+            warp = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                fsh[k] = p.f_shift[k];
+                warp |= fsh[k] != 1.0;
+            }
+            ratio = (double)p.formant_shift;
+            any_warp = (warp && formants) || p.formant_shift != 1.0f;
+            apply_bright = p.apply_brightness;
+            cut_below = p.cut_below_f0;
+        }
+        const int t = (int)(f - w.fbase);
+        const float2 pv = picks[f];
+        const float f0f = pv.x;
+        const bool voiced = apply_bright && pv.y > 0.f;
+        const int64_t src = row_src[f];
+
+        // 1. windowed frame -> complex FFT; the lane's points Z[lane + 64 t] stay in registers
+        float2 z[R];
+        {
+            float2 v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int m = lane + WAVE * r;
+                const float2 wn = *reinterpret_cast<const float2 *>(w.win + 2 * m);
+                v[r] = make_float2(raw[r].x * wn.x, raw[r].y * wn.y);
+            }
+            wave_fft_keep_tw<M>(v, w.buf, w.tw1_r, w.tw2_r, lane, z);
+        }
+
+        // 2. even/odd split: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 e^{-i pi k/M} (Z[k] - conj Z[M-k]); mirrored points through LDS.
+        //    The spectrum waits in row2 while the envelope row is warped (the warp needs the registers).
+#pragma unroll
+        for (int r = 0; r < R; ++r) w.buf[lds_pad(lane + WAVE * r)] = z[r];
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int k = lane + WAVE * r;
+            const float2 zk = z[r], zm = w.buf[lds_pad((M - k) & (M - 1))];
+            const float2 A = make_float2(zk.x + zm.x, zk.y - zm.y);
+            const float2 Bv = make_float2(zk.x - zm.x, zk.y + zm.y);
+            const float2 Cv = cmul_conj(w.wc_r[r], Bv);               // the split twiddle is the conjugate of the inverse one
+            w.row2[k] = make_float2(0.5f * (A.x + Cv.y), 0.5f * (A.y - Cv.x));
+        }
+        if (lane == 0) w.row2[M] = make_float2(z[0].x - z[0].y, 0.f);   // Nyquist bin from Z[0]
+        wave_lds_sync();
+
+        // 3. harmonic envelope: formant-anchored + uniform warp of the source row (GOOFER.py:1004-1017), then into the
+        //    transform's layout k = lane + 64 i
+        *reinterpret_cast<float4 *>(ra + 8 * lane) = ea;
+        *reinterpret_cast<float4 *>(ra + 8 * lane + 4) = eb4;
+        if (lane == 63) ra[B - 1] = e_ny;
+        wave_lds_sync();
+        const float *eg = ra;
+        if (any_warp) eg = warp_row(ra, rb, B, nyq, formants ? formants + src * 4 : nullptr, fsh, warp, ratio, lane, w.seg);
+        float evc[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) evc[i] = eg[lane + WAVE * i < B ? lane + WAVE * i : B - 1];
+        wave_lds_sync();                                             // envelope rows dead: buf is free
+        if (f + 1 < f1) fetch(f + 1);
+        float2 X[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) X[i] = w.row2[lane + WAVE * i < B ? lane + WAVE * i : B - 1];
+
+        // 4. shaping (GOOFER.py:1102-1144); 1 / max(|S| + 1e-8) commutes with the linear chain and is applied by k_note_finish
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int k = lane + WAVE * i;
+            if (k >= B) { X[i] = make_float2(0.f, 0.f); continue; }
+            float2 s = X[i];
+            if (cut_below) {
+                const float h = hp_mask(t_fq[k], f0f);
+                s.x *= h; s.y *= h;
+            }
+            mx = fmaxf(mx, cabs_fast(s) + 1e-8f);
+            const float gch = evc[i], bo = t_bo[k];
+            s.x = (s.x * gch) * bo;
+            s.y = (s.y * gch) * bo;
+            if (voiced) {
+                const float b = t_br[k];
+                s.x *= b; s.y *= b;
+            }
+            X[i] = s;
+        }
+        mx = wave_max(mx);
+        if (lane == 0) atomic_max_pos(note_mag + w.note, mx);
+        if (voiced) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = lane + WAVE * i;
+                if (k < B) w.buf[k] = X[i];
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int k = lane + WAVE * i;
+                if (k < B) X[i] = blur5f(w.buf, k, B, taps.t5);
+            }
+            wave_lds_sync();
+        }
+
+        // 5. inverse transform + overlap-add; hop t leaves un-normalised by the note's spectrum maximum
+        float2 e[G];
+        w.inverse_ola_regs(X, t, carry, e);
+        if (f >= f0) {
+            emit(t, e);
+            if (t == w.T - 1) {
+                for (int h = t + 1; h * HOP - M < w.n; ++h) {
+                    float2 fl[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) fl[g] = carry[g];
+                    emit(h, fl);
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One workgroup per note, two passes over its three stems (the second pass is served from L2: a 1.1 s note is 0.6 MB):
+// harm / max|S|, peak of harm + uv + breath, then gain = (1 / peak)^normalize on everything (GOOFER.py:1121, 1208-1218)
+// and the V/B/U mix (SillySampler.py:1142-1151).  Same operations in the same order as k_irfft_ola3's output stage +
+// k_apply_gain.
+constexpr int FIN_THREADS = 1024;
+
+__global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__ harm, float *__restrict__ uv, float *__restrict__ bre,
+                                                             float *__restrict__ rec, float *__restrict__ mix,
+                                                             const int64_t *__restrict__ sample_off,
+                                                             const goofer_note_params *__restrict__ params,
+                                                             const float *__restrict__ note_mag, float *__restrict__ note_peak,
+                                                             int write_stems)
+{
+    __shared__ float s_red[FIN_THREADS / WAVE];
+    const int note = blockIdx.x;
+    const int64_t base = sample_off[note];
+    const int n = (int)(sample_off[note + 1] - base);
+    const float mag = note_mag[note], rmag = 1.0f / mag;
+    float *h_ = harm + base, *u_ = uv + base, *b_ = bre + base;
+    // 16-byte accesses on the aligned body [a0, a1) of the note; the ragged head and tail go sample by sample
+    int a0 = (int)((4 - (base & 3)) & 3);
+    if (a0 > n) a0 = n;
+    const int a1 = a0 + ((n - a0) & ~3);
+    const bool vec = ((((uintptr_t)harm | (uintptr_t)uv | (uintptr_t)bre | (uintptr_t)rec | (uintptr_t)mix) & 15) == 0);
+
+    float pk = 0.f;
+    if (vec) {
+        for (int i = a0 + 4 * (int)threadIdx.x; i < a1; i += 4 * FIN_THREADS) {
+            const float4 h = *reinterpret_cast<const float4 *>(h_ + i);
+            const float4 u = *reinterpret_cast<const float4 *>(u_ + i);
+            const float4 b = *reinterpret_cast<const float4 *>(b_ + i);
+            pk = fmaxf(pk, fabsf((div_by(h.x, mag, rmag) + u.x) + b.x));
+            pk = fmaxf(pk, fabsf((div_by(h.y, mag, rmag) + u.y) + b.y));
+            pk = fmaxf(pk, fabsf((div_by(h.z, mag, rmag) + u.z) + b.z));
+            pk = fmaxf(pk, fabsf((div_by(h.w, mag, rmag) + u.w) + b.w));
+        }
+    }
+    for (int i = (int)threadIdx.x; i < n; i += FIN_THREADS) {
+        if (vec && i >= a0 && i < a1) continue;
+        pk = fmaxf(pk, fabsf((div_by(h_[i], mag, rmag) + u_[i]) + b_[i]));
+    }
+    pk = wave_max(pk);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = pk;
+    __syncthreads();
+    float peak = 0.f;
+#pragma unroll
+    for (int q = 0; q < FIN_THREADS / WAVE; ++q) peak = fmaxf(peak, s_red[q]);
+    if (threadIdx.x == 0) note_peak[note] = peak;
+
+    const goofer_note_params &p = params[note];
+    const float pk12 = peak + 1e-12f;                                 // fp32 add, like np.float32 + 1e-12
+    const double amt = (double)fminf(fmaxf(p.normalize, 0.f), 1.f);
+    const float gain = (float)pow(1.0 / (double)pk12, amt);
+    const float m_h = p.mix_harm, m_b = p.mix_breath, m_u = p.mix_unvoiced, vol = p.volume;
+    auto one = [&](float h, float u, float b, float &ho, float &uo, float &bo, float &ro, float &mo) {
+        h = div_by(h, mag, rmag);
+        const float comb = (h + u) + b;
+        ho = h * gain; uo = u * gain; bo = b * gain;
+        ro = comb * gain;
+        mo = ((ho * m_h + bo * m_b) + uo * m_u) * vol;
+    };
+    if (vec) {
+        for (int i = a0 + 4 * (int)threadIdx.x; i < a1; i += 4 * FIN_THREADS) {
+            const float4 h = *reinterpret_cast<const float4 *>(h_ + i);
+            const float4 u = *reinterpret_cast<const float4 *>(u_ + i);
+            const float4 b = *reinterpret_cast<const float4 *>(b_ + i);
+            float4 ho, uo, bo, ro, mo;
+            one(h.x, u.x, b.x, ho.x, uo.x, bo.x, ro.x, mo.x);
+            one(h.y, u.y, b.y, ho.y, uo.y, bo.y, ro.y, mo.y);
+            one(h.z, u.z, b.z, ho.z, uo.z, bo.z, ro.z, mo.z);
+            one(h.w, u.w, b.w, ho.w, uo.w, bo.w, ro.w, mo.w);
+            if (write_stems) {
+                *reinterpret_cast<float4 *>(h_ + i) = ho;
+                *reinterpret_cast<float4 *>(u_ + i) = uo;
+                *reinterpret_cast<float4 *>(b_ + i) = bo;
+            }
+            if (rec) *reinterpret_cast<float4 *>(rec + base + i) = ro;
+            if (mix) *reinterpret_cast<float4 *>(mix + base + i) = mo;
+        }
+    }
+    for (int i = (int)threadIdx.x; i < n; i += FIN_THREADS) {
+        if (vec && i >= a0 && i < a1) continue;
+        float ho, uo, bo, ro, mo;
+        one(h_[i], u_[i], b_[i], ho, uo, bo, ro, mo);
+        if (write_stems) { h_[i] = ho; u_[i] = uo; b_[i] = bo; }
+        if (rec) rec[base + i] = ro;
+        if (mix) mix[base + i] = mo;
+    }
+}
+
+// per-frame picks of the per-sample arrays: x[::hop] edge-padded to the frame count (GOOFER.py:1104-1106)
+__global__ void k_frame_picks(const int64_t *__restrict__ frame_off, const int *__restrict__ frame_note, int64_t total_frames,
+                              const int64_t *__restrict__ sample_off, const float *__restrict__ f0, const float *__restrict__ mask,
+                              int hop, float2 *__restrict__ picks)
+{
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= total_frames) return;
+    const int note = frame_note[f];
+    const int64_t t = f - frame_off[note];
+    const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+    float2 pv = make_float2(0.f, 0.f);
+    if (n > 0) {
+        const int64_t at = pick_index(t, n, hop);
+        pv = make_float2(f0[base + at], mask[base + at]);
+    }
+    picks[f] = pv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Frames per wave.  A run replays `halo` frames it does not emit, so longer runs waste less; and every wave does the same
+// work, so the grid should fill the device a whole number of times: with k rounds of `slots` waves,
+// run = ceil(frames / (k slots)), k the smallest that keeps a run at or below 128 frames.
+static int run_length(int64_t total_frames, int slots)
+{
+    const int64_t rounds = (total_frames + (int64_t)slots * 128 - 1) / ((int64_t)slots * 128);
+    const int64_t fit = (total_frames + rounds * slots - 1) / (rounds * slots);
+    return (int)(fit > 32 ? fit : 32);
+}
+
+static stem_taps plan_taps(const goofer_plan_t &p)
+{
+    stem_taps t;
+    for (int j = 0; j < 5; ++j) t.t5[j] = p.taps5_f[j];
+    for (int j = 0; j < 15; ++j) t.t175[j] = p.taps175_f[j];
+    return t;
+}
+
+bool stems_supported(const goofer_plan_t &p) { return p.n_fft == 1024 && p.hop * 4 == p.n_fft; }
+
+int launch_frame_picks(goofer_ctx *ctx, const int64_t *frame_off, const int *frame_note, int64_t F, const int64_t *sample_off,
+                       const float *f0, const float *mask, float2 *picks, hipStream_t st)
+{
+    if (F <= 0) return GOOFER_OK;
+    hipLaunchKernelGGL(k_frame_picks, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, frame_off, frame_note, F, sample_off, f0, mask,
+                       ctx->plan.hop, picks);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+int launch_noise_stems(goofer_ctx *ctx, const float *env, int ld, const int64_t *row_src, const float *phi, int64_t F,
+                       const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, const float2 *picks,
+                       const goofer_note_params *params, uint64_t seed, bool preblurred, const double *short_s, const double *steps,
+                       float *uv, float *bre, hipStream_t st)
+{
+    if (F <= 0) return GOOFER_OK;
+    const goofer_plan_t &p = ctx->plan;
+    if (!stems_supported(p)) return goofer_fail(ctx, GOOFER_EINVAL, "the stem walkers need n_fft 1024 and hop == n_fft / 4");
+    constexpr int M = 512;
+    const void *fn = (const void *)k_noise_stems<M>;
+    const size_t lds = stem_cfg<M>::lds_bytes;
+    int rc, slots = 0;
+    if ((rc = kernel_allow_max_lds(ctx, fn))) return rc;
+    if ((rc = kernel_resident_waves(ctx, fn, lds, &slots))) return rc;
+    const int run = run_length(F, slots);
+    const int64_t runs = (F + run - 1) / run;
+    hipLaunchKernelGGL(k_noise_stems<M>, dim3((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), dim3(256), lds, st, env, ld,
+                       row_src, phi, F, frame_note, frame_off, sample_off, picks, params, seed, p.freqs, p.bright_b, plan_taps(p),
+                       preblurred ? 0 : 1, short_s, steps, uv, bre, run, p.tw_full, p.tw_half, p.window);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+int launch_harm_stem(goofer_ctx *ctx, const float *pulse, const float *env, int ld, const int64_t *row_src, const double *formants,
+                     int64_t F, const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, const float2 *picks,
+                     const goofer_note_params *params, float *harm, float *note_mag, hipStream_t st)
+{
+    if (F <= 0) return GOOFER_OK;
+    const goofer_plan_t &p = ctx->plan;
+    if (!stems_supported(p)) return goofer_fail(ctx, GOOFER_EINVAL, "the stem walkers need n_fft 1024 and hop == n_fft / 4");
+    constexpr int M = 512;
+    const void *fn = (const void *)k_harm_stem<M>;
+    const size_t lds = stem_cfg<M>::lds_bytes;
+    int rc, slots = 0;
+    if ((rc = kernel_allow_max_lds(ctx, fn))) return rc;
+    if ((rc = kernel_resident_waves(ctx, fn, lds, &slots))) return rc;
+    const int run = run_length(F, slots);
+    const int64_t runs = (F + run - 1) / run;
+    hipLaunchKernelGGL(k_harm_stem<M>, dim3((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), dim3(256), lds, st, pulse, env, ld,
+                       row_src, formants, F, frame_note, frame_off, sample_off, picks, params, p.freqs, p.boost, p.bright_h, plan_taps(p),
+                       (double)p.sr / 2.0, harm, note_mag, run, p.tw_full, p.tw_half, p.window);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+int launch_note_finish(goofer_ctx *ctx, float *harm, float *uv, float *bre, float *rec, float *mix, const int64_t *sample_off,
+                       int n_notes, const goofer_note_params *params, const float *note_mag, float *note_peak, bool write_stems,
+                       hipStream_t st)
+{
+    if (n_notes <= 0) return GOOFER_OK;
+    hipLaunchKernelGGL(k_note_finish, dim3((unsigned)n_notes), dim3(FIN_THREADS), 0, st, harm, uv, bre, rec, mix, sample_off, params,
+                       note_mag, note_peak, write_stems ? 1 : 0);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
