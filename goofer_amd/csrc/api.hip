@@ -94,8 +94,8 @@ int launch_frame_picks(goofer_ctx *, const int64_t *, const int *, int64_t, cons
 int launch_noise_stems(goofer_ctx *, const float *, int, const int64_t *, const float *, int64_t, const int *, const int64_t *,
                        const int64_t *, const float2 *, const goofer_note_params *, uint64_t, bool, const double *, const double *, float *,
                        float *, hipStream_t);
-int launch_harm_stem(goofer_ctx *, const float *, const float *, int, const int64_t *, const double *, int64_t, const int *,
-                     const int64_t *, const int64_t *, const float2 *, const goofer_note_params *, float *, float *, hipStream_t);
+int launch_harm_stem(goofer_ctx *, const float *, const float *, int, const int64_t *, int64_t, const int *, const int64_t *,
+                     const int64_t *, const float2 *, const goofer_note_params *, float *, float *, hipStream_t);
 int launch_note_finish(goofer_ctx *, float *, float *, float *, float *, float *, const int64_t *, int, const goofer_note_params *,
                        const float *, float *, bool, hipStream_t);
 
@@ -1201,6 +1201,11 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                                      b->bre, st)))
             return r2;
         if (side_on) MARK_Q(1);
+        // harmonic envelope rows for the harmonic walker: formant-anchored + uniform warp, one wave per row (GOOFER.py:1004-1017).
+        // Here, beside the pulse chain, rather than inside the walker: the crossing-anchor path is several times slower than
+        // the sorted one, and a walker wave holds ~95 frames of ONE note (the slow notes would set the kernel's time).
+        if ((r2 = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, st)))
+            return r2;
         return GOOFER_OK;
     };
     // The pulse walk is one latency-bound wave per SIMD: it goes to a side stream FIRST (so its workgroups are resident
@@ -1284,11 +1289,13 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                                          b->sample_off, picks, b->params, b->seed, b->env_noise != nullptr, short_s, note_steps, b->uv,
                                          b->bre, st)))
                 return rc;
+            if ((rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, st)))
+                return rc;
         }
         MARK();   // 8
         MARK();   // 9: harm_stem = rFFT + shaping + irFFT + overlap-add of the harmonic stem
-        if ((rc = launch_harm_stem(ctx, pulse, b->env, ld, row_src, b->formants, F, frame_note, b->frame_off, b->sample_off, picks,
-                                   b->params, b->harm, note_mag, st)))
+        if ((rc = launch_harm_stem(ctx, pulse, env_h, ld, nullptr, F, frame_note, b->frame_off, b->sample_off, picks, b->params, b->harm,
+                                   note_mag, st)))
             return rc;
         MARK();   // 10..12
         MARK();

@@ -40,17 +40,17 @@ template <int M> struct stem_cfg {
     static constexpr int B = M + 1;
     static constexpr int PER = R + 1;          // bins per lane: k = lane + 64 i; i == R is the Nyquist bin (lane 0 only)
     static constexpr int ROWF = (B + 3) & ~3;  // floats of a staged fp32 row / bin table
-    static constexpr int ROWC = (B + 1) & ~1;  // float2 slots of a staged complex row
     static constexpr int KN = HOP / MASK_DS + KNOT_MARGIN;
     static constexpr int KPL = (KN + WAVE - 1) / WAVE;
-    static constexpr int NTAB = 3;             // per-bin tables staged per workgroup (frequencies, boost / brightness curves)
-    // per-wave LDS: the FFT exchange buffer (also the staged envelope rows and the complex row of the 5-tap blur, one after
-    // the other), a second complex row (the unvoiced spectrum waits there while the breath stem is transformed), the mask
-    // knots of a hop, the warp's segment table
-    static constexpr size_t wave_bytes = sizeof(float2) * (fft_cfg<M>::BUF + ROWC) + sizeof(double) * (KN + WARP_SEG_DOUBLES);
-    static constexpr size_t table_bytes = sizeof(float2) * (M + M / 2 + 2 + M) + sizeof(float) * (NF + NTAB * ROWF);
-    static constexpr size_t lds_bytes = table_bytes + WAVES_PER_BLOCK * wave_bytes;
-    static_assert(table_bytes % 16 == 0 && wave_bytes % 16 == 0, "16-byte aligned LDS carving");
+    // Workgroup tables: FFT twiddles, conj-trick twiddles per bin, scaled synthesis window per sample pair, NTAB per-bin
+    // curves, and (WIN) the plain window.  Per wave: the FFT exchange buffer — which also stages the envelope row, the
+    // complex row of the 5-tap blur and the mirrored-bin exchange, one after the other — and the mask knots of a hop.
+    // Sized so that four workgroups share a CU (4 waves per SIMD): a walker is a latency-bound chain of LDS exchanges and
+    // needs the waves more than it needs registers.
+    static constexpr size_t wave_bytes = sizeof(float2) * fft_cfg<M>::BUF + sizeof(double) * KN;
+    template <int NTAB, bool WIN> static constexpr size_t table_bytes() { return sizeof(float2) * 3 * M + sizeof(float) * (NTAB * ROWF + (WIN ? NF : 0)); }
+    template <int NTAB, bool WIN> static constexpr size_t lds_bytes() { return table_bytes<NTAB, WIN>() + WAVES_PER_BLOCK * wave_bytes; }
+    static_assert(wave_bytes % 16 == 0, "16-byte aligned LDS carving");
 };
 
 // cmul(conj(a), b) in two packed instructions (see cmul in fft_core.h): the conjugation is a neg modifier
@@ -80,55 +80,85 @@ __device__ __forceinline__ float2 blur5f(const float2 *r, int k, int n_bins, con
     return make_float2(re, im);
 }
 
+// Per-frame records of 64 consecutive frames, one frame per lane: which note, where in it, which envelope row, the frame's
+// picks of f0 and the voicing mask.  A wave reads the record of its current frame with v_readlane — no memory access and
+// no chain of dependent scalar loads per frame (frame -> note -> offsets); the block is refilled every 64 frames.
+struct frame_block {
+    int note, t, T, n, src, base_lo, base_hi;
+    float f0, mk;
+    int64_t blk0;
+
+    __device__ __forceinline__ void load(int64_t first, int64_t total_frames, const int *__restrict__ frame_note,
+                                         const int64_t *__restrict__ frame_off, const int64_t *__restrict__ sample_off,
+                                         const int64_t *__restrict__ row_src, const float2 *__restrict__ picks, int lane)
+    {
+        blk0 = first;
+        int64_t f = first + lane;
+        f = f < total_frames ? f : total_frames - 1;
+        note = frame_note[f];
+        const int64_t fo = frame_off[note], so = sample_off[note];
+        t = (int)(f - fo);
+        T = (int)(frame_off[note + 1] - fo);
+        n = (int)(sample_off[note + 1] - so);
+        base_lo = (int)(uint32_t)so;
+        base_hi = (int)(so >> 32);
+        src = row_src ? (int)row_src[f] : (int)f;
+        const float2 pv = picks[f];                           // x[::hop] edge-padded to the frame count (GOOFER.py:1104-1106)
+        f0 = pv.x;
+        mk = pv.y;
+    }
+    __device__ __forceinline__ bool holds(int64_t f) const { return f >= blk0 && f < blk0 + WAVE; }
+};
+#define FB_GET(fb, field, idx) __builtin_amdgcn_readlane((fb).field, (idx))
+#define FB_GETF(fb, field, idx) __int_as_float(__builtin_amdgcn_readlane(__float_as_int((fb).field), (idx)))
+#define FB_BASE(fb, idx) ((int64_t)(((uint64_t)(uint32_t)FB_GET(fb, base_hi, idx) << 32) | (uint32_t)FB_GET(fb, base_lo, idx)))
+
 // Shared state of a walker wave: tables, per-lane constants, the note it is in.
-template <int M> struct walker {
+template <int M, int NTAB, bool WIN> struct walker {
     using C = stem_cfg<M>;
     static constexpr int R = C::R, G = C::G, NF = C::NF, HOP = C::HOP, B = C::B;
-    float2 *tw, *twh, *buf, *row2, *wsc;
+    float2 *tw, *wct, *wsc, *buf;
     float *win, *tab;
-    double *kbuf, *seg;
+    const float *g_win;
+    double *kbuf;
     int lane;
-    float2 tw1_r[7], tw2_r[7];                 // radix-8 pass twiddles of this lane
-    float2 wc_r[R];                            // conj-trick twiddle of bin k = lane + 64 r
     float ws_c[G][2], rws_c[G][2];             // summed squared window of this lane's hop samples (interior hops) and 1 / it
     // note state (wave-uniform)
     int note = -1, n = 0, T = 0, out_len = 0;
-    int64_t base = 0, fbase = 0;
+    int64_t base = 0;
 
-    __device__ __forceinline__ void init(unsigned char *smem, const float2 *g_tw, const float2 *g_twh, const float *g_win,
+    __device__ __forceinline__ void init(unsigned char *smem, const float2 *g_tw, const float2 *g_twh, const float *g_window,
                                          const float *t0, const float *t1, const float *t2)
     {
+        g_win = g_window;
         tw = reinterpret_cast<float2 *>(smem);
-        twh = tw + M;
-        wsc = twh + (M / 2 + 2);
-        win = reinterpret_cast<float *>(wsc + M);
-        tab = win + NF;
+        wct = tw + M;
+        wsc = wct + M;
+        tab = reinterpret_cast<float *>(wsc + M);
+        win = tab + NTAB * C::ROWF;
+        const float *tsrc[3] = {t0, t1, t2};
         for (int i = threadIdx.x; i < C::ROWF; i += blockDim.x) {
             const int k = i < B ? i : B - 1;
-            tab[i] = t0[k];
-            tab[C::ROWF + i] = t1[k];
-            tab[2 * C::ROWF + i] = t2 ? t2[k] : 0.f;
+#pragma unroll
+            for (int q = 0; q < NTAB; ++q) tab[q * C::ROWF + i] = tsrc[q][k];
         }
-        {
-            // synthesis window of sample pair m with the transform's 1/M and the input stage's 1/2 folded in:
-            // (z / M) * w == z * (w / M) exactly (M is a power of two), and the conjugate's sign rides along
-            const float inv_m = 0.5f / (float)M;
-            for (int m = threadIdx.x; m < M; m += blockDim.x) wsc[m] = make_float2(g_win[2 * m] * inv_m, -(g_win[2 * m + 1] * inv_m));
+        const float inv_m = 0.5f / (float)M;   // 1/M of the transform and the 1/2 of the input stage (irfft_pre)
+        for (int k = threadIdx.x; k < M; k += blockDim.x) {
+            tw[k] = g_tw[k];
+            // conj-trick twiddle of bin k: the conjugate of the half-bin twiddle exp(-i pi k / M)
+            wct[k] = (k <= M / 2) ? cconj(g_twh[k]) : make_float2(-g_twh[M - k].x, -g_twh[M - k].y);
+            // synthesis window of sample pair k with 1/M and 1/2 folded in: (z / M) * w == z * (w / M) exactly (M is a
+            // power of two), and the conjugate's sign rides along
+            wsc[k] = make_float2(g_win[2 * k] * inv_m, -(g_win[2 * k + 1] * inv_m));
         }
-        load_tables<M>(tw, twh, win, g_tw, g_twh, g_win);      // ends with the block barrier
+        if (WIN)
+            for (int i = threadIdx.x; i < NF; i += blockDim.x) win[i] = g_win[i];
+        __syncthreads();
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         lane = threadIdx.x & 63;
-        unsigned char *per = smem + C::table_bytes + (size_t)wave * C::wave_bytes;
+        unsigned char *per = smem + C::template table_bytes<NTAB, WIN>() + (size_t)wave * C::wave_bytes;
         buf = reinterpret_cast<float2 *>(per);
-        row2 = buf + fft_cfg<M>::BUF;
-        kbuf = reinterpret_cast<double *>(row2 + C::ROWC);
-        seg = kbuf + C::KN;
-        fft_lane_twiddles<M>(tw, lane, tw1_r, tw2_r);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int k = lane + WAVE * r;
-            wc_r[r] = (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y);
-        }
+        kbuf = reinterpret_cast<double *>(buf + fft_cfg<M>::BUF);
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -136,7 +166,7 @@ template <int M> struct walker {
                 const int j = 2 * (lane + WAVE * g) + c;
                 float ws = 0.f;
                 for (int q = (NF - 1 - j) / HOP; q >= 0; --q) {       // ascending frame order = descending offset
-                    const float w = win[j + q * HOP];
+                    const float w = g_win[j + q * HOP];
                     ws += w * w;
                 }
                 ws_c[g][c] = ws;
@@ -158,30 +188,35 @@ template <int M> struct walker {
         return true;
     }
 
-    __device__ __forceinline__ void enter_note(int nt, const int64_t *frame_off, const int64_t *sample_off)
+    __device__ __forceinline__ void enter_note(const frame_block &fb, int idx)
     {
-        note = nt;
-        base = sample_off[nt];
-        n = (int)(sample_off[nt + 1] - base);
-        fbase = frame_off[nt];
-        T = (int)(frame_off[nt + 1] - fbase);
+        note = FB_GET(fb, note, idx);
+        n = FB_GET(fb, n, idx);
+        T = FB_GET(fb, T, idx);
         out_len = HOP * (T - 1);
+        base = FB_BASE(fb, idx);
     }
 
-    // irFFT of a spectrum X[0..M] given this lane's bins x[r] = X[lane + 64 r] and their mirrors xm[r] = X[M - lane - 64 r],
-    // windowed and overlap-added into `carry`; out[g] = the finished groups of hop t.  `buf` must be free.
-    __device__ __forceinline__ void inverse_ola(const float2 (&x)[R], const float2 (&xm)[R], int t, float2 (&carry)[R - G],
-                                                float2 (&out)[G])
+    // irFFT of the spectrum whose bins k = lane + 64 i this lane holds in x[] (x[R]: the Nyquist bin, lane 0): the complex row
+    // goes through `buf` for the mirrored bins, the complex M-point transform runs (twiddles from LDS), the frame is windowed
+    // and overlap-added into `carry`; out[g] = the finished groups of hop t.
+    __device__ __forceinline__ void inverse_ola(const float2 (&x)[C::PER], int t, float2 (&carry)[R - G], float2 (&out)[G])
     {
+#pragma unroll
+        for (int i = 0; i < R; ++i) buf[lane + WAVE * i] = x[i];
+        if (lane == 0) buf[M] = x[R];
+        wave_lds_sync();
         float2 v[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float2 xk = x[r], xq = xm[r];
-            if (lane + WAVE * r == 0) { xk.y = 0.f; xq.y = 0.f; }     // irfft ignores Im of DC and Nyquist
-            v[r] = irfft_pre(xk, xq, wc_r[r]);
+            const int k = lane + WAVE * r;
+            float2 xk = x[r], xq = buf[M - k];
+            if (k == 0) { xk.y = 0.f; xq.y = 0.f; }                  // irfft ignores Im of DC and Nyquist
+            v[r] = irfft_pre(xk, xq, wct[k]);
         }
+        wave_lds_sync();                                             // the row is read before the transform reuses buf
         float2 z[R];
-        wave_fft_keep_tw<M>(v, buf, tw1_r, tw2_r, lane, z);
+        wave_fft_keep<M>(v, buf, tw, lane, z);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const float2 wn = wsc[lane + WAVE * r];
@@ -194,59 +229,27 @@ template <int M> struct walker {
         }
     }
 
-    // the same from registers: the complex row goes through `buf` for the mirrored bins (x[R]: the Nyquist bin, lane 0)
-    __device__ __forceinline__ void inverse_ola_regs(const float2 (&x)[C::PER], int t, float2 (&carry)[R - G], float2 (&out)[G])
+    // Overlap-add divisor of this lane's sample (g, c) of hop h (GOOFER.py:385-389): the summed squared window over the
+    // frames that exist.  Interior hops (wave-uniform test) have the per-lane constant and its reciprocal at hand.
+    __device__ __forceinline__ bool interior(int h) const { return h >= (NF - 1) / HOP && h <= T - 1; }
+    __device__ __forceinline__ float partial_ws(int h, int g, int c) const
     {
-#pragma unroll
-        for (int i = 0; i < R; ++i) buf[lane + WAVE * i] = x[i];
-        if (lane == 0) buf[M] = x[R];
-        wave_lds_sync();
-        float2 xk[R], xm[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            xk[r] = x[r];
-            xm[r] = buf[M - (lane + WAVE * r)];
-        }
-        wave_lds_sync();                                             // (compiler fence) the row is read before the transform reuses buf
-        inverse_ola(xk, xm, t, carry, out);
-    }
-
-    // and from a complex row already in LDS
-    __device__ __forceinline__ void inverse_ola_row(const float2 *row, int t, float2 (&carry)[R - G], float2 (&out)[G])
-    {
-        float2 xk[R], xm[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            xk[r] = row[lane + WAVE * r];
-            xm[r] = row[M - (lane + WAVE * r)];
-        }
-        wave_lds_sync();
-        inverse_ola(xk, xm, t, carry, out);
-    }
-
-    // overlap-add quotient of sample (g, c) of hop h: the per-lane constant for interior hops, the partial window sum at
-    // the ends of a note (GOOFER.py:385-389)
-    __device__ __forceinline__ float norm(float x, int h, int g, int c) const
-    {
-        constexpr int max_back = (NF - 1) / HOP;
-        if (h >= max_back && h <= T - 1) {
-            const float ws = ws_c[g][c];
-            return ws > 1e-9f ? div_by(x, ws, rws_c[g][c]) : x;
-        }
         const int j = 2 * (lane + WAVE * g) + c;
         const int back = (NF - 1 - j) / HOP;
         const int flo = h - back < 0 ? 0 : h - back, fhi = h > T - 1 ? T - 1 : h;
         float ws = 0.f;
         for (int fr = flo; fr <= fhi; ++fr) {
-            const float w = win[j + (h - fr) * HOP];
+            const float w = g_win[j + (h - fr) * HOP];
             ws += w * w;
         }
-        return ws > 1e-9f ? x / ws : x;
+        return ws;
     }
 };
 
 // ---------------------------------------------------------------------------------------------
-template <int M>
+// PHI: injected phases (parity runs; accurate libm sin / cos) instead of Philox + hardware sin / cos.  A template parameter,
+// not a branch: the libm code is nine inlined range reductions and would triple the loop body of the production kernel.
+template <int M, bool PHI>
 __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict__ env, int ld, const int64_t *__restrict__ row_src,
                                                         const float *__restrict__ phi, int64_t total_frames,
                                                         const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
@@ -263,24 +266,26 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
     constexpr int R = C::R, G = C::G, HOP = C::HOP, B = C::B, PER = C::PER, KN = C::KN, KPL = C::KPL, ROWF = C::ROWF;
     static_assert(R == 8, "the row staging below moves two 16-byte pieces per lane");
     extern __shared__ __align__(16) unsigned char smem[];
-    walker<M> w;
+    walker<M, 2, false> w;
     w.init(smem, g_tw, g_twh, g_win, freqs, bright, nullptr);
     const int lane = w.lane;
     const float *t_fq = w.tab, *t_br = w.tab + ROWF;
     int64_t fs, f0, f1;
     if (!w.range(total_frames, run, frame_note, frame_off, fs, f0, f1)) return;   // no block barrier below
+    frame_block fb;
+    fb.load(fs, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
 
     // the next frame's envelope row is in flight while the current one is transformed: bins 8 lane .. 8 lane + 7 as two
     // 16-byte loads, the Nyquist bin beside them
     float4 ea, eb4;
     float e_ny;
-    auto fetch = [&](int64_t f) {
-        const float *er = env + row_src[f] * (int64_t)ld;
+    auto fetch = [&](int src) {
+        const float *er = env + (int64_t)src * ld;
         ea = *reinterpret_cast<const float4 *>(er + 8 * lane);
         eb4 = *reinterpret_cast<const float4 *>(er + 8 * lane + 4);
         e_ny = er[B - 1];
     };
-    fetch(fs);
+    fetch(FB_GET(fb, src, 0));
 
     float2 carry_u[R - G], carry_b[R - G];
 #pragma unroll
@@ -311,56 +316,14 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
         }
         kn_lo = lo;
     };
-    auto knots_park = [&]() {
-#pragma unroll
-        for (int c = 0; c < KPL; ++c) {
-            const int e = lane + WAVE * c;
-            if (e < KN) w.kbuf[e] = kn_r[c];
-        }
-        wave_lds_sync();
-    };
-    // finished hop h -> window-sum quotient -> mask upsample -> stem gains -> out (GOOFER.py:385-389, 1179-1183)
-    auto emit = [&](int h, const float2 (&eu)[G], const float2 (&eb)[G]) {
-        const int p0 = h * HOP - M;
-        const int e_hi = KN - 1, lo = kn_lo;
-        auto knot = [&](int k) {
-            const int e = k - lo;
-            return w.kbuf[e < e_hi ? e : e_hi];
-        };
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int i0 = p0 + 2 * (lane + WAVE * g);
-            if (i0 < 0 || i0 >= w.n) continue;
-            float xu[2] = {eu[g].x, eu[g].y}, xb[2] = {eb[g].x, eb[g].y};
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int i = i0 + c;
-                if (i < w.out_len) {
-                    xu[c] = w.norm(xu[c], h, g, c);
-                    xb[c] = w.norm(xb[c], h, g, c);
-                } else {
-                    xu[c] = 0.f;                                     // zero tail of istft (GOOFER.py:409-412)
-                    xb[c] = 0.f;
-                }
-                const float ms = smooth_mask_at32(knot, ns, i < w.n ? i : w.n - 1, w.n, step_n, step_s, kps);
-                xb[c] = (xb[c] * ms) * g_b;
-                xu[c] = (xu[c] * (1.0f - ms)) * g_u;
-            }
-            if (i0 + 1 < w.n) {
-                *reinterpret_cast<float2_u *>(uv + w.base + i0) = make_float2(xu[0], xu[1]);
-                *reinterpret_cast<float2_u *>(bre + w.base + i0) = make_float2(xb[0], xb[1]);
-            } else {
-                uv[w.base + i0] = xu[0];
-                bre[w.base + i0] = xb[0];
-            }
-        }
-    };
 
     float *rp = reinterpret_cast<float *>(w.buf);             // staged fp32 rows (dead before the spectra use buf)
     for (int64_t f = fs; f < f1; ++f) {
-        const int nt = frame_note[f];
-        if (nt != w.note) {
-            w.enter_note(nt, frame_off, sample_off);
+        const int idx = (int)(f - fb.blk0);
+        const int t = FB_GET(fb, t, idx);
+        if (FB_GET(fb, note, idx) != w.note) {
+            w.enter_note(fb, idx);
+            const int nt = w.note;
             const goofer_note_params &p = params[nt];
             ns = (w.n + MASK_DS - 1) / MASK_DS;
             g_b = p.breath_strength;
@@ -368,74 +331,76 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
             step_n = steps[2 * nt];
             step_s = steps[2 * nt + 1];
             kps = w.n > 1 ? (float)(ns - 1) / (float)(w.n - 1) : 0.f;
-            ss = short_s + short_base(sample_off, nt);
+            ss = short_s + (w.base / MASK_DS + nt);           // short_base()
             key = seed ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
             apply_bright = p.apply_brightness;
         }
-        const int t = (int)(f - w.fbase);
-        const float2 pv = picks[f];                           // (f0, mask) of the frame: x[::hop] edge-padded (GOOFER.py:1104-1106)
-        const float f0f = pv.x;
-        const bool voiced = apply_bright && pv.y > 0.f;
+        const float f0f = FB_GETF(fb, f0, idx);
+        const bool voiced = apply_bright && FB_GETF(fb, mk, idx) > 0.f;
         if (f >= f0) knots_fetch(t);                          // lands during the two transforms below
 
         // 1. noise envelope: sigma-1.75 blur of the un-warped row (GOOFER.py:993), fp32 FMAs in tap order.  A lane blurs its
         //    eight consecutive bins from a 24-value window (its own eight, eight on either side from LDS), lane 63 also the
         //    Nyquist bin; the blurred row then goes through LDS once more into the transform's layout k = lane + 64 i.
-        float ec[8] = {ea.x, ea.y, ea.z, ea.w, eb4.x, eb4.y, eb4.z, eb4.w};
-        float o9[9];
-        if (do_blur) {
-            *reinterpret_cast<float4 *>(rp + 8 + 8 * lane) = ea;
-            *reinterpret_cast<float4 *>(rp + 8 + 8 * lane + 4) = eb4;
-            wave_lds_sync();
-            float x[24];
-            {
-                const float4 l0 = *reinterpret_cast<const float4 *>(rp + 8 * lane), l1 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 4);
-                const float4 r0 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 16), r1 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 20);
-                x[0] = l0.x; x[1] = l0.y; x[2] = l0.z; x[3] = l0.w; x[4] = l1.x; x[5] = l1.y; x[6] = l1.z; x[7] = l1.w;
-                x[16] = r0.x; x[17] = r0.y; x[18] = r0.z; x[19] = r0.w; x[20] = r1.x; x[21] = r1.y; x[22] = r1.z; x[23] = r1.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[8 + j] = ec[j];
-            // numpy 'reflect' at the two ends of the row: bins -1..-7 are bins 1..7, bins 513..519 are bins 511..505
-#pragma unroll
-            for (int j = 1; j < 8; ++j) {
-                x[8 - j] = lane == 0 ? ec[j] : x[8 - j];
-                x[16 + j] = lane == 63 ? ec[8 - j] : x[16 + j];
-            }
-            x[16] = lane == 63 ? e_ny : x[16];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                float acc = taps.t175[0] * x[j + 1];
-#pragma unroll
-                for (int q = 1; q < 15; ++q) acc = fmaf(taps.t175[q], x[j + 1 + q], acc);
-                o9[j] = acc;
-            }
-            wave_lds_sync();
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o9[j] = ec[j];
-            o9[8] = e_ny;
-        }
-        *reinterpret_cast<float4 *>(rp + 8 * lane) = make_float4(o9[0], o9[1], o9[2], o9[3]);
-        *reinterpret_cast<float4 *>(rp + 8 * lane + 4) = make_float4(o9[4], o9[5], o9[6], o9[7]);
-        if (lane == 63) rp[B - 1] = o9[8];
-        wave_lds_sync();
         float en[PER];
+        {
+            float o9[9];
+            if (do_blur) {
+                *reinterpret_cast<float4 *>(rp + 8 + 8 * lane) = ea;
+                *reinterpret_cast<float4 *>(rp + 8 + 8 * lane + 4) = eb4;
+                wave_lds_sync();
+                float x[24];
+                {
+                    const float4 l0 = *reinterpret_cast<const float4 *>(rp + 8 * lane), l1 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 4);
+                    const float4 r0 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 16), r1 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 20);
+                    x[0] = l0.x; x[1] = l0.y; x[2] = l0.z; x[3] = l0.w; x[4] = l1.x; x[5] = l1.y; x[6] = l1.z; x[7] = l1.w;
+                    x[16] = r0.x; x[17] = r0.y; x[18] = r0.z; x[19] = r0.w; x[20] = r1.x; x[21] = r1.y; x[22] = r1.z; x[23] = r1.w;
+                }
+                const float ec[8] = {ea.x, ea.y, ea.z, ea.w, eb4.x, eb4.y, eb4.z, eb4.w};
 #pragma unroll
-        for (int i = 0; i < PER; ++i) en[i] = rp[lane + WAVE * i < B ? lane + WAVE * i : B - 1];
-        wave_lds_sync();                                      // row dead: buf is free
-        if (f + 1 < f1) fetch(f + 1);
+                for (int j = 0; j < 8; ++j) x[8 + j] = ec[j];
+                // numpy 'reflect' at the two ends of the row: bins -1..-7 are bins 1..7, bins 513..519 are bins 511..505
+#pragma unroll
+                for (int j = 1; j < 8; ++j) {
+                    x[8 - j] = lane == 0 ? ec[j] : x[8 - j];
+                    x[16 + j] = lane == 63 ? ec[8 - j] : x[16 + j];
+                }
+                x[16] = lane == 63 ? e_ny : x[16];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    float acc = taps.t175[0] * x[j + 1];
+#pragma unroll
+                    for (int q = 1; q < 15; ++q) acc = fmaf(taps.t175[q], x[j + 1 + q], acc);
+                    o9[j] = acc;
+                }
+                wave_lds_sync();
+            } else {
+                o9[0] = ea.x; o9[1] = ea.y; o9[2] = ea.z; o9[3] = ea.w; o9[4] = eb4.x; o9[5] = eb4.y; o9[6] = eb4.z; o9[7] = eb4.w;
+                o9[8] = e_ny;
+            }
+            *reinterpret_cast<float4 *>(rp + 8 * lane) = make_float4(o9[0], o9[1], o9[2], o9[3]);
+            *reinterpret_cast<float4 *>(rp + 8 * lane + 4) = make_float4(o9[4], o9[5], o9[6], o9[7]);
+            if (lane == 63) rp[B - 1] = o9[8];
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < PER; ++i) en[i] = rp[lane + WAVE * i < B ? lane + WAVE * i : B - 1];
+            wave_lds_sync();                                  // row dead: buf is free
+        }
+        if (f + 1 < f1) {                                     // the row registers are consumed: start the next frame's row
+            if (!fb.holds(f + 1)) fb.load(f + 1, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
+            fetch(FB_GET(fb, src, (int)(f + 1 - fb.blk0)));
+        }
 
-        // 2. U * env_n (unvoiced spectrum, parked in row2) and U * env_n * HP (* brightness) (breath spectrum)  GOOFER.py:1148-1173
-        float2 sb[PER];
+        // 2. U * env_n (unvoiced spectrum; waits in registers) and U * env_n * HP (* brightness) (breath spectrum)  GOOFER.py:1148-1173
+        float2 su[PER], sb[PER];
         uint4 rnd = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int k = lane + WAVE * i;
-            sb[i] = make_float2(0.f, 0.f);
+            su[i] = sb[i] = make_float2(0.f, 0.f);
             if (k >= B) continue;
             float c, s;
-            if (phi) {
+            if constexpr (PHI) {
                 const float ph = phi[f * (int64_t)ld + k];
                 c = cosf(ph);
                 s = sinf(ph);
@@ -447,10 +412,9 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
                 c = __builtin_amdgcn_cosf(rev);
                 s = __builtin_amdgcn_sinf(rev);
             }
-            const float2 su = make_float2(c * en[i], s * en[i]);
-            w.row2[k] = su;
+            su[i] = make_float2(c * en[i], s * en[i]);
             const float h = hp_mask(t_fq[k], f0f);
-            sb[i] = make_float2(su.x * h, su.y * h);
+            sb[i] = make_float2(su[i].x * h, su[i].y * h);
             if (voiced) {
                 const float b = t_br[k];
                 sb[i].x *= b; sb[i].y *= b;
@@ -470,25 +434,66 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
             }
             wave_lds_sync();
         }
-
         // 3. inverse transforms + overlap-add
         float2 ob[G], ou[G];
-        w.inverse_ola_regs(sb, t, carry_b, ob);
-        w.inverse_ola_row(w.row2, t, carry_u, ou);
+        w.inverse_ola(sb, t, carry_b, ob);
+        w.inverse_ola(su, t, carry_u, ou);
 
         if (f >= f0) {
-            // hop t; behind a note's last frame also the hop still open in the registers and the zero tail
-            knots_park();
-            emit(t, ou, ob);
-            if (t == w.T - 1) {
-                for (int h = t + 1; h * HOP - M < w.n; ++h) {
-                    knots_fetch(h);
-                    knots_park();
-                    float2 fu[G], fb[G];
+            // 4. hop t -> window-sum quotient -> mask upsample -> stem gains -> out (GOOFER.py:385-389, 1179-1183); behind a note's
+            //    last frame also the hop still open in the registers and the zero tail
+            for (int h = t;;) {
 #pragma unroll
-                    for (int g = 0; g < G; ++g) { fu[g] = carry_u[g]; fb[g] = carry_b[g]; }
-                    emit(h, fu, fb);                          // h == T: the sums in the registers; beyond: zeros (i >= out_len)
+                for (int c = 0; c < KPL; ++c) {
+                    const int e = lane + WAVE * c;
+                    if (e < KN) w.kbuf[e] = kn_r[c];
                 }
+                wave_lds_sync();
+                const int p0 = h * HOP - M;
+                const int e_hi = KN - 1, lo = kn_lo;
+                auto knot = [&](int k) {
+                    const int e = k - lo;
+                    return w.kbuf[e < e_hi ? e : e_hi];
+                };
+                const bool inner = w.interior(h);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int i0 = p0 + 2 * (lane + WAVE * g);
+                    if (i0 < 0 || i0 >= w.n) continue;
+                    float xu[2] = {ou[g].x, ou[g].y}, xb[2] = {ob[g].x, ob[g].y};
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int i = i0 + c;
+                        if (i < w.out_len) {
+                            if (inner) {
+                                const float ws = w.ws_c[g][c], rw = w.rws_c[g][c];
+                                if (ws > 1e-9f) { xu[c] = div_by(xu[c], ws, rw); xb[c] = div_by(xb[c], ws, rw); }
+                            } else {
+                                const float ws = w.partial_ws(h, g, c);
+                                if (ws > 1e-9f) { xu[c] /= ws; xb[c] /= ws; }
+                            }
+                        } else {
+                            xu[c] = 0.f;                             // zero tail of istft (GOOFER.py:409-412)
+                            xb[c] = 0.f;
+                        }
+                        const float ms = smooth_mask_at32(knot, ns, i < w.n ? i : w.n - 1, w.n, step_n, step_s, kps);
+                        xb[c] = (xb[c] * ms) * g_b;
+                        xu[c] = (xu[c] * (1.0f - ms)) * g_u;
+                    }
+                    if (i0 + 1 < w.n) {
+                        *reinterpret_cast<float2_u *>(uv + w.base + i0) = make_float2(xu[0], xu[1]);
+                        *reinterpret_cast<float2_u *>(bre + w.base + i0) = make_float2(xb[0], xb[1]);
+                    } else {
+                        uv[w.base + i0] = xu[0];
+                        bre[w.base + i0] = xb[0];
+                    }
+                }
+                ++h;
+                if (t != w.T - 1 || h * HOP - M >= w.n) break;
+                // flush: hop T is the sums still in the registers; beyond it only zeros are written (i >= out_len)
+#pragma unroll
+                for (int g = 0; g < G; ++g) { ou[g] = carry_u[g]; ob[g] = carry_b[g]; }
+                knots_fetch(h);
             }
         }
         wave_lds_sync();
@@ -496,40 +501,39 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// `env` holds the harmonic envelope rows as the shaping step needs them: already warped (k_warp_bins, one row per frame)
+// or, when no note of the batch warps, the source rows addressed through row_src.
 template <int M>
 __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ pulse, const float *__restrict__ env, int ld,
-                                                      const int64_t *__restrict__ row_src, const double *__restrict__ formants,
-                                                      int64_t total_frames, const int *__restrict__ frame_note,
-                                                      const int64_t *__restrict__ frame_off, const int64_t *__restrict__ sample_off,
-                                                      const float2 *__restrict__ picks, const goofer_note_params *__restrict__ params,
-                                                      const float *__restrict__ freqs, const float *__restrict__ boost,
-                                                      const float *__restrict__ bright, const stem_taps taps, double nyq,
-                                                      float *__restrict__ harm, float *__restrict__ note_mag, int run,
-                                                      const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twh,
+                                                      const int64_t *__restrict__ row_src, int64_t total_frames,
+                                                      const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
+                                                      const int64_t *__restrict__ sample_off, const float2 *__restrict__ picks,
+                                                      const goofer_note_params *__restrict__ params, const float *__restrict__ freqs,
+                                                      const float *__restrict__ boost, const float *__restrict__ bright,
+                                                      const stem_taps taps, float *__restrict__ harm, float *__restrict__ note_mag,
+                                                      int run, const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twh,
                                                       const float *__restrict__ g_win)
 {
     using C = stem_cfg<M>;
     constexpr int R = C::R, G = C::G, HOP = C::HOP, B = C::B, PER = C::PER, ROWF = C::ROWF;
-    static_assert(R == 8, "the row staging below moves two 16-byte pieces per lane");
     extern __shared__ __align__(16) unsigned char smem[];
-    walker<M> w;
+    walker<M, 3, true> w;
     w.init(smem, g_tw, g_twh, g_win, freqs, boost, bright);
     const int lane = w.lane;
     const float *t_fq = w.tab, *t_bo = w.tab + ROWF, *t_br = w.tab + 2 * ROWF;
     int64_t fs, f0, f1;
     if (!w.range(total_frames, run, frame_note, frame_off, fs, f0, f1)) return;   // no block barrier below
+    frame_block fb;
+    fb.load(fs, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
 
     // raw sample pairs (reflect-padded at the note ends, GOOFER.py:358-360) and the envelope row of the next frame are in
     // flight while the current frame is transformed
     float2 raw[R];
-    float4 ea, eb4;
-    float e_ny;
-    auto fetch = [&](int64_t f) {
-        const int nt = frame_note[f];
-        const int64_t nb = sample_off[nt];
-        const int64_t nn = sample_off[nt + 1] - nb;
-        const int64_t start = (f - frame_off[nt]) * HOP - M;       // first sample of the frame, un-padded coordinates
-        const float *xs = pulse + nb;
+    float ev[PER];
+    auto fetch = [&](int64_t f, int idx) {
+        const int nn = FB_GET(fb, n, idx);
+        const int start = FB_GET(fb, t, idx) * HOP - M;            // first sample of the frame, un-padded coordinates
+        const float *xs = pulse + FB_BASE(fb, idx);
         if (start >= 0 && start + 2 * M <= nn) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -537,115 +541,91 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
                 raw[r] = make_float2(xs[start + 2 * m], xs[start + 2 * m + 1]);
             }
         } else {
+            // numpy 'reflect' as a periodic map (n == 1: 'edge'); 32-bit: notes are far shorter than 2^31 samples
+            const int period = nn > 1 ? 2 * (nn - 1) : 1;
+            auto refl = [&](int i) {
+                if (nn <= 1) return 0;
+                if (i < 0 || i >= period) {
+                    i %= period;
+                    if (i < 0) i += period;
+                }
+                return i < nn ? i : period - i;
+            };
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int m = lane + WAVE * r;
-                const float a = nn > 0 ? xs[reflect_index(start + 2 * m, nn)] : 0.f;
-                const float b = nn > 0 ? xs[reflect_index(start + 2 * m + 1, nn)] : 0.f;
+                const float a = nn > 0 ? xs[refl(start + 2 * m)] : 0.f;
+                const float b = nn > 0 ? xs[refl(start + 2 * m + 1)] : 0.f;
                 raw[r] = make_float2(a, b);
             }
         }
-        const float *er = env + row_src[f] * (int64_t)ld;
-        ea = *reinterpret_cast<const float4 *>(er + 8 * lane);
-        eb4 = *reinterpret_cast<const float4 *>(er + 8 * lane + 4);
-        e_ny = er[B - 1];
+        const float *er = env + (int64_t)FB_GET(fb, src, idx) * ld;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) ev[i] = er[lane + WAVE * i < B ? lane + WAVE * i : B - 1];
     };
-    fetch(fs);
 
     float2 carry[R - G];
 #pragma unroll
     for (int r = 0; r < R - G; ++r) carry[r] = make_float2(0.f, 0.f);
-
-    bool warp = false, any_warp = false;
     int apply_bright = 0, cut_below = 0;
-    double fsh[4] = {1.0, 1.0, 1.0, 1.0}, ratio = 1.0;
 
-    auto emit = [&](int h, const float2 (&e)[G]) {
-        const int p0 = h * HOP - M;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int i0 = p0 + 2 * (lane + WAVE * g);
-            if (i0 < 0 || i0 >= w.n) continue;
-            float x[2] = {e[g].x, e[g].y};
-#pragma unroll
-            for (int c = 0; c < 2; ++c) x[c] = i0 + c < w.out_len ? w.norm(x[c], h, g, c) : 0.f;
-            if (i0 + 1 < w.n) *reinterpret_cast<float2_u *>(harm + w.base + i0) = make_float2(x[0], x[1]);
-            else harm[w.base + i0] = x[0];
-        }
-    };
-
-    float *ra = reinterpret_cast<float *>(w.buf), *rb = ra + ROWF;   // envelope rows of the warp (2 ROWF floats <= BUF float2)
-    static_assert(2 * ROWF <= 2 * fft_cfg<M>::BUF, "two fp32 rows fit the exchange buffer");
-    for (int64_t f = fs; f < f1; ++f) {
-        const int nt = frame_note[f];
-        if (nt != w.note) {
-            w.enter_note(nt, frame_off, sample_off);
-            const goofer_note_params &p = params[nt];
-            warp = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                fsh[k] = p.f_shift[k];
-                warp |= fsh[k] != 1.0;
+    // one iteration in front of the run only starts the first fetch, so that the fetch code exists once
+    for (int64_t f = fs - 1; f < f1; ++f) {
+        float2 X[PER];
+        float evc[PER];
+        int t = 0;
+        float f0f = 0.f;
+        bool voiced = false;
+        if (f >= fs) {
+            const int idx = (int)(f - fb.blk0);
+            t = FB_GET(fb, t, idx);
+            if (FB_GET(fb, note, idx) != w.note) {
+                w.enter_note(fb, idx);
+                const goofer_note_params &p = params[w.note];
+                apply_bright = p.apply_brightness;
+                cut_below = p.cut_below_f0;
             }
-            ratio = (double)p.formant_shift;
-            any_warp = (warp && formants) || p.formant_shift != 1.0f;
-            apply_bright = p.apply_brightness;
-            cut_below = p.cut_below_f0;
-        }
-        const int t = (int)(f - w.fbase);
-        const float2 pv = picks[f];
-        const float f0f = pv.x;
-        const bool voiced = apply_bright && pv.y > 0.f;
-        const int64_t src = row_src[f];
+            f0f = FB_GETF(fb, f0, idx);
+            voiced = apply_bright && FB_GETF(fb, mk, idx) > 0.f;
 
-        // 1. windowed frame -> complex FFT; the lane's points Z[lane + 64 t] stay in registers
-        float2 z[R];
-        {
-            float2 v[R];
+            // 1. windowed frame -> complex FFT; the lane's points Z[lane + 64 t] stay in registers
+            float2 z[R];
+            {
+                float2 v[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int m = lane + WAVE * r;
+                    const float2 wn = *reinterpret_cast<const float2 *>(w.win + 2 * m);
+                    v[r] = make_float2(raw[r].x * wn.x, raw[r].y * wn.y);
+                }
+                wave_fft_keep<M>(v, w.buf, w.tw, lane, z);
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) evc[i] = ev[i];
+
+            // 2. even/odd split: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 e^{-i pi k/M} (Z[k] - conj Z[M-k]); mirrored points through LDS
+#pragma unroll
+            for (int r = 0; r < R; ++r) w.buf[lds_pad(lane + WAVE * r)] = z[r];
+            wave_lds_sync();
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int m = lane + WAVE * r;
-                const float2 wn = *reinterpret_cast<const float2 *>(w.win + 2 * m);
-                v[r] = make_float2(raw[r].x * wn.x, raw[r].y * wn.y);
+                const int k = lane + WAVE * r;
+                const float2 zk = z[r], zm = w.buf[lds_pad((M - k) & (M - 1))];
+                const float2 A = make_float2(zk.x + zm.x, zk.y - zm.y);
+                const float2 Bv = make_float2(zk.x - zm.x, zk.y + zm.y);
+                const float2 Cv = cmul_conj(w.wct[k], Bv);            // the split twiddle is the conjugate of the inverse one
+                X[r] = make_float2(0.5f * (A.x + Cv.y), 0.5f * (A.y - Cv.x));
             }
-            wave_fft_keep_tw<M>(v, w.buf, w.tw1_r, w.tw2_r, lane, z);
+            X[R] = make_float2(z[0].x - z[0].y, 0.f);                // Nyquist bin from Z[0] (lane 0)
+            wave_lds_sync();
         }
-
-        // 2. even/odd split: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 e^{-i pi k/M} (Z[k] - conj Z[M-k]); mirrored points through LDS.
-        //    The spectrum waits in row2 while the envelope row is warped (the warp needs the registers).
-#pragma unroll
-        for (int r = 0; r < R; ++r) w.buf[lds_pad(lane + WAVE * r)] = z[r];
-        wave_lds_sync();
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int k = lane + WAVE * r;
-            const float2 zk = z[r], zm = w.buf[lds_pad((M - k) & (M - 1))];
-            const float2 A = make_float2(zk.x + zm.x, zk.y - zm.y);
-            const float2 Bv = make_float2(zk.x - zm.x, zk.y + zm.y);
-            const float2 Cv = cmul_conj(w.wc_r[r], Bv);               // the split twiddle is the conjugate of the inverse one
-            w.row2[k] = make_float2(0.5f * (A.x + Cv.y), 0.5f * (A.y - Cv.x));
+        if (f + 1 < f1) {                                            // raw pairs and row are consumed: start the next frame's
+            if (!fb.holds(f + 1)) fb.load(f + 1, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
+            fetch(f + 1, (int)(f + 1 - fb.blk0));
         }
-        if (lane == 0) w.row2[M] = make_float2(z[0].x - z[0].y, 0.f);   // Nyquist bin from Z[0]
-        wave_lds_sync();
+        if (f < fs) continue;
 
-        // 3. harmonic envelope: formant-anchored + uniform warp of the source row (GOOFER.py:1004-1017), then into the
-        //    transform's layout k = lane + 64 i
-        *reinterpret_cast<float4 *>(ra + 8 * lane) = ea;
-        *reinterpret_cast<float4 *>(ra + 8 * lane + 4) = eb4;
-        if (lane == 63) ra[B - 1] = e_ny;
-        wave_lds_sync();
-        const float *eg = ra;
-        if (any_warp) eg = warp_row(ra, rb, B, nyq, formants ? formants + src * 4 : nullptr, fsh, warp, ratio, lane, w.seg);
-        float evc[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) evc[i] = eg[lane + WAVE * i < B ? lane + WAVE * i : B - 1];
-        wave_lds_sync();                                             // envelope rows dead: buf is free
-        if (f + 1 < f1) fetch(f + 1);
-        float2 X[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) X[i] = w.row2[lane + WAVE * i < B ? lane + WAVE * i : B - 1];
-
-        // 4. shaping (GOOFER.py:1102-1144); 1 / max(|S| + 1e-8) commutes with the linear chain and is applied by k_note_finish
+        // 3. shaping (GOOFER.py:1102-1144); 1 / max(|S| + 1e-8) commutes with the linear chain and is applied by k_note_finish
         float mx = 0.f;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -657,9 +637,9 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
                 s.x *= h; s.y *= h;
             }
             mx = fmaxf(mx, cabs_fast(s) + 1e-8f);
-            const float gch = evc[i], bo = t_bo[k];
-            s.x = (s.x * gch) * bo;
-            s.y = (s.y * gch) * bo;
+            const float bo = t_bo[k];
+            s.x = (s.x * evc[i]) * bo;
+            s.y = (s.y * evc[i]) * bo;
             if (voiced) {
                 const float b = t_br[k];
                 s.x *= b; s.y *= b;
@@ -683,18 +663,39 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
             wave_lds_sync();
         }
 
-        // 5. inverse transform + overlap-add; hop t leaves un-normalised by the note's spectrum maximum
+        // 4. inverse transform + overlap-add; hop t leaves un-normalised by the note's spectrum maximum
         float2 e[G];
-        w.inverse_ola_regs(X, t, carry, e);
+        w.inverse_ola(X, t, carry, e);
         if (f >= f0) {
-            emit(t, e);
-            if (t == w.T - 1) {
-                for (int h = t + 1; h * HOP - M < w.n; ++h) {
-                    float2 fl[G];
+            for (int h = t;;) {
+                const int p0 = h * HOP - M;
+                const bool inner = w.interior(h);
 #pragma unroll
-                    for (int g = 0; g < G; ++g) fl[g] = carry[g];
-                    emit(h, fl);
+                for (int g = 0; g < G; ++g) {
+                    const int i0 = p0 + 2 * (lane + WAVE * g);
+                    if (i0 < 0 || i0 >= w.n) continue;
+                    float x[2] = {e[g].x, e[g].y};
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        if (i0 + c < w.out_len) {
+                            if (inner) {
+                                const float ws = w.ws_c[g][c];
+                                if (ws > 1e-9f) x[c] = div_by(x[c], ws, w.rws_c[g][c]);
+                            } else {
+                                const float ws = w.partial_ws(h, g, c);
+                                if (ws > 1e-9f) x[c] /= ws;
+                            }
+                        } else {
+                            x[c] = 0.f;                              // zero tail of istft (GOOFER.py:409-412)
+                        }
+                    }
+                    if (i0 + 1 < w.n) *reinterpret_cast<float2_u *>(harm + w.base + i0) = make_float2(x[0], x[1]);
+                    else harm[w.base + i0] = x[0];
                 }
+                ++h;
+                if (t != w.T - 1 || h * HOP - M >= w.n) break;
+#pragma unroll
+                for (int g = 0; g < G; ++g) e[g] = carry[g];        // flush: the sums still in the registers, then zeros
             }
         }
         wave_lds_sync();
@@ -849,23 +850,31 @@ int launch_noise_stems(goofer_ctx *ctx, const float *env, int ld, const int64_t 
     if (F <= 0) return GOOFER_OK;
     const goofer_plan_t &p = ctx->plan;
     if (!stems_supported(p)) return goofer_fail(ctx, GOOFER_EINVAL, "the stem walkers need n_fft 1024 and hop == n_fft / 4");
+    if ((ld & 3) || ((uintptr_t)env & 15)) return goofer_fail(ctx, GOOFER_EINVAL, "envelope rows must be 16-byte aligned");
     constexpr int M = 512;
-    const void *fn = (const void *)k_noise_stems<M>;
-    const size_t lds = stem_cfg<M>::lds_bytes;
+    const void *fn = phi ? (const void *)k_noise_stems<M, true> : (const void *)k_noise_stems<M, false>;
+    const size_t lds = stem_cfg<M>::lds_bytes<2, false>();
     int rc, slots = 0;
     if ((rc = kernel_allow_max_lds(ctx, fn))) return rc;
     if ((rc = kernel_resident_waves(ctx, fn, lds, &slots))) return rc;
     const int run = run_length(F, slots);
     const int64_t runs = (F + run - 1) / run;
-    hipLaunchKernelGGL(k_noise_stems<M>, dim3((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), dim3(256), lds, st, env, ld,
-                       row_src, phi, F, frame_note, frame_off, sample_off, picks, params, seed, p.freqs, p.bright_b, plan_taps(p),
-                       preblurred ? 0 : 1, short_s, steps, uv, bre, run, p.tw_full, p.tw_half, p.window);
+    const dim3 grid((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+    if (phi)
+        hipLaunchKernelGGL((k_noise_stems<M, true>), grid, dim3(256), lds, st, env, ld, row_src, phi, F, frame_note, frame_off,
+                           sample_off, picks, params, seed, p.freqs, p.bright_b, plan_taps(p), preblurred ? 0 : 1, short_s, steps, uv,
+                           bre, run, p.tw_full, p.tw_half, p.window);
+    else
+        hipLaunchKernelGGL((k_noise_stems<M, false>), grid, dim3(256), lds, st, env, ld, row_src, phi, F, frame_note, frame_off,
+                           sample_off, picks, params, seed, p.freqs, p.bright_b, plan_taps(p), preblurred ? 0 : 1, short_s, steps, uv,
+                           bre, run, p.tw_full, p.tw_half, p.window);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
 
-int launch_harm_stem(goofer_ctx *ctx, const float *pulse, const float *env, int ld, const int64_t *row_src, const double *formants,
-                     int64_t F, const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, const float2 *picks,
+// env: warped rows, one per frame (row_src == nullptr), or source rows through row_src when nothing warps
+int launch_harm_stem(goofer_ctx *ctx, const float *pulse, const float *env, int ld, const int64_t *row_src, int64_t F,
+                     const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, const float2 *picks,
                      const goofer_note_params *params, float *harm, float *note_mag, hipStream_t st)
 {
     if (F <= 0) return GOOFER_OK;
@@ -873,15 +882,15 @@ int launch_harm_stem(goofer_ctx *ctx, const float *pulse, const float *env, int 
     if (!stems_supported(p)) return goofer_fail(ctx, GOOFER_EINVAL, "the stem walkers need n_fft 1024 and hop == n_fft / 4");
     constexpr int M = 512;
     const void *fn = (const void *)k_harm_stem<M>;
-    const size_t lds = stem_cfg<M>::lds_bytes;
+    const size_t lds = stem_cfg<M>::lds_bytes<3, true>();
     int rc, slots = 0;
     if ((rc = kernel_allow_max_lds(ctx, fn))) return rc;
     if ((rc = kernel_resident_waves(ctx, fn, lds, &slots))) return rc;
     const int run = run_length(F, slots);
     const int64_t runs = (F + run - 1) / run;
     hipLaunchKernelGGL(k_harm_stem<M>, dim3((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), dim3(256), lds, st, pulse, env, ld,
-                       row_src, formants, F, frame_note, frame_off, sample_off, picks, params, p.freqs, p.boost, p.bright_h, plan_taps(p),
-                       (double)p.sr / 2.0, harm, note_mag, run, p.tw_full, p.tw_half, p.window);
+                       row_src, F, frame_note, frame_off, sample_off, picks, params, p.freqs, p.boost, p.bright_h, plan_taps(p), harm,
+                       note_mag, run, p.tw_full, p.tw_half, p.window);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

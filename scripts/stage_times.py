@@ -1,5 +1,5 @@
 """Per-stage HIP-event times of the default bench workload (config 3, 1024 notes), one line per stage.
-Usage (on the GPU box): python scripts/stage_times.py [notes] [steps] [--serial]
+Usage (on the GPU box): python scripts/stage_times.py [notes] [steps] [--serial] [--opt name=value ...]
 --serial turns the side stream off (option "overlap" = 0), so every stage is timed alone on the chip."""
 import os
 import sys
@@ -9,13 +9,17 @@ from goofer_amd.device import Context
 from goofer_amd.workload import SamplerWorkload
 
 serial = "--serial" in sys.argv
-argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+opts = [a.split("=") for a in sys.argv[1:] if "=" in a]
+argv = [a for a in sys.argv[1:] if not a.startswith("--") and "=" not in a]
 notes = int(argv[0]) if len(argv) > 0 else 1024
 steps = int(argv[1]) if len(argv) > 1 else 10
+config = int(argv[2]) if len(argv) > 2 else 3
 ctx = Context(0)
 if serial:
     ctx.set_option("overlap", 0)
-wl = SamplerWorkload(ctx, 3, list(range(notes)))
+for k, v in opts:
+    ctx.set_option(k, int(v))
+wl = SamplerWorkload(ctx, config, list(range(notes)))
 for _ in range(3):
     wl.step()
 torch.cuda.synchronize()
