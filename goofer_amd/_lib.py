@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgoofer_hip.so")
+LIB_PATH = os.environ.get("GOOFER_HIP_LIB") or os.path.join(HERE, "libgoofer_hip.so")   # override: kernel experiments only
 
 # numpy mirror of goofer_note_params (C layout, 112 bytes; checked against goofer_sizeof)
 NOTE_PARAMS = np.dtype({

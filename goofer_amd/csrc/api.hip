@@ -394,6 +394,7 @@ void goofer_destroy(goofer_ctx *ctx)
     free(ctx->prof_main2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_maps) (void)hipEventDestroy(ctx->ev_maps);
     if (ctx->ev_entry) (void)hipEventDestroy(ctx->ev_entry);
     if (ctx->ev_f0) (void)hipEventDestroy(ctx->ev_f0);
     if (ctx->ev_f0s) (void)hipEventDestroy(ctx->ev_f0s);
@@ -1017,6 +1018,7 @@ static int ensure_side_stream(goofer_ctx *ctx)
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_maps, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_entry, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_f0, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_f0s, hipEventDisableTiming));
@@ -1201,11 +1203,6 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                                      b->bre, st)))
             return r2;
         if (side_on) MARK_Q(1);
-        // harmonic envelope rows for the harmonic walker: formant-anchored + uniform warp, one wave per row (GOOFER.py:1004-1017).
-        // Here, beside the pulse chain, rather than inside the walker: the crossing-anchor path is several times slower than
-        // the sorted one, and a walker wave holds ~95 frames of ONE note (the slow notes would set the kernel's time).
-        if ((r2 = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, st)))
-            return r2;
         return GOOFER_OK;
     };
     // The pulse walk is one latency-bound wave per SIMD: it goes to a side stream FIRST (so its workgroups are resident
@@ -1217,6 +1214,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         int rc2 = ensure_side_stream(ctx);
         if (rc2) return rc2;
         if (pev) sev = ctx->prof_side + (size_t)ctx->prof_steps * 4;
+        if (stem_path) HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st));   // the frame maps and everything before them on this stream
         if (!early) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
@@ -1238,6 +1236,15 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     MARK();
     if (sev) HIP_TRY(ctx, hipEventRecord(sev[2], pst));
     if ((rc = launch_pulse_place(ctx, (onset_t *)onsets, onset_cnt, b->sample_off, n, N, pulse, pst))) return rc;
+    // Harmonic envelope rows for the harmonic walker: formant-anchored + uniform warp, one wave per row (GOOFER.py:1004-1017),
+    // behind the pulse placement on its stream (the caller's stream carries the mask smoothing and the noise walker meanwhile).
+    // Not inside the walker: the crossing-anchor path is several times slower than the sorted one, and a walker wave holds
+    // ~95 frames of ONE note, so the slow notes would set the kernel's time.
+    if (stem_path && side_on) {
+        HIP_TRY(ctx, hipStreamWaitEvent(pst, ctx->ev_maps, 0));            // frame_note / row_src come from the caller's stream
+        if ((rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, pst)))
+            return rc;
+    }
     if (side_on) {
         if (sev) HIP_TRY(ctx, hipEventRecord(sev[3], pst));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, pst));

@@ -45,7 +45,7 @@ struct goofer_ctx {
     size_t dbg_bytes[16] = {0};
     bool overlap = true;          // noise spectra + mask smoothing on a side stream, beside the latency-bound pulse walk
     hipStream_t side = nullptr;   // created on first use
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_maps = nullptr;
     // goofer_render_batch: the pulse chain forks as soon as the assembled f0 exists, not when the synthesis call starts
     hipEvent_t ev_entry = nullptr, ev_f0 = nullptr, ev_f0s = nullptr;
     const float2 *frame_picks = nullptr;   // per-frame (f0, mask) picks of the running goofer_synth_batch, or null

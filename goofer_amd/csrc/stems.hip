@@ -229,6 +229,16 @@ template <int M, int NTAB, bool WIN> struct walker {
         }
     }
 
+    // A frame whose transform is skipped (its spectrum cannot reach a non-zero output sample): the ring still moves on
+    __device__ __forceinline__ void skip_ola(int t, float2 (&carry)[R - G], float2 (&out)[G])
+    {
+        const float2 zero = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < G; ++g) out[g] = t != 0 ? carry[g] : zero;
+#pragma unroll
+        for (int r = G; r < R; ++r) carry[r - G] = (r < R - G && t != 0) ? carry[r] : zero;
+    }
+
     // Overlap-add divisor of this lane's sample (g, c) of hop h (GOOFER.py:385-389): the summed squared window over the
     // frames that exist.  Interior hops (wave-uniform test) have the per-lane constant and its reciprocal at hand.
     __device__ __forceinline__ bool interior(int h) const { return h >= (NF - 1) / HOP && h <= T - 1; }
@@ -317,11 +327,54 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
         kn_lo = lo;
     };
 
+    // Exact sparsity of the stem gains (GOOFER.py:1179-1183): where the smoothed mask is flat at 1 the unvoiced stem is
+    // multiplied by exactly 0, where it is flat at 0 the breath stem is.  Frame t reaches hops t .. t + 3 only; when all the
+    // mask knots those hops can read are one constant c with 1 - float(c) == 0 (float(c) == 0), the frame's unvoiced (breath)
+    // spectrum cannot reach a non-zero sample and its transform is skipped — every sample that is not exactly zero still
+    // receives all its frames, in order.  Bit j of the masks: hop t + j is flat at one / at zero; unknown hops (the first
+    // three frames of a run or a note) count as not flat.
+    unsigned one_bits = 0, zero_bits = 0;
+    double hk[2] = {0.0, 0.0}, hk_c = 0.0;
+    int hk_lo = 0, hk_hi = -1;
+    bool hk_none = false;
+    auto hop_check_issue = [&](int h) {
+        int i_lo = (h - 2) * HOP, i_hi = (h - 1) * HOP - 1;
+        hk_none = i_hi < 0 || i_lo >= w.n || ns <= 0;            // the hop has no output sample
+        i_lo = i_lo < 0 ? 0 : i_lo;
+        i_hi = i_hi > w.n - 1 ? w.n - 1 : i_hi;
+        int lo = (int)((float)i_lo * kps) - 4, hi = (int)((float)i_hi * kps) + 6;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > ns - 1 ? ns - 1 : hi;
+        hk_lo = lo;
+        hk_hi = hk_none ? lo - 1 : hi;
+        if (!hk_none) {
+            hk_c = ss[lo];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int k = lo + lane + WAVE * c;
+                hk[c] = ss[k <= hi ? k : hi];
+            }
+        }
+    };
+    auto hop_check_done = [&]() {
+        bool one = true, zero = true;
+        if (!hk_none) {
+            const bool same = hk[0] == hk_c && hk[1] == hk_c && hk_hi - hk_lo < 2 * WAVE;
+            const bool flat = __all(same);
+            const float cf = (float)hk_c;
+            one = flat && (1.0f - cf) == 0.0f;
+            zero = flat && cf == 0.0f;
+        }
+        one_bits = (one_bits >> 1) | (one ? 8u : 0u);
+        zero_bits = (zero_bits >> 1) | (zero ? 8u : 0u);
+    };
+
     float *rp = reinterpret_cast<float *>(w.buf);             // staged fp32 rows (dead before the spectra use buf)
     for (int64_t f = fs; f < f1; ++f) {
         const int idx = (int)(f - fb.blk0);
         const int t = FB_GET(fb, t, idx);
         if (FB_GET(fb, note, idx) != w.note) {
+            one_bits = zero_bits = 0;
             w.enter_note(fb, idx);
             const int nt = w.note;
             const goofer_note_params &p = params[nt];
@@ -338,6 +391,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
         const float f0f = FB_GETF(fb, f0, idx);
         const bool voiced = apply_bright && FB_GETF(fb, mk, idx) > 0.f;
         if (f >= f0) knots_fetch(t);                          // lands during the two transforms below
+        hop_check_issue(t + 3);
 
         // 1. noise envelope: sigma-1.75 blur of the un-warped row (GOOFER.py:993), fp32 FMAs in tap order.  A lane blurs its
         //    eight consecutive bins from a 24-value window (its own eight, eight on either side from LDS), lane 63 also the
@@ -434,10 +488,13 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
             }
             wave_lds_sync();
         }
-        // 3. inverse transforms + overlap-add
+        // 3. inverse transforms + overlap-add (skipped where the stem's gain is exactly zero over everything the frame reaches)
+        hop_check_done();
         float2 ob[G], ou[G];
-        w.inverse_ola(sb, t, carry_b, ob);
-        w.inverse_ola(su, t, carry_u, ou);
+        if (zero_bits == 15u) w.skip_ola(t, carry_b, ob);
+        else w.inverse_ola(sb, t, carry_b, ob);
+        if (one_bits == 15u) w.skip_ola(t, carry_u, ou);
+        else w.inverse_ola(su, t, carry_u, ou);
 
         if (f >= f0) {
             // 4. hop t -> window-sum quotient -> mask upsample -> stem gains -> out (GOOFER.py:385-389, 1179-1183); behind a note's
