@@ -62,18 +62,36 @@ STAGE_KERNEL = {"rfft_frames": "void k_rfft_frames<512>", "rfft_frames_standalon
                 "noise_stems": "void k_noise_stems<512>", "harm_stem": "void k_harm_stem<512>", "note_finish": "k_note_finish"}
 
 
-PMC_FILE = "r01l_pmc_traffic.json"      # committed rocprofv3 counter passes of this same command (scripts/collect_profiles.sh)
+def _pmc_file():
+    """Newest committed rocprofv3 counter passes (profiles/<tag>_pmc_traffic.json, tags sort in time order)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(HERE, "profiles", "r*_pmc_traffic.json")))
+    return files[-1] if files else None
 
 
 def pmc_traffic(stage, frames):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json), with the
-    gfx950 FETCH_SIZE correction; None when no matching measurement exists for this workload size."""
+    """(HBM bytes per launch, source tag) from the newest committed rocprofv3 PMC passes of this same command
+    (scripts/collect_profiles.sh), with the gfx950 FETCH_SIZE correction.  The counters cannot be read inside this
+    process, so the figure is the committed measurement of this code path, not of this run: the tag says which.
+    (None, None) when the workload size or the kernel does not match."""
     try:
-        d = json.load(open(os.path.join(HERE, "profiles", PMC_FILE)))
+        fn = _pmc_file()
+        d = json.load(open(fn))
         k = d["kernels"][STAGE_KERNEL[stage]]
         if d["_meta"]["frames"] != frames:
+            return None, None
+        return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0, os.path.basename(fn)
+    except Exception:
+        return None, None
+
+
+def pmc_step_traffic(frames):
+    try:
+        fn = _pmc_file()
+        d = json.load(open(fn))
+        if d["_meta"]["frames"] != frames:
             return None
-        return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
+        return {"bytes": d["_meta"]["step_hbm_bytes"], "source": os.path.basename(fn)}
     except Exception:
         return None
 
@@ -243,8 +261,9 @@ def main():
         def roof(stage):
             ms = per[stage]
             a = stage_alg_bytes(stage, wl.frames, wl.samples, B, hop, n_fft) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            traffic, src = pmc_traffic(stage, wl.frames)
             return {"kernel": stage, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": a / HBM_PEAK_GBS, "traffic": pmc_traffic(stage, wl.frames), "ms_per_launch": ms,
+                    "frac": a / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "ms_per_launch": ms,
                     "alg_bytes_per_launch": stage_alg_bytes(stage, wl.frames, wl.samples, B, hop, n_fft)}
 
         line = {

@@ -7,7 +7,7 @@ tag=$1
 root=$PWD
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
-python3 bench.py --steps 20 --warmup 3 > "$out/bench.json" 2> "$out/bench.err"
+python3 bench.py --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
 tail -1 "$out/bench.json" | head -c 600; echo
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$out/trace" -o r --output-format csv -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$out/trace.log" 2>&1

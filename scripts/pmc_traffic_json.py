@@ -30,6 +30,14 @@ for which, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 meta = {"workload": bench["config"]["workload"], "frames": bench["config"]["frames_per_gpu"], "samples": bench["config"]["samples_per_gpu"],
         "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (only --kernel-trace beside them); per-launch means in KB",
         "correction": "gfx950: FETCH_SIZE reports half of a coalesced streaming read (MI355X_MICROARCH.md, HBM) -> bytes = (2*FETCH + WRITE)*1024"}
+# HBM bytes of one step: every kernel's mean x its launches per step (a step = one k_sample_assemble launch)
+steps = max(1, res.get("k_sample_assemble", {}).get("launches_sampled", 1))
+tot = 0.0
+for k, v in res.items():
+    if k.startswith(("k_", "void k_")) and "FETCH_SIZE_KB" in v and "WRITE_SIZE_KB" in v:
+        tot += (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 * v["launches_sampled"] / steps
+meta["step_hbm_bytes"] = tot
+meta["step_hbm_bytes_note"] = "sum over the step's kernels of (2*FETCH + WRITE)*1024 x launches per step; plan-time kernels (k_pulse_peak, k_pulse_shape_table) run once per process and are included pro rata"
 json.dump({"_meta": meta, "kernels": {k: v for k, v in sorted(res.items()) if k.startswith(("k_", "void k_"))}},
           open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
 print("wrote", os.listdir(dst))
