@@ -27,6 +27,9 @@ def _ctx(sr, n_fft, hop, ctx=None) -> Context:
     return (ctx or default_context()).plan(sr, n_fft, hop)
 
 
+MASK_DS = 4          # smooth_mask_ds decimation (GOOFER.py:556)
+
+
 # -- feature files (host-side format code, byte-compatible with GOOFER.py:287-339) -----------------
 def formants_to_int_keys(d):
     out = {}
@@ -167,6 +170,17 @@ def gaussian_filter1d(input_array, sigma, axis=-1, truncate=4.0, ctx=None):
     lines = np.ascontiguousarray(moved, dtype=np.float64).reshape(-1, moved.shape[-1])
     out = c.gauss_rows_f64(c.tensor(lines), gaussian_taps(sigma, truncate)).cpu().numpy()
     return np.moveaxis(out.reshape(moved.shape), -1, axis)
+
+
+def smooth_mask_ds(mask, sigma=100, ds=4, sr=44100, n_fft=1024, hop_length=256, ctx=None):
+    """gf.smooth_mask_ds (GOOFER.py:556-569) on the device: mask[::4] -> Gaussian max(1, sigma / 4) -> linear upsample."""
+    if ds != MASK_DS:
+        raise ValueError("the device path decimates by %d (GOOFER.py:556 default)" % MASK_DS)
+    c = _ctx(sr, n_fft, hop_length, ctx)
+    m = np.ascontiguousarray(mask, dtype=np.float32)
+    if m.size == 0:
+        return m.copy()
+    return c.smooth_mask_ds(c.tensor(m), sigma=float(sigma)).cpu().numpy()
 
 
 def gaussian_filter(input_array, sigma, ctx=None):

@@ -88,6 +88,7 @@ int launch_apply_gain(goofer_ctx *, float *, float *, float *, float *, float *,
                       const goofer_note_params *, const float *, bool, hipStream_t);
 
 int launch_note_steps(goofer_ctx *, const int64_t *, int, double *, hipStream_t);
+int launch_mask_upsample(goofer_ctx *, const double *, const int64_t *, int, int64_t, double *, bool, float *, hipStream_t);
 bool stems_supported(const goofer_plan_t &);
 int launch_frame_picks(goofer_ctx *, const int64_t *, const int *, int64_t, const int64_t *, const float *, const float *, float2 *,
                        hipStream_t);
@@ -781,6 +782,31 @@ int goofer_knot_gather(goofer_ctx *ctx, const double *env, int ld64, int64_t row
 {
     if (!ctx) return GOOFER_EINVAL;
     return launch_knot_gather(ctx, env, ld64, rows, knot_bin, K, knots_f16, (hipStream_t)stream);
+}
+
+/* gf.smooth_mask_ds (GOOFER.py:556-569) for a ragged batch of masks: decimate by 4, Gaussian sigma/4 (fp64), linear
+ * upsample on float32 linspace grids.  `fast_interp` selects the interpolant form the stem walkers use. */
+int goofer_smooth_mask_ds(goofer_ctx *ctx, const float *mask, const int64_t *sample_off, int n_notes, int64_t total_samples,
+                          float sigma, int fast_interp, float *out, void *stream)
+{
+    NEED_PLAN(ctx);
+    if (!mask || !sample_off || !out || n_notes <= 0) return goofer_fail(ctx, GOOFER_EINVAL, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<double> taps;
+    int radius;
+    gauss_taps_host(std::max(1.0, (double)sigma / 4.0), taps, radius);                // GOOFER.py:561
+    if (radius > 2048) return goofer_fail(ctx, GOOFER_EINVAL, "transition sigma too large");
+    const size_t n_short = (size_t)(total_samples / 4 + n_notes + 16);
+    const size_t need = (taps.size() + 16 + n_short + 2 * (size_t)n_notes + 16) * sizeof(double);
+    int rc = ensure_small(ctx, need);
+    if (rc) return rc;
+    double *d_taps = (double *)ctx->small, *short_s = d_taps + taps.size() + 16, *steps = short_s + n_short;
+    HIP_TRY(ctx, hipMemcpyAsync(d_taps, taps.data(), taps.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));                                            // the host vector goes out of scope
+    double acc = 0.0;
+    for (double tv : taps) acc += tv * 1.0;
+    if ((rc = launch_mask_short(ctx, mask, sample_off, n_notes, total_samples, d_taps, radius, acc, short_s, st))) return rc;
+    return launch_mask_upsample(ctx, short_s, sample_off, n_notes, total_samples, steps, fast_interp != 0, out, st);
 }
 
 int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *asmb, void *stream)

@@ -580,6 +580,45 @@ static int irfft_ola3_impl(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u
     return GOOFER_OK;
 }
 
+// smooth_mask_ds's last step on its own (GOOFER.py:563-567): np.interp of the smoothed decimated mask back to the sample
+// grid.  `fast` selects the walkers' 32-bit interpolant (smooth_mask_at32: flat-knot shortcut, one-step index fix-up)
+// instead of the search-loop form the separate stem-gain kernels use; the two must agree bit for bit.
+__global__ __launch_bounds__(256) void k_mask_upsample(const double *__restrict__ short_s, const int64_t *__restrict__ sample_off,
+                                                       int n_notes, int64_t total_samples, const double *__restrict__ steps, int fast,
+                                                       float *__restrict__ out)
+{
+    __shared__ int s_pair[2];
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    int lo, hi;
+    block_note_range(sample_off, n_notes, g0, total_samples, s_pair, lo, hi);
+    const int64_t g = g0 + threadIdx.x;
+    if (g >= total_samples) return;
+    int note = lo;
+    while (sample_off[note + 1] <= g) ++note;
+    const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+    const int64_t ns = (n + MASK_DS - 1) / MASK_DS;
+    const double *ss = short_s + short_base(sample_off, note);
+    if (fast) {
+        const float kps = n > 1 ? (float)(ns - 1) / (float)(n - 1) : 0.f;
+        auto knot = [&](int k) { return ss[k]; };
+        out[g] = smooth_mask_at32(knot, (int)ns, (int)(g - base), (int)n, steps[2 * note], steps[2 * note + 1], kps);
+    } else {
+        out[g] = smooth_mask_at(ss, ns, g - base, n, steps[2 * note], steps[2 * note + 1]);
+    }
+}
+
+int launch_mask_upsample(goofer_ctx *ctx, const double *short_s, const int64_t *sample_off, int n_notes, int64_t total_samples,
+                         double *steps, bool fast, float *out, hipStream_t st)
+{
+    if (total_samples <= 0) return GOOFER_OK;
+    hipLaunchKernelGGL(k_note_steps, dim3((n_notes + 255) / 256), dim3(256), 0, st, sample_off, n_notes, steps);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_mask_upsample, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, st, short_s, sample_off, n_notes,
+                       total_samples, steps, fast ? 1 : 0, out);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
 int launch_note_steps(goofer_ctx *ctx, const int64_t *sample_off, int n_notes, double *steps, hipStream_t st)
 {
     if (n_notes <= 0) return GOOFER_OK;

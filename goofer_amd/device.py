@@ -252,6 +252,16 @@ class Context:
         out._keep = off
         return out
 
+    def smooth_mask_ds(self, mask, lengths=None, sigma: float = 100.0, fast_interp: bool = False):
+        """gf.smooth_mask_ds (GOOFER.py:556-569) of fp32 device masks (a ragged batch when ``lengths`` is given)."""
+        n_total = mask.numel()
+        lengths = [n_total] if lengths is None else list(lengths)
+        off = self.tensor(np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64))
+        out = torch.empty(n_total, dtype=torch.float32, device=self.device)
+        self._check(self.lib.goofer_smooth_mask_ds(self.h, _ptr(mask), _ptr(off), len(lengths), n_total, float(sigma),
+                                                   int(bool(fast_interp)), _ptr(out), self._stream()))
+        return out
+
     def stretch_rows(self, x, rows_out: int):
         """gf.stretch_feature along axis 0 (GOOFER.py:597-616): a 1-D fp32 tensor, or an ld-strided [rows, bins] view."""
         if x.dim() == 1:

@@ -305,6 +305,12 @@ int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *assembly, const 
 
 /* gf.stretch_feature (GOOFER.py:597-616): np.interp(linspace(0,1,rows_out), linspace(0,1,rows_in), column) along
  * axis 0 of a [rows x n_cols] fp32 matrix with row strides ld_in / ld_out (n_cols = 1, ld = 1: a 1-D array). */
+/* gf.smooth_mask_ds (GOOFER.py:556-569) on its own, for a ragged batch of voicing masks (sample_off[n_notes + 1]): decimate by
+ * 4, Gaussian max(1, sigma / 4) in fp64, np.interp back on float32 linspace grids -> out[total_samples] fp32.
+ * fast_interp != 0 selects the interpolant form the stem walkers use (must give the same bits). */
+int goofer_smooth_mask_ds(goofer_ctx *ctx, const float *mask, const int64_t *sample_off, int n_notes, int64_t total_samples,
+                          float sigma, int fast_interp, float *out, void *stream);
+
 int goofer_stretch_rows(goofer_ctx *ctx, const float *in, int64_t ld_in, int64_t rows_in, float *out, int64_t ld_out,
                         int64_t rows_out, int n_cols, void *stream);
 

@@ -320,3 +320,35 @@ def test_module_level_helpers_vs_oracle(ctx):
     assert np.array_equal(core.create_volume_jitter(4000, 44100, speed=150.0, strength=0.15, vibrato=True, ctx=ctx),
                           R.volume_jitter_curve(4000, 44100, speed=150.0, strength=0.15, vibrato=True))
     assert abs(core.rms(x) - R.rms(x)) < 1e-15
+
+
+def test_smooth_mask_ds_vs_reference(ctx):
+    """a7 on its own (GOOFER.py:556-569): the reference's smooth_mask_ds outputs, both interpolant forms (the search-loop form
+    of the separate stem-gain kernel and the walkers' flat-knot shortcut form) bit-identical, ragged batches vs the oracle."""
+    from oracle import goofer_ref as R
+    g = golden("mask_interp")
+    ctx.plan(44100, 1024, 256)
+    m = ctx.tensor(np.asarray(g["mask"], dtype=np.float32))
+    for sigma, key in ((100.0, "smooth_100"), (1.0, "smooth_1")):
+        a = ctx.smooth_mask_ds(m, sigma=sigma).cpu().numpy()
+        b = ctx.smooth_mask_ds(m, sigma=sigma, fast_interp=True).cpu().numpy()
+        assert a.dtype == np.float32 and a.shape == g[key].shape
+        assert np.max(np.abs(a - g[key])) < 1e-7, sigma
+        assert np.array_equal(a, b), sigma
+    rng = np.random.default_rng(17)
+    lens = [1, 2, 3, 4, 5, 7, 8, 9, 255, 1024, 4097, 20000]
+    masks = []
+    for n in lens:
+        x = (rng.random(n) > 0.4).astype(np.float32)
+        x[n // 3:n // 2] = 1.0
+        masks.append(x)
+    cat = ctx.tensor(np.concatenate(masks))
+    for sigma in (100.0, 37.0):
+        a = ctx.smooth_mask_ds(cat, lengths=lens, sigma=sigma).cpu().numpy()
+        b = ctx.smooth_mask_ds(cat, lengths=lens, sigma=sigma, fast_interp=True).cpu().numpy()
+        assert np.array_equal(a, b)
+        o = 0
+        for n, x in zip(lens, masks):
+            want = R.smooth_mask(x, sigma, 4)
+            assert np.max(np.abs(a[o:o + n] - want)) < 1e-7, (n, sigma)
+            o += n

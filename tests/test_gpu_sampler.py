@@ -439,3 +439,39 @@ def test_flag_combinations_match_reference(renderer, name):
     assert out.shape == ref.shape
     e = rms_err(out, ref) / max(1.0, float(np.max(np.abs(ref))))
     assert e < TOL, (flags, e)
+
+
+def test_index_plans_on_device(renderer):
+    """The integer path end to end on the device: the reference's 53 index-plan cases (loop modes L0/L1/L2, every slicing
+    variant, reverse, velocity) with the probe features env[b, t] = t, mask[n] = n.  The assembled envelope spells out which
+    source frames every output frame was built from and the assembled mask which source sample every output sample is —
+    they must be the reference's (SillySampler.py:453-500, 625-788): the mask bit for bit, frames that are copies exactly,
+    cross-faded / resampled frames to fp32 rounding of the frame number."""
+    from goofer_amd.render import Source
+    from goofer_amd import sampler as S
+    from test_product_sampler import probe_source
+    g = golden("index_plans")
+    env, f0, mask, forms, sr, n, T = probe_source()
+    jobs, tags = [], []
+    for tag in g["names"]:
+        if f"{tag}_error" in g.files:
+            continue
+        req = S.decode_request(*[str(a) for a in g[f"{tag}_args"]])
+        jobs.append((Source.from_pack(env, f0, mask, forms, sr, n), req))
+        tags.append(str(tag))
+    assert len(jobs) >= 45
+    _, parts = renderer.render(jobs, phi_seeds=list(range(len(jobs))), return_parts=True)
+    env_dev = parts["env"].cpu().numpy()
+    mask_dev = parts["mask"].cpu().numpy()
+    e_off, s_off = parts["env_off"], parts["sample_off"]
+    for j, tag in enumerate(tags):
+        want_row = g[f"{tag}_env_row"]
+        got_row = env_dev[e_off[j]:e_off[j + 1], 0].astype(np.float64)
+        assert got_row.shape == want_row.shape, tag
+        whole = want_row == np.round(want_row)
+        assert np.array_equal(got_row[whole], want_row[whole]), tag
+        assert np.max(np.abs(got_row - want_row), initial=0.0) <= 2e-7 * max(1.0, float(want_row.max(initial=0.0))), tag
+        # every bin of a frame is the same combination of source frames
+        assert np.array_equal(env_dev[e_off[j]:e_off[j + 1], 0], env_dev[e_off[j]:e_off[j + 1], 512]), tag
+        want_mask = np.asarray(g[f"{tag}_mask"], dtype=np.float32)
+        assert np.array_equal(mask_dev[s_off[j]:s_off[j + 1]], want_mask), tag
