@@ -67,7 +67,9 @@ class BatchCollector:
         with self._lock:
             self._queue.append(p)
             self._lock.notify_all()
-        p.done.wait()
+        while not p.done.wait(1.0):
+            if not self._thread.is_alive():
+                raise RuntimeError("the render worker has stopped")
         if p.error is not None:
             raise p.error
 
@@ -86,7 +88,15 @@ class BatchCollector:
                     return
                 self._lock.wait(self.window_s)            # let a burst accumulate
                 batch, self._queue = self._queue[:self.max_batch], self._queue[self.max_batch:]
-            self._render(batch)
+            try:
+                self._render(batch)
+            except BaseException as e:   # noqa: BLE001 - nothing may kill the worker: every waiter gets an answer
+                for p in batch:
+                    if not p.done.is_set():
+                        p.error = e if isinstance(e, Exception) else RuntimeError(f"render worker: {e!r}")
+                        p.done.set()
+                if not isinstance(e, Exception):
+                    raise
 
     def _render(self, batch):
         from . import core
@@ -119,7 +129,7 @@ class BatchCollector:
                 results, errors = {}, {}
                 for j in idxs:
                     try:
-                        results[j] = self.renderer.render([jobs[j]])[0]
+                        results[j] = self.renderer.render([jobs[j]], seed=int(np.random.SeedSequence().generate_state(1)[0]))[0]
                     except Exception as e:   # noqa: BLE001
                         errors[j] = e
             self.batches.append(len(idxs))
@@ -164,7 +174,10 @@ def make_handler(collector: BatchCollector):
     return RequestHandler
 
 
-def serve(port: int = 8572, collector: BatchCollector | None = None, host: str = ""):
+def serve(port: int = 8572, collector: BatchCollector | None = None, host: str = "127.0.0.1"):
+    """The resampler server.  The reference listens on every interface (SillySampler.py:1220-1224); a request names the file it
+    reads (a pickle-bearing .goofy) and the file it overwrites, so this one binds to the loopback address OpenUtau connects
+    to and leaves other interfaces to an explicit ``--host``."""
     collector = collector or BatchCollector()
     httpd = ThreadedHTTPServer((host, port), make_handler(collector))
     return httpd, collector
@@ -174,9 +187,10 @@ def main(argv=None) -> int:
     logging.basicConfig(format="%(message)s", level=logging.INFO)
     argv = list(sys.argv[1:] if argv is None else argv)
     logging.info(f"SillySampler {S.VERSION} (goofer_amd / MI355X)")
-    if not argv:
-        httpd, _ = serve()
-        print("Starting HTTP server on port 8572...")
+    if not argv or argv[0] == "--host":
+        host = argv[1] if len(argv) > 1 else "127.0.0.1"
+        httpd, _ = serve(host=host)
+        print(f"Starting HTTP server on port 8572 ({host or 'all interfaces'})...")
         httpd.serve_forever()
         return 0
     logging.info(f"Args: {argv} (count={len(argv)})")

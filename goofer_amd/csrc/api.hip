@@ -489,10 +489,25 @@ int goofer_debug_table(goofer_ctx *ctx, int which, float *host_out, int capacity
 // copy intermediate `which` of the last goofer_synth_batch to host memory (tests / debugging):
 // 0 frame_note 1 row_src 2 f0_scaled 3 pulse 4 S_harm 5 S_uv 6 S_breath 7 frames(last stem) 8 env_harm
 // 9 env_noise 10 mask_short 11 note_mag 12 note_peak 13 onset_cnt.  Returns the byte size.
+/* Synchronise the device and report what the asynchronous batch calls could not: a note whose pulse onsets did not fit its
+ * onset slots (n / 2 + 16 per note — more than one pulse per two samples; the onsets beyond were dropped). */
+int goofer_check(goofer_ctx *ctx)
+{
+    if (!ctx) return GOOFER_EINVAL;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (!ctx->ovf_flag) return GOOFER_OK;
+    int32_t v = 0;
+    HIP_TRY(ctx, hipMemcpy(&v, ctx->ovf_flag, sizeof(v), hipMemcpyDeviceToHost));
+    if (v != 0)
+        return goofer_fail(ctx, GOOFER_EINVAL, "note %d of the last batch has more pulse onsets than n / 2 + 16 (f0 above sr / 2?): "
+                           "the pulses beyond its onset slots were dropped", v - 1);
+    return GOOFER_OK;
+}
+
 int64_t goofer_debug_fetch(goofer_ctx *ctx, int which, void *host_out, int64_t capacity_bytes)
 {
     if (!ctx || which < 0 || which >= 16 || !ctx->dbg_ptr[which]) return GOOFER_EINVAL;
-    if (hipDeviceSynchronize() != hipSuccess) return GOOFER_EHIP;
+    if (int rc = goofer_check(ctx)) return rc;
     size_t nb = ctx->dbg_bytes[which] < (size_t)capacity_bytes ? ctx->dbg_bytes[which] : (size_t)capacity_bytes;
     if (hipMemcpy(host_out, ctx->dbg_ptr[which], nb, hipMemcpyDeviceToHost) != hipSuccess) return GOOFER_EHIP;
     return (int64_t)ctx->dbg_bytes[which];
@@ -648,6 +663,7 @@ int goofer_pulse_train(goofer_ctx *ctx, const float *f0, const int64_t *sample_o
     int32_t *oidx = a.take<int32_t>(total_samples / 2 + 16 * (size_t)n_notes + 16);
     int32_t *cnt = a.take<int32_t>(n_notes + 16);
     int32_t *ovf = a.take<int32_t>(16);
+    ctx->ovf_flag = ovf;
     if (!inc || !onsets || !oidx || !cnt || !ovf) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), st));
     return launch_pulse_train(ctx, f0, 1.0f, sample_off, n_notes, total_samples, pulse, inc, (onset_t *)onsets, oidx, cnt, ovf, st);
@@ -659,7 +675,7 @@ int goofer_gauss_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows
     if (!ctx) return GOOFER_EINVAL;
     if (radius < 0 || radius > 4096 || n_bins <= 0 || ld < n_bins) return goofer_fail(ctx, GOOFER_EINVAL, "bad gauss geometry");
     hipStream_t st = (hipStream_t)stream;
-    int rc = ensure_small(ctx, 65536);
+    int rc = ensure_small(ctx, std::max<size_t>(65536, (size_t)(2 * radius + 1) * sizeof(double) + 64));
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->small, taps, (2 * radius + 1) * sizeof(double), hipMemcpyHostToDevice, st));
     return launch_gauss_bins(ctx, in, out, rows, n_bins, ld, (const double *)ctx->small, radius, nullptr, st);
@@ -743,7 +759,7 @@ int goofer_gauss_bins_f64(goofer_ctx *ctx, const float *in, int ld, double *out,
     if (!ctx) return GOOFER_EINVAL;
     if (radius < 0 || radius > 4096 || ld < n_bins || ld64 < n_bins) return goofer_fail(ctx, GOOFER_EINVAL, "bad gauss geometry");
     hipStream_t st = (hipStream_t)stream;
-    int rc = ensure_small(ctx, 65536);
+    int rc = ensure_small(ctx, std::max<size_t>(65536, (size_t)(2 * radius + 1) * sizeof(double) + 64));
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->small, taps, (2 * radius + 1) * sizeof(double), hipMemcpyHostToDevice, st));
     return launch_gauss_rows64(ctx, in, ld, out, ld64, rows, n_bins, (const double *)ctx->small, radius, st);

@@ -48,6 +48,9 @@ int launch_gauss_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows
 {
     if (rows <= 0) return GOOFER_OK;
     size_t lds = sizeof(double) * (2 * radius + 1) + sizeof(float) * ROWS_PER_BLOCK * n_bins;
+    if (lds > 160 * 1024) return goofer_fail(ctx, GOOFER_EINVAL, "Gaussian radius %d with %d bins needs more than 160 KiB of LDS", radius, n_bins);
+    if (lds > 64 * 1024)
+        if (int arc = kernel_allow_max_lds(ctx, (const void *)k_gauss_bins)) return arc;
     hipLaunchKernelGGL(k_gauss_bins, dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), lds, st, in, out,
                        rows, n_bins, ld, d_taps, radius, row_src);
     LAUNCH_CHECK(ctx);

@@ -48,6 +48,7 @@ struct goofer_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_maps = nullptr;
     // goofer_render_batch: the pulse chain forks as soon as the assembled f0 exists, not when the synthesis call starts
     hipEvent_t ev_entry = nullptr, ev_f0 = nullptr, ev_f0s = nullptr;
+    const int32_t *ovf_flag = nullptr;     // device word of the last synth batch: 1 + index of a note whose onset slots overflowed
     const float2 *frame_picks = nullptr;   // per-frame (f0, mask) picks of the running goofer_synth_batch, or null
     bool early_req = false;           // set for the duration of one goofer_render_batch
     const float *early_f0 = nullptr;  // f0 array ev_f0 stands for (null: no event recorded)

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_pulse_onsets_wrap(const double *__restr
     flush();
     if (lane == 0) {
         onset_cnt[note] = cnt < cap ? cnt : cap;
-        if (cnt > cap) *overflow = 1;
+        if (cnt > cap) atomicMax(overflow, note + 1);          // reported at the next synchronising call (goofer_check)
     }
 }
 
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_pulse_onsets_scan(const float *__restri
     }
     if (lane == 0) {
         onset_cnt[note] = cnt < cap ? cnt : cap;
-        if (cnt > cap) *overflow = 1;
+        if (cnt > cap) atomicMax(overflow, note + 1);          // reported at the next synchronising call (goofer_check)
     }
 }
 

@@ -115,6 +115,10 @@ class Context:
         names = [self.lib.goofer_profile_stage_name_ex(self.h, i).decode() for i in range(18)]
         return {"steps": k, "ms": {nm: v for nm, v in zip(names, ms.tolist()) if nm}}
 
+    def check(self):
+        """Synchronise and raise what the asynchronous batch calls detected on the device (goofer_check)."""
+        self._check(self.lib.goofer_check(self.h))
+
     def set_option(self, name: str, value: int):
         self._check(self.lib.goofer_set_option(self.h, name.encode(), int(value)))
 

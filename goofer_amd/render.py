@@ -33,14 +33,35 @@ class Source:
 
     @staticmethod
     def from_pack(env_pack, f0, mask, formants, sr, ylen):
+        """Features as load_features returns them.  Everything the device kernels index by these sizes is checked here —
+        a short mask, a knot table that disagrees with its frequencies or an envelope with the wrong frame count would
+        otherwise shift every later note's offsets in the batch and read out of bounds on the device."""
+        sr, ylen = int(sr), int(ylen)
+        mask = np.asarray(mask, dtype=np.float32)
+        if sr <= 0 or ylen <= 0:
+            raise ValueError(f"bad features: sr {sr}, y_len {ylen}")
+        if mask.ndim != 1 or mask.size < ylen:
+            raise ValueError(f"bad features: voicing mask has {mask.size} samples, y_len is {ylen}")
         if not (isinstance(env_pack, dict) and env_pack.get("mode") == "knots"):
             env = np.asarray(env_pack)                        # dense [bins, T]: stored fp16, computed fp32 (GOOFER.py:306-333)
-            if env.ndim != 2:
+            if env.ndim != 2 or env.shape[0] < 3 or env.shape[1] < 1:
                 raise ValueError("features must be a knots dict or a [bins, T] envelope")
-            return Source(env.astype(np.float16), None, np.asarray(mask, dtype=np.float32), formants, int(sr), int(ylen),
-                          2 * env.shape[0] - 2)
-        return Source(np.asarray(env_pack["knot_vals_log"], dtype=np.float16), np.asarray(env_pack["hz_knots"], dtype=np.float32),
-                      np.asarray(mask, dtype=np.float32), formants, int(sr), int(ylen), int(env_pack["n_fft"]))
+            src = Source(env.astype(np.float16), None, mask, formants, sr, ylen, 2 * env.shape[0] - 2)
+        else:
+            knots = np.asarray(env_pack["knot_vals_log"], dtype=np.float16)
+            hz = np.asarray(env_pack["hz_knots"], dtype=np.float32)
+            if knots.ndim != 2 or hz.ndim != 1 or knots.shape[0] != hz.size or hz.size < 2 or knots.shape[1] < 1:
+                raise ValueError(f"bad features: knot table {knots.shape} against {hz.size} knot frequencies")
+            if int(env_pack["n_bins"]) != int(env_pack["n_fft"]) // 2 + 1:
+                raise ValueError("bad features: n_bins does not match n_fft")
+            src = Source(knots, hz, mask, formants, sr, ylen, int(env_pack["n_fft"]))
+        if not isinstance(formants, dict):
+            raise ValueError("bad features: formants must be a dict of tracks")
+        for k, v in formants.items():
+            a = np.asarray(v)
+            if a.ndim != 1 or not np.issubdtype(a.dtype, np.number):
+                raise ValueError(f"bad features: formant track {k!r} is not a numeric vector")
+        return src
 
 
 def _lerp_plan(sr, n_fft, hz):
@@ -85,7 +106,7 @@ class Renderer:
             return []
         prep = self.prepare(jobs, phi_seeds=phi_seeds)
         out = self.run(prep, seed=seed, keep_stems=return_parts)
-        torch.cuda.synchronize(self.ctx.device)
+        self.ctx.check()                                   # synchronises; raises if the device flagged a note
         mix = out["mix"].cpu().numpy()
         offs = prep["sample_off"]
         res = [mix[offs[i]:offs[i + 1]] for i in range(len(jobs))]
@@ -198,6 +219,9 @@ class Renderer:
         plans = []
         for src, req in jobs:
             T_src = src.knots.shape[1]
+            if T_src != 1 + src.ylen // self.hop:             # frames of the analysis STFT (GOOFER.py:355-370)
+                raise ValueError(f"bad features: envelope has {T_src} frames, y_len {src.ylen} at hop {self.hop} implies "
+                                 f"{1 + src.ylen // self.hop}")
             plans.append(S.plan_note(req, src.sr, src.ylen, T_src, src.formants, self.hop))
 
         # tables shared across notes

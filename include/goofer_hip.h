@@ -305,6 +305,10 @@ int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *assembly, const 
 
 /* gf.stretch_feature (GOOFER.py:597-616): np.interp(linspace(0,1,rows_out), linspace(0,1,rows_in), column) along
  * axis 0 of a [rows x n_cols] fp32 matrix with row strides ld_in / ld_out (n_cols = 1, ld = 1: a 1-D array). */
+/* Synchronise the device and report errors the asynchronous batch calls detect on the device (today: a note with more
+ * pulse onsets than its n / 2 + 16 onset slots, GOOFER.py:493 with f0 above sr / 2).  0, or GOOFER_EINVAL + goofer_last_error. */
+int goofer_check(goofer_ctx *ctx);
+
 /* gf.smooth_mask_ds (GOOFER.py:556-569) on its own, for a ragged batch of voicing masks (sample_off[n_notes + 1]): decimate by
  * 4, Gaussian max(1, sigma / 4) in fp64, np.interp back on float32 linspace grids -> out[total_samples] fp32.
  * fast_interp != 0 selects the interpolant form the stem walkers use (must give the same bits). */

@@ -77,3 +77,47 @@ def test_http_server_batches_concurrent_requests(tmp_path):
         httpd.shutdown()
         collector.close()
         ctx.close()
+
+
+def test_malformed_features_are_rejected_before_upload():
+    """A short mask, a knot table that disagrees with its frequencies, a non-numeric formant track: Source.from_pack refuses
+    them on the host (they would shift every later note's offsets in a device batch)."""
+    import numpy as np
+    import pytest
+    from goofer_amd import synthetic as syn
+    from goofer_amd.render import Source
+    src = syn.make_source(5, seconds=0.2)
+    ok = Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+    assert ok.knots.shape[1] == 1 + src["y_len"] // 256
+    with pytest.raises(ValueError, match="voicing mask"):
+        Source.from_pack(src["env_pack"], src["f0"], src["mask"][:-10], src["formants"], src["sr"], src["y_len"])
+    bad = dict(src["env_pack"])
+    bad["hz_knots"] = bad["hz_knots"][:-1]
+    with pytest.raises(ValueError, match="knot table"):
+        Source.from_pack(bad, src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+    with pytest.raises(ValueError, match="formant"):
+        Source.from_pack(src["env_pack"], src["f0"], src["mask"], {1: ["a", "b"]}, src["sr"], src["y_len"])
+    with pytest.raises(ValueError):
+        Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], 0)
+
+
+def test_server_binds_to_loopback_by_default_and_worker_survives_errors():
+    from goofer_amd import cli
+
+    class Boom:
+        def render(self, jobs, seed=0):
+            raise MemoryError("device gone")
+
+    col = cli.BatchCollector(renderer=Boom(), window_s=0.0)
+    httpd, _ = cli.serve(port=0, collector=col)
+    try:
+        assert httpd.server_address[0] == "127.0.0.1"
+        import pytest
+        with pytest.raises(Exception):
+            col.submit(["a.wav", "b.wav"] + ["0"] * 11)
+        with pytest.raises(Exception):                       # the worker thread is still there for the next request
+            col.submit(["a.wav", "b.wav"] + ["0"] * 11)
+        assert col._thread.is_alive()
+    finally:
+        httpd.server_close()
+        col.close()
