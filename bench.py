@@ -222,7 +222,7 @@ def main():
     # CSR geometry as the batch, HIP events on the launch stream (k_frame_note, ~5 us, rides along)
     o = wl.prep["offsets"]
     xin = torch.randn(wl.samples, device="cuda")
-    Sout = torch.empty((wl.frames, B + 1), dtype=torch.complex64, device="cuda")
+    Sout = torch.empty((wl.frames, (B + 15) & ~15), dtype=torch.complex64, device="cuda")      # 128-byte aligned rows
     for _ in range(2):
         ctx.rfft_frames(xin, o["d_s"], o["d_f"], wl.frames, out=Sout)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -261,7 +261,7 @@ struct arena {
 
 static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t samples, int64_t notes)
 {
-    size_t ldc = p.n_bins + 1, ld = (p.n_bins + 3) & ~3;
+    size_t ldc = spec_stride(p.n_bins), ld = (p.n_bins + 3) & ~3;
     size_t b = 0;
     auto add = [&](size_t bytes) { b += (bytes + 255) & ~(size_t)255; };
     add(frames * sizeof(int));                    // frame_note
@@ -1077,7 +1077,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     hipStream_t st = (hipStream_t)stream;
     ctx->frame_picks = nullptr;
     const int64_t F = b->total_frames, N = b->total_samples;
-    const int n = b->n_notes, ld = b->ld, ldc = p.n_bins + 1;
+    const int n = b->n_notes, ld = b->ld, ldc = spec_stride(p.n_bins);
 
     const bool jit_f0 = b->noise_f0 != nullptr, vol_vib = b->volume_vibrato != 0,
                jit_vol = vol_vib || (b->noise_vol_h != nullptr && b->noise_vol_b != nullptr);

@@ -80,6 +80,9 @@ struct goofer_ctx {
 };
 
 int goofer_fail(goofer_ctx *ctx, int code, const char *fmt, ...);
+// float2 slots per row of a [frames x bins] complex spectrum matrix: n_bins rounded up to 16 (128-byte aligned rows, so that
+// the framewise rFFT's 16-byte stores and every row-wise reader start on a cache-line boundary)
+static inline int spec_stride(int n_bins) { return (n_bins + 15) & ~15; }
 // opt a kernel in to the full 160 KiB of dynamic LDS on this handle's device (once per handle)
 int kernel_allow_max_lds(goofer_ctx *ctx, const void *fn, int bytes = 160 * 1024);
 // waves of `fn` (256-thread workgroups, `lds` bytes of dynamic LDS) resident on this handle's device at once

@@ -12,8 +12,11 @@
 #include "fft_core.h"
 
 // ---------------------------------------------------------------------------------------------
+#ifndef RFFT_WAVES
+#define RFFT_WAVES 4
+#endif
 template <int M>
-__global__ __launch_bounds__(256) void k_rfft_frames(const float *__restrict__ x, const int64_t *__restrict__ sample_off,
+__global__ __launch_bounds__(256, RFFT_WAVES) void k_rfft_frames(const float *__restrict__ x, const int64_t *__restrict__ sample_off,
                                                      const int64_t *__restrict__ frame_off, const int *__restrict__ frame_note,
                                                      int64_t total_frames, float2 *__restrict__ S, int ldc, int hop,
                                                      const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twh,
@@ -30,6 +33,7 @@ __global__ __launch_bounds__(256) void k_rfft_frames(const float *__restrict__ x
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2 *buf = bufs + wave * fft_cfg<M>::BUF;
     const int64_t f_begin = (int64_t)blockIdx.x * FRAMES_PER_BLOCK;
+    const bool wide = (ldc & 1) == 0 && ((uintptr_t)S & 15) == 0;      // rows 16-byte aligned: two bins per store
 
     // raw sample pairs of a frame (reflect-padded at the note ends); the next frame's are in flight during the FFT
     auto fetch = [&](int64_t f, float2 (&raw)[R]) {
@@ -55,39 +59,78 @@ __global__ __launch_bounds__(256) void k_rfft_frames(const float *__restrict__ x
             }
         }
     };
-    float2 nx[R];
-    if (f_begin + wave < total_frames) fetch(f_begin + wave, nx);
-
-    for (int i = wave; i < FRAMES_PER_BLOCK; i += WAVES_PER_BLOCK) {
-        const int64_t f = f_begin + i;
-        if (f >= total_frames) break;                 // wave-uniform
-        float2 v[R];
+    // One frame: window in place, transform, split, store.  `nf` = the frame whose sample pairs go into the same registers as
+    // soon as the transform has consumed them — issued BEFORE this frame's stores.  Loads and stores share one in-order
+    // counter (vmcnt): a wave that waits for a load also waits for every store issued before it, and a store completes
+    // microseconds after issue.  With two frames in flight and the loads ahead of the stores, the wait for frame i + 1's
+    // samples covers only stores that are two frames old — the kernel then runs at the larger of its load / compute time
+    // and its store time instead of their sum (0.33 -> 0.2x ms on the 1024-note batch).
+    auto frame = [&](int64_t f, float2 (&v)[R], int64_t nf) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            int m = lane + WAVE * r;
-            v[r] = make_float2(nx[r].x * win[2 * m], nx[r].y * win[2 * m + 1]);
+            const int m = lane + WAVE * r;
+            v[r] = make_float2(v[r].x * win[2 * m], v[r].y * win[2 * m + 1]);
         }
-        if (i + WAVES_PER_BLOCK < FRAMES_PER_BLOCK && f + WAVES_PER_BLOCK < total_frames) fetch(f + WAVES_PER_BLOCK, nx);
         wave_fft<M>(v, buf, tw, lane);
+        if (nf >= 0) fetch(nf, v);
 
         // even/odd split: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 e^{-i pi k/M} (Z[k] - conj Z[M-k])
         float2 *row = S + f * (int64_t)ldc;
+        auto split = [&](int k) {
+            const float2 zk = buf[lds_pad(k)];
+            const float2 zm = buf[lds_pad((M - k) & (M - 1))];
+            const float2 w = (k <= M / 2) ? twh[k] : make_float2(-twh[M - k].x, twh[M - k].y);
+            const float2 A = make_float2(zk.x + zm.x, zk.y - zm.y);
+            const float2 B = make_float2(zk.x - zm.x, zk.y + zm.y);
+            const float2 C = cmul(w, B);
+            return make_float2(0.5f * (A.x + C.y), 0.5f * (A.y - C.x));
+        };
+        if (wide) {
+            // The split reads stay conflict-free (bin k = lane + 64 r per lane); neighbouring lanes then trade one bin each
+            // (a 2 x 2 transpose over two r values, one quad-permute DPP move per dword), so that an even lane holds bins
+            // (k, k + 1) of row segment r and the odd lane beside it bins (k - 1, k) of segment r + 1: every lane issues
+            // 16-byte stores, on 128-byte aligned rows.
+            const bool odd = lane & 1;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            int k = lane + WAVE * r;
-            float2 zk = buf[lds_pad(k)];
-            float2 zm = buf[lds_pad((M - k) & (M - 1))];
-            float2 w = (k <= M / 2) ? twh[k] : make_float2(-twh[M - k].x, twh[M - k].y);
-            float2 A = make_float2(zk.x + zm.x, zk.y - zm.y);
-            float2 B = make_float2(zk.x - zm.x, zk.y + zm.y);
-            float2 C = cmul(w, B);
-            row[k] = make_float2(0.5f * (A.x + C.y), 0.5f * (A.y - C.x));
+            for (int r = 0; r < R; r += 2) {
+                const float2 xa = split(lane + WAVE * r), xb = split(lane + WAVE * (r + 1));
+                const float2 send = odd ? xa : xb;
+                float2 recv;
+                recv.x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send.x), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+                recv.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send.y), 0xB1, 0xF, 0xF, false));
+                const float4 o = odd ? make_float4(recv.x, recv.y, xb.x, xb.y) : make_float4(xa.x, xa.y, recv.x, recv.y);
+                const int k0 = odd ? lane - 1 + WAVE * (r + 1) : lane + WAVE * r;
+                *reinterpret_cast<float4 *>(row + k0) = o;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int k = lane + WAVE * r;
+                row[k] = split(k);
+            }
         }
         if (lane == 0) {
             float2 z0 = buf[0];
             row[M] = make_float2(z0.x - z0.y, 0.f);
         }
         wave_lds_sync();
+    };
+
+    // frames f_begin + wave + 4 q of this wave, q = 0 .. FRAMES_PER_BLOCK / 4 - 1, two at a time in registers A and B
+    constexpr int PER_WAVE = FRAMES_PER_BLOCK / WAVES_PER_BLOCK;
+    static_assert(PER_WAVE % 2 == 0, "frames per wave are processed in pairs");
+    auto frame_id = [&](int q) -> int64_t {
+        const int64_t f = f_begin + wave + (int64_t)WAVES_PER_BLOCK * q;
+        return (q < PER_WAVE && f < total_frames) ? f : -1;
+    };
+    float2 A[R], B[R];
+    if (frame_id(0) >= 0) fetch(frame_id(0), A);
+    if (frame_id(1) >= 0) fetch(frame_id(1), B);
+    for (int q = 0; q < PER_WAVE; q += 2) {
+        if (frame_id(q) < 0) break;                   // wave-uniform
+        frame(frame_id(q), A, frame_id(q + 2));
+        if (frame_id(q + 1) < 0) break;
+        frame(frame_id(q + 1), B, frame_id(q + 3));
     }
 }
 

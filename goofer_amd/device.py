@@ -18,6 +18,11 @@ def row_stride(n_bins: int) -> int:
     return (n_bins + 3) & ~3
 
 
+def spec_stride(n_bins: int) -> int:
+    """complex64 slots per row of a [frames x bins] spectrum matrix: 128-byte aligned rows (csrc/common.h:spec_stride)."""
+    return (n_bins + 15) & ~15
+
+
 class GooferError(RuntimeError):
     pass
 
@@ -136,8 +141,9 @@ class Context:
     def rfft_frames(self, x, sample_off, frame_off, total_frames: int, out=None):
         """x fp32 [N_total] -> complex64 [F_total, n_bins] (gf.stft per note)."""
         nb = self.n_bins
-        ldc = nb + 1
-        S = out if out is not None else torch.empty((total_frames, ldc), dtype=torch.complex64, device=self.device)
+        if out is None:
+            out = torch.empty((total_frames, spec_stride(nb)), dtype=torch.complex64, device=self.device)
+        S, ldc = out, out.stride(0)
         self._check(self.lib.goofer_rfft_frames(self.h, _ptr(x), _ptr(sample_off), _ptr(frame_off), sample_off.numel() - 1,
                                                 total_frames, _ptr(S), ldc, self._stream()))
         return S[:, :nb]

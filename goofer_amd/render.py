@@ -216,20 +216,27 @@ class Renderer:
         ctx.plan(sr, n_fft, self.hop)
         B, ld = ctx.n_bins, row_stride(ctx.n_bins)
         n = len(jobs)
-        plans = []
         for src, req in jobs:
             T_src = src.knots.shape[1]
             if T_src != 1 + src.ylen // self.hop:             # frames of the analysis STFT (GOOFER.py:355-370)
                 raise ValueError(f"bad features: envelope has {T_src} frames, y_len {src.ylen} at hop {self.hop} implies "
                                  f"{1 + src.ylen // self.hop}")
-            plans.append(S.plan_note(req, src.sr, src.ylen, T_src, src.formants, self.hop))
+        # notes that share cut points / lengths share one index plan; their formant tracks are processed as one array
+        plans = S.plan_notes([(req, src.sr, src.ylen, src.knots.shape[1], src.formants) for src, req in jobs], self.hop)
 
         # tables shared across notes
         lerp_keys, tilt_keys, fw_keys, es_keys = {}, {}, {}, {}
         lerp_tabs, tilt_tabs, fw_tabs, es_taps, es_off = [], [], [], [], 0
         P = np.zeros(n, dtype=_lib.NOTE_PLAN)
+        col = {k: [] for k in ("knot_off", "K", "lerp_plan", "n_src_rows", "reverse", "row_lo", "n_edit", "edit_off", "tilt", "es_mode",
+                               "es_amount", "es_taps_off", "es_radius", "fw_plan", "tap_off", "env_off", "n_out_rows", "env_f64", "fst",
+                               "src_sample_off", "ylen", "out_sample_off", "n_out", "n_pre", "s_pre", "s_tail", "tail_len",
+                               "want_samples", "n_before_vel", "vel_active", "vel_factor", "pre_new", "force_voiced", "bend_off", "n_bend",
+                               "pitch_m", "pitch_t", "tick_dt", "fry_hz", "fry_dir", "fry_const_lo", "fry_const_hi", "fry_glide_lo",
+                               "fry_glide_hi", "fry_a", "fry_b", "fry_fade", "pd_on", "pd_base")}
         knots_cat, mask_cat, bend_cat, tapi_cat, tapw_cat, fst_cat, F_cat = [], [], [], [], [], [], []
         k_off = e_off = t_off = s_off = o_off = b_off = 0
+        hz_ids = {}
         for i, ((src, req), p) in enumerate(zip(jobs, plans)):
             K = src.knots.shape[0]
             if src.hz_knots is None:                           # dense source: rows are the envelope, no lerp plan
@@ -237,63 +244,68 @@ class Renderer:
                     raise ValueError("dense envelope has %d bins, the plan has %d" % (K, B))
                 lp = -1
             else:
-                key = (K, src.hz_knots.tobytes())
-                if key not in lerp_keys:
-                    lerp_keys[key] = len(lerp_tabs)
-                    lerp_tabs.append(_lerp_plan(sr, n_fft, src.hz_knots))
-                lp = lerp_keys[key]
-            q = P[i]
-            q["knot_off"], q["K"], q["lerp_plan"], q["n_src_rows"] = k_off, K, lp, src.knots.shape[1]
-            q["reverse"] = int(req.reverse)
-            q["row_lo"], q["n_edit"], q["edit_off"] = p.row_lo, p.row_hi - p.row_lo, e_off
-            q["tilt"] = -1
+                lp = hz_ids.get(id(src.hz_knots))              # the same array object again (one voicebank): no hashing of its bytes
+                if lp is None:
+                    key = (K, src.hz_knots.tobytes())
+                    if key not in lerp_keys:
+                        lerp_keys[key] = len(lerp_tabs)
+                        lerp_tabs.append(_lerp_plan(sr, n_fft, src.hz_knots))
+                    lp = hz_ids[id(src.hz_knots)] = lerp_keys[key]
+            c = col
+            c["knot_off"].append(k_off); c["K"].append(K); c["lerp_plan"].append(lp); c["n_src_rows"].append(src.knots.shape[1])
+            c["reverse"].append(int(req.reverse))
+            c["row_lo"].append(p.row_lo); c["n_edit"].append(p.row_hi - p.row_lo); c["edit_off"].append(e_off)
+            tilt = -1
             if req.brightness_env != 1.0:
                 tk = float(req.brightness_env)
                 if tk not in tilt_keys:
                     tilt_keys[tk] = len(tilt_tabs)
                     tilt_tabs.append(_tilt(sr, B, req.brightness_env))
-                q["tilt"] = tilt_keys[tk]
-            q["es_mode"] = 0
+                tilt = tilt_keys[tk]
+            c["tilt"].append(tilt)
+            es_mode, es_amount, es_toff, es_rad = 0, 0.0, 0, 0
             if req.env_shape != 0.0:
                 s_ = abs(req.env_shape)
-                mode = 1 if req.env_shape < 0.0 else 2
-                sigma = (1.0 + 6.0 * s_) if mode == 1 else (0.8 + 4.0 * s_)
-                ek = (mode, sigma)
+                es_mode = 1 if req.env_shape < 0.0 else 2
+                sigma = (1.0 + 6.0 * s_) if es_mode == 1 else (0.8 + 4.0 * s_)
+                ek = (es_mode, sigma)
                 if ek not in es_keys:
                     taps = S.gauss_taps(sigma)
                     es_keys[ek] = (es_off, (taps.size - 1) // 2)
                     es_taps.append(taps)
                     es_off += taps.size
-                q["es_mode"], q["es_amount"] = mode, 5 * s_
-                q["es_taps_off"], q["es_radius"] = es_keys[ek]
-            q["fw_plan"] = -1
+                es_amount = 5 * s_
+                es_toff, es_rad = es_keys[ek]
+            c["es_mode"].append(es_mode); c["es_amount"].append(es_amount); c["es_taps_off"].append(es_toff); c["es_radius"].append(es_rad)
+            fw = -1
             if req.formant_width != 0.0:
                 fk = float(req.formant_width)
                 if fk not in fw_keys:
                     fw_keys[fk] = len(fw_tabs)
                     fw_tabs.append(_fw_plan(B, req.formant_width))
-                q["fw_plan"] = fw_keys[fk]
+                fw = fw_keys[fk]
+            c["fw_plan"].append(fw)
             T_env = p.tap_idx.shape[0]
-            q["tap_off"], q["env_off"], q["n_out_rows"], q["env_f64"] = t_off, t_off, T_env, int(p.env_f64)
-            q["fst"] = req.formant_strength
-            q["src_sample_off"], q["ylen"], q["out_sample_off"] = s_off, src.ylen, o_off
-            q["n_out"], q["n_pre"], q["s_pre"], q["s_tail"] = p.n_out, p.n_pre, p.extra["s_pre"], p.extra["s_tail"]
-            q["tail_len"], q["want_samples"], q["n_before_vel"] = p.tail_len, p.want_samples, p.n_before_vel
-            q["vel_active"], q["vel_factor"] = int(p.vel_active), p.vel_factor
-            q["pre_new"] = max(1, int(round(p.n_pre * p.vel_factor))) if p.vel_active else p.n_pre
-            q["force_voiced"] = int(req.force_voiced)
-            q["bend_off"], q["n_bend"] = b_off, len(req.bend)
-            q["pitch_m"] = float(req.pitch_m)
+            c["tap_off"].append(t_off); c["env_off"].append(t_off); c["n_out_rows"].append(T_env); c["env_f64"].append(int(p.env_f64))
+            c["fst"].append(req.formant_strength)
+            c["src_sample_off"].append(s_off); c["ylen"].append(src.ylen); c["out_sample_off"].append(o_off)
+            c["n_out"].append(p.n_out); c["n_pre"].append(p.n_pre); c["s_pre"].append(p.extra["s_pre"]); c["s_tail"].append(p.extra["s_tail"])
+            c["tail_len"].append(p.tail_len); c["want_samples"].append(p.want_samples); c["n_before_vel"].append(p.n_before_vel)
+            c["vel_active"].append(int(p.vel_active)); c["vel_factor"].append(p.vel_factor)
+            c["pre_new"].append(max(1, int(round(p.n_pre * p.vel_factor))) if p.vel_active else p.n_pre)
+            c["force_voiced"].append(int(req.force_voiced))
+            c["bend_off"].append(b_off); c["n_bend"].append(len(req.bend))
+            c["pitch_m"].append(float(req.pitch_m))
             tc = req.flags.get("t", 0)
-            q["pitch_t"] = (tc / 100.0) if tc else 0.0
-            q["tick_dt"] = 60.0 / (req.tempo * 96.0)
+            c["pitch_t"].append((tc / 100.0) if tc else 0.0)
+            c["tick_dt"].append(60.0 / (req.tempo * 96.0))
             fx = p.extra
-            q["fry_hz"], q["fry_dir"] = req.fry_hz, fx["fry_dir"]
-            q["fry_const_lo"], q["fry_const_hi"] = fx["fry_const"]
-            q["fry_glide_lo"], q["fry_glide_hi"] = fx["fry_glide"]
-            (q["fry_a"], q["fry_b"]), q["fry_fade"] = fx["fry_mask"], fx["fry_fade"]
-            q["pd_on"], q["pd_base"] = int(req.pitch_dyn != 0.0), req.pitch_m + ((req.flags.get("t", 0) or 0) / 100.0)
-            knots_cat.append(np.ascontiguousarray(src.knots.T))
+            c["fry_hz"].append(req.fry_hz); c["fry_dir"].append(fx["fry_dir"])
+            c["fry_const_lo"].append(fx["fry_const"][0]); c["fry_const_hi"].append(fx["fry_const"][1])
+            c["fry_glide_lo"].append(fx["fry_glide"][0]); c["fry_glide_hi"].append(fx["fry_glide"][1])
+            c["fry_a"].append(fx["fry_mask"][0]); c["fry_b"].append(fx["fry_mask"][1]); c["fry_fade"].append(fx["fry_fade"])
+            c["pd_on"].append(int(req.pitch_dyn != 0.0)); c["pd_base"].append(req.pitch_m + ((req.flags.get("t", 0) or 0) / 100.0))
+            knots_cat.append(src.knots)
             mask_cat.append(src.mask[:src.ylen])
             semis = req.bend.astype(np.float64) / 100.0 + req.pitch_m      # SillySampler.py:838-846
             if tc:
@@ -309,6 +321,8 @@ class Renderer:
             s_off += src.ylen
             o_off += p.n_out
             b_off += len(req.bend)
+        for name, vals in col.items():                         # one column assignment per field instead of 45 scalar stores per note
+            P[name] = vals
         if any(pl.n_out <= 0 for pl in plans):
             raise ValueError("a note assembles to zero samples")
 
@@ -317,7 +331,7 @@ class Renderer:
 
         d = dict(
             notes=ctx.tensor(P.view(np.uint8)),
-            knots=ctx.tensor(np.concatenate([k.reshape(-1) for k in knots_cat]).view(np.uint16)),
+            knots=ctx.tensor(np.concatenate([np.ascontiguousarray(k.T).reshape(-1) for k in knots_cat]).view(np.uint16)),
             lerp_idx=cat_tab(lerp_tabs, 0, np.int32), lerp_w0=cat_tab(lerp_tabs, 1, np.float32), lerp_w1=cat_tab(lerp_tabs, 2, np.float32),
             tilts=ctx.tensor(np.concatenate(tilt_tabs)) if tilt_tabs else None,
             es_taps=ctx.tensor(np.concatenate(es_taps)) if es_taps else None,
@@ -344,21 +358,20 @@ class Renderer:
                           any_fry=int(any_fry))
         # per-note synthesize parameters
         par = default_params(n)
-        for i, (_, req) in enumerate(jobs):
-            par[i]["formant_shift"] = req.formant_shift
-            par[i]["f_shift"] = req.f_shift
-            par[i]["normalize"] = req.normalize
-            par[i]["mix_harm"], par[i]["mix_breath"], par[i]["mix_unvoiced"] = req.harmonic_mix, req.breathiness_mix, req.unvoiced_mix
-            par[i]["volume"] = req.volume
-            nid = int(note_ids[i]) if note_ids is not None else i      # Philox stream of the note: its id, not its batch position
-            par[i]["seed"] = [nid & 0xFFFFFFFF, (nid >> 32) & 0xFFFFFFFF]
-            if req.f0_jitter:
-                par[i]["f0_jitter"] = req.f0_jitter_strength
-            if req.volume_jitter:
-                par[i]["vol_jitter_harm"] = req.volume_jitter_strength
-                par[i]["vol_jitter_breath"] = req.volume_jitter_strength * 2
-            if req.add_subharm:
-                par[i]["subharm_weight"] = req.subharm_weight
+        reqs = [r for _, r in jobs]
+        par["formant_shift"] = [r.formant_shift for r in reqs]
+        par["f_shift"] = [r.f_shift for r in reqs]
+        par["normalize"] = [r.normalize for r in reqs]
+        par["mix_harm"] = [r.harmonic_mix for r in reqs]
+        par["mix_breath"] = [r.breathiness_mix for r in reqs]
+        par["mix_unvoiced"] = [r.unvoiced_mix for r in reqs]
+        par["volume"] = [r.volume for r in reqs]
+        nids = np.asarray(note_ids if note_ids is not None else range(n), dtype=np.uint64)   # Philox stream of the note: its id, not its batch position
+        par["seed"] = np.stack([nids & np.uint64(0xFFFFFFFF), (nids >> np.uint64(32)) & np.uint64(0xFFFFFFFF)], axis=1)
+        par["f0_jitter"] = [r.f0_jitter_strength if r.f0_jitter else 0.0 for r in reqs]
+        par["vol_jitter_harm"] = [r.volume_jitter_strength if r.volume_jitter else 0.0 for r in reqs]
+        par["vol_jitter_breath"] = [r.volume_jitter_strength * 2 if r.volume_jitter else 0.0 for r in reqs]
+        par["subharm_weight"] = [r.subharm_weight if r.add_subharm else 0.0 for r in reqs]
         lens = [p.n_out for p in plans]
         # sh / sr draws come from the legacy global np.random stream, note by note, in the reference's order
         # (f0 jitter, harmonic volume, breath volume: GOOFER.py:666, 653)
@@ -375,12 +388,18 @@ class Renderer:
                 noise_vol = (ctx.tensor(np.concatenate(nh)), ctx.tensor(np.concatenate(nb)))
         # sample-domain post chain: per-note table (offsets into the extra synth calls are filled in by run())
         post = np.zeros(n, dtype=_lib.POST_NOTE)
+        post["su_off"] = post["sj_off"] = post["sa_off"] = -1
+        post["su_gain"] = [r.subharm_gain for r in reqs]
+        post["sj_mix"] = [r.growl_mix for r in reqs]
+        post["sa_mix"] = [r.aperiodic_mix for r in reqs]
+        post["sd_strength"] = [r.sd_strength for r in reqs]
+        post["tension"] = [r.tension for r in reqs]
+        post["pitch_dyn"] = [r.pitch_dyn for r in reqs]
+        post["fry_a"] = [pl.extra["fry_mask"][0] for pl in plans]
+        post["fry_b"] = [pl.extra["fry_mask"][1] for pl in plans]
+        post["fry_fade"] = [pl.extra["fry_fade"] for pl in plans]
         growl = {}
-        for i, ((_, req), pl) in enumerate(zip(jobs, plans)):
-            post[i]["su_off"] = post[i]["sj_off"] = post[i]["sa_off"] = -1
-            post[i]["su_gain"], post[i]["sj_mix"], post[i]["sa_mix"] = req.subharm_gain, req.growl_mix, req.aperiodic_mix
-            post[i]["sd_strength"], post[i]["tension"], post[i]["pitch_dyn"] = req.sd_strength, req.tension, req.pitch_dyn
-            (post[i]["fry_a"], post[i]["fry_b"]), post[i]["fry_fade"] = pl.extra["fry_mask"], pl.extra["fry_fade"]
+        for i, (req, pl) in enumerate(zip(reqs, plans)):
             if req.growl_mix > 0.0:                            # 'sj': f0 * 0.5 * 2^N(0, mix^2), a fresh generator per call  :1063-1065
                 rng = np.random.default_rng(phi_seeds[i]) if phi_seeds is not None else np.random.default_rng()
                 growl[i] = 0.5 * (2.0 ** rng.normal(loc=0.0, scale=req.growl_mix ** 2, size=pl.n_out))

@@ -53,7 +53,7 @@ def _run(ctx, envs, f0s, masks, par, n, seed, stems):
         if not stems:
             F = sum(e.shape[0] for e in envs)
             for name in ("S_uv", "S_breath"):
-                res[name] = ctx.debug_fetch(name).reshape(F, NB + 1)[:, :NB].copy()
+                res[name] = ctx.debug_fetch(name).reshape(F, (NB + 15) & ~15)[:, :NB].copy()      # rows are 128-byte aligned
     finally:
         ctx.set_option("stems", 1)
     return res
