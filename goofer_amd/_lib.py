@@ -139,6 +139,7 @@ EXPORTS = {
     "goofer_profile_stage_name_ex": (C.c_char_p, [C.c_void_p, C.c_int]),
     "goofer_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "goofer_check": (C.c_int, [C.c_void_p]),
+    "goofer_host_gauss_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "goofer_smooth_mask_ds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p,
                                         C.c_void_p]),
 }

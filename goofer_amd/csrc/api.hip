@@ -489,6 +489,37 @@ int goofer_debug_table(goofer_ctx *ctx, int which, float *host_out, int capacity
 // copy intermediate `which` of the last goofer_synth_batch to host memory (tests / debugging):
 // 0 frame_note 1 row_src 2 f0_scaled 3 pulse 4 S_harm 5 S_uv 6 S_breath 7 frames(last stem) 8 env_harm
 // 9 env_noise 10 mask_short 11 note_mag 12 note_peak 13 onset_cnt.  Returns the byte size.
+/* Host helper of the note planner (goofer_amd/sampler.py, SillySampler.py:264-283): Gaussian FIR along the rows of a small
+ * fp64 matrix with numpy 'reflect' padding, accumulated tap by tap in ascending order (product rounded, then added: the
+ * arithmetic of the planner's numpy loop, so the tracks are the same bits either way).  Pure CPU code: no device is touched. */
+int goofer_host_gauss_rows(const double *x, int64_t rows, int T, const double *taps, int radius, double *out)
+{
+    if (!x || !taps || !out || rows < 0 || T <= 0 || radius < 0) return GOOFER_EINVAL;
+    const int nt = 2 * radius + 1;
+    std::vector<int> idx((size_t)T + 2 * radius);
+    const int period = T > 1 ? 2 * (T - 1) : 1;
+    for (int q = -radius; q < T + radius; ++q) {              // numpy 'reflect' as a periodic map (T == 1: 'edge')
+        int m = T > 1 ? ((q % period) + period) % period : 0;
+        idx[q + radius] = m < T ? m : period - m;
+    }
+    std::vector<double> pad((size_t)T + 2 * radius);
+    for (int64_t r = 0; r < rows; ++r) {
+        const double *xr = x + r * T;
+        double *o = out + r * T;
+        for (int q = 0; q < T + 2 * radius; ++q) pad[q] = xr[idx[q]];
+        const double *pp = pad.data();
+        for (int t = 0; t < T; ++t) o[t] = taps[0] * pp[t];
+        for (int j = 1; j < nt; ++j) {                       // tap-outer: every o[t] still sums its taps in ascending order
+            const double kj = taps[j];
+            for (int t = 0; t < T; ++t) {
+                const double prod = kj * pp[t + j];
+                o[t] = o[t] + prod;
+            }
+        }
+    }
+    return GOOFER_OK;
+}
+
 /* Synchronise the device and report what the asynchronous batch calls could not: a note whose pulse onsets did not fit its
  * onset slots (n / 2 + 16 per note — more than one pulse per two samples; the onsets beyond were dropped). */
 int goofer_check(goofer_ctx *ctx)

@@ -366,13 +366,23 @@ def _gauss_taps_cached(sigma: float):
 
 
 def _gauss_tracks(x, sigma):
-    """gaussian_filter1d along the last axis of a [rows, T] array of short tracks (numpy 'reflect' padding), fp64.  Written as
-    a loop over the taps on whole columns: every row gets the same additions in the same order whatever the number of rows,
-    so a note's tracks are the same bits planned alone or inside a batch."""
+    """gaussian_filter1d along the last axis of a [rows, T] array of short tracks (numpy 'reflect' padding), fp64: the taps are
+    applied in ascending order, product then sum, row by row — every row gets the same additions in the same order whatever
+    the number of rows, so a note's tracks are the same bits planned alone or inside a batch.  The loop itself lives in the
+    C-ABI library (goofer_host_gauss_rows, host code); without the library the same arithmetic runs as numpy column ops."""
     k = _gauss_taps_cached(float(sigma))
     r = (k.size - 1) // 2
-    x = np.asarray(x, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
     T = x.shape[-1]
+    if x.size == 0:
+        return x.copy()
+    lib = _host_lib()
+    if lib is not None:
+        out = np.empty_like(x)
+        rc = lib.goofer_host_gauss_rows(x.ctypes.data, x.size // T, T, k.ctypes.data, r, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("goofer_host_gauss_rows failed (%d)" % rc)
+        return out
     pad = np.pad(x, [(0, 0)] * (x.ndim - 1) + [(r, r)], mode="reflect")
     out = np.empty(x.shape, dtype=np.float64)
     flat_p, flat_o = pad.reshape(-1, pad.shape[-1]), out.reshape(-1, T)
@@ -388,19 +398,35 @@ def _gauss_tracks(x, sigma):
     return out
 
 
+_HOST_LIB = [False]
+
+
+def _host_lib():
+    """The C-ABI library's host helpers, if the library is built (the planner itself must stay usable without it)."""
+    if _HOST_LIB[0] is False:
+        try:
+            from . import _lib
+            _HOST_LIB[0] = _lib.load()
+        except Exception:
+            _HOST_LIB[0] = None
+    return _HOST_LIB[0]
+
+
 def _fit_len(a, T):
     """pad_trim_to_len along the last axis (edge-pad / truncate, GOOFER.py:64-70); rows of zero length stay what the caller made them."""
     L = a.shape[-1]
     if L >= T:
         return a[..., :T]
-    return np.pad(a, [(0, 0)] * (a.ndim - 1) + [(0, T - L)], mode="edge")
+    if L == 0:
+        return np.pad(a, [(0, 0)] * (a.ndim - 1) + [(0, T)], mode="edge")   # numpy's own error for an empty edge pad
+    return np.concatenate([a, np.repeat(a[..., -1:], T - L, axis=-1)], axis=-1)
 
 
-def _sanitize_tracks(tracks, T, sr, min_hz, sigma_frames=4):
-    """SillySampler.py:264-283 for [rows, L] tracks at once: out-of-range / non-finite values are re-interpolated from the good
-    ones (row by row: the repair is data dependent and rare), all-bad rows become 300 Hz, then the sigma-4 blur.
-    Keeps the reference's aliasing: when ``tracks`` is already fp32 and at least T long, the repair edits the caller's array in
-    place (those repaired values reach synthesize); an all-bad row is replaced in a fresh array and stays as it was."""
+def _repair_tracks(tracks, T, sr, min_hz):
+    """SillySampler.py:264-279 for [rows, L] tracks at once: out-of-range / non-finite values are re-interpolated from the good
+    ones (row by row: the repair is data dependent and rare), all-bad rows become 300 Hz.  Keeps the reference's aliasing:
+    when ``tracks`` is already fp32 and at least T long, the repair edits the caller's array in place (those repaired values
+    reach synthesize); an all-bad row is replaced in a fresh array and stays as it was."""
     max_hz = sr * 0.48
     x = np.asarray(tracks, dtype=np.float32)
     x = _fit_len(x, T)                                        # a view when long enough, a padded copy otherwise
@@ -416,7 +442,12 @@ def _sanitize_tracks(tracks, T, sr, min_hz, sigma_frames=4):
     if all_bad:
         x = x.copy()
         x[all_bad] = 300.0
-    return _gauss_tracks(x, sigma_frames).astype(np.float32)
+    return x
+
+
+def _sanitize_tracks(tracks, T, sr, min_hz, sigma_frames=4):
+    """sanitize_smooth_formant (SillySampler.py:264-283): repair, then the sigma-4 blur."""
+    return _gauss_tracks(_repair_tracks(tracks, T, sr, min_hz), sigma_frames).astype(np.float32)
 
 
 def _interp_rows(x_old, y, x_new):
@@ -583,13 +614,14 @@ def _plan_tracks(g: NotePlan, tracks: list):
         canon.append(_fit_len(a, T_target) if a.shape[1] else a)
     while len(canon) < 4:
         canon.append(None)
-    fst = np.zeros((n_notes, T_env, 4), dtype=np.float32)
     F = np.zeros((n_notes, T_env, 4), dtype=np.float64)
+    rep = np.empty((4, n_notes, T_env), dtype=np.float32)
     for c, lo in enumerate((120.0, 300.0, 1500.0, 2000.0)):
         a = canon[c]
-        fst[:, :, c] = _sanitize_tracks(a if a is not None and a.shape[1] else np.zeros((n_notes, T_env), dtype=np.float32), T_env, sr, lo)
+        rep[c] = _repair_tracks(a if a is not None and a.shape[1] else np.zeros((n_notes, T_env), dtype=np.float32), T_env, sr, lo)
         if a is not None and a.shape[1]:
-            F[:, :, c] = _fit_len(np.asarray(a, dtype=np.float64), T_env)
+            F[:, :, c] = _fit_len(np.asarray(a, dtype=np.float64), T_env)      # after the repair: it may have edited `a` in place
+    fst = np.ascontiguousarray(np.moveaxis(_gauss_tracks(rep, 4).astype(np.float32), 0, 2))   # one blur call for the four formants
     return F, fst
 
 
@@ -615,6 +647,9 @@ def _finish_plan(g: NotePlan, req: Request, F, fst) -> NotePlan:
     return p
 
 
+_GEO_CACHE = {}
+
+
 def plan_notes(jobs, hop: int = HOP) -> list:
     """``plan_note`` for a batch: jobs = [(request, sr, ylen, n_src_frames, formants)].  Notes that agree on the geometry key
     (a render job repeats few lengths / cut points) share one index plan — taps, cut points, sample counts are the same
@@ -626,7 +661,13 @@ def plan_notes(jobs, hop: int = HOP) -> list:
     plans = [None] * len(jobs)
     for idxs in groups.values():
         req0, sr, ylen, T_src, _ = jobs[idxs[0]]
-        g = _plan_geometry(req0, sr, ylen, T_src, hop)
+        key = _geometry_key(req0, sr, ylen, T_src, hop)
+        g = _GEO_CACHE.get(key)
+        if g is None:                                         # index plans are reused across calls: a song repeats its note lengths
+            g = _plan_geometry(req0, sr, ylen, T_src, hop)
+            if len(_GEO_CACHE) >= 8192:
+                _GEO_CACHE.clear()
+            _GEO_CACHE[key] = g
         arrs = _track_arrays([jobs[i][4] for i in idxs])
         if arrs is None:                                      # ragged / oddly keyed formant dicts: note by note
             for i in idxs:

@@ -305,6 +305,10 @@ int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *assembly, const 
 
 /* gf.stretch_feature (GOOFER.py:597-616): np.interp(linspace(0,1,rows_out), linspace(0,1,rows_in), column) along
  * axis 0 of a [rows x n_cols] fp32 matrix with row strides ld_in / ld_out (n_cols = 1, ld = 1: a 1-D array). */
+/* Host-side helper of the note planner (no device involved): Gaussian FIR along the rows of an fp64 [rows x T] matrix, numpy
+ * 'reflect' padding, taps applied in ascending order — the sigma-4 smoothing of the formant tracks, SillySampler.py:264-283. */
+int goofer_host_gauss_rows(const double *x, int64_t rows, int T, const double *taps, int radius, double *out);
+
 /* Synchronise the device and report errors the asynchronous batch calls detect on the device (today: a note with more
  * pulse onsets than its n / 2 + 16 onset slots, GOOFER.py:493 with f0 above sr / 2).  0, or GOOFER_EINVAL + goofer_last_error. */
 int goofer_check(goofer_ctx *ctx);
