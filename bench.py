@@ -5,15 +5,22 @@
 
 One process per GPU (the driver launches N>1 through torch.distributed.run; RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* come from the environment).  A *step* is one pass of the hot path
-(goofer_synth_batch: pulse train -> framewise rFFT -> envelope warps / shaping -> 3x irFFT+OLA ->
-gains -> peak normalise -> V/B/U mix) over one ragged batch of synthetic notes already resident in
-HBM.  Notes are independent, so ranks shard by note id with no data-path collective (weak scaling:
+(goofer_render_batch: note assembly, pulse train, then the stem walkers — noise stems and the harmonic stem each from
+their inputs to finished samples — and the per-note finish: 1 / max|S|, peak normalise, V/B/U mix) over one ragged batch
+of synthetic notes already resident in HBM.  Notes are independent, so ranks shard by note id with no data-path collective (weak scaling:
 `--notes` per GPU); the only collectives are the barriers and the MAX of the elapsed time.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      HIP-event duration of the dominant kernel inside the timed steps vs its algorithmic bytes
   roofline_fft  the same for the framewise rFFT kernel (the kernel BASELINE's 40 % target names)
-  cpu_baseline  the numpy/C oracle (a port of the reference's CPU path) timed on this box's host cores
+  roofline_step the whole step against its end-to-end algorithmic bytes and the HBM traffic the counter passes measured
+  cpu_baseline  the numpy/C oracle (a port of the reference's CPU path) timed on this box's host cores: one thread, and a
+                pool of worker processes over notes
+  host_inclusive what a host that starts from argument strings pays around the step (decode, plan, upload, download)
+
+`--job-notes N --config 4` (or 5) renders ONE fixed job of N notes instead: every rank derives the same
+longest-processing-time assignment from the notes' frame counts, renders its share in sub-batches, and the line reports
+`"scaling": "strong"` with the per-rank frames and the imbalance.
 """
 import argparse
 import json
@@ -121,33 +128,103 @@ def pcie_leg(wl, step_s):
             "frames_per_s": wl.frames / tot, "note": "serial copies + compute, pinned host buffers; not the headline value"}
 
 
-def cpu_baseline(wl, hop, budget_s=15.0, min_notes=4):
-    """Oracle (CPU port of the reference path, oracle/) on the same notes — the full render the reference does
-    per note: decode features, assemble, synthesize, mix — single thread, bounded sample."""
+def _oracle_notes(config, ids, n_fft, hop, budget_s, min_notes):
+    """Render notes `ids` of a BASELINE config with the oracle until the budget is spent: (frames, seconds, notes).  The
+    synthetic notes are built before the clock starts; the first note warms tables / the native library and is not counted."""
     from oracle import goofer_ref as R
     from oracle import sampler_ref as SR
     from goofer_amd import synthetic as syn
     R._native()
-    frames = 0
-    done = 0
+    notes = [syn.config_note(config, int(i)) for i in ids]
+    frames = done = 0
     t0 = time.perf_counter()
-    for j, (src, req, phi_seed) in enumerate(wl.raw):
+    for j, (src, req, phi_seed) in enumerate(notes):
         feats = (src["env_pack"], src["f0"].copy(), src["mask"].copy(), {k: v.copy() for k, v in src["formants"].items()},
                  src["sr"], src["y_len"])
         params = SR.decode_request(*syn.request_args(req))
         if j == 1:
-            t0 = time.perf_counter()          # note 0 warms tables / the native lib and is not counted
-        out = SR.render(feats, params, seed=phi_seed, n_fft=wl.geo["n_fft"], hop=hop)
+            t0 = time.perf_counter()
+        out = SR.render(feats, params, seed=phi_seed, n_fft=n_fft, hop=hop)
         if j >= 1:
             frames += 1 + len(out) // hop
             done += 1
         if done >= min_notes and time.perf_counter() - t0 > budget_s:
             break
-    dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{done} notes of the same workload ({frames} frames) through oracle/sampler_ref.render (numpy + "
-                      f"gcc -O2 loops standing in for numba): knot decode, assembly, synthesize, mix; {dt:.1f} s",
-            "host_cpus": os.cpu_count()}
+    return frames, time.perf_counter() - t0, done
+
+
+def _pool_worker(job):
+    return _oracle_notes(*job)
+
+
+def cpu_baseline(config, ids, n_fft, hop, budget_s=10.0, min_notes=4):
+    """Oracle (CPU port of the reference path, oracle/) on the same notes — the full render the reference does per note:
+    decode features, assemble, synthesize, mix (wav I/O excluded).  Leg (i): one worker process, numpy / BLAS threads = 1.
+    Leg (ii): a pool of worker processes over notes, one per host core of this GPU's share (16 of the
+    box's cores).  Workers are spawned, with single-threaded numpy, before this process touches the GPU."""
+    import multiprocessing as mp
+    ids = list(ids)
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved:
+        os.environ[k] = "1"                    # inherited by the spawned workers (set before they import numpy)
+    try:
+        ctx = mp.get_context("spawn")
+        per1 = min(len(ids), 1 + max(min_notes, int(budget_s * 70)))
+        with ctx.Pool(1) as pool:
+            frames, dt, done = pool.map(_pool_worker, [(config, ids[:per1], n_fft, hop, budget_s, min_notes)])[0]
+        res = {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"{done} notes of the same workload ({frames} frames) through oracle/sampler_ref.render (numpy + "
+                         f"gcc -O2 loops standing in for numba): knot decode, assembly, synthesize, mix; {dt:.1f} s, one process, "
+                         "numpy threads = 1", "host_cpus": os.cpu_count()}
+        workers = max(1, min(16, os.cpu_count() or 1))
+        per = 1 + max(min_notes, int(np.ceil(budget_s * done / dt)))          # about budget_s of work per worker
+        jobs = [(config, [ids[(w * per + k) % len(ids)] for k in range(per)], n_fft, hop, budget_s, min_notes) for w in range(workers)]
+        t0 = time.perf_counter()
+        with ctx.Pool(workers) as pool:
+            out = pool.map(_pool_worker, jobs)
+        wall = time.perf_counter() - t0
+        res["pool"] = {"value": sum(o[0] / o[1] for o in out), "unit": "frames/s", "cores": workers, "kind": "port",
+                       "sample": f"{sum(o[2] for o in out)} notes ({sum(o[0] for o in out)} frames) over {workers} spawned worker "
+                                 f"processes rendering side by side for {max(o[1] for o in out):.1f} s (sum of the workers' rates; "
+                                 f"{wall:.1f} s wall with start-up and note synthesis)"}
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return res
+
+
+def host_inclusive(wl, ctx, step_s):
+    """What one batch costs a host that starts from the 13 argument strings and ends with the audio in host memory: decode,
+    plan + tables + upload (Renderer.prepare), one device step, download of the mix.  Never part of `value`."""
+    import torch
+    from goofer_amd import sampler as S
+    from goofer_amd import synthetic as syn
+    from goofer_amd.render import Source
+    raw = wl.raw
+    args = [syn.request_args(q) for _, q, _ in raw]
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        reqs = [S.decode_request(*a) for a in args]
+        jobs = [(Source.from_pack(s["env_pack"], s["f0"], s["mask"], s["formants"], s["sr"], s["y_len"]), q) for (s, _, _), q in zip(raw, reqs)]
+        t1 = time.perf_counter()
+        prep = wl.renderer.prepare(jobs, note_ids=list(range(len(jobs))))
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        out = wl.renderer.run(prep, seed=0)
+        mix = out["mix"].cpu()
+        t3 = time.perf_counter()
+        cur = {"decode_ms": 1e3 * (t1 - t0), "plan_upload_ms": 1e3 * (t2 - t1), "step_and_download_ms": 1e3 * (t3 - t2),
+               "total_ms": 1e3 * (t3 - t0), "frames_per_s": prep["frames"] / (t3 - t0), "notes_per_s": len(jobs) / (t3 - t0)}
+        if best is None or cur["total_ms"] < best["total_ms"]:
+            best = cur
+        del prep, out, mix
+    best["note"] = ("one host thread: 13 argument strings -> Request (decode), plans + tables + H2D (Renderer.prepare), device step, "
+                    "D2H of the mix; the best of two passes; the device step alone is ms_per_step")
+    return best
 
 
 def main():
@@ -157,7 +234,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--notes", type=int, default=1024, help="notes per GPU (weak scaling)")
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (1-based)")
+    ap.add_argument("--job-notes", type=int, default=0, help="a FIXED job of this many notes (BASELINE configs 4 / 5): sharded over the "
+                    "ranks by longest-processing-time assignment, rendered in sub-batches; reports strong scaling")
+    ap.add_argument("--sub-batch", type=int, default=1024, help="notes per device batch of a fixed job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time the optional ragged gather of finished audio to rank 0 "
                     "(RCCL over xGMI; never part of `value`)")
     args = ap.parse_args()
@@ -170,19 +251,37 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # The CPU baseline runs first, before this process touches the GPU: its pool leg starts worker processes, and nothing
+    # that holds a device context should be forked / exec'd from.
+    cpu_line = None
+    if world == 1 and not args.no_cpu_baseline:
+        from goofer_amd import synthetic as syn0
+        g0_ = syn0.config_geometry(args.config)
+        n_ids = args.job_notes if args.job_notes > 0 else args.notes
+        cpu_line = cpu_baseline(args.config, list(range(n_ids)), g0_["n_fft"], g0_["hop"])
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
+    from goofer_amd import synthetic as syn
     from goofer_amd.device import Context
     from goofer_amd.workload import SamplerWorkload
 
-    from goofer_amd.shard import note_range, reduce_timing
+    from goofer_amd.shard import assign_lpt, note_range, reduce_timing
 
     ctx = Context(local)
-    ids = note_range(rank, world, args.notes)
-    wl = SamplerWorkload(ctx, args.config, ids)
+    job = args.job_notes > 0
+    if job:
+        # every rank derives the same assignment from the frame counts of the whole job: no communication
+        est = [syn.config_note_frames(args.config, i) for i in range(args.job_notes)]
+        ids = assign_lpt(est, world)[rank]
+        subs = [SamplerWorkload(ctx, args.config, ids[k:k + args.sub_batch]) for k in range(0, len(ids), args.sub_batch)]
+    else:
+        ids = list(note_range(rank, world, args.notes))
+        subs = [SamplerWorkload(ctx, args.config, ids)]
+    wl = subs[0]
+    my_frames, my_samples = sum(w.frames for w in subs), sum(w.samples for w in subs)
     geo = wl.geo
     B, hop, n_fft, sr = geo["n_fft"] // 2 + 1, geo["hop"], geo["n_fft"], geo["sr"]
 
@@ -191,22 +290,27 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def step():
+        out = None
+        for w in subs:
+            out = w.step()
+        return out
+
     for _ in range(args.warmup):
-        wl.step()
+        step()
     barrier()
-    ctx.profile_begin(args.steps)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ctx.profile_begin(args.steps * len(subs))
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()                 # torch's current stream is the stream the library launches on
-        wl.step()
-        ev[k][1].record()
+        last = step()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
     elapsed = t1 - t0
     prof = ctx.profile_end()
-    step_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    # the timed path must have produced audio: finite, not silent (the last sub-batch of the last step)
+    mix = last["mix"]
+    assert bool(torch.isfinite(mix).all()) and float(mix.abs().max()) > 0.0, "the timed steps produced no valid audio"
     # the assembly call on its own (the synth stages overlap on two streams, so step - sum(stages) no longer isolates it)
     a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a0.record()
@@ -215,8 +319,13 @@ def main():
     a1.record()
     torch.cuda.synchronize()
     prof["ms"]["assemble"] = a0.elapsed_time(a1) / args.steps * max(1, prof["steps"])
-    _ = step_ms
-    elapsed, frames_total = reduce_timing(elapsed, wl.frames, device="cuda")
+    elapsed, frames_total = reduce_timing(elapsed, my_frames, device="cuda")
+    per_rank = [my_frames]
+    if world > 1:
+        t = torch.tensor([float(my_frames)], dtype=torch.float64, device="cuda")
+        allf = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allf, t)
+        per_rank = [int(round(v.item())) for v in allf]
 
     # the framewise rFFT kernel on its own (the kernel BASELINE's >= 40 % HBM target names): same frames and
     # CSR geometry as the batch, HIP events on the launch stream (k_frame_note, ~5 us, rides along)
@@ -244,51 +353,76 @@ def main():
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
-            assert sum(int(a.numel()) for a, _ in got) == world * wl.samples
+            assert sum(int(a.numel()) for a, _ in got) >= wl.samples
         del got
 
     if rank == 0:
         value = frames_total * args.steps / elapsed
         steps = max(1, prof["steps"])
-        per = {k: v / steps for k, v in prof["ms"].items()}              # ms per launch, this rank
+        per = {k: v / steps for k, v in prof["ms"].items()}              # ms per launch (per sub-batch), this rank
         # the dominant kernel is picked among the stages that run alone on the chip: the event-bracketed times of the
-        # forked stages (pulse chain on the side stream, noise spectra / mask smoothing beside it) include each other
+        # forked stages (pulse chain on the side stream, noise walker / mask smoothing beside it) include each other
         shared = {"pulse_onsets", "pulse_place", "noise_spectra", "noise_stems", "mask_short", "phase_inc", "setup_maps", "assemble"}
         solo = {k: v for k, v in per.items() if k not in shared} or per
         dom = max(solo, key=solo.get)
         per["rfft_frames_standalone"] = rfft_ms
+        Fb, Nb = my_frames / len(subs), my_samples / len(subs)           # frames / samples per launch (mean sub-batch)
 
-        def roof(stage):
+        def roof(stage, frames=None, samples=None):
+            frames = Fb if frames is None else frames
+            samples = Nb if samples is None else samples
             ms = per[stage]
-            a = stage_alg_bytes(stage, wl.frames, wl.samples, B, hop, n_fft) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            traffic, src = pmc_traffic(stage, wl.frames)
+            alg = stage_alg_bytes(stage, frames, samples, B, hop, n_fft)
+            a = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            traffic, src = pmc_traffic(stage, wl.frames) if not job else (None, None)
             return {"kernel": stage, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": a / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "ms_per_launch": ms,
-                    "alg_bytes_per_launch": stage_alg_bytes(stage, wl.frames, wl.samples, B, hop, n_fft)}
+                    "alg_bytes_per_launch": alg}
 
+        step_ms = elapsed / args.steps * 1e3
+        alg_step = (4 * B + 20 * hop) * frames_total / world            # SURVEY 8d ALG_BYTES_FRAME x frames of one rank's step
+        if job:
+            shape = (f"BASELINE config {args.config} as ONE fixed job of {args.job_notes} notes sharded over {world} GPU(s) by "
+                     f"longest-processing-time assignment on frame counts, sub-batches of {args.sub_batch} notes")
+        else:
+            shape = f"BASELINE config {args.config}: {args.notes} notes/GPU x ~1.1 s"
         line = {
             "metric": "resynth_frames_per_sec", "value": value, "unit": "frames/s",
             "realtime_factor": value * hop / sr,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE config {args.config}: {args.notes} notes/GPU x ~1.1 s, sr {sr}, n_fft {n_fft}, "
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+            "higher_is_better": True, "scaling": "strong" if job else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{shape}, sr {sr}, n_fft {n_fft}, "
                                    f"hop {hop} ({1e3 * hop / sr:.1f} ms); per-note flags {wl_flags(args.config)}; one step = "
                                    "goofer_render_batch = goofer_assemble_batch + goofer_synth_batch (SillySampler.resample + gf.synthesize + V/B/U mix) "
                                    "from .goofy features and host-made plans resident in HBM, on-device Philox phases",
-                       "notes_per_gpu": args.notes, "frames_per_gpu": wl.frames, "samples_per_gpu": wl.samples,
+                       "notes_per_gpu": len(ids), "frames_per_gpu": my_frames, "samples_per_gpu": my_samples,
+                       "sub_batches_per_gpu": len(subs),
                        "sharding": "independent notes, no data-path collective"},
             "stage_ms": per,
             "roofline": roof(dom),
             # in-pipeline launch when the active path has a standalone rFFT stage, else the entry-point timing
-            "roofline_fft": roof("rfft_frames" if per.get("rfft_frames", 0) > 0 else "rfft_frames_standalone"),
+            "roofline_fft": roof("rfft_frames", wl.frames, wl.samples) if per.get("rfft_frames", 0) > 0
+            else roof("rfft_frames_standalone", wl.frames, wl.samples),
+            # the whole step against the end-to-end algorithmic bytes (4 B + 20 hop per frame) and, from the committed counter
+            # passes of this command, the HBM bytes all its kernels really moved
+            "roofline_step": {"bound": "hbm", "alg_bytes_per_step": alg_step, "achieved": alg_step / (step_ms * 1e-3) / 1e9,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "traffic": None if job else pmc_step_traffic(wl.frames),
+                              "note": "the fused frame walkers are vector-issue / latency bound (about 30 flop per algorithmic byte), "
+                                      "not HBM bound: DESIGN.md section 3"},
         }
+        if job or world > 1:
+            line["per_rank_frames"] = per_rank
+            line["imbalance"] = max(per_rank) / (sum(per_rank) / len(per_rank))
         if gather_ms is not None:
             line["gather_to_rank0"] = {"ms": gather_ms, "bytes": 4 * wl.samples * (world - 1), "note": "ragged gather of the finished "
                                        "notes (goofer_amd.shard.gather_audio), outside the timed steps"}
-        if world == 1:
+        if world == 1 and not job:
             line["pcie_inclusive"] = pcie_leg(wl, elapsed / args.steps)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(wl, hop)
+            if not args.no_host_inclusive:
+                line["host_inclusive"] = host_inclusive(wl, ctx, elapsed / args.steps)
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -184,6 +184,19 @@ def config_note(config: int, i: int) -> tuple:
     return src, req, 5000 + i
 
 
+def config_note_frames(config: int, i: int) -> int:
+    """Output frames of note ``i`` of a BASELINE config without building it (what a rank needs of EVERY note of a fixed job
+    to derive the same longest-processing-time assignment as every other rank, shard.assign_lpt): the request's length and
+    consonant in samples (SillySampler.py:449-500, velocity 100), 1 + n // hop frames."""
+    geo = config_geometry(config)
+    length = 1000.0
+    if config == 4:
+        rng = np.random.default_rng(9000 + i)
+        length = float(np.exp(rng.uniform(np.log(100.0), np.log(3000.0))))
+    n = int(100.0 / 1000.0 * geo["sr"]) + int(round(length) / 1000.0 * geo["sr"])
+    return 1 + n // geo["hop"]
+
+
 def random_flags(rng) -> str:
     """A random subset (3-8 flags) of the reference's flag vocabulary with in-range values (SillySampler.py:307-410):
     used by the flag-interaction fixtures (tests/golden/make_golden.py) and the fuzz tests."""
