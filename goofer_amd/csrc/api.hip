@@ -90,6 +90,9 @@ int launch_apply_gain(goofer_ctx *, float *, float *, float *, float *, float *,
 int launch_note_steps(goofer_ctx *, const int64_t *, int, double *, hipStream_t);
 int launch_mask_upsample(goofer_ctx *, const double *, const int64_t *, int, int64_t, double *, bool, float *, hipStream_t);
 bool stems_supported(const goofer_plan_t &);
+bool ola_split_supported(const goofer_plan_t &);
+int launch_irfft_ola1(goofer_ctx *, const float2 *, const float2 *, const float2 *, int, int64_t, const int *, const int64_t *,
+                      const int64_t *, int, const double *, double *, const goofer_note_params *, float *, float *, float *, hipStream_t);
 int launch_frame_picks(goofer_ctx *, const int64_t *, const int *, int64_t, const int64_t *, const float *, const float *, float2 *,
                        hipStream_t);
 int launch_noise_stems(goofer_ctx *, const float *, int, const int64_t *, const float *, int64_t, const int *, const int64_t *,
@@ -1425,6 +1428,24 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     MARK();   // 12: decimated + smoothed voicing mask
     if (!side_on && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
     MARK();   // 13: (irFFT of the three stems +) overlap-add + gains + per-note peak, one pass
+    // n_fft 2048: one stem per wave (two waves per SIMD instead of one), then the per-note finish of the stem-split path
+    const bool ola_split = ola_one && ctx->stems && ola_split_supported(p) && !jit_vol;
+    if (ola_split) {
+        if ((rc = launch_irfft_ola1(ctx, S_h, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, n, short_s, note_steps,
+                                    b->params, b->harm, b->uv, b->bre, st)))
+            return rc;
+        MARK();   // 14
+        if ((rc = launch_note_finish(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, b->params, note_mag, note_peak,
+                                     !(b->mix_only && (b->mix || b->rec)), st)))
+            return rc;
+        MARK();   // 15..17 unused
+        MARK();
+        MARK();
+        MARK();   // end
+        if (pev) ctx->prof_steps++;
+        ctx->frame_picks = nullptr;
+        return GOOFER_OK;
+    }
     if (ola_one) {
         if ((rc = launch_irfft_ola3(ctx, S_h, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, n, note_mag, short_s,
                                     note_steps, b->params, b->harm, b->uv, b->bre, note_peak, st)))

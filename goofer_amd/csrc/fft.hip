@@ -12,11 +12,9 @@
 #include "fft_core.h"
 
 // ---------------------------------------------------------------------------------------------
-#ifndef RFFT_WAVES
-#define RFFT_WAVES 4
-#endif
+// register budget: two frames of M / 64 sample pairs in flight; the 2048-point frame takes the 256-VGPR budget
 template <int M>
-__global__ __launch_bounds__(256, RFFT_WAVES) void k_rfft_frames(const float *__restrict__ x, const int64_t *__restrict__ sample_off,
+__global__ __launch_bounds__(256, M <= 512 ? 4 : 2) void k_rfft_frames(const float *__restrict__ x, const int64_t *__restrict__ sample_off,
                                                      const int64_t *__restrict__ frame_off, const int *__restrict__ frame_note,
                                                      int64_t total_frames, float2 *__restrict__ S, int ldc, int hop,
                                                      const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twh,

@@ -549,6 +549,239 @@ __global__ __launch_bounds__(256, M <= 512 ? 2 : 1) void k_irfft_ola3(const floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pass with ONE stem per wave, for geometries whose three rings do not leave room for a second wave per SIMD
+// (n_fft 2048: 24 KB of rings + 8 KB of exchange buffer per wave, 1 wave per SIMD, 0.17-0.22 of the HBM roofline).  A wave
+// walks a run of frames of one stem — job = 3 * run + stem — with a single n_fft-float ring (16.6 KB per wave at 2048:
+// eight waves per CU), and leaves its stem the way the stem walkers of stems.hip do: the harmonic stem divided by the
+// window sum only (1 / max|S| is applied by k_note_finish, which also takes the peak), the noise stems with their
+// mask gains.  Same transforms, same ascending-frame accumulation: bit-identical to k_irfft_ola3 + k_apply_gain (tested).
+template <int M, int WPB>
+__global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__restrict__ S_h, const float2 *__restrict__ S_u,
+                                                    const float2 *__restrict__ S_b, int ldc, int64_t total_frames,
+                                                    const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
+                                                    const int64_t *__restrict__ sample_off, int hop, int run, int halo,
+                                                    const double *__restrict__ short_s, const double *__restrict__ steps,
+                                                    const goofer_note_params *__restrict__ params, float *__restrict__ harm,
+                                                    float *__restrict__ uv, float *__restrict__ bre, const float2 *__restrict__ g_tw,
+                                                    const float2 *__restrict__ g_twh, const float *__restrict__ g_win)
+{
+    constexpr int R = fft_cfg<M>::R, NF = 2 * M, BUF = fft_cfg<M>::BUF;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *tw = reinterpret_cast<float2 *>(smem);
+    float2 *twh = tw + M;
+    float2 *bufs = twh + (M / 2 + 1);
+    float *win = reinterpret_cast<float *>(bufs + WPB * BUF);
+    float *rings = win + NF;
+    double *knots = reinterpret_cast<double *>(rings + (size_t)WPB * NF);
+    load_tables<M>(tw, twh, win, g_tw, g_twh, g_win);
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float2 *buf = bufs + wave * BUF;
+    float *ring = rings + (size_t)wave * NF;
+    const int64_t job = (int64_t)blockIdx.x * WPB + wave;
+    const int stem = (int)(job % 3);                          // wave-uniform
+    const int64_t f0 = (job / 3) * run;
+    if (f0 >= total_frames) return;                           // no block barrier below
+    const int64_t f1 = f0 + run < total_frames ? f0 + run : total_frames;
+    const float inv_m = 0.5f / (float)M;                     // 1/M of the transform and the 1/2 of the input stage (irfft_pre)
+    const float2 *S = stem == 0 ? S_h : (stem == 1 ? S_u : S_b);
+    float *out = stem == 0 ? harm : (stem == 1 ? uv : bre);
+
+    int64_t fs = f0;
+    {
+        const int nt = frame_note[f0];
+        const int64_t t0 = f0 - frame_off[nt];
+        fs = f0 - (t0 < halo ? t0 : halo);
+    }
+    float2 nk[R], nm[R];                                      // spectrum rows of the next frame, fetched during the transform
+    auto fetch = [&](int64_t f) {
+        const float2 *row = S + f * (int64_t)ldc;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int k = lane + WAVE * r;
+            nk[r] = row[k];
+            nm[r] = row[M - k];
+        }
+    };
+    fetch(fs);
+
+    int note = -1;
+    int64_t base = 0, fbase = 0;
+    int n = 0, T = 0, ns = 0, out_len = 0;
+    float gain = 0.f, kps = 0.f;
+    double step_n = 0.0, step_s = 0.0;
+    const double *ss = nullptr;
+    const int max_back = (NF - 1) / hop;
+    auto wc_of = [&](int k) { return (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y); };
+    auto win_of = [&](int k) { return make_float2(win[2 * k] * inv_m, -(win[2 * k + 1] * inv_m)); };
+
+    const int KN = hop / MASK_DS + KNOT_MARGIN;
+    double *kbuf = knots + (size_t)wave * (512 / MASK_DS + KNOT_MARGIN);
+    constexpr int KPL = (512 / MASK_DS + KNOT_MARGIN + WAVE - 1) / WAVE;
+    double kn_r[KPL];
+    int kn_lo = 0;
+    const bool slots_ok = hop <= 512 && stem != 0;            // the harmonic stem has no mask gain
+    auto knots_fetch = [&](int h) {
+        int i0 = h * hop - M;
+        i0 = i0 < 0 ? 0 : i0;
+        int lo = (int)((float)i0 * kps) - 4;
+        lo = lo < 0 ? 0 : lo;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+            const int e = lane + WAVE * c;
+            const int k = lo + e < ns - 1 ? lo + e : ns - 1;
+            kn_r[c] = (e < KN && ns > 0) ? ss[k] : 0.0;
+        }
+        kn_lo = lo;
+    };
+    // finished hop h of the current note -> window-sum quotient -> (noise stems) mask gain -> out; also the flush hops and the zero tail
+    auto emit = [&](int h) {
+        const int e_hi = KN - 1, lo = kn_lo;
+        auto knot_l = [&](int k) {
+            const int e = k - lo;
+            return kbuf[e < e_hi ? e : e_hi];
+        };
+        auto knot_g = [&](int k) { return ss[k]; };
+        for (int j = lane; j < hop; j += WAVE) {
+            const int i = h * hop + j - M;
+            if (i < 0 || i >= n) continue;
+            float x = 0.f;
+            if (i < out_len) {
+                const int back = (NF - 1 - j) / hop;
+                const int flo = h - back < 0 ? 0 : h - back, fhi = h > T - 1 ? T - 1 : h;
+                float ws = 0.f;
+                for (int fr = flo; fr <= fhi; ++fr) {
+                    const float w = win[j + (h - fr) * hop];
+                    ws += w * w;
+                }
+                x = ring[(h * hop + j) & (NF - 1)];
+                if (ws > 1e-9f) x /= ws;
+            }
+            if (stem != 0) {
+                const float ms = slots_ok ? smooth_mask_at32(knot_l, ns, i, n, step_n, step_s, kps)
+                                          : smooth_mask_at32(knot_g, ns, i, n, step_n, step_s, kps);
+                x = (x * (stem == 1 ? 1.0f - ms : ms)) * gain;
+            }
+            out[base + i] = x;
+        }
+    };
+    (void)max_back;
+
+    for (int64_t f = fs; f < f1; ++f) {
+        const int nt = frame_note[f];
+        if (nt != note) {
+            note = nt;
+            base = sample_off[note];
+            n = (int)(sample_off[note + 1] - base);
+            fbase = frame_off[note];
+            T = (int)(frame_off[note + 1] - fbase);
+            ns = (n + MASK_DS - 1) / MASK_DS;
+            out_len = hop * (T - 1);
+            gain = stem == 1 ? params[note].uv_strength : params[note].breath_strength;
+            step_n = steps[2 * note];
+            step_s = steps[2 * note + 1];
+            kps = n > 1 ? (float)(ns - 1) / (float)(n - 1) : 0.f;
+            ss = short_s + short_base(sample_off, note);
+        }
+        const int t = (int)(f - fbase);
+        if (f >= f0 && slots_ok) knots_fetch(t);
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int k = lane + WAVE * r;
+            float2 xk = nk[r], xm = nm[r];
+            if (k == 0) { xk.y = 0.f; xm.y = 0.f; }           // irfft ignores Im of DC and Nyquist
+            v[r] = irfft_pre(xk, xm, wc_of(k));
+        }
+        if (f + 1 < f1) fetch(f + 1);
+        const int shift = (t * hop) & (NF - 1);
+        float2 z[R];
+        wave_fft_keep<M>(v, buf, tw, lane, z);                // the lane's output points stay in registers
+        // ring reads ahead of ring writes, eight slots at a time (the R slots of a lane are distinct)
+#pragma unroll
+        for (int r0 = 0; r0 < R; r0 += 8) {
+            float2 o[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int m = lane + WAVE * (r0 + q);
+                o[q] = *reinterpret_cast<const float2 *>(ring + ((2 * m + shift) & (NF - 1)));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int m = lane + WAVE * (r0 + q);
+                const float2 wn = win_of(m);
+                const float a = z[r0 + q].x * wn.x, b = z[r0 + q].y * wn.y;
+                const bool first = t == 0 || 2 * m >= NF - hop;   // first contribution: y starts from zero
+                *reinterpret_cast<float2 *>(ring + ((2 * m + shift) & (NF - 1))) = make_float2(first ? a : o[q].x + a, first ? b : o[q].y + b);
+            }
+        }
+        wave_lds_sync();
+        if (f >= f0) {
+            for (int h = t;;) {
+                if (slots_ok) {
+#pragma unroll
+                    for (int c = 0; c < KPL; ++c) {
+                        const int e = lane + WAVE * c;
+                        if (e < KN) kbuf[e] = kn_r[c];
+                    }
+                    wave_lds_sync();
+                }
+                emit(h);
+                ++h;
+                if (t != T - 1 || h * hop - M >= n) break;
+                if (slots_ok) knots_fetch(h);
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+template <int M>
+static int irfft_ola1_impl(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u, const float2 *S_b, int ldc, int64_t total_frames,
+                           const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, const double *short_s,
+                           const double *steps, const goofer_note_params *params, float *harm, float *uv, float *bre, hipStream_t st)
+{
+    constexpr int WPB = 8;
+    const goofer_plan_t &p = ctx->plan;
+    const int halo = (p.n_fft + p.hop - 1) / p.hop - 1;
+    const size_t lds = sizeof(float2) * (M + M / 2 + 1 + WPB * fft_cfg<M>::BUF) + sizeof(float) * 2 * M + sizeof(float) * WPB * 2 * M + 16 +
+                       sizeof(double) * WPB * (512 / MASK_DS + KNOT_MARGIN);
+    if (lds > 160 * 1024) return goofer_fail(ctx, GOOFER_EINVAL, "one-stem overlap-add: %zu bytes of LDS", lds);
+    const void *fn = (const void *)k_irfft_ola1<M, WPB>;
+    int rc = kernel_allow_max_lds(ctx, fn);
+    if (rc) return rc;
+    int cus = 0;
+    HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    const int64_t slots = (int64_t)(cus > 0 ? cus : 256) * WPB;          // one workgroup per CU
+    // jobs = 3 stems x runs; runs sized so that the jobs fill the device a whole number of times, a run >= 8 halos
+    const int min_run = halo <= 4 ? 32 : 8 * halo;
+    const int64_t rounds = (3 * total_frames + slots * 256 - 1) / (slots * 256);
+    int64_t fit = (3 * total_frames + rounds * slots - 1) / (rounds * slots);
+    const int run = (int)(fit > min_run ? fit : min_run);
+    const int64_t runs = (total_frames + run - 1) / run, jobs = 3 * runs;
+    hipLaunchKernelGGL((k_irfft_ola1<M, WPB>), dim3((unsigned)((jobs + WPB - 1) / WPB)), dim3(64 * WPB), lds, st, S_h, S_u, S_b, ldc,
+                       total_frames, frame_note, frame_off, sample_off, p.hop, run, halo, short_s, steps, params, harm, uv, bre,
+                       p.tw_full, p.tw_half, p.window);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+// one stem per wave (n_fft 2048); needs k_note_finish behind it (1 / max|S|, peak, gain)
+bool ola_split_supported(const goofer_plan_t &p) { return p.n_fft == 2048 && (p.hop & 1) == 0; }
+
+int launch_irfft_ola1(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u, const float2 *S_b, int ldc, int64_t total_frames,
+                      const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, int n_notes, const double *short_s,
+                      double *steps, const goofer_note_params *params, float *harm, float *uv, float *bre, hipStream_t st)
+{
+    if (total_frames <= 0) return GOOFER_OK;
+    if (!ola_split_supported(ctx->plan)) return goofer_fail(ctx, GOOFER_EINVAL, "one-stem overlap-add is built for n_fft 2048");
+    hipLaunchKernelGGL(k_note_steps, dim3((n_notes + 255) / 256), dim3(256), 0, st, sample_off, n_notes, steps);
+    LAUNCH_CHECK(ctx);
+    return irfft_ola1_impl<1024>(ctx, S_h, S_u, S_b, ldc, total_frames, frame_note, frame_off, sample_off, short_s, steps, params,
+                                 harm, uv, bre, st);
+}
+
 template <int M>
 static int irfft_ola3_impl(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u, const float2 *S_b, int ldc, int64_t total_frames,
                            const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, const float *note_mag,
