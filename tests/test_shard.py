@@ -111,3 +111,61 @@ def test_gloo_two_ranks_gather_finished_audio():
     got = next(r for r in res if r is not None)
     assert got[0] == ([float(v) for v in range(8)], [5, 3])
     assert got[1] == ([100.0 + v for v in range(13)], [2, 7, 4])
+
+
+def _job_worker(rank, world, port, q):
+    """What bench.py --job-notes does on every rank: the same LPT assignment from the frame counts of the whole job, derived
+    without communication; then the per-rank frame totals are all-gathered (imbalance) and the timing reduced."""
+    import torch
+    import torch.distributed as dist
+    from goofer_amd import synthetic as syn
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    est = [syn.config_note_frames(4, i) for i in range(200)]
+    mine = shard.assign_lpt(est, world)[rank]
+    frames = sum(est[i] for i in mine)
+    t = torch.tensor([float(frames)], dtype=torch.float64)
+    allf = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allf, t)
+    elapsed, total = shard.reduce_timing(1.0 + 0.25 * rank, frames)
+    q.put((rank, mine, frames, [int(v.item()) for v in allf], elapsed, total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_two_ranks_fixed_job_assignment():
+    """A fixed job (BASELINE config 4: log-uniform note lengths) sharded over two ranks: every note rendered exactly once,
+    the shares within 1 % of each other in frames, the same plan on both ranks, no data-path collective."""
+    import torch.multiprocessing as mp
+    from goofer_amd import synthetic as syn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, ids0, f0, all0, t0, tot0), (r1, ids1, f1, all1, t1, tot1) = res
+    assert sorted(ids0 + ids1) == list(range(200)) and not set(ids0) & set(ids1)
+    assert all0 == all1 == [f0, f1]
+    assert max(f0, f1) / (0.5 * (f0 + f1)) < 1.01
+    assert t0 == t1 == 1.25 and tot0 == tot1 == f0 + f1
+    est = [syn.config_note_frames(4, i) for i in range(200)]
+    assert f0 + f1 == sum(est)
+
+
+def test_frame_estimate_of_a_job_matches_the_planner():
+    """config_note_frames (what the ranks balance a fixed job by) is the planner's frame count of the same note."""
+    from goofer_amd import sampler as S
+    from goofer_amd import synthetic as syn
+    for cfg, ids in ((3, [0, 1, 7]), (4, [0, 1, 2, 3, 50, 51, 999]), (5, [0, 1])):
+        geo = syn.config_geometry(cfg)
+        for i in ids:
+            src, req, _ = syn.config_note(cfg, i)
+            p = S.plan_note(S.decode_request(*syn.request_args(req)), src["sr"], src["y_len"], src["env_pack"]["knot_vals_log"].shape[1],
+                            src["formants"], geo["hop"])
+            assert 1 + p.n_out // geo["hop"] == syn.config_note_frames(cfg, i), (cfg, i)
