@@ -390,6 +390,7 @@ void goofer_destroy(goofer_ctx *ctx)
     if (ctx->small) (void)hipFree(ctx->small);
     if (ctx->asm_scratch) (void)hipFree(ctx->asm_scratch);
     if (ctx->mask_taps) (void)hipFree(ctx->mask_taps);
+    if (ctx->warp_rows) (void)hipFree(ctx->warp_rows);
     for (int i = 0; i < ctx->prof_cap * (PROF_STAGES + 1); ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
     free(ctx->prof_ev);
     for (int i = 0; ctx->prof_side && i < ctx->prof_cap * 4; ++i) (void)hipEventDestroy(ctx->prof_side[i]);
@@ -1316,7 +1317,8 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // behind the pulse placement on its stream (the caller's stream carries the mask smoothing and the noise walker meanwhile).
     // Not inside the walker: the crossing-anchor path is several times slower than the sorted one, and a walker wave holds
     // ~95 frames of ONE note, so the slow notes would set the kernel's time.
-    if (stem_path && side_on) {
+    const bool warp_ready = stem_path && ctx->warp_done;               // goofer_render_batch: the assembly already wrote the warped rows
+    if (stem_path && side_on && !warp_ready) {
         HIP_TRY(ctx, hipStreamWaitEvent(pst, ctx->ev_maps, 0));            // frame_note / row_src come from the caller's stream
         if ((rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, pst)))
             return rc;
@@ -1372,13 +1374,14 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                                          b->sample_off, picks, b->params, b->seed, b->env_noise != nullptr, short_s, note_steps, b->uv,
                                          b->bre, st)))
                 return rc;
-            if ((rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, st)))
+            if (!ctx->warp_done &&
+                (rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, st)))
                 return rc;
         }
         MARK();   // 8
         MARK();   // 9: harm_stem = rFFT + shaping + irFFT + overlap-add of the harmonic stem
-        if ((rc = launch_harm_stem(ctx, pulse, env_h, ld, nullptr, F, frame_note, b->frame_off, b->sample_off, picks, b->params, b->harm,
-                                   note_mag, st)))
+        if ((rc = launch_harm_stem(ctx, pulse, ctx->warp_done ? ctx->warp_rows : env_h, ld, ctx->warp_done ? row_src : nullptr, F, frame_note,
+                                   b->frame_off, b->sample_off, picks, b->params, b->harm, note_mag, st)))
             return rc;
         MARK();   // 10..12
         MARK();
@@ -1499,8 +1502,29 @@ int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *asmb, const goof
         HIP_TRY(ctx, hipEventRecord(ctx->ev_entry, st));      // every input of either descriptor precedes this point
         ctx->early_req = true;
     }
+    // Stem-split path: the harmonic walker wants warped envelope rows.  The assembly's frame-gather kernel has every row in
+    // hand, so it writes the warped copy too (k_env_loop<true>) — one pass instead of a separate read + write of the matrix.
+    ctx->warp_out = nullptr;
+    ctx->warp_done = false;
+    if (ctx->stems && !ctx->fused && ctx->ola_fused && ctx->overlap && stems_supported(ctx->plan) && asmb->env_out == b->env &&
+        asmb->n_notes == b->n_notes && asmb->total_out_rows == b->total_env_rows && asmb->ld == b->ld && !asmb->any_fry) {
+        const size_t need = (size_t)b->total_env_rows * b->ld * sizeof(float);
+        if (need > ctx->warp_rows_bytes) {
+            HIP_TRY(ctx, hipDeviceSynchronize());
+            if (ctx->warp_rows) HIP_TRY(ctx, hipFree(ctx->warp_rows));
+            ctx->warp_rows = nullptr;
+            ctx->warp_rows_bytes = 0;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->warp_rows, need + need / 4));
+            ctx->warp_rows_bytes = need + need / 4;
+        }
+        ctx->warp_formants = b->formants;
+        ctx->warp_params = b->params;
+        ctx->warp_out = ctx->warp_rows;
+    }
     rc = goofer_assemble_batch(ctx, asmb, stream);
+    ctx->warp_out = nullptr;
     if (!rc) rc = goofer_synth_batch(ctx, b, stream);
+    ctx->warp_done = false;
     ctx->early_req = false;
     ctx->early_f0 = nullptr;
     return rc;

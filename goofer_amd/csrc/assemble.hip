@@ -10,7 +10,7 @@
 // One wave per row for the matrix kernels (row staged in LDS), one thread per sample for the last.
 #include <hip/hip_fp16.h>
 
-#include "common.h"
+#include "binops_core.h"
 
 constexpr int A_ROWS = 4;   // rows (waves) per workgroup
 
@@ -98,8 +98,16 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64_t total_out_rows, const int *__restrict__ row_note)
+// WARP: also write the row as gf.synthesize's harmonic branch wants it — formant-anchored + uniform warp (GOOFER.py:1004-1017,
+// warp_row of binops_core.h) with the synthesis batch's per-note shifts and per-row formants — while the row is at hand
+// (goofer_render_batch: one read of the edited rows instead of a second pass over the assembled envelope).
+template <bool WARP>
+__global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64_t total_out_rows, const int *__restrict__ row_note,
+                                                  const double *__restrict__ w_formants, const goofer_note_params *__restrict__ w_params,
+                                                  float *__restrict__ w_out, double nyq_d)
 {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double s_seg[A_ROWS][WARP_SEG_DOUBLES];
     const int B = a.n_bins;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // uniform row: scalar plan / tap loads
     const int64_t orow = (int64_t)blockIdx.x * A_ROWS + wave;
@@ -149,7 +157,25 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
                 gain *= 1.0f + gk[k] * wt;
             }
         }
-        out[b] = p.env_f64 ? (float)(v * (double)gain) : ((float)v) * gain;
+        const float o = p.env_f64 ? (float)(v * (double)gain) : ((float)v) * gain;
+        out[b] = o;
+        if (WARP) reinterpret_cast<float *>(smem)[(size_t)(2 * wave) * B + b] = o;
+    }
+    if (WARP) {
+        float *ra = reinterpret_cast<float *>(smem) + (size_t)(2 * wave) * B, *rb = ra + B;
+        wave_lds_sync();
+        const goofer_note_params &q = w_params[note];
+        double fs[4];
+        bool warp = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            fs[k] = q.f_shift[k];
+            warp |= fs[k] != 1.0;
+        }
+        const float *cur = warp_row(ra, rb, B, nyq_d, w_formants ? w_formants + orow * 4 : nullptr, fs, warp, (double)q.formant_shift, lane,
+                                    s_seg[wave]);
+        float *wo = w_out + orow * (int64_t)a.ld;
+        for (int b = lane; b < B; b += WAVE) wo[b] = cur[b];
     }
 }
 
@@ -383,8 +409,16 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         hipLaunchKernelGGL(k_row_notes, dim3((unsigned)((a->total_out_rows + 255) / 256)), dim3(256), 0, st, a->notes, a->n_notes,
                            a->total_out_rows, 1, row_note_out);
         LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(k_env_loop, dim3((unsigned)((a->total_out_rows + A_ROWS - 1) / A_ROWS)), dim3(256), 0, st, *a,
-                           a->total_out_rows, row_note_out);
+        const dim3 lgrid((unsigned)((a->total_out_rows + A_ROWS - 1) / A_ROWS));
+        ctx->warp_done = false;
+        if (ctx->warp_out && !a->any_fry) {                   // (the fry edit rewrites rows afterwards: the warp then stays a pass of its own)
+            hipLaunchKernelGGL(k_env_loop<true>, lgrid, dim3(256), sizeof(float) * 2 * A_ROWS * B, st, *a, a->total_out_rows, row_note_out,
+                               ctx->warp_formants, ctx->warp_params, ctx->warp_out, (double)ctx->plan.sr / 2.0);
+            ctx->warp_done = true;
+        } else {
+            hipLaunchKernelGGL(k_env_loop<false>, lgrid, dim3(256), 0, st, *a, a->total_out_rows, row_note_out, (const double *)nullptr,
+                               (const goofer_note_params *)nullptr, (float *)nullptr, 0.0);
+        }
         LAUNCH_CHECK(ctx);
         if (a->any_fry) {
             size_t lds = (size_t)A_ROWS * ((B + 3) & ~3) * sizeof(float);

@@ -49,6 +49,14 @@ struct goofer_ctx {
     // goofer_render_batch: the pulse chain forks as soon as the assembled f0 exists, not when the synthesis call starts
     hipEvent_t ev_entry = nullptr, ev_f0 = nullptr, ev_f0s = nullptr;
     const int32_t *ovf_flag = nullptr;     // device word of the last synth batch: 1 + index of a note whose onset slots overflowed
+    // goofer_render_batch, stem-split path: the assembly's frame-gather kernel also writes the rows the harmonic walker needs
+    // (formant-anchored + uniform warp), into a buffer the handle owns
+    const double *warp_formants = nullptr;
+    const goofer_note_params *warp_params = nullptr;
+    float *warp_out = nullptr;            // non-null for the duration of one goofer_render_batch that wants the fused warp
+    bool warp_done = false;               // the assembly wrote warp_rows for the batch being synthesised
+    float *warp_rows = nullptr;
+    size_t warp_rows_bytes = 0;
     const float2 *frame_picks = nullptr;   // per-frame (f0, mask) picks of the running goofer_synth_batch, or null
     bool early_req = false;           // set for the duration of one goofer_render_batch
     const float *early_f0 = nullptr;  // f0 array ev_f0 stands for (null: no event recorded)
