@@ -9,10 +9,15 @@
 
 #include "samples_core.h"
 
-// Each wave owns 64 consecutive short samples.  When they all belong to one note (the common case) the
-// wave first parks the 64 + 2*radius decimated mask values it needs in LDS (each value fetched once
-// instead of 2*radius+1 times); taps are shared by the block.  fp64 accumulate in tap order.
-#define MS_MAXWIN 1152     // floats per wave: 64 + 2*radius, radius <= 544
+// A workgroup owns MS_TILE consecutive short samples of the concatenated axis.  For every note that tile touches (one,
+// almost always) it parks the decimated mask values of the segment plus 2*radius in LDS — each fetched once instead of
+// 2*radius+1 times, and the note lookup / tap staging paid once per 1024 outputs: the kernel is a chain of dependent
+// loads in front of very little arithmetic, so fewer, longer workgroups are what makes it fast — then the waves take
+// the segment's 64-sample chunks in turn.  A chunk whose 64 + 2*radius window is all zeros (ones) answers 0 (the running
+// sum of the taps: the same additions in the same order) without the 2*radius+1-tap loop — voicing masks are 0/1
+// almost everywhere.  fp64 accumulate in tap order.
+#define MS_MAXWIN 1152     // LDS floats per workgroup = 4 * MS_MAXWIN >= MS_TILE + 2*radius
+#define MS_TILE 1024
 
 __global__ __launch_bounds__(256) void k_mask_short(const float *__restrict__ mask, const int64_t *__restrict__ sample_off,
                                                     int n_notes, int64_t total_short, const double *__restrict__ taps, int radius,
@@ -23,73 +28,70 @@ __global__ __launch_bounds__(256) void k_mask_short(const float *__restrict__ ma
     float *s_all = reinterpret_cast<float *>(s_taps + (2 * radius + 1));          // 4 * MS_MAXWIN floats
     __shared__ int s_lo[2];
     for (int i = threadIdx.x; i < 2 * radius + 1; i += blockDim.x) s_taps[i] = taps[i];
-    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t g0 = (int64_t)blockIdx.x * MS_TILE;
+    int64_t g1 = g0 + MS_TILE;                               // one past the tile
+    if (g1 > total_short) g1 = total_short;
     if (threadIdx.x < WAVE) {                               // largest note with short_base(note) <= g, first wave cooperatively
         auto key = [&](int k) { return short_base(sample_off, k); };
-        int64_t gl = g0 + blockDim.x - 1;
-        if (gl > total_short - 1) gl = total_short - 1;
         const int a = wave_find(n_notes, g0, (int)threadIdx.x, key);
-        const int b = wave_find(n_notes, gl, (int)threadIdx.x, key);
+        const int b = wave_find(n_notes, g1 - 1, (int)threadIdx.x, key);
         if (threadIdx.x == 0) { s_lo[0] = a; s_lo[1] = b; }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t g = g0 + threadIdx.x;
     const int n_lo = __builtin_amdgcn_readfirstlane(s_lo[0]), n_hi = __builtin_amdgcn_readfirstlane(s_lo[1]);
 
-    // Block-level staging: the 256 + 2r decimated mask values of the tile are fetched once for all four waves.
-    // A wave whose own 64 + 2r window is all zeros (ones) answers 0 (the running sum of the taps: the same
-    // additions in the same order) without the 2r+1-tap loop — voicing masks are 0/1 almost everywhere.
-    if (n_lo == n_hi && 2 * radius + (int)blockDim.x <= 4 * MS_MAXWIN) {
-        const int note = n_lo;
-        const int64_t sb = short_base(sample_off, note);
-        const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
-        const int64_t ns = (n + MASK_DS - 1) / MASK_DS;
-        const int64_t q0 = g0 - sb;
-        const float *m = mask + base;
-        const int win = (int)blockDim.x + 2 * radius;
-        for (int w = threadIdx.x; w < win; w += blockDim.x) {
-            const int64_t idx = reflect_index(q0 - radius + w, ns);
-            s_all[w] = ns > 0 ? m[MASK_DS * idx] : 0.f;
-        }
-        __syncthreads();
-        const int64_t q = g - sb;
-        const bool live = g < total_short && q < ns;
-        const float *x0 = s_all + wv * WAVE;                 // this wave's window: 64 + 2r values
-        bool all0 = true, all1 = true;
-        for (int w = lane; w < WAVE + 2 * radius; w += WAVE) {
-            const float v = x0[w];
-            all0 &= v == 0.0f;
-            all1 &= v == 1.0f;
-        }
-        if (__all(all0)) {
-            if (live) short_s[g] = 0.0;
-            return;
-        }
-        if (__all(all1)) {
-            if (live) short_s[g] = tap_sum;
-            return;
-        }
-        if (live) {
-            double acc = 0.0;
-            const float *x = x0 + lane;
-            for (int j = 0; j <= 2 * radius; ++j) acc += s_taps[j] * (double)x[j];
-            short_s[g] = acc;
+    if (2 * radius + MS_TILE <= 4 * MS_MAXWIN) {
+        for (int note = n_lo; note <= n_hi; ++note) {
+            const int64_t sb = short_base(sample_off, note);
+            const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+            const int64_t ns = (n + MASK_DS - 1) / MASK_DS;
+            const int64_t s0 = g0 > sb ? g0 : sb, s1 = g1 < sb + ns ? g1 : sb + ns;    // the tile's part of this note's live range
+            if (s1 <= s0) continue;                          // workgroup-uniform
+            const int64_t q0 = s0 - sb;
+            const int len = (int)(s1 - s0);
+            const float *m = mask + base;
+            if (note != n_lo) __syncthreads();               // the previous note's window is no longer read
+            for (int w = threadIdx.x; w < len + 2 * radius; w += blockDim.x) s_all[w] = m[MASK_DS * reflect_index(q0 - radius + w, ns)];
+            __syncthreads();
+            for (int c0 = wv * WAVE; c0 < len; c0 += 4 * WAVE) {
+                const float *x0 = s_all + c0;                // this chunk's window: cl + 2r values
+                const int cl = len - c0 < WAVE ? len - c0 : WAVE;
+                const bool live = lane < cl;
+                bool all0 = true, all1 = true;
+                for (int w = lane; w < cl + 2 * radius; w += WAVE) {
+                    const float v = x0[w];
+                    all0 &= v == 0.0f;
+                    all1 &= v == 1.0f;
+                }
+                double acc;
+                if (__all(all0)) {
+                    acc = 0.0;
+                } else if (__all(all1)) {
+                    acc = tap_sum;
+                } else {
+                    acc = 0.0;
+                    const float *x = x0 + lane;
+                    if (live)
+                        for (int j = 0; j <= 2 * radius; ++j) acc += s_taps[j] * (double)x[j];
+                }
+                if (live) short_s[s0 + c0 + lane] = acc;
+            }
         }
         return;
     }
-    __syncthreads();
-    if (g >= total_short) return;
-    int note = n_lo;
-    while (note + 1 < n_notes && short_base(sample_off, note + 1) <= g) ++note;
-    const int64_t q = g - short_base(sample_off, note);
-    const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
-    const int64_t ns = (n + MASK_DS - 1) / MASK_DS;
-    if (q >= ns) return;
-    const float *m = mask + base;
-    double acc = 0.0;
-    for (int j = 0; j <= 2 * radius; ++j) acc += s_taps[j] * (double)m[MASK_DS * reflect_index(q + j - radius, ns)];
-    short_s[g] = acc;
+    for (int64_t g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
+        int note = n_lo;
+        while (note + 1 < n_notes && short_base(sample_off, note + 1) <= g) ++note;
+        const int64_t q = g - short_base(sample_off, note);
+        const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+        const int64_t ns = (n + MASK_DS - 1) / MASK_DS;
+        if (q >= ns) continue;
+        const float *m = mask + base;
+        double acc = 0.0;
+        for (int j = 0; j <= 2 * radius; ++j) acc += s_taps[j] * (double)m[MASK_DS * reflect_index(q + j - radius, ns)];
+        short_s[g] = acc;
+    }
 }
 
 // per-note constants of the mask upsampler: 1/(n-1) and 1/(ns-1) as true divisions (numpy's linspace step)
@@ -977,7 +979,7 @@ int launch_mask_short(goofer_ctx *ctx, const float *mask, const int64_t *sample_
 {
     int64_t total_short = total_samples / MASK_DS + n_notes;
     if (total_short <= 0) return GOOFER_OK;
-    hipLaunchKernelGGL(k_mask_short, dim3((unsigned)((total_short + 255) / 256)), dim3(256),
+    hipLaunchKernelGGL(k_mask_short, dim3((unsigned)((total_short + MS_TILE - 1) / MS_TILE)), dim3(256),
                        sizeof(double) * (2 * radius + 1) + sizeof(float) * 4 * MS_MAXWIN, st, mask, sample_off, n_notes, total_short,
                        d_taps, radius, short_s, tap_sum);
     LAUNCH_CHECK(ctx);
