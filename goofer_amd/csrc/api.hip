@@ -1291,7 +1291,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         int rc2 = ensure_side_stream(ctx);
         if (rc2) return rc2;
         if (pev) sev = ctx->prof_side + (size_t)ctx->prof_steps * 4;
-        if (stem_path) HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st));   // the frame maps and everything before them on this stream
+        if (stem_path && !ctx->warp_done) HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st));   // the frame maps and everything before them on this stream (for k_warp_bins)
         if (!early) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
@@ -1327,7 +1327,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if (sev) HIP_TRY(ctx, hipEventRecord(sev[3], pst));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, pst));
         // meanwhile, on the caller's stream
-        if (early) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_f0s, 0));   // the scaled f0 comes from the side stream
+        if (early && !f0_alias) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_f0s, 0));   // the scaled f0 comes from the side stream
         if (stem_path) {
             if ((rc = stems_aperiodic())) return rc;
         } else {

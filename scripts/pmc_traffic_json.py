@@ -30,14 +30,25 @@ for which, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 meta = {"workload": bench["config"]["workload"], "frames": bench["config"]["frames_per_gpu"], "samples": bench["config"]["samples_per_gpu"],
         "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (only --kernel-trace beside them); per-launch means in KB",
         "correction": "gfx950: FETCH_SIZE reports half of a coalesced streaming read (MI355X_MICROARCH.md, HBM) -> bytes = (2*FETCH + WRITE)*1024"}
-# HBM bytes of one step: every kernel's mean x its launches per step (a step = one k_sample_assemble launch)
-steps = max(1, res.get("k_sample_assemble", {}).get("launches_sampled", 1))
-tot = 0.0
+# HBM bytes of one step (= one goofer_render_batch).  The profiled command also times the assembly alone and the stand-alone
+# rFFT, so launches are not simply "per step": a kernel launched at least once per step counts once, the once-per-process
+# plan kernels pro rata, and the kernels that only the extra stages launch are left out.
+steps = max(1, res.get("k_note_finish", res.get("k_sample_assemble", {})).get("launches_sampled", 1))
+stems = any(k.startswith("void k_harm_stem") for k in res)
+fused_warp = any(k.startswith("void k_env_loop<true>") for k in res)
+tot, per_kernel = 0.0, {}
 for k, v in res.items():
-    if k.startswith(("k_", "void k_")) and "FETCH_SIZE_KB" in v and "WRITE_SIZE_KB" in v:
-        tot += (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 * v["launches_sampled"] / steps
+    if not k.startswith(("k_", "void k_")) or "FETCH_SIZE_KB" not in v or "WRITE_SIZE_KB" not in v:
+        continue
+    if (stems and k.startswith("void k_rfft_frames")) or (fused_warp and k.startswith("void k_env_loop<false>")):
+        continue
+    per_step = min(1.0, v["launches_sampled"] / steps)
+    per_kernel[k] = (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 * per_step
+    tot += per_kernel[k]
 meta["step_hbm_bytes"] = tot
-meta["step_hbm_bytes_note"] = "sum over the step's kernels of (2*FETCH + WRITE)*1024 x launches per step; plan-time kernels (k_pulse_peak, k_pulse_shape_table) run once per process and are included pro rata"
+meta["step_hbm_bytes_by_kernel"] = {k: round(v) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1])}
+meta["step_hbm_bytes_note"] = ("sum over the kernels of one goofer_render_batch of (2*FETCH + WRITE)*1024 per launch; kernels the bench launches "
+                               "outside the step (stand-alone rFFT, assembly-only timing) are left out, plan-time kernels counted pro rata")
 json.dump({"_meta": meta, "kernels": {k: v for k, v in sorted(res.items()) if k.startswith(("k_", "void k_"))}},
           open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
 print("wrote", os.listdir(dst))
