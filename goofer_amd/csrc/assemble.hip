@@ -13,6 +13,7 @@
 #include "binops_core.h"
 
 constexpr int A_ROWS = 4;   // rows (waves) per workgroup
+constexpr int ES_HALO = 64; // k_env_edit: halo floats either side of the staged row (the 'es' blur has radius <= 28)
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -29,10 +30,10 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t er = (int64_t)blockIdx.x * A_ROWS + wave;
     if (er >= total_edit_rows) return;                       // no block barrier below
-    const int stride = (3 * B + a.max_K + 3) & ~3;            // floats per wave, 16-byte multiple
+    const int stride = (3 * B + 2 * ES_HALO + a.max_K + 3) & ~3;   // floats per wave, 16-byte multiple
     double *tmp = reinterpret_cast<double *>(reinterpret_cast<float *>(smem) + (size_t)wave * stride);   // [B] fp64 scratch
-    float *row = reinterpret_cast<float *>(tmp + B);          // [B] current row
-    float *kv = row + B;                                      // [max_K] decoded knot values
+    float *row = reinterpret_cast<float *>(tmp + B) + ES_HALO;   // [B] current row, ES_HALO floats of reflected halo either side
+    float *kv = row + B + ES_HALO;                            // [max_K] decoded knot values
     const int note = row_note[er];
     const goofer_note_plan p = a.notes[note];
     const int r = (int)(er - p.edit_off);                     // index inside the note's edited window
@@ -65,9 +66,22 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
         const double *taps = a.es_taps + p.es_taps_off;
         const int rad = p.es_radius;
         double s_src = 0.0, s_mod = 0.0;
+        const bool halo = rad <= ES_HALO && rad < B;          // numpy 'reflect' halo parked beside the row: no index map per tap
+        if (halo) {
+            for (int h = lane; h < 2 * rad; h += WAVE) {
+                const int i = h < rad ? -1 - h : B + (h - rad);
+                row[i] = row[(int)reflect_index(i, B)];
+            }
+            wave_lds_sync();
+        }
         for (int b = lane; b < B; b += WAVE) {
             double acc = 0.0;
-            for (int j = 0; j <= 2 * rad; ++j) acc += taps[j] * (double)row[reflect_index(b + j - rad, B)];
+            if (halo) {
+                const float *x = row + (b - rad);
+                for (int j = 0; j <= 2 * rad; ++j) acc += taps[j] * (double)x[j];
+            } else {
+                for (int j = 0; j <= 2 * rad; ++j) acc += taps[j] * (double)row[reflect_index(b + j - rad, B)];
+            }
             double src = (double)row[b];
             double mod = p.es_mode == 1 ? acc : fmax(0.0, src + p.es_amount * (src - acc));
             tmp[b] = mod;
@@ -412,7 +426,7 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         hipLaunchKernelGGL(k_row_notes, dim3((unsigned)((a->total_edit_rows + 255) / 256)), dim3(256), 0, st, a->notes, a->n_notes,
                            a->total_edit_rows, 0, row_note_edit);
         LAUNCH_CHECK(ctx);
-        size_t lds = (size_t)A_ROWS * ((3 * B + a->max_K + 3) & ~3) * sizeof(float);
+        size_t lds = (size_t)A_ROWS * ((3 * B + 2 * ES_HALO + a->max_K + 3) & ~3) * sizeof(float);
         if (lds > 64 * 1024) {
             if (lds > 160 * 1024) return goofer_fail(ctx, GOOFER_EINVAL, "envelope rows too wide for the edit kernel's LDS staging");
             if (int arc = kernel_allow_max_lds(ctx, (const void *)k_env_edit)) return arc;
