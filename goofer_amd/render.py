@@ -104,7 +104,7 @@ class Renderer:
         device draws phases from Philox keyed by ``seed`` and the note index."""
         if not jobs:
             return []
-        prep = self.prepare(jobs, phi_seeds=phi_seeds)
+        prep = self.prepare(jobs, phi_seeds=phi_seeds, trim_rows=not return_parts)   # tests look at the whole assembled envelope
         out = self.run(prep, seed=seed, keep_stems=return_parts)
         self.ctx.check()                                   # synchronises; raises if the device flagged a note
         mix = out["mix"].cpu().numpy()
@@ -205,10 +205,14 @@ class Renderer:
         ctx._check(ctx.lib.goofer_post_batch(ctx.h, C.byref(P), ctx._stream()))
         out["_keep_post"] = (extra, post, s_host)
 
-    def prepare(self, jobs, phi_seeds=None, note_ids=None):
+    def prepare(self, jobs, phi_seeds=None, note_ids=None, trim_rows: bool = True):
         """Plan every note on the host and make the batch resident in HBM (plans, tables, sources).
         ``note_ids`` key the on-device noise phases (default: the position in ``jobs``), so a note can render to the
-        same bits whatever batch or rank it lands in."""
+        same bits whatever batch or rank it lands in.
+        ``trim_rows``: assemble only the envelope rows synthesize can reach.  The reference's L0 loop hands over more
+        envelope frames than the note has STFT frames (every cross-faded repeat is appended again, SillySampler.py:657-672)
+        and ``gf.synthesize`` cuts the envelope to ``1 + n // hop`` frames (GOOFER.py:1115-1119): the rows behind that are
+        never read — a fifth of the rows of a one-second note.  ``False`` keeps them (tests that compare the whole envelope)."""
         ctx = self.ctx
         sr, n_fft = jobs[0][0].sr, jobs[0][0].n_fft
         if any(j[0].sr != sr or j[0].n_fft != n_fft for j in jobs):
@@ -236,7 +240,7 @@ class Renderer:
                                "fry_glide_hi", "fry_a", "fry_b", "fry_fade", "pd_on", "pd_base")}
         knots_cat, mask_cat, bend_cat, tapi_cat, tapw_cat, fst_cat, F_cat = [], [], [], [], [], [], []
         k_off = e_off = t_off = s_off = o_off = b_off = 0
-        hz_ids = {}
+        hz_ids, live_rows, env_lens = {}, {}, []
         for i, ((src, req), p) in enumerate(zip(jobs, plans)):
             K = src.knots.shape[0]
             if src.hz_knots is None:                           # dense source: rows are the envelope, no lerp plan
@@ -254,7 +258,6 @@ class Renderer:
             c = col
             c["knot_off"].append(k_off); c["K"].append(K); c["lerp_plan"].append(lp); c["n_src_rows"].append(src.knots.shape[1])
             c["reverse"].append(int(req.reverse))
-            c["row_lo"].append(p.row_lo); c["n_edit"].append(p.row_hi - p.row_lo); c["edit_off"].append(e_off)
             tilt = -1
             if req.brightness_env != 1.0:
                 tk = float(req.brightness_env)
@@ -286,6 +289,15 @@ class Renderer:
                 fw = fw_keys[fk]
             c["fw_plan"].append(fw)
             T_env = p.tap_idx.shape[0]
+            row_lo, row_hi = p.row_lo, p.row_hi
+            if trim_rows and T_env > 1 + p.n_out // self.hop:
+                T_env = 1 + p.n_out // self.hop
+                lim = live_rows.get(id(p.tap_idx))             # notes of one geometry share the tap arrays
+                if lim is None or lim[0] != T_env:
+                    used = p.tap_idx[:T_env][p.tap_w[:T_env] != 0.0]
+                    lim = live_rows[id(p.tap_idx)] = (T_env, int(used.min()) if used.size else 0, int(used.max()) + 1 if used.size else 0)
+                row_lo, row_hi = lim[1], lim[2]
+            c["row_lo"].append(row_lo); c["n_edit"].append(row_hi - row_lo); c["edit_off"].append(e_off)
             c["tap_off"].append(t_off); c["env_off"].append(t_off); c["n_out_rows"].append(T_env); c["env_f64"].append(int(p.env_f64))
             c["fst"].append(req.formant_strength)
             c["src_sample_off"].append(s_off); c["ylen"].append(src.ylen); c["out_sample_off"].append(o_off)
@@ -311,12 +323,13 @@ class Renderer:
             if tc:
                 semis = semis + (tc / 100.0)
             bend_cat.append(semis)
-            tapi_cat.append(p.tap_idx)
-            tapw_cat.append(p.tap_w)
-            fst_cat.append(p.fst_tracks)
-            F_cat.append(p.formants)
+            tapi_cat.append(p.tap_idx[:T_env])
+            tapw_cat.append(p.tap_w[:T_env])
+            fst_cat.append(p.fst_tracks[:T_env])
+            F_cat.append(p.formants[:T_env])
+            env_lens.append(T_env)
             k_off += src.knots.size
-            e_off += p.row_hi - p.row_lo
+            e_off += row_hi - row_lo
             t_off += T_env
             s_off += src.ylen
             o_off += p.n_out
@@ -416,7 +429,6 @@ class Renderer:
             a.f0_mul, a.f0_mul_out = d["f0_mul"].data_ptr(), f0_growl.data_ptr()
         has_post = any(r.subharm_gain > 0 or r.growl_mix > 0 or r.aperiodic_mix > 0 or r.sd_strength > 0 or r.tension != 0
                        or r.pitch_dyn != 0 for _, r in jobs) or any_fry
-        env_lens = [p.tap_idx.shape[0] for p in plans]
         phi = None
         if phi_seeds is not None:
             mats = []

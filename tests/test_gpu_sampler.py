@@ -475,3 +475,26 @@ def test_index_plans_on_device(renderer):
         assert np.array_equal(env_dev[e_off[j]:e_off[j + 1], 0], env_dev[e_off[j]:e_off[j + 1], 512]), tag
         want_mask = np.asarray(g[f"{tag}_mask"], dtype=np.float32)
         assert np.array_equal(mask_dev[s_off[j]:s_off[j + 1]], want_mask), tag
+
+
+def test_trimmed_envelope_rows_change_nothing(renderer):
+    """Renderer.prepare(trim_rows=True) leaves out the envelope rows gf.synthesize never reaches (the L0 loop hands over more
+    frames than the note has STFT frames, GOOFER.py:1115-1119 cuts them): the audio is the same bits, with fewer rows assembled."""
+    from goofer_amd.render import Source
+    from goofer_amd import sampler as S
+    jobs, seeds = [], []
+    for k, (flags, length, vel) in enumerate([("L0fst30", 900, 100), ("L1g-10", 700, 100), ("L2br20", 800, 60), ("L0R1es-40", 1000, 140),
+                                              ("fa20fw30vf30", 650, 100), ("L0sa40", 500, 100)]):
+        src = syn.make_source(91000 + k, seconds=0.45)
+        args = ("C4", str(vel), flags, "30", str(length), "80", "40", "100", "0", "!120", "AA#5#AF#3#/+")
+        jobs.append((Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]),
+                     S.decode_request(*args)))
+        seeds.append(8100 + k)
+    full = renderer.prepare(jobs, phi_seeds=seeds, trim_rows=False)
+    trim = renderer.prepare(jobs, phi_seeds=seeds, trim_rows=True)
+    assert sum(trim["env_lens"]) < sum(full["env_lens"]) and trim["lens"] == full["lens"]
+    a = renderer.run(full, seed=3)["mix"].cpu().numpy()
+    b = renderer.run(trim, seed=3)["mix"].cpu().numpy()
+    renderer.ctx.check()
+    assert a.shape == b.shape and np.array_equal(a, b)
+    assert np.isfinite(a).all() and np.abs(a).max() > 0
