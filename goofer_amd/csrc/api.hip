@@ -637,6 +637,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "fused_ola")) { ctx->ola_fused = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "overlap")) { ctx->overlap = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "stems")) { ctx->stems = value != 0; return GOOFER_OK; }
+    if (!strcmp(name, "skip_zero")) { ctx->skip_zero = value != 0; return GOOFER_OK; }
     return goofer_fail(ctx, GOOFER_EINVAL, "unknown option %s", name);
 }
 

@@ -67,6 +67,7 @@ struct goofer_ctx {
     bool fused = false;           // opt-in fused per-frame kernels (fused.hip); default: one kernel per reference step
     bool stems = true;            // stem-split frame walkers (stems.hip) where the geometry allows (hop == n_fft / 4); false: the
                                   // one-kernel-per-reference-step pipeline with the spectra in HBM (A/B parity path)
+    bool skip_zero = true;        // noise walker: skip transforms whose stem gain is exactly zero over everything they reach (option "skip_zero")
     bool prof_stems = false;      // the last profiled batch ran the stem-split path (stage order differs)
     // per-context kernel state: hipFuncSetAttribute is per device, and a handle belongs to one device, so what was set /
     // queried is remembered here and never in process-wide statics

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
                                                         const int64_t *__restrict__ sample_off, const float2 *__restrict__ picks,
                                                         const goofer_note_params *__restrict__ params, uint64_t seed,
                                                         const float *__restrict__ freqs, const float *__restrict__ bright,
-                                                        const stem_taps taps, int do_blur,
+                                                        const stem_taps taps, int mode,   // bit 0: blur the rows here; bit 1: never skip a transform (A/B)
                                                         const double *__restrict__ short_s, const double *__restrict__ steps,
                                                         float *__restrict__ uv, float *__restrict__ bre, int run,
                                                         const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twh,
@@ -357,13 +357,13 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
         }
     };
     auto hop_check_done = [&]() {
-        bool one = true, zero = true;
+        bool one = !(mode & 2), zero = one;
         if (!hk_none) {
             const bool same = hk[0] == hk_c && hk[1] == hk_c && hk_hi - hk_lo < 2 * WAVE;
             const bool flat = __all(same);
             const float cf = (float)hk_c;
-            one = flat && (1.0f - cf) == 0.0f;
-            zero = flat && cf == 0.0f;
+            one = one && flat && (1.0f - cf) == 0.0f;
+            zero = zero && flat && cf == 0.0f;
         }
         one_bits = (one_bits >> 1) | (one ? 8u : 0u);
         zero_bits = (zero_bits >> 1) | (zero ? 8u : 0u);
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
         float en[PER];
         {
             float o9[9];
-            if (do_blur) {
+            if (mode & 1) {
                 *reinterpret_cast<float4 *>(rp + 8 + 8 * lane) = ea;
                 *reinterpret_cast<float4 *>(rp + 8 + 8 * lane + 4) = eb4;
                 wave_lds_sync();
@@ -919,11 +919,11 @@ int launch_noise_stems(goofer_ctx *ctx, const float *env, int ld, const int64_t 
     const dim3 grid((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
     if (phi)
         hipLaunchKernelGGL((k_noise_stems<M, true>), grid, dim3(256), lds, st, env, ld, row_src, phi, F, frame_note, frame_off,
-                           sample_off, picks, params, seed, p.freqs, p.bright_b, plan_taps(p), preblurred ? 0 : 1, short_s, steps, uv,
+                           sample_off, picks, params, seed, p.freqs, p.bright_b, plan_taps(p), (preblurred ? 0 : 1) | (ctx->skip_zero ? 0 : 2), short_s, steps, uv,
                            bre, run, p.tw_full, p.tw_half, p.window);
     else
         hipLaunchKernelGGL((k_noise_stems<M, false>), grid, dim3(256), lds, st, env, ld, row_src, phi, F, frame_note, frame_off,
-                           sample_off, picks, params, seed, p.freqs, p.bright_b, plan_taps(p), preblurred ? 0 : 1, short_s, steps, uv,
+                           sample_off, picks, params, seed, p.freqs, p.bright_b, plan_taps(p), (preblurred ? 0 : 1) | (ctx->skip_zero ? 0 : 2), short_s, steps, uv,
                            bre, run, p.tw_full, p.tw_half, p.window);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;

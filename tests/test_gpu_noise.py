@@ -124,6 +124,14 @@ def test_stem_walkers_draw_the_same_noise_as_the_checked_path(ctx, voiced):
         assert np.array_equal(a[k], b[k]), k
     assert np.abs(a["uv"]).max() > 0 and np.all(np.isfinite(a["mix"]))
     assert (np.abs(a["bre"]).max() > 0) == voiced                 # an all-unvoiced note has no breath stem (mask smooths to 0)
+    # and with the exact-zero transform skipping switched off (every frame runs both inverse transforms): the same values
+    ctx.set_option("skip_zero", 0)
+    try:
+        c = _run(ctx, envs, f0s, masks, par, n, seed=99, stems=1)
+    finally:
+        ctx.set_option("skip_zero", 1)
+    for k in ("harm", "uv", "bre", "mix"):
+        assert np.array_equal(a[k], c[k]), k
 
 
 def test_unvoiced_stem_band_power_matches_the_oracle_over_64_seeds(ctx):
