@@ -170,13 +170,21 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
         bhi[k] = on[k] ? (Fk[k] + R) * inv_fstep + 1.0f : -3.0e38f;
     }
     float *out = a.env_out + orow * (int64_t)a.ld;
+    // a plain copy of one source row (most rows: slices and loop repeats outside the cross-fades): 0.0 + 1.0 x is x, and
+    // both roundings of the product below — fp32, or fp64 rounded to fp32 — are the fp32 product, so the row stays in fp32
+    const bool copy = w[0] == 1.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 0.0;
     for (int c0 = 0; c0 < B; c0 += WAVE) {
         const int b = c0 + lane;
         if (b >= B) break;
         double v = 0.0;
+        float vf = 0.f;
+        if (copy) {
+            vf = src[0][b];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (w[k] != 0.0) v += w[k] * (double)src[k][b];
+            for (int k = 0; k < 4; ++k)
+                if (w[k] != 0.0) v += w[k] * (double)src[k][b];
+        }
         float gain = 1.0f;
         const float fb = (float)(b >= B - 1 ? (double)a.sr / 2.0 : (double)b * fstep);    // np.linspace(0, sr/2, B) as fp32
 #pragma unroll
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
                 gain *= 1.0f + gk[k] * wt;
             }
         }
-        const float o = p.env_f64 ? (float)(v * (double)gain) : ((float)v) * gain;
+        const float o = copy ? vf * gain : (p.env_f64 ? (float)(v * (double)gain) : ((float)v) * gain);
         out[b] = o;
         if (WARP) reinterpret_cast<float *>(smem)[(size_t)(2 * wave) * B + b] = o;
     }

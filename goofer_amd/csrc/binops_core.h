@@ -169,16 +169,28 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, dou
                     seg[3 * lane + 2] = xk;
                 }
                 wave_lds_sync();
-                const double d1 = dst[1], d2 = len > 2 ? dst[2] : 0.0, d3 = len > 3 ? dst[3] : 0.0, d4 = len > 4 ? dst[4] : 0.0,
-                             d5 = len > 5 ? dst[5] : 0.0;
+                // segment of bin b = number of anchors d_k (k >= 1) with d_k <= x(b), x(b) = b step (nyq for the last bin) — x is
+                // increasing in b, so anchor k contributes from the first bin thr_k on: lane k finds thr_k once per row with the
+                // very comparison the per-bin search would make, and the bins compare integers (five fp64 compares, a
+                // conversion and a multiply per bin less)
+                int thr = n_bins;
+                if (lane >= 1 && lane < len) {
+                    double dk = 0.0;
+#pragma unroll
+                    for (int k = 1; k < 6; ++k)
+                        if (k == lane) dk = dst[k];
+                    auto xb = [&](int c) { return c >= n_bins - 1 ? nyq : (double)c * step; };
+                    const double est = ceil(dk * inv_step);
+                    int c = est < 0.0 ? 0 : (est > (double)(n_bins - 1) ? n_bins - 1 : (int)est);
+                    while (c > 0 && dk <= xb(c - 1)) --c;
+                    while (c < n_bins && !(dk <= xb(c))) ++c;
+                    thr = c;
+                }
+                const int t1 = __shfl(thr, 1, WAVE), t2 = len > 2 ? __shfl(thr, 2, WAVE) : n_bins, t3 = len > 3 ? __shfl(thr, 3, WAVE) : n_bins,
+                          t4 = len > 4 ? __shfl(thr, 4, WAVE) : n_bins, t5 = len > 5 ? __shfl(thr, 5, WAVE) : n_bins;
                 const double top = (double)(n_bins - 1);
                 for (int b = lane; b < n_bins; b += WAVE) {
-                    const double x = b >= n_bins - 1 ? nyq : (double)b * step;
-                    int j = (d1 <= x);
-                    j += (len > 2) & (d2 <= x);
-                    j += (len > 3) & (d3 <= x);
-                    j += (len > 4) & (d4 <= x);
-                    j += (len > 5) & (d5 <= x);
+                    const int j = (b >= t1) + (b >= t2) + (b >= t3) + (b >= t4) + (b >= t5);
                     double pos = fma(seg[3 * j + 1], (double)b, seg[3 * j]);
                     pos = pos < 0.0 ? 0.0 : (pos > top ? top : pos);
                     int j2 = (int)pos;
