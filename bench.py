@@ -48,8 +48,6 @@ def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int) ->
         "harm_shape": (16 * B + 4 * B) * F,          # S in+out, env in
         "noise_spectra": (16 * B + 4 * B) * F,       # two spectra out, env in (+4B when phi is injected)
         "gauss_env": 8 * B * F, "warp_env": 8 * B * F, "assemble": 12 * B * F + 12 * N,
-        # fused frame kernels: unique pulse samples + env row in, windowed frame(s) out
-        "harm_frames": (4 * hop + 4 * B + 4 * n_fft) * F, "noise_frames": (4 * B + 8 * n_fft) * F,
         "phase_inc": 12 * N, "pulse_onsets": 4 * N, "pulse_place": 4 * N,     # the walk reads f0 and divides by sr itself
         "mask_short": 4 * N / 4 + 8 * N / 4, "stem_gains": 24 * N,
         "apply_gain": 16 * N,                         # three stems in, the mix out (mix_only)
@@ -408,7 +406,7 @@ def main():
             "roofline_step": {"bound": "hbm", "alg_bytes_per_step": alg_step, "achieved": alg_step / (step_ms * 1e-3) / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "traffic": None if job else pmc_step_traffic(wl.frames),
-                              "note": "the fused frame walkers are vector-issue / latency bound (about 30 flop per algorithmic byte), "
+                              "note": "the stem walkers are vector-issue / latency bound (about 30 flop per algorithmic byte), "
                                       "not HBM bound: DESIGN.md section 3"},
         }
         if job or world > 1:

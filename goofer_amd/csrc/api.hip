@@ -79,9 +79,6 @@ int launch_vocal_roughness(goofer_ctx *, const float *, const float *, const flo
 int launch_lerp_axis0(goofer_ctx *, const float *, int64_t, int64_t, float *, int64_t, int64_t, int, hipStream_t);
 int launch_lerp_1d(goofer_ctx *, const float *, int64_t, float *, int64_t, hipStream_t);
 int launch_stem_peak(goofer_ctx *, const float *, const float *, const float *, const int64_t *, int, int64_t, float *, hipStream_t);
-int launch_harm_frames(goofer_ctx *, const float *, const goofer_batch *, const float *, const int *, const int64_t *, float *, float *,
-                       hipStream_t);
-int launch_noise_frames(goofer_ctx *, const goofer_batch *, const float *, const int *, const int64_t *, float *, float *, hipStream_t);
 int launch_stem_gains(goofer_ctx *, float *, float *, float *, const double *, const int64_t *, int, int64_t,
                       const goofer_note_params *, float *, double *, hipStream_t);
 int launch_apply_gain(goofer_ctx *, float *, float *, float *, float *, float *, const int64_t *, int, int64_t,
@@ -609,10 +606,6 @@ int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages)
 
 const char *goofer_profile_stage_name(int stage) { return stage >= 0 && stage < PROF_STAGES ? PROF_NAMES[stage] : ""; }
 
-static const char *const PROF_NAMES_FUSED[PROF_STAGES] = {
-    "setup_maps", "", "", "phase_inc", "pulse_onsets", "pulse_place", "harm_frames", "", "", "noise_frames", "", "",
-    "mask_short", "ola3_gains", "apply_gain", "", "", ""};
-
 static const char *const PROF_NAMES_STEMS[PROF_STAGES] = {
     "setup_maps", "", "", "phase_inc", "pulse_onsets", "pulse_place", "mask_short", "noise_stems",
     "", "harm_stem", "", "", "", "note_finish", "", "", "", ""};
@@ -624,16 +617,14 @@ static const char *const PROF_NAMES_OLA[PROF_STAGES] = {
 const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage)
 {
     if (stage < 0 || stage >= PROF_STAGES) return "";
-    if (ctx && ctx->fused) return PROF_NAMES_FUSED[stage];
     if (ctx && ctx->prof_stems) return PROF_NAMES_STEMS[stage];
     return (ctx && ctx->ola_fused) ? PROF_NAMES_OLA[stage] : PROF_NAMES[stage];
 }
 
-/* options: "fused" = 1 (default) fused per-frame kernels, 0 one kernel per reference step (A/B parity) */
+/* options: see include/goofer_hip.h */
 int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return GOOFER_EINVAL;
-    if (!strcmp(name, "fused")) { ctx->fused = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "fused_ola")) { ctx->ola_fused = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "overlap")) { ctx->overlap = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "stems")) { ctx->stems = value != 0; return GOOFER_OK; }
@@ -1211,14 +1202,14 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         ++stage;                                                     \
     } while (0)
 
-    const bool ola_one = ctx->ola_fused && !(ctx->fused && !b->env_noise) && (p.hop % 2 == 0);
+    const bool ola_one = ctx->ola_fused && (p.hop % 2 == 0);
     unsigned fb = (unsigned)((F + 255) / 256);
     // goofer_render_batch: the assembly recorded ev_f0 right after the f0 / mask kernel.  The pulse chain (f0 scaling,
     // sequential walk, placement) then runs on the side stream from that point on, beside the envelope assembly and the
     // map kernels, instead of starting when this call's first kernel is reached in stream order.
     // Stem-split walkers (stems.hip): no spectra in HBM.  The legacy kernels stay for the other geometries, for the
     // volume-jitter / sub-harmonic layers (which edit the stems or the pulse train between the steps) and as the A/B path.
-    const bool stem_path = ctx->stems && ola_one && !ctx->fused && stems_supported(p) && !sub_on && !jit_vol;
+    const bool stem_path = ctx->stems && ola_one && stems_supported(p) && !sub_on && !jit_vol;
     if (pev) ctx->prof_stems = stem_path;
     const bool side_on = ctx->overlap && ola_one && !sub_on;
     const bool early = side_on && !jit_f0 && ctx->early_req && ctx->early_f0 == b->f0 && ctx->side != nullptr;
@@ -1401,16 +1392,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         return GOOFER_OK;
     }
     // spectra -> windowed time frames of the three stems
-    if (ctx->fused && !b->env_noise) {
-        MARK();   // 6: harm_frames = rFFT + warp + shape + irFFT (envelope stages 1, 2 folded in)
-        if ((rc = launch_harm_frames(ctx, pulse, b, f0s, frame_note, row_src, frames, note_mag, st))) return rc;
-        MARK();   // 7
-        MARK();   // 8
-        MARK();   // 9: noise_frames = blur + spectra + 2 irFFT
-        if ((rc = launch_noise_frames(ctx, b, f0s, frame_note, row_src, frames_u, frames_b, st))) return rc;
-        MARK();   // 10
-        MARK();   // 11
-    } else {
+    {
         MARK();   // 6: framewise rFFT of the pulse train
         if ((rc = launch_rfft_frames_mapped(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, st))) return rc;
         MARK();   // 7
@@ -1507,7 +1489,7 @@ int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *asmb, const goof
     // hand, so it writes the warped copy too (k_env_loop<true>) — one pass instead of a separate read + write of the matrix.
     ctx->warp_out = nullptr;
     ctx->warp_done = false;
-    if (ctx->stems && !ctx->fused && ctx->ola_fused && ctx->overlap && stems_supported(ctx->plan) && asmb->env_out == b->env &&
+    if (ctx->stems && ctx->ola_fused && ctx->overlap && stems_supported(ctx->plan) && asmb->env_out == b->env &&
         asmb->n_notes == b->n_notes && asmb->total_out_rows == b->total_env_rows && asmb->ld == b->ld && !asmb->any_fry) {
         const size_t need = (size_t)b->total_env_rows * b->ld * sizeof(float);
         if (need > ctx->warp_rows_bytes) {

@@ -1,4 +1,4 @@
-// Bin-axis device helpers shared by binops.hip and fused.hip (gfx950): numpy-exact interpolation,
+// Bin-axis device helpers shared by binops.hip, assemble.hip and stems.hip (gfx950): numpy-exact interpolation,
 // envelope warps on an LDS row, high-pass mask, 5-tap blur, frame picks, Philox.
 #pragma once
 

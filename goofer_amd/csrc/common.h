@@ -64,7 +64,6 @@ struct goofer_ctx {
     hipEvent_t *prof_main2 = nullptr;   // [prof_cap][2]: ends of noise_spectra / mask_short when they run beside it
     bool prof_side_used = false;
     bool ola_fused = true;        // irFFT x3 + overlap-add + gains in one kernel (k_irfft_ola3); false: separate irFFT launches + k_ola3_gains
-    bool fused = false;           // opt-in fused per-frame kernels (fused.hip); default: one kernel per reference step
     bool stems = true;            // stem-split frame walkers (stems.hip) where the geometry allows (hop == n_fft / 4); false: the
                                   // one-kernel-per-reference-step pipeline with the spectra in HBM (A/B parity path)
     bool skip_zero = true;        // noise walker: skip transforms whose stem gain is exactly zero over everything they reach (option "skip_zero")

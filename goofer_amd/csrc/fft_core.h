@@ -1,4 +1,4 @@
-// Wave-level FFT core shared by fft.hip and fused.hip (gfx950): one 64-lane wave transforms one frame.
+// Wave-level FFT core shared by fft.hip, samples.hip and stems.hip (gfx950): one 64-lane wave transforms one frame.
 // A real n_fft-point transform is a complex M = n_fft/2 point Stockham autosort FFT: the lane holds
 // M/64 points, the first radix-(M/64) pass runs in registers, two radix-8 passes exchange through a
 // padded per-wave LDS buffer; an even/odd split recovers the n_fft/2+1 real-input bins.

@@ -351,12 +351,15 @@ int goofer_post_batch(goofer_ctx *ctx, const goofer_post *post, void *stream);
 int goofer_profile_begin(goofer_ctx *ctx, int max_steps);
 int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages);
 const char *goofer_profile_stage_name(int stage);
-const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage);   /* names of the active (fused/modular) path */
+const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage);   /* names of the path the last profiled batch took */
 
 /* Options (all exist for A/B parity runs; every setting produces the same stems):
  *   "fused_ola" 1 (default): irFFT of the three stems + overlap-add + gains in one kernel; 0: separate kernels
  *   "overlap"   1 (default): pulse chain on the handle's side stream beside the aperiodic branch; 0: one stream
- *   "fused"     0 (default); 1: rFFT+shape+irFFT / noise+2 irFFT per-frame kernels (slower: register pressure)   */
+ *   "stems"     1 (default): stem-split walker kernels where the geometry allows (hop == n_fft / 4); 0: one kernel per
+ *               reference step up to the spectra, then the fused overlap-add
+ *   "skip_zero" 1 (default): the noise walker skips a transform whose stem gain is exactly zero over every sample it
+ *               reaches; 0: every frame runs both inverse transforms                                              */
 int goofer_set_option(goofer_ctx *ctx, const char *name, int value);
 
 /* Copy a plan table (0 window, 1 freqs, 2 boost, 3 bright_harm, 4 bright_breath, 5 pulse peak) or an

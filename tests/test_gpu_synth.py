@@ -146,22 +146,6 @@ def test_batch_equals_single_notes_bitwise(ctx):
         o += lens[i]
 
 
-def test_fused_path_equals_modular_path(ctx):
-    """The fused per-frame kernels and the one-kernel-per-step path are the same arithmetic."""
-    from goofer_amd.workload import SynthWorkload
-    wl = SynthWorkload(ctx, 3, [0, 1, 2, 3, 4, 5])
-    ctx.set_option("fused", 1)
-    a = wl.step(want_rec=True)
-    torch.cuda.synchronize()
-    a = {k: a[k].cpu().numpy() for k in ("harm", "uv", "bre", "rec", "mix")}
-    ctx.set_option("fused", 0)
-    b = wl.step(want_rec=True)
-    torch.cuda.synchronize()
-    ctx.set_option("fused", 1)
-    for k in a:
-        assert rms_err(a[k], b[k].cpu().numpy()) < 1e-7, k
-
-
 @pytest.mark.parametrize("vibrato", [False, True])
 def test_synthesize_jitter_kwargs_vs_oracle(ctx, vibrato):
     """f0_jitter / volume_jitter (noise or volume_vibrato sinusoid) kwargs of gf.synthesize: same legacy RNG stream on both sides."""
