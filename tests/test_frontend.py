@@ -67,9 +67,21 @@ def test_http_server_batches_concurrent_requests(tmp_path):
         assert status[:6] == [200] * 6 and all(t == "" for t in text[:6])
         assert status[6] == 500 and text[6].startswith("An error occurred.\n") and "FileNotFoundError" in text[6]
         assert max(collector.batches) >= 2                    # concurrent requests shared a device batch
+        # the audio itself: the same six requests rendered directly (another Philox seed: the noise stems differ sample by
+        # sample, the harmonic stem — most of the energy — does not), compared through level and the low-band waveform
+        from goofer_amd.render import Source
+        direct = Renderer(ctx).render([(Source.from_pack(*core.load_features(str(tmp_path / f"s{i}_features.goofy"))),
+                                        S.decode_request(*S.split_arguments(bodies[i])[2:])) for i in range(6)], seed=12345)
         for i in range(6):
             with wave.open(str(tmp_path / f"o{i}.wav"), "rb") as w:
                 assert w.getframerate() == 44100 and w.getnframes() == int(0.1 * 44100) + int((0.2 + 0.04 * i) * 44100)
+                assert w.getsampwidth() == 2
+                raw = w.readframes(w.getnframes())
+            got = np.frombuffer(raw, dtype="<i2").astype(np.float64) / 32768.0
+            want = np.asarray(direct[i], dtype=np.float64)
+            assert got.shape == want.shape and np.isfinite(got).all() and np.abs(got).max() > 1e-3
+            r_got, r_want = np.sqrt(np.mean(got ** 2)), np.sqrt(np.mean(want ** 2))
+            assert abs(r_got - r_want) <= 0.1 * r_want, (i, r_got, r_want)
         c = http.client.HTTPConnection("127.0.0.1", port, timeout=30)
         c.request("GET", "/")
         assert c.getresponse().status == 200
