@@ -31,6 +31,15 @@ class Source:
     ylen: int
     n_fft: int = S.N_FFT
 
+    def knot_rows(self) -> np.ndarray:
+        """The knot table frame-major ([T, K] contiguous, flattened), the layout the device kernels index; made once per source
+        (a voicebank sample is rendered many times)."""
+        kr = getattr(self, "_knot_rows", None)
+        if kr is None:
+            kr = np.ascontiguousarray(self.knots.T).reshape(-1)
+            object.__setattr__(self, "_knot_rows", kr)
+        return kr
+
     @staticmethod
     def from_pack(env_pack, f0, mask, formants, sr, ylen):
         """Features as load_features returns them.  Everything the device kernels index by these sizes is checked here —
@@ -317,7 +326,7 @@ class Renderer:
             c["fry_glide_lo"].append(fx["fry_glide"][0]); c["fry_glide_hi"].append(fx["fry_glide"][1])
             c["fry_a"].append(fx["fry_mask"][0]); c["fry_b"].append(fx["fry_mask"][1]); c["fry_fade"].append(fx["fry_fade"])
             c["pd_on"].append(int(req.pitch_dyn != 0.0)); c["pd_base"].append(req.pitch_m + ((req.flags.get("t", 0) or 0) / 100.0))
-            knots_cat.append(src.knots)
+            knots_cat.append(src.knot_rows())
             mask_cat.append(src.mask[:src.ylen])
             semis = req.bend.astype(np.float64) / 100.0 + req.pitch_m      # SillySampler.py:838-846
             if tc:
@@ -344,15 +353,15 @@ class Renderer:
 
         d = dict(
             notes=ctx.tensor(P.view(np.uint8)),
-            knots=ctx.tensor(np.concatenate([np.ascontiguousarray(k.T).reshape(-1) for k in knots_cat]).view(np.uint16)),
+            knots=ctx.tensor(np.concatenate(knots_cat).view(np.uint16)),
             lerp_idx=cat_tab(lerp_tabs, 0, np.int32), lerp_w0=cat_tab(lerp_tabs, 1, np.float32), lerp_w1=cat_tab(lerp_tabs, 2, np.float32),
             tilts=ctx.tensor(np.concatenate(tilt_tabs)) if tilt_tabs else None,
             es_taps=ctx.tensor(np.concatenate(es_taps)) if es_taps else None,
             fw_lo=cat_tab(fw_tabs, 0, np.int32), fw_hi=cat_tab(fw_tabs, 1, np.int32), fw_frac=cat_tab(fw_tabs, 2, np.float64),
-            tap_idx=ctx.tensor(np.concatenate(tapi_cat).astype(np.int32)), tap_w=ctx.tensor(np.concatenate(tapw_cat)),
-            fst_tracks=ctx.tensor(np.concatenate(fst_cat).astype(np.float32)),
-            mask_src=ctx.tensor(np.concatenate(mask_cat).astype(np.float32)),
-            bend=ctx.tensor(np.concatenate(bend_cat).astype(np.float64)),
+            tap_idx=ctx.tensor(np.concatenate(tapi_cat).astype(np.int32, copy=False)), tap_w=ctx.tensor(np.concatenate(tapw_cat)),
+            fst_tracks=ctx.tensor(np.concatenate(fst_cat).astype(np.float32, copy=False)),
+            mask_src=ctx.tensor(np.concatenate(mask_cat).astype(np.float32, copy=False)),
+            bend=ctx.tensor(np.concatenate(bend_cat).astype(np.float64, copy=False)),
         )
         env = ctx.rows(t_off, B)
         f0 = torch.empty(o_off, dtype=torch.float32, device=ctx.device)
