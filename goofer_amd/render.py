@@ -249,7 +249,7 @@ class Renderer:
                                "fry_glide_hi", "fry_a", "fry_b", "fry_fade", "pd_on", "pd_base")}
         knots_cat, mask_cat, bend_cat, tapi_cat, tapw_cat, fst_cat, F_cat = [], [], [], [], [], [], []
         k_off = e_off = t_off = s_off = o_off = b_off = 0
-        hz_ids, live_rows, env_lens = {}, {}, []
+        hz_ids, live_rows, env_lens, src_at = {}, {}, [], {}
         for i, ((src, req), p) in enumerate(zip(jobs, plans)):
             K = src.knots.shape[0]
             if src.hz_knots is None:                           # dense source: rows are the envelope, no lerp plan
@@ -265,7 +265,15 @@ class Renderer:
                         lerp_tabs.append(_lerp_plan(sr, n_fft, src.hz_knots))
                     lp = hz_ids[id(src.hz_knots)] = lerp_keys[key]
             c = col
-            c["knot_off"].append(k_off); c["K"].append(K); c["lerp_plan"].append(lp); c["n_src_rows"].append(src.knots.shape[1])
+            # a voicebank sample rendered by several notes of the batch is uploaded once (same Source object)
+            placed = src_at.get(id(src))
+            if placed is None:
+                placed = src_at[id(src)] = (k_off, s_off)
+                knots_cat.append(src.knot_rows())
+                mask_cat.append(src.mask[:src.ylen])
+                k_off += src.knots.size
+                s_off += src.ylen
+            c["knot_off"].append(placed[0]); c["K"].append(K); c["lerp_plan"].append(lp); c["n_src_rows"].append(src.knots.shape[1])
             c["reverse"].append(int(req.reverse))
             tilt = -1
             if req.brightness_env != 1.0:
@@ -309,7 +317,7 @@ class Renderer:
             c["row_lo"].append(row_lo); c["n_edit"].append(row_hi - row_lo); c["edit_off"].append(e_off)
             c["tap_off"].append(t_off); c["env_off"].append(t_off); c["n_out_rows"].append(T_env); c["env_f64"].append(int(p.env_f64))
             c["fst"].append(req.formant_strength)
-            c["src_sample_off"].append(s_off); c["ylen"].append(src.ylen); c["out_sample_off"].append(o_off)
+            c["src_sample_off"].append(placed[1]); c["ylen"].append(src.ylen); c["out_sample_off"].append(o_off)
             c["n_out"].append(p.n_out); c["n_pre"].append(p.n_pre); c["s_pre"].append(p.extra["s_pre"]); c["s_tail"].append(p.extra["s_tail"])
             c["tail_len"].append(p.tail_len); c["want_samples"].append(p.want_samples); c["n_before_vel"].append(p.n_before_vel)
             c["vel_active"].append(int(p.vel_active)); c["vel_factor"].append(p.vel_factor)
@@ -326,8 +334,6 @@ class Renderer:
             c["fry_glide_lo"].append(fx["fry_glide"][0]); c["fry_glide_hi"].append(fx["fry_glide"][1])
             c["fry_a"].append(fx["fry_mask"][0]); c["fry_b"].append(fx["fry_mask"][1]); c["fry_fade"].append(fx["fry_fade"])
             c["pd_on"].append(int(req.pitch_dyn != 0.0)); c["pd_base"].append(req.pitch_m + ((req.flags.get("t", 0) or 0) / 100.0))
-            knots_cat.append(src.knot_rows())
-            mask_cat.append(src.mask[:src.ylen])
             semis = req.bend.astype(np.float64) / 100.0 + req.pitch_m      # SillySampler.py:838-846
             if tc:
                 semis = semis + (tc / 100.0)
@@ -337,10 +343,8 @@ class Renderer:
             fst_cat.append(p.fst_tracks[:T_env])
             F_cat.append(p.formants[:T_env])
             env_lens.append(T_env)
-            k_off += src.knots.size
             e_off += row_hi - row_lo
             t_off += T_env
-            s_off += src.ylen
             o_off += p.n_out
             b_off += len(req.bend)
         for name, vals in col.items():                         # one column assignment per field instead of 45 scalar stores per note

@@ -496,3 +496,23 @@ def test_trimmed_envelope_rows_change_nothing(renderer):
     renderer.ctx.check()
     assert a.shape == b.shape and np.array_equal(a, b)
     assert np.isfinite(a).all() and np.abs(a).max() > 0
+
+
+def test_notes_sharing_a_source_render_like_single_notes(renderer):
+    """Several notes cut from ONE voicebank sample (the usual case in a song): the batch uploads the sample once and every note
+    renders to the bits it has alone."""
+    from goofer_amd.render import Source
+    from goofer_amd import sampler as S
+    srcs = [syn.make_source(93000 + k, seconds=0.5) for k in range(2)]
+    sources = [Source.from_pack(s["env_pack"], s["f0"], s["mask"], s["formants"], s["sr"], s["y_len"]) for s in srcs]
+    reqs = [("C4", "100", "g10", "30", "400", "80", "40"), ("E4", "120", "L1fa20", "10", "700", "60", "-200"), ("G3", "80", "L2br30", "50", "300", "90", "20"),
+            ("A3", "100", "R1", "20", "500", "70", "30"), ("D4", "100", "fst30es-30", "0", "350", "50", "60")]
+    jobs, seeds = [], []
+    for k, r in enumerate(reqs):
+        args = r + ("100", "0", "!120", "AA#5#AF#3#/+")
+        jobs.append((sources[k % 2], S.decode_request(*args)))
+        seeds.append(9400 + k)
+    batch = renderer.render(jobs, phi_seeds=seeds)
+    for k, job in enumerate(jobs):
+        (one,) = renderer.render([job], phi_seeds=[seeds[k]])
+        assert np.array_equal(one, batch[k]), k
