@@ -12,6 +12,7 @@ a request that fails (bad flags, missing features, ...) is isolated and does not
 """
 from __future__ import annotations
 
+import collections
 import logging
 import sys
 import threading
@@ -44,9 +45,10 @@ class _Pending:
 class BatchCollector:
     """Gathers concurrent render requests and runs them as one device batch."""
 
-    def __init__(self, renderer=None, window_s: float = 0.005, max_batch: int = 4096):
+    def __init__(self, renderer=None, window_s: float = 0.005, max_batch: int = 4096, max_sources: int = 512):
         self._renderer = renderer
-        self.window_s, self.max_batch = window_s, max_batch
+        self.window_s, self.max_batch, self.max_sources = window_s, max_batch, max_sources
+        self._sources = collections.OrderedDict()          # feature cache: path -> ((mtime_ns, size), Source)
         self._lock = threading.Condition()
         self._queue = []
         self._stop = False
@@ -98,9 +100,27 @@ class BatchCollector:
                 if not isinstance(e, Exception):
                     raise
 
-    def _render(self, batch):
+    def _source(self, feat: Path):
+        """Features of one voicebank sample, kept across requests (a song asks for the same samples over and over): keyed by
+        path, dropped when the file changes (size / mtime), at most ``max_sources`` of them.  The same Source object in several
+        notes of a batch is also what lets the renderer upload it once."""
         from . import core
-        from .render import Source, write_wav
+        from .render import Source
+        st = feat.stat()
+        key, stamp = str(feat), (st.st_mtime_ns, st.st_size)
+        hit = self._sources.get(key)
+        if hit is not None and hit[0] == stamp:
+            self._sources.move_to_end(key)
+            return hit[1]
+        env, f0, mask, forms, sr, ylen = core.load_features(feat)
+        src = Source.from_pack(env, f0, mask, forms, sr, ylen)
+        self._sources[key] = (stamp, src)
+        while len(self._sources) > self.max_sources:
+            self._sources.popitem(last=False)
+        return src
+
+    def _render(self, batch):
+        from .render import write_wav
         jobs, owners = [], []
         for p in batch:                                    # per-note decode / feature load: errors stay per note
             try:
@@ -111,9 +131,9 @@ class BatchCollector:
                 feat = in_file.with_name(f"{in_file.stem}_features.goofy")
                 if not feat.exists():
                     raise FileNotFoundError(f"{feat} not found (feature extraction from raw audio needs Praat)")
-                env, f0, mask, forms, sr, ylen = core.load_features(feat)
-                jobs.append((Source.from_pack(env, f0, mask, forms, sr, ylen), req))
-                owners.append((p, out_file, sr))
+                src = self._source(feat)
+                jobs.append((src, req))
+                owners.append((p, out_file, src.sr))
             except Exception as e:      # noqa: BLE001 - reported to the client as a 500
                 p.error = e
                 p.done.set()

@@ -133,3 +133,29 @@ def test_server_binds_to_loopback_by_default_and_worker_survives_errors():
     finally:
         httpd.server_close()
         col.close()
+
+
+def test_server_keeps_loaded_features_until_the_file_changes(tmp_path):
+    """The collector's feature cache: the same voicebank sample asked for again is the same Source object (so a batch uploads
+    it once); a rewritten file is loaded again; the cache is bounded."""
+    import os
+    from goofer_amd import core
+    col = cli.BatchCollector(renderer=object(), max_sources=2)
+    try:
+        paths = []
+        for i in range(3):
+            src = syn.make_source(300 + i, seconds=0.3)
+            f = tmp_path / f"v{i}_features.goofy"
+            core.save_features(f, src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+            paths.append(f)
+        a = col._source(paths[0])
+        assert col._source(paths[0]) is a and a.ylen == int(round(0.3 * 44100))
+        src = syn.make_source(999, seconds=0.4)
+        core.save_features(paths[0], src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+        os.utime(paths[0], ns=(1, 1))                       # whatever the clock granularity: the stamp differs
+        b = col._source(paths[0])
+        assert b is not a and b.ylen == int(round(0.4 * 44100))
+        col._source(paths[1]); col._source(paths[2])
+        assert len(col._sources) == 2 and str(paths[0]) not in col._sources
+    finally:
+        col.close()
