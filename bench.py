@@ -274,6 +274,10 @@ def main():
         # every rank derives the same assignment from the frame counts of the whole job: no communication
         est = [syn.config_note_frames(args.config, i) for i in range(args.job_notes)]
         ids = assign_lpt(est, world)[rank]
+        # sub-batches of similar lengths: the pulse walk of a sub-batch takes as long as its longest note (one wave per note,
+        # sequential in time), which then hides behind that sub-batch's own envelope assembly instead of a 3 s note stalling
+        # a sub-batch of short ones
+        ids = sorted(ids, key=lambda i: (-est[i], i))
         subs = [SamplerWorkload(ctx, args.config, ids[k:k + args.sub_batch]) for k in range(0, len(ids), args.sub_batch)]
     else:
         ids = list(note_range(rank, world, args.notes))
