@@ -234,7 +234,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (1-based)")
     ap.add_argument("--job-notes", type=int, default=0, help="a FIXED job of this many notes (BASELINE configs 4 / 5): sharded over the "
                     "ranks by longest-processing-time assignment, rendered in sub-batches; reports strong scaling")
-    ap.add_argument("--sub-batch", type=int, default=1024, help="notes per device batch of a fixed job")
+    ap.add_argument("--sub-batch", type=int, default=4096, help="notes per device batch of a fixed job (4096: the pulse walk runs one wave per note, four rounds of resident waves at most; "
+                    "smaller batches fill the device worse, one 10 000-note batch makes the walk the critical path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time the optional ragged gather of finished audio to rank 0 "
