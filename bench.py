@@ -403,6 +403,9 @@ def main():
                        "sharding": "independent notes, no data-path collective"},
             "stage_ms": per,
             "roofline": roof(dom),
+            # the longest kernel by rocprof average when the noise walker is it: its event-bracketed time includes the tail of
+            # the pulse placement that runs beside its start (so this fraction is a lower bound on the kernel alone)
+            "roofline_noise": roof("noise_stems") if per.get("noise_stems", 0) > 0 else None,
             # in-pipeline launch when the active path has a standalone rFFT stage, else the entry-point timing
             "roofline_fft": roof("rfft_frames", wl.frames, wl.samples) if per.get("rfft_frames", 0) > 0
             else roof("rfft_frames_standalone", wl.frames, wl.samples),
