@@ -64,7 +64,7 @@ STAGE_KERNEL = {"rfft_frames": "void k_rfft_frames<512>", "rfft_frames_standalon
                 "noise_spectra": "void k_noise_spectra<9>", "ola3_gains": "k_ola3_gains", "irfft_ola3": "void k_irfft_ola3<512>",
                 "apply_gain": "k_apply_gain", "pulse_onsets": "k_pulse_onsets_scan", "pulse_place": "k_pulse_place",
                 "mask_short": "k_mask_short", "phase_inc": "k_phase_inc", "setup_maps": "k_scale_f0",
-                "noise_stems": "void k_noise_stems<512>", "harm_stem": "void k_harm_stem<512>", "note_finish": "k_note_finish"}
+                "noise_stems": "void k_noise_stems<512, false>", "harm_stem": "void k_harm_stem<512>", "note_finish": "k_note_finish"}
 
 
 def _pmc_file():
@@ -99,6 +99,28 @@ def pmc_step_traffic(frames):
         return {"bytes": d["_meta"]["step_hbm_bytes"], "source": os.path.basename(fn)}
     except Exception:
         return None
+
+
+def sq_valu_issue(stage, ms, frames):
+    """Vector-issue fraction of a kernel from the newest committed SQ counter pass (profiles/r*_sq_counters.txt, collected with
+    scripts/pmc_pass.sh on the 1024-note default workload): SQ_INSTS_VALU per launch / this run's kernel time, against what
+    1024 SIMDs can issue (one wave instruction per 4 cycles at 2.4 GHz).  The walkers are bound by what the vector and LDS pipes
+    issue, not by HBM: this is the fraction that says how close they are.  None when no pass matches."""
+    try:
+        if frames != 194560:
+            return None
+        import glob
+        files = sorted(glob.glob(os.path.join(HERE, "profiles", "r*_sq_counters.txt")))
+        name = STAGE_KERNEL[stage].replace("void ", "").split("<")[0]
+        for ln in open(files[-1]):
+            if ln.startswith(name + " ") and "SQ_INSTS_VALU=" in ln:
+                insts = float(ln.split("SQ_INSTS_VALU=")[1].split()[0])
+                peak = 1024 * 2.4e9 / 4.0
+                return {"insts_valu_per_launch": insts, "issue_frac": insts / (ms * 1e-3) / peak, "peak_wave_insts_per_s": peak,
+                        "source": os.path.basename(files[-1])}
+    except Exception:
+        pass
+    return None
 
 
 def pcie_leg(wl, step_s):
@@ -380,7 +402,7 @@ def main():
             traffic, src = pmc_traffic(stage, wl.frames) if not job else (None, None)
             return {"kernel": stage, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": a / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "ms_per_launch": ms,
-                    "alg_bytes_per_launch": alg}
+                    "alg_bytes_per_launch": alg, "valu": sq_valu_issue(stage, ms, wl.frames) if not job else None}
 
         step_ms = elapsed / args.steps * 1e3
         alg_step = (4 * B + 20 * hop) * frames_total / world            # SURVEY 8d ALG_BYTES_FRAME x frames of one rank's step
