@@ -115,7 +115,13 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
 // WARP: also write the row as gf.synthesize's harmonic branch wants it — formant-anchored + uniform warp (GOOFER.py:1004-1017,
 // warp_row of binops_core.h) with the synthesis batch's per-note shifts and per-row formants — while the row is at hand
 // (goofer_render_batch: one read of the edited rows instead of a second pass over the assembled envelope).
-template <bool WARP>
+// CH: 64-bin chunks of a row when known at compile time (the loop over them is unrolled: constant offsets, no per-chunk
+// address arithmetic), 0 = any width.
+//
+// Everything that depends on the row only — the four bells' centres, widths and reach, the warp's anchors — is computed
+// once per row ACROSS lanes (lane k owns formant k) and handed to the per-bin code through v_readlane, instead of once per
+// lane: the per-row set-up used to be half of this kernel's vector instructions and most of its scalar ones.
+template <bool WARP, int CH>
 __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64_t total_out_rows, const int *__restrict__ row_note,
                                                   const double *__restrict__ w_formants, const goofer_note_params *__restrict__ w_params,
                                                   float *__restrict__ w_out, double nyq_d)
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
     const int64_t orow = (int64_t)blockIdx.x * A_ROWS + wave;
     if (orow >= total_out_rows) return;
     const int note = row_note[orow];
-    const goofer_note_plan p = a.notes[note];
+    const goofer_note_plan &p = a.notes[note];
     const int64_t t = orow - p.env_off;
     const int32_t *ti = a.tap_idx + (p.tap_off + t) * 4;
     const double *tw = a.tap_w + (p.tap_off + t) * 4;
@@ -139,43 +145,52 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
         src[k] = a.edit_rows + (p.edit_off + (ti[k] - p.row_lo)) * (int64_t)a.ld;
     }
     // formant-strength bells for this frame                    SillySampler.py:817-830
-    float Fk[4];
-    double sv[4];
-    bool on[4];
+    // lane k < 4: bell k.  1/sigma and -0.5*log2(e): the bell exp(-0.5 ((f - F)/sigma)^2) through the hardware exp2 (<= 1e-6
+    // relative on the gain where the bell is not negligible) instead of an IEEE division and libm expf per bin and formant
+    const int li = lane & 3;
     const float nyq = (float)((double)a.sr * 0.5);
-    // 1/sigma and -0.5*log2(e): the bell exp(-0.5 ((f - F)/sigma)^2) through the hardware exp2 (<= 1e-6 relative on
-    // the gain where the bell is not negligible) instead of an IEEE division and libm expf per bin and formant
-    const float isig[4] = {1.0f / 100.0f, 1.0f / 200.0f, 1.0f / 350.0f, 1.0f / 500.0f};
-    float gk[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        sv[k] = p.fst[k];
-        Fk[k] = a.fst_tracks[(p.env_off + t) * 4 + k];
-        on[k] = !(fabs(sv[k]) < 1e-6) && isfinite(Fk[k]) && !(Fk[k] <= 50.0f) && !(Fk[k] >= nyq);
-        gk[k] = (float)((1.0 + sv[k]) - 1.0);                // python-float (gain - 1.0), weak-cast to fp32
-    }
+    const double sv = p.fst[li];
+    const float Fl = a.fst_tracks[(p.env_off + t) * 4 + li];
+    const bool on = !(fabs(sv) < 1e-6) && isfinite(Fl) && !(Fl <= 50.0f) && !(Fl >= nyq);
+    const float gl = (float)((1.0 + sv) - 1.0);                 // python-float (gain - 1.0), weak-cast to fp32
+    const float isl = li == 0 ? 1.0f / 100.0f : (li == 1 ? 1.0f / 200.0f : (li == 2 ? 1.0f / 350.0f : 1.0f / 500.0f));
     const double fstep = ((double)a.sr / 2.0) / (double)(B - 1);
     // Bins a bell cannot move: the factor 1.0f + gk*wt rounds to exactly 1.0f once |gk| wt < 2^-25, i.e. beyond
     // z^2 > (25 + log2|gk|) / (0.5 log2 e).  Two more bits and a bin on either side cover the hardware exp2 / log2 and the
     // rounding of fb; a 64-bin chunk wholly outside [blo, bhi] skips the bell (a wave-uniform branch), which is most of
-    // them: sigma is 100-500 Hz against 22 kHz of bins.  The product is unchanged bit for bit.
-    float blo[4], bhi[4];
-    const float inv_fstep = (float)(1.0 / fstep);
+    // them: sigma is 100-500 Hz against 22 kHz of bins.  The product is unchanged bit for bit.  The reach is kept as the
+    // range of chunks [c_lo, c_hi] it touches (rounded outwards: an extra chunk only multiplies by exactly 1.0f).
+    int c_lo = 1 << 20, c_hi = -1;
+    {
+        const float inv_fstep = (float)(1.0 / fstep);
+        const float lg = __builtin_amdgcn_logf(fabsf(gl));                    // log2
+        const float z2 = (27.0f + fmaxf(lg, 0.0f)) * 1.3862943611198906f;     // / (0.5 log2 e)
+        const float R = __builtin_amdgcn_sqrtf(z2) / isl;
+        const float blo = (Fl - R) * inv_fstep - 1.0f, bhi = (Fl + R) * inv_fstep + 1.0f;
+        if (on) {
+            c_lo = (int)floorf(fminf(fmaxf((blo - 63.0f) * (1.0f / 64.0f), 0.0f), 65536.0f));
+            c_hi = (int)ceilf(fminf(fmaxf(bhi * (1.0f / 64.0f), -1.0f), 65536.0f));
+        }
+    }
+    float Fk[4], gk[4], isig[4];
+    int clo[4], chi[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float lg = __builtin_amdgcn_logf(fabsf(gk[k]));                 // log2
-        const float z2 = (27.0f + fmaxf(lg, 0.0f)) * 1.3862943611198906f;     // / (0.5 log2 e)
-        const float R = __builtin_amdgcn_sqrtf(z2) / isig[k];
-        blo[k] = on[k] ? (Fk[k] - R) * inv_fstep - 1.0f : 3.0e38f;
-        bhi[k] = on[k] ? (Fk[k] + R) * inv_fstep + 1.0f : -3.0e38f;
+        Fk[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Fl), k));
+        gk[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), k));
+        isig[k] = k == 0 ? 1.0f / 100.0f : (k == 1 ? 1.0f / 200.0f : (k == 2 ? 1.0f / 350.0f : 1.0f / 500.0f));
+        clo[k] = __builtin_amdgcn_readlane(c_lo, k);
+        chi[k] = __builtin_amdgcn_readlane(c_hi, k);
     }
     float *out = a.env_out + orow * (int64_t)a.ld;
+    float *ra = reinterpret_cast<float *>(smem) + (size_t)(2 * wave) * B;
     // a plain copy of one source row (most rows: slices and loop repeats outside the cross-fades): 0.0 + 1.0 x is x, and
     // both roundings of the product below — fp32, or fp64 rounded to fp32 — are the fp32 product, so the row stays in fp32
     const bool copy = w[0] == 1.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 0.0;
-    for (int c0 = 0; c0 < B; c0 += WAVE) {
+    const int env_f64 = p.env_f64;
+    auto chunk = [&](int c, int c0) {
         const int b = c0 + lane;
-        if (b >= B) break;
+        if (b >= B) return;
         double v = 0.0;
         float vf = 0.f;
         if (copy) {
@@ -186,21 +201,32 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
                 if (w[k] != 0.0) v += w[k] * (double)src[k][b];
         }
         float gain = 1.0f;
-        const float fb = (float)(b >= B - 1 ? (double)a.sr / 2.0 : (double)b * fstep);    // np.linspace(0, sr/2, B) as fp32
+        const bool in0 = c >= clo[0] && c <= chi[0], in1 = c >= clo[1] && c <= chi[1], in2 = c >= clo[2] && c <= chi[2],
+                   in3 = c >= clo[3] && c <= chi[3];
+        if (in0 || in1 || in2 || in3) {
+            const float fb = (float)(b >= B - 1 ? (double)a.sr / 2.0 : (double)b * fstep);    // np.linspace(0, sr/2, B) as fp32
+            const bool in[4] = {in0, in1, in2, in3};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if ((float)(c0 + WAVE - 1) >= blo[k] && (float)c0 <= bhi[k]) {
-                const float z = (fb - Fk[k]) * isig[k];
-                const float wt = __builtin_amdgcn_exp2f((z * z) * -0.72134752044448170368f);
-                gain *= 1.0f + gk[k] * wt;
+            for (int k = 0; k < 4; ++k) {
+                if (in[k]) {
+                    const float z = (fb - Fk[k]) * isig[k];
+                    const float wt = __builtin_amdgcn_exp2f((z * z) * -0.72134752044448170368f);
+                    gain *= 1.0f + gk[k] * wt;
+                }
             }
         }
-        const float o = copy ? vf * gain : (p.env_f64 ? (float)(v * (double)gain) : ((float)v) * gain);
+        const float o = copy ? vf * gain : (env_f64 ? (float)(v * (double)gain) : ((float)v) * gain);
         out[b] = o;
-        if (WARP) reinterpret_cast<float *>(smem)[(size_t)(2 * wave) * B + b] = o;
+        if (WARP) ra[b] = o;
+    };
+    if (CH > 0) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) chunk(c, c * WAVE);
+    } else {
+        for (int c = 0, c0 = 0; c0 < B; ++c, c0 += WAVE) chunk(c, c0);
     }
     if (WARP) {
-        float *ra = reinterpret_cast<float *>(smem) + (size_t)(2 * wave) * B, *rb = ra + B;
+        float *rb = ra + B;
         wave_lds_sync();
         const goofer_note_params &q = w_params[note];
         double fs[4];
@@ -213,7 +239,15 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
         const float *cur = warp_row(ra, rb, B, nyq_d, w_formants ? w_formants + orow * 4 : nullptr, fs, warp, (double)q.formant_shift, lane,
                                     s_seg[wave]);
         float *wo = w_out + orow * (int64_t)a.ld;
-        for (int b = lane; b < B; b += WAVE) wo[b] = cur[b];
+        if (CH > 0) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int b = c * WAVE + lane;
+                if (b < B) wo[b] = cur[b];
+            }
+        } else {
+            for (int b = lane; b < B; b += WAVE) wo[b] = cur[b];
+        }
     }
 }
 
@@ -226,12 +260,27 @@ __device__ __forceinline__ double mask_src(const float *__restrict__ m, const go
     return (double)m[p.reverse ? (int)p.ylen - 1 - idx : idx];
 }
 
-// mask of the assembled note BEFORE the velocity stretch, at index q in [0, n_before_vel)
-__device__ __forceinline__ double mask_stage1(const float *__restrict__ m, const goofer_note_plan &p, int q)
+// k mod d for a wave-uniform divisor (the tail length) with rd ~ 1 / d (hardware reciprocal): for k < 2^21 the float quotient
+// estimate is within one of the true quotient, and one conditional correction finishes it — seven full-rate instructions instead of the ~30 (two of them quarter-rate multiplies) of the
+// generic 32-bit remainder.
+__device__ __forceinline__ uint32_t mod_small(uint32_t k, uint32_t d, float rd)
+{
+    if (d >= (1u << 24) || k >= (1u << 21)) return k % d;    // (47 s of loop at 44.1 kHz: never, in practice)
+    const uint32_t q = (uint32_t)((float)k * rd);            // within one of floor(k / d): the estimate is good to 2e-7 * 2^21 < 1/2
+    uint32_t qd;                                             // (the compiler lowers __umul24 to the quarter-rate v_mul_lo_u32 here)
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(qd) : "v"(q), "v"(d));
+    int32_t r = (int32_t)(k - qd);
+    if (r < 0) r += (int32_t)d;
+    else if (r >= (int32_t)d) r -= (int32_t)d;
+    return (uint32_t)r;
+}
+
+// mask of the assembled note BEFORE the velocity stretch, at index q in [0, n_before_vel); rd ~ 1 / tail_len
+__device__ __forceinline__ double mask_stage1(const float *__restrict__ m, const goofer_note_plan &p, int q, float rd)
 {
     if (q < p.n_pre) return mask_src(m, p, p.s_pre + q);
     uint32_t k = (uint32_t)(q - p.n_pre);
-    if (p.tail_len < p.want_samples) k = k % (uint32_t)p.tail_len;
+    if (p.tail_len < p.want_samples) k = mod_small(k, (uint32_t)p.tail_len, rd);
     return mask_src(m, p, p.s_tail + (int)k);
 }
 
@@ -244,10 +293,30 @@ __device__ __forceinline__ double div_by(double x, double d, double r)
     return fma(fma(-q, d, x), r, q);
 }
 
+// 2^x in fp64 for |x| < 1000: round-to-nearest split x = n + f, |f| <= 1/2, and the degree-12 Taylor polynomial of
+// e^(f ln 2) with the powers of ln 2 folded into the coefficients (truncation 1.7e-16, Horner rounding ~2e-16 relative).
+// libm's exp2 costs 80 vector instructions per sample here (half of them moves of its table constants); the curve only
+// has to agree with the reference's pow(2, x) well below the fp32 rounding of f0 (6e-8) — either is a 1e-16 approximation.
+// ln2^k / k!, k = 12 .. 1: read through the scalar cache into SGPRs once per wave (VOP3 has no 64-bit literals: as
+// immediates every coefficient costs two v_mov per use).  Not `static`: a symbol the compiler must load, not fold.
+__constant__ double EXP2_C[12] = {2.5678435993488206e-11, 4.4455382718708116e-10, 7.054911620801123e-09, 1.01780860092397e-07,
+                                         1.321548679014431e-06,  1.5252733804059841e-05, 0.0001540353039338161,  0.0013333558146428443,
+                                         0.009618129107628477,   0.05550410866482158,    0.24022650695910072,    0.6931471805599453};
+__device__ __forceinline__ double exp2_poly(double x)
+{
+    const double n = rint(x), f = x - n;
+    double q = EXP2_C[0];
+#pragma unroll
+    for (int k = 1; k < 12; ++k) q = fma(q, f, EXP2_C[k]);
+    q = fma(q, f, 1.0);
+    return ldexp(q, (int)n);
+}
+
 __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, const goofer_note_plan &p, int64_t g)
 {
     const int i = (int)(g - p.out_sample_off);
     const float *m = a.mask_src + p.src_sample_off;
+    const float rd_tail = __builtin_amdgcn_rcpf((float)p.tail_len);   // per note
 
     // voicing mask: direct, or np.interp over the pre-velocity sequence at old_pos   :176-187, 787-788
     double mk;
@@ -258,38 +327,52 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
         if (j > n1 - 1) j = n1 - 1;
         if (j < 0) j = 0;
         if (j >= n1 - 1) {
-            mk = mask_stage1(m, p, n1 - 1);
+            mk = mask_stage1(m, p, n1 - 1, rd_tail);
         } else {
-            const double y0 = mask_stage1(m, p, j), y1 = mask_stage1(m, p, j + 1);
+            const double y0 = mask_stage1(m, p, j, rd_tail), y1 = mask_stage1(m, p, j + 1, rd_tail);
             mk = pos == (double)j ? y0 : (y1 - y0) * (pos - (double)j) + y0;
         }
     } else {
-        mk = mask_stage1(m, p, i);
+        mk = mask_stage1(m, p, i, rd_tail);
     }
 
     // pitch curve: bend cents/100 + MIDI (+t), ticks of 60/(tempo*96) s, clamped linear interpolation
     const double *bend = a.bend + p.bend_off;                // MIDI semitones per tick, built on the host like the reference
     const double sr = (double)a.sr;
     double tsec = div_by((double)i, sr, 1.0 / sr);           // np.arange(n) / sr
-    const double t_last = (double)(p.n_bend - 1) * p.tick_dt;
+    const double dt = p.tick_dt, t_last = (double)(p.n_bend - 1) * dt;
     tsec = tsec < 0.0 ? 0.0 : (tsec > t_last ? t_last : tsec);
     double midi;
     if (p.n_bend == 1) {
         midi = bend[0];
     } else {
-        int j = (int)(tsec * fast_rcp(p.tick_dt));           // estimate; the two loops below settle it on the true tick grid
+        // tick index: the estimate tsec * RN(1 / dt) is within one of the answer on the true tick grid k * dt (relative
+        // error 3e-16 on a quotient below 2^31), so one conditional step either way settles it
+        const double rdt = fast_rcp(dt);                     // per note: hoisted out of the per-sample code by the compiler
+        int j = (int)(tsec * rdt);
         if (j > p.n_bend - 1) j = p.n_bend - 1;
-        while (j + 1 <= p.n_bend - 1 && (double)(j + 1) * p.tick_dt <= tsec) ++j;
-        while (j > 0 && (double)j * p.tick_dt > tsec) --j;
+        double x0 = (double)j * dt, x1 = (double)(j + 1) * dt;
+        if (j + 1 <= p.n_bend - 1 && x1 <= tsec) {
+            ++j;
+            x0 = x1;
+            x1 = (double)(j + 1) * dt;
+        } else if (j > 0 && x0 > tsec) {
+            --j;
+            x1 = x0;
+            x0 = (double)j * dt;
+        }
         if (j >= p.n_bend - 1) {
             midi = bend[p.n_bend - 1];
         } else {
             const double y0 = bend[j], y1 = bend[j + 1];
-            const double x0 = (double)j * p.tick_dt, x1 = (double)(j + 1) * p.tick_dt;
-            midi = tsec == x0 ? y0 : ((y1 - y0) * fast_rcp(x1 - x0)) * (tsec - x0) + y0;
+            // 1 / (x1 - x0): the spacing is dt up to the rounding of the two products (4e-14 relative), so one Newton step
+            // from RN(1 / dt) is the 1e-16 reciprocal fast_rcp would build from scratch
+            const double den = x1 - x0;
+            const double rden = fma(fma(-den, rdt, 1.0), rdt, rdt);
+            midi = tsec == x0 ? y0 : ((y1 - y0) * rden) * (tsec - x0) + y0;
         }
     }
-    const double hz = 440.0 * exp2(div_by(midi - 69.0, 12.0, 0.083333333333333329));   // RN(1/12)
+    const double hz = 440.0 * exp2_poly(div_by(midi - 69.0, 12.0, 0.083333333333333329));   // RN(1/12)
     a.mask_out[g] = (float)mk;
     double f0 = mk * hz;
     if (p.pd_on && a.bend_out) a.bend_out[g] = (float)(midi - p.pd_base);                    // 'pd' bend in semitones   :861-863
@@ -449,14 +532,25 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         LAUNCH_CHECK(ctx);
         const dim3 lgrid((unsigned)((a->total_out_rows + A_ROWS - 1) / A_ROWS));
         ctx->warp_done = false;
-        if (ctx->warp_out && !a->any_fry) {                   // (the fry edit rewrites rows afterwards: the warp then stays a pass of its own)
-            hipLaunchKernelGGL(k_env_loop<true>, lgrid, dim3(256), sizeof(float) * 2 * A_ROWS * B, st, *a, a->total_out_rows, row_note_out,
-                               ctx->warp_formants, ctx->warp_params, ctx->warp_out, (double)ctx->plan.sr / 2.0);
+        const bool fused_warp = ctx->warp_out && !a->any_fry;   // (the fry edit rewrites rows afterwards: the warp then stays a pass of its own)
+        const size_t lds_w = fused_warp ? sizeof(float) * 2 * A_ROWS * B : 0;
+        const double *wf = fused_warp ? ctx->warp_formants : nullptr;
+        const goofer_note_params *wp = fused_warp ? ctx->warp_params : nullptr;
+        float *wo = fused_warp ? ctx->warp_out : nullptr;
+        const double nyq_d = (double)ctx->plan.sr / 2.0;
+#define ENV_LOOP(W, C) hipLaunchKernelGGL((k_env_loop<W, C>), lgrid, dim3(256), lds_w, st, *a, a->total_out_rows, row_note_out, wf, wp, wo, nyq_d)
+        const int chunks = (B + WAVE - 1) / WAVE;
+        if (fused_warp) {
+            if (chunks == 9) ENV_LOOP(true, 9);
+            else if (chunks == 17) ENV_LOOP(true, 17);
+            else ENV_LOOP(true, 0);
             ctx->warp_done = true;
         } else {
-            hipLaunchKernelGGL(k_env_loop<false>, lgrid, dim3(256), 0, st, *a, a->total_out_rows, row_note_out, (const double *)nullptr,
-                               (const goofer_note_params *)nullptr, (float *)nullptr, 0.0);
+            if (chunks == 9) ENV_LOOP(false, 9);
+            else if (chunks == 17) ENV_LOOP(false, 17);
+            else ENV_LOOP(false, 0);
         }
+#undef ENV_LOOP
         LAUNCH_CHECK(ctx);
         if (a->any_fry) {
             size_t lds = (size_t)A_ROWS * ((B + 3) & ~3) * sizeof(float);

@@ -135,19 +135,31 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, dou
     float *cur = ra, *nxt = rb;
 
     if (warp && formants) {
-        // anchors: (0,0), valid (shifted -> orig), (nyq, nyq)      GOOFER.py:850-865
-        double dst[6], sp[6];
-        int len = 0;
-        dst[len] = 0.0; sp[len] = 0.0; ++len;
-        for (int i = 0; i < 4; ++i) {
-            double fo = formants[i];
-            double fsft = fo * fs[i];
-            if (fo > 50.0 && fo < nyq && fsft > 50.0) { dst[len] = fsft; sp[len] = fo; ++len; }
+        // anchors: (0,0), valid (shifted -> orig) in formant order, (nyq, nyq)      GOOFER.py:850-865
+        // The row's anchor set is wave-uniform data, so it is built ONCE per row across lanes instead of once per lane:
+        // lane i < 4 tests formant i, a ballot compacts the valid ones (rank = anchors in front), and the table lives in
+        // the wave's 18 doubles of LDS — x (shifted) at seg[k], y (original) at seg[6 + k].  (Per-lane register arrays
+        // indexed by the running length cost ~400 select instructions per row.)
+        const int li = lane & 3;
+        const double fo = formants[li];
+        const double fsl = li == 0 ? fs[0] : (li == 1 ? fs[1] : (li == 2 ? fs[2] : fs[3]));
+        const double fsft = fo * fsl;
+        const bool valid = lane < 4 && fo > 50.0 && fo < nyq && fsft > 50.0;
+        const unsigned vm = (unsigned)__ballot(valid) & 15u;
+        const int len = __popc(vm) + 2;
+        if (valid) {
+            const int rank = 1 + __popc(vm & ((1u << li) - 1u));
+            seg[rank] = fsft;
+            seg[6 + rank] = fo;
         }
-        dst[len] = nyq; sp[len] = nyq; ++len;
-
-        bool sorted = true;
-        for (int k = 1; k < len; ++k) sorted &= dst[k - 1] <= dst[k];
+        if (lane == 4) { seg[0] = 0.0; seg[6] = 0.0; }
+        if (lane == 5) { seg[len - 1] = nyq; seg[6 + len - 1] = nyq; }
+        wave_lds_sync();
+        const double *dst = seg, *sp = seg + 6;
+        // lane k < len holds anchor k and its successor
+        const int kk = lane < len ? lane : len - 1, kn = kk + 1 < len ? kk + 1 : kk;
+        const double xk = dst[kk], yk = sp[kk], xn = dst[kn], yn = sp[kn];
+        const bool sorted = __all(!(lane < len - 1) || xk <= xn);
         if (sorted || len <= 4) {
             // monotone anchors (or numpy's guess-free linear search for len <= 4): the answer does not depend on the
             // guess chain — index = number of anchors (after the first) that are <= x
@@ -156,13 +168,8 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, dou
                 // pos(b) = A_k + s_k b on segment k, with s_k the np.interp slope and A_k = (y_k - s_k x_k) / step.
                 // Folding the two interpolations into that form moves the fp64 intermediates by ~1e-13 bins — far
                 // below the fp32 rounding of the result — and leaves ~25 vector instructions per bin instead of ~85.
+                wave_lds_sync();                                       // every lane holds its anchors: the table may be overwritten
                 if (lane < len) {
-                    double xk = 0.0, yk = 0.0, xn = 0.0, yn = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        if (k == lane) { xk = dst[k]; yk = sp[k]; }
-                        if (k == lane + 1 && k < len) { xn = dst[k]; yn = sp[k]; }
-                    }
                     const double sl = lane < len - 1 ? (yn - yk) * fast_rcp(xn - xk) : 0.0;
                     seg[3 * lane] = (yk - sl * xk) * inv_step;         // A_k
                     seg[3 * lane + 1] = sl;                            // s_k
@@ -175,10 +182,7 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, dou
                 // conversion and a multiply per bin less)
                 int thr = n_bins;
                 if (lane >= 1 && lane < len) {
-                    double dk = 0.0;
-#pragma unroll
-                    for (int k = 1; k < 6; ++k)
-                        if (k == lane) dk = dst[k];
+                    const double dk = xk;
                     auto xb = [&](int c) { return c >= n_bins - 1 ? nyq : (double)c * step; };
                     const double est = ceil(dk * inv_step);
                     int c = est < 0.0 ? 0 : (est > (double)(n_bins - 1) ? n_bins - 1 : (int)est);
@@ -186,8 +190,9 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, dou
                     while (c < n_bins && !(dk <= xb(c))) ++c;
                     thr = c;
                 }
-                const int t1 = __shfl(thr, 1, WAVE), t2 = len > 2 ? __shfl(thr, 2, WAVE) : n_bins, t3 = len > 3 ? __shfl(thr, 3, WAVE) : n_bins,
-                          t4 = len > 4 ? __shfl(thr, 4, WAVE) : n_bins, t5 = len > 5 ? __shfl(thr, 5, WAVE) : n_bins;
+                // lanes >= len keep n_bins, so absent anchors never count
+                const int t1 = __builtin_amdgcn_readlane(thr, 1), t2 = __builtin_amdgcn_readlane(thr, 2), t3 = __builtin_amdgcn_readlane(thr, 3),
+                          t4 = __builtin_amdgcn_readlane(thr, 4), t5 = __builtin_amdgcn_readlane(thr, 5);
                 const double top = (double)(n_bins - 1);
                 for (int b = lane; b < n_bins; b += WAVE) {
                     const int j = (b >= t1) + (b >= t2) + (b >= t3) + (b >= t4) + (b >= t5);
@@ -211,21 +216,8 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, dou
         // Resolve np.interp's guess chain over the ascending bin frequencies.  The clamped guess
         // takes at most 3 values (1..len-3), so each bin is a map state->state; lanes own
         // contiguous chunks, compose their maps, scan across the wave, then replay.
-        // The anchors are parked in LDS first: the searches index them with run-time values, which on
-        // register arrays turns into long select chains (crossing formants are common: F1*1.3 vs F2*0.8).
-        if (lane < len) {
-            double xk = 0.0, yk = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-                if (k == lane) { xk = dst[k]; yk = sp[k]; }
-            double xn = 0.0, yn = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-                if (k == lane + 1 && k < len) { xn = dst[k]; yn = sp[k]; }
-            seg[lane] = xk;
-            seg[6 + lane] = yk;
-            seg[12 + lane] = lane < len - 1 ? (yn - yk) * fast_rcp(xn - xk) : 0.0;   // np.interp's slope of segment `lane`
-        }
+        // The anchors already sit in LDS (x at seg[k], y at seg[6 + k]); the slopes of np.interp's segments join them.
+        if (lane < len) seg[12 + lane] = lane < len - 1 ? (yn - yk) * fast_rcp(xn - xk) : 0.0;
         wave_lds_sync();
         const double *xp = seg, *fp = seg + 6;                // run-time indexed copies (np_interp_eval)
         const int per = (n_bins + WAVE - 1) / WAVE;

@@ -86,6 +86,7 @@ __device__ __forceinline__ float2 blur5f(const float2 *r, int k, int n_bins, con
 struct frame_block {
     int note, t, T, n, src, base_lo, base_hi;
     float f0, mk;
+    uint32_t ny_u;             // noise walker, Philox mode: the random word of the frame's Nyquist bin (see load_nyquist)
     int64_t blk0;
 
     __device__ __forceinline__ void load(int64_t first, int64_t total_frames, const int *__restrict__ frame_note,
@@ -106,6 +107,14 @@ struct frame_block {
         const float2 pv = picks[f];                           // x[::hop] edge-padded to the frame count (GOOFER.py:1104-1106)
         f0 = pv.x;
         mk = pv.y;
+    }
+    // Bin M (Nyquist) is the one bin past the 8 x 64 a wave holds, and only lane 0 owns it: drawing its phase inside the frame
+    // loop costs a whole Philox block per frame for one lane's word.  Here the 64 frames of the block draw theirs at once, one
+    // frame per lane — the same block (key of the frame's note, counter (frame, slot 128), word 0) philox_u32(.., bin M) names.
+    __device__ __forceinline__ void load_nyquist(const goofer_note_params *__restrict__ params, uint64_t seed, int m_bin)
+    {
+        const uint64_t key = seed ^ ((uint64_t)params[note].seed[0] | ((uint64_t)params[note].seed[1] << 32));
+        ny_u = philox_u32(key, (uint64_t)t, (uint32_t)m_bin);
     }
     __device__ __forceinline__ bool holds(int64_t f) const { return f >= blk0 && f < blk0 + WAVE; }
 };
@@ -284,6 +293,10 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
     if (!w.range(total_frames, run, frame_note, frame_off, fs, f0, f1)) return;   // no block barrier below
     frame_block fb;
     fb.load(fs, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
+    if constexpr (!PHI) fb.load_nyquist(params, seed, M);
+    // bins 64 .. M sit a whole 64-bin stride above the lowest bins: when f0 + 100 Hz is still below bin 64 their high-pass
+    // factor is exactly 1.0f (1 + exp(-z) rounds to 1 for z > 18, i.e. 90 Hz above f0; rcp(1) = 1) and is not evaluated
+    const float fq64 = w.tab[WAVE];
 
     // the next frame's envelope row is in flight while the current one is transformed: bins 8 lane .. 8 lane + 7 as two
     // 16-byte loads, the Nyquist bin beside them
@@ -390,8 +403,13 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
         }
         const float f0f = FB_GETF(fb, f0, idx);
         const bool voiced = apply_bright && FB_GETF(fb, mk, idx) > 0.f;
-        if (f >= f0) knots_fetch(t);                          // lands during the two transforms below
+        // hop t's flatness was settled three frames ago (bit 1 until this frame's check shifts the masks): a flat hop's mask
+        // gain is one constant and needs no knots
+        const bool flat_t = (((one_bits | zero_bits) >> 1) & 1u) != 0;
+        if (f >= f0 && !flat_t) knots_fetch(t);               // lands during the two transforms below
         hop_check_issue(t + 3);
+        const uint32_t ny_u = PHI ? 0u : (uint32_t)FB_GET(fb, ny_u, idx);
+        const bool hp_low_only = fq64 - f0f > 100.0f;
 
         // 1. noise envelope: sigma-1.75 blur of the un-warped row (GOOFER.py:993), fp32 FMAs in tap order.  A lane blurs its
         //    eight consecutive bins from a 24-value window (its own eight, eight on either side from LDS), lane 63 also the
@@ -441,7 +459,10 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
             wave_lds_sync();                                  // row dead: buf is free
         }
         if (f + 1 < f1) {                                     // the row registers are consumed: start the next frame's row
-            if (!fb.holds(f + 1)) fb.load(f + 1, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
+            if (!fb.holds(f + 1)) {
+                fb.load(f + 1, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
+                if constexpr (!PHI) fb.load_nyquist(params, seed, M);
+            }
             fetch(FB_GET(fb, src, (int)(f + 1 - fb.blk0)));
         }
 
@@ -459,15 +480,16 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
                 c = cosf(ph);
                 s = sinf(ph);
             } else {
-                // one Philox block feeds four bins of this lane (bins lane + 64 i, i = 4q..4q+3)
-                if ((i & 3) == 0) rnd = philox_4x32(key, (uint64_t)t, (uint32_t)(lane + WAVE * (i >> 2)));
-                const uint32_t u = (i & 3) == 0 ? rnd.x : ((i & 3) == 1 ? rnd.y : ((i & 3) == 2 ? rnd.z : rnd.w));
+                // one Philox block feeds four bins of this lane (bins lane + 64 i, i = 4q..4q+3); the Nyquist bin's word was
+                // drawn with the frame records
+                if ((i & 3) == 0 && i < R) rnd = philox_4x32(key, (uint64_t)t, (uint32_t)(lane + WAVE * (i >> 2)));
+                const uint32_t u = i == R ? ny_u : ((i & 3) == 0 ? rnd.x : ((i & 3) == 1 ? rnd.y : ((i & 3) == 2 ? rnd.z : rnd.w)));
                 const float rev = (float)(u >> 8) * (1.0f / 16777216.0f);      // phase / 2 pi, uniform in [0, 1)
                 c = __builtin_amdgcn_cosf(rev);
                 s = __builtin_amdgcn_sinf(rev);
             }
             su[i] = make_float2(c * en[i], s * en[i]);
-            const float h = hp_mask(t_fq[k], f0f);
+            const float h = (i == 0 || !hp_low_only) ? hp_mask(t_fq[k], f0f) : 1.0f;
             sb[i] = make_float2(su[i].x * h, su[i].y * h);
             if (voiced) {
                 const float b = t_br[k];
@@ -500,12 +522,20 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
             // 4. hop t -> window-sum quotient -> mask upsample -> stem gains -> out (GOOFER.py:385-389, 1179-1183); behind a note's
             //    last frame also the hop still open in the registers and the zero tail
             for (int h = t;;) {
+                // a hop known flat (see hop_check_done; bit h - t of the masks) has ONE mask gain: 1 where the smoothed mask is
+                // flat at the tap sum, 0 where it is flat at zero — smooth_mask_at32 would return exactly that for every sample
+                const int sh = h - t;
+                const bool flat1 = sh < 4 && ((one_bits >> sh) & 1u), flat0 = sh < 4 && ((zero_bits >> sh) & 1u);
+                const bool flat = flat1 || flat0;
+                const float ms_flat = flat1 ? 1.0f : 0.0f;
+                if (!flat) {
 #pragma unroll
-                for (int c = 0; c < KPL; ++c) {
-                    const int e = lane + WAVE * c;
-                    if (e < KN) w.kbuf[e] = kn_r[c];
+                    for (int c = 0; c < KPL; ++c) {
+                        const int e = lane + WAVE * c;
+                        if (e < KN) w.kbuf[e] = kn_r[c];
+                    }
+                    wave_lds_sync();
                 }
-                wave_lds_sync();
                 const int p0 = h * HOP - M;
                 const int e_hi = KN - 1, lo = kn_lo;
                 auto knot = [&](int k) {
@@ -533,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
                             xu[c] = 0.f;                             // zero tail of istft (GOOFER.py:409-412)
                             xb[c] = 0.f;
                         }
-                        const float ms = smooth_mask_at32(knot, ns, i < w.n ? i : w.n - 1, w.n, step_n, step_s, kps);
+                        const float ms = flat ? ms_flat : smooth_mask_at32(knot, ns, i < w.n ? i : w.n - 1, w.n, step_n, step_s, kps);
                         xb[c] = (xb[c] * ms) * g_b;
                         xu[c] = (xu[c] * (1.0f - ms)) * g_u;
                     }
@@ -550,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
                 // flush: hop T is the sums still in the registers; beyond it only zeros are written (i >= out_len)
 #pragma unroll
                 for (int g = 0; g < G; ++g) { ou[g] = carry_u[g]; ob[g] = carry_b[g]; }
-                knots_fetch(h);
+                if (!(h - t < 4 && (((one_bits | zero_bits) >> (h - t)) & 1u))) knots_fetch(h);
             }
         }
         wave_lds_sync();
@@ -683,13 +713,14 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
         if (f < fs) continue;
 
         // 3. shaping (GOOFER.py:1102-1144); 1 / max(|S| + 1e-8) commutes with the linear chain and is applied by k_note_finish
+        const bool hp_low_only = t_fq[WAVE] - f0f > 100.0f;
         float mx = 0.f;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int k = lane + WAVE * i;
             if (k >= B) { X[i] = make_float2(0.f, 0.f); continue; }
             float2 s = X[i];
-            if (cut_below) {
+            if (cut_below && (i == 0 || !hp_low_only)) {          // bins 64 and up: the factor is exactly 1.0f (see k_noise_stems)
                 const float h = hp_mask(t_fq[k], f0f);
                 s.x *= h; s.y *= h;
             }
