@@ -121,10 +121,16 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
 // Everything that depends on the row only — the four bells' centres, widths and reach, the warp's anchors — is computed
 // once per row ACROSS lanes (lane k owns formant k) and handed to the per-bin code through v_readlane, instead of once per
 // lane: the per-row set-up used to be half of this kernel's vector instructions and most of its scalar ones.
+struct env_loop_grid {
+    double fstep;            // np.linspace(0, sr/2, B) spacing of the bell frequencies
+    float inv_fstep, nyq_f;
+    warp_grid warp;
+};
+
 template <bool WARP, int CH>
 __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64_t total_out_rows, const int *__restrict__ row_note,
                                                   const double *__restrict__ w_formants, const goofer_note_params *__restrict__ w_params,
-                                                  float *__restrict__ w_out, double nyq_d)
+                                                  float *__restrict__ w_out, const env_loop_grid eg)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ double s_seg[A_ROWS][WARP_SEG_DOUBLES];
@@ -137,56 +143,54 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
     const int64_t t = orow - p.env_off;
     const int32_t *ti = a.tap_idx + (p.tap_off + t) * 4;
     const double *tw = a.tap_w + (p.tap_off + t) * 4;
-    const float *src[4];
     double w[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        w[k] = tw[k];
-        src[k] = a.edit_rows + (p.edit_off + (ti[k] - p.row_lo)) * (int64_t)a.ld;
-    }
+    for (int k = 0; k < 4; ++k) w[k] = tw[k];
+    // row r of the edited-row scratch (row counts and strides are 32-bit: one 32 x 32 -> 64 multiply per pointer)
+    const int64_t e0 = p.edit_off - p.row_lo;
+    auto src_row = [&](int k) { return a.edit_rows + (uint64_t)(uint32_t)(e0 + ti[k]) * (uint32_t)a.ld; };
     // formant-strength bells for this frame                    SillySampler.py:817-830
     // lane k < 4: bell k.  1/sigma and -0.5*log2(e): the bell exp(-0.5 ((f - F)/sigma)^2) through the hardware exp2 (<= 1e-6
     // relative on the gain where the bell is not negligible) instead of an IEEE division and libm expf per bin and formant
     const int li = lane & 3;
-    const float nyq = (float)((double)a.sr * 0.5);
     const double sv = p.fst[li];
     const float Fl = a.fst_tracks[(p.env_off + t) * 4 + li];
-    const bool on = !(fabs(sv) < 1e-6) && isfinite(Fl) && !(Fl <= 50.0f) && !(Fl >= nyq);
+    const bool on = !(fabs(sv) < 1e-6) && isfinite(Fl) && !(Fl <= 50.0f) && !(Fl >= eg.nyq_f);
     const float gl = (float)((1.0 + sv) - 1.0);                 // python-float (gain - 1.0), weak-cast to fp32
-    const float isl = li == 0 ? 1.0f / 100.0f : (li == 1 ? 1.0f / 200.0f : (li == 2 ? 1.0f / 350.0f : 1.0f / 500.0f));
-    const double fstep = ((double)a.sr / 2.0) / (double)(B - 1);
+    const float sgl = li == 0 ? 100.0f : (li == 1 ? 200.0f : (li == 2 ? 350.0f : 500.0f));
     // Bins a bell cannot move: the factor 1.0f + gk*wt rounds to exactly 1.0f once |gk| wt < 2^-25, i.e. beyond
     // z^2 > (25 + log2|gk|) / (0.5 log2 e).  Two more bits and a bin on either side cover the hardware exp2 / log2 and the
-    // rounding of fb; a 64-bin chunk wholly outside [blo, bhi] skips the bell (a wave-uniform branch), which is most of
-    // them: sigma is 100-500 Hz against 22 kHz of bins.  The product is unchanged bit for bit.  The reach is kept as the
-    // range of chunks [c_lo, c_hi] it touches (rounded outwards: an extra chunk only multiplies by exactly 1.0f).
-    int c_lo = 1 << 20, c_hi = -1;
-    {
-        const float inv_fstep = (float)(1.0 / fstep);
+    // rounding of fb; a 64-bin chunk wholly outside the reach skips the bell (a wave-uniform branch), which is most of
+    // them: sigma is 100-500 Hz against 22 kHz of bins.  The product is unchanged bit for bit.  The reach is kept as a bit
+    // per chunk it touches (rounded outwards: an extra chunk only multiplies by exactly 1.0f).
+    unsigned cm = 0;
+    if (on) {
         const float lg = __builtin_amdgcn_logf(fabsf(gl));                    // log2
         const float z2 = (27.0f + fmaxf(lg, 0.0f)) * 1.3862943611198906f;     // / (0.5 log2 e)
-        const float R = __builtin_amdgcn_sqrtf(z2) / isl;
-        const float blo = (Fl - R) * inv_fstep - 1.0f, bhi = (Fl + R) * inv_fstep + 1.0f;
-        if (on) {
-            c_lo = (int)floorf(fminf(fmaxf((blo - 63.0f) * (1.0f / 64.0f), 0.0f), 65536.0f));
-            c_hi = (int)ceilf(fminf(fmaxf(bhi * (1.0f / 64.0f), -1.0f), 65536.0f));
-        }
+        const float R = __builtin_amdgcn_sqrtf(z2) * sgl * 1.0001f;           // (x sigma for / (1/sigma): rounded outwards)
+        const float blo = (Fl - R) * eg.inv_fstep - 1.0f, bhi = (Fl + R) * eg.inv_fstep + 1.0f;
+        const int c_lo = (int)floorf(fminf(fmaxf((blo - 63.0f) * (1.0f / 64.0f), 0.0f), 31.0f));
+        const int c_hi = (int)ceilf(fminf(fmaxf(bhi * (1.0f / 64.0f), -1.0f), 31.0f));
+        if (c_hi >= c_lo) cm = (0xffffffffu >> (31 - c_hi)) & (0xffffffffu << c_lo);
     }
-    float Fk[4], gk[4], isig[4];
-    int clo[4], chi[4];
+    float Fk[4], gk[4];
+    const float isig[4] = {1.0f / 100.0f, 1.0f / 200.0f, 1.0f / 350.0f, 1.0f / 500.0f};
+    unsigned cmk[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         Fk[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Fl), k));
         gk[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), k));
-        isig[k] = k == 0 ? 1.0f / 100.0f : (k == 1 ? 1.0f / 200.0f : (k == 2 ? 1.0f / 350.0f : 1.0f / 500.0f));
-        clo[k] = __builtin_amdgcn_readlane(c_lo, k);
-        chi[k] = __builtin_amdgcn_readlane(c_hi, k);
+        cmk[k] = (unsigned)__builtin_amdgcn_readlane((int)cm, k);
     }
+    const unsigned cm_any = cmk[0] | cmk[1] | cmk[2] | cmk[3];
     float *out = a.env_out + orow * (int64_t)a.ld;
     float *ra = reinterpret_cast<float *>(smem) + (size_t)(2 * wave) * B;
     // a plain copy of one source row (most rows: slices and loop repeats outside the cross-fades): 0.0 + 1.0 x is x, and
     // both roundings of the product below — fp32, or fp64 rounded to fp32 — are the fp32 product, so the row stays in fp32
     const bool copy = w[0] == 1.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 0.0;
+    const float *src0 = src_row(0);
+    const float *src1 = nullptr, *src2 = nullptr, *src3 = nullptr;
+    if (!copy) { src1 = src_row(1); src2 = src_row(2); src3 = src_row(3); }
     const int env_f64 = p.env_f64;
     auto chunk = [&](int c, int c0) {
         const int b = c0 + lane;
@@ -194,21 +198,19 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
         double v = 0.0;
         float vf = 0.f;
         if (copy) {
-            vf = src[0][b];
+            vf = src0[b];
         } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (w[k] != 0.0) v += w[k] * (double)src[k][b];
+            if (w[0] != 0.0) v += w[0] * (double)src0[b];
+            if (w[1] != 0.0) v += w[1] * (double)src1[b];
+            if (w[2] != 0.0) v += w[2] * (double)src2[b];
+            if (w[3] != 0.0) v += w[3] * (double)src3[b];
         }
         float gain = 1.0f;
-        const bool in0 = c >= clo[0] && c <= chi[0], in1 = c >= clo[1] && c <= chi[1], in2 = c >= clo[2] && c <= chi[2],
-                   in3 = c >= clo[3] && c <= chi[3];
-        if (in0 || in1 || in2 || in3) {
-            const float fb = (float)(b >= B - 1 ? (double)a.sr / 2.0 : (double)b * fstep);    // np.linspace(0, sr/2, B) as fp32
-            const bool in[4] = {in0, in1, in2, in3};
+        if ((cm_any >> c) & 1u) {
+            const float fb = (float)(b >= B - 1 ? (double)a.sr / 2.0 : (double)b * eg.fstep);    // np.linspace(0, sr/2, B) as fp32
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (in[k]) {
+                if ((cmk[k] >> c) & 1u) {
                     const float z = (fb - Fk[k]) * isig[k];
                     const float wt = __builtin_amdgcn_exp2f((z * z) * -0.72134752044448170368f);
                     gain *= 1.0f + gk[k] * wt;
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
 #pragma unroll
         for (int c = 0; c < CH; ++c) chunk(c, c * WAVE);
     } else {
-        for (int c = 0, c0 = 0; c0 < B; ++c, c0 += WAVE) chunk(c, c0);
+        for (int c = 0, c0 = 0; c0 < B; ++c, c0 += WAVE) chunk(c < 31 ? c : 31, c0);
     }
     if (WARP) {
         float *rb = ra + B;
@@ -236,8 +238,8 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
             fs[k] = q.f_shift[k];
             warp |= fs[k] != 1.0;
         }
-        const float *cur = warp_row(ra, rb, B, nyq_d, w_formants ? w_formants + orow * 4 : nullptr, fs, warp, (double)q.formant_shift, lane,
-                                    s_seg[wave]);
+        const float *cur = warp_row<CH>(ra, rb, B, eg.warp, w_formants ? w_formants + orow * 4 : nullptr, fs, warp, (double)q.formant_shift,
+                                        lane, s_seg[wave]);
         float *wo = w_out + orow * (int64_t)a.ld;
         if (CH > 0) {
 #pragma unroll
@@ -537,8 +539,12 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         const double *wf = fused_warp ? ctx->warp_formants : nullptr;
         const goofer_note_params *wp = fused_warp ? ctx->warp_params : nullptr;
         float *wo = fused_warp ? ctx->warp_out : nullptr;
-        const double nyq_d = (double)ctx->plan.sr / 2.0;
-#define ENV_LOOP(W, C) hipLaunchKernelGGL((k_env_loop<W, C>), lgrid, dim3(256), lds_w, st, *a, a->total_out_rows, row_note_out, wf, wp, wo, nyq_d)
+        env_loop_grid eg;
+        eg.fstep = ((double)a->sr / 2.0) / (double)(B - 1);
+        eg.inv_fstep = (float)(1.0 / eg.fstep);
+        eg.nyq_f = (float)((double)a->sr * 0.5);
+        eg.warp = make_warp_grid(ctx->plan.sr, B);
+#define ENV_LOOP(W, C) hipLaunchKernelGGL((k_env_loop<W, C>), lgrid, dim3(256), lds_w, st, *a, a->total_out_rows, row_note_out, wf, wp, wo, eg)
         const int chunks = (B + WAVE - 1) / WAVE;
         if (fused_warp) {
             if (chunks == 9) ENV_LOOP(true, 9);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_warp_bins(const float *__restrict__ in,
                                                    const double *__restrict__ f_shift_global,
                                                    const goofer_note_params *__restrict__ params,
                                                    const int *__restrict__ row_note, const int64_t *__restrict__ row_src,
-                                                   double ratio_global, double nyq)
+                                                   double ratio_global, const warp_grid grid)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ double s_seg[ROWS_PER_BLOCK][WARP_SEG_DOUBLES];
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_warp_bins(const float *__restrict__ in,
         for (int i = 0; i < 4; ++i) fs[i] = f_shift_global[i];
         warp = true;   // the caller decides (gf.synthesize tests any(shift != 1))
     }
-    float *cur = warp_row(ra, rb, n_bins, nyq, formants ? formants + src * 4 : nullptr, fs, warp, ratio, lane, s_seg[wave]);
+    float *cur = warp_row(ra, rb, n_bins, grid, formants ? formants + src * 4 : nullptr, fs, warp, ratio, lane, s_seg[wave]);
     for (int b = lane; b < n_bins; b += WAVE) out[row * ld + b] = cur[b];
 }
 
@@ -103,7 +103,7 @@ int launch_warp_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows,
     if (rows <= 0) return GOOFER_OK;
     size_t lds = sizeof(float) * 2 * ROWS_PER_BLOCK * n_bins;
     hipLaunchKernelGGL(k_warp_bins, dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), lds, st, in, out,
-                       rows, n_bins, ld, formants, d_f_shift, params, row_note, row_src, ratio, (double)ctx->plan.sr / 2.0);
+                       rows, n_bins, ld, formants, d_f_shift, params, row_note, row_src, ratio, make_warp_grid(ctx->plan.sr, n_bins));
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
                                                     const float *__restrict__ freqs, const float *__restrict__ boost,
                                                     const float *__restrict__ bright, const double *__restrict__ taps5,
                                                     int n_bins, int hop, const int64_t *__restrict__ row_src,
-                                                    const double *__restrict__ formants, double nyq,
+                                                    const double *__restrict__ formants, const warp_grid grid,
                                                     const float2 *__restrict__ picks)
 {
     // env is either the already-warped [frames x ld] matrix (row_src == nullptr) or the source rows, in which
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
                 if (k < n_bins) ra[k] = ev[i];
             }
             wave_lds_sync();
-            eg = warp_row(ra, rb, n_bins, nyq, formants ? formants + src * 4 : nullptr, fs, warp, (double)p.formant_shift, lane,
+            eg = warp_row(ra, rb, n_bins, grid, formants ? formants + src * 4 : nullptr, fs, warp, (double)p.formant_shift, lane,
                           s_seg[wave]);
         }
     }
@@ -267,7 +267,7 @@ int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames,
 #define HARM_SHAPE(IT)                                                                                                             \
     hipLaunchKernelGGL(k_harm_shape<IT>, grid, dim3(256), lds, st, S, ldc, total_frames, frame_note, frame_off, sample_off, f0,   \
                        mask, env, ld, params, note_mag, pl.freqs, pl.boost, pl.bright_h, pl.blur5, pl.n_bins, pl.hop, row_src,    \
-                       formants, (double)pl.sr / 2.0, ctx->frame_picks)
+                       formants, make_warp_grid(pl.sr, pl.n_bins), ctx->frame_picks)
     switch ((pl.n_bins + WAVE - 1) / WAVE) {
     case 5: HARM_SHAPE(5); break;
     case 9: HARM_SHAPE(9); break;

@@ -127,11 +127,27 @@ __device__ __forceinline__ double row_interp(const float *r, int n_bins, double 
 // GOOFER.py:840-875, 618-627; each stage rounds to fp32 like the reference.
 constexpr int WARP_SEG_DOUBLES = 18;
 
-__device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, double nyq, const double *formants, const double *fs,
+// The bin grid of a plan, made once on the host (three fp64 divisions per row otherwise): np.linspace(0, nyq, n_bins)'s
+// spacing and its reciprocal.
+struct warp_grid {
+    double nyq, step, inv_step;
+};
+static inline warp_grid make_warp_grid(int sr, int n_bins)
+{
+    warp_grid g;
+    g.nyq = (double)sr / 2.0;
+    g.step = g.nyq / (double)(n_bins - 1);
+    g.inv_step = 1.0 / g.step;
+    return g;
+}
+
+// CH: 64-bin chunks of a row when known at compile time (the per-bin loop of the common sorted-anchor case is then
+// unrolled, so its LDS round trips overlap), 0 = any width.
+template <int CH = 0>
+__device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, const warp_grid &grid, const double *formants, const double *fs,
                                            bool warp, double ratio, int lane, double *seg)
 {
-    const double step = nyq / (double)(n_bins - 1);
-    const double inv_step = fast_rcp(step);
+    const double nyq = grid.nyq, step = grid.step, inv_step = grid.inv_step;
     float *cur = ra, *nxt = rb;
 
     if (warp && formants) {
@@ -184,25 +200,36 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, dou
                 if (lane >= 1 && lane < len) {
                     const double dk = xk;
                     auto xb = [&](int c) { return c >= n_bins - 1 ? nyq : (double)c * step; };
+                    // ceil(dk / step) through the reciprocal is within one of the first bin with dk <= x(bin) (both are a
+                    // few 1e-16 relative away from the real quotient), so one conditional step either way settles it
                     const double est = ceil(dk * inv_step);
                     int c = est < 0.0 ? 0 : (est > (double)(n_bins - 1) ? n_bins - 1 : (int)est);
-                    while (c > 0 && dk <= xb(c - 1)) --c;
-                    while (c < n_bins && !(dk <= xb(c))) ++c;
+                    if (c > 0 && dk <= xb(c - 1)) --c;
+                    else if (c < n_bins && !(dk <= xb(c))) ++c;
                     thr = c;
                 }
                 // lanes >= len keep n_bins, so absent anchors never count
                 const int t1 = __builtin_amdgcn_readlane(thr, 1), t2 = __builtin_amdgcn_readlane(thr, 2), t3 = __builtin_amdgcn_readlane(thr, 3),
                           t4 = __builtin_amdgcn_readlane(thr, 4), t5 = __builtin_amdgcn_readlane(thr, 5);
                 const double top = (double)(n_bins - 1);
-                for (int b = lane; b < n_bins; b += WAVE) {
+                auto bin = [&](int b) {
                     const int j = (b >= t1) + (b >= t2) + (b >= t3) + (b >= t4) + (b >= t5);
                     double pos = fma(seg[3 * j + 1], (double)b, seg[3 * j]);
-                    pos = pos < 0.0 ? 0.0 : (pos > top ? top : pos);
+                    pos = __builtin_fmax(0.0, __builtin_fmin(pos, top));          // (finite: the anchors are)
                     int j2 = (int)pos;
                     if (j2 > n_bins - 2) j2 = n_bins - 2;
                     const double d = pos - (double)j2;
                     const double r0 = (double)cur[j2];
                     nxt[b] = (float)(((double)cur[j2 + 1] - r0) * d + r0);
+                };
+                if (CH > 0) {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int b = lane + WAVE * c;
+                        if (c < CH - 1 || b < n_bins) bin(b);
+                    }
+                } else {
+                    for (int b = lane; b < n_bins; b += WAVE) bin(b);
                 }
             } else {
                 for (int b = lane; b < n_bins; b += WAVE) {

@@ -32,6 +32,20 @@ struct stem_taps {
     float t175[15];            // sigma = 1.75 taps of the noise-envelope blur (GOOFER.py:993), fp32
 };
 
+// Read a kernel argument from the kernarg segment at the point of use.  The walkers keep ~40 scalars of wave state across
+// their frame loop; arguments that are only needed every 64 frames (the frame-record arrays) or once per note kept live
+// beside them pushed the compiler past the 102 SGPRs of a wave, and every overflow costs a v_writelane / v_readlane pair in
+// the loop (the noise walker carried 105 such spills).  The empty asm hides the segment pointer from the optimiser, so the
+// load cannot be hoisted back to the kernel entry; it is a scalar load from the constant cache.
+template <typename T>
+__device__ __forceinline__ T cold_arg(size_t offset)
+{
+    const char __attribute__((address_space(4))) *ka = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return *reinterpret_cast<const T __attribute__((address_space(4))) *>(ka + offset);
+}
+#define COLD(type, field) cold_arg<decltype(type::field)>(offsetof(type, field))
+
 template <int M> struct stem_cfg {
     static constexpr int R = M / 64;           // sample pairs (and FFT points) per lane
     static constexpr int G = R / 4;            // 64-pair groups per hop
@@ -128,7 +142,6 @@ template <int M, int NTAB, bool WIN> struct walker {
     static constexpr int R = C::R, G = C::G, NF = C::NF, HOP = C::HOP, B = C::B;
     float2 *tw, *wct, *wsc, *buf;
     float *win, *tab;
-    const float *g_win;
     double *kbuf;
     int lane;
     float ws_c[G][2], rws_c[G][2];             // summed squared window of this lane's hop samples (interior hops) and 1 / it
@@ -136,10 +149,9 @@ template <int M, int NTAB, bool WIN> struct walker {
     int note = -1, n = 0, T = 0, out_len = 0;
     int64_t base = 0;
 
-    __device__ __forceinline__ void init(unsigned char *smem, const float2 *g_tw, const float2 *g_twh, const float *g_window,
+    __device__ __forceinline__ void init(unsigned char *smem, const float2 *g_tw, const float2 *g_twh, const float *g_win,
                                          const float *t0, const float *t1, const float *t2)
     {
-        g_win = g_window;
         tw = reinterpret_cast<float2 *>(smem);
         wct = tw + M;
         wsc = wct + M;
@@ -251,7 +263,7 @@ template <int M, int NTAB, bool WIN> struct walker {
     // Overlap-add divisor of this lane's sample (g, c) of hop h (GOOFER.py:385-389): the summed squared window over the
     // frames that exist.  Interior hops (wave-uniform test) have the per-lane constant and its reciprocal at hand.
     __device__ __forceinline__ bool interior(int h) const { return h >= (NF - 1) / HOP && h <= T - 1; }
-    __device__ __forceinline__ float partial_ws(int h, int g, int c) const
+    __device__ __forceinline__ float partial_ws(int h, int g, int c, const float *g_win) const
     {
         const int j = 2 * (lane + WAVE * g) + c;
         const int back = (NF - 1 - j) / HOP;
@@ -268,35 +280,63 @@ template <int M, int NTAB, bool WIN> struct walker {
 // ---------------------------------------------------------------------------------------------
 // PHI: injected phases (parity runs; accurate libm sin / cos) instead of Philox + hardware sin / cos.  A template parameter,
 // not a branch: the libm code is nine inlined range reductions and would triple the loop body of the production kernel.
+struct noise_args {
+    // used every frame
+    const float *env, *phi;
+    float *uv, *bre;
+    const double *short_s;
+    int ld, mode, run;             // mode bit 0: blur the rows here; bit 1: never skip a transform (A/B)
+    float t5[3], t175[8];          // first halves of the two (symmetric) tap sets
+    // set-up, frame records (every 64 frames), note entry: read where they are used (cold_arg)
+    int64_t total_frames;
+    uint64_t seed;
+    const int64_t *row_src;
+    const int *frame_note;
+    const int64_t *frame_off, *sample_off;
+    const float2 *picks;
+    const goofer_note_params *params;
+    const double *steps;
+    const float *freqs, *bright;
+    const float2 *g_tw, *g_twh;
+    const float *g_win;
+};
+#define NCOLD(field) COLD(noise_args, field)
+
 template <int M, bool PHI>
-__global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict__ env, int ld, const int64_t *__restrict__ row_src,
-                                                        const float *__restrict__ phi, int64_t total_frames,
-                                                        const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
-                                                        const int64_t *__restrict__ sample_off, const float2 *__restrict__ picks,
-                                                        const goofer_note_params *__restrict__ params, uint64_t seed,
-                                                        const float *__restrict__ freqs, const float *__restrict__ bright,
-                                                        const stem_taps taps, int mode,   // bit 0: blur the rows here; bit 1: never skip a transform (A/B)
-                                                        const double *__restrict__ short_s, const double *__restrict__ steps,
-                                                        float *__restrict__ uv, float *__restrict__ bre, int run,
-                                                        const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twh,
-                                                        const float *__restrict__ g_win)
+__global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
 {
     using C = stem_cfg<M>;
     constexpr int R = C::R, G = C::G, HOP = C::HOP, B = C::B, PER = C::PER, KN = C::KN, KPL = C::KPL, ROWF = C::ROWF;
     static_assert(R == 8, "the row staging below moves two 16-byte pieces per lane");
     extern __shared__ __align__(16) unsigned char smem[];
     walker<M, 2, false> w;
-    w.init(smem, g_tw, g_twh, g_win, freqs, bright, nullptr);
+    w.init(smem, NCOLD(g_tw), NCOLD(g_twh), NCOLD(g_win), NCOLD(freqs), NCOLD(bright), nullptr);
     const int lane = w.lane;
     const float *t_fq = w.tab, *t_br = w.tab + ROWF;
+    const float *__restrict__ env = A.env;
+    const float *__restrict__ phi = A.phi;
+    float *__restrict__ uv = A.uv, *__restrict__ bre = A.bre;
+    const int ld = A.ld, mode = A.mode;
     int64_t fs, f0, f1;
-    if (!w.range(total_frames, run, frame_note, frame_off, fs, f0, f1)) return;   // no block barrier below
+    {
+        const int64_t total_frames = NCOLD(total_frames);
+        if (!w.range(total_frames, A.run, NCOLD(frame_note), NCOLD(frame_off), fs, f0, f1)) return;   // no block barrier below
+    }
     frame_block fb;
-    fb.load(fs, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
-    if constexpr (!PHI) fb.load_nyquist(params, seed, M);
+    auto load_block = [&](int64_t first) {
+        fb.load(first, NCOLD(total_frames), NCOLD(frame_note), NCOLD(frame_off), NCOLD(sample_off), NCOLD(row_src), NCOLD(picks), lane);
+        if constexpr (!PHI) fb.load_nyquist(NCOLD(params), NCOLD(seed), M);
+    };
+    load_block(fs);
     // bins 64 .. M sit a whole 64-bin stride above the lowest bins: when f0 + 100 Hz is still below bin 64 their high-pass
     // factor is exactly 1.0f (1 + exp(-z) rounds to 1 for z > 18, i.e. 90 Hz above f0; rcp(1) = 1) and is not evaluated
     const float fq64 = w.tab[WAVE];
+    // the two tap sets are symmetric (gauss_taps_host): tap q of the second half is tap len - 1 - q
+    float t5[5], t175[15];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) t5[q] = A.t5[q < 3 ? q : 4 - q];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) t175[q] = A.t175[q < 8 ? q : 14 - q];
 
     // the next frame's envelope row is in flight while the current one is transformed: bins 8 lane .. 8 lane + 7 as two
     // 16-byte loads, the Nyquist bin beside them
@@ -390,15 +430,16 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
             one_bits = zero_bits = 0;
             w.enter_note(fb, idx);
             const int nt = w.note;
-            const goofer_note_params &p = params[nt];
+            const goofer_note_params &p = NCOLD(params)[nt];
             ns = (w.n + MASK_DS - 1) / MASK_DS;
             g_b = p.breath_strength;
             g_u = p.uv_strength;
+            const double *steps = NCOLD(steps);
             step_n = steps[2 * nt];
             step_s = steps[2 * nt + 1];
             kps = w.n > 1 ? (float)(ns - 1) / (float)(w.n - 1) : 0.f;
-            ss = short_s + (w.base / MASK_DS + nt);           // short_base()
-            key = seed ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
+            ss = A.short_s + (w.base / MASK_DS + nt);         // short_base()
+            key = NCOLD(seed) ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
             apply_bright = p.apply_brightness;
         }
         const float f0f = FB_GETF(fb, f0, idx);
@@ -440,9 +481,9 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
                 x[16] = lane == 63 ? e_ny : x[16];
 #pragma unroll
                 for (int j = 0; j < 9; ++j) {
-                    float acc = taps.t175[0] * x[j + 1];
+                    float acc = t175[0] * x[j + 1];
 #pragma unroll
-                    for (int q = 1; q < 15; ++q) acc = fmaf(taps.t175[q], x[j + 1 + q], acc);
+                    for (int q = 1; q < 15; ++q) acc = fmaf(t175[q], x[j + 1 + q], acc);
                     o9[j] = acc;
                 }
                 wave_lds_sync();
@@ -459,10 +500,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
             wave_lds_sync();                                  // row dead: buf is free
         }
         if (f + 1 < f1) {                                     // the row registers are consumed: start the next frame's row
-            if (!fb.holds(f + 1)) {
-                fb.load(f + 1, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
-                if constexpr (!PHI) fb.load_nyquist(params, seed, M);
-            }
+            if (!fb.holds(f + 1)) load_block(f + 1);
             fetch(FB_GET(fb, src, (int)(f + 1 - fb.blk0)));
         }
 
@@ -506,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int k = lane + WAVE * i;
-                if (k < B) sb[i] = blur5f(w.buf, k, B, taps.t5);
+                if (k < B) sb[i] = blur5f(w.buf, k, B, t5);
             }
             wave_lds_sync();
         }
@@ -556,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const float *__restrict_
                                 const float ws = w.ws_c[g][c], rw = w.rws_c[g][c];
                                 if (ws > 1e-9f) { xu[c] = div_by(xu[c], ws, rw); xb[c] = div_by(xb[c], ws, rw); }
                             } else {
-                                const float ws = w.partial_ws(h, g, c);
+                                const float ws = w.partial_ws(h, g, c, NCOLD(g_win));
                                 if (ws > 1e-9f) { xu[c] /= ws; xb[c] /= ws; }
                             }
                         } else {
@@ -770,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
                                 const float ws = w.ws_c[g][c];
                                 if (ws > 1e-9f) x[c] = div_by(x[c], ws, w.rws_c[g][c]);
                             } else {
-                                const float ws = w.partial_ws(h, g, c);
+                                const float ws = w.partial_ws(h, g, c, g_win);
                                 if (ws > 1e-9f) x[c] /= ws;
                             }
                         } else {
@@ -948,14 +986,16 @@ int launch_noise_stems(goofer_ctx *ctx, const float *env, int ld, const int64_t 
     const int run = run_length(F, slots);
     const int64_t runs = (F + run - 1) / run;
     const dim3 grid((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
-    if (phi)
-        hipLaunchKernelGGL((k_noise_stems<M, true>), grid, dim3(256), lds, st, env, ld, row_src, phi, F, frame_note, frame_off,
-                           sample_off, picks, params, seed, p.freqs, p.bright_b, plan_taps(p), (preblurred ? 0 : 1) | (ctx->skip_zero ? 0 : 2), short_s, steps, uv,
-                           bre, run, p.tw_full, p.tw_half, p.window);
-    else
-        hipLaunchKernelGGL((k_noise_stems<M, false>), grid, dim3(256), lds, st, env, ld, row_src, phi, F, frame_note, frame_off,
-                           sample_off, picks, params, seed, p.freqs, p.bright_b, plan_taps(p), (preblurred ? 0 : 1) | (ctx->skip_zero ? 0 : 2), short_s, steps, uv,
-                           bre, run, p.tw_full, p.tw_half, p.window);
+    noise_args A;
+    A.env = env; A.phi = phi; A.uv = uv; A.bre = bre; A.short_s = short_s;
+    A.ld = ld; A.mode = (preblurred ? 0 : 1) | (ctx->skip_zero ? 0 : 2); A.run = run;
+    for (int q = 0; q < 3; ++q) A.t5[q] = p.taps5_f[q];
+    for (int q = 0; q < 8; ++q) A.t175[q] = p.taps175_f[q];
+    A.total_frames = F; A.seed = seed; A.row_src = row_src; A.frame_note = frame_note; A.frame_off = frame_off;
+    A.sample_off = sample_off; A.picks = picks; A.params = params; A.steps = steps; A.freqs = p.freqs; A.bright = p.bright_b;
+    A.g_tw = p.tw_full; A.g_twh = p.tw_half; A.g_win = p.window;
+    if (phi) hipLaunchKernelGGL((k_noise_stems<M, true>), grid, dim3(256), lds, st, A);
+    else hipLaunchKernelGGL((k_noise_stems<M, false>), grid, dim3(256), lds, st, A);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
