@@ -629,6 +629,10 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "overlap")) { ctx->overlap = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "stems")) { ctx->stems = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "skip_zero")) { ctx->skip_zero = value != 0; return GOOFER_OK; }
+    if (!strcmp(name, "walk_lds_kb")) { ctx->walk_lds_kb = value < 32 ? 32 : (value > 160 ? 160 : value); return GOOFER_OK; }
+    if (!strcmp(name, "finish_lds_kb")) { ctx->finish_lds_kb = value < 0 ? 0 : (value > 160 ? 160 : value); return GOOFER_OK; }
+    if (!strcmp(name, "maps_side")) { ctx->maps_side = value != 0; return GOOFER_OK; }
+    if (!strcmp(name, "sa_spt")) { ctx->sa_spt = value >= 16 ? 16 : (value >= 8 ? 8 : 4); return GOOFER_OK; }
     return goofer_fail(ctx, GOOFER_EINVAL, "unknown option %s", name);
 }
 
@@ -1187,8 +1191,6 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     const double *d_mtaps = ctx->mask_taps;
     const int mrad = ctx->mask_taps_radius;
 
-    HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), st));
-
     hipEvent_t *pev = nullptr;
     if (ctx->prof_on && ctx->prof_steps < ctx->prof_cap) pev = ctx->prof_ev + (size_t)ctx->prof_steps * (PROF_STAGES + 1);
     int stage = 0;
@@ -1220,11 +1222,19 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         f0s = const_cast<float *>(b->f0);
         ctx->dbg_ptr[2] = f0s;
     }
+    // goofer_render_batch, stem path: the frame maps (frame -> note, frame -> envelope row, per-frame picks, mask steps) need
+    // nothing but the offsets and the assembled f0 / mask, so they go to the side stream in front of the pulse chain and run
+    // beside the envelope assembly — on the caller's stream they sat, with their launch gaps, between the envelope gather
+    // and the mask smoothing (0.07 ms of the critical path).
+    const bool maps_side = early && f0_alias && stem_path && ctx->maps_side;
+    hipStream_t mst = maps_side ? ctx->side : st;
+    if (!maps_side) HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), st));
     MARK();   // 0: setup
     if (early) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_entry, 0));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_f0, 0));
         HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), ctx->side));
+        if (maps_side) HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), ctx->side));
         if (!f0_alias) {
             hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, ctx->side, b->f0, b->sample_off, n, N,
                                b->params, f0s);
@@ -1234,7 +1244,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     } else {
         HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), st));
     }
-    if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, st))) return rc;
+    if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, mst))) return rc;
     if (!early && !f0_alias) {
         hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params,
                            f0s);                                     // (the pulse walk divides by sr itself)
@@ -1244,9 +1254,13 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // nothing jitters it in place later, and it is not being produced on the side stream
     const bool picks_on = !jit_f0 && !sub_jit && !(early && !f0_alias);
     ctx->frame_picks = picks_on ? picks : nullptr;
-    hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, st, b->frame_off, b->env_off, frame_note, F, row_src, b->sample_off,
+    hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, mst, b->frame_off, b->env_off, frame_note, F, row_src, b->sample_off,
                        (const float *)f0s, b->mask, p.hop, picks_on ? picks : (float2 *)nullptr);
     LAUNCH_CHECK(ctx);
+    if (maps_side) {
+        if ((rc = launch_note_steps(ctx, b->sample_off, n, note_steps, mst))) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, mst));
+    }
     if (jit_f0 || jit_vol) {
         hipLaunchKernelGGL(k_note_flags, dim3((n + 255) / 256), dim3(256), 0, st, b->params, n, on_f0, on_vol);
         LAUNCH_CHECK(ctx);
@@ -1266,7 +1280,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if (!picks_on && (r2 = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return r2;
         if ((r2 = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return r2;
         if (side_on) MARK_Q(0);
-        if ((r2 = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return r2;
+        if (!maps_side && (r2 = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return r2;
         if ((r2 = launch_noise_stems(ctx, b->env_noise ? b->env_noise : b->env, ld, row_src, b->phi, F, frame_note, b->frame_off,
                                      b->sample_off, picks, b->params, b->seed, b->env_noise != nullptr, short_s, note_steps, b->uv,
                                      b->bre, st)))
@@ -1283,7 +1297,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         int rc2 = ensure_side_stream(ctx);
         if (rc2) return rc2;
         if (pev) sev = ctx->prof_side + (size_t)ctx->prof_steps * 4;
-        if (stem_path && !ctx->warp_done) HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st));   // the frame maps and everything before them on this stream (for k_warp_bins)
+        if (stem_path && !ctx->warp_done && !maps_side) HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st));   // the frame maps and everything before them on this stream (for k_warp_bins)
         if (!early) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
@@ -1311,7 +1325,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // ~95 frames of ONE note, so the slow notes would set the kernel's time.
     const bool warp_ready = stem_path && ctx->warp_done;               // goofer_render_batch: the assembly already wrote the warped rows
     if (stem_path && side_on && !warp_ready) {
-        HIP_TRY(ctx, hipStreamWaitEvent(pst, ctx->ev_maps, 0));            // frame_note / row_src come from the caller's stream
+        if (!maps_side) HIP_TRY(ctx, hipStreamWaitEvent(pst, ctx->ev_maps, 0));   // frame_note / row_src come from the caller's stream
         if ((rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, pst)))
             return rc;
     }
@@ -1321,6 +1335,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         // meanwhile, on the caller's stream
         if (early && !f0_alias) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_f0s, 0));   // the scaled f0 comes from the side stream
         if (stem_path) {
+            if (maps_side) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_maps, 0));        // the maps come from the side stream
             if ((rc = stems_aperiodic())) return rc;
         } else {
             if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,

@@ -396,8 +396,10 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
 }
 
 
-#define SA_SPT 4   // samples per thread, strided by the workgroup so loads and stores stay coalesced
-
+// SA_SPT samples per thread, strided by the workgroup so loads and stores stay coalesced.  A workgroup starts with two rounds
+// of dependent loads (which note?) and the scalar loads of the note's 300-byte plan before its first sample: more samples
+// per workgroup amortise that latency.
+template <int SA_SPT>
 __global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a, int64_t total_samples)
 {
     __shared__ int s_pair[2];
@@ -507,8 +509,11 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
     // goofer_render_batch starts it on the side stream while the envelope kernels below are still running
     ctx->early_f0 = nullptr;
     if (a->total_samples > 0) {
-        hipLaunchKernelGGL(k_sample_assemble, dim3((unsigned)((a->total_samples + 256 * SA_SPT - 1) / (256 * SA_SPT))), dim3(256), 0, st, *a,
-                           a->total_samples);
+        const int spt = ctx->sa_spt;
+        const dim3 sgrid((unsigned)((a->total_samples + 256 * spt - 1) / (256 * spt)));
+        if (spt == 16) hipLaunchKernelGGL(k_sample_assemble<16>, sgrid, dim3(256), 0, st, *a, a->total_samples);
+        else if (spt == 8) hipLaunchKernelGGL(k_sample_assemble<8>, sgrid, dim3(256), 0, st, *a, a->total_samples);
+        else hipLaunchKernelGGL(k_sample_assemble<4>, sgrid, dim3(256), 0, st, *a, a->total_samples);
         LAUNCH_CHECK(ctx);
         if (ctx->early_req && ctx->ev_f0) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_f0, st));

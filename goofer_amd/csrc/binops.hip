@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
                 float h = hp_mask(fq[i], f0f);
                 s.x *= h; s.y *= h;
             }
-            mx = fmaxf(mx, cabs_fast(s) + 1e-8f);
+            mx = fmaxf(mx, s.x * s.x + s.y * s.y);                 // |s|^2: the square root is taken once, of the maximum
             const float g = eg ? eg[k] : ev[i];
             s.x = (s.x * g) * bo[i];
             s.y = (s.y * g) * bo[i];
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
             else row[k] = s;
         }
     }
-    mx = wave_max(mx);
+    mx = __builtin_amdgcn_sqrtf(wave_max(mx)) + 1e-8f;              // max(|s| + 1e-8) = sqrt(max |s|^2) + 1e-8: sqrt is monotone
     if (lane == 0) atomic_max_pos(note_mag + note, mx);
     if (voiced) {
         wave_lds_sync();

@@ -348,9 +348,6 @@ __device__ __forceinline__ float hp_mask(float freq, float f0f)
     return __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-// |s| for the per-note max(abs(S) + 1e-8): plain sqrt (no overflow risk at these magnitudes)
-__device__ __forceinline__ float cabs_fast(float2 s) { return __builtin_amdgcn_sqrtf(s.x * s.x + s.y * s.y); }
-
 // 5-tap sigma=0.5 blur of a complex row held in LDS (reflect padded).  The reference accumulates in complex128 and
 // rounds to complex64; here the five products are fp32 FMAs in the same tap order (<= 2e-7 relative).
 __device__ __forceinline__ float2 blur5(const float2 *r, int k, int n_bins, const double *t5)

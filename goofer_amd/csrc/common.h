@@ -68,6 +68,11 @@ struct goofer_ctx {
                                   // one-kernel-per-reference-step pipeline with the spectra in HBM (A/B parity path)
     bool skip_zero = true;        // noise walker: skip transforms whose stem gain is exactly zero over everything they reach (option "skip_zero")
     bool prof_stems = false;      // the last profiled batch ran the stem-split path (stage order differs)
+    // tuning knobs (goofer_set_option; the defaults are the measured optima — round 3 swept them: nothing within 1 % to gain)
+    int walk_lds_kb = 81;         // LDS the sequential phase walk reserves per workgroup (what it uses: 32 KiB)
+    int finish_lds_kb = 0;        // LDS k_note_finish reserves per workgroup (0: none) — caps the notes in flight per CU
+    int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
+    int maps_side = 0;            // goofer_render_batch: frame maps on the side stream in front of the pulse chain (A/B: +0.4 %, off)
     // per-context kernel state: hipFuncSetAttribute is per device, and a handle belongs to one device, so what was set /
     // queried is remembered here and never in process-wide statics
     struct kernel_state {

@@ -71,6 +71,23 @@ __device__ __forceinline__ float2 irfft_pre(float2 xk, float2 xm, float2 wc)
     return to_f2(r);
 }
 
+// rFFT output stage for bin k: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 e^{-i pi k/M} (Z[k] - conj Z[M-k]) with wc the CONJUGATE of
+// the half-bin twiddle (the table the inverse input stage uses):  A = zk + conj zm,  B = zk - conj zm,  C = conj(wc) B,
+// X = ((A.x + C.y)/2, (A.y - C.x)/2).  Six packed instructions; written on {x, y} structs the compiler spends five more
+// moves per bin putting the halves together.  Same operations, same roundings.
+__device__ __forceinline__ float2 rfft_post(float2 zk, float2 zm, float2 wc)
+{
+    const cplx k = to_c(zk), m = to_c(zm), w = to_c(wc), half = {0.5f, 0.5f};
+    cplx A, B, t, C, S, X;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(A) : "v"(k), "v"(m));                 // (kx + mx, ky - my)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(B) : "v"(k), "v"(m));                 // (kx - mx, ky + my)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(w), "v"(B));              // cmul(conj(w), B), see cmul_conj
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(C) : "v"(w), "v"(B), "v"(t));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(S) : "v"(A), "v"(C));   // (Ax + Cy, Ay - Cx)
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(X) : "v"(S), "v"(half));
+    return to_f2(X);
+}
+
 // ROT2: element 2 still has to be multiplied by -i (the W8^2 twiddle of the odd half of a radix-8 butterfly)
 template <bool ROT2>
 __device__ __forceinline__ void dft4_c(cplx *v)

@@ -582,8 +582,8 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
         const int blocks = (n_notes + 3) / 4;
         const int per_cu = (blocks + 255) / 256;              // MI355X: 256 CUs, 160 KiB LDS each
         size_t lds = (size_t)(160 * 1024) / per_cu;
-        if (lds > 81 * 1024) lds = 81 * 1024;                 // two of these cannot share a CU, and 79 KiB stay free for the
-                                                              // kernel running beside the walk (three noise-spectra workgroups)
+        if (lds > (size_t)ctx->walk_lds_kb * 1024) lds = (size_t)ctx->walk_lds_kb * 1024;   // 81 KiB: two of these cannot share a CU,
+                                                              // and 79 KiB stay free for the kernel running beside the walk
         lds = lds / 1024 * 1024;
         const size_t need = 4 * 2 * OC * sizeof(double);      // 32 KiB actually used
         if (lds < need) lds = need;

@@ -735,11 +735,7 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int k = lane + WAVE * r;
-                const float2 zk = z[r], zm = w.buf[lds_pad((M - k) & (M - 1))];
-                const float2 A = make_float2(zk.x + zm.x, zk.y - zm.y);
-                const float2 Bv = make_float2(zk.x - zm.x, zk.y + zm.y);
-                const float2 Cv = cmul_conj(w.wct[k], Bv);            // the split twiddle is the conjugate of the inverse one
-                X[r] = make_float2(0.5f * (A.x + Cv.y), 0.5f * (A.y - Cv.x));
+                X[r] = rfft_post(z[r], w.buf[lds_pad((M - k) & (M - 1))], w.wct[k]);   // the split twiddle is the conjugate of the inverse one
             }
             X[R] = make_float2(z[0].x - z[0].y, 0.f);                // Nyquist bin from Z[0] (lane 0)
             wave_lds_sync();
@@ -762,7 +758,7 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
                 const float h = hp_mask(t_fq[k], f0f);
                 s.x *= h; s.y *= h;
             }
-            mx = fmaxf(mx, cabs_fast(s) + 1e-8f);
+            mx = fmaxf(mx, s.x * s.x + s.y * s.y);                 // |s|^2: the square root is taken once, of the maximum
             const float bo = t_bo[k];
             s.x = (s.x * evc[i]) * bo;
             s.y = (s.y * evc[i]) * bo;
@@ -772,7 +768,7 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
             }
             X[i] = s;
         }
-        mx = wave_max(mx);
+        mx = __builtin_amdgcn_sqrtf(wave_max(mx)) + 1e-8f;          // max(|s| + 1e-8) = sqrt(max |s|^2) + 1e-8: sqrt is monotone
         if (lane == 0) atomic_max_pos(note_mag + w.note, mx);
         if (voiced) {
 #pragma unroll
@@ -1028,7 +1024,10 @@ int launch_note_finish(goofer_ctx *ctx, float *harm, float *uv, float *bre, floa
                        hipStream_t st)
 {
     if (n_notes <= 0) return GOOFER_OK;
-    hipLaunchKernelGGL(k_note_finish, dim3((unsigned)n_notes), dim3(FIN_THREADS), 0, st, harm, uv, bre, rec, mix, sample_off, params,
+    const size_t lds = (size_t)ctx->finish_lds_kb * 1024;
+    if (lds > 64 * 1024)
+        if (int arc = kernel_allow_max_lds(ctx, (const void *)k_note_finish)) return arc;
+    hipLaunchKernelGGL(k_note_finish, dim3((unsigned)n_notes), dim3(FIN_THREADS), lds, st, harm, uv, bre, rec, mix, sample_off, params,
                        note_mag, note_peak, write_stems ? 1 : 0);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;

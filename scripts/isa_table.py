@@ -57,11 +57,12 @@ def sub_class(op):
     return out
 
 
-def parse(path, kernel):
+def parse(path, kernel, by_root=False):
     files = {}
     cur = None
     inside = False
     loc = (None, 0)
+    root = None
     label = "<entry>"
     insts = []                       # (label, op, file, line, text)
     fre = re.compile(r'\s*\.file\s+(\d+)\s+"([^"]*)"\s+"([^"]*)"')
@@ -72,6 +73,7 @@ def parse(path, kernel):
             if m:
                 files[int(m.group(1))] = m.group(3)
                 continue
+            comment = raw.split(";", 1)[1] if ";" in raw else ""
             s = raw.rstrip("\n").split(";")[0].rstrip()
             if not inside:
                 if s.endswith(":") and not s.startswith((".", "\t", " ")) and kernel in s:
@@ -83,6 +85,11 @@ def parse(path, kernel):
             m = lre.match(s)
             if m:
                 loc = (int(m.group(1)), int(m.group(2)))
+                root = None
+                if by_root:                      # outermost frame of the inlined-at chain: "a.h:10:3 @[ b.hip:200:7 @[ c.hip:50:1 ] ]"
+                    chain = re.findall(r"([^\s\[\]@]+):(\d+):\d+", comment)
+                    if chain:
+                        root = (chain[-1][0].split("/")[-1], int(chain[-1][1]))
                 continue
             t = s.strip()
             if not t or t.startswith((";", "//")):
@@ -95,7 +102,10 @@ def parse(path, kernel):
             op = t.split()[0]
             if not re.match(r"^[a-z][a-z0-9_]+$", op):
                 continue
-            insts.append((label, op, files.get(loc[0], "?"), loc[1], t))
+            if by_root and root:
+                insts.append((label, op, root[0], root[1], t))
+            else:
+                insts.append((label, op, files.get(loc[0], "?"), loc[1], t))
     return cur, insts
 
 
@@ -118,8 +128,10 @@ def main():
     ap.add_argument("--from", dest="lo")
     ap.add_argument("--to", dest="hi")
     ap.add_argument("--lines", action="store_true", help="per source line instead of per phase")
+    ap.add_argument("--by-root", action="store_true", help="attribute an instruction to the outermost frame of its inlined-at chain (the kernel body's line) instead of the innermost location")
+    ap.add_argument("--loop", action="store_true", help="restrict to the largest loop of the kernel (the longest back-edge span)")
     a = ap.parse_args()
-    name, insts = parse(a.asm, a.kernel)
+    name, insts = parse(a.asm, a.kernel, a.by_root)
     if not insts:
         sys.exit("kernel not found")
     print("kernel:", name, "| instructions:", len(insts))
@@ -138,6 +150,23 @@ def main():
                     span = sum(count[x] for x in order[pos[tgt]:pos[lab] + 1])
                     print("  back edge %-12s -> %-12s  loop span %5d instructions" % (lab, tgt, span))
         return
+    if a.loop:
+        order = []
+        count = collections.Counter()
+        for lab, *_ in insts:
+            if lab not in count:
+                order.append(lab)
+            count[lab] += 1
+        pos = {lab: i for i, lab in enumerate(order)}
+        best = (0, None, None)
+        for lab, op, f, line, text in insts:
+            if op.startswith(("s_cbranch", "s_branch")):
+                tgt = text.split()[-1]
+                if tgt in pos and pos[tgt] <= pos[lab]:
+                    span = sum(count[x] for x in order[pos[tgt]:pos[lab] + 1])
+                    if span > best[0]:
+                        best = (span, tgt, lab)
+        a.lo, a.hi = best[1], best[2]
     if a.lo or a.hi:
         order = []
         for lab, *_ in insts:
