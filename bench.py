@@ -11,7 +11,9 @@ of synthetic notes already resident in HBM.  Notes are independent, so ranks sha
 `--notes` per GPU); the only collectives are the barriers and the MAX of the elapsed time.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      HIP-event duration of the dominant kernel inside the timed steps vs its algorithmic bytes
+  roofline      HIP-event duration of the longest kernel of the timed steps vs its algorithmic bytes; `traffic` (HBM bytes from the
+                committed counter passes) only when those passes were measured on this very source tree, else "stale": true
+  value_skip_zero_off / value_unvoiced_30pct   the same step with no transform skipped / on 30 %-unvoiced sources
   roofline_fft  the same for the framewise rFFT kernel (the kernel BASELINE's 40 % target names)
   roofline_step the whole step against its end-to-end algorithmic bytes and the HBM traffic the counter passes measured
   cpu_baseline  the numpy/C oracle (a port of the reference's CPU path) timed on this box's host cores: one thread, and a
@@ -67,6 +69,11 @@ STAGE_KERNEL = {"rfft_frames": "void k_rfft_frames<512>", "rfft_frames_standalon
                 "noise_stems": "void k_noise_stems<512, false>", "harm_stem": "void k_harm_stem<512>", "note_finish": "k_note_finish"}
 
 
+def _tree_hash():
+    from goofer_amd.build import source_hash
+    return source_hash()
+
+
 def _pmc_file():
     """Newest committed rocprofv3 counter passes (profiles/<tag>_pmc_traffic.json, tags sort in time order)."""
     import glob
@@ -75,28 +82,30 @@ def _pmc_file():
 
 
 def pmc_traffic(stage, frames):
-    """(HBM bytes per launch, source tag) from the newest committed rocprofv3 PMC passes of this same command
-    (scripts/collect_profiles.sh), with the gfx950 FETCH_SIZE correction.  The counters cannot be read inside this
-    process, so the figure is the committed measurement of this code path, not of this run: the tag says which.
-    (None, None) when the workload size or the kernel does not match."""
+    """{bytes, source, stale} from the newest committed rocprofv3 PMC passes of this same command (scripts/collect_profiles.sh),
+    with the gfx950 FETCH_SIZE correction.  The counters cannot be read inside this process, so the figure is the committed
+    measurement of a code tree, and only that tree's: the file carries the sha256 of goofer_amd/csrc it was measured on, and when
+    it differs from the tree being timed (or the workload size does) the bytes are withheld and `stale` is true."""
     try:
         fn = _pmc_file()
         d = json.load(open(fn))
         k = d["kernels"][STAGE_KERNEL[stage]]
-        if d["_meta"]["frames"] != frames:
-            return None, None
-        return (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0, os.path.basename(fn)
+        src = os.path.basename(fn)
+        if d["_meta"].get("csrc_sha256") != _tree_hash() or d["_meta"]["frames"] != frames:
+            return {"bytes": None, "source": src, "stale": True}
+        return {"bytes": (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0, "source": src, "stale": False}
     except Exception:
-        return None, None
+        return {"bytes": None, "source": None, "stale": None}
 
 
 def pmc_step_traffic(frames):
     try:
         fn = _pmc_file()
         d = json.load(open(fn))
-        if d["_meta"]["frames"] != frames:
-            return None
-        return {"bytes": d["_meta"]["step_hbm_bytes"], "source": os.path.basename(fn)}
+        src = os.path.basename(fn)
+        if d["_meta"].get("csrc_sha256") != _tree_hash() or d["_meta"]["frames"] != frames:
+            return {"bytes": None, "source": src, "stale": True}
+        return {"bytes": d["_meta"]["step_hbm_bytes"], "source": src, "stale": False}
     except Exception:
         return None
 
@@ -105,19 +114,24 @@ def sq_valu_issue(stage, ms, frames):
     """Vector-issue fraction of a kernel from the newest committed SQ counter pass (profiles/r*_sq_counters.txt, collected with
     scripts/pmc_pass.sh on the 1024-note default workload): SQ_INSTS_VALU per launch / this run's kernel time, against what
     1024 SIMDs can issue (one wave instruction per 4 cycles at 2.4 GHz).  The walkers are bound by what the vector and LDS pipes
-    issue, not by HBM: this is the fraction that says how close they are.  None when no pass matches."""
+    issue, not by HBM: this is the fraction that says how close they are.  The file's first line carries the sha256 of the
+    kernel sources it was measured on; a different tree gets {"stale": true} and no number."""
     try:
         if frames != 194560:
             return None
         import glob
         files = sorted(glob.glob(os.path.join(HERE, "profiles", "r*_sq_counters.txt")))
         name = STAGE_KERNEL[stage].replace("void ", "").split("<")[0]
-        for ln in open(files[-1]):
+        lines = open(files[-1]).read().splitlines()
+        src = os.path.basename(files[-1])
+        if not (lines and lines[0].startswith("# csrc_sha256=") and lines[0].split("=", 1)[1].strip() == _tree_hash()):
+            return {"stale": True, "source": src}
+        for ln in lines:
             if ln.startswith(name + " ") and "SQ_INSTS_VALU=" in ln:
                 insts = float(ln.split("SQ_INSTS_VALU=")[1].split()[0])
                 peak = 1024 * 2.4e9 / 4.0
                 return {"insts_valu_per_launch": insts, "issue_frac": insts / (ms * 1e-3) / peak, "peak_wave_insts_per_s": peak,
-                        "source": os.path.basename(files[-1])}
+                        "source": src, "stale": False}
     except Exception:
         pass
     return None
@@ -260,6 +274,7 @@ def main():
                     "smaller batches fill the device worse, one 10 000-note batch makes the walk the critical path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inclusive", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the skip_zero-off / 30 %-unvoiced variants of the step")
     ap.add_argument("--gather", action="store_true", help="also time the optional ragged gather of finished audio to rank 0 "
                     "(RCCL over xGMI; never part of `value`)")
     args = ap.parse_args()
@@ -368,6 +383,35 @@ def main():
     rfft_ms = e0.elapsed_time(e1) / args.steps
     del xin, Sout
 
+    # The headline workload is fully voiced behind the notes' 50 ms offset, so the noise walker skips the unvoiced stem's
+    # transform (exactly zero gain) on every frame.  Two variants of the same step say what that is worth: the skipping
+    # switched off (both transforms on every frame: SURVEY 8d's "1 rFFT + 3 irFFT-OLA" literally), and 30 % of every source
+    # unvoiced in 50 ms gaps.  Same notes, same flags, same step function; `value` stays the BASELINE workload.
+    variants = None
+    if world == 1 and not job and not args.no_variants:
+        def timed(w, k):
+            for _ in range(3):
+                w.step()
+            torch.cuda.synchronize()
+            v0, v1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            v0.record()
+            for _ in range(k):
+                w.step()
+            v1.record()
+            torch.cuda.synchronize()
+            return v0.elapsed_time(v1) / k
+        ctx.set_option("skip_zero", 0)
+        ms_off = timed(wl, args.steps)
+        ctx.set_option("skip_zero", 1)
+        wl30 = SamplerWorkload(ctx, args.config, ids, unvoiced_share=0.3)
+        ms_30 = timed(wl30, args.steps)
+        voiced30 = float((wl30.prep["mask"] > 0).float().mean())
+        variants = {"skip_zero_off": {"value": my_frames / (ms_off * 1e-3), "ms_per_step": ms_off,
+                                      "what": "option skip_zero = 0: no transform is skipped (one rFFT + three irFFT-OLA on every frame)"},
+                    "unvoiced_30pct": {"value": wl30.frames / (ms_30 * 1e-3), "ms_per_step": ms_30, "voiced_share_of_samples": voiced30,
+                                       "what": "30 % of every source unvoiced in 50 ms gaps (synthetic.with_unvoiced_gaps), skipping on"}}
+        del wl30
+
     gather_ms = None
     if args.gather:
         from goofer_amd.shard import gather_audio
@@ -385,11 +429,15 @@ def main():
         value = frames_total * args.steps / elapsed
         steps = max(1, prof["steps"])
         per = {k: v / steps for k, v in prof["ms"].items()}              # ms per launch (per sub-batch), this rank
-        # the dominant kernel is picked among the stages that run alone on the chip: the event-bracketed times of the
-        # forked stages (pulse chain on the side stream, noise walker / mask smoothing beside it) include each other
-        shared = {"pulse_onsets", "pulse_place", "noise_spectra", "noise_stems", "mask_short", "phase_inc", "setup_maps", "assemble"}
-        solo = {k: v for k, v in per.items() if k not in shared} or per
-        dom = max(solo, key=solo.get)
+        # the dominant kernel = the longest single kernel of the step.  (Stages bracketing several launches — the assembly, the
+        # map kernels — and the latency-bound phase walk, which moves 4 B per sample in half a millisecond by design, are not
+        # roofline candidates.)  Some stages share the chip with the side stream: their event time includes that, see `shared_with`.
+        multi = {"assemble", "setup_maps", "phase_inc", "pulse_onsets"}
+        shared_with = {"noise_stems": "the tail of k_pulse_place on the side stream (its time alone is a few percent lower)",
+                       "noise_spectra": "the pulse chain on the side stream", "mask_short": "the pulse chain on the side stream",
+                       "pulse_place": "the envelope gather / noise walker on the caller's stream"}
+        single = {k: v for k, v in per.items() if k not in multi and v > 0} or per
+        dom = max(single, key=single.get)
         per["rfft_frames_standalone"] = rfft_ms
         Fb, Nb = my_frames / len(subs), my_samples / len(subs)           # frames / samples per launch (mean sub-batch)
 
@@ -399,10 +447,11 @@ def main():
             ms = per[stage]
             alg = stage_alg_bytes(stage, frames, samples, B, hop, n_fft)
             a = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            traffic, src = pmc_traffic(stage, wl.frames) if not job else (None, None)
+            tr = pmc_traffic(stage, wl.frames) if not job else {"bytes": None, "source": None, "stale": None}
             return {"kernel": stage, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": a / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "ms_per_launch": ms,
-                    "alg_bytes_per_launch": alg, "valu": sq_valu_issue(stage, ms, wl.frames) if not job else None}
+                    "frac": a / HBM_PEAK_GBS, "traffic": tr["bytes"], "traffic_source": tr["source"], "stale": tr["stale"],
+                    "ms_per_launch": ms, "alg_bytes_per_launch": alg, "shared_with": shared_with.get(stage),
+                    "valu": sq_valu_issue(stage, ms, wl.frames) if not job else None}
 
         step_ms = elapsed / args.steps * 1e3
         alg_step = (4 * B + 20 * hop) * frames_total / world            # SURVEY 8d ALG_BYTES_FRAME x frames of one rank's step
@@ -424,10 +473,9 @@ def main():
                        "sub_batches_per_gpu": len(subs),
                        "sharding": "independent notes, no data-path collective"},
             "stage_ms": per,
-            "roofline": roof(dom),
-            # the longest kernel by rocprof average when the noise walker is it: its event-bracketed time includes the tail of
-            # the pulse placement that runs beside its start (so this fraction is a lower bound on the kernel alone)
+            "roofline": roof(dom),                # the longest kernel of the step (the noise walker on the default workload)
             "roofline_noise": roof("noise_stems") if per.get("noise_stems", 0) > 0 else None,
+            "roofline_harm": roof("harm_stem") if per.get("harm_stem", 0) > 0 else None,
             # in-pipeline launch when the active path has a standalone rFFT stage, else the entry-point timing
             "roofline_fft": roof("rfft_frames", wl.frames, wl.samples) if per.get("rfft_frames", 0) > 0
             else roof("rfft_frames_standalone", wl.frames, wl.samples),
@@ -445,6 +493,10 @@ def main():
         if gather_ms is not None:
             line["gather_to_rank0"] = {"ms": gather_ms, "bytes": 4 * wl.samples * (world - 1), "note": "ragged gather of the finished "
                                        "notes (goofer_amd.shard.gather_audio), outside the timed steps"}
+        if variants:
+            line["value_skip_zero_off"] = variants["skip_zero_off"]["value"]
+            line["value_unvoiced_30pct"] = variants["unvoiced_30pct"]["value"]
+            line["variants"] = variants
         if world == 1 and not job:
             line["pcie_inclusive"] = pcie_leg(wl, elapsed / args.steps)
             if not args.no_host_inclusive:

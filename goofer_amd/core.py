@@ -20,9 +20,6 @@ from .device import Context, default_context, default_params, row_stride
 DSTORAGE = np.float16
 DCOMPUTE = np.float32
 
-_UNSUPPORTED = ()
-
-
 def _ctx(sr, n_fft, hop, ctx=None) -> Context:
     return (ctx or default_context()).plan(sr, n_fft, hop)
 
@@ -31,20 +28,27 @@ MASK_DS = 4          # smooth_mask_ds decimation (GOOFER.py:556)
 
 
 # -- feature files (host-side format code, byte-compatible with GOOFER.py:287-339) -----------------
+def _formant_slot(key):
+    """1..4 for a formant-track key (an int, or a string 'F<n>' / 'f<n>'), else None."""
+    if isinstance(key, str):
+        if not key[:1] in ("F", "f"):
+            return None
+        try:
+            key = int(key[1:])
+        except Exception:
+            return None
+    if isinstance(key, (int, np.integer)) and 1 <= int(key) <= 4:
+        return int(key)
+    return None
+
+
 def formants_to_int_keys(d):
-    out = {}
-    if isinstance(d, dict):
-        for k, v in d.items():
-            if isinstance(k, str) and k[:1].upper() == "F":
-                try:
-                    k = int(k[1:])
-                except Exception:
-                    continue
-            if isinstance(k, (int, np.integer)) and 1 <= int(k) <= 4:
-                out[int(k)] = np.asarray(v)
-    for i in (1, 2, 3, 4):
-        out.setdefault(i, np.zeros(1, dtype=np.float64))
-    return out
+    """{1..4: ndarray} from a formant dict with int or 'F<n>' keys; absent tracks become one zero (GOOFER.py:48-62).
+    The tracks keep the order the input listed them in (the dict is pickled into the .goofy file)."""
+    slots = ((_formant_slot(k), v) for k, v in d.items()) if isinstance(d, dict) else ()
+    tracks = {slot: np.asarray(v) for slot, v in slots if slot is not None}
+    tracks.update({i: np.zeros(1, dtype=np.float64) for i in (1, 2, 3, 4) if i not in tracks})
+    return tracks
 
 
 def save_features(path, features, f0_interp, voicing_mask, formants, sr, y_len):
@@ -157,10 +161,8 @@ def gaussian_filter1d(input_array, sigma, axis=-1, truncate=4.0, ctx=None):
     """gf.gaussian_filter1d (GOOFER.py:241-261) on the device: numpy-'reflect' padding, fp64 accumulate in tap order,
     every 1-D line along ``axis`` filtered independently.  Returns float64 (complex128 for complex input)."""
     arr = np.asarray(input_array)
-    if arr.size == 0 or arr.shape[axis] == 0 or sigma <= 0.0:
-        return arr.copy()
-    radius = int(truncate * sigma + 0.5)
-    if radius <= 0:
+    radius = int(truncate * sigma + 0.5) if sigma > 0.0 else 0
+    if radius <= 0 or arr.size == 0:                            # nothing to blur: a copy, dtype untouched
         return arr.copy()
     if np.iscomplexobj(arr):
         return (gaussian_filter1d(arr.real, sigma, axis, truncate, ctx) +
@@ -183,70 +185,79 @@ def smooth_mask_ds(mask, sigma=100, ds=4, sr=44100, n_fft=1024, hop_length=256, 
     return c.smooth_mask_ds(c.tensor(m), sigma=float(sigma)).cpu().numpy()
 
 
+def _axis_sigmas(sigma):
+    """(sigma of axis 0, sigma of axis 1), negatives clamped to 0, from a number or a pair."""
+    pair = tuple(sigma) if isinstance(sigma, (list, tuple)) else (sigma, sigma)
+    if len(pair) != 2:
+        raise ValueError("sigma must be a float or a 2-tuple for 2D arrays.")
+    return tuple(max(float(v), 0.0) for v in pair)
+
+
 def gaussian_filter(input_array, sigma, ctx=None):
-    """gf.gaussian_filter (GOOFER.py:263-285): separable, sigma a float or a (rows, cols) pair."""
+    """gf.gaussian_filter (GOOFER.py:263-285): the separable blur of a matrix, one gaussian_filter1d pass (on the device)
+    per axis whose sigma is positive."""
     arr = np.asarray(input_array)
     if arr.ndim != 2:
         raise ValueError("gaussian_filter expects a 2D array.")
-    if arr.size == 0 or arr.shape[0] == 0 or arr.shape[1] == 0:
+    if 0 in arr.shape:
         return arr.copy()
-    if isinstance(sigma, (list, tuple)):
-        if len(sigma) != 2:
-            raise ValueError("sigma must be a float or a 2-tuple for 2D arrays.")
-        s0, s1 = (max(float(v), 0.0) for v in sigma)
-    else:
-        s0 = s1 = max(float(sigma), 0.0)
-    out = arr
-    if s0 > 0.0:
-        out = gaussian_filter1d(out, s0, axis=0, ctx=ctx)
-    if s1 > 0.0:
-        out = gaussian_filter1d(out, s1, axis=1, ctx=ctx)
-    return out
+    for axis, s in enumerate(_axis_sigmas(sigma)):
+        if s > 0.0:
+            arr = gaussian_filter1d(arr, s, axis=axis, ctx=ctx)
+    return arr
+
+
+class _LinearInterp:
+    """The callable gf.interp1d returns (GOOFER.py:173-239).  Inside [x[0], x[-1]] it is np.interp; outside either the two
+    end segments continued (their slopes carry the reference's +1e-10 in the denominator) or a constant.  A single point
+    is a constant function (with a fill value: the fill everywhere but at that point)."""
+
+    def __init__(self, x, y, fill_value):
+        self.x, self.y = x, y
+        self.extrapolate = fill_value == "extrapolate"
+        self.fill_value = fill_value
+        if len(x) > 1:
+            self.edge_slopes = ((y[1] - y[0]) / (x[1] - x[0] + 1e-10), (y[-1] - y[-2]) / (x[-1] - x[-2] + 1e-10))
+
+    def _fill(self):
+        try:
+            return float(self.fill_value)
+        except (TypeError, ValueError):
+            raise ValueError("fill_value must be 'extrapolate' or a number")
+
+    def __call__(self, q):
+        q = np.asarray(q)
+        x, y = self.x, self.y
+        if len(x) == 1:
+            if self.extrapolate:
+                return np.full_like(q, y[0], dtype=y.dtype)
+            out = np.full_like(q, self._fill())
+            out[np.isclose(q, x[0])] = y[0]
+            return out
+        below, above = q < x[0], q > x[-1]
+        if self.extrapolate:
+            out = np.interp(q, x, y)
+            for side, x_end, y_end, slope in ((below, x[0], y[0], self.edge_slopes[0]), (above, x[-1], y[-1], self.edge_slopes[1])):
+                if np.any(side):
+                    out[side] = y_end + slope * (q[side] - x_end)
+            return out
+        fill = self._fill()
+        inside = ~(below | above)
+        out = np.empty_like(q)
+        if np.any(inside):
+            out[inside] = np.interp(q[inside], x, y)
+        out[~inside] = fill
+        return out
 
 
 def interp1d(x, y, kind="linear", fill_value="extrapolate"):
-    """gf.interp1d (GOOFER.py:173-239): a callable linear interpolant with linear extrapolation (edge slopes carry the
-    reference's +1e-10) or a constant fill.  A host-side convenience, like the reference's; the hot path does its
-    interpolations in the kernels."""
+    """gf.interp1d: a host-side convenience like the reference's (the hot path interpolates in its kernels)."""
     if kind != "linear":
         raise ValueError("Only 'linear' interpolation is supported.")
     x, y = np.asarray(x), np.asarray(y)
     if len(x) == 0:
         raise ValueError("x cannot be empty")
-    if fill_value != "extrapolate":
-        try:
-            fill = float(fill_value)
-        except (TypeError, ValueError):
-            raise ValueError("fill_value must be 'extrapolate' or a number")
-    if len(x) == 1:
-        def one(q):
-            q = np.asarray(q)
-            if fill_value == "extrapolate":
-                return np.full_like(q, y[0], dtype=y.dtype)
-            out = np.full_like(q, fill)
-            out[np.isclose(q, x[0])] = y[0]
-            return out
-        return one
-    left = (y[1] - y[0]) / (x[1] - x[0] + 1e-10)
-    right = (y[-1] - y[-2]) / (x[-1] - x[-2] + 1e-10)
-
-    def f(q):
-        q = np.asarray(q)
-        if fill_value != "extrapolate":
-            inside = (q >= x[0]) & (q <= x[-1])
-            out = np.empty_like(q)
-            if np.any(inside):
-                out[inside] = np.interp(q[inside], x, y)
-            out[~inside] = fill
-            return out
-        out = np.interp(q, x, y)
-        lo, hi = q < x[0], q > x[-1]
-        if np.any(lo):
-            out[lo] = y[0] + left * (q[lo] - x[0])
-        if np.any(hi):
-            out[hi] = y[-1] + right * (q[hi] - x[-1])
-        return out
-    return f
+    return _LinearInterp(x, y, fill_value)
 
 
 def stretch_feature(feature, stretch, kind="linear", ctx=None):
@@ -271,24 +282,32 @@ def stretch_feature(feature, stretch, kind="linear", ctx=None):
     raise ValueError("Only 1D or 2D features are supported.")
 
 
+def _vibrato_wave(length, sr, speed, seeded):
+    """sin(2 pi speed t + phase) with a 0.1 s linear fade-in; the phase is drawn (legacy RNG) only for a seeded call."""
+    phase = np.random.uniform(0, 2 * np.pi) if seeded else 0
+    wave = np.sin(2 * np.pi * speed * (np.arange(length) / sr) + phase)
+    n_fade = int(0.1 * sr)
+    if n_fade < length:
+        wave[:n_fade] *= np.linspace(0, 1, n_fade)
+    return wave
+
+
+def _smoothed_noise(length, sr, speed, ctx):
+    """legacy-RNG normal draws, Gaussian-smoothed (sigma = sr / (6 speed) samples, on the device), peak-normalised."""
+    noise = gaussian_filter1d(np.random.randn(length), sigma=sr / (speed * 6), ctx=ctx)
+    noise /= np.max(np.abs(noise) + 1e-6)
+    return noise
+
+
 def create_volume_jitter(length, sr, speed=6.0, strength=0.1, seed=None, vibrato=False, ctx=None):
-    """gf.create_volume_jitter (GOOFER.py:638-660): a sinusoid with a 0.1 s fade-in (vibrato) or smoothed legacy-RNG noise
-    (the Gaussian FIR of sigma = sr / (6 speed) runs on the device), as 1 + x * strength."""
+    """gf.create_volume_jitter (GOOFER.py:638-660): the multiplicative volume curve 1 + strength * x of the 'sr' / 'sd' flags —
+    x a faded sinusoid (clipped to [0.5, 1.5]) or smoothed noise.  Draws come from the legacy global generator in the
+    reference's order (seed, then phase or noise)."""
     if seed is not None:
         np.random.seed(seed)
-    t = np.arange(length) / sr
     if vibrato:
-        phase = np.random.uniform(0, 2 * np.pi) if seed is not None else 0
-        noise = np.sin(2 * np.pi * speed * t + phase)
-        fade = int(0.1 * sr)
-        if fade < length:
-            noise[:fade] *= np.linspace(0, 1, fade)
-    else:
-        noise = np.random.randn(len(t))
-        noise = gaussian_filter1d(noise, sigma=sr / (speed * 6), ctx=ctx)
-        noise /= np.max(np.abs(noise) + 1e-6)
-    envelope = 1.0 + noise * strength
-    return np.clip(envelope, 0.5, 1.5) if vibrato else envelope
+        return np.clip(1.0 + _vibrato_wave(length, sr, speed, seed is not None) * strength, 0.5, 1.5)
+    return 1.0 + _smoothed_noise(len(np.arange(length)), sr, speed, ctx) * strength     # (np.arange: the reference's length rule)
 
 
 def make_mel_knots(sr, n_fft, K):
@@ -446,11 +465,9 @@ def _finish(c, out, d_mask, n, sr, kw):
         return tuple(out[k].cpu().numpy() for k in ("rec", "harm", "uv", "bre"))
     k_list = list(kw.get("rough_k_list", (2, 3, 4)))
     h_list = kw.get("rough_h_list")
-    if h_list is None:
-        h_list = [0.45, 0.28, 0.18][:len(k_list)]
-        if len(h_list) < len(k_list):
-            extra = len(k_list) - len(h_list)
-            h_list += [h_list[-1] * 0.6 ** i for i in range(1, extra + 1)]
+    if h_list is None:                                        # default partial weights: 0.45, 0.28, 0.18, then x 0.6 per further partial
+        base = (0.45, 0.28, 0.18)
+        h_list = [base[i] if i < 3 else base[2] * 0.6 ** (i - 2) for i in range(len(k_list))]
     k_list, h_list = k_list[:len(h_list)], list(h_list)[:len(k_list)]          # zip() of the reference
     alpha = float(kw.get("rough_alpha", 0.6))
     d_f0 = c.tensor(c.debug_fetch("f0")[:n])                  # f0_interp as the synthesis left it (scaled, stretched, jittered)
@@ -516,15 +533,25 @@ def _synthesize_stretched(c, d_env, f0, mask, F, params, sr, hop, phi, seed, kw)
     return _finish(c, out, d_mask, n, sr, kw)
 
 
-def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=256, phi=None, seed=None, ctx=None, **kw):
+def synthesize(env_spec, f0_interp, voicing_mask, y, sr, n_fft=1024, hop_length=256, glottal_smoothing=False,
+               stretch_factor=1.0, start_sec=None, end_sec=None, apply_brightness=True, normalize=1.0, uv_strength=0.75,
+               breath_strength=0.1, noise_transition_smoothness=100, pitch_shift=1.0, formant_shift=1.0, f0_jitter=False,
+               f0_jitter_speed=100, f0_jitter_strength=1.5, volume_jitter=False, volume_vibrato=False, volume_jitter_speed=150,
+               volume_jitter_strength_harm=50, volume_jitter_strength_breath=100, add_subharm=False, subharm_semitones=-12,
+               subharm_weight=0.5, subharm_vibrato=False, cut_subharm_below_f0=True, subharm_vibrato_rate=6.0,
+               subharm_vibrato_depth=0.1, subharm_f0_jitter=0, subharm_vibrato_delay=0.1, F1_shift=1.0, F2_shift=1.0,
+               F3_shift=1.0, F4_shift=1.0, formants=None, roughness_on=False, rough_k_list=(2, 3, 4), rough_h_list=None,
+               rough_alpha=0.6, rough_hp_fc=320.0, rough_noise_amp=0.6, rough_noise_smooth_ms=120.0, rough_alpha_slew_ms=120.0,
+               *, phi=None, seed=None, ctx=None):
     """gf.synthesize for one note on the GPU -> (reconstruct, harmonic, aper_uv, aper_bre), fp32.
 
-    ``phi`` ``[bins, T]`` injects the aperiodic branch's random phases (parity runs); otherwise the
-    device draws them from Philox keyed by ``seed`` (a fresh key per call when None, like the
-    reference's unseeded generator)."""
-    for k in _UNSUPPORTED:
-        if kw.get(k):
-            raise NotImplementedError(f"{k} is not on the device path yet (SURVEY.md §8 f)")
+    The positional order and keyword set are the reference's (GOOFER.py:971-983; ``glottal_smoothing`` is accepted and
+    unused there too); an unknown keyword raises TypeError like it does there.  Three keyword-ONLY additions:
+    ``phi`` ``[bins, T]`` injects the aperiodic branch's random phases (parity runs); otherwise the device draws them
+    from Philox keyed by ``seed`` (a fresh key per call when None, like the reference's unseeded generator); ``ctx``
+    picks the device context."""
+    kw = {k: v for k, v in locals().items() if k not in ("env_spec", "f0_interp", "voicing_mask", "y", "sr", "n_fft", "hop_length",
+                                                         "phi", "seed", "ctx")}
     c = _ctx(sr, n_fft, hop_length, ctx)
     if isinstance(env_spec, dict) and env_spec.get("mode") == "knots":
         env_spec = decode_env_from_knots(env_spec, ctx=c)

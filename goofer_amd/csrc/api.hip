@@ -259,7 +259,9 @@ struct arena {
     }
 };
 
-static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t samples, int64_t notes)
+// spectra: the one-kernel-per-step pipeline will run (complex spectra + windowed frames of the three stems in HBM: 24 KB per
+// frame); the stem walkers need none of it.  subharm: the 'sg' trackers' fp64 phase increments.
+static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t samples, int64_t notes, bool spectra = true, bool subharm = true)
 {
     size_t ldc = spec_stride(p.n_bins), ld = (p.n_bins + 3) & ~3;
     size_t b = 0;
@@ -268,15 +270,17 @@ static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t sampl
     add(frames * sizeof(int64_t));                // row_src
     add(frames * sizeof(float2));                 // per-frame (f0, mask) picks
     add(samples * sizeof(float));                 // f0 scaled
-    add(samples * sizeof(double));                // phase increments
+    if (subharm) add(samples * sizeof(double));   // phase increments
     add((samples / 2 + 16 * notes + 16) * ONSET_BYTES);
     add((samples / 2 + 16 * notes + 16) * sizeof(int32_t));   // raw onset sample indices
     add(notes * sizeof(int32_t) + 64);            // onset counts
     add(64);                                      // overflow flag
     add(samples * sizeof(float));                 // pulse
-    add(3 * frames * ldc * sizeof(float2));       // S_h, S_uv, S_br
-    add(3 * frames * (size_t)p.n_fft * sizeof(float));  // windowed time frames (three stems in the fused path)
-    add(2 * frames * ld * sizeof(float));         // env_h, env_n
+    if (spectra) {
+        add(3 * frames * ldc * sizeof(float2));       // S_h, S_uv, S_br
+        add(3 * frames * (size_t)p.n_fft * sizeof(float));  // windowed time frames (three stems in the fused path)
+    }
+    add((spectra ? 2 : 1) * frames * ld * sizeof(float));   // env_h (, env_n)
     add((samples / 4 + notes + 16) * sizeof(double));  // smoothed decimated mask
     add(2 * notes * sizeof(float) + 64);          // note_mag, note_peak
     add(2 * notes * sizeof(double) + 64);         // per-note linspace steps
@@ -373,6 +377,11 @@ int goofer_create(int device_id, goofer_ctx **out)
     if (hipSetDevice(device_id) != hipSuccess) return GOOFER_EHIP;
     goofer_ctx *c = new goofer_ctx();
     c->device = device_id;
+    // the onset-overflow word lives as long as the handle (never inside the re-carved, re-allocated scratch arena)
+    if (hipMalloc((void **)&c->ovf_flag, 64) != hipSuccess || hipMemset(c->ovf_flag, 0, 64) != hipSuccess) {
+        delete c;
+        return GOOFER_EHIP;
+    }
     *out = c;
     return GOOFER_OK;
 }
@@ -388,6 +397,7 @@ void goofer_destroy(goofer_ctx *ctx)
     if (ctx->asm_scratch) (void)hipFree(ctx->asm_scratch);
     if (ctx->mask_taps) (void)hipFree(ctx->mask_taps);
     if (ctx->warp_rows) (void)hipFree(ctx->warp_rows);
+    if (ctx->ovf_flag) (void)hipFree(ctx->ovf_flag);
     for (int i = 0; i < ctx->prof_cap * (PROF_STAGES + 1); ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
     free(ctx->prof_ev);
     for (int i = 0; ctx->prof_side && i < ctx->prof_cap * 4; ++i) (void)hipEventDestroy(ctx->prof_side[i]);
@@ -469,7 +479,8 @@ int goofer_reserve(goofer_ctx *ctx, int64_t max_frames, int64_t max_samples, int
 {
     if (!ctx) return GOOFER_EINVAL;
     if (!ctx->plan.n_fft) return goofer_fail(ctx, GOOFER_ENOPLAN, "goofer_plan first");
-    return ensure_scratch(ctx, scratch_need(ctx->plan, max_frames, max_samples, max_notes));
+    const bool walkers = ctx->stems && ctx->ola_fused && stems_supported(ctx->plan);   // else: room for the spectra of the one-kernel-per-step path
+    return ensure_scratch(ctx, scratch_need(ctx->plan, max_frames, max_samples, max_notes, !walkers, !walkers));
 }
 
 // copy one plan table to host memory (tests / debugging); which: 0 window 1 freqs 2 boost 3 bright_h
@@ -522,7 +533,9 @@ int goofer_host_gauss_rows(const double *x, int64_t rows, int T, const double *t
 }
 
 /* Synchronise the device and report what the asynchronous batch calls could not: a note whose pulse onsets did not fit its
- * onset slots (n / 2 + 16 per note — more than one pulse per two samples; the onsets beyond were dropped). */
+ * onset slots (n / 2 + 16 per note — more than one pulse per two samples; the onsets beyond were dropped).  The flag is a
+ * handle-owned word every pulse-chain launch (goofer_pulse_train, goofer_synth_batch / goofer_render_batch incl. the extra
+ * synthesis calls of the post chain) raises with atomicMax; it stays up until this call reads and clears it. */
 int goofer_check(goofer_ctx *ctx)
 {
     if (!ctx) return GOOFER_EINVAL;
@@ -530,9 +543,11 @@ int goofer_check(goofer_ctx *ctx)
     if (!ctx->ovf_flag) return GOOFER_OK;
     int32_t v = 0;
     HIP_TRY(ctx, hipMemcpy(&v, ctx->ovf_flag, sizeof(v), hipMemcpyDeviceToHost));
-    if (v != 0)
-        return goofer_fail(ctx, GOOFER_EINVAL, "note %d of the last batch has more pulse onsets than n / 2 + 16 (f0 above sr / 2?): "
-                           "the pulses beyond its onset slots were dropped", v - 1);
+    if (v != 0) {
+        HIP_TRY(ctx, hipMemset(ctx->ovf_flag, 0, sizeof(v)));        // reported once
+        return goofer_fail(ctx, GOOFER_EINVAL, "note %d of a batch since the last check has more pulse onsets than n / 2 + 16 (f0 above "
+                           "sr / 2?): the pulses beyond its onset slots were dropped", v - 1);
+    }
     return GOOFER_OK;
 }
 
@@ -693,10 +708,8 @@ int goofer_pulse_train(goofer_ctx *ctx, const float *f0, const int64_t *sample_o
     char *onsets = a.take<char>((total_samples / 2 + 16 * (size_t)n_notes + 16) * ONSET_BYTES);
     int32_t *oidx = a.take<int32_t>(total_samples / 2 + 16 * (size_t)n_notes + 16);
     int32_t *cnt = a.take<int32_t>(n_notes + 16);
-    int32_t *ovf = a.take<int32_t>(16);
-    ctx->ovf_flag = ovf;
-    if (!inc || !onsets || !oidx || !cnt || !ovf) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
-    HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), st));
+    int32_t *ovf = ctx->ovf_flag;
+    if (!inc || !onsets || !oidx || !cnt) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     return launch_pulse_train(ctx, f0, 1.0f, sample_off, n_notes, total_samples, pulse, inc, (onset_t *)onsets, oidx, cnt, ovf, st);
 }
 
@@ -1116,31 +1129,34 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     const bool sub_jit = sub_on && b->noise_subharm != nullptr;
     const size_t jit_bytes = ((jit_f0 || jit_vol || sub_jit) ? (3 * (size_t)N * sizeof(double) + 3 * 256 * (size_t)n + 8192) : 0) +
                              (sub_on ? ((size_t)N * (sizeof(double) + sizeof(float)) + 3 * 256 * (size_t)n + 8192) : 0);
-    int rc = ensure_scratch(ctx, scratch_need(p, F, N, n) + (size_t)F * (ld - ((p.n_bins + 3) & ~3)) * 2 * sizeof(float) + jit_bytes);
+    // which pipeline will run decides what the arena holds (the same predicate as `stem_path` below)
+    const bool walkers = ctx->stems && ctx->ola_fused && (p.hop % 2 == 0) && stems_supported(p) && !sub_on && !jit_vol;
+    int rc = ensure_scratch(ctx, scratch_need(p, F, N, n, !walkers, sub_on) + (size_t)F * (ld - ((p.n_bins + 3) & ~3)) * 2 * sizeof(float) + jit_bytes);
     if (rc) return rc;
     arena a{(char *)ctx->scratch, ctx->scratch_bytes, 0};
     int *frame_note = a.take<int>(F);
     int64_t *row_src = a.take<int64_t>(F);
     float2 *picks = a.take<float2>(F);
     float *f0s = a.take<float>(N);
-    double *inc = a.take<double>(N);                          // increments of the sub-harmonic trackers ('sg') only
+    double *inc = sub_on ? a.take<double>(N) : nullptr;       // increments of the sub-harmonic trackers ('sg') only
     char *onsets = a.take<char>((N / 2 + 16 * (size_t)n + 16) * ONSET_BYTES);
     int32_t *onset_idx = a.take<int32_t>(N / 2 + 16 * (size_t)n + 16);
     int32_t *onset_cnt = a.take<int32_t>(n + 16);
-    int32_t *ovf = a.take<int32_t>(16);
+    int32_t *ovf = ctx->ovf_flag;
     float *pulse = a.take<float>(N);
-    float2 *S_h = a.take<float2>((size_t)F * ldc);
-    float2 *S_uv = a.take<float2>((size_t)F * ldc);
-    float2 *S_br = a.take<float2>((size_t)F * ldc);
-    float *frames = a.take<float>((size_t)F * p.n_fft);
-    float *frames_u = a.take<float>((size_t)F * p.n_fft);
-    float *frames_b = a.take<float>((size_t)F * p.n_fft);
+    const size_t spec_n = walkers ? 0 : (size_t)F * ldc, frame_n = walkers ? 0 : (size_t)F * p.n_fft;
+    float2 *S_h = a.take<float2>(spec_n);
+    float2 *S_uv = a.take<float2>(spec_n);
+    float2 *S_br = a.take<float2>(spec_n);
+    float *frames = a.take<float>(frame_n);
+    float *frames_u = a.take<float>(frame_n);
+    float *frames_b = a.take<float>(frame_n);
     float *env_h = a.take<float>((size_t)F * ld);
-    float *env_n = a.take<float>((size_t)F * ld);
+    float *env_n = a.take<float>(walkers ? 0 : (size_t)F * ld);
     double *short_s = a.take<double>(N / 4 + n + 16);
     float *note_mag = a.take<float>(2 * (size_t)n + 16);
     double *note_steps = a.take<double>(2 * (size_t)n + 16);
-    if (!picks || !frames_u || !frames_b || !frame_note || !row_src || !f0s || !inc || !onsets || !onset_idx || !onset_cnt || !ovf || !pulse || !S_h || !S_uv || !S_br || !frames ||
+    if (!picks || !frames_u || !frames_b || !frame_note || !row_src || !f0s || (sub_on && !inc) || !onsets || !onset_idx || !onset_cnt || !ovf || !pulse || !S_h || !S_uv || !S_br || !frames ||
         !env_h || !env_n || !short_s || !note_mag || !note_steps)
         return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     float *note_peak = note_mag + n;
@@ -1165,9 +1181,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     }
     {
         const void *ptrs[] = {frame_note, row_src, f0s, pulse, S_h, S_uv, S_br, frames, env_h, env_n, short_s, note_mag, note_peak, onset_cnt};
-        size_t bytes[] = {F * sizeof(int), F * sizeof(int64_t), N * sizeof(float), N * sizeof(float), (size_t)F * ldc * sizeof(float2),
-                          (size_t)F * ldc * sizeof(float2), (size_t)F * ldc * sizeof(float2), (size_t)F * p.n_fft * sizeof(float),
-                          (size_t)F * ld * sizeof(float), (size_t)F * ld * sizeof(float), (N / 4 + n) * sizeof(double),
+        size_t bytes[] = {F * sizeof(int), F * sizeof(int64_t), N * sizeof(float), N * sizeof(float), spec_n * sizeof(float2),
+                          spec_n * sizeof(float2), spec_n * sizeof(float2), frame_n * sizeof(float),
+                          (size_t)F * ld * sizeof(float), walkers ? 0 : (size_t)F * ld * sizeof(float), (N / 4 + n) * sizeof(double),
                           n * sizeof(float), n * sizeof(float), n * sizeof(int32_t)};
         for (int i = 0; i < 14; ++i) { ctx->dbg_ptr[i] = ptrs[i]; ctx->dbg_bytes[i] = bytes[i]; }
     }
@@ -1211,7 +1227,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // map kernels, instead of starting when this call's first kernel is reached in stream order.
     // Stem-split walkers (stems.hip): no spectra in HBM.  The legacy kernels stay for the other geometries, for the
     // volume-jitter / sub-harmonic layers (which edit the stems or the pulse train between the steps) and as the A/B path.
-    const bool stem_path = ctx->stems && ola_one && stems_supported(p) && !sub_on && !jit_vol;
+    const bool stem_path = walkers;                           // (== ctx->stems && ola_one && stems_supported(p) && !sub_on && !jit_vol)
     if (pev) ctx->prof_stems = stem_path;
     const bool side_on = ctx->overlap && ola_one && !sub_on;
     const bool early = side_on && !jit_f0 && ctx->early_req && ctx->early_f0 == b->f0 && ctx->side != nullptr;
@@ -1233,7 +1249,6 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     if (early) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_entry, 0));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_f0, 0));
-        HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), ctx->side));
         if (maps_side) HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), ctx->side));
         if (!f0_alias) {
             hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, ctx->side, b->f0, b->sample_off, n, N,
@@ -1241,8 +1256,6 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
             LAUNCH_CHECK(ctx);
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_f0s, ctx->side));
-    } else {
-        HIP_TRY(ctx, hipMemsetAsync(ovf, 0, sizeof(int32_t), st));
     }
     if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, mst))) return rc;
     if (!early && !f0_alias) {
@@ -1505,7 +1518,10 @@ int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *asmb, const goof
     ctx->warp_out = nullptr;
     ctx->warp_done = false;
     if (ctx->stems && ctx->ola_fused && ctx->overlap && stems_supported(ctx->plan) && asmb->env_out == b->env &&
-        asmb->n_notes == b->n_notes && asmb->total_out_rows == b->total_env_rows && asmb->ld == b->ld && !asmb->any_fry) {
+        asmb->n_notes == b->n_notes && asmb->total_out_rows == b->total_env_rows && asmb->ld == b->ld && !asmb->any_fry &&
+        // ... and the synthesis will take the stem path (the 'sg' layer and the volume jitter run the legacy kernels, which warp
+        // in k_harm_shape: a warped copy written here would never be read)
+        !(b->subharm_ratio > 0.0) && !(b->volume_vibrato != 0 || (b->noise_vol_h != nullptr && b->noise_vol_b != nullptr))) {
         const size_t need = (size_t)b->total_env_rows * b->ld * sizeof(float);
         if (need > ctx->warp_rows_bytes) {
             HIP_TRY(ctx, hipDeviceSynchronize());

@@ -48,7 +48,8 @@ struct goofer_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_maps = nullptr;
     // goofer_render_batch: the pulse chain forks as soon as the assembled f0 exists, not when the synthesis call starts
     hipEvent_t ev_entry = nullptr, ev_f0 = nullptr, ev_f0s = nullptr;
-    const int32_t *ovf_flag = nullptr;     // device word of the last synth batch: 1 + index of a note whose onset slots overflowed
+    int32_t *ovf_flag = nullptr;           // handle-owned device word, sticky between goofer_check calls: 1 + index (inside its batch) of a
+                                           // note whose pulse onsets overflowed their slots, written with atomicMax by every pulse-chain launch
     // goofer_render_batch, stem-split path: the assembly's frame-gather kernel also writes the rows the harmonic walker needs
     // (formant-anchored + uniform warp), into a buffer the handle owns
     const double *warp_formants = nullptr;

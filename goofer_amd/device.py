@@ -265,7 +265,12 @@ class Context:
     def smooth_mask_ds(self, mask, lengths=None, sigma: float = 100.0, fast_interp: bool = False):
         """gf.smooth_mask_ds (GOOFER.py:556-569) of fp32 device masks (a ragged batch when ``lengths`` is given)."""
         n_total = mask.numel()
-        lengths = [n_total] if lengths is None else list(lengths)
+        lengths = [n_total] if lengths is None else [int(v) for v in lengths]
+        # the kernels index the mask by these lengths: a mismatch would read and write out of bounds on the device
+        if not (isinstance(mask, torch.Tensor) and mask.dtype == torch.float32 and mask.is_contiguous() and mask.device == self.device):
+            raise ValueError("smooth_mask_ds expects a contiguous fp32 tensor on this context's device")
+        if any(v < 0 for v in lengths) or sum(lengths) != n_total:
+            raise ValueError(f"smooth_mask_ds: the lengths sum to {sum(lengths)}, the mask has {n_total} samples")
         off = self.tensor(np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64))
         out = torch.empty(n_total, dtype=torch.float32, device=self.device)
         self._check(self.lib.goofer_smooth_mask_ds(self.h, _ptr(mask), _ptr(off), len(lengths), n_total, float(sigma),

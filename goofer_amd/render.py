@@ -70,6 +70,9 @@ class Source:
             a = np.asarray(v)
             if a.ndim != 1 or not np.issubdtype(a.dtype, np.number):
                 raise ValueError(f"bad features: formant track {k!r} is not a numeric vector")
+        for k in (1, 2, 3, 4):                                # the planner takes F1..F4 by position in the sorted key list:
+            if k not in formants:                             # a dict without one of them would silently shift the others
+                raise KeyError(k)                             # (gf.synthesize raises the same KeyError, GOOFER.py:1000)
         return src
 
 

@@ -216,3 +216,20 @@ def random_flags(rng) -> str:
     keys = list(pool)
     chosen = rng.choice(len(keys), size=int(rng.integers(3, 9)), replace=False)
     return "".join(f"{keys[i]}{pool[keys[i]]()}" for i in sorted(chosen))
+
+
+def with_unvoiced_gaps(src: dict, share: float, seed: int) -> dict:
+    """A copy of a synthetic source with `share` of its samples unvoiced in 50 ms gaps at seeded random places (mask and f0
+    zeroed): consonant-like holes.  The BASELINE notes are fully voiced behind their offset; this is the variant bench.py and
+    scripts/voicing_sweep.py time beside them, because the noise walker skips the transform of a stem whose gain is exactly zero."""
+    out = dict(src)
+    n = src["y_len"]
+    m, f = src["mask"].copy(), src["f0"].copy()
+    rng = np.random.default_rng(seed + 7)
+    gap = max(1, int(0.05 * src["sr"]))
+    for _ in range(int(round(share * n / gap))):
+        a0 = int(rng.integers(0, max(1, n - gap)))
+        m[a0:a0 + gap] = 0.0
+        f[a0:a0 + gap] = 0.0
+    out["mask"], out["f0"] = m, f
+    return out

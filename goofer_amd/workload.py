@@ -146,7 +146,7 @@ class SamplerWorkload:
     Planning happens once on the host; plans, tables and sources stay resident in HBM; ``step()`` is the
     device work of one render of the whole batch (assemble + synthesize + mix)."""
 
-    def __init__(self, ctx: Context, config: int, note_ids):
+    def __init__(self, ctx: Context, config: int, note_ids, unvoiced_share: float = 0.0):
         from .render import Renderer, Source
         from . import sampler as S
         self.geo = syn.config_geometry(config)
@@ -157,6 +157,8 @@ class SamplerWorkload:
         jobs = []
         for i in note_ids:
             src, req, phi_seed = syn.config_note(config, int(i))
+            if unvoiced_share > 0.0:
+                src = syn.with_unvoiced_gaps(src, unvoiced_share, 1000 + int(i))
             self.raw.append((src, req, phi_seed))
             jobs.append((Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]),
                          S.decode_request(*syn.request_args(req))))

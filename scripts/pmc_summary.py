@@ -9,6 +9,9 @@ for fn in files:
             name = row.get("Kernel_Name", "")
             short = name.split("(")[0].split("<")[0].replace("void ", "")
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from goofer_amd.build import source_hash
+print("# csrc_sha256=" + source_hash())
 for k in sorted(acc):
     if not k.startswith("k_"):
         continue

@@ -27,7 +27,9 @@ for which, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for k, v in vals.items():
         res[k][key + "_KB"] = sum(v) / len(v)
         res[k]["launches_sampled"] = len(v)
-meta = {"workload": bench["config"]["workload"], "frames": bench["config"]["frames_per_gpu"], "samples": bench["config"]["samples_per_gpu"],
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from goofer_amd.build import source_hash
+meta = {"csrc_sha256": source_hash(), "workload": bench["config"]["workload"], "frames": bench["config"]["frames_per_gpu"], "samples": bench["config"]["samples_per_gpu"],
         "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (only --kernel-trace beside them); per-launch means in KB",
         "correction": "gfx950: FETCH_SIZE reports half of a coalesced streaming read (MI355X_MICROARCH.md, HBM) -> bytes = (2*FETCH + WRITE)*1024"}
 # HBM bytes of one step (= one goofer_render_batch).  The profiled command also times the assembly alone and the stand-alone

@@ -37,23 +37,8 @@ for rep in range(2):
     print(f"fully voiced, skipping off: {time_step(wl):.3f} ms")
     ctx.set_option("skip_zero", 1)
 del wl
-orig = syn.make_source
 for share in (0.1, 0.2, 0.4):
-    def gapped(seed, *a, _s=share, **k):
-        src = orig(seed, *a, **k)
-        n = src["y_len"]
-        m, f = src["mask"].copy(), src["f0"].copy()
-        rng = np.random.default_rng(seed + 7)
-        gap = max(1, int(0.05 * src["sr"]))                       # 50 ms gaps
-        for _ in range(int(round(_s * n / gap))):
-            a0 = int(rng.integers(0, max(1, n - gap)))
-            m[a0:a0 + gap] = 0.0
-            f[a0:a0 + gap] = 0.0
-        src["mask"], src["f0"] = m, f
-        return src
-    syn.make_source = gapped
-    wl = SamplerWorkload(ctx, 3, list(range(notes)))
-    syn.make_source = orig
+    wl = SamplerWorkload(ctx, 3, list(range(notes)), unvoiced_share=share)
     voiced = float((wl.prep["mask"] > 0).float().mean())
     print(f"{share:.0%} of the source unvoiced in 50 ms gaps (assembled mask {voiced:.0%} voiced): {time_step(wl):.3f} ms")
     del wl

@@ -111,6 +111,9 @@ def test_malformed_features_are_rejected_before_upload():
         Source.from_pack(src["env_pack"], src["f0"], src["mask"], {1: ["a", "b"]}, src["sr"], src["y_len"])
     with pytest.raises(ValueError):
         Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], 0)
+    no_f1 = {k: v for k, v in src["formants"].items() if k != 1}          # F2..F4 would silently take F1..F3's places
+    with pytest.raises(KeyError):
+        Source.from_pack(src["env_pack"], src["f0"], src["mask"], no_f1, src["sr"], src["y_len"])
 
 
 def test_server_binds_to_loopback_by_default_and_worker_survives_errors():

@@ -458,10 +458,14 @@ def test_index_plans_on_device(renderer):
         jobs.append((Source.from_pack(env, f0, mask, forms, sr, n), req))
         tags.append(str(tag))
     assert len(jobs) >= 45
-    _, parts = renderer.render(jobs, phi_seeds=list(range(len(jobs))), return_parts=True)
-    env_dev = parts["env"].cpu().numpy()
-    mask_dev = parts["mask"].cpu().numpy()
-    e_off, s_off = parts["env_off"], parts["sample_off"]
+    # assembly only: the probe mask counts samples, so the "f0" it gates is absurd and a synthesis of it overflows the pulse
+    # onset slots (which Context.check() now reports, as it should)
+    prep = renderer.prepare(jobs, phi_seeds=list(range(len(jobs))), trim_rows=False)
+    renderer.assemble(prep)
+    torch.cuda.synchronize()
+    env_dev = prep["env"].cpu().numpy()
+    mask_dev = prep["mask"].cpu().numpy()
+    e_off, s_off = prep["env_off"], prep["sample_off"]
     for j, tag in enumerate(tags):
         want_row = g[f"{tag}_env_row"]
         got_row = env_dev[e_off[j]:e_off[j + 1], 0].astype(np.float64)

@@ -417,3 +417,48 @@ def test_side_stream_overlap_equals_single_stream(ctx):
         ctx.set_option("overlap", 1)
     for k in a:
         assert np.array_equal(a[k], b[k].cpu().numpy()), k
+
+
+def test_onset_overflow_is_reported_after_a_batch(ctx):
+    """A note whose f0 sits above sr / 2 produces more than one pulse per two samples: its onset slots overflow, the batch
+    call (asynchronous) cannot say so, and Context.check() must — once — after the render (the flag used to be a
+    stale pointer into the scratch arena that goofer_synth_batch never set)."""
+    from goofer_amd import core
+    from goofer_amd.device import GooferError
+    sr, n = 44100, 6000
+    env = np.ones((513, 1 + n // 256), dtype=np.float32)
+    mask = np.ones(n, dtype=np.float32)
+    ok = core.synthesize(env, np.full(n, 220.0, dtype=np.float32), mask, np.empty(n, bool), sr, ctx=ctx, seed=1)
+    assert np.isfinite(ok[0]).all()
+    ctx.check()                                                 # nothing to report
+    core.synthesize(env, np.full(n, 30000.0, dtype=np.float32), mask, np.empty(n, bool), sr, ctx=ctx, seed=1)
+    with pytest.raises(GooferError, match="pulse onsets"):
+        ctx.check()
+    ctx.check()                                                 # reported once, then clear
+    core.synthesize(env, np.full(n, 220.0, dtype=np.float32), mask, np.empty(n, bool), sr, ctx=ctx, seed=1)
+    ctx.check()
+
+
+def test_synthesize_signature_is_the_references(ctx):
+    """Positional order and keyword set of GOOFER.py:971-983; phi / seed / ctx are keyword-only; unknown keywords raise."""
+    import inspect
+    from goofer_amd import core
+    names = list(inspect.signature(core.synthesize).parameters)
+    assert names[:11] == ["env_spec", "f0_interp", "voicing_mask", "y", "sr", "n_fft", "hop_length", "glottal_smoothing",
+                          "stretch_factor", "start_sec", "end_sec"]
+    kinds = inspect.signature(core.synthesize).parameters
+    assert all(kinds[k].kind is inspect.Parameter.KEYWORD_ONLY for k in ("phi", "seed", "ctx"))
+    n = 2000
+    env = np.ones((513, 1 + n // 256), dtype=np.float32)
+    with pytest.raises(TypeError):
+        core.synthesize(env, np.full(n, 200.0), np.ones(n), np.empty(n, bool), 44100, ctx=ctx, no_such_keyword=1)
+
+
+def test_smooth_mask_ds_rejects_mismatched_lengths(ctx):
+    m = ctx.tensor(np.ones(1000, dtype=np.float32))
+    with pytest.raises(ValueError):
+        ctx.smooth_mask_ds(m, lengths=[400, 500])
+    with pytest.raises(ValueError):
+        ctx.smooth_mask_ds(m.double())
+    out = ctx.smooth_mask_ds(m, lengths=[400, 600])
+    assert out.shape == (1000,)
