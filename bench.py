@@ -277,7 +277,11 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the skip_zero-off / 30 %-unvoiced variants of the step")
     ap.add_argument("--gather", action="store_true", help="also time the optional ragged gather of finished audio to rank 0 "
                     "(RCCL over xGMI; never part of `value`)")
+    ap.add_argument("--rehearse", action="store_true", help="dress rehearsal of the multi-rank logic WITHOUT a GPU: gloo process "
+                    "group, the same assignment / sub-batching / planning / reductions, a sleep standing in for the device step")
     args = ap.parse_args()
+    if args.rehearse:
+        return rehearse(args)
 
     import torch
     import torch.distributed as dist
@@ -503,6 +507,88 @@ def main():
                 line["host_inclusive"] = host_inclusive(wl, ctx, elapsed / args.steps)
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def rehearse(args):
+    """`bench.py --rehearse`: everything a rank does around the device work, on CPUs under gloo — the note assignment (weak:
+    note_range, fixed job: LPT over planner frame counts, notes ordered by length, sub-batches), the host set-up of every
+    sub-batch (synthetic sources, 13-argument decode, index plans: what SamplerWorkload does before its first upload), the
+    barrier / MAX-elapsed / SUM-frames reductions, the per-rank gather and the JSON line.  The device step is a sleep of
+    frames / 60e6 s.  Prints the set-up seconds of every rank, so that the first real 8-GPU run does not discover its Python
+    costs in front of the barrier.  No GPU is touched; `value` of this line means nothing."""
+    import torch
+    import torch.distributed as dist
+    from goofer_amd import sampler as S
+    from goofer_amd import synthetic as syn
+    from goofer_amd.render import Source
+    from goofer_amd.shard import assign_lpt, note_range, reduce_timing
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    geo = syn.config_geometry(args.config)
+    hop = geo["hop"]
+    job = args.job_notes > 0
+    t_setup = time.perf_counter()
+    if job:
+        est = [syn.config_note_frames(args.config, i) for i in range(args.job_notes)]
+        ids = sorted(assign_lpt(est, world)[rank], key=lambda i: (-est[i], i))
+        subs = [ids[k:k + args.sub_batch] for k in range(0, len(ids), args.sub_batch)]
+    else:
+        ids = list(note_range(rank, world, args.notes))
+        subs = [ids]
+    t_assign = time.perf_counter() - t_setup
+    sub_frames = []
+    for sub in subs:                                           # host half of SamplerWorkload.__init__ / Renderer.prepare
+        jobs = []
+        for i in sub:
+            src, req, _ = syn.config_note(args.config, int(i))
+            sobj = Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+            jobs.append((S.decode_request(*syn.request_args(req)), sobj.sr, sobj.ylen, sobj.knots.shape[1], sobj.formants))
+        plans = S.plan_notes(jobs, hop)
+        sub_frames.append(sum(1 + p.n_out // hop for p in plans))
+    setup_s = time.perf_counter() - t_setup
+    my_frames = sum(sub_frames)
+    if job:
+        assert my_frames == sum(est[i] for i in ids), "the planner and the assignment disagree on frame counts"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for f in sub_frames:
+            time.sleep(f / 60e6)
+    t1 = time.perf_counter()
+    barrier()
+    elapsed, frames_total = reduce_timing(t1 - t0, my_frames)
+    per_rank, setups = [my_frames], [setup_s]
+    if world > 1:
+        t = torch.tensor([float(my_frames), setup_s, t_assign], dtype=torch.float64)
+        allf = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allf, t)
+        per_rank = [int(round(v[0].item())) for v in allf]
+        setups = [float(v[1].item()) for v in allf]
+    if rank == 0:
+        line = {"rehearsal": True, "metric": "resynth_frames_per_sec", "value": frames_total * args.steps / elapsed, "unit": "frames/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "strong" if job else "weak", "backend": "gloo (no GPU: the device step is a sleep of frames / 60e6 s)",
+                "config": {"workload": f"BASELINE config {args.config}" + (f" as ONE fixed job of {args.job_notes} notes" if job else f", {args.notes} notes per rank"),
+                           "sub_batch": args.sub_batch, "sub_batches_rank0": len(subs)},
+                "per_rank_frames": per_rank, "imbalance": max(per_rank) / (sum(per_rank) / len(per_rank)),
+                "setup_seconds_per_rank": [round(v, 3) for v in setups],
+                "setup_note": "assignment + synthetic sources + 13-argument decode + index plans of every sub-batch, one host thread per rank; "
+                              "uploads and the first device step come on top on the GPU box"}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

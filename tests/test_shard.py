@@ -169,3 +169,30 @@ def test_frame_estimate_of_a_job_matches_the_planner():
             p = S.plan_note(S.decode_request(*syn.request_args(req)), src["sr"], src["y_len"], src["env_pack"]["knot_vals_log"].shape[1],
                             src["formants"], geo["hop"])
             assert 1 + p.n_out // geo["hop"] == syn.config_note_frames(cfg, i), (cfg, i)
+
+
+@pytest.mark.parametrize("argv", [["--config", "4", "--job-notes", "1600", "--sub-batch", "128"], ["--config", "3", "--notes", "40"]])
+def test_eight_rank_dress_rehearsal_of_bench(argv):
+    """`bench.py --rehearse` under 8 gloo ranks, launched the way the driver launches the GPU bench: assignment, sub-batching,
+    host planning, barrier + MAX/SUM reductions, per-rank gather, one JSON line from rank 0 (no GPU; the device step is a sleep)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(here, "bench.py"), "--rehearse", "--gpus", "8", "--steps", "2"] + argv
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=here)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                    # rank 0 alone prints, once
+    line = json.loads(lines[0])
+    assert line["rehearsal"] and line["n_gpus"] == 8 and len(line["per_rank_frames"]) == 8 and len(line["setup_seconds_per_rank"]) == 8
+    job = "--job-notes" in argv
+    assert line["scaling"] == ("strong" if job else "weak")
+    total = sum(line["per_rank_frames"])
+    if job:
+        assert total == sum(syn.config_note_frames(4, i) for i in range(1600)) and line["imbalance"] < 1.01
+    else:
+        assert total == sum(syn.config_note_frames(3, i) for i in range(8 * 40)) and line["imbalance"] < 1.05
+    assert abs(line["value"] - total * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
