@@ -24,6 +24,7 @@ from socketserver import ThreadingMixIn
 import numpy as np
 
 from . import sampler as S
+from . import trackers
 
 HELP = (
     "Usage:\n"
@@ -45,8 +46,9 @@ class _Pending:
 class BatchCollector:
     """Gathers concurrent render requests and runs them as one device batch."""
 
-    def __init__(self, renderer=None, window_s: float = 0.005, max_batch: int = 4096, max_sources: int = 512):
+    def __init__(self, renderer=None, window_s: float = 0.005, max_batch: int = 4096, max_sources: int = 512, tracker=None):
         self._renderer = renderer
+        self.tracker = tracker                              # f0 / formant tracker of the cold-cache path (goofer_amd.trackers.get)
         self.window_s, self.max_batch, self.max_sources = window_s, max_batch, max_sources
         self._sources = collections.OrderedDict()          # feature cache: path -> ((mtime_ns, size), Source)
         self._lock = threading.Condition()
@@ -128,9 +130,10 @@ class BatchCollector:
                     raise TypeError(f"Expected 13 arguments but got {len(p.args)}")
                 in_file, out_file = Path(p.args[0]), Path(p.args[1])
                 req = S.decode_request(*p.args[2:13])
-                feat = in_file.with_name(f"{in_file.stem}_features.goofy")
+                # cached features, or analysed from the wav and cached on the first request for a sample (SillySampler.py:415-432)
+                feat = trackers.features_path(in_file)
                 if not feat.exists():
-                    raise FileNotFoundError(f"{feat} not found (feature extraction from raw audio needs Praat)")
+                    feat = trackers.ensure_features(in_file, hop_length=self.renderer.hop, tracker=self.tracker, ctx=self.renderer.ctx)
                 src = self._source(feat)
                 jobs.append((src, req))
                 owners.append((p, out_file, src.sr))
@@ -217,8 +220,10 @@ def main(argv=None) -> int:
     try:
         if all(Path(a).suffix.lower() == ".goofy" for a in argv):
             raise NotImplementedError("the Tk voicing editor is out of scope for the GPU backend")
-        if len(argv) == 1 and Path(argv[0]).exists():
-            raise NotImplementedError("folder feature extraction needs Praat (f0 / formant tracks); run the reference's extractor")
+        if len(argv) == 1 and Path(argv[0]).exists():                # folder (or single file) feature extraction   :1252-1263
+            from .render import Renderer
+            tally = trackers.extract_folder(argv[0], ctx=Renderer().ctx)
+            return 0 if tally["failed"] == 0 else 1
         if len(argv) < 13:
             raise TypeError(f"Expected 13 arguments but got {len(argv)}")
         from .render import GooferResampler

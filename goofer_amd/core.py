@@ -358,37 +358,14 @@ def envelope_features(y, sr, n_fft=1024, hop_length=256, ctx=None):
 
 
 def extract_features(y, sr, n_fft=1024, hop_length=256, f0_min=75, f0_max=600, f0_merge_range=2, pitch_tracker=None, ctx=None):
-    """gf.extract_features (GOOFER.py:940-969).  The envelope half runs on the GPU; f0 and formant tracks come from
-    ``pitch_tracker(y, sr, hop_length, n_frames) -> (f0_track [frames], formants {1..5: [frames]})`` because the
-    reference computes them with Praat (third-party, unpinned: SURVEY §8 c) — without one this raises."""
-    if pitch_tracker is None:
-        raise NotImplementedError("f0 / formant tracking needs Praat in the reference; pass pitch_tracker= to supply the tracks")
-    env_spec, env_knots = envelope_features(y, sr, n_fft, hop_length, ctx=ctx)
-    n_frames = env_spec.shape[1]
-    f0_track, formants = pitch_tracker(np.asarray(y), sr, hop_length, n_frames)
-    f0_track = np.nan_to_num(np.asarray(f0_track, dtype=np.float64))
-    i, nfr = 0, len(f0_track)                                  # fix_f0_gaps(max_gap): bridge short zero runs (GOOFER.py:415-435)
-    fixed = f0_track.copy()
-    while i < nfr:
-        if fixed[i] == 0.0:
-            a = i
-            while i < nfr and fixed[i] == 0.0:
-                i += 1
-            gap = i - a
-            if a > 0 and i < nfr and gap <= f0_merge_range:
-                for j in range(gap):
-                    r = (j + 1) / (gap + 1)
-                    fixed[a + j] = fixed[a - 1] * (1 - r) + fixed[i] * r
-        else:
-            i += 1
-    t_f0 = np.linspace(0, len(y) / sr, num=len(fixed))
-    t_s = np.linspace(0, len(y) / sr, num=len(y))
-    inside = (t_s >= t_f0[0]) & (t_s <= t_f0[-1])
-    f0_interp = np.zeros(len(y))
-    f0_interp[inside] = np.interp(t_s[inside], t_f0, fixed)
-    f0_interp = np.clip(f0_interp, 1e-5, 2000)
-    voicing_mask = (f0_interp > f0_min).astype(float)
-    return env_spec, f0_interp, voicing_mask, formants, env_knots
+    """gf.extract_features (GOOFER.py:940-969) -> (env_spec fp64 [bins, T], f0 per sample, voicing mask, formants {1..5}, knots).
+    The envelope half runs on the GPU.  The f0 and formant tracks come from a tracker
+    ``pitch_tracker(y, sr, hop_length, n_frames) -> (f0_track [frames'], {1..5: [n_frames]})`` — the reference computes them
+    with Praat (third-party, unpinned: SURVEY §8 c, parity unpinned): ``goofer_amd.trackers`` makes the reference's own
+    parselmouth calls when that package is installed, ``GOOFER_TRACKER`` names another one, and without any this raises
+    ``trackers.TrackerUnavailable`` (a NotImplementedError).  ``f0_max`` is accepted and unused, as in the reference."""
+    from . import trackers
+    return trackers.analyse(y, sr, n_fft, hop_length, f0_min, f0_merge_range, tracker=pitch_tracker, ctx=ctx)
 
 
 # -- synthesize --------------------------------------------------------------------------------------

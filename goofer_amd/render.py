@@ -471,22 +471,25 @@ class GooferResampler:
     """``GooferResampler(in_file, out_file, pitch, velocity, flags, offset, length, consonant, cutoff, volume,
     modulation, tempo, pitch_string)`` — construction renders and writes ``out_file`` (SillySampler.py:285-413).
 
-    Needs ``<in_stem>_features.goofy`` next to the input wav (analysis of raw audio needs Praat — SURVEY §8 c).
-    wav output uses the stdlib ``wave`` module (PCM16, what soundfile's default WAV subtype writes)."""
+    Uses ``<in_stem>_features.goofy`` next to the input wav; when it is missing the wav is analysed and the cache written
+    first, like the reference does (``goofer_amd.trackers``: needs a tracker for the Praat half — parity unpinned).  The first
+    render then uses the features as cached (fp16 knots), where the reference's first render still holds the unquantised
+    envelope.  wav output uses the stdlib ``wave`` module (PCM16, what soundfile's default WAV subtype writes)."""
 
     def __init__(self, in_file, out_file, pitch, velocity, flags="", offset=0, length=1000, consonant=0, cutoff=0,
-                 volume=100, modulation=0, tempo="!120", pitch_string="AA", renderer: Renderer | None = None, seed=None):
+                 volume=100, modulation=0, tempo="!120", pitch_string="AA", renderer: Renderer | None = None, seed=None, tracker=None):
         from pathlib import Path
         from . import core
         self.in_file, self.out_file = Path(in_file), Path(out_file)
         self.request = S.decode_request(pitch, velocity, flags, offset, length, consonant, cutoff, volume, modulation, tempo,
                                         pitch_string)
-        feat = self.in_file.with_name(f"{self.in_file.stem}_features.goofy")
-        if not feat.exists():
-            raise FileNotFoundError(f"{feat} not found: feature extraction from raw audio needs Praat (not on the device path)")
+        # cached features, or — the first render of a sample — analysed now and cached (SillySampler.py:415-432): the envelope
+        # half on the GPU, the f0 / formant tracks from the tracker (goofer_amd.trackers; raises when none is available)
+        from . import trackers
+        self.renderer = renderer or Renderer()
+        feat = trackers.ensure_features(self.in_file, hop_length=self.renderer.hop, tracker=tracker, ctx=self.renderer.ctx)
         env, f0, mask, forms, sr, ylen = core.load_features(feat)
         self.source = Source.from_pack(env, f0, mask, forms, sr, ylen)
-        self.renderer = renderer or Renderer()
         if seed is None:
             seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
         self.out = self.renderer.render([(self.source, self.request)], seed=seed)[0]

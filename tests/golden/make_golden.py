@@ -650,6 +650,101 @@ def gen_post_chain():
     save("post_chain", **out)
 
 
+def gen_cold_cache():
+    """gf.extract_features end to end (GOOFER.py:940-969) with a FAKE parselmouth: the Praat half of the analysis is
+    third-party arithmetic (parity unpinned), but everything the reference does around it is its own — which calls it makes
+    with which arguments, nan_to_num + fix_f0_gaps, the per-sample interpolation / clip / voicing threshold, the formant
+    dict padded / trimmed to the STFT frame count, the envelope and its knots.  The fake returns deterministic tracks (with
+    unvoiced gaps of 1-3 frames, a NaN, leading / trailing zeros, formant values that are None or raise) and records the
+    arguments it was called with; the product's cold-cache path is tested with a stub tracker returning the same tracks."""
+    calls = {}
+
+    class _Pitch:
+        def __init__(self, freq):
+            self.selected_array = {"frequency": freq}
+
+    class _Formant:
+        def __init__(self, n, step, t0):
+            self.n, self.step, self.t0 = n, step, t0
+
+        def get_number_of_frames(self):
+            return self.n
+
+        def get_time_from_frame_number(self, k):                  # 1-based, like Praat
+            return self.t0 + (k - 1) * self.step
+
+        def get_value_at_time(self, num, t):
+            k = int(round((t - self.t0) / self.step))
+            if num == 5 and k % 7 == 3:
+                raise RuntimeError("undefined")
+            if num == 4 and k % 5 == 0:
+                return None
+            return float(num * 650.0 + 40.0 * np.sin(0.3 * k + num))
+
+    class _Sound:
+        class ToPitchMethod:
+            AC = "AC"
+
+        def __init__(self, y, sr):
+            self.y, self.sr = np.asarray(y), sr
+
+        def to_pitch(self, **kw):
+            calls["to_pitch"] = dict(kw)
+            n = int(len(self.y) / self.sr / kw["time_step"]) - 2          # Praat's frame count differs from the STFT's
+            k = np.arange(n)
+            f = 220.0 + 30.0 * np.sin(0.21 * k)
+            f[:2] = 0.0                                                    # leading zeros: no left neighbour, stay zero
+            if n > 40:
+                f[8] = 0.0                                                 # gaps of 1, 2 (bridged at max_gap 2) and 3 (kept)
+                f[14:16] = 0.0
+                f[22:25] = 0.0
+                f[30] = np.nan                                             # nan_to_num -> 0 -> a one-frame gap
+                f[-3:] = 0.0                                               # trailing zeros: no right neighbour
+            else:
+                f[4] = 0.0
+            return _Pitch(f)
+
+        def to_formant_burg(self, **kw):
+            calls["to_formant_burg"] = dict(kw)
+            n = int(len(self.y) / self.sr / kw["time_step"]) + 3           # more frames than the STFT: trimmed
+            return _Formant(n, kw["time_step"], 0.5 * kw["time_step"])
+
+    fake = types.ModuleType("parselmouth")
+    fake.Sound = _Sound
+    real = gf.parselmouth
+    gf.parselmouth = fake
+    try:
+        r = _orig_default_rng(2024)
+        sr, n = 44100, 11700
+        t = np.arange(n) / sr
+        y = (0.4 * np.sin(2 * np.pi * 220.0 * t) * (1 + 0.3 * np.sin(2 * np.pi * 3.0 * t)) + 0.05 * r.standard_normal(n))
+        env, f0i, vmask, forms, knots = gf.extract_features(y, sr)
+        out = {"y": y, "sr": np.array([sr]), "env_spec": env, "f0_interp": f0i, "voicing_mask": vmask,
+               "knot_vals_log": knots["knot_vals_log"], "hz_knots": knots["hz_knots"],
+               "knots_meta": np.array([knots["n_bins"], knots["n_fft"], knots["sr"]]),
+               "pitch_track": _Sound(y, sr).to_pitch(**calls["to_pitch"]).selected_array["frequency"],
+               "pitch_kw_names": np.array(sorted(k for k in calls["to_pitch"] if k != "method")),
+               "pitch_kw_vals": np.array([float(calls["to_pitch"][k]) for k in sorted(calls["to_pitch"]) if k != "method"]),
+               "pitch_method": np.array([str(calls["to_pitch"]["method"])]),
+               "formant_kw_names": np.array(sorted(calls["to_formant_burg"])),
+               "formant_kw_vals": np.array([float(calls["to_formant_burg"][k]) for k in sorted(calls["to_formant_burg"])])}
+        for k, v in forms.items():
+            out["formant_%d" % k] = np.asarray(v, dtype=np.float64)
+        # a short second case: fewer pitch frames than three, a track that is all zeros after the gap repair
+        y2 = y[:3000]
+        env2, f0i2, vmask2, forms2, _ = gf.extract_features(y2, sr)
+        out.update(y2_f0_interp=f0i2, y2_voicing_mask=vmask2, y2_formant_1=np.asarray(forms2[1], dtype=np.float64),
+                   y2_pitch_track=_Sound(y2, sr).to_pitch(**calls["to_pitch"]).selected_array["frequency"])
+        # fix_f0_gaps on its own, other max_gap values
+        tr = np.array([0, 0, 200, 0, 210, 0, 0, 230, 0, 0, 0, 260, 0, 0, 0, 0, 300, 0], dtype=np.float64)
+        out["gaps_in"] = tr
+        for g in (0, 1, 2, 4):
+            out["gaps_out_%d" % g] = gf.fix_f0_gaps(tr, g)
+        save("cold_cache", **out)
+    finally:
+        gf.parselmouth = real
+
+
 if __name__ == "__main__" and len(sys.argv) > 1:
     for which in sys.argv[1:]:                         # regenerate only the named groups, e.g. `make_golden.py sampler_combos`
         globals()["gen_" + which]()
@@ -666,6 +761,7 @@ elif __name__ == "__main__":
     gen_flags_pitch()
     gen_goofy_file()
     gen_post_chain()
+    gen_cold_cache()
     gen_index_plans()
     gen_sampler()
     gen_sampler_combos()

@@ -1,0 +1,178 @@
+"""The cold-cache path (goofer_amd/trackers.py): the reference's own arithmetic around the Praat tracks, against
+tests/golden/cold_cache.npz — outputs of the reference's extract_features run over a fake parselmouth (make_golden.py).
+CPU tests: gap repair, per-sample f0 / voicing, formant fitting, tracker resolution, wav reader.  GPU tests: the whole
+extract_features with a stub tracker returning the fixture's tracks, and a render from a bare wav that writes the cache."""
+import os
+import wave
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+from goofer_amd import trackers
+
+
+def _fixture_tracker(g, prefix=""):
+    """A tracker that returns the tracks the fake parselmouth gave the reference (formants re-derived the same way)."""
+    def track(y, sr, hop, n_frames):
+        n = int(len(y) / sr / (hop / sr)) + 3
+        t0, step = 0.5 * hop / sr, hop / sr
+        forms = {}
+        for num in range(1, 6):
+            vals = []
+            for k in range(n):
+                if num == 5 and k % 7 == 3:
+                    vals.append(0.0)
+                elif num == 4 and k % 5 == 0:
+                    vals.append(0.0)
+                else:
+                    kk = int(round(((t0 + k * step) - t0) / step))
+                    vals.append(float(num * 650.0 + 40.0 * np.sin(0.3 * kk + num)))
+            forms[num] = vals
+        return g[prefix + "pitch_track"], trackers.fit_formants(forms, n_frames)
+    return track
+
+
+def test_fix_f0_gaps_matches_reference():
+    g = golden("cold_cache")
+    for gap in (0, 1, 2, 4):
+        assert np.array_equal(trackers.fix_f0_gaps(g["gaps_in"], gap), g["gaps_out_%d" % gap]), gap
+    assert trackers.fix_f0_gaps(np.zeros(0), 2).size == 0
+    assert np.array_equal(trackers.fix_f0_gaps(np.zeros(5), 9), np.zeros(5))          # no neighbour on either side
+
+
+def test_per_sample_f0_and_voicing_match_reference():
+    g = golden("cold_cache")
+    sr = int(g["sr"][0])
+    f0, vm = trackers.per_sample_f0(g["pitch_track"], len(g["y"]), sr)
+    assert np.array_equal(f0, g["f0_interp"]) and np.array_equal(vm, g["voicing_mask"])
+    f0, vm = trackers.per_sample_f0(g["y2_pitch_track"], 3000, sr)
+    assert np.array_equal(f0, g["y2_f0_interp"]) and np.array_equal(vm, g["y2_voicing_mask"])
+    with pytest.raises(ValueError):
+        trackers.per_sample_f0(np.zeros(0), 100, sr)
+
+
+def test_praat_call_arguments_are_the_references():
+    """What the reference passes to parselmouth (recorded by the fake): the adapter's literals must be these."""
+    g = golden("cold_cache")
+    pk = dict(zip(g["pitch_kw_names"], g["pitch_kw_vals"]))
+    assert str(g["pitch_method"][0]) == "AC" and pk["pitch_floor"] == 75 and pk["pitch_ceiling"] == 950
+    assert abs(pk["time_step"] - 256 / 44100) < 1e-15
+    fk = dict(zip(g["formant_kw_names"], g["formant_kw_vals"]))
+    assert fk["max_number_of_formants"] == 5 and abs(fk["time_step"] - 256 / 44100) < 1e-15
+    import inspect
+    src = inspect.getsource(trackers.praat_tracker)
+    for needle in ("ToPitchMethod.AC", "pitch_floor=75", "pitch_ceiling=950", "max_number_of_formants=5", "time_step=step"):
+        assert needle in src, needle
+
+
+def test_fit_formants_pads_and_trims():
+    out = trackers.fit_formants({1: [1.0, 2.0, 3.0], 2: [5.0]}, 2)
+    assert out == {1: [1.0, 2.0], 2: [5.0, 0.0]}
+
+
+def test_tracker_resolution(monkeypatch):
+    monkeypatch.delenv("GOOFER_TRACKER", raising=False)
+    fn = lambda y, sr, hop, T: (np.zeros(T), {})                # noqa: E731
+    assert trackers.get(fn) is fn
+    trackers.register("unit-test", fn)
+    assert trackers.get("unit-test") is fn
+    monkeypatch.setenv("GOOFER_TRACKER", "goofer_amd.trackers:praat_tracker")
+    assert trackers.get() is trackers.praat_tracker
+    monkeypatch.setenv("GOOFER_TRACKER", "no-such-tracker")
+    with pytest.raises(trackers.TrackerUnavailable):
+        trackers.get()
+    monkeypatch.delenv("GOOFER_TRACKER")
+    try:
+        import parselmouth  # noqa: F401
+    except ImportError:
+        with pytest.raises(NotImplementedError):                # TrackerUnavailable is one: no Praat, no tracker named
+            trackers.get()
+        with pytest.raises(trackers.TrackerUnavailable):
+            trackers.praat_tracker(np.zeros(100), 44100, 256, 1)
+
+
+def test_wav_reader_stdlib(tmp_path):
+    x = np.clip(np.sin(np.arange(2000) * 0.05) * 0.7, -1, 1)
+    p = tmp_path / "a.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(22050)
+        inter = np.stack([x, -x * 0.5], axis=1)
+        w.writeframes(np.round(inter * 32767).astype("<i2").tobytes())
+    y, sr = trackers.read_audio(p)
+    assert sr == 22050 and y.shape == (2000,)
+    assert np.max(np.abs(y - 0.25 * x)) < 1e-4                  # channel mean
+    with pytest.raises(FileNotFoundError):
+        trackers.ensure_features(tmp_path / "missing.wav", tracker=lambda *a: None)
+
+
+@pytest.mark.gpu
+def test_extract_features_with_fixture_tracks_matches_reference():
+    torch = pytest.importorskip("torch")
+    from goofer_amd import core
+    from goofer_amd.device import Context
+    g = golden("cold_cache")
+    ctx = Context(0)
+    try:
+        sr = int(g["sr"][0])
+        env, f0, vm, forms, knots = core.extract_features(g["y"], sr, pitch_tracker=_fixture_tracker(g), ctx=ctx)
+        assert env.shape == g["env_spec"].shape
+        assert np.max(np.abs(env - g["env_spec"])) <= 2e-6 * np.abs(g["env_spec"]).max()
+        assert np.array_equal(f0, g["f0_interp"]) and np.array_equal(vm, g["voicing_mask"])
+        for k in range(1, 6):
+            assert np.array_equal(np.asarray(forms[k], dtype=np.float64), g["formant_%d" % k]), k
+        assert np.array_equal(knots["hz_knots"], g["hz_knots"])
+        a, b = knots["knot_vals_log"].astype(np.float32), g["knot_vals_log"].astype(np.float32)
+        assert a.shape == b.shape and np.mean(a == b) > 0.995 and np.max(np.abs(a - b)) <= 0.008
+        _, f02, vm2, forms2, _ = core.extract_features(g["y"][:3000], sr, pitch_tracker=_fixture_tracker(g, "y2_"), ctx=ctx)
+        assert np.array_equal(f02, g["y2_f0_interp"]) and np.array_equal(vm2, g["y2_voicing_mask"])
+        assert np.array_equal(np.asarray(forms2[1], dtype=np.float64), g["y2_formant_1"])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_render_from_a_bare_wav_writes_the_cache(tmp_path):
+    """No .goofy beside the wav: the first render analyses the wav (GPU envelope + stub tracker), writes a .goofy the
+    reference-format reader loads back, and renders from it; the second render finds the cache (the tracker is not called)."""
+    torch = pytest.importorskip("torch")
+    from goofer_amd import core
+    from goofer_amd import synthetic as syn
+    from goofer_amd.device import Context
+    from goofer_amd.render import GooferResampler, Renderer
+    g = golden("cold_cache")
+    sr = int(g["sr"][0])
+    y = np.tile(g["y"], 3)                                       # 0.8 s
+    wav = tmp_path / "voice.wav"
+    with wave.open(str(wav), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr)
+        w.writeframes(np.round(np.clip(y, -1, 1) * 32767).astype("<i2").tobytes())
+    calls = []
+
+    def tracker(yy, s, hop, T):
+        calls.append(len(yy))
+        f = np.full(T - 2, 220.0)
+        f[:3] = 0.0
+        return f, {k: [600.0 * k] * (T + 1) for k in range(1, 6)}
+
+    ctx = Context(0)
+    try:
+        r = Renderer(ctx)
+        req = syn.make_request(2000, "t0g0", length_ms=300)
+        out1 = tmp_path / "o1.wav"
+        a = GooferResampler(str(wav), str(out1), *syn.request_args(req), renderer=r, seed=5, tracker=tracker)
+        feat = trackers.features_path(wav)
+        assert feat.exists() and calls == [len(y)] and not list(tmp_path.glob("*.tmp*"))
+        env, f0, mask, forms, sr2, ylen = core.load_features(feat)
+        assert sr2 == sr and ylen == len(y) and env["mode"] == "knots" and env["knot_vals_log"].shape[1] == 1 + len(y) // 256
+        assert f0.shape == (len(y),) and set(forms) == {1, 2, 3, 4} and mask[-1] == 1.0 and mask[0] == 0.0
+        assert np.isfinite(a.out).all() and np.abs(a.out).max() > 0.01
+        b = GooferResampler(str(wav), str(tmp_path / "o2.wav"), *syn.request_args(req), renderer=r, seed=5, tracker=tracker)
+        assert calls == [len(y)] and np.array_equal(a.out, b.out)                 # the cache was used
+        # folder mode: one more wav gets its cache, the existing one is skipped
+        os.link(wav, tmp_path / "second.wav") if hasattr(os, "link") else None
+        tally = trackers.extract_folder(tmp_path, tracker=tracker, ctx=ctx)
+        assert tally["skipped"] >= 1 and tally["failed"] == 0 and trackers.features_path(tmp_path / "second.wav").exists()
+    finally:
+        ctx.close()
