@@ -73,6 +73,7 @@ struct goofer_ctx {
     int walk_lds_kb = 81;         // LDS the sequential phase walk reserves per workgroup (what it uses: 32 KiB)
     int finish_lds_kb = 0;        // LDS k_note_finish reserves per workgroup (0: none) — caps the notes in flight per CU
     int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
+    int walk_npw = 0;             // notes per wave of the phase walk: 1, 2, 4; 0 = by batch size
     int maps_side = 0;            // goofer_render_batch: frame maps on the side stream in front of the pulse chain (A/B: +0.4 %, off)
     // per-context kernel state: hipFuncSetAttribute is per device, and a handle belongs to one device, so what was set /
     // queried is remembered here and never in process-wide statics

@@ -260,80 +260,122 @@ __device__ __forceinline__ int32_t wave_scan_incl(int32_t x, Op op)
     return x;
 }
 
+// The same scan inside segments of LPN consecutive lanes (16: one DPP row, 32: two rows, 64: the wave): the row-broadcast
+// steps that would carry a segment's total into the next one are left out.
+template <int LPN, typename Op>
+__device__ __forceinline__ int32_t note_scan_incl(int32_t x, Op op)
+{
+    x = op(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));   // row_shr:1
+    x = op(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));   // row_shr:2
+    x = op(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));   // row_shr:4
+    x = op(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));   // row_shr:8
+    if (LPN >= 32) x = op(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    if (LPN >= 64) x = op(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 // The plain (non-wrapping) accumulator of the pulse train, GOOFER.py:487-493, with the onset test taken off the
 // sequential chain.  After sample i the reference has recorded R_i = max(R_{i-1}, floor(phase_i)) onsets (its
-// `while phase >= next_k` loop, next_k = R + 1), so the onsets are a function of the partial sums alone.  The wave-
-// uniform walk therefore runs nothing but the dependent fp64 adds; on the way lane l keeps the phase in front of
-// sample 8l of the chunk (two v_cndmask per 8 samples, in the shadow of the adds).  The onsets of a finished chunk are
-// then extracted in parallel while the next chunk is already being walked: every lane replays its 8 additions from the
+// `while phase >= next_k` loop, next_k = R + 1), so the onsets are a function of the partial sums alone.  The
+// walk therefore runs nothing but the dependent fp64 adds; on the way a lane keeps the phase in front of its own
+// samples of the chunk (one v_cndmask per walk block, in the shadow of the adds).  The onsets of a finished chunk are
+// then extracted in parallel while the next chunk is already being walked: every lane replays its additions from the
 // phase it kept — the same additions in the same order, so the same partial sums — takes floor, and a max-scan and a
-// sum-scan across the wave give each lane R in front of its samples and the slot of its first onset.  Negative
+// sum-scan across the note's lanes give each lane R in front of its samples and the slot of its first onset.  Negative
 // increments and several onsets at one sample need no special case.
+//
+// NPW notes share a wave, 64 / NPW lanes each.  A walk instruction is one dependent add whatever the lanes hold, and with
+// one note per wave all 64 lanes held the same chain: a quarter of the wave per note runs FOUR chains on the same
+// instructions (the chunk of a note is spread over its 16 lanes, 32 samples each, and the scans stop at the 16-lane DPP
+// rows).  The chain latency — one dependent v_add_f64 per sample, 16.8 cycles — is what the kernel takes either way; what
+// shrinks is the vector-issue and LDS bandwidth it takes from the kernels running beside it (94 M -> 30 M wave
+// instructions per 1024-note batch).  The notes of a wave are walked to the longest one's length (padding adds +0.0).
+template <int NPW>
 __global__ __launch_bounds__(256) void k_pulse_onsets_scan(const float *__restrict__ f0, double sr, const int64_t *__restrict__ sample_off,
                                                            int n_notes, int32_t *__restrict__ onset_idx,
                                                            int32_t *__restrict__ onset_cnt, int32_t *__restrict__ overflow)
 {
+    constexpr int LPN = WAVE / NPW;                           // lanes per note
+    constexpr int SPL = OC / LPN;                             // samples of a chunk per lane
+    constexpr int BPL = SPL / OB > 0 ? SPL / OB : 1;          // walk blocks per lane (NPW = 4: 2), or lanes per block (NPW = 1: 2)
+    static_assert(NPW == 1 || NPW == 2 || NPW == 4, "a note's lanes are whole DPP rows");
     extern __shared__ __align__(16) unsigned char smem[];
     __builtin_amdgcn_s_setprio(3);                            // see k_pulse_onsets_wrap
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int note = blockIdx.x * 4 + wv;
-    if (note >= n_notes) return;                              // whole wave; no block barrier below
-    double (*tile)[OC] = reinterpret_cast<double (*)[OC]>(smem) + 2 * wv;
+    const int sub = lane / LPN, ln = lane % LPN;              // which note of the wave, lane inside the note
+    // a workgroup is 4 / NPW waves = four notes either way: the same 32 KiB of tiles per workgroup (and, with the launcher's
+    // padded LDS request, one workgroup per CU)
+    const int group = blockIdx.x * (4 / NPW) + wv;
+    const int note_raw = group * NPW + sub;
+    if (__builtin_amdgcn_readfirstlane(group * NPW) >= n_notes) return;   // whole wave; no block barrier below
+    const bool live = note_raw < n_notes;
+    const int note = live ? note_raw : n_notes - 1;
+    // [buffer][note of the wave][OC] increments
+    double *tiles = reinterpret_cast<double *>(smem) + (size_t)wv * 2 * NPW * OC;
     const int64_t base = sample_off[note];
-    const int64_t n = sample_off[note + 1] - base;
+    const int64_t n = live ? sample_off[note + 1] - base : 0;
     const int64_t obase = base / 2 + 16 * (int64_t)note;
     const int32_t cap = (int32_t)((sample_off[note + 1] / 2 + 16 * (int64_t)(note + 1)) - obase);
+    // longest note of the wave: the walk's trip count
+    int64_t n_max = n;
+#pragma unroll
+    for (int o = LPN; o < WAVE; o <<= 1) {
+        const int64_t other = __shfl_xor(n_max, o, WAVE);
+        n_max = other > n_max ? other : n_max;
+    }
+    n_max = __builtin_amdgcn_readfirstlane((int)(n_max >> 32)) * (int64_t(1) << 32) + (uint32_t)__builtin_amdgcn_readfirstlane((int)n_max);
     // The increments f0[i] / sr (GOOFER.py:491) are formed here, in the parallel fetch stage, instead of by a pass of their
     // own that writes 8 bytes per sample and reads them back.  With r = RN(1 / sr) the quotient correction
     // q + fma(-q, sr, x) r is the correctly rounded x / sr (Markstein), i.e. the increment the reference divides out.
     const float *__restrict__ a = f0 + base;
     const double rsr = 1.0 / sr;
     int32_t *__restrict__ out = onset_idx + obase;
-    double phase = 0.0;
-    int32_t cnt = 0;                                          // onsets recorded so far == R
+    double phase = 0.0;                                       // per lane: the chain of this lane's note
+    int32_t cnt = 0;                                          // onsets recorded so far == R (the same in all lanes of a note)
 
-    float r[8];
-    auto fetch = [&](int64_t c0) {                            // wave-uniform branch on purpose, see k_pulse_onsets_wrap
-        const int64_t s = c0 + (int64_t)lane * 8;
-        if (c0 + OC <= n) {
+    float r[SPL];
+    auto fetch = [&](int64_t c0) {
+        const int64_t s = c0 + (int64_t)ln * SPL;
+        if (__all(c0 + OC <= n)) {                            // wave-uniform branch on purpose, see k_pulse_onsets_wrap
 #pragma unroll
-            for (int k = 0; k < 8; ++k) r[k] = a[s + k];
+            for (int k = 0; k < SPL; ++k) r[k] = a[s + k];
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < SPL; ++k) {
                 const int64_t i = s + k;
-                const float v = a[i < n ? i : n - 1];
+                const float v = n > 0 ? a[i < n ? i : n - 1] : 0.f;
                 r[k] = i < n ? v : 0.f;                       // 0 / sr = +0.0: the padding leaves the phase alone
             }
         }
     };
-    // onsets of a walked chunk: t = its increments, p0 = this lane's phase in front of its 8 samples
-    auto emit = [&](const double *t, double p0, int32_t c0, int valid) {
-        int32_t m[8];
+    // onsets of a walked chunk: t = the note's increments, p0 = this lane's phase in front of its SPL samples
+    auto emit = [&](const double *t, double p0, int32_t c0, int64_t n_left) {
+        const int valid = n_left >= OC ? OC : (n_left > 0 ? (int)n_left : 0);
+        int32_t m[SPL];
         int32_t run = 0;
         double acc = p0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = lane * 8 + k;
+        for (int k = 0; k < SPL; ++k) {
+            const int i = ln * SPL + k;
             acc += t[i];
             const int32_t f = i < valid ? (int32_t)acc : 0;   // trunc == floor wherever it can raise the running max
             run = max(run, f);
             m[k] = run;
         }
-        const int32_t upto = wave_scan_incl(run, [](int32_t x, int32_t y) { return max(x, y); });
+        const int32_t upto = note_scan_incl<LPN>(run, [](int32_t x, int32_t y) { return max(x, y); });
         int32_t before = __shfl_up(upto, 1);
-        if (lane == 0) before = 0;
+        if (ln == 0) before = 0;
         const int32_t start = max(cnt, before);               // R in front of this lane's first sample
         const int32_t mine = max(run, start) - start;
-        const int32_t s = wave_scan_incl(mine, [](int32_t x, int32_t y) { return x + y; });
-        const int32_t tot = __builtin_amdgcn_readlane(s, WAVE - 1);
+        const int32_t s = note_scan_incl<LPN>(mine, [](int32_t x, int32_t y) { return x + y; });
+        const int32_t tot = __shfl(s, (lane | (LPN - 1)), WAVE);              // the note's last lane
         if (mine > 0) {
             int32_t at = cnt + s - mine, prev = start;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < SPL; ++k) {
                 const int32_t c = max(prev, m[k]);
                 for (; prev < c; ++prev, ++at)
-                    if (at < cap) out[at] = c0 + lane * 8 + k;
+                    if (at < cap) out[at] = c0 + ln * SPL + k;
             }
         }
         cnt += tot;
@@ -342,26 +384,31 @@ __global__ __launch_bounds__(256) void k_pulse_onsets_scan(const float *__restri
     fetch(0);
     int buf = 0;
     double kept = 0.0, kept_prev = 0.0;
-    for (int64_t c0 = 0; c0 < n; c0 += OC, buf ^= 1) {
-        double *t = tile[buf];
+    for (int64_t c0 = 0; c0 < n_max; c0 += OC, buf ^= 1) {
+        double *t = tiles + ((size_t)buf * NPW + sub) * OC;                  // this lane's note
+        double *t_prev = tiles + ((size_t)(buf ^ 1) * NPW + sub) * OC;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < SPL; ++k) {
             const double x = (double)r[k], q = x * rsr;
-            t[lane * 8 + k] = fma(fma(-q, sr, x), rsr, q);
+            t[ln * SPL + k] = fma(fma(-q, sr, x), rsr, q);
         }
         wave_lds_sync();
-        if (c0 + OC < n) fetch(c0 + OC);                    // in flight during the walk below
-        if (c0 > 0) emit(tile[buf ^ 1], kept_prev, (int32_t)(c0 - OC), OC);   // its stores complete during the walk as well
-        const int64_t left = n - c0;
+        if (c0 + OC < n_max) fetch(c0 + OC);                // in flight during the walk below
+        if (c0 > 0) emit(t_prev, kept_prev, (int32_t)(c0 - OC), n - (c0 - OC));   // its stores complete during the walk as well
+        const int64_t left = n_max - c0;
         // blocks are walked in pairs; a padded block adds +0.0 sixteen times and leaves the phase where it was
         const int blocks = left >= OC ? OC / OB : (int)((left + 2 * OB - 1) / (2 * OB)) * 2;
         auto walk = [&](const double (&x)[OB], int g) {
             double ps[OB];
-            kept = lane == 2 * g ? phase : kept;
+            if (NPW == 1) {                                   // two lanes per block: lane 2g in front of it, lane 2g + 1 in its middle
+                kept = ln == 2 * g ? phase : kept;
+            } else {                                          // BPL blocks per lane: lane g / BPL in front of its first one
+                kept = (g % BPL == 0 && ln == g / BPL) ? phase : kept;
+            }
             ps[0] = phase + x[0];
 #pragma unroll
             for (int k = 1; k < OB; ++k) ps[k] = ps[k - 1] + x[k];
-            kept = lane == 2 * g + 1 ? ps[OB / 2 - 1] : kept;
+            if (NPW == 1) kept = ln == 2 * g + 1 ? ps[OB / 2 - 1] : kept;
             phase = ps[OB - 1];
         };
         auto load = [&](double (&x)[OB], int g) {
@@ -385,11 +432,12 @@ __global__ __launch_bounds__(256) void k_pulse_onsets_scan(const float *__restri
         }
         kept_prev = kept;
     }
-    if (n > 0) {
-        const int64_t c_last = (n - 1) / OC * OC;
-        emit(tile[buf ^ 1], kept_prev, (int32_t)c_last, (int)(n - c_last));
+    if (n_max > 0) {
+        const int64_t c_last = (n_max - 1) / OC * OC;
+        double *t_last = tiles + ((size_t)(buf ^ 1) * NPW + sub) * OC;
+        emit(t_last, kept_prev, (int32_t)c_last, n - c_last);
     }
-    if (lane == 0) {
+    if (ln == 0 && live) {
         onset_cnt[note] = cnt < cap ? cnt : cap;
         if (cnt > cap) atomicMax(overflow, note + 1);          // reported at the next synchronising call (goofer_check)
     }
@@ -579,7 +627,12 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
     if (n_notes <= 0) return GOOFER_OK;
     if (f0_scale != 1.0f) return goofer_fail(ctx, GOOFER_EINVAL, "pulse onsets expect pre-scaled f0");
     {
-        const int blocks = (n_notes + 3) / 4;
+        // One note per wave.  Two or four per wave (option walk_npw) cut the walk's vector instructions to a half / a third —
+        // 94 M -> 30 M per 1024-note batch — and make the STEP slower (2.77 -> 2.78 / 2.89 ms, A/B in one run): a lane then
+        // replays 16 / 32 samples per chunk when the onsets are extracted, the walk takes longer, the pulse placement behind
+        // it runs further into the noise walker.  What the rest of the step feels is the walk's duration, not its issue slots.
+        const int npw = ctx->walk_npw > 0 ? ctx->walk_npw : 1;
+        const int blocks = (n_notes + 3) / 4;                  // four notes per workgroup, in 4 / npw waves
         const int per_cu = (blocks + 255) / 256;              // MI355X: 256 CUs, 160 KiB LDS each
         size_t lds = (size_t)(160 * 1024) / per_cu;
         if (lds > (size_t)ctx->walk_lds_kb * 1024) lds = (size_t)ctx->walk_lds_kb * 1024;   // 81 KiB: two of these cannot share a CU,
@@ -587,9 +640,14 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
         lds = lds / 1024 * 1024;
         const size_t need = 4 * 2 * OC * sizeof(double);      // 32 KiB actually used
         if (lds < need) lds = need;
-        if (int arc = kernel_allow_max_lds(ctx, (const void *)k_pulse_onsets_scan)) return arc;
-        hipLaunchKernelGGL(k_pulse_onsets_scan, dim3(blocks), dim3(256), lds, st, f0, (double)ctx->plan.sr, sample_off, n_notes,
-                           onset_idx, onset_cnt, overflow);
+        const void *fn = npw == 4 ? (const void *)k_pulse_onsets_scan<4> : (npw == 2 ? (const void *)k_pulse_onsets_scan<2> : (const void *)k_pulse_onsets_scan<1>);
+        if (int arc = kernel_allow_max_lds(ctx, fn)) return arc;
+        if (npw == 4)
+            hipLaunchKernelGGL(k_pulse_onsets_scan<4>, dim3(blocks), dim3(64), lds, st, f0, (double)ctx->plan.sr, sample_off, n_notes, onset_idx, onset_cnt, overflow);
+        else if (npw == 2)
+            hipLaunchKernelGGL(k_pulse_onsets_scan<2>, dim3(blocks), dim3(128), lds, st, f0, (double)ctx->plan.sr, sample_off, n_notes, onset_idx, onset_cnt, overflow);
+        else
+            hipLaunchKernelGGL(k_pulse_onsets_scan<1>, dim3(blocks), dim3(256), lds, st, f0, (double)ctx->plan.sr, sample_off, n_notes, onset_idx, onset_cnt, overflow);
         LAUNCH_CHECK(ctx);
     }
     hipLaunchKernelGGL(k_onset_finish, dim3(n_notes), dim3(64), 0, st, f0, sample_off, n_notes, (double)ctx->plan.sr, onset_idx,
