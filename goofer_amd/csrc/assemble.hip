@@ -10,6 +10,8 @@
 // One wave per row for the matrix kernels (row staged in LDS), one thread per sample for the last.
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "binops_core.h"
 
 constexpr int A_ROWS = 4;   // rows (waves) per workgroup
@@ -74,20 +76,51 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
             }
             wave_lds_sync();
         }
-        for (int b = lane; b < B; b += WAVE) {
-            double acc = 0.0;
-            if (halo) {
-                const float *x = row + (b - rad);
-                for (int j = 0; j <= 2 * rad; ++j) acc += taps[j] * (double)x[j];
-            } else {
-                for (int j = 0; j <= 2 * rad; ++j) acc += taps[j] * (double)row[reflect_index(b + j - rad, B)];
-            }
+        auto finish_bin = [&](int b, double acc) {
             double src = (double)row[b];
             double mod = p.es_mode == 1 ? acc : fmax(0.0, src + p.es_amount * (src - acc));
             tmp[b] = mod;
             s_src += src;
             s_mod += mod;
-        }
+        };
+        // Taps outside, the lane's bins inside: a tap is fetched once per row (it is a wave-uniform scalar load — inside the
+        // per-bin loop it came back for every bin and, sharing its counter with the LDS reads, serialised them) and the
+        // CHUNKS reads of a tap are independent.  Every bin still sums its products in ascending tap order.
+        auto blur_rows = [&](auto chunks_tag) {
+            constexpr int CHUNKS = decltype(chunks_tag)::value;
+            double acc[CHUNKS];
+#pragma unroll
+            for (int i = 0; i < CHUNKS; ++i) acc[i] = 0.0;
+            const float *x0 = row + lane - rad;
+            for (int j = 0; j <= 2 * rad; ++j) {
+                const double tj = taps[j];
+#pragma unroll
+                for (int i = 0; i < CHUNKS; ++i) {
+                    const int b = lane + WAVE * i;
+                    if (i < CHUNKS - 1 || b < B) acc[i] += tj * (double)x0[WAVE * i + j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CHUNKS; ++i) {
+                const int b = lane + WAVE * i;
+                if (i < CHUNKS - 1 || b < B) finish_bin(b, acc[i]);
+            }
+        };
+        const int chunks = (B + WAVE - 1) / WAVE;
+        if (halo && chunks == 17) blur_rows(std::integral_constant<int, 17>{});
+        else if (halo && chunks == 9) blur_rows(std::integral_constant<int, 9>{});
+        else if (halo && chunks == 5) blur_rows(std::integral_constant<int, 5>{});
+        else
+            for (int b = lane; b < B; b += WAVE) {
+                double acc = 0.0;
+                if (halo) {
+                    const float *x = row + (b - rad);
+                    for (int j = 0; j <= 2 * rad; ++j) acc += taps[j] * (double)x[j];
+                } else {
+                    for (int j = 0; j <= 2 * rad; ++j) acc += taps[j] * (double)row[reflect_index(b + j - rad, B)];
+                }
+                finish_bin(b, acc);
+            }
         s_src = wave_sum(s_src);
         s_mod = wave_sum(s_mod);
         const float m0 = (float)(s_src / (double)B);          // np.mean of the fp32 block row -> fp32
