@@ -419,7 +419,8 @@ const char *goofer_last_error(const goofer_ctx *ctx) { return ctx ? ctx->err : "
 int goofer_plan(goofer_ctx *ctx, int sr, int n_fft, int hop)
 {
     if (!ctx) return GOOFER_EINVAL;
-    if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) return goofer_fail(ctx, GOOFER_EINVAL, "n_fft must be 512, 1024 or 2048 (got %d)", n_fft);
+    if (n_fft != 512 && n_fft != 768 && n_fft != 1024 && n_fft != 1536 && n_fft != 2048)
+        return goofer_fail(ctx, GOOFER_EINVAL, "n_fft must be 512, 768, 1024, 1536 or 2048 (got %d)", n_fft);
     if (hop <= 0 || hop > n_fft || sr <= 0) return goofer_fail(ctx, GOOFER_EINVAL, "bad sr/hop (%d, %d)", sr, hop);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());
@@ -1221,7 +1222,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         ++stage;                                                     \
     } while (0)
 
-    const bool ola_one = ctx->ola_fused && (p.hop % 2 == 0);
+    // the fused overlap-add rings index by position mod n_fft with a mask: power-of-two transforms only (768 / 1536 take the
+    // separate irFFT + gather kernels)
+    const bool ola_one = ctx->ola_fused && (p.hop % 2 == 0) && (p.n_fft & (p.n_fft - 1)) == 0;
     unsigned fb = (unsigned)((F + 255) / 256);
     // goofer_render_batch: the assembly recorded ev_f0 right after the f0 / mask kernel.  The pulse chain (f0 scaling,
     // sequential walk, placement) then runs on the side stream from that point on, beside the envelope assembly and the

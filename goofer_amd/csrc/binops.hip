@@ -270,6 +270,8 @@ int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames,
                        formants, make_warp_grid(pl.sr, pl.n_bins), ctx->frame_picks)
     switch ((pl.n_bins + WAVE - 1) / WAVE) {
     case 5: HARM_SHAPE(5); break;
+    case 7: HARM_SHAPE(7); break;
+    case 13: HARM_SHAPE(13); break;
     case 9: HARM_SHAPE(9); break;
     case 17: HARM_SHAPE(17); break;
     default: return goofer_fail(ctx, GOOFER_EINVAL, "unsupported bin count %d", pl.n_bins);
@@ -417,6 +419,8 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
                        row_src, preblurred ? (const double *)nullptr : pl.blur175, ctx->frame_picks)
     switch ((pl.n_bins + WAVE - 1) / WAVE) {
     case 5: NOISE_SPECTRA(5); break;
+    case 7: NOISE_SPECTRA(7); break;
+    case 13: NOISE_SPECTRA(13); break;
     case 9: NOISE_SPECTRA(9); break;
     case 17: NOISE_SPECTRA(17); break;
     default: return goofer_fail(ctx, GOOFER_EINVAL, "unsupported bin count %d", pl.n_bins);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, M <= 512 ? 4 : 2) void k_rfft_frames(const flo
         float2 *row = S + f * (int64_t)ldc;
         auto split = [&](int k) {
             const float2 zk = buf[lds_pad(k)];
-            const float2 zm = buf[lds_pad((M - k) & (M - 1))];
+            const float2 zm = buf[lds_pad(k == 0 ? 0 : M - k)];
             const float2 w = (k <= M / 2) ? twh[k] : make_float2(-twh[M - k].x, twh[M - k].y);
             const float2 A = make_float2(zk.x + zm.x, zk.y - zm.y);
             const float2 B = make_float2(zk.x - zm.x, zk.y + zm.y);
@@ -261,6 +261,8 @@ int launch_rfft_frames_mapped(goofer_ctx *ctx, const float *x, const int64_t *sa
     case 512: return rfft_impl<256>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
     case 1024: return rfft_impl<512>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
     case 2048: return rfft_impl<1024>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
+    case 768: return rfft_impl<384>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
+    case 1536: return rfft_impl<768>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
     }
     return goofer_fail(ctx, GOOFER_EINVAL, "unsupported n_fft %d", ctx->plan.n_fft);
 }
@@ -283,6 +285,8 @@ int launch_irfft_frames(goofer_ctx *ctx, const float2 *S, int ldc, int64_t total
     case 512: return irfft_impl<256>(ctx, S, ldc, total_frames, frames, st);
     case 1024: return irfft_impl<512>(ctx, S, ldc, total_frames, frames, st);
     case 2048: return irfft_impl<1024>(ctx, S, ldc, total_frames, frames, st);
+    case 768: return irfft_impl<384>(ctx, S, ldc, total_frames, frames, st);
+    case 1536: return irfft_impl<768>(ctx, S, ldc, total_frames, frames, st);
     }
     return goofer_fail(ctx, GOOFER_EINVAL, "unsupported n_fft %d", ctx->plan.n_fft);
 }

@@ -166,6 +166,43 @@ template <> struct dft<16> {
     }
 };
 
+// Sizes with a factor 3 (n_fft 768 / 1536: M = 384 / 768 = 64 x 6 / 64 x 12): the first pass is a 6- or 12-point DFT, written
+// as the plain sum over a table of the twelfth roots of unity (R^2 complex products: these sizes are entry-point
+// conveniences — gf.synthesize / stft / istft take any n_fft, GOOFER.py:972 — not the hot geometry).
+template <int R>
+__device__ __forceinline__ void dft_direct(float2 *v)
+{
+    static_assert(12 % R == 0, "roots taken from the W12 table");
+    const float2 w12[12] = {{1.f, 0.f}, {0.86602540378443865f, -0.5f}, {0.5f, -0.86602540378443865f}, {0.f, -1.f},
+                            {-0.5f, -0.86602540378443865f}, {-0.86602540378443865f, -0.5f}, {-1.f, 0.f},
+                            {-0.86602540378443865f, 0.5f}, {-0.5f, 0.86602540378443865f}, {0.f, 1.f},
+                            {0.5f, 0.86602540378443865f}, {0.86602540378443865f, 0.5f}};
+    float2 y[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        float2 acc = v[0];
+#pragma unroll
+        for (int n = 1; n < R; ++n) {
+            const int e = ((n * t) % R) * (12 / R);
+            const float2 p = (e == 0) ? v[n] : cmul(v[n], w12[e]);
+            acc = cadd(acc, p);
+        }
+        y[t] = acc;
+    }
+#pragma unroll
+    for (int t = 0; t < R; ++t) v[t] = y[t];
+}
+template <> struct dft<6> {
+    __device__ __forceinline__ static void run(float2 *v) { dft_direct<6>(v); }
+};
+template <> struct dft<12> {
+    __device__ __forceinline__ static void run(float2 *v) { dft_direct<12>(v); }
+};
+
+// index into the M-entry twiddle table: products t k STEP of a radix-8 pass stay below 7 M / 8, so no wrap is ever taken
+// (the mask only documents the power-of-two sizes)
+template <int M> __device__ __forceinline__ constexpr int tw_wrap(int i) { return (M & (M - 1)) == 0 ? (i & (M - 1)) : i; }
+
 __host__ __device__ __forceinline__ constexpr int lds_pad(int i) { return i + (i >> 5); }
 
 template <int M> struct fft_cfg {
@@ -184,7 +221,7 @@ __device__ __forceinline__ void radix8_pass(float2 *buf, const float2 *tw, int l
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         int b = lane + WAVE * u;
-        if (NB >= WAVE || b < NB) {
+        if (NB % WAVE == 0 || b < NB) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) v[u][t] = buf[lds_pad(b + t * NB)];
         }
@@ -193,12 +230,12 @@ __device__ __forceinline__ void radix8_pass(float2 *buf, const float2 *tw, int l
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         int b = lane + WAVE * u;
-        if (NB >= WAVE || b < NB) {
+        if (NB % WAVE == 0 || b < NB) {
             int k = b % NS;
             // twiddle exp(-2 pi i t k / (8 NS)) = tw[t * k * (M / (8 NS))]
             constexpr int STEP = M / (8 * NS);
 #pragma unroll
-            for (int t = 1; t < 8; ++t) v[u][t] = cmul(v[u][t], tw[(t * k * STEP) & (M - 1)]);
+            for (int t = 1; t < 8; ++t) v[u][t] = cmul(v[u][t], tw[tw_wrap<M>(t * k * STEP)]);
             dft<8>::run(v[u]);
             int j0 = (b / NS) * NS * 8 + k;
 #pragma unroll
@@ -243,7 +280,7 @@ __device__ __forceinline__ void wave_fft_keep(float2 *v, float2 *buf, const floa
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] = buf[lds_pad(b + t * NB)];
 #pragma unroll
-        for (int t = 1; t < 8; ++t) x[t] = cmul(x[t], tw[(t * b) & (M - 1)]);    // NS = M/8: exp(-2 pi i t b / M)
+        for (int t = 1; t < 8; ++t) x[t] = cmul(x[t], tw[tw_wrap<M>(t * b)]);    // NS = M/8: exp(-2 pi i t b / M)
         dft<8>::run(x);
 #pragma unroll
         for (int t = 0; t < 8; ++t) out[u + PER * t] = x[t];
@@ -384,7 +421,7 @@ __device__ __forceinline__ void rfft_split(const float2 *buf, const float2 *twh,
     for (int r = 0; r < R; ++r) {
         int k = lane + WAVE * r;
         float2 zk = buf[lds_pad(k)];
-        float2 zm = buf[lds_pad((M - k) & (M - 1))];
+        float2 zm = buf[lds_pad(k == 0 ? 0 : M - k)];
         float2 w = (k <= M / 2) ? twh[k] : make_float2(-twh[M - k].x, twh[M - k].y);
         float2 A = make_float2(zk.x + zm.x, zk.y - zm.y);
         float2 B = make_float2(zk.x - zm.x, zk.y + zm.y);

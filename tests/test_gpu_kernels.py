@@ -383,3 +383,48 @@ def test_smooth_mask_ds_vs_reference(ctx):
             want = R.smooth_mask(x, sigma, 4)
             assert np.max(np.abs(a[o:o + n] - want)) < 1e-7, (n, sigma)
             o += n
+
+
+@pytest.mark.parametrize("n_fft,hop", [(768, 192), (1536, 384), (768, 100), (1536, 96)])
+def test_transform_sizes_with_a_factor_three(ctx, n_fft, hop):
+    """gf.stft / istft / synthesize take any n_fft (GOOFER.py:355, 392, 972).  Beside the powers of two the device path has
+    768 and 1536 (M = 384 / 768 = 64 lanes x a 6- / 12-point first pass): spectra, inverse + overlap-add and the whole
+    synthesis against the oracle (numpy pocketfft at those sizes)."""
+    from goofer_amd import core
+    from oracle import goofer_ref as R
+    sr = 44100
+    rng = np.random.default_rng(n_fft + hop)
+    lens = [5000, 3, n_fft - 1, 2 * n_fft + 17]
+    win = R.sqrt_hann(n_fft)
+    ctx.plan(sr, n_fft, hop)
+    xs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    Ts = [1 + n // hop for n in lens]
+    S = ctx.rfft_frames(ctx.tensor(np.concatenate(xs)), _off(ctx, lens), _off(ctx, Ts), sum(Ts)).cpu().numpy()
+    o = 0
+    for x, T in zip(xs, Ts):
+        ref = R.stft(x, n_fft, hop, win).T
+        assert ref.shape == (T, n_fft // 2 + 1)
+        assert rel_rms(S[o:o + T], ref) < 6e-7, (n_fft, hop, len(x))
+        o += T
+        if T < 2:
+            continue                                          # a one-frame spectrum inverts to zero samples
+        y = core.istft(ref.T, hop_length=hop, sr=sr, ctx=ctx)
+        y_ref = R.istft(ref.T, hop, win)
+        assert y.shape == y_ref.shape and rms_err(y, y_ref) < 4e-7 * max(1.0, float(np.abs(y_ref).max())), (n_fft, hop, len(x))
+    # gf.synthesize at this geometry, injected phases
+    n = 6000
+    B, T = n_fft // 2 + 1, 1 + n // hop
+    f = np.arange(B) * (sr / n_fft)
+    env = (np.exp(-f / 3000.0)[:, None] * (1.0 + 0.2 * np.sin(np.arange(T) / 5.0))[None, :]).astype(np.float32)
+    f0 = (200.0 + 20.0 * np.sin(np.arange(n) / 900.0)).astype(np.float32)
+    mask = np.ones(n, dtype=np.float32)
+    mask[:700] = 0.0
+    f0 = f0 * mask
+    phi = rng.uniform(0.0, 2.0 * np.pi, size=(B, T)).astype(np.float32)
+    forms = {k: np.full(T, 600.0 * k) for k in (1, 2, 3, 4)}
+    kw = dict(n_fft=n_fft, hop_length=hop, formants=forms, F1_shift=1.2, formant_shift=0.9)
+    ref = R.synthesize(env, f0.astype(np.float64), mask, np.empty(n, bool), sr, phi=phi, **kw)
+    got = core.synthesize(env, f0, mask, np.empty(n, bool), sr, phi=phi, ctx=ctx, **kw)
+    for a, b, name in zip(got, ref, ("rec", "harm", "uv", "bre")):
+        assert rms_err(a, b) < 2e-5, (n_fft, hop, name, rms_err(a, b))
+    ctx.plan(44100, 1024, 256)
