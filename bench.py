@@ -394,16 +394,19 @@ def main():
     variants = None
     if world == 1 and not job and not args.no_variants:
         def timed(w, k):
-            for _ in range(3):
-                w.step()
-            torch.cuda.synchronize()
-            v0, v1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            v0.record()
-            for _ in range(k):
-                w.step()
-            v1.record()
-            torch.cuda.synchronize()
-            return v0.elapsed_time(v1) / k
+            best = float("inf")
+            for _ in range(2):                                 # the better of two passes (a first pass after a change of option /
+                for _ in range(3):                             # workload has been seen to run a third slower once)
+                    w.step()
+                torch.cuda.synchronize()
+                v0, v1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                v0.record()
+                for _ in range(k):
+                    w.step()
+                v1.record()
+                torch.cuda.synchronize()
+                best = min(best, v0.elapsed_time(v1) / k)
+            return best
         ctx.set_option("skip_zero", 0)
         ms_off = timed(wl, args.steps)
         ctx.set_option("skip_zero", 1)

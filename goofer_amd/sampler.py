@@ -572,16 +572,16 @@ def _plan_tracks(g: NotePlan, tracks: list):
     want_f, T_target, n_pre_f, vel = g.extra["want_f"], g.extra["T_target"], g.extra["n_pre_f"], g.extra["vel"]
     T_env = g.tap_idx.shape[0]
     n_notes = tracks[0].shape[0] if tracks else 0
-    fm = []
-    for src in tracks:
-        src = np.asarray(src)
+    def recipe(src):
+        """slice / loop / pad / velocity-stretch along the LAST axis of src ([..., T_src]); leading axes ride along."""
         if req.reverse:
-            src = src[:, ::-1]
-        pre_t = src[:, slice(seg["start_frame"], seg["consonant_frame"])]
-        tr = np.asarray(src[:, slice(seg["consonant_frame"], seg["end_frame"])], dtype=np.float32)
-        L = tr.shape[1]
+            src = src[..., ::-1]
+        pre_t = src[..., slice(seg["start_frame"], seg["consonant_frame"])]
+        tr = np.asarray(src[..., slice(seg["consonant_frame"], seg["end_frame"])], dtype=np.float32)
+        L = tr.shape[-1]
+        lead = src.shape[:-1]
         if L == 0:
-            lp = np.zeros((n_notes, want_f), dtype=np.float32)
+            lp = np.zeros(lead + (want_f,), dtype=np.float32)
         elif req.loop_mode == "stretch":
             factor = want_f / float(L)
             if factor == 1.0:
@@ -591,22 +591,28 @@ def _plan_tracks(g: NotePlan, tracks: list):
                 lp = _interp_rows(np.linspace(0, 1, L), tr, np.linspace(0, 1, n_new)).astype(np.float32)
         else:
             reps, rem = want_f // L, want_f % L
-            tile = (tr + tr[:, ::-1]) * 0.5 if req.loop_mode == "avg" else tr
-            lp = np.tile(tile, (1, reps))
+            tile = (tr + tr[..., ::-1]) * 0.5 if req.loop_mode == "avg" else tr
+            lp = np.tile(tile, (1,) * len(lead) + (reps,))
             if rem > 0:
-                lp = np.concatenate([lp, tile[:, :rem]], axis=1)
+                lp = np.concatenate([lp, tile[..., :rem]], axis=-1)
             lp = lp.astype(np.float32)
-        f = np.concatenate([pre_t, lp], axis=1)
-        fm.append(_fit_len(f, T_target) if f.shape[1] else np.zeros((n_notes, 0)))
-    if g.vel_active:
-        for k in range(len(fm)):
-            Lk = fm[k].shape[1]
+        f = np.concatenate([pre_t, lp], axis=-1)
+        f = _fit_len(f, T_target) if f.shape[-1] else np.zeros(lead + (0,))
+        if g.vel_active:
+            Lk = f.shape[-1]
             if Lk > 1:
-                f = _interp_rows(np.arange(Lk, dtype=np.float64), np.asarray(fm[k], dtype=np.float64),
-                                 _prefix_positions(Lk, n_pre_f, vel))
+                f = _interp_rows(np.arange(Lk, dtype=np.float64), np.asarray(f, dtype=np.float64), _prefix_positions(Lk, n_pre_f, vel))
             else:
-                f = np.asarray(fm[k], dtype=np.float64)
-            fm[k] = _fit_len(f, T_env) if f.shape[1] else f
+                f = np.asarray(f, dtype=np.float64)
+            f = _fit_len(f, T_env) if f.shape[-1] else f
+        return f
+
+    arrs = [np.asarray(t) for t in tracks]
+    if arrs and all(a.shape == arrs[0].shape and a.dtype == arrs[0].dtype for a in arrs):
+        # the usual case: F1..F4(5) of a source have one length — one pass over [formants, notes, frames] instead of one per formant
+        fm = list(recipe(np.stack(arrs)))
+    else:
+        fm = [recipe(a) for a in arrs]
     # canon + formant-strength tracks   :791-806 (canon uses the PRE-velocity frame count)
     canon = []
     for v in fm:
