@@ -357,7 +357,7 @@ template <typename T> static int upload(goofer_ctx *ctx, T **dst, const std::vec
 
 static void free_plan(goofer_plan_t &p)
 {
-    void *ptrs[] = {p.window, p.win_sq, p.freqs, p.boost, p.bright_h, p.bright_b, p.tw_full, p.tw_half, p.pulse_peak, p.pulse_shape, p.blur5, p.blur175};
+    void *ptrs[] = {p.window, p.window_blur, p.blur_edge, p.win_sq, p.freqs, p.boost, p.bright_h, p.bright_b, p.tw_full, p.tw_half, p.pulse_peak, p.pulse_shape, p.blur5, p.blur175};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     p = goofer_plan_t();
@@ -454,7 +454,58 @@ int goofer_plan(goofer_ctx *ctx, int sr, int n_fft, int hop)
     gauss_taps_host(0.5, t5, r5);
     gauss_taps_host(1.75, t175, r175);
 
+    // Time-domain image of the sigma-0.5 bin blur (GOOFER.py:1143, 1171).  A circular convolution of a frame's spectrum with
+    // the symmetric taps t is a multiplication of its samples by W[n] = t2 + 2 t1 cos(2 pi n / N) + 2 t0 cos(4 pi n / N); the
+    // stem walkers fold W into the synthesis window of the frames that get the blur (stems.hip).
+    std::vector<float> winb(n_fft);
+    for (int i = 0; i < n_fft; ++i) {
+        const double a = 2.0 * PI * (double)i / (double)n_fft;
+        winb[i] = (float)((double)win[i] * (t5[2] + 2.0 * t5[1] * cos(a) + 2.0 * t5[0] * cos(2.0 * a)));
+    }
+    // ... circularly, i.e. over the spectrum's own Hermitian continuation past DC and Nyquist, where the reference's
+    // gaussian_filter1d reflects the array.  The two differ by a purely imaginary E on four bins (E_1 = i (2 t0 Im X_1 + t1 Im X_0),
+    // E_2 = i t0 Im X_0, and the mirror image below Nyquist); adding D with blur(D) = E to the spectrum in front of the transform
+    // makes the product form the reflected blur.  On imaginary, odd-continued sequences the blur is the matrix T below; its
+    // inverse decays like 0.135^k, six bins carry it to 6e-6 of E.  c1 / c2 = the first two columns of T^-1, stored per lane of
+    // the walkers' bin layout (bin k = lane + 64 i): rows 0, 1 for bins 1..6 (slot 0), rows 2, 3 for bins M-6..M-1 (last slot).
+    std::vector<float> edge(4 * 64, 0.f);
+    {
+        const int K = 6;
+        double T[6][12] = {{0}};
+        for (int k = 1; k <= K; ++k) {
+            const int dd[5] = {-2, -1, 0, 1, 2};
+            for (int q = 0; q < 5; ++q) {
+                int j = k + dd[q];
+                double sg = 1.0;
+                if (j == 0) continue;                          // Im D_0 = 0
+                if (j < 0) { j = -j; sg = -1.0; }              // odd continuation
+                if (j <= K) T[k - 1][j - 1] += sg * t5[q];
+            }
+            T[k - 1][K + k - 1] = 1.0;                          // [T | I] -> Gauss-Jordan
+        }
+        for (int c = 0; c < K; ++c) {
+            int piv = c;
+            for (int r = c + 1; r < K; ++r)
+                if (fabs(T[r][c]) > fabs(T[piv][c])) piv = r;
+            for (int j = 0; j < 2 * K; ++j) std::swap(T[c][j], T[piv][j]);
+            const double d = T[c][c];
+            for (int j = 0; j < 2 * K; ++j) T[c][j] /= d;
+            for (int r = 0; r < K; ++r) {
+                if (r == c) continue;
+                const double f = T[r][c];
+                for (int j = 0; j < 2 * K; ++j) T[r][j] -= f * T[c][j];
+            }
+        }
+        for (int j = 1; j <= K; ++j) {
+            edge[0 * 64 + j] = (float)T[j - 1][K + 0];           // c1_j at lane j (bin j)
+            edge[1 * 64 + j] = (float)T[j - 1][K + 1];           // c2_j
+            edge[2 * 64 + (64 - j)] = (float)T[j - 1][K + 0];    // bin M - j sits in lane 64 - j of the last slot
+            edge[3 * 64 + (64 - j)] = (float)T[j - 1][K + 1];
+        }
+    }
     int rc;
+    if ((rc = upload(ctx, &p.blur_edge, edge))) return rc;
+    if ((rc = upload(ctx, &p.window_blur, winb))) return rc;
     if ((rc = upload(ctx, &p.window, win))) return rc;
     if ((rc = upload(ctx, &p.win_sq, wsq))) return rc;
     if ((rc = upload(ctx, &p.freqs, freqs))) return rc;
@@ -645,6 +696,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "overlap")) { ctx->overlap = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "stems")) { ctx->stems = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "skip_zero")) { ctx->skip_zero = value != 0; return GOOFER_OK; }
+    if (!strcmp(name, "td_blur")) { ctx->td_blur = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "walk_lds_kb")) { ctx->walk_lds_kb = value < 32 ? 32 : (value > 160 ? 160 : value); return GOOFER_OK; }
     if (!strcmp(name, "finish_lds_kb")) { ctx->finish_lds_kb = value < 0 ? 0 : (value > 160 ? 160 : value); return GOOFER_OK; }
     if (!strcmp(name, "maps_side")) { ctx->maps_side = value != 0; return GOOFER_OK; }

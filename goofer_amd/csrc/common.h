@@ -15,6 +15,8 @@
 struct goofer_plan_t {
     int sr = 0, n_fft = 0, hop = 0, n_bins = 0;
     float *window = nullptr;      // [n_fft] sqrt-Hann, fp32                      GOOFER.py:12-18
+    float *window_blur = nullptr; // [n_fft] window x the time-domain image of the sigma-0.5 bin blur (see stems.hip)
+    float *blur_edge = nullptr;   // [4][64] per-lane coefficients of the blur's edge correction (bins 1..6 and M-6..M-1)
     float *win_sq = nullptr;      // [n_fft] window*window in fp32 (OLA weights)  GOOFER.py:385
     float *freqs = nullptr;       // [n_bins] rfftfreq fp32                       GOOFER.py:20-26
     float *boost = nullptr;       // [n_bins] linspace(1,100)                     GOOFER.py:28-35
@@ -68,6 +70,7 @@ struct goofer_ctx {
     bool stems = true;            // stem-split frame walkers (stems.hip) where the geometry allows (hop == n_fft / 4); false: the
                                   // one-kernel-per-reference-step pipeline with the spectra in HBM (A/B parity path)
     bool skip_zero = true;        // noise walker: skip transforms whose stem gain is exactly zero over everything they reach (option "skip_zero")
+    bool td_blur = true;          // stem walkers: the 5-tap bin blur of voiced frames as a window on the frame's samples (option "td_blur")
     bool prof_stems = false;      // the last profiled batch ran the stem-split path (stage order differs)
     // tuning knobs (goofer_set_option; the defaults are the measured optima — round 3 swept them: nothing within 1 % to gain)
     int walk_lds_kb = 81;         // LDS the sequential phase walk reserves per workgroup (what it uses: 32 KiB)

@@ -62,7 +62,7 @@ template <int M> struct stem_cfg {
     // Sized so that four workgroups share a CU (4 waves per SIMD): a walker is a latency-bound chain of LDS exchanges and
     // needs the waves more than it needs registers.
     static constexpr size_t wave_bytes = sizeof(float2) * fft_cfg<M>::BUF + sizeof(double) * KN;
-    template <int NTAB, bool WIN> static constexpr size_t table_bytes() { return sizeof(float2) * 3 * M + sizeof(float) * (NTAB * ROWF + (WIN ? NF : 0)); }
+    template <int NTAB, bool WIN> static constexpr size_t table_bytes() { return sizeof(float2) * 4 * M + sizeof(float) * (NTAB * ROWF + (WIN ? NF : 0)); }
     template <int NTAB, bool WIN> static constexpr size_t lds_bytes() { return table_bytes<NTAB, WIN>() + WAVES_PER_BLOCK * wave_bytes; }
     static_assert(wave_bytes % 16 == 0, "16-byte aligned LDS carving");
 };
@@ -140,7 +140,7 @@ struct frame_block {
 template <int M, int NTAB, bool WIN> struct walker {
     using C = stem_cfg<M>;
     static constexpr int R = C::R, G = C::G, NF = C::NF, HOP = C::HOP, B = C::B;
-    float2 *tw, *wct, *wsc, *buf;
+    float2 *tw, *wct, *wsc, *wsv, *buf;
     float *win, *tab;
     double *kbuf;
     int lane;
@@ -150,12 +150,13 @@ template <int M, int NTAB, bool WIN> struct walker {
     int64_t base = 0;
 
     __device__ __forceinline__ void init(unsigned char *smem, const float2 *g_tw, const float2 *g_twh, const float *g_win,
-                                         const float *t0, const float *t1, const float *t2)
+                                         const float *g_winb, const float *t0, const float *t1, const float *t2)
     {
         tw = reinterpret_cast<float2 *>(smem);
         wct = tw + M;
         wsc = wct + M;
-        tab = reinterpret_cast<float *>(wsc + M);
+        wsv = wsc + M;
+        tab = reinterpret_cast<float *>(wsv + M);
         win = tab + NTAB * C::ROWF;
         const float *tsrc[3] = {t0, t1, t2};
         for (int i = threadIdx.x; i < C::ROWF; i += blockDim.x) {
@@ -171,6 +172,10 @@ template <int M, int NTAB, bool WIN> struct walker {
             // synthesis window of sample pair k with 1/M and 1/2 folded in: (z / M) * w == z * (w / M) exactly (M is a
             // power of two), and the conjugate's sign rides along
             wsc[k] = make_float2(g_win[2 * k] * inv_m, -(g_win[2 * k + 1] * inv_m));
+            // the same for frames whose spectrum the reference blurs along bins with the sigma-0.5 taps (brightened voiced
+            // frames, GOOFER.py:1143 / 1171): blurring a spectrum circularly is multiplying the samples by the taps' transform,
+            // so those frames are windowed with window x W and the 5-tap pass over the bins is not run at all
+            wsv[k] = make_float2(g_winb[2 * k] * inv_m, -(g_winb[2 * k + 1] * inv_m));
         }
         if (WIN)
             for (int i = threadIdx.x; i < NF; i += blockDim.x) win[i] = g_win[i];
@@ -221,7 +226,8 @@ template <int M, int NTAB, bool WIN> struct walker {
     // irFFT of the spectrum whose bins k = lane + 64 i this lane holds in x[] (x[R]: the Nyquist bin, lane 0): the complex row
     // goes through `buf` for the mirrored bins, the complex M-point transform runs (twiddles from LDS), the frame is windowed
     // and overlap-added into `carry`; out[g] = the finished groups of hop t.
-    __device__ __forceinline__ void inverse_ola(const float2 (&x)[C::PER], int t, float2 (&carry)[R - G], float2 (&out)[G])
+    __device__ __forceinline__ void inverse_ola(const float2 (&x)[C::PER], int t, float2 (&carry)[R - G], float2 (&out)[G],
+                                                const float2 *wtab)
     {
 #pragma unroll
         for (int i = 0; i < R; ++i) buf[lane + WAVE * i] = x[i];
@@ -240,7 +246,7 @@ template <int M, int NTAB, bool WIN> struct walker {
         wave_fft_keep<M>(v, buf, tw, lane, z);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const float2 wn = wsc[lane + WAVE * r];
+            const float2 wn = wtab[lane + WAVE * r];
             const float a = z[r].x * wn.x, b = z[r].y * wn.y;
             float2 s;
             if (r < R - G && t != 0) s = make_float2(carry[r].x + a, carry[r].y + b);
@@ -248,6 +254,22 @@ template <int M, int NTAB, bool WIN> struct walker {
             if (r < G) out[r] = s;
             else carry[r - G] = s;                                   // slot r - G was consumed G steps ago
         }
+    }
+
+    // The reference blurs a voiced frame's spectrum over the bins with numpy-'reflect' edges; the blurred window (wsv) blurs it
+    // over its Hermitian continuation.  This adds, to the six bins next to either edge, the purely imaginary D with
+    // blur(D) = the difference (see goofer_plan: blur_edge), so that the two agree to fp32 rounding.  ec[]: this lane's four
+    // coefficients; t0, t1: the outer taps.
+    __device__ __forceinline__ void blur_edges(float2 (&x)[C::PER], const float (&ec)[4], float t0, float t1) const
+    {
+        const float im0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[0].y), 0));
+        const float im1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[0].y), 1));
+        const float imM = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[R].y), 0));
+        const float imN = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[R - 1].y), WAVE - 1));
+        const float a = fmaf(2.0f * t0, im1, t1 * im0), b = t0 * im0;
+        const float at = fmaf(2.0f * t0, imN, t1 * imM), bt = t0 * imM;
+        x[0].y = fmaf(ec[0], a, fmaf(ec[1], b, x[0].y));
+        x[R - 1].y = fmaf(ec[2], at, fmaf(ec[3], bt, x[R - 1].y));
     }
 
     // A frame whose transform is skipped (its spectrum cannot reach a non-zero output sample): the ring still moves on
@@ -285,7 +307,8 @@ struct noise_args {
     const float *env, *phi;
     float *uv, *bre;
     const double *short_s;
-    int ld, mode, run;             // mode bit 0: blur the rows here; bit 1: never skip a transform (A/B)
+    int ld, mode, run;             // mode bit 0: blur the rows here; bit 1: never skip a transform (A/B); bit 2: the 5-tap bin blur
+                                   // of voiced frames as a window on the samples
     float t5[3], t175[8];          // first halves of the two (symmetric) tap sets
     // set-up, frame records (every 64 frames), note entry: read where they are used (cold_arg)
     int64_t total_frames;
@@ -298,7 +321,7 @@ struct noise_args {
     const double *steps;
     const float *freqs, *bright;
     const float2 *g_tw, *g_twh;
-    const float *g_win;
+    const float *g_win, *g_winb, *g_edge;
 };
 #define NCOLD(field) COLD(noise_args, field)
 
@@ -310,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
     static_assert(R == 8, "the row staging below moves two 16-byte pieces per lane");
     extern __shared__ __align__(16) unsigned char smem[];
     walker<M, 2, false> w;
-    w.init(smem, NCOLD(g_tw), NCOLD(g_twh), NCOLD(g_win), NCOLD(freqs), NCOLD(bright), nullptr);
+    w.init(smem, NCOLD(g_tw), NCOLD(g_twh), NCOLD(g_win), NCOLD(g_winb), NCOLD(freqs), NCOLD(bright), nullptr);
     const int lane = w.lane;
     const float *t_fq = w.tab, *t_br = w.tab + ROWF;
     const float *__restrict__ env = A.env;
@@ -331,6 +354,12 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
     // bins 64 .. M sit a whole 64-bin stride above the lowest bins: when f0 + 100 Hz is still below bin 64 their high-pass
     // factor is exactly 1.0f (1 + exp(-z) rounds to 1 for z > 18, i.e. 90 Hz above f0; rcp(1) = 1) and is not evaluated
     const float fq64 = w.tab[WAVE];
+    float ec[4];
+    {
+        const float *g_edge = NCOLD(g_edge);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ec[q] = g_edge[q * WAVE + lane];
+    }
     // the two tap sets are symmetric (gauss_taps_host): tap q of the second half is tap len - 1 - q
     float t5[5], t175[15];
 #pragma unroll
@@ -534,7 +563,8 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
                 sb[i].x *= b; sb[i].y *= b;
             }
         }
-        if (voiced) {
+        const bool td_blur = (mode & 4) != 0;
+        if (voiced && !td_blur) {
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int k = lane + WAVE * i;
@@ -548,13 +578,18 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
             }
             wave_lds_sync();
         }
-        // 3. inverse transforms + overlap-add (skipped where the stem's gain is exactly zero over everything the frame reaches)
+        // 3. inverse transforms + overlap-add (skipped where the stem's gain is exactly zero over everything the frame reaches);
+        //    the breath frame of a voiced frame leaves through the blurred window (see walker::init) unless the pass above ran
         hop_check_done();
         float2 ob[G], ou[G];
-        if (zero_bits == 15u) w.skip_ola(t, carry_b, ob);
-        else w.inverse_ola(sb, t, carry_b, ob);
+        if (zero_bits == 15u) {
+            w.skip_ola(t, carry_b, ob);
+        } else {
+            if (voiced && td_blur) w.blur_edges(sb, ec, t5[0], t5[1]);
+            w.inverse_ola(sb, t, carry_b, ob, (voiced && td_blur) ? w.wsv : w.wsc);
+        }
         if (one_bits == 15u) w.skip_ola(t, carry_u, ou);
-        else w.inverse_ola(su, t, carry_u, ou);
+        else w.inverse_ola(su, t, carry_u, ou, w.wsc);
 
         if (f >= f0) {
             // 4. hop t -> window-sum quotient -> mask upsample -> stem gains -> out (GOOFER.py:385-389, 1179-1183); behind a note's
@@ -637,13 +672,13 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
                                                       const float *__restrict__ boost, const float *__restrict__ bright,
                                                       const stem_taps taps, float *__restrict__ harm, float *__restrict__ note_mag,
                                                       int run, const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twh,
-                                                      const float *__restrict__ g_win)
+                                                      const float *__restrict__ g_win, const float *__restrict__ g_winb, const float *__restrict__ g_edge, int td_blur)
 {
     using C = stem_cfg<M>;
     constexpr int R = C::R, G = C::G, HOP = C::HOP, B = C::B, PER = C::PER, ROWF = C::ROWF;
     extern __shared__ __align__(16) unsigned char smem[];
     walker<M, 3, true> w;
-    w.init(smem, g_tw, g_twh, g_win, freqs, boost, bright);
+    w.init(smem, g_tw, g_twh, g_win, g_winb, freqs, boost, bright);
     const int lane = w.lane;
     const float *t_fq = w.tab, *t_bo = w.tab + ROWF, *t_br = w.tab + 2 * ROWF;
     int64_t fs, f0, f1;
@@ -693,6 +728,9 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
 #pragma unroll
     for (int r = 0; r < R - G; ++r) carry[r] = make_float2(0.f, 0.f);
     int apply_bright = 0, cut_below = 0;
+    float ec[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ec[q] = g_edge[q * WAVE + lane];
 
     // one iteration in front of the run only starts the first fetch, so that the fetch code exists once
     for (int64_t f = fs - 1; f < f1; ++f) {
@@ -770,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
         }
         mx = __builtin_amdgcn_sqrtf(wave_max(mx)) + 1e-8f;          // max(|s| + 1e-8) = sqrt(max |s|^2) + 1e-8: sqrt is monotone
         if (lane == 0) atomic_max_pos(note_mag + w.note, mx);
-        if (voiced) {
+        if (voiced && !td_blur) {
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int k = lane + WAVE * i;
@@ -787,7 +825,8 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
 
         // 4. inverse transform + overlap-add; hop t leaves un-normalised by the note's spectrum maximum
         float2 e[G];
-        w.inverse_ola(X, t, carry, e);
+        if (voiced && td_blur) w.blur_edges(X, ec, taps.t5[0], taps.t5[1]);
+        w.inverse_ola(X, t, carry, e, (voiced && td_blur) ? w.wsv : w.wsc);   // voiced: the bin blur rides on the window
         if (f >= f0) {
             for (int h = t;;) {
                 const int p0 = h * HOP - M;
@@ -984,12 +1023,12 @@ int launch_noise_stems(goofer_ctx *ctx, const float *env, int ld, const int64_t 
     const dim3 grid((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
     noise_args A;
     A.env = env; A.phi = phi; A.uv = uv; A.bre = bre; A.short_s = short_s;
-    A.ld = ld; A.mode = (preblurred ? 0 : 1) | (ctx->skip_zero ? 0 : 2); A.run = run;
+    A.ld = ld; A.mode = (preblurred ? 0 : 1) | (ctx->skip_zero ? 0 : 2) | (ctx->td_blur ? 4 : 0); A.run = run;
     for (int q = 0; q < 3; ++q) A.t5[q] = p.taps5_f[q];
     for (int q = 0; q < 8; ++q) A.t175[q] = p.taps175_f[q];
     A.total_frames = F; A.seed = seed; A.row_src = row_src; A.frame_note = frame_note; A.frame_off = frame_off;
     A.sample_off = sample_off; A.picks = picks; A.params = params; A.steps = steps; A.freqs = p.freqs; A.bright = p.bright_b;
-    A.g_tw = p.tw_full; A.g_twh = p.tw_half; A.g_win = p.window;
+    A.g_tw = p.tw_full; A.g_twh = p.tw_half; A.g_win = p.window; A.g_winb = p.window_blur; A.g_edge = p.blur_edge;
     if (phi) hipLaunchKernelGGL((k_noise_stems<M, true>), grid, dim3(256), lds, st, A);
     else hipLaunchKernelGGL((k_noise_stems<M, false>), grid, dim3(256), lds, st, A);
     LAUNCH_CHECK(ctx);
@@ -1014,7 +1053,7 @@ int launch_harm_stem(goofer_ctx *ctx, const float *pulse, const float *env, int 
     const int64_t runs = (F + run - 1) / run;
     hipLaunchKernelGGL(k_harm_stem<M>, dim3((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), dim3(256), lds, st, pulse, env, ld,
                        row_src, F, frame_note, frame_off, sample_off, picks, params, p.freqs, p.boost, p.bright_h, plan_taps(p), harm,
-                       note_mag, run, p.tw_full, p.tw_half, p.window);
+                       note_mag, run, p.tw_full, p.tw_half, p.window, p.window_blur, p.blur_edge, ctx->td_blur ? 1 : 0);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

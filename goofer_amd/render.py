@@ -137,16 +137,54 @@ class Renderer:
         """The device work of one batch (asynchronous): goofer_render_batch, i.e. assembly + synthesis as one call;
         ``split=True`` issues goofer_assemble_batch and goofer_synth_batch separately (same results)."""
         ctx = self.ctx
-        if split:
+        par = prep["params"]
+        # Notes with the 'sg' pulse layer or the 'sr' volume jitter are synthesised by the one-kernel-per-step pipeline (those
+        # layers edit the pulse train / the stems between its steps), everything else by the stem walkers — and the library
+        # picks the pipeline per BATCH.  So that a note renders to the same bits whatever company it keeps (the two pipelines
+        # agree to fp32 rounding, not to the bit: the walkers fold the voiced frames' bin blur into the synthesis window), a
+        # mixed batch is synthesised as two: one per pipeline.
+        slow = np.nonzero((par["subharm_weight"] > 0) | (par["vol_jitter_harm"] != 0) | (par["vol_jitter_breath"] != 0))[0]
+        if 0 < slow.size < len(par):
             self.assemble(prep)
-        out = ctx.synth_batch(prep["env"], prep["env_lens"], prep["f0"], prep["mask"], prep["lens"], prep["params"],
-                              formants=prep["formants"], phi=prep["phi"], seed=seed, want_rec=False, want_mix=True,
-                              offsets=prep["offsets"], noise_f0=prep["noise_f0"], noise_vol=prep["noise_vol"],
-                              subharm=S.SUBHARM if prep["subharm"] else None,
-                              mix_only=prep["post"] is None and not keep_stems,
-                              assembly=None if split else prep["assembly"])
+            out = self._synth_partitioned(prep, [np.setdiff1d(np.arange(len(par)), slow), slow], seed, keep_stems)
+        else:
+            if split:
+                self.assemble(prep)
+            out = ctx.synth_batch(prep["env"], prep["env_lens"], prep["f0"], prep["mask"], prep["lens"], par,
+                                  formants=prep["formants"], phi=prep["phi"], seed=seed, want_rec=False, want_mix=True,
+                                  offsets=prep["offsets"], noise_f0=prep["noise_f0"], noise_vol=prep["noise_vol"],
+                                  subharm=S.SUBHARM if prep["subharm"] else None,
+                                  mix_only=prep["post"] is None and not keep_stems,
+                                  assembly=None if split else prep["assembly"])
         if prep["post"] is not None:
             self._post_chain(prep, out, seed)
+        return out
+
+    def _synth_partitioned(self, prep, groups, seed, keep_stems):
+        """goofer_synth_batch once per group of notes of an assembled batch; the stems land at the notes' places."""
+        ctx = self.ctx
+        so = prep["sample_off"]
+        total = int(so[-1])
+        out = {k: torch.empty(total, dtype=torch.float32, device=ctx.device) for k in ("harm", "uv", "bre", "mix")}
+        cat = lambda t, idxs: None if t is None else torch.cat([t[int(so[i]):int(so[i + 1])] for i in idxs])
+        for idxs in groups:
+            idxs = [int(i) for i in idxs]
+            sub = self._subset(prep, idxs)
+            par = prep["params"][idxs].copy()
+            lens, env_lens = [prep["lens"][i] for i in idxs], [prep["env_lens"][i] for i in idxs]
+            nv = prep["noise_vol"]
+            wants_sub = bool(np.any(par["subharm_weight"] > 0))
+            wants_vol = nv is not None and bool(np.any((par["vol_jitter_harm"] != 0) | (par["vol_jitter_breath"] != 0)))
+            o = ctx.synth_batch(sub["env"], env_lens, sub["f0"], sub["mask"], lens, par, formants=sub["formants"], phi=sub["phi"],
+                                seed=seed, want_rec=False, want_mix=True,
+                                noise_f0=cat(prep["noise_f0"], idxs) if bool(np.any(par["f0_jitter"] != 0)) else None,
+                                noise_vol=(cat(nv[0], idxs), cat(nv[1], idxs)) if wants_vol else None,
+                                subharm=S.SUBHARM if (prep["subharm"] and wants_sub) else None,
+                                mix_only=prep["post"] is None and not keep_stems)
+            sub_off = np.concatenate([[0], np.cumsum(lens)])
+            for k in out:
+                for j, i in enumerate(idxs):
+                    out[k][int(so[i]):int(so[i + 1])] = o[k][int(sub_off[j]):int(sub_off[j + 1])]
         return out
 
     # -- sample-domain post chain (SillySampler.py:1037-1182) ------------------------------------------------------

@@ -276,6 +276,7 @@ def test_fused_overlap_add_equals_separate_kernels(ctx, config, ids):
     from goofer_amd.workload import SynthWorkload
     wl = SynthWorkload(ctx, config, ids)
     try:
+        ctx.set_option("td_blur", 0)                          # bitwise A/B: the bin blur as the 5-tap pass on both sides
         ctx.set_option("fused_ola", 1)
         a = wl.step(want_rec=True)
         torch.cuda.synchronize()
@@ -285,6 +286,7 @@ def test_fused_overlap_add_equals_separate_kernels(ctx, config, ids):
         torch.cuda.synchronize()
     finally:
         ctx.set_option("fused_ola", 1)
+        ctx.set_option("td_blur", 1)
     for k in a:
         assert np.array_equal(a[k], b[k].cpu().numpy()), k
 
@@ -336,6 +338,7 @@ def test_fused_overlap_add_other_geometries(ctx, n_fft, hop):
     par = default_params(len(lens))
     args = (ctx.rows_from(np.concatenate(envs)), env_len, ctx.tensor(np.concatenate(f0s)), ctx.tensor(np.concatenate(masks)), lens, par)
     try:
+        ctx.set_option("td_blur", 0)
         ctx.set_option("fused_ola", 1)
         a = ctx.synth_batch(*args, seed=9)
         torch.cuda.synchronize()
@@ -345,6 +348,7 @@ def test_fused_overlap_add_other_geometries(ctx, n_fft, hop):
         torch.cuda.synchronize()
     finally:
         ctx.set_option("fused_ola", 1)
+        ctx.set_option("td_blur", 1)
         ctx.plan(44100, 1024, 256)
     for k in a:
         assert np.array_equal(a[k], b[k].cpu().numpy()), k
@@ -374,6 +378,7 @@ def test_fused_overlap_add_tiny_and_ragged_notes(ctx):
     par = default_params(len(lens))
     args = (ctx.rows_from(np.concatenate(envs)), env_len, ctx.tensor(np.concatenate(f0s)), ctx.tensor(np.concatenate(masks)), lens, par)
     try:
+        ctx.set_option("td_blur", 0)
         ctx.set_option("fused_ola", 1)
         a = ctx.synth_batch(*args, seed=5)
         torch.cuda.synchronize()
@@ -383,6 +388,7 @@ def test_fused_overlap_add_tiny_and_ragged_notes(ctx):
         torch.cuda.synchronize()
     finally:
         ctx.set_option("fused_ola", 1)
+        ctx.set_option("td_blur", 1)
     for k in a:
         assert np.array_equal(a[k], b[k].cpu().numpy()), k
         assert np.all(np.isfinite(a[k])), k
