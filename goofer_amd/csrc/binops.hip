@@ -359,10 +359,9 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
             c = cosf(ph[i]);
             s = sinf(ph[i]);
         } else {
-            // one Philox-4x32-10 block feeds four bins of this lane (bins lane+64i, i = 4q..4q+3)
-            if ((i & 3) == 0) rnd = philox_4x32(key, (uint64_t)t, (uint32_t)(lane + WAVE * (i >> 2)));
-            const uint32_t u = (i & 3) == 0 ? rnd.x : ((i & 3) == 1 ? rnd.y : ((i & 3) == 2 ? rnd.z : rnd.w));
-            const float rev = (float)(u >> 8) * (1.0f / 16777216.0f);      // phase / 2 pi, uniform in [0, 1)
+            // one Philox-4x32-7 block feeds eight bins of this lane (bins lane + 64 i, i = 8q..8q+7), 16 bits each
+            if ((i & 7) == 0) rnd = philox_4x32(key, (uint64_t)t, (uint32_t)(lane + WAVE * (i >> 3)));
+            const float rev = (float)philox_half(rnd, i & 7) * (1.0f / 65536.0f);      // phase / 2 pi, uniform in [0, 1)
             c = __builtin_amdgcn_cosf(rev);
             s = __builtin_amdgcn_sinf(rev);
         }

@@ -368,10 +368,11 @@ __device__ __forceinline__ float2 blur5(const float2 *r, int k, int n_bins, cons
     return make_float2(re, im);
 }
 
-// Philox-4x32 with 7 rounds (the Crush-resistant minimum of the Random123 paper; its 32-bit multiplies run at quarter
-// rate here and only feed noise phases) keyed by (seed), counter (frame, slot): four 32-bit words per block.  The phase of bin k comes
-// from slot (k & 63) + 64 * (k >> 8), word (k >> 6) & 3, so a lane that owns bins lane, lane+64, ... needs one
-// block per four of its bins; philox_u32 is the same mapping evaluated for a single bin.
+// Philox-4x32 with 7 rounds (the Crush-resistant minimum of the Random123 paper; its 32-bit multiplies only feed noise
+// phases) keyed by (seed), counter (frame, slot): four 32-bit words per block = EIGHT 16-bit phases (2 pi / 65536: the
+// reference's float32 uniforms resolve finer, no ear or statistic does).  The phase of bin k comes from slot (k & 63) + 64 (k >> 9),
+// word (k >> 7) & 3, half (k >> 6) & 1 — so a lane that owns bins lane, lane + 64, ... needs ONE block per eight of its bins (one
+// block per frame for n_fft 1024; it was two with 24-bit phases).  philox_u16 is the same mapping evaluated for a single bin.
 __device__ __forceinline__ uint4 philox_4x32(uint64_t seed, uint64_t ctr_hi, uint32_t ctr_lo)
 {
     uint32_t c0 = ctr_lo, c1 = (uint32_t)ctr_hi, c2 = (uint32_t)(ctr_hi >> 32), c3 = 0x9E3779B9u;
@@ -387,9 +388,15 @@ __device__ __forceinline__ uint4 philox_4x32(uint64_t seed, uint64_t ctr_hi, uin
     return make_uint4(c0, c1, c2, c3);
 }
 
-__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t frame, uint32_t bin)
+__device__ __forceinline__ uint32_t philox_half(const uint4 &v, int i)       // i = index of the bin among its lane's eight
 {
-    const uint4 v = philox_4x32(seed, frame, (bin & 63u) + 64u * (bin >> 8));
-    const uint32_t w = (bin >> 6) & 3u;
-    return w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w));
+    const int w = (i >> 1) & 3;
+    const uint32_t word = w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w));
+    return (i & 1) ? (word >> 16) : (word & 0xffffu);
+}
+
+__device__ __forceinline__ uint32_t philox_u16(uint64_t seed, uint64_t frame, uint32_t bin)
+{
+    const uint4 v = philox_4x32(seed, frame, (bin & 63u) + 64u * (bin >> 9));
+    return philox_half(v, (int)((bin >> 6) & 7u));
 }

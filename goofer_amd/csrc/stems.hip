@@ -124,11 +124,11 @@ struct frame_block {
     }
     // Bin M (Nyquist) is the one bin past the 8 x 64 a wave holds, and only lane 0 owns it: drawing its phase inside the frame
     // loop costs a whole Philox block per frame for one lane's word.  Here the 64 frames of the block draw theirs at once, one
-    // frame per lane — the same block (key of the frame's note, counter (frame, slot 128), word 0) philox_u32(.., bin M) names.
+    // frame per lane — the same block, word and half philox_u16(.., bin M) names.
     __device__ __forceinline__ void load_nyquist(const goofer_note_params *__restrict__ params, uint64_t seed, int m_bin)
     {
         const uint64_t key = seed ^ ((uint64_t)params[note].seed[0] | ((uint64_t)params[note].seed[1] << 32));
-        ny_u = philox_u32(key, (uint64_t)t, (uint32_t)m_bin);
+        ny_u = philox_u16(key, (uint64_t)t, (uint32_t)m_bin);
     }
     __device__ __forceinline__ bool holds(int64_t f) const { return f >= blk0 && f < blk0 + WAVE; }
 };
@@ -547,11 +547,10 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
                 c = cosf(ph);
                 s = sinf(ph);
             } else {
-                // one Philox block feeds four bins of this lane (bins lane + 64 i, i = 4q..4q+3); the Nyquist bin's word was
-                // drawn with the frame records
-                if ((i & 3) == 0 && i < R) rnd = philox_4x32(key, (uint64_t)t, (uint32_t)(lane + WAVE * (i >> 2)));
-                const uint32_t u = i == R ? ny_u : ((i & 3) == 0 ? rnd.x : ((i & 3) == 1 ? rnd.y : ((i & 3) == 2 ? rnd.z : rnd.w)));
-                const float rev = (float)(u >> 8) * (1.0f / 16777216.0f);      // phase / 2 pi, uniform in [0, 1)
+                // one Philox block feeds the lane's eight bins (16-bit phases); the Nyquist bin's was drawn with the frame records
+                if (i == 0) rnd = philox_4x32(key, (uint64_t)t, (uint32_t)lane);
+                const uint32_t u = i == R ? ny_u : philox_half(rnd, i);
+                const float rev = (float)u * (1.0f / 65536.0f);                 // phase / 2 pi, uniform in [0, 1)
                 c = __builtin_amdgcn_cosf(rev);
                 s = __builtin_amdgcn_sinf(rev);
             }
