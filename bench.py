@@ -232,32 +232,76 @@ def cpu_baseline(config, ids, n_fft, hop, budget_s=10.0, min_notes=4):
 
 def host_inclusive(wl, ctx, step_s):
     """What one batch costs a host that starts from the 13 argument strings and ends with the audio in host memory: decode,
-    plan + tables + upload (Renderer.prepare), one device step, download of the mix.  Never part of `value`."""
+    plan + tables + upload (Renderer.prepare), one device step, download of the mix into a pinned buffer.  `serial`: one batch
+    after the other on one host thread.  `pipelined`: a second host thread prepares batch k + 1 (its planner and its copies
+    run outside the interpreter lock) while batch k is on the device — the steady-state cost of a long job.  Never part of
+    `value`."""
+    import threading
     import torch
     from goofer_amd import sampler as S
     from goofer_amd import synthetic as syn
     from goofer_amd.render import Source
     raw = wl.raw
     args = [syn.request_args(q) for _, q, _ in raw]
-    best = None
-    for _ in range(2):
+    srcs = [Source.from_pack(s["env_pack"], s["f0"], s["mask"], s["formants"], s["sr"], s["y_len"]) for s, _, _ in raw]
+    ids = list(range(len(raw)))
+    host_mix = torch.empty(wl.samples, dtype=torch.float32).pin_memory()
+
+    def prepare():
         t0 = time.perf_counter()
-        reqs = [S.decode_request(*a) for a in args]
-        jobs = [(Source.from_pack(s["env_pack"], s["f0"], s["mask"], s["formants"], s["sr"], s["y_len"]), q) for (s, _, _), q in zip(raw, reqs)]
+        reqs = S.decode_requests(args)
         t1 = time.perf_counter()
-        prep = wl.renderer.prepare(jobs, note_ids=list(range(len(jobs))))
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
+        prep = wl.renderer.prepare(list(zip(srcs, reqs)), note_ids=ids)
+        return prep, 1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1)
+
+    def run(prep):
         out = wl.renderer.run(prep, seed=0)
-        mix = out["mix"].cpu()
+        host_mix.copy_(out["mix"], non_blocking=True)
+        torch.cuda.synchronize()
+
+    from goofer_amd.render import SourceArena
+    wl.renderer.sources = SourceArena(ctx)                     # pass 0 uploads the batch's samples, the later passes find them resident
+    best, first = None, None
+    for k in range(4):
+        t0 = time.perf_counter()
+        prep, dec_ms, prep_ms = prepare()
+        t2 = time.perf_counter()
+        run(prep)
         t3 = time.perf_counter()
-        cur = {"decode_ms": 1e3 * (t1 - t0), "plan_upload_ms": 1e3 * (t2 - t1), "step_and_download_ms": 1e3 * (t3 - t2),
-               "total_ms": 1e3 * (t3 - t0), "frames_per_s": prep["frames"] / (t3 - t0), "notes_per_s": len(jobs) / (t3 - t0)}
-        if best is None or cur["total_ms"] < best["total_ms"]:
+        cur = {"decode_ms": dec_ms, "plan_upload_ms": prep_ms, "step_and_download_ms": 1e3 * (t3 - t2),
+               "total_ms": 1e3 * (t3 - t0), "frames_per_s": prep["frames"] / (t3 - t0), "notes_per_s": len(raw) / (t3 - t0)}
+        if k == 0:
+            first = cur
+        elif best is None or cur["total_ms"] < best["total_ms"]:
             best = cur
-        del prep, out, mix
-    best["note"] = ("one host thread: 13 argument strings -> Request (decode), plans + tables + H2D (Renderer.prepare), device step, "
-                    "D2H of the mix; the best of two passes; the device step alone is ms_per_step")
+        frames = prep["frames"]
+        del prep
+    best["first_batch"] = {"total_ms": first["total_ms"], "plan_upload_ms": first["plan_upload_ms"], "frames_per_s": first["frames_per_s"],
+                           "note": "the same batch when none of its 1024 voicebank samples is resident in HBM yet (knot tables + voicing masks uploaded)"}
+    # double-buffered: prepare(k + 1) beside run(k)
+    rounds, box = 8, {}
+
+    def worker():
+        box["prep"] = prepare()[0]
+
+    prep = prepare()[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(rounds):
+        th = None
+        if k + 1 < rounds:
+            th = threading.Thread(target=worker)
+            th.start()
+        run(prep)
+        if th is not None:
+            th.join()
+            prep = box.pop("prep")
+    dt = (time.perf_counter() - t0) / rounds
+    best["pipelined"] = {"ms_per_batch": 1e3 * dt, "frames_per_s": frames / dt, "batches": rounds,
+                         "note": "prepare(k + 1) on a second host thread while batch k runs and downloads"}
+    best["note"] = ("serial, one host thread: 13 argument strings -> Requests (decode_requests), plans in the library's host planner + "
+                    "tables + H2D of the plans (Renderer.prepare; the voicebank samples are resident in HBM, see first_batch), device step, "
+                    "D2H of the mix into pinned memory; the best of three passes; the device step alone is ms_per_step")
     return best
 
 
@@ -556,8 +600,8 @@ def rehearse(args):
             src, req, _ = syn.config_note(args.config, int(i))
             sobj = Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
             jobs.append((S.decode_request(*syn.request_args(req)), sobj.sr, sobj.ylen, sobj.knots.shape[1], sobj.formants))
-        plans = S.plan_notes(jobs, hop)
-        sub_frames.append(sum(1 + p.n_out // hop for p in plans))
+        planned = S.plan_notes_arrays(jobs, hop, trim_rows=True)          # the library's host planner (pure CPU code)
+        sub_frames.append(int((1 + planned.geo["n_out"].astype(np.int64) // hop).sum()))
     setup_s = time.perf_counter() - t_setup
     my_frames = sum(sub_frames)
     if job:

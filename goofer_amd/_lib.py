@@ -40,6 +40,22 @@ NOTE_PLAN = np.dtype([
     ("pd_base", "<f8"),
 ], align=True)
 
+# goofer_plan_request / goofer_plan_geometry (host-side planner)
+PLAN_REQUEST = np.dtype([
+    ("offset", "<f8"), ("length", "<f8"), ("consonant", "<f8"), ("cutoff", "<f8"), ("vel_factor", "<f8"), ("fry", "<f8"),
+    ("fry_glide", "<f8"), ("ylen", "<i8"), ("sr", "<i4"), ("n_src_frames", "<i4"), ("loop_mode", "<i4"), ("reverse", "<i4"),
+    ("tracks", "<u8", 4), ("track_len", "<i4", 4),
+], align=True)
+PLAN_GEOMETRY = np.dtype([
+    ("start_sample", "<i8"), ("consonant_sample", "<i8"), ("end_sample", "<i8"), ("tap_off", "<i8"), ("vel_factor", "<f8"),
+    ("status", "<i4"), ("start_frame", "<i4"), ("consonant_frame", "<i4"), ("end_frame", "<i4"), ("n_rows", "<i4"),
+    ("n_out_rows", "<i4"), ("row_lo", "<i4"), ("row_hi", "<i4"), ("env_f64", "<i4"),
+    ("n_out", "<i4"), ("n_pre", "<i4"), ("s_pre", "<i4"), ("s_tail", "<i4"), ("tail_len", "<i4"), ("want_samples", "<i4"),
+    ("n_before_vel", "<i4"), ("pre_new", "<i4"), ("vel_active", "<i4"),
+    ("fry_dir", "<i4"), ("fry_const_lo", "<i4"), ("fry_const_hi", "<i4"), ("fry_glide_lo", "<i4"), ("fry_glide_hi", "<i4"),
+    ("fry_a", "<i4"), ("fry_b", "<i4"), ("fry_fade", "<i4"), ("reserved", "<i4"),
+], align=True)
+
 # goofer_onepole_job / goofer_post_note
 ONEPOLE_JOB = np.dtype([
     ("src_off", "<i8"), ("dst_off", "<i8"), ("f0_off", "<i8"), ("n", "<i4"), ("order", "<i4"), ("highpass", "<i4"),
@@ -140,6 +156,11 @@ EXPORTS = {
     "goofer_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "goofer_check": (C.c_int, [C.c_void_p]),
     "goofer_host_gauss_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "goofer_host_plan_notes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "goofer_host_plans_view": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "goofer_host_plans_free": (None, [C.c_void_p]),
+    "goofer_host_decode_bends": (C.c_int64, [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "goofer_smooth_mask_ds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p,
                                         C.c_void_p]),
 }

@@ -715,6 +715,8 @@ int goofer_sizeof(int which)
     case 4: return (int)sizeof(goofer_onepole_job);
     case 5: return (int)sizeof(goofer_post_note);
     case 6: return (int)sizeof(goofer_post);
+    case 7: return (int)sizeof(goofer_plan_request);
+    case 8: return (int)sizeof(goofer_plan_geometry);
     }
     return -1;
 }

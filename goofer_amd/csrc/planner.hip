@@ -1,0 +1,627 @@
+// Host-side note planner of goofer_assemble_batch (no device code, no HIP call): everything SillySampler.resample decides
+// about a note before it touches an array, for a whole batch in one call.
+//
+//   cut points and clipped slices                                   SillySampler.py:453-500
+//   loop-mode frame taps: L0 cross-faded repeats, L1 mirror mean, L2 stretch           :625-696
+//   sample counts, velocity prefix stretch (a second 2-tap lerp on top of the first)   :698-788
+//   the F1..F4 tracks handed to gf.synthesize and the repaired + sigma-4 smoothed tracks of the 'fst' gain   :714-763, 264-283, 791-806
+//   vocal-fry sample ranges                                         :883-955
+//
+// goofer_amd/sampler.py holds the same decisions as numpy code (pinned by the reference's 53 index-plan fixtures); this file
+// is that arithmetic note by note in C++ — fp64 / fp32 operations in the order numpy performs them, so the two agree to the
+// bit (tests/test_planner_native.py) — because a render job of notes that all differ spent 0.15 ms per note in numpy
+// dispatch, forty times the device time of the note.  Notes are independent: the batch is split over a few host threads.
+//
+// What numpy does that matters here:
+//   linspace(a, b, n)   = arange(n) * ((b - a) / (n - 1)) + a, last element set to b; n == 1: [a]
+//   np.interp           = slope * (x - xp[j]) + fp[j] in fp64, fp[j] itself on an exact hit, fp[-1] at / beyond the right end
+//   Python round()      = round half to even (nearbyint in the default rounding mode); int() truncates; // floors
+//   float32 <op> Python float  = float32 arithmetic (NEP 50 weak scalars)
+#include <algorithm>
+#include <cfenv>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/goofer_hip.h"
+
+namespace {
+
+struct tap4 {
+    int32_t i[4];
+    double w[4];
+};
+
+inline int64_t floor_div(int64_t a, int64_t b) { return a / b - ((a % b != 0) && ((a < 0) != (b < 0))); }
+inline int64_t py_round(double x) { return (int64_t)std::nearbyint(x); }
+
+// x[a:b] on a sequence of length n (Python slice semantics), stop >= start
+inline void clip_slice(int64_t a, int64_t b, int64_t n, int64_t &lo, int64_t &hi)
+{
+    auto fix = [n](int64_t v) {
+        if (v < 0) {
+            v += n;
+            return v < 0 ? (int64_t)0 : v;
+        }
+        return v > n ? n : v;
+    };
+    lo = fix(a);
+    hi = std::max(lo, fix(b));
+}
+
+inline void linspace(double a, double b, int64_t n, std::vector<double> &out)
+{
+    out.resize((size_t)std::max<int64_t>(n, 0));
+    if (n <= 0) return;
+    if (n == 1) {
+        out[0] = a;
+        return;
+    }
+    const double delta = b - a, step = delta / (double)(n - 1);
+    if (step == 0.0) {
+        for (int64_t i = 0; i < n; ++i) out[i] = ((double)i / (double)(n - 1)) * delta + a;
+    } else {
+        for (int64_t i = 0; i < n; ++i) out[i] = (double)i * step + a;
+    }
+    out[n - 1] = b;
+}
+
+// np.interp(x_new, x_old, .) as (j, 1 - c, c): the planner's _interp_taps
+struct lerp_tap {
+    int32_t j;
+    double w0, w1;
+};
+inline lerp_tap interp_tap(const std::vector<double> &x_old, double x)
+{
+    const int64_t n = (int64_t)x_old.size();
+    if (n == 1) return {0, 1.0, 0.0};
+    int64_t j = (int64_t)(std::upper_bound(x_old.begin(), x_old.end(), x) - x_old.begin()) - 1;
+    j = std::min(std::max<int64_t>(j, 0), std::max<int64_t>(n - 2, 0));
+    double c = (x - x_old[j]) / (x_old[j + 1] - x_old[j]);
+    if (x == x_old[j]) c = 0.0;
+    if (x >= x_old[n - 1]) {
+        j = n - 2;
+        c = 1.0;
+    }
+    return {(int32_t)j, 1.0 - c, c};
+}
+
+// the planner's _interp_rows for one fp64 row (np.interp's formula + interp1d's linear extrapolation, GOOFER.py:204-205)
+inline double interp_row(const std::vector<double> &x_old, const double *y, double x)
+{
+    const int64_t n = (int64_t)x_old.size();
+    if (n == 1) return y[0];
+    if (x < x_old[0]) {
+        const double sl = (y[1] - y[0]) / (x_old[1] - x_old[0] + 1e-10);
+        return y[0] + sl * (x - x_old[0]);
+    }
+    if (x > x_old[n - 1]) {
+        const double sr = (y[n - 1] - y[n - 2]) / (x_old[n - 1] - x_old[n - 2] + 1e-10);
+        return y[n - 1] + sr * (x - x_old[n - 1]);
+    }
+    if (x >= x_old[n - 1]) return y[n - 1];
+    int64_t j = (int64_t)(std::upper_bound(x_old.begin(), x_old.end(), x) - x_old.begin()) - 1;
+    j = std::min(std::max<int64_t>(j, 0), n - 2);
+    if (x == x_old[j]) return y[j];
+    const double slope = (y[j + 1] - y[j]) / (x_old[j + 1] - x_old[j]);
+    return slope * (x - x_old[j]) + y[j];
+}
+
+// _prefix_positions: where output frame i of the velocity-stretched note sits on the frame axis before the stretch
+inline void prefix_positions(int64_t n, int64_t pre_len, double factor, std::vector<double> &pos)
+{
+    const int64_t pre_new = std::max<int64_t>(1, py_round((double)pre_len * factor));
+    const int64_t m = pre_new + (n - pre_len);
+    pos.resize((size_t)std::max<int64_t>(m, 0));
+    for (int64_t i = 0; i < m; ++i) pos[i] = i < pre_new ? (double)i / factor : (double)(i - pre_new) + (double)pre_len;
+}
+
+struct note_out {
+    goofer_plan_geometry g;
+    std::vector<tap4> taps;       // [n_out_rows]
+    std::vector<double> F;        // [n_out_rows x 4]
+    std::vector<float> fst;       // [n_out_rows x 4]
+};
+
+// pad_trim_to_len (GOOFER.py:64-70) on a non-empty vector
+template <typename T> inline void fit_len(std::vector<T> &v, int64_t T_)
+{
+    if ((int64_t)v.size() >= T_) v.resize((size_t)std::max<int64_t>(T_, 0));
+    else v.resize((size_t)T_, v.back());
+}
+
+struct scratch {
+    std::vector<tap4> stage1;
+    std::vector<double> xo, xn, pos, f, tmp, pad;
+    std::vector<float> tr, lp, canon, work;
+    std::vector<int32_t> rows;
+};
+
+// sanitize_smooth_formant's repair (SillySampler.py:264-279) on fp32 values x[0..T): returns false when every value is bad
+bool repair_track(float *x, int64_t T, float min_hz, float max_hz, scratch &s)
+{
+    int64_t n_bad = 0;
+    for (int64_t i = 0; i < T; ++i) n_bad += (!std::isfinite(x[i]) || x[i] < min_hz || x[i] > max_hz) ? 1 : 0;
+    if (n_bad == 0) return true;
+    if (n_bad == T) return false;
+    // good positions (as float32, like the reference's astype) and values
+    std::vector<double> &gx = s.xo, &gy = s.tmp;
+    gx.clear();
+    gy.clear();
+    std::vector<char> bad((size_t)T);
+    for (int64_t i = 0; i < T; ++i) {
+        bad[i] = (!std::isfinite(x[i]) || x[i] < min_hz || x[i] > max_hz) ? 1 : 0;
+        if (!bad[i]) {
+            gx.push_back((double)(float)i);
+            gy.push_back((double)x[i]);
+        }
+    }
+    const int64_t ng = (int64_t)gx.size();
+    const float x0 = (float)gx[0], xl = (float)gx[ng - 1], y0 = (float)gy[0], yl = (float)gy[ng - 1];
+    float sl = 0.f, sr = 0.f;
+    if (ng > 1) {      // float32 slopes of the two ends: (y1 - y0) / (x1 - x0 + 1e-10) with every operand float32
+        sl = ((float)gy[1] - y0) / (((float)gx[1] - x0) + 1e-10f);
+        sr = (yl - (float)gy[ng - 2]) / ((xl - (float)gx[ng - 2]) + 1e-10f);
+    }
+    for (int64_t i = 0; i < T; ++i) {
+        if (!bad[i]) continue;
+        const float q = (float)i;
+        if (ng == 1) {
+            x[i] = y0;
+        } else if (q < x0) {
+            x[i] = y0 + sl * (q - x0);
+        } else if (q > xl) {
+            x[i] = yl + sr * (q - xl);
+        } else {
+            const double qd = (double)q;
+            int64_t j = (int64_t)(std::upper_bound(gx.begin(), gx.end(), qd) - gx.begin()) - 1;
+            const double slope = (gy[j + 1] - gy[j]) / (gx[j + 1] - gx[j]);
+            x[i] = (float)(slope * (qd - gx[j]) + gy[j]);
+        }
+    }
+    return true;
+}
+
+// One note.  status != 0: a case the reference answers with an exception (or Python slicing of negative counts) — the caller
+// re-plans the batch with the numpy planner, which raises what the reference raises.
+void plan_one(const goofer_plan_request &r, int hop, int trim_rows, const double *gtaps, int gradius, note_out &o, scratch &s)
+{
+    goofer_plan_geometry &g = o.g;
+    std::memset(&g, 0, sizeof(g));
+    const double sr = (double)r.sr;
+    const int64_t ylen = r.ylen, T_src = r.n_src_frames;
+    // -- cut points (:453-487)
+    const double total = (double)ylen / sr;
+    const double a0 = r.offset;
+    const double b0 = r.cutoff < 0 ? (r.offset - r.cutoff) : (total - r.cutoff);
+    double off = r.offset, cut = r.cutoff;
+    if (r.reverse) {
+        const double L = b0 - a0;
+        off = total - b0;
+        cut = total - (off + L);
+    }
+    const int64_t s0 = (int64_t)(off * sr);
+    const int64_t s1 = s0 + (int64_t)(r.consonant * sr);
+    const int64_t s2 = (int64_t)((cut < 0 ? (off - cut) : (total - cut)) * sr);
+    const int64_t fr0 = floor_div(s0, hop), fr1 = floor_div(s1, hop), fr2 = floor_div(s2, hop);
+    g.start_sample = s0; g.consonant_sample = s1; g.end_sample = s2;
+    g.start_frame = (int32_t)fr0; g.consonant_frame = (int32_t)fr1; g.end_frame = (int32_t)fr2;
+
+    int64_t f0a, f0b, f1a, f1b;
+    clip_slice(fr0, fr1, T_src, f0a, f0b);
+    clip_slice(fr1, fr2, T_src, f1a, f1b);
+    const int64_t n_pre_f = f0b - f0a, n_tail = f1b - f1a;
+    const int64_t want_f = (int64_t)std::ceil(r.length * sr / (double)hop);
+    const int64_t want_s = (int64_t)(r.length * sr);
+    int64_t s0a, s0b, s1a, s1b;
+    clip_slice(s0, s1, ylen, s0a, s0b);
+    clip_slice(s1, s2, ylen, s1a, s1b);
+    const int64_t n_pre = s0b - s0a, tail_len = s1b - s1a;
+    if (want_f < 0 || want_s < 0 || (n_tail < want_f && n_tail == 0) || (tail_len < want_s && tail_len == 0)) {
+        g.status = 1;
+        return;
+    }
+    // -- loop-mode frame taps (:631-696)
+    std::vector<tap4> &st = s.stage1;
+    st.clear();
+    bool f64 = false;
+    auto copy_row = [&](int64_t row) { st.push_back(tap4{{(int32_t)row, (int32_t)row, 0, 0}, {1.0, 0.0, 0.0, 0.0}}); };
+    for (int64_t q = f0a; q < f0b; ++q) copy_row(q);
+    if (n_tail >= want_f) {
+        for (int64_t q = 0; q < want_f; ++q) copy_row(f1a + q);
+    } else if (r.loop_mode == 2) {
+        const int64_t n_new = (int64_t)((double)n_tail * ((double)want_f / (double)n_tail));
+        linspace(0.0, 1.0, n_tail, s.xo);
+        linspace(0.0, 1.0, n_new, s.xn);
+        for (int64_t q = 0; q < n_new; ++q) {
+            const lerp_tap t = interp_tap(s.xo, s.xn[q]);
+            const int32_t j1 = n_tail == 1 ? t.j : t.j + 1;
+            st.push_back(tap4{{(int32_t)(f1a + t.j), (int32_t)(f1a + j1), 0, 0}, {t.w0, t.w1, 0.0, 0.0}});
+        }
+        f64 = true;                                            // even when n_new == 0: Taps(.., True) of an empty stretch is not counted (len 0)
+        if (n_new == 0) f64 = false;
+    } else if (r.loop_mode == 1) {
+        const int64_t reps = want_f / n_tail, rem = want_f % n_tail;
+        for (int64_t c = 0; c <= reps; ++c) {
+            const int64_t m = c < reps ? n_tail : rem;
+            for (int64_t q = 0; q < m; ++q) st.push_back(tap4{{(int32_t)(f1a + q), (int32_t)(f1a + n_tail - 1 - q), 0, 0}, {0.5, 0.5, 0.0, 0.0}});
+        }
+    } else {
+        // L0: every repeat but the last is "the tail, its last k frames cross-faded into the first k of a fresh copy, then the
+        // rest of that copy" — and the fresh copy is appended again as the next chunk (:657-672)
+        const int64_t n = n_tail, reps = want_f / n, rem = want_f % n;
+        auto faded = [&](int64_t m, int64_t k) {               // tail[:n-k] + cross-fade(k) + first m frames of the tail from k on
+            for (int64_t q = 0; q < n - k; ++q) copy_row(f1a + q);
+            if (k > 0) {
+                linspace(0.0, 1.0, k, s.xo);                   // up
+                linspace(1.0, 0.0, k, s.xn);                   // down
+                for (int64_t q = 0; q < k; ++q) st.push_back(tap4{{(int32_t)(f1a + n - k + q), (int32_t)(f1a + q), 0, 0}, {s.xn[q], s.xo[q], 0.0, 0.0}});
+                f64 = true;
+            }
+            for (int64_t q = k; q < m; ++q) copy_row(f1a + q);
+        };
+        const int64_t k = std::min<int64_t>(8, n / 2);
+        for (int64_t c = 0; c + 1 < reps; ++c) {
+            if (k == 0) for (int64_t q = 0; q < n; ++q) copy_row(f1a + q);      // a one-frame tail: the chunk is the tail itself
+            else faded(n, k);
+        }
+        if (rem) {
+            const int64_t kr = std::min<int64_t>(8, rem / 2);
+            if (kr > 0) {
+                faded(rem, kr);
+            } else {
+                for (int64_t q = 0; q < n; ++q) copy_row(f1a + q);
+                for (int64_t q = 0; q < rem; ++q) copy_row(f1a + q);
+            }
+        } else {
+            for (int64_t q = 0; q < n; ++q) copy_row(f1a + q);
+        }
+    }
+    const int64_t n1 = (int64_t)st.size();                     // T_target
+    // -- samples and the velocity prefix stretch (:698-788)
+    g.n_pre = (int32_t)n_pre; g.tail_len = (int32_t)tail_len; g.want_samples = (int32_t)want_s;
+    g.s_pre = (int32_t)s0a; g.s_tail = (int32_t)s1a;
+    g.n_before_vel = (int32_t)(n_pre + want_s);
+    const double vel = r.vel_factor;
+    const bool vel_active = std::fabs(vel - 1.0) > 1e-6 && n_pre_f > 1 && n_pre > 1;
+    g.vel_active = vel_active ? 1 : 0;
+    g.vel_factor = vel_active ? vel : 1.0;
+    std::vector<tap4> &out = o.taps;
+    out.clear();
+    if (vel_active) {
+        prefix_positions(n1, n_pre_f, vel, s.pos);
+        s.xo.resize((size_t)n1);
+        for (int64_t q = 0; q < n1; ++q) s.xo[q] = (double)q;
+        out.reserve(s.pos.size());
+        for (double p : s.pos) {
+            const lerp_tap t = interp_tap(s.xo, p);
+            const tap4 &a = st[t.j], &b = st[t.j + 1];
+            out.push_back(tap4{{a.i[0], a.i[1], b.i[0], b.i[1]}, {a.w[0] * t.w0, a.w[1] * t.w0, b.w[0] * t.w1, b.w[1] * t.w1}});
+        }
+        f64 = true;
+        const int64_t pre_new = std::max<int64_t>(1, py_round((double)n_pre * vel));
+        g.pre_new = (int32_t)pre_new;
+        g.n_out = (int32_t)(pre_new + want_s);
+    } else {
+        out.reserve((size_t)n1);
+        for (const tap4 &a : st) out.push_back(tap4{{a.i[0], a.i[1], a.i[0], a.i[1]}, {a.w[0], a.w[1], 0.0, 0.0}});
+        g.pre_new = (int32_t)n_pre;
+        g.n_out = g.n_before_vel;
+    }
+    g.env_f64 = f64 ? 1 : 0;
+    const int64_t T_full = (int64_t)out.size();
+    g.n_rows = (int32_t)T_full;
+    int64_t T_env = T_full;
+    if (trim_rows && g.n_out > 0 && T_env > 1 + g.n_out / hop) T_env = 1 + g.n_out / hop;   // gf.synthesize never reads further (GOOFER.py:1115-1119)
+    g.n_out_rows = (int32_t)T_env;
+    int32_t lo = INT32_MAX, hi = -1;
+    for (int64_t t = 0; t < T_env; ++t)
+        for (int c = 0; c < 4; ++c)
+            if (out[t].w[c] != 0.0) {
+                lo = std::min(lo, out[t].i[c]);
+                hi = std::max(hi, out[t].i[c]);
+            }
+    g.row_lo = hi < 0 ? 0 : lo;
+    g.row_hi = hi < 0 ? 0 : hi + 1;
+
+    // -- vocal fry ranges (:883-955)
+    {
+        const int64_t n = g.n_out;
+        const double vf = r.fry;
+        if (vf != 0.0) {
+            const int64_t L = py_round((double)n * (std::fabs(vf) / 100.0));
+            if (L > 0) {
+                const int64_t gl = std::min(std::max<int64_t>(py_round((double)L * (r.fry_glide / 100.0)), 0), L), cl = L - gl;
+                g.fry_dir = vf > 0 ? 1 : -1;
+                if (vf > 0) {
+                    g.fry_const_lo = 0; g.fry_const_hi = (int32_t)cl; g.fry_glide_lo = (int32_t)cl; g.fry_glide_hi = (int32_t)L;
+                } else {
+                    const int64_t stt = n - L;
+                    g.fry_glide_lo = (int32_t)stt; g.fry_glide_hi = (int32_t)(stt + gl); g.fry_const_lo = (int32_t)(stt + gl); g.fry_const_hi = (int32_t)n;
+                }
+            }
+            const int64_t mid = floor_div(n, 2);
+            int64_t a, b;
+            if (vf > 0) {
+                a = 0;
+                b = std::max<int64_t>(0, std::min(n, py_round((double)mid * (vf / 100.0))));
+            } else {
+                a = std::max<int64_t>(0, n - py_round((double)(n - mid) * (std::fabs(vf) / 100.0)));
+                b = n;
+            }
+            if (b > a) {
+                g.fry_a = (int32_t)a; g.fry_b = (int32_t)b;
+                g.fry_fade = (int32_t)(0.01 * sr);
+            }
+        }
+    }
+
+    // -- formant tracks (:714-763, 771-806)
+    o.F.assign((size_t)T_env * 4, 0.0);
+    o.fst.assign((size_t)T_env * 4, 0.f);
+    const float max_hz = (float)(sr * 0.48);
+    const float min_hz[4] = {120.0f, 300.0f, 1500.0f, 2000.0f};
+    for (int c = 0; c < 4; ++c) {
+        const double *src = r.tracks[c];
+        const int64_t Tk = r.track_len[c];                     // < 0: the source has no such track
+        auto at = [&](int64_t i) { return r.reverse ? src[Tk - 1 - i] : src[i]; };
+        std::vector<double> &f = s.f;
+        f.clear();
+        if (Tk >= 0) {
+            int64_t pa, pb, ta, tb;
+            clip_slice(fr0, fr1, Tk, pa, pb);
+            clip_slice(fr1, fr2, Tk, ta, tb);
+            for (int64_t q = pa; q < pb; ++q) f.push_back(at(q));
+            const int64_t L = tb - ta;
+            std::vector<float> &tr = s.tr, &lp = s.lp;
+            tr.resize((size_t)L);
+            for (int64_t q = 0; q < L; ++q) tr[q] = (float)at(ta + q);
+            lp.clear();
+            if (L == 0) {
+                lp.assign((size_t)want_f, 0.f);
+            } else if (r.loop_mode == 2) {
+                const double factor = (double)want_f / (double)L;
+                if (factor == 1.0) {
+                    lp = tr;
+                } else {
+                    const int64_t n_new = (int64_t)((double)L * factor);
+                    linspace(0.0, 1.0, L, s.xo);
+                    linspace(0.0, 1.0, n_new, s.xn);
+                    s.tmp.resize((size_t)L);
+                    for (int64_t q = 0; q < L; ++q) s.tmp[q] = (double)tr[q];
+                    lp.resize((size_t)std::max<int64_t>(n_new, 0));
+                    for (int64_t q = 0; q < n_new; ++q) lp[q] = (float)interp_row(s.xo, s.tmp.data(), s.xn[q]);
+                }
+            } else {
+                const int64_t reps = want_f / L, rem = want_f % L;
+                lp.reserve((size_t)want_f);
+                for (int64_t cc = 0; cc <= reps; ++cc) {
+                    const int64_t m = cc < reps ? L : rem;
+                    for (int64_t q = 0; q < m; ++q) lp.push_back(r.loop_mode == 1 ? (tr[q] + tr[L - 1 - q]) * 0.5f : tr[q]);
+                }
+            }
+            for (float v : lp) f.push_back((double)v);
+        }
+        std::vector<float> &canon = s.canon;
+        canon.clear();
+        if (!f.empty()) {
+            if (n1 == 0) {                                     // pad_trim of a non-empty track to zero frames: empty, i.e. no track
+                f.clear();
+            } else {
+                fit_len(f, n1);
+                if (vel_active) {                              // (n1 >= 2 here)
+                    s.tmp = f;
+                    s.xo.resize((size_t)n1);
+                    for (int64_t q = 0; q < n1; ++q) s.xo[q] = (double)q;
+                    f.resize(s.pos.size());
+                    for (size_t q = 0; q < s.pos.size(); ++q) f[q] = interp_row(s.xo, s.tmp.data(), s.pos[q]);
+                    if (!f.empty()) fit_len(f, T_full);
+                }
+                canon.resize(f.size());
+                for (size_t q = 0; q < f.size(); ++q) canon[q] = (float)f[q];
+                if (!canon.empty()) fit_len(canon, n1);       // the canon tracks use the PRE-velocity frame count (:791-806)
+            }
+        }
+        // repair on [0, T_full): in place on the canon track when it is long enough (the repaired values then reach
+        // synthesize: the reference's aliasing), on a padded copy otherwise; an all-bad track becomes 300 Hz and leaves the canon alone
+        std::vector<float> &work = s.work;
+        const bool have = !canon.empty();
+        float *wp;
+        if (have && (int64_t)canon.size() >= T_full) {
+            wp = canon.data();
+        } else {
+            work.assign(canon.begin(), canon.end());
+            if (have) fit_len(work, T_full);
+            else work.assign((size_t)T_full, 0.f);
+            wp = work.data();
+        }
+        bool all_bad = false;
+        if (T_full > 0) {
+            all_bad = !repair_track(wp, T_full, min_hz[c], max_hz, s);   // (writes only when some value is good: an all-bad canon stays)
+        }
+        // sigma-4 blur of the repaired track (fp64 taps in ascending order, numpy 'reflect'), rounded to fp32
+        if (T_full > 0) {
+            std::vector<double> &pad = s.pad;
+            pad.resize((size_t)(T_full + 2 * gradius));
+            const int64_t period = T_full > 1 ? 2 * (T_full - 1) : 1;
+            for (int64_t q = -gradius; q < T_full + gradius; ++q) {
+                int64_t m = T_full > 1 ? ((q % period) + period) % period : 0;
+                m = m < T_full ? m : period - m;
+                pad[q + gradius] = all_bad ? 300.0 : (double)wp[m];
+            }
+            for (int64_t t = 0; t < T_env; ++t) {
+                double acc = gtaps[0] * pad[t];
+                for (int j = 1; j < 2 * gradius + 1; ++j) {
+                    const double prod = gtaps[j] * pad[t + j];
+                    acc = acc + prod;
+                }
+                o.fst[(size_t)t * 4 + c] = (float)acc;
+            }
+        }
+        if (have) {
+            const int64_t Lc = (int64_t)canon.size();
+            for (int64_t t = 0; t < T_env; ++t) o.F[(size_t)t * 4 + c] = (double)canon[t < Lc ? t : Lc - 1];
+        }
+    }
+    out.resize((size_t)T_env);
+}
+
+}  // namespace
+
+struct goofer_host_plans {
+    std::vector<goofer_plan_geometry> geo;
+    std::vector<int32_t> tap_idx;
+    std::vector<double> tap_w, F;
+    std::vector<float> fst;
+    int64_t rows = 0;
+};
+
+extern "C" {
+
+int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps,
+                           int gauss_radius, int n_threads, goofer_host_plans **out)
+{
+    if (!req || !out || n_notes < 0 || hop <= 0 || !gauss_taps || gauss_radius < 0) return GOOFER_EINVAL;
+    for (int i = 0; i < n_notes; ++i)
+        if (req[i].sr <= 0 || req[i].ylen < 0 || (req[i].track_len[0] > 0 && !req[i].tracks[0]) || req[i].n_src_frames < 0 || req[i].ylen > INT32_MAX || req[i].loop_mode < 0 || req[i].loop_mode > 2)
+            return GOOFER_EINVAL;
+    std::vector<note_out> notes((size_t)n_notes);
+    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    nt = std::max(1, std::min(nt, (n_notes + 63) / 64));
+    auto work = [&](int t) {
+        std::fesetround(FE_TONEAREST);
+        scratch s;
+        for (int i = t; i < n_notes; i += nt) plan_one(req[i], hop, trim_rows, gauss_taps, gauss_radius, notes[i], s);
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    goofer_host_plans *h = new (std::nothrow) goofer_host_plans;
+    if (!h) return GOOFER_ENOMEM;
+    h->geo.resize((size_t)n_notes);
+    int64_t rows = 0;
+    for (int i = 0; i < n_notes; ++i) {
+        notes[i].g.tap_off = rows;
+        h->geo[i] = notes[i].g;
+        if (notes[i].g.status == 0) rows += notes[i].g.n_out_rows;
+    }
+    h->rows = rows;
+    h->tap_idx.resize((size_t)rows * 4);
+    h->tap_w.resize((size_t)rows * 4);
+    h->F.resize((size_t)rows * 4);
+    h->fst.resize((size_t)rows * 4);
+    auto gather = [&](int t) {
+        for (int i = t; i < n_notes; i += nt) {
+            const note_out &o = notes[i];
+            if (o.g.status != 0) continue;
+            const int64_t r0 = o.g.tap_off, T = o.g.n_out_rows;
+            for (int64_t q = 0; q < T; ++q)
+                for (int c = 0; c < 4; ++c) {
+                    h->tap_idx[(size_t)(r0 + q) * 4 + c] = o.taps[q].i[c];
+                    h->tap_w[(size_t)(r0 + q) * 4 + c] = o.taps[q].w[c];
+                }
+            if (T > 0) {
+                std::memcpy(&h->F[(size_t)r0 * 4], o.F.data(), (size_t)T * 4 * sizeof(double));
+                std::memcpy(&h->fst[(size_t)r0 * 4], o.fst.data(), (size_t)T * 4 * sizeof(float));
+            }
+        }
+    };
+    if (nt == 1) {
+        gather(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(gather, t);
+        gather(0);
+        for (auto &x : th) x.join();
+    }
+    *out = h;
+    return GOOFER_OK;
+}
+
+int goofer_host_plans_view(const goofer_host_plans *h, const goofer_plan_geometry **geometry, int64_t *rows, const int32_t **tap_idx,
+                           const double **tap_w, const double **formants, const float **fst_tracks)
+{
+    if (!h) return GOOFER_EINVAL;
+    if (geometry) *geometry = h->geo.data();
+    if (rows) *rows = h->rows;
+    if (tap_idx) *tap_idx = h->tap_idx.data();
+    if (tap_w) *tap_w = h->tap_w.data();
+    if (formants) *formants = h->F.data();
+    if (fst_tracks) *fst_tracks = h->fst.data();
+    return GOOFER_OK;
+}
+
+void goofer_host_plans_free(goofer_host_plans *h) { delete h; }
+
+// UTAU pitch-bend strings (SillySampler.py:56-84): base64 pairs = 12-bit two's complement cents, "#n#" = repeat the last
+// value n more times.  text = the strings back to back, text_off[n + 1] their bounds.  out == NULL: only count.  Returns the
+// total number of values (out_off[n + 1] = where each note's values start), or -(i + 1) when string i is not well formed (odd
+// segment, bad character, a run with nothing in front, an empty string: the caller's character loop then raises — or
+// answers — what the reference does).
+int64_t goofer_host_decode_bends(const char *text, const int64_t *text_off, int n, float *out, int64_t capacity, int64_t *out_off)
+{
+    if (!text || !text_off || n < 0 || !out_off) return 0;
+    static const auto lut = [] {
+        std::vector<int> t(256, -1);
+        for (int c = 0; c < 256; ++c) {
+            if (c >= 'a' && c <= 'z') t[c] = c - 71;
+            else if (c >= 'A' && c <= 'Z') t[c] = c - 65;
+            else if (c >= '0' && c <= '9') t[c] = c + 4;
+            else if (c == '+') t[c] = 62;
+            else if (c == '/') t[c] = 63;
+        }
+        return t;
+    }();
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        out_off[i] = total;
+        const char *p = text + text_off[i], *e = text + text_off[i + 1];
+        bool have = false;
+        float last = 0.f;
+        int64_t count = 0;
+        while (p < e) {
+            // a segment of base64 pairs up to '#' or the end
+            const char *q = p;
+            while (q < e && *q != '#') ++q;
+            if ((q - p) & 1) return -(int64_t)(i + 1);
+            for (; p < q; p += 2) {
+                const int a = lut[(unsigned char)p[0]], b = lut[(unsigned char)p[1]];
+                if (a < 0 || b < 0) return -(int64_t)(i + 1);
+                int v = (a << 6) | b;
+                if (v & 0x800) v -= 4096;
+                last = (float)v;
+                have = true;
+                if (out && total + count < capacity) out[total + count] = last;
+                ++count;
+            }
+            if (p >= e) break;
+            // "#digits#" (the closing '#' may be missing at the end of the string: str.split still yields the count)
+            ++p;
+            const char *d = p;
+            int64_t run = 0;
+            while (p < e && *p != '#') {
+                if (*p < '0' || *p > '9' || run > (1 << 24)) return -(int64_t)(i + 1);
+                run = run * 10 + (*p - '0');
+                ++p;
+            }
+            if (p == d || !have) return -(int64_t)(i + 1);
+            for (int64_t k = 0; k < run; ++k) {
+                if (out && total + count < capacity) out[total + count] = last;
+                ++count;
+            }
+            if (p < e) ++p;                                   // the closing '#'
+        }
+        if (count == 0) return -(int64_t)(i + 1);
+        total += count;
+    }
+    out_off[n] = total;
+    return total;
+}
+
+}  // extern "C"

@@ -40,6 +40,14 @@ class Source:
             object.__setattr__(self, "_knot_rows", kr)
         return kr
 
+    def tracks64(self):
+        """F1..F4 as the library's host planner takes them (``sampler.source_tracks64``; None: not the plain fp64 case)."""
+        t = getattr(self, "_tracks64", False)
+        if t is False:
+            t = S.source_tracks64(self.formants)
+            object.__setattr__(self, "_tracks64", t)
+        return t
+
     @staticmethod
     def from_pack(env_pack, f0, mask, formants, sr, ylen):
         """Features as load_features returns them.  Everything the device kernels index by these sizes is checked here —
@@ -104,10 +112,63 @@ def _fw_plan(n_bins, amount):
     return lo.astype(np.int32), np.minimum(lo + 1, n_bins - 1).astype(np.int32), (w - lo)
 
 
+class SourceArena:
+    """Voicebank samples resident in HBM: the fp16 knot tables (frame-major) and the voicing masks of every Source a Renderer has
+    seen, back to back in two device arrays that only grow.  A render job touches a few hundred samples thousands of times; each
+    is uploaded once and the notes' plans carry element offsets into the arrays (goofer_note_plan.knot_off / src_sample_off).
+    288 GB of HBM holds any voicebank: ``budget_bytes`` (default 48 GiB) only bounds a process that streams unrelated
+    sources for days — past it the arena starts over in fresh arrays (batches already prepared keep the old ones alive)."""
+
+    def __init__(self, ctx: Context, budget_bytes: int = 48 << 30):
+        import threading
+        self.ctx, self.budget = ctx, int(budget_bytes)
+        self.lock = threading.Lock()
+        self._reset()
+
+    def _reset(self):
+        self.where = {}                                        # id(Source) -> (Source, knot_off, sample_off)
+        self.knots = torch.empty(0, dtype=torch.int16, device=self.ctx.device)
+        self.mask = torch.empty(0, dtype=torch.float32, device=self.ctx.device)
+        self.k_used = self.m_used = 0
+
+    @staticmethod
+    def _grown(t, used, need):
+        if used + need <= t.numel():
+            return t
+        new = torch.empty(max(2 * t.numel(), used + need, 1 << 20), dtype=t.dtype, device=t.device)
+        new[:used].copy_(t[:used])
+        return new
+
+    def place(self, sources):
+        """(knot_off, sample_off) int64 arrays for ``sources``, uploading the ones not resident yet; also the two device
+        arrays those offsets index (to be kept alive with the batch)."""
+        with self.lock:
+            fresh = [sc for sc in {id(sc): sc for sc in sources}.values() if id(sc) not in self.where]
+            if fresh:
+                nk, nm = sum(sc.knots.size for sc in fresh), sum(sc.ylen for sc in fresh)
+                if 2 * (self.k_used + nk) + 4 * (self.m_used + nm) > self.budget and self.where:
+                    self._reset()
+                    fresh = list({id(sc): sc for sc in sources}.values())
+                    nk, nm = sum(sc.knots.size for sc in fresh), sum(sc.ylen for sc in fresh)
+                self.knots = self._grown(self.knots, self.k_used, nk)
+                self.mask = self._grown(self.mask, self.m_used, nm)
+                kc = np.concatenate([sc.knot_rows() for sc in fresh]).view(np.int16)
+                mc = np.concatenate([sc.mask[:sc.ylen] for sc in fresh]).astype(np.float32, copy=False)
+                self.knots[self.k_used:self.k_used + nk].copy_(torch.from_numpy(kc))
+                self.mask[self.m_used:self.m_used + nm].copy_(torch.from_numpy(mc))
+                for sc in fresh:
+                    self.where[id(sc)] = (sc, self.k_used, self.m_used)
+                    self.k_used += sc.knots.size
+                    self.m_used += sc.ylen
+            at = [self.where[id(sc)] for sc in sources]
+            return (np.array([a[1] for a in at], dtype=np.int64), np.array([a[2] for a in at], dtype=np.int64), self.knots, self.mask)
+
+
 class Renderer:
     def __init__(self, ctx: Context | None = None, hop: int = S.HOP):
         self.ctx = ctx or default_context()
         self.hop = hop
+        self.sources = SourceArena(self.ctx)
 
     def render(self, jobs, seed: int = 0, phi_seeds=None, return_parts: bool = False):
         """jobs: list of (Source, Request).  Returns a list of fp32 arrays (the mix the reference writes to
@@ -124,7 +185,7 @@ class Renderer:
         res = [mix[offs[i]:offs[i + 1]] for i in range(len(jobs))]
         if return_parts:
             parts = {"env": prep["env"], "f0": prep["f0"], "mask": prep["mask"], "env_off": prep["env_off"], "sample_off": offs,
-                     "plans": prep["plans"], "stems": out}
+                     "planned": prep["planned"], "stems": out}
             return res, parts
         return res
 
@@ -262,160 +323,140 @@ class Renderer:
         ``trim_rows``: assemble only the envelope rows synthesize can reach.  The reference's L0 loop hands over more
         envelope frames than the note has STFT frames (every cross-faded repeat is appended again, SillySampler.py:657-672)
         and ``gf.synthesize`` cuts the envelope to ``1 + n // hop`` frames (GOOFER.py:1115-1119): the rows behind that are
-        never read — a fifth of the rows of a one-second note.  ``False`` keeps them (tests that compare the whole envelope)."""
+        never read — a fifth of the rows of a one-second note.  ``False`` keeps them (tests that compare the whole envelope).
+
+        Host cost: the per-note decisions run in the library's host planner (a batch per call, csrc/planner.hip) and everything
+        here is column arithmetic over the batch — no per-note Python except a handful of attribute reads."""
         ctx = self.ctx
         sr, n_fft = jobs[0][0].sr, jobs[0][0].n_fft
-        if any(j[0].sr != sr or j[0].n_fft != n_fft for j in jobs):
+        n = len(jobs)
+        srcs = [j[0] for j in jobs]
+        reqs = [j[1] for j in jobs]
+        # distinct sources (a voicebank sample rendered by several notes is uploaded once: same Source object)
+        uniq, src_ix = {}, np.empty(n, dtype=np.int64)
+        for i, sc in enumerate(srcs):
+            src_ix[i] = uniq.setdefault(id(sc), len(uniq))
+        usrc = [None] * len(uniq)
+        for sc in srcs:
+            usrc[uniq[id(sc)]] = sc
+        if any(sc.sr != sr or sc.n_fft != n_fft for sc in usrc):
             raise ValueError("one batch must share sr / n_fft")
         ctx.plan(sr, n_fft, self.hop)
         B, ld = ctx.n_bins, row_stride(ctx.n_bins)
-        n = len(jobs)
-        for src, req in jobs:
-            T_src = src.knots.shape[1]
-            if T_src != 1 + src.ylen // self.hop:             # frames of the analysis STFT (GOOFER.py:355-370)
-                raise ValueError(f"bad features: envelope has {T_src} frames, y_len {src.ylen} at hop {self.hop} implies "
-                                 f"{1 + src.ylen // self.hop}")
-        # notes that share cut points / lengths share one index plan; their formant tracks are processed as one array
-        plans = S.plan_notes([(req, src.sr, src.ylen, src.knots.shape[1], src.formants) for src, req in jobs], self.hop)
+        for sc in usrc:
+            T_src = sc.knots.shape[1]
+            if T_src != 1 + sc.ylen // self.hop:               # frames of the analysis STFT (GOOFER.py:355-370)
+                raise ValueError(f"bad features: envelope has {T_src} frames, y_len {sc.ylen} at hop {self.hop} implies "
+                                 f"{1 + sc.ylen // self.hop}")
+        u_K = np.array([sc.knots.shape[0] for sc in usrc], dtype=np.int64)
+        u_T = np.array([sc.knots.shape[1] for sc in usrc], dtype=np.int64)
+        u_ylen = np.array([sc.ylen for sc in usrc], dtype=np.int64)
+        u_koff, u_soff, d_knots, d_mask_src = self.sources.place(usrc)   # resident in HBM; new samples are uploaded here
+        lerp_keys, lerp_tabs, u_lerp = {}, [], np.full(len(usrc), -1, dtype=np.int64)
+        for k, sc in enumerate(usrc):
+            if sc.hz_knots is None:                            # dense source: rows are the envelope, no lerp plan
+                if sc.knots.shape[0] != B:
+                    raise ValueError("dense envelope has %d bins, the plan has %d" % (sc.knots.shape[0], B))
+                continue
+            key = (sc.knots.shape[0], sc.hz_knots.tobytes())
+            if key not in lerp_keys:
+                lerp_keys[key] = len(lerp_tabs)
+                lerp_tabs.append(_lerp_plan(sr, n_fft, sc.hz_knots))
+            u_lerp[k] = lerp_keys[key]
 
-        # tables shared across notes
-        lerp_keys, tilt_keys, fw_keys, es_keys = {}, {}, {}, {}
-        lerp_tabs, tilt_tabs, fw_tabs, es_taps, es_off = [], [], [], [], 0
-        P = np.zeros(n, dtype=_lib.NOTE_PLAN)
-        col = {k: [] for k in ("knot_off", "K", "lerp_plan", "n_src_rows", "reverse", "row_lo", "n_edit", "edit_off", "tilt", "es_mode",
-                               "es_amount", "es_taps_off", "es_radius", "fw_plan", "tap_off", "env_off", "n_out_rows", "env_f64", "fst",
-                               "src_sample_off", "ylen", "out_sample_off", "n_out", "n_pre", "s_pre", "s_tail", "tail_len",
-                               "want_samples", "n_before_vel", "vel_active", "vel_factor", "pre_new", "force_voiced", "bend_off", "n_bend",
-                               "pitch_m", "pitch_t", "tick_dt", "fry_hz", "fry_dir", "fry_const_lo", "fry_const_hi", "fry_glide_lo",
-                               "fry_glide_hi", "fry_a", "fry_b", "fry_fade", "pd_on", "pd_base")}
-        knots_cat, mask_cat, bend_cat, tapi_cat, tapw_cat, fst_cat, F_cat = [], [], [], [], [], [], []
-        k_off = e_off = t_off = s_off = o_off = b_off = 0
-        hz_ids, live_rows, env_lens, src_at = {}, {}, [], {}
-        for i, ((src, req), p) in enumerate(zip(jobs, plans)):
-            K = src.knots.shape[0]
-            if src.hz_knots is None:                           # dense source: rows are the envelope, no lerp plan
-                if K != B:
-                    raise ValueError("dense envelope has %d bins, the plan has %d" % (K, B))
-                lp = -1
-            else:
-                lp = hz_ids.get(id(src.hz_knots))              # the same array object again (one voicebank): no hashing of its bytes
-                if lp is None:
-                    key = (K, src.hz_knots.tobytes())
-                    if key not in lerp_keys:
-                        lerp_keys[key] = len(lerp_tabs)
-                        lerp_tabs.append(_lerp_plan(sr, n_fft, src.hz_knots))
-                    lp = hz_ids[id(src.hz_knots)] = lerp_keys[key]
-            c = col
-            # a voicebank sample rendered by several notes of the batch is uploaded once (same Source object)
-            placed = src_at.get(id(src))
-            if placed is None:
-                placed = src_at[id(src)] = (k_off, s_off)
-                knots_cat.append(src.knot_rows())
-                mask_cat.append(src.mask[:src.ylen])
-                k_off += src.knots.size
-                s_off += src.ylen
-            c["knot_off"].append(placed[0]); c["K"].append(K); c["lerp_plan"].append(lp); c["n_src_rows"].append(src.knots.shape[1])
-            c["reverse"].append(int(req.reverse))
-            tilt = -1
-            if req.brightness_env != 1.0:
-                tk = float(req.brightness_env)
-                if tk not in tilt_keys:
-                    tilt_keys[tk] = len(tilt_tabs)
-                    tilt_tabs.append(_tilt(sr, B, req.brightness_env))
-                tilt = tilt_keys[tk]
-            c["tilt"].append(tilt)
-            es_mode, es_amount, es_toff, es_rad = 0, 0.0, 0, 0
-            if req.env_shape != 0.0:
-                s_ = abs(req.env_shape)
-                es_mode = 1 if req.env_shape < 0.0 else 2
-                sigma = (1.0 + 6.0 * s_) if es_mode == 1 else (0.8 + 4.0 * s_)
-                ek = (es_mode, sigma)
-                if ek not in es_keys:
-                    taps = S.gauss_taps(sigma)
-                    es_keys[ek] = (es_off, (taps.size - 1) // 2)
-                    es_taps.append(taps)
-                    es_off += taps.size
-                es_amount = 5 * s_
-                es_toff, es_rad = es_keys[ek]
-            c["es_mode"].append(es_mode); c["es_amount"].append(es_amount); c["es_taps_off"].append(es_toff); c["es_radius"].append(es_rad)
-            fw = -1
-            if req.formant_width != 0.0:
-                fk = float(req.formant_width)
-                if fk not in fw_keys:
-                    fw_keys[fk] = len(fw_tabs)
-                    fw_tabs.append(_fw_plan(B, req.formant_width))
-                fw = fw_keys[fk]
-            c["fw_plan"].append(fw)
-            T_env = p.tap_idx.shape[0]
-            row_lo, row_hi = p.row_lo, p.row_hi
-            if trim_rows and T_env > 1 + p.n_out // self.hop:
-                T_env = 1 + p.n_out // self.hop
-                lim = live_rows.get(id(p.tap_idx))             # notes of one geometry share the tap arrays
-                if lim is None or lim[0] != T_env:
-                    used = p.tap_idx[:T_env][p.tap_w[:T_env] != 0.0]
-                    lim = live_rows[id(p.tap_idx)] = (T_env, int(used.min()) if used.size else 0, int(used.max()) + 1 if used.size else 0)
-                row_lo, row_hi = lim[1], lim[2]
-            c["row_lo"].append(row_lo); c["n_edit"].append(row_hi - row_lo); c["edit_off"].append(e_off)
-            c["tap_off"].append(t_off); c["env_off"].append(t_off); c["n_out_rows"].append(T_env); c["env_f64"].append(int(p.env_f64))
-            c["fst"].append(req.formant_strength)
-            c["src_sample_off"].append(placed[1]); c["ylen"].append(src.ylen); c["out_sample_off"].append(o_off)
-            c["n_out"].append(p.n_out); c["n_pre"].append(p.n_pre); c["s_pre"].append(p.extra["s_pre"]); c["s_tail"].append(p.extra["s_tail"])
-            c["tail_len"].append(p.tail_len); c["want_samples"].append(p.want_samples); c["n_before_vel"].append(p.n_before_vel)
-            c["vel_active"].append(int(p.vel_active)); c["vel_factor"].append(p.vel_factor)
-            c["pre_new"].append(max(1, int(round(p.n_pre * p.vel_factor))) if p.vel_active else p.n_pre)
-            c["force_voiced"].append(int(req.force_voiced))
-            c["bend_off"].append(b_off); c["n_bend"].append(len(req.bend))
-            c["pitch_m"].append(float(req.pitch_m))
-            tc = req.flags.get("t", 0)
-            c["pitch_t"].append((tc / 100.0) if tc else 0.0)
-            c["tick_dt"].append(60.0 / (req.tempo * 96.0))
-            fx = p.extra
-            c["fry_hz"].append(req.fry_hz); c["fry_dir"].append(fx["fry_dir"])
-            c["fry_const_lo"].append(fx["fry_const"][0]); c["fry_const_hi"].append(fx["fry_const"][1])
-            c["fry_glide_lo"].append(fx["fry_glide"][0]); c["fry_glide_hi"].append(fx["fry_glide"][1])
-            c["fry_a"].append(fx["fry_mask"][0]); c["fry_b"].append(fx["fry_mask"][1]); c["fry_fade"].append(fx["fry_fade"])
-            c["pd_on"].append(int(req.pitch_dyn != 0.0)); c["pd_base"].append(req.pitch_m + ((req.flags.get("t", 0) or 0) / 100.0))
-            semis = req.bend.astype(np.float64) / 100.0 + req.pitch_m      # SillySampler.py:838-846
-            if tc:
-                semis = semis + (tc / 100.0)
-            bend_cat.append(semis)
-            tapi_cat.append(p.tap_idx[:T_env])
-            tapw_cat.append(p.tap_w[:T_env])
-            fst_cat.append(p.fst_tracks[:T_env])
-            F_cat.append(p.formants[:T_env])
-            env_lens.append(T_env)
-            e_off += row_hi - row_lo
-            t_off += T_env
-            o_off += p.n_out
-            b_off += len(req.bend)
-        for name, vals in col.items():                         # one column assignment per field instead of 45 scalar stores per note
-            P[name] = vals
-        if any(pl.n_out <= 0 for pl in plans):
+        # -- the notes' plans: cut points, frame taps, sample counts, formant tracks (SillySampler.py:449-833)
+        tracks = [sc.tracks64() for sc in usrc]
+        pb = None
+        if all(t is not None for t in tracks):
+            rec = S.plan_records(reqs, sr, u_ylen[src_ix], u_T[src_ix], [tracks[k] for k in src_ix])
+            pb = S.plan_native(rec, self.hop, trim_rows, keep=(tracks, rec))
+        if pb is None:                                         # odd formant dicts, or a note the reference refuses (raises here)
+            pb = S.plans_to_arrays(S.plan_notes([(r, sc.sr, sc.ylen, sc.knots.shape[1], sc.formants) for sc, r in jobs], self.hop),
+                                   self.hop, trim_rows)
+        geo = pb.geo
+        if (geo["n_out"] <= 0).any():
             raise ValueError("a note assembles to zero samples")
+        env_lens = geo["n_out_rows"].astype(np.int64)
+        lens = geo["n_out"].astype(np.int64)
+        n_edit = (geo["row_hi"] - geo["row_lo"]).astype(np.int64)
+        csum0 = lambda v: np.concatenate([[0], np.cumsum(v)])
+        env_off, sample_off, edit_off = csum0(env_lens), csum0(lens), csum0(n_edit)
+        t_off, o_off, e_off = int(env_off[-1]), int(sample_off[-1]), int(edit_off[-1])
+
+        # -- request scalars as columns
+        rq = np.array([(r.reverse, r.brightness_env, r.env_shape, r.formant_width, r.force_voiced, r.pitch_m, r.tempo, r.fry_hz,
+                        r.pitch_dyn, r.formant_shift, r.normalize, r.harmonic_mix, r.breathiness_mix, r.unvoiced_mix, r.volume,
+                        r.f0_jitter_strength if r.f0_jitter else 0.0, r.volume_jitter_strength if r.volume_jitter else 0.0,
+                        r.subharm_weight if r.add_subharm else 0.0, r.subharm_gain, r.growl_mix, r.aperiodic_mix, r.sd_strength,
+                        r.tension) for r in reqs], dtype=np.float64).reshape(n, 23)
+        (c_rev, c_be, c_es, c_fw, c_fv, c_pm, c_tempo, c_fhz, c_pd, c_fs, c_norm, c_hm, c_bm, c_um, c_vol, c_f0j, c_vj, c_sub, c_su, c_sj,
+         c_sa, c_sd, c_st) = rq.T
+        c_tc = np.array([r.flags.get("t", 0) or 0 for r in reqs], dtype=np.float64)
+        n_bend = np.array([len(r.bend) for r in reqs], dtype=np.int64)
+        bend_off = csum0(n_bend)
+
+        def table_ids(col, off_value, make):
+            """Index of every note's table among the tables of the distinct values of ``col`` (-1 where col == off_value)."""
+            on = col != off_value
+            ids = np.full(n, -1, dtype=np.int64)
+            if not on.any():
+                return ids, []
+            vals, inv = np.unique(col[on], return_inverse=True)
+            ids[on] = inv
+            return ids, [make(float(v)) for v in vals]
+
+        tilt_id, tilt_tabs = table_ids(c_be, 1.0, lambda v: _tilt(sr, B, v))
+        fw_id, fw_tabs = table_ids(c_fw, 0.0, lambda v: _fw_plan(B, v))
+        es_id, es_tabs = table_ids(c_es, 0.0, lambda v: S.gauss_taps((1.0 + 6.0 * abs(v)) if v < 0.0 else (0.8 + 4.0 * abs(v))))
+        es_toff = csum0([t.size for t in es_tabs])
+        es_rad = np.array([(t.size - 1) // 2 for t in es_tabs], dtype=np.int64)
+        es_on = es_id >= 0
+
+        P = np.zeros(n, dtype=_lib.NOTE_PLAN)
+        P["knot_off"], P["K"], P["lerp_plan"], P["n_src_rows"] = u_koff[src_ix], u_K[src_ix], u_lerp[src_ix], u_T[src_ix]
+        P["reverse"], P["tilt"], P["fw_plan"] = c_rev, tilt_id, fw_id
+        P["es_mode"] = np.where(es_on, np.where(c_es < 0.0, 1, 2), 0)
+        P["es_amount"] = np.where(es_on, 5 * np.abs(c_es), 0.0)
+        P["es_taps_off"] = np.where(es_on, es_toff[np.maximum(es_id, 0)], 0) if es_tabs else 0
+        P["es_radius"] = np.where(es_on, es_rad[np.maximum(es_id, 0)], 0) if es_tabs else 0
+        P["row_lo"], P["n_edit"], P["edit_off"] = geo["row_lo"], n_edit, edit_off[:-1]
+        P["tap_off"], P["env_off"], P["n_out_rows"], P["env_f64"] = env_off[:-1], env_off[:-1], env_lens, geo["env_f64"]
+        P["fst"] = [r.formant_strength for r in reqs]
+        P["src_sample_off"], P["ylen"], P["out_sample_off"] = u_soff[src_ix], u_ylen[src_ix], sample_off[:-1]
+        for k in ("n_out", "n_pre", "s_pre", "s_tail", "tail_len", "want_samples", "n_before_vel", "vel_active", "vel_factor", "pre_new",
+                  "fry_dir", "fry_const_lo", "fry_const_hi", "fry_glide_lo", "fry_glide_hi", "fry_a", "fry_b", "fry_fade"):
+            P[k] = geo[k]
+        P["force_voiced"], P["bend_off"], P["n_bend"], P["pitch_m"] = c_fv, bend_off[:-1], n_bend, c_pm
+        P["pitch_t"] = c_tc / 100.0
+        P["tick_dt"] = 60.0 / (c_tempo * 96.0)
+        P["fry_hz"], P["pd_on"], P["pd_base"] = c_fhz, c_pd != 0.0, c_pm + c_tc / 100.0
+        # pitch curve per tick in MIDI semitones: bend / 100 + pitch_m (+ t / 100 where the flag is set)   SillySampler.py:838-846
+        bend = np.concatenate([r.bend for r in reqs]).astype(np.float64) / 100.0 + np.repeat(c_pm, n_bend)
+        if c_tc.any():
+            sel = np.repeat(c_tc != 0.0, n_bend)
+            bend[sel] = bend[sel] + np.repeat(c_tc / 100.0, n_bend)[sel]
 
         def cat_tab(tabs, k, dtype):
             return ctx.tensor(np.concatenate([t[k] for t in tabs]).astype(dtype)) if tabs else None
 
         d = dict(
             notes=ctx.tensor(P.view(np.uint8)),
-            knots=ctx.tensor(np.concatenate(knots_cat).view(np.uint16)),
+            knots=d_knots, mask_src=d_mask_src,
             lerp_idx=cat_tab(lerp_tabs, 0, np.int32), lerp_w0=cat_tab(lerp_tabs, 1, np.float32), lerp_w1=cat_tab(lerp_tabs, 2, np.float32),
             tilts=ctx.tensor(np.concatenate(tilt_tabs)) if tilt_tabs else None,
-            es_taps=ctx.tensor(np.concatenate(es_taps)) if es_taps else None,
+            es_taps=ctx.tensor(np.concatenate(es_tabs)) if es_tabs else None,
             fw_lo=cat_tab(fw_tabs, 0, np.int32), fw_hi=cat_tab(fw_tabs, 1, np.int32), fw_frac=cat_tab(fw_tabs, 2, np.float64),
-            tap_idx=ctx.tensor(np.concatenate(tapi_cat).astype(np.int32, copy=False)), tap_w=ctx.tensor(np.concatenate(tapw_cat)),
-            fst_tracks=ctx.tensor(np.concatenate(fst_cat).astype(np.float32, copy=False)),
-            mask_src=ctx.tensor(np.concatenate(mask_cat).astype(np.float32, copy=False)),
-            bend=ctx.tensor(np.concatenate(bend_cat).astype(np.float64, copy=False)),
+            tap_idx=ctx.tensor(pb.tap_idx), tap_w=ctx.tensor(pb.tap_w), fst_tracks=ctx.tensor(pb.fst),
+            bend=ctx.tensor(bend),
         )
         env = ctx.rows(t_off, B)
         f0 = torch.empty(o_off, dtype=torch.float32, device=ctx.device)
         mask = torch.empty(o_off, dtype=torch.float32, device=ctx.device)
         ptr = lambda t: t.data_ptr() if t is not None else None
-        any_pd = any(r.pitch_dyn != 0.0 for _, r in jobs)
-        any_fry = any(pl.extra["fry_mask"][1] > pl.extra["fry_mask"][0] for pl in plans)
+        any_pd = bool((c_pd != 0.0).any())
+        any_fry = bool((geo["fry_b"] > geo["fry_a"]).any())
         bend_out = torch.zeros(o_off, dtype=torch.float32, device=ctx.device) if any_pd else None
-        a = _lib.Assembly(n_notes=n, n_bins=B, ld=ld, sr=sr, max_K=int(max(s.knots.shape[0] for s, _ in jobs)),
+        a = _lib.Assembly(n_notes=n, n_bins=B, ld=ld, sr=sr, max_K=int(u_K.max()),
                           total_edit_rows=e_off, total_out_rows=t_off, total_samples=o_off,
                           notes=ptr(d["notes"]), knots=ptr(d["knots"]), lerp_idx=ptr(d["lerp_idx"]), lerp_w0=ptr(d["lerp_w0"]),
                           lerp_w1=ptr(d["lerp_w1"]), tilts=ptr(d["tilts"]), es_taps=ptr(d["es_taps"]), fw_lo=ptr(d["fw_lo"]),
@@ -425,81 +466,64 @@ class Renderer:
                           any_fry=int(any_fry))
         # per-note synthesize parameters
         par = default_params(n)
-        reqs = [r for _, r in jobs]
-        par["formant_shift"] = [r.formant_shift for r in reqs]
+        par["formant_shift"], par["normalize"] = c_fs, c_norm
         par["f_shift"] = [r.f_shift for r in reqs]
-        par["normalize"] = [r.normalize for r in reqs]
-        par["mix_harm"] = [r.harmonic_mix for r in reqs]
-        par["mix_breath"] = [r.breathiness_mix for r in reqs]
-        par["mix_unvoiced"] = [r.unvoiced_mix for r in reqs]
-        par["volume"] = [r.volume for r in reqs]
+        par["mix_harm"], par["mix_breath"], par["mix_unvoiced"], par["volume"] = c_hm, c_bm, c_um, c_vol
         nids = np.asarray(note_ids if note_ids is not None else range(n), dtype=np.uint64)   # Philox stream of the note: its id, not its batch position
         par["seed"] = np.stack([nids & np.uint64(0xFFFFFFFF), (nids >> np.uint64(32)) & np.uint64(0xFFFFFFFF)], axis=1)
-        par["f0_jitter"] = [r.f0_jitter_strength if r.f0_jitter else 0.0 for r in reqs]
-        par["vol_jitter_harm"] = [r.volume_jitter_strength if r.volume_jitter else 0.0 for r in reqs]
-        par["vol_jitter_breath"] = [r.volume_jitter_strength * 2 if r.volume_jitter else 0.0 for r in reqs]
-        par["subharm_weight"] = [r.subharm_weight if r.add_subharm else 0.0 for r in reqs]
-        lens = [p.n_out for p in plans]
+        par["f0_jitter"], par["vol_jitter_harm"], par["vol_jitter_breath"], par["subharm_weight"] = c_f0j, c_vj, c_vj * 2, c_sub
+        lens_l = [int(v) for v in lens]
+        env_lens_l = [int(v) for v in env_lens]
         # sh / sr draws come from the legacy global np.random stream, note by note, in the reference's order
         # (f0 jitter, harmonic volume, breath volume: GOOFER.py:666, 653)
         noise_f0 = noise_vol = None
-        if any(r.f0_jitter for _, r in jobs) or any(r.volume_jitter for _, r in jobs):
+        any_f0j, any_vj = any(r.f0_jitter for r in reqs), any(r.volume_jitter for r in reqs)
+        if any_f0j or any_vj:
             nf, nh, nb = [], [], []
-            for (_, req), n_ in zip(jobs, lens):
+            for req, n_ in zip(reqs, lens_l):
                 nf.append(np.random.randn(n_) if req.f0_jitter else np.zeros(n_))
                 nh.append(np.random.randn(n_) if req.volume_jitter else np.zeros(n_))
                 nb.append(np.random.randn(n_) if req.volume_jitter else np.zeros(n_))
-            if any(r.f0_jitter for _, r in jobs):
+            if any_f0j:
                 noise_f0 = ctx.tensor(np.concatenate(nf))
-            if any(r.volume_jitter for _, r in jobs):
+            if any_vj:
                 noise_vol = (ctx.tensor(np.concatenate(nh)), ctx.tensor(np.concatenate(nb)))
         # sample-domain post chain: per-note table (offsets into the extra synth calls are filled in by run())
         post = np.zeros(n, dtype=_lib.POST_NOTE)
         post["su_off"] = post["sj_off"] = post["sa_off"] = -1
-        post["su_gain"] = [r.subharm_gain for r in reqs]
-        post["sj_mix"] = [r.growl_mix for r in reqs]
-        post["sa_mix"] = [r.aperiodic_mix for r in reqs]
-        post["sd_strength"] = [r.sd_strength for r in reqs]
-        post["tension"] = [r.tension for r in reqs]
-        post["pitch_dyn"] = [r.pitch_dyn for r in reqs]
-        post["fry_a"] = [pl.extra["fry_mask"][0] for pl in plans]
-        post["fry_b"] = [pl.extra["fry_mask"][1] for pl in plans]
-        post["fry_fade"] = [pl.extra["fry_fade"] for pl in plans]
+        post["su_gain"], post["sj_mix"], post["sa_mix"], post["sd_strength"], post["tension"], post["pitch_dyn"] = c_su, c_sj, c_sa, c_sd, c_st, c_pd
+        post["fry_a"], post["fry_b"], post["fry_fade"] = geo["fry_a"], geo["fry_b"], geo["fry_fade"]
         growl = {}
-        for i, (req, pl) in enumerate(zip(reqs, plans)):
-            if req.growl_mix > 0.0:                            # 'sj': f0 * 0.5 * 2^N(0, mix^2), a fresh generator per call  :1063-1065
-                rng = np.random.default_rng(phi_seeds[i]) if phi_seeds is not None else np.random.default_rng()
-                growl[i] = 0.5 * (2.0 ** rng.normal(loc=0.0, scale=req.growl_mix ** 2, size=pl.n_out))
+        for i in np.nonzero(c_sj > 0.0)[0]:                    # 'sj': f0 * 0.5 * 2^N(0, mix^2), a fresh generator per call  :1063-1065
+            rng = np.random.default_rng(phi_seeds[i]) if phi_seeds is not None else np.random.default_rng()
+            growl[int(i)] = 0.5 * (2.0 ** rng.normal(loc=0.0, scale=reqs[i].growl_mix ** 2, size=lens_l[i]))
         f0_growl = None
         if growl:
             # the layer's f0 is the fp64 pitch curve times the factor, rounded to fp32 once (SillySampler.py:1065): the
             # assembly kernel writes it next to f0 while it still holds the fp64 value
-            so = np.concatenate([[0], np.cumsum(lens)])
-            mul = np.ones(int(so[-1]), dtype=np.float64)
+            mul = np.ones(o_off, dtype=np.float64)
             for i, gv in growl.items():
-                mul[int(so[i]):int(so[i + 1])] = gv
+                mul[int(sample_off[i]):int(sample_off[i + 1])] = gv
             d["f0_mul"] = ctx.tensor(mul)
-            f0_growl = torch.zeros(int(so[-1]), dtype=torch.float32, device=ctx.device)
+            f0_growl = torch.zeros(o_off, dtype=torch.float32, device=ctx.device)
             a.f0_mul, a.f0_mul_out = d["f0_mul"].data_ptr(), f0_growl.data_ptr()
-        has_post = any(r.subharm_gain > 0 or r.growl_mix > 0 or r.aperiodic_mix > 0 or r.sd_strength > 0 or r.tension != 0
-                       or r.pitch_dyn != 0 for _, r in jobs) or any_fry
+        has_post = bool(((c_su > 0) | (c_sj > 0) | (c_sa > 0) | (c_sd > 0) | (c_st != 0) | (c_pd != 0)).any()) or any_fry
         phi = None
         if phi_seeds is not None:
             mats = []
-            for p, sd in zip(plans, phi_seeds):
-                T = 1 + p.n_out // self.hop
+            for n_, sd in zip(lens_l, phi_seeds):
+                T = 1 + n_ // self.hop
                 mats.append(np.random.default_rng(sd).uniform(0.0, 2.0 * np.pi, size=(B, T)).astype(np.float32).T)
             phi = ctx.rows_from(np.concatenate(mats))
-        offsets = ctx.device_offsets(env_lens, lens, par)
-        frames = int(sum(ctx.frame_counts(lens)))
-        ctx.reserve(frames, int(sum(lens)), n)
+        offsets = ctx.device_offsets(env_lens_l, lens_l, par)
+        frames = int(sum(ctx.frame_counts(lens_l)))
+        ctx.reserve(frames, o_off, n)
         torch.cuda.synchronize(ctx.device)
-        return {"assembly": a, "keep": d, "env": env, "f0": f0, "mask": mask, "params": par, "lens": lens, "env_lens": env_lens,
-                "noise_f0": noise_f0, "noise_vol": noise_vol, "subharm": any(r.add_subharm for _, r in jobs),
+        return {"assembly": a, "keep": d, "env": env, "f0": f0, "mask": mask, "params": par, "lens": lens_l, "env_lens": env_lens_l,
+                "noise_f0": noise_f0, "noise_vol": noise_vol, "subharm": bool((c_sub > 0).any()),
                 "post": post if has_post else None, "growl": growl, "f0_growl": f0_growl, "bend_out": bend_out, "jobs": jobs,
-                "formants": ctx.tensor(np.concatenate(F_cat)), "phi": phi, "plans": plans, "offsets": offsets,
-                "sample_off": np.concatenate([[0], np.cumsum(lens)]), "env_off": np.concatenate([[0], np.cumsum(env_lens)]),
-                "frames": frames, "samples": int(sum(lens)), "edit_rows": e_off}
+                "formants": ctx.tensor(pb.formants), "phi": phi, "planned": pb, "offsets": offsets,
+                "sample_off": sample_off, "env_off": env_off, "frames": frames, "samples": o_off, "edit_rows": e_off}
 
 
 # ---------------------------------------------------------------------------------------------

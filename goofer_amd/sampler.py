@@ -221,6 +221,46 @@ def decode_request(pitch, velocity, flags="", offset=0, length=1000, consonant=0
                    bend=pitch_string_to_cents(pitch_string), **d["fields"])
 
 
+def pitch_strings_to_cents(texts) -> list:
+    """``pitch_string_to_cents`` for a batch: one call into the C-ABI library's host decoder (goofer_host_decode_bends) for
+    all strings, views of one array back.  A string the decoder does not take (malformed, non-ASCII) goes through
+    ``pitch_string_to_cents``, which raises — or answers — what the reference does."""
+    lib = _host_lib()
+    texts = list(texts)
+    if lib is None or not texts or not all(t.isascii() for t in texts):
+        return [pitch_string_to_cents(t) for t in texts]
+    blob = "".join(texts).encode("ascii")
+    off = np.zeros(len(texts) + 1, dtype=np.int64)
+    np.cumsum([len(t) for t in texts], out=off[1:])
+    out_off = np.empty(len(texts) + 1, dtype=np.int64)
+    total = lib.goofer_host_decode_bends(blob, off.ctypes.data, len(texts), None, 0, out_off.ctypes.data)
+    if total < 0:                                             # note -(total + 1) is not well formed: one by one
+        return [pitch_string_to_cents(t) for t in texts]
+    vals = np.empty(total, dtype=np.float32)
+    lib.goofer_host_decode_bends(blob, off.ctypes.data, len(texts), vals.ctypes.data, total, out_off.ctypes.data)
+    return [vals[out_off[i]:out_off[i + 1]] for i in range(len(texts))]
+
+
+def decode_requests(arg_lists) -> list:
+    """``decode_request`` for a batch of 13-argument lists (positions 2.. as in the resampler call: pitch, velocity, flags,
+    offset, length, consonant, cutoff, volume, modulation, tempo, pitch_string) — same Requests, the pitch strings decoded
+    together."""
+    arg_lists = [tuple(a) for a in arg_lists]
+    full = [a + _REQ_DEFAULTS[len(a) - 2:] if len(a) < 11 else a for a in arg_lists]
+    bends = pitch_strings_to_cents([a[10] for a in full])
+    out = []
+    for a, bend in zip(full, bends):
+        d = _decode_flags(a[2])
+        out.append(Request(pitch_m=note_to_midi(a[0]), velocity=float(a[1]), flags=dict(d["flags"]), offset=float(a[3]) / 1000.0,
+                           length=float(a[4]) / 1000.0, consonant=float(a[5]) / 1000.0, cutoff=float(a[6]) / 1000.0,
+                           volume=float(a[7]) / 100.0, modulation=float(a[8]) / 100.0, tempo=float(a[9].lstrip("!")), bend=bend,
+                           **d["fields"]))
+    return out
+
+
+_REQ_DEFAULTS = ("", 0, 1000, 0, 0, 100, 0, "!120", "AA")       # flags .. pitch_string of decode_request
+
+
 # ---------------------------------------------------------------------------------------------
 # planning
 # ---------------------------------------------------------------------------------------------
@@ -692,6 +732,165 @@ def plan_notes(jobs, hop: int = HOP) -> list:
 def plan_note(req: Request, sr: int, ylen: int, n_src_frames: int, formants_src: dict, hop: int = HOP) -> NotePlan:
     """Everything ``resample`` decides before touching an array (SillySampler.py:449-833), for one note."""
     return plan_notes([(req, sr, ylen, n_src_frames, formants_src)], hop)[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# the same plans from the C-ABI library's host planner (csrc/planner.hip), a batch per call
+# ---------------------------------------------------------------------------------------------
+_LOOP_CODE = {"concat": 0, "avg": 1, "stretch": 2}
+
+
+class PlannedBatch:
+    """Plans of a batch as arrays: ``geo`` [n] records (``_lib.PLAN_GEOMETRY``), and per planned envelope row
+    ``tap_idx`` int32 [rows, 4], ``tap_w`` fp64 [rows, 4], ``formants`` fp64 [rows, 4], ``fst`` fp32 [rows, 4]; note i owns
+    rows geo["tap_off"][i] .. + geo["n_out_rows"][i]."""
+
+    def __init__(self, geo, tap_idx, tap_w, formants, fst, owner=None):
+        self.geo, self.tap_idx, self.tap_w, self.formants, self.fst = geo, tap_idx, tap_w, formants, fst
+        self._owner = owner                                   # keeps library memory alive while the views are
+
+    def note(self, i):
+        g = self.geo[i]
+        a, b = int(g["tap_off"]), int(g["tap_off"]) + int(g["n_out_rows"])
+        return g, self.tap_idx[a:b], self.tap_w[a:b], self.formants[a:b], self.fst[a:b]
+
+
+class _PlansHandle:
+    def __init__(self, lib, h):
+        self.lib, self.h = lib, h
+
+    def __del__(self):
+        if self.h:
+            self.lib.goofer_host_plans_free(self.h)
+            self.h = None
+
+
+def source_tracks64(formants: dict):
+    """The F1..F4 tracks of a source as the native planner takes them: four 1-D float64 arrays, or None when the dict is not
+    the plain case (keys that do not start 1, 2, 3, 4 in sorted order, tracks of another dtype or shape) — the numpy planner
+    then handles it with the reference's promotion and aliasing rules."""
+    try:
+        ks = sorted(formants)
+    except TypeError:
+        return None
+    if ks[:4] != [1, 2, 3, 4]:
+        return None
+    out = []
+    for k in (1, 2, 3, 4):
+        v = formants[k]
+        a = np.asarray(v)
+        if a.ndim != 1 or a.dtype != np.float64:
+            return None
+        out.append(np.ascontiguousarray(a))
+    return tuple(out)
+
+
+def plan_native(records, hop: int, trim_rows: bool, keep=None, threads: int = 0):
+    """goofer_host_plan_notes over ``records`` (``_lib.PLAN_REQUEST`` array).  Returns a PlannedBatch, or None when the library
+    is not there or some note is a case the reference answers with an exception (the caller then runs the numpy planner,
+    which raises it)."""
+    import ctypes as C
+    from . import _lib
+    lib = _host_lib()
+    if lib is None:
+        return None
+    records = np.ascontiguousarray(records, dtype=_lib.PLAN_REQUEST)
+    n = records.shape[0]
+    taps = np.ascontiguousarray(_gauss_taps_cached(4.0))
+    h = C.c_void_p()
+    rc = lib.goofer_host_plan_notes(records.ctypes.data, n, int(hop), int(bool(trim_rows)), taps.ctypes.data, (taps.size - 1) // 2,
+                                    int(threads), C.byref(h))
+    if rc != 0:
+        return None
+    owner = _PlansHandle(lib, h)
+    g_p, ti_p, tw_p, f_p, fs_p, rows = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+    lib.goofer_host_plans_view(h, C.byref(g_p), C.byref(rows), C.byref(ti_p), C.byref(tw_p), C.byref(f_p), C.byref(fs_p))
+    R = rows.value
+
+    def view(ptr, count, dtype):
+        if count == 0 or not ptr.value:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype, count=count)
+
+    geo = view(g_p, n, _lib.PLAN_GEOMETRY)
+    if n and (geo["status"] != 0).any():
+        return None
+    return PlannedBatch(geo, view(ti_p, R * 4, np.int32).reshape(-1, 4), view(tw_p, R * 4, np.float64).reshape(-1, 4),
+                        view(f_p, R * 4, np.float64).reshape(-1, 4), view(fs_p, R * 4, np.float32).reshape(-1, 4), owner=(owner, keep))
+
+
+def plan_records(reqs, srs, ylens, n_src_frames, tracks):
+    """``_lib.PLAN_REQUEST`` records of a batch: the requests' scalars as columns, ``tracks`` = per note the tuple of
+    ``source_tracks64`` (kept alive by the caller)."""
+    from . import _lib
+    n = len(reqs)
+    rec = np.zeros(n, dtype=_lib.PLAN_REQUEST)
+    cols = np.array([(r.offset, r.length, r.consonant, r.cutoff, r.fry, r.fry_glide, float(bool(r.reverse))) for r in reqs],
+                    dtype=np.float64).reshape(n, 7)
+    rec["offset"], rec["length"], rec["consonant"], rec["cutoff"] = cols[:, 0], cols[:, 1], cols[:, 2], cols[:, 3]
+    rec["fry"], rec["fry_glide"], rec["reverse"] = cols[:, 4], cols[:, 5], cols[:, 6]
+    rec["vel_factor"] = [float(2.0 ** (1.0 - (r.velocity / 100.0))) for r in reqs]     # Python's pow, like the reference (:765)
+    rec["loop_mode"] = [_LOOP_CODE[r.loop_mode] for r in reqs]
+    rec["sr"], rec["ylen"], rec["n_src_frames"] = srs, ylens, n_src_frames
+    ptr_of, len_of = {}, {}
+    for t in tracks:                                           # few distinct sources, many notes
+        if id(t) not in ptr_of:
+            ptr_of[id(t)] = [a.ctypes.data if a.size else 0 for a in t]
+            len_of[id(t)] = [a.size for a in t]
+    rec["tracks"] = [ptr_of[id(t)] for t in tracks]
+    rec["track_len"] = [len_of[id(t)] for t in tracks]
+    return rec
+
+
+def plan_notes_arrays(jobs, hop: int = HOP, trim_rows: bool = False, threads: int = 0) -> PlannedBatch:
+    """The plans of a batch (jobs as for ``plan_notes``) as a PlannedBatch: from the library's host planner when every source's
+    tracks are the plain float64 case, otherwise — and for every batch holding a note the reference refuses — from
+    ``plan_notes`` (same values; tests/test_planner_native.py)."""
+    tracks = [source_tracks64(j[4]) for j in jobs]
+    if jobs and all(t is not None for t in tracks):
+        uniq = {}
+        tracks = [uniq.setdefault(tuple(a.ctypes.data for a in t) + tuple(a.size for a in t), t) for t in tracks]
+        rec = plan_records([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], [j[3] for j in jobs], tracks)
+        pb = plan_native(rec, hop, trim_rows, keep=(tracks, rec), threads=threads)
+        if pb is not None:
+            return pb
+    return plans_to_arrays(plan_notes(jobs, hop), hop, trim_rows)
+
+
+def plans_to_arrays(plans, hop: int, trim_rows: bool) -> PlannedBatch:
+    """NotePlans (the numpy planner) as a PlannedBatch."""
+    from . import _lib
+    n = len(plans)
+    geo = np.zeros(n, dtype=_lib.PLAN_GEOMETRY)
+    ti, tw, F, fst = [], [], [], []
+    live = {}
+    off = 0
+    for i, p in enumerate(plans):
+        g = geo[i]
+        T_env = p.tap_idx.shape[0]
+        row_lo, row_hi = p.row_lo, p.row_hi
+        if trim_rows and p.n_out > 0 and T_env > 1 + p.n_out // hop:
+            T_env = 1 + p.n_out // hop
+            lim = live.get(id(p.tap_idx))                      # notes of one geometry share the tap arrays
+            if lim is None or lim[0] != T_env:
+                used = p.tap_idx[:T_env][p.tap_w[:T_env] != 0.0]
+                lim = live[id(p.tap_idx)] = (T_env, int(used.min()) if used.size else 0, int(used.max()) + 1 if used.size else 0)
+            row_lo, row_hi = lim[1], lim[2]
+        for k in ("start_sample", "consonant_sample", "end_sample", "start_frame", "consonant_frame", "end_frame"):
+            g[k] = p.seg[k]
+        g["tap_off"], g["n_rows"], g["n_out_rows"], g["row_lo"], g["row_hi"], g["env_f64"] = off, p.tap_idx.shape[0], T_env, row_lo, row_hi, int(p.env_f64)
+        g["n_out"], g["n_pre"], g["s_pre"], g["s_tail"], g["tail_len"] = p.n_out, p.n_pre, p.extra["s_pre"], p.extra["s_tail"], p.tail_len
+        g["want_samples"], g["n_before_vel"], g["vel_active"], g["vel_factor"] = p.want_samples, p.n_before_vel, int(p.vel_active), p.vel_factor
+        g["pre_new"] = max(1, int(round(p.n_pre * p.vel_factor))) if p.vel_active else p.n_pre
+        fx = p.extra
+        g["fry_dir"], g["fry_const_lo"], g["fry_const_hi"] = fx["fry_dir"], fx["fry_const"][0], fx["fry_const"][1]
+        g["fry_glide_lo"], g["fry_glide_hi"] = fx["fry_glide"]
+        g["fry_a"], g["fry_b"], g["fry_fade"] = fx["fry_mask"][0], fx["fry_mask"][1], fx["fry_fade"]
+        ti.append(p.tap_idx[:T_env]); tw.append(p.tap_w[:T_env]); F.append(p.formants[:T_env]); fst.append(p.fst_tracks[:T_env])
+        off += T_env
+    cat = lambda parts, dt: np.concatenate(parts).astype(dt, copy=False).reshape(-1, 4) if parts else np.zeros((0, 4), dtype=dt)
+    return PlannedBatch(geo, cat(ti, np.int32), cat(tw, np.float64), cat(F, np.float64), cat(fst, np.float32))
 
 
 def fry_plan(req: Request, sr: int, n: int) -> dict:

@@ -309,6 +309,56 @@ int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *assembly, const 
  * 'reflect' padding, taps applied in ascending order — the sigma-4 smoothing of the formant tracks, SillySampler.py:264-283. */
 int goofer_host_gauss_rows(const double *x, int64_t rows, int T, const double *taps, int radius, double *out);
 
+/* ---- host-side note planner (pure CPU code: no device, no handle) ----------------------------------------------------
+ * What SillySampler.resample decides about a note before it touches an array (SillySampler.py:449-500 cut points, :625-696
+ * loop modes, :698-788 sample counts + velocity stretch, :714-763 / 264-283 / 791-806 formant tracks, :883-955 fry ranges),
+ * for a whole batch in one call; the arithmetic of goofer_amd/sampler.py's numpy planner, bit for bit. */
+typedef struct {
+    double offset, length, consonant, cutoff;   /* seconds: the request's offset / length / consonant / cutoff / 1000     */
+    double vel_factor;                          /* 2 ** (1 - velocity / 100)                                :765           */
+    double fry, fry_glide;                      /* 'vf' (clipped to +-100), 'vl'                            :883-888       */
+    int64_t ylen;                               /* samples of the source                                                   */
+    int32_t sr, n_src_frames;                   /* n_src_frames = rows of the source envelope = 1 + ylen / hop             */
+    int32_t loop_mode, reverse;                 /* 0 concat (L0), 1 mirror mean (L1), 2 stretch (L2); 'R1'                 */
+    const double *tracks[4];                    /* the source's F1..F4 tracks (Hz, fp64, HOST memory)                      */
+    int32_t track_len[4];                       /* their lengths; -1: the source has no such track                         */
+} goofer_plan_request;
+
+typedef struct {
+    int64_t start_sample, consonant_sample, end_sample;     /* cut points                                   :453-487       */
+    int64_t tap_off;                            /* first row of the note in the arrays of goofer_host_plans_view           */
+    double vel_factor;                          /* the stretch factor when vel_active, else 1                              */
+    int32_t status;                             /* 0 planned; 1: a case the reference answers with an exception (empty     */
+                                                /* tail to loop, negative length): nothing else of the record is valid     */
+    int32_t start_frame, consonant_frame, end_frame;
+    int32_t n_rows;                             /* envelope frames the reference would assemble                            */
+    int32_t n_out_rows;                         /* rows planned: n_rows, or 1 + n_out / hop when trim_rows cut the rest     */
+    int32_t row_lo, row_hi;                     /* source rows [row_lo, row_hi) the planned rows read                      */
+    int32_t env_f64;                            /* the reference holds this note's envelope in float64 (lerps / fades)     */
+    int32_t n_out, n_pre, s_pre, s_tail, tail_len, want_samples, n_before_vel, pre_new, vel_active;   /* goofer_note_plan */
+    int32_t fry_dir, fry_const_lo, fry_const_hi, fry_glide_lo, fry_glide_hi, fry_a, fry_b, fry_fade;  /* goofer_note_plan */
+    int32_t reserved;
+} goofer_plan_geometry;
+
+typedef struct goofer_host_plans goofer_host_plans;
+
+/* Plan n_notes notes.  gauss_taps[2 * gauss_radius + 1]: the sigma-4 taps of sanitize_smooth_formant (:281), made by the
+ * caller the way numpy makes them.  trim_rows != 0: plan only the envelope rows gf.synthesize can reach (GOOFER.py:1115-1119).
+ * n_threads <= 0: up to eight host threads.  The result is freed with goofer_host_plans_free. */
+int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps,
+                           int gauss_radius, int n_threads, goofer_host_plans **out);
+/* The planned batch: geometry[n_notes]; rows = sum of n_out_rows over the notes with status 0; tap_idx / tap_w [rows x 4]
+ * (goofer_assembly.tap_idx / tap_w), formants [rows x 4] fp64 (goofer_batch.formants), fst_tracks [rows x 4] fp32
+ * (goofer_assembly.fst_tracks).  HOST memory owned by the handle.  Any out pointer may be NULL. */
+int goofer_host_plans_view(const goofer_host_plans *plans, const goofer_plan_geometry **geometry, int64_t *rows,
+                           const int32_t **tap_idx, const double **tap_w, const double **formants, const float **fst_tracks);
+void goofer_host_plans_free(goofer_host_plans *plans);
+
+/* UTAU pitch-bend strings of a batch (SillySampler.py:56-84): text = the strings back to back, text_off[n + 1] their bounds.
+ * Writes out_off[n + 1] and, when out != NULL, the decoded cents (at most `capacity` values); returns the number of values,
+ * or -(i + 1) when string i is not well formed (the caller's character loop then raises what the reference raises). */
+int64_t goofer_host_decode_bends(const char *text, const int64_t *text_off, int n, float *out, int64_t capacity, int64_t *out_off);
+
 /* Synchronise the device and report errors the asynchronous batch calls detect on the device (today: a note with more
  * pulse onsets than its n / 2 + 16 onset slots, GOOFER.py:493 with f0 above sr / 2).  0, or GOOFER_EINVAL + goofer_last_error. */
 int goofer_check(goofer_ctx *ctx);
@@ -365,7 +415,8 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value);
 /* Copy a plan table (0 window, 1 freqs, 2 boost, 3 bright_harm, 4 bright_breath, 5 pulse peak) or an
  * intermediate of the last synth batch to HOST memory; return element count / byte size. Tests only. */
 int goofer_debug_table(goofer_ctx *ctx, int which, float *host_out, int capacity);
-/* sizeof of the ABI structs (0 note_params, 1 batch, 2 note_plan, 3 assembly) so bindings can verify layout */
+/* sizeof of the ABI structs (0 note_params, 1 batch, 2 note_plan, 3 assembly, 4 onepole_job, 5 post_note, 6 post,
+ * 7 plan_request, 8 plan_geometry) so bindings can verify layout */
 int goofer_sizeof(int which);
 int64_t goofer_debug_fetch(goofer_ctx *ctx, int which, void *host_out, int64_t capacity_bytes);
 

@@ -36,6 +36,8 @@ def test_binding_covers_header_and_struct_layout():
     assert _lib.ONEPOLE_JOB.itemsize == lib.goofer_sizeof(4)
     assert _lib.POST_NOTE.itemsize == lib.goofer_sizeof(5)
     assert ctypes.sizeof(_lib.Post) == lib.goofer_sizeof(6)
+    assert _lib.PLAN_REQUEST.itemsize == lib.goofer_sizeof(7)
+    assert _lib.PLAN_GEOMETRY.itemsize == lib.goofer_sizeof(8)
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -1,0 +1,166 @@
+"""The C-ABI library's host planner (csrc/planner.hip: goofer_host_plan_notes, goofer_host_decode_bends) against the numpy
+planner of goofer_amd/sampler.py — which the reference's 53 index-plan fixtures and the product tests pin — bit for bit:
+cut points, frame taps and weights, sample counts, fry ranges, the formant tracks handed to synthesize and the repaired +
+smoothed tracks of the formant-strength gain.  Pure host code: no GPU."""
+import numpy as np
+import pytest
+
+from goofer_amd import sampler as S
+from conftest import golden
+
+
+def _same(A, B):
+    for name in A.geo.dtype.names:
+        if name == "reserved":
+            continue
+        assert np.array_equal(A.geo[name], B.geo[name]), name
+    for nm in ("tap_idx", "tap_w", "formants", "fst"):
+        a, b = getattr(A, nm), getattr(B, nm)
+        assert a.shape == b.shape and a.dtype == b.dtype, nm
+        assert np.array_equal(a, b, equal_nan=True), nm
+
+
+def _native(jobs, hop, trim):
+    tracks = [S.source_tracks64(j[4]) for j in jobs]
+    assert all(t is not None for t in tracks)
+    rec = S.plan_records([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], [j[3] for j in jobs], tracks)
+    return S.plan_native(rec, hop, trim, keep=(tracks, rec))
+
+
+def _random_jobs(seed, n, hop=256, sr=44100):
+    rng = np.random.default_rng(seed)
+    jobs = []
+    for i in range(n):
+        ylen = int(rng.integers(hop * 3, sr * 2))
+        T = 1 + ylen // hop
+        forms = {}
+        for k in (1, 2, 3, 4):
+            tr = (400.0 * k + 900.0 * rng.random(T)).astype(np.float64)
+            mode = rng.integers(0, 8)
+            if mode == 0:                                     # out-of-range stretches and NaNs: the repair path
+                a = int(rng.integers(0, T))
+                tr[a:a + int(rng.integers(1, 30))] = [0.0, np.nan, 1e6][int(rng.integers(0, 3))]
+            elif mode == 1:
+                tr[:int(rng.integers(1, 12))] = 0.0           # bad from the start: float32 extrapolation on the left
+            elif mode == 2:
+                tr[-int(rng.integers(1, 12)):] = np.inf
+            elif mode == 3 and k == 4:
+                tr[:] = 0.0                                   # nothing good: 300 Hz
+            elif mode == 4:
+                tr[:] = 0.0
+                tr[int(rng.integers(0, T))] = 700.0 * k       # a single good value
+            forms[k] = tr
+        if rng.random() < 0.2:
+            forms[5] = 4500.0 + rng.random(T)                 # F5 rides along unused
+        if rng.random() < 0.1:
+            forms[2] = forms[2][:max(1, T - int(rng.integers(1, 40)))]     # tracks of unequal length
+        flags = "L%d" % int(rng.integers(0, 3))
+        if rng.random() < 0.3:
+            flags += "R1"
+        if rng.random() < 0.3:
+            flags += "vf%dvl%d" % (int(rng.integers(-100, 101)), int(rng.integers(0, 101)))
+        dur = ylen / sr * 1000.0
+        off = float(rng.integers(0, int(dur * 0.4)))
+        cons = float(rng.integers(0, int(dur * 0.4))) if rng.random() < 0.85 else 0.0
+        cutoff = float(rng.integers(-int(dur * 0.5), int(dur * 0.3)))
+        length = float(rng.integers(20, 2500))
+        vel = [100, 100, 60, 140, 0, 200, 99][int(rng.integers(0, 7))]
+        req = S.decode_request("C4", str(vel), flags, str(off), str(length), str(cons), str(cutoff), "100", "0", "!120", "AA")
+        jobs.append((req, sr, ylen, T, forms))
+    return jobs
+
+
+def _plannable(jobs, hop):
+    keep = []
+    for j in jobs:
+        try:
+            S._GEO_CACHE.clear()
+            S.plan_notes([j], hop)
+            keep.append(j)
+        except (ZeroDivisionError, ValueError):
+            pass
+    return keep
+
+
+@pytest.mark.parametrize("seed,hop", [(1, 256), (2, 256), (3, 96), (4, 512)])
+def test_native_plans_equal_numpy_plans(seed, hop):
+    jobs = _plannable(_random_jobs(seed, 160, hop=hop, sr=44100 if hop != 96 else 96000), hop)
+    assert len(jobs) > 100
+    modes = {j[0].loop_mode for j in jobs}
+    assert modes == {"concat", "avg", "stretch"}
+    for trim in (False, True):
+        S._GEO_CACHE.clear()
+        A = S.plans_to_arrays(S.plan_notes(jobs, hop), hop, trim)
+        B = _native(jobs, hop, trim)
+        assert B is not None
+        _same(A, B)
+    assert A.geo["vel_active"].any() and (A.geo["fry_b"] > A.geo["fry_a"]).any() and A.geo["env_f64"].any()
+
+
+def test_native_plans_on_the_reference_index_plan_cases():
+    """The argument sets of the reference's 53 index-plan fixtures (every slicing variant, L0/L1/L2, reverse, velocity): the cases
+    the reference renders come out equal to the numpy planner's, the cases it refuses make plan_native step aside."""
+    from test_product_sampler import probe_source
+    g = golden("index_plans")
+    env, f0, mask, forms, sr, n, T = probe_source()
+    forms = {k: np.asarray(v, dtype=np.float64) for k, v in forms.items()}
+    good, refused = [], []
+    for tag in g["names"]:
+        req = S.decode_request(*[str(a) for a in g[f"{tag}_args"]])
+        (refused if f"{tag}_error" in g.files else good).append((req, sr, n, T, forms))
+    assert len(good) >= 45 and refused
+    for trim in (False, True):
+        _same(S.plans_to_arrays(S.plan_notes(good, 256), 256, trim), _native(good, 256, trim))
+    for j in refused:
+        assert _native([j], 256, False) is None
+        with pytest.raises((ZeroDivisionError, ValueError)):
+            S.plan_notes_arrays([j], 256)
+
+
+def test_thread_count_changes_nothing():
+    jobs = _plannable(_random_jobs(9, 300), 256)
+    tracks = [S.source_tracks64(j[4]) for j in jobs]
+    rec = S.plan_records([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], [j[3] for j in jobs], tracks)
+    one = S.plan_native(rec, 256, True, keep=(tracks, rec), threads=1)
+    many = S.plan_native(rec, 256, True, keep=(tracks, rec), threads=5)
+    _same(one, many)
+
+
+def test_odd_sources_take_the_numpy_planner():
+    jobs = _plannable(_random_jobs(5, 6), 256)
+    odd = [(j[0], j[1], j[2], j[3], {k: v.astype(np.float32) for k, v in j[4].items()}) for j in jobs]
+    assert S.source_tracks64(odd[0][4]) is None
+    S._GEO_CACHE.clear()
+    _same(S.plans_to_arrays(S.plan_notes(odd, 256), 256, True), S.plan_notes_arrays(odd, 256, True))
+    assert S.source_tracks64({0: [1.0], 1: [1.0], 2: [1.0], 3: [1.0], 4: [1.0]}) is None
+    assert S.source_tracks64({1: [1.0], 2: [1.0], 3: [1.0]}) is None
+
+
+def test_batch_decode_of_pitch_strings():
+    rng = np.random.default_rng(3)
+    alpha = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/"
+    texts = ["AA", "AA#5#AF#3#/+", "//#200#", "Ab#3", "4f"]
+    for _ in range(200):
+        t = ""
+        for _ in range(int(rng.integers(1, 6))):
+            t += "".join(alpha[int(c)] for c in rng.integers(0, 64, size=2 * int(rng.integers(1, 9))))
+            if rng.random() < 0.6:
+                t += "#%d#" % int(rng.integers(0, 40))
+        texts.append(t)
+    got = S.pitch_strings_to_cents(texts)
+    for t, a in zip(texts, got):
+        b = S.pitch_string_to_cents(t)
+        assert a.dtype == b.dtype == np.float32 and np.array_equal(a, b), t
+    # malformed strings: the batch answers / raises what the one-by-one decoder does
+    for bad in ("A", "AA#x#", "#3#AA", "A?", "", "AA##"):
+        try:
+            want = S.pitch_string_to_cents(bad)
+        except Exception as e:                                # noqa: BLE001
+            with pytest.raises(type(e)):
+                S.pitch_strings_to_cents(["AA", bad])
+        else:
+            assert np.array_equal(S.pitch_strings_to_cents(["AA", bad])[1], want)
+    reqs = S.decode_requests([("C4", "100", "L1g-10", "30", "700", "80", "40", "100", "0", "!120", "AA#5#AF#3#/+"), ("A#3", "80")])
+    one = S.decode_request("C4", "100", "L1g-10", "30", "700", "80", "40", "100", "0", "!120", "AA#5#AF#3#/+")
+    assert reqs[0].loop_mode == "avg" and np.array_equal(reqs[0].bend, one.bend) and reqs[0].formant_shift == one.formant_shift
+    assert reqs[1].pitch_m == S.note_to_midi("A#3") and reqs[1].length == 1.0
