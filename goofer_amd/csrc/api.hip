@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.h"
+#include "samples_core.h"
 
 // launchers living in the other translation units
 int launch_frame_note(goofer_ctx *, const int64_t *, int, int64_t, int *, hipStream_t);
@@ -172,6 +173,42 @@ __global__ void k_row_src(const int64_t *__restrict__ frame_off, const int64_t *
         picks[f] = pv;
     }
     int64_t rows = env_off[note + 1] - env_off[note];
+    if (t > rows - 1) t = rows - 1;     // edge-repeat (np.pad mode='edge'); truncation is implicit
+    if (t < 0) t = 0;
+    row_src[f] = env_off[note] + t;
+}
+
+// The frame maps of the stem path in one launch (they were a memset and three small kernels in a row on the critical path,
+// ~10 us of dispatch each): frame -> note, frame -> envelope row, the frame's (f0, mask) picks; per note the two reciprocal
+// steps of the mask upsampler and the zeroed maxima the walkers reduce into.
+__global__ void k_frame_maps(const int64_t *__restrict__ frame_off, const int64_t *__restrict__ env_off, int n_notes, int64_t total_frames,
+                             int *__restrict__ frame_note, int64_t *__restrict__ row_src, const int64_t *__restrict__ sample_off,
+                             const float *__restrict__ f0, const float *__restrict__ mask, int hop, float2 *__restrict__ picks,
+                             double *__restrict__ steps, float *__restrict__ note_mag)
+{
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < 2 * (int64_t)n_notes) note_mag[f] = 0.f;
+    if (f < n_notes) {
+        const int64_t n = sample_off[f + 1] - sample_off[f];
+        const int64_t ns = (n + MASK_DS - 1) / MASK_DS;
+        steps[2 * f] = n > 1 ? 1.0 / (double)(n - 1) : 0.0;
+        steps[2 * f + 1] = ns > 1 ? 1.0 / (double)(ns - 1) : 0.0;
+    }
+    if (f >= total_frames) return;
+    const int note = csr_find(frame_off, n_notes, f);
+    frame_note[f] = note;
+    int64_t t = f - frame_off[note];
+    if (picks) {
+        const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+        float2 pv = make_float2(0.f, 0.f);
+        if (n > 0) {
+            int64_t at = t * hop;
+            if (at >= n) at = ((n - 1) / hop) * hop;          // edge-padded: the last pick
+            pv = make_float2(f0[base + at], mask[base + at]);
+        }
+        picks[f] = pv;
+    }
+    const int64_t rows = env_off[note + 1] - env_off[note];
     if (t > rows - 1) t = rows - 1;     // edge-repeat (np.pad mode='edge'); truncation is implicit
     if (t < 0) t = 0;
     row_src[f] = env_off[note] + t;
@@ -1302,7 +1339,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // and the mask smoothing (0.07 ms of the critical path).
     const bool maps_side = early && f0_alias && stem_path && ctx->maps_side;
     hipStream_t mst = maps_side ? ctx->side : st;
-    if (!maps_side) HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), st));
+    // one launch for all the maps when they stay on the caller's stream
+    const bool maps_fused = stem_path && !maps_side;
+    if (!maps_side && !maps_fused) HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), st));
     MARK();   // 0: setup
     if (early) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_entry, 0));
@@ -1315,7 +1354,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_f0s, ctx->side));
     }
-    if ((rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, mst))) return rc;
+    if (!maps_fused && (rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, mst))) return rc;
     if (!early && !f0_alias) {
         hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params,
                            f0s);                                     // (the pulse walk divides by sr itself)
@@ -1325,8 +1364,14 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // nothing jitters it in place later, and it is not being produced on the side stream
     const bool picks_on = !jit_f0 && !sub_jit && !(early && !f0_alias);
     ctx->frame_picks = picks_on ? picks : nullptr;
-    hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, mst, b->frame_off, b->env_off, frame_note, F, row_src, b->sample_off,
-                       (const float *)f0s, b->mask, p.hop, picks_on ? picks : (float2 *)nullptr);
+    if (maps_fused) {
+        const int64_t threads = std::max<int64_t>(F, 2 * (int64_t)n);
+        hipLaunchKernelGGL(k_frame_maps, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, b->frame_off, b->env_off, n, F, frame_note,
+                           row_src, b->sample_off, (const float *)f0s, b->mask, p.hop, picks_on ? picks : (float2 *)nullptr, note_steps, note_mag);
+    } else {
+        hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, mst, b->frame_off, b->env_off, frame_note, F, row_src, b->sample_off,
+                           (const float *)f0s, b->mask, p.hop, picks_on ? picks : (float2 *)nullptr);
+    }
     LAUNCH_CHECK(ctx);
     if (maps_side) {
         if ((rc = launch_note_steps(ctx, b->sample_off, n, note_steps, mst))) return rc;
@@ -1351,7 +1396,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if (!picks_on && (r2 = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return r2;
         if ((r2 = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return r2;
         if (side_on) MARK_Q(0);
-        if (!maps_side && (r2 = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return r2;
+        if (!maps_side && !maps_fused && (r2 = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return r2;
         if ((r2 = launch_noise_stems(ctx, b->env_noise ? b->env_noise : b->env, ld, row_src, b->phi, F, frame_note, b->frame_off,
                                      b->sample_off, picks, b->params, b->seed, b->env_noise != nullptr, short_s, note_steps, b->uv,
                                      b->bre, st)))
@@ -1447,7 +1492,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         MARK();
         if (!side_on) {
             if (!picks_on && (rc = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return rc;
-            if ((rc = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return rc;
+            if (!maps_fused && (rc = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return rc;
             if ((rc = launch_noise_stems(ctx, b->env_noise ? b->env_noise : b->env, ld, row_src, b->phi, F, frame_note, b->frame_off,
                                          b->sample_off, picks, b->params, b->seed, b->env_noise != nullptr, short_s, note_steps, b->uv,
                                          b->bre, st)))

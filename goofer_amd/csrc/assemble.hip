@@ -535,6 +535,27 @@ __global__ void k_row_notes(const goofer_note_plan *__restrict__ notes, int n_no
     row_note[r] = lo;
 }
 
+// both row -> note maps of an assembly (edited source rows, output rows) in one launch
+__global__ void k_row_notes2(const goofer_note_plan *__restrict__ notes, int n_notes, int64_t edit_rows, int64_t out_rows,
+                             int *__restrict__ row_note_edit, int *__restrict__ row_note_out)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= edit_rows && r >= out_rows) return;
+    int lo = 0, hi = n_notes, lo2 = 0, hi2 = n_notes;
+    while (hi - lo > 1 || hi2 - lo2 > 1) {
+        if (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (notes[mid].edit_off <= r) lo = mid; else hi = mid;
+        }
+        if (hi2 - lo2 > 1) {
+            const int mid = (lo2 + hi2) >> 1;
+            if (notes[mid].env_off <= r) lo2 = mid; else hi2 = mid;
+        }
+    }
+    if (r < edit_rows) row_note_edit[r] = lo;
+    if (r < out_rows) row_note_out[r] = lo2;
+}
+
 int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edit, int *row_note_out, hipStream_t st)
 {
     const int B = a->n_bins;
@@ -553,10 +574,15 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
             ctx->early_f0 = a->f0_out;
         }
     }
+    {
+        const int64_t rows = std::max(a->total_edit_rows, a->total_out_rows);
+        if (rows > 0) {
+            hipLaunchKernelGGL(k_row_notes2, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, a->notes, a->n_notes, a->total_edit_rows,
+                               a->total_out_rows, row_note_edit, row_note_out);
+            LAUNCH_CHECK(ctx);
+        }
+    }
     if (a->total_edit_rows > 0) {
-        hipLaunchKernelGGL(k_row_notes, dim3((unsigned)((a->total_edit_rows + 255) / 256)), dim3(256), 0, st, a->notes, a->n_notes,
-                           a->total_edit_rows, 0, row_note_edit);
-        LAUNCH_CHECK(ctx);
         size_t lds = (size_t)A_ROWS * ((3 * B + 2 * ES_HALO + a->max_K + 3) & ~3) * sizeof(float);
         if (lds > 64 * 1024) {
             if (lds > 160 * 1024) return goofer_fail(ctx, GOOFER_EINVAL, "envelope rows too wide for the edit kernel's LDS staging");
@@ -567,9 +593,6 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         LAUNCH_CHECK(ctx);
     }
     if (a->total_out_rows > 0) {
-        hipLaunchKernelGGL(k_row_notes, dim3((unsigned)((a->total_out_rows + 255) / 256)), dim3(256), 0, st, a->notes, a->n_notes,
-                           a->total_out_rows, 1, row_note_out);
-        LAUNCH_CHECK(ctx);
         const dim3 lgrid((unsigned)((a->total_out_rows + A_ROWS - 1) / A_ROWS));
         ctx->warp_done = false;
         const bool fused_warp = ctx->warp_out && !a->any_fry;   // (the fry edit rewrites rows afterwards: the warp then stays a pass of its own)

@@ -37,10 +37,10 @@ def phases_of(lines):
         ("frame records, note entry, flatness checks, knot prefetch (every frame; note entry once per note)", [(L("    float2 carry_u[R - G], carry_b[R - G];", n0), L("// 1. noise envelope: sigma-1.75 blur", n0) - 1)]),
         ("1. row staging through LDS + sigma-1.75 blur (every frame)", [(L("// 1. noise envelope: sigma-1.75 blur", n0), L("if (f + 1 < f1) {                                     // the row registers are consumed", n0) - 1)]),
         ("next row's fetch + frame-record refill (refill every 64 frames)", [(L("if (f + 1 < f1) {                                     // the row registers are consumed", n0), L("// 2. U * env_n", n0) - 1)]),
-        ("2. Philox, sin/cos, U*env, high-pass, brightness (every frame; brightness on voiced frames)", [(L("// 2. U * env_n", n0), L("        if (voiced) {\n", n0) - 1)]),
-        ("2b. 5-tap blur of the breath spectrum (voiced frames)", [(L("        if (voiced) {\n", n0), L("// 3. inverse transforms + overlap-add", n0) - 1)]),
-        ("3. irFFT + overlap-add, breath stem (skipped where the stem gain is exactly 0: unvoiced stretches)", [(L("else w.inverse_ola(sb, t, carry_b, ob);", n0), L("else w.inverse_ola(sb, t, carry_b, ob);", n0))]),
-        ("3. irFFT + overlap-add, unvoiced stem (skipped where exactly 0: voiced stretches = the bench workload)", [(L("else w.inverse_ola(su, t, carry_u, ou);", n0), L("else w.inverse_ola(su, t, carry_u, ou);", n0))]),
+        ("2. Philox, sin/cos, U*env, high-pass, brightness (every frame; brightness on voiced frames)", [(L("// 2. U * env_n", n0), L("        const bool td_blur = (mode & 4) != 0;", n0) - 1)]),
+        ("2b. 5-tap blur of the breath spectrum (voiced frames, only with td_blur off: the default folds it into the window)", [(L("        const bool td_blur = (mode & 4) != 0;", n0), L("// 3. inverse transforms + overlap-add", n0) - 1)]),
+        ("3. irFFT + overlap-add, breath stem (skipped where the stem gain is exactly 0: unvoiced stretches)", [(L("if (voiced && td_blur) w.blur_edges(sb, ec, t5[0], t5[1]);", n0), L("w.inverse_ola(sb, t, carry_b, ob, (voiced && td_blur) ? w.wsv : w.wsc);", n0))]),
+        ("3. irFFT + overlap-add, unvoiced stem (skipped where exactly 0: voiced stretches = the bench workload)", [(L("else w.inverse_ola(su, t, carry_u, ou, w.wsc);", n0), L("else w.inverse_ola(su, t, carry_u, ou, w.wsc);", n0))]),
         ("3. skip bookkeeping (ring rotation of a skipped transform, flatness bits)", [(L("// 3. inverse transforms + overlap-add", n0), L("// 4. hop t -> window-sum quotient", n0) - 2)]),
         ("4. output: window-sum quotient, mask gain, stores (every emitted frame; smooth_mask_at32 only on non-flat hops)", [(L("// 4. hop t -> window-sum quotient", n0) - 1, h0 - 1)]),
     ]
@@ -50,10 +50,10 @@ def phases_of(lines):
         ("1. window + forward FFT (every frame)", [(L("// 1. windowed frame -> complex FFT", h0), L("// 2. even/odd split", h0) - 1)]),
         ("2. even/odd split through LDS (every frame)", [(L("// 2. even/odd split", h0), L("if (f + 1 < f1) {                                            // raw pairs and row are consumed", h0) - 1)]),
         ("next frame's fetch: 8 sample pairs + envelope row (+ reflect padding at note ends, record refill every 64 frames)", [(L("if (f + 1 < f1) {                                            // raw pairs and row are consumed", h0), L("// 3. shaping (GOOFER.py:1102-1144)", h0) - 1), (L("    auto fetch = [&](int64_t f, int idx) {", h0), L("    float2 carry[R - G];", h0) - 1)]),
-        ("3. shaping: high-pass, max|S|, env * boost, brightness (every frame)", [(L("// 3. shaping (GOOFER.py:1102-1144)", h0), L("        if (voiced) {\n", h0) - 1)]),
-        ("3b. 5-tap blur (voiced frames)", [(L("        if (voiced) {\n", h0), L("// 4. inverse transform + overlap-add; hop t leaves", h0) - 1)]),
-        ("4. irFFT + overlap-add (every frame)", [(L("// 4. inverse transform + overlap-add; hop t leaves", h0), L("w.inverse_ola(X, t, carry, e);", h0))]),
-        ("4b. output: window-sum quotient, stores (every emitted frame)", [(L("w.inverse_ola(X, t, carry, e);", h0) + 1, fin - 1)]),
+        ("3. shaping: high-pass, max|S|, env * boost, brightness (every frame)", [(L("// 3. shaping (GOOFER.py:1102-1144)", h0), L("        if (voiced && !td_blur) {\n", h0) - 1)]),
+        ("3b. 5-tap blur (voiced frames, only with td_blur off)", [(L("        if (voiced && !td_blur) {\n", h0), L("// 4. inverse transform + overlap-add; hop t leaves", h0) - 1)]),
+        ("4. blur edge correction + irFFT + overlap-add (every frame)", [(L("// 4. inverse transform + overlap-add; hop t leaves", h0), L("w.inverse_ola(X, t, carry, e, (voiced && td_blur) ? w.wsv : w.wsc);", h0))]),
+        ("4b. output: window-sum quotient, stores (every emitted frame)", [(L("w.inverse_ola(X, t, carry, e, (voiced && td_blur) ? w.wsv : w.wsc);", h0) + 1, fin - 1)]),
     ]
     mk = lambda ph: [{"name": n, "file": "stems.hip", "lines": [list(r) for r in rs]} for n, rs in ph]
     return mk(noise), mk(harm)
