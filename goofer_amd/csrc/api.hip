@@ -36,7 +36,9 @@ int launch_harm_shape(goofer_ctx *, float2 *, int, int64_t, const int *, const i
                       hipStream_t);
 int launch_noise_spectra(goofer_ctx *, float2 *, float2 *, int, int64_t, const int *, const int64_t *, const int64_t *,
                          const float *, const float *, const float *, const float *, int, const goofer_note_params *, uint64_t,
-                         const int64_t *, bool, hipStream_t);
+                         const int64_t *, bool, const unsigned char *, hipStream_t);
+int launch_frame_skip(goofer_ctx *, const double *, const int64_t *, const int64_t *, const int *, int, int64_t, unsigned char *,
+                      unsigned char *, hipStream_t);
 int launch_mask_short(goofer_ctx *, const float *, const int64_t *, int, int64_t, const double *, int, double, double *, hipStream_t);
 int launch_assemble(goofer_ctx *, const goofer_assembly *, int *, int *, hipStream_t);
 int launch_mag_rows(goofer_ctx *, const float2 *, int, int64_t, int, float *, int, hipStream_t);
@@ -90,7 +92,8 @@ int launch_mask_upsample(goofer_ctx *, const double *, const int64_t *, int, int
 bool stems_supported(const goofer_plan_t &);
 bool ola_split_supported(const goofer_plan_t &);
 int launch_irfft_ola1(goofer_ctx *, const float2 *, const float2 *, const float2 *, int, int64_t, const int *, const int64_t *,
-                      const int64_t *, int, const double *, double *, const goofer_note_params *, float *, float *, float *, hipStream_t);
+                      const int64_t *, int, const double *, double *, const goofer_note_params *, float *, float *, float *,
+                      const unsigned char *, hipStream_t);
 int launch_frame_picks(goofer_ctx *, const int64_t *, const int *, int64_t, const int64_t *, const float *, const float *, float2 *,
                        hipStream_t);
 int launch_noise_stems(goofer_ctx *, const float *, int, const int64_t *, const float *, int64_t, const int *, const int64_t *,
@@ -321,6 +324,11 @@ static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t sampl
     add((samples / 4 + notes + 16) * sizeof(double));  // smoothed decimated mask
     add(2 * notes * sizeof(float) + 64);          // note_mag, note_peak
     add(2 * notes * sizeof(double) + 64);         // per-note linspace steps
+    if (spectra) {                                // per-hop flatness + per-frame skip bits of the LDS-ring pipeline
+        const int64_t reach = (p.n_fft + p.hop - 1) / p.hop;
+        add((size_t)(frames + reach * notes) + 64);
+        add((size_t)frames + 64);
+    }
     return b + 4096;
 }
 
@@ -1249,6 +1257,13 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     double *short_s = a.take<double>(N / 4 + n + 16);
     float *note_mag = a.take<float>(2 * (size_t)n + 16);
     double *note_steps = a.take<double>(2 * (size_t)n + 16);
+    // n_fft 2048: one stem per wave (two waves per SIMD instead of one), then the per-note finish of the stem-split path
+    const bool ola_split = !walkers && ctx->ola_fused && (p.hop % 2 == 0) && ctx->stems && ola_split_supported(p) && !jit_vol;
+    // ... with the exact sparsity of the noise stems decided per frame up front (k_frame_skip)
+    const bool skip_frames = ola_split && ctx->skip_zero && ctx->overlap && !sub_on && p.hop <= 512;
+    unsigned char *hop_flat = skip_frames ? a.take<unsigned char>((size_t)F + (size_t)((p.n_fft + p.hop - 1) / p.hop) * n + 16) : nullptr;
+    unsigned char *frame_skip = skip_frames ? a.take<unsigned char>((size_t)F + 16) : nullptr;
+    if (skip_frames && (!hop_flat || !frame_skip)) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     if (!picks || !frames_u || !frames_b || !frame_note || !row_src || !f0s || (sub_on && !inc) || !onsets || !onset_idx || !onset_cnt || !ovf || !pulse || !S_h || !S_uv || !S_br || !frames ||
         !env_h || !env_n || !short_s || !note_mag || !note_steps)
         return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
@@ -1454,12 +1469,17 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
             if (maps_side) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_maps, 0));        // the maps come from the side stream
             if ((rc = stems_aperiodic())) return rc;
         } else {
+            // (the skip bits need the smoothed mask: it goes first then)
+            if (skip_frames) {
+                if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
+                if ((rc = launch_frame_skip(ctx, short_s, b->sample_off, b->frame_off, frame_note, n, F, hop_flat, frame_skip, st))) return rc;
+            }
             if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
                                            b->env_noise ? b->env_noise : b->env, b->phi, ld, b->params, b->seed, row_src,
-                                           b->env_noise != nullptr, st)))
+                                           b->env_noise != nullptr, frame_skip, st)))
                 return rc;
             MARK_Q(0);
-            if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
+            if (!skip_frames && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
             MARK_Q(1);
         }
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
@@ -1535,7 +1555,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         MARK();   // 9: aperiodic spectra
         if (!side_on && (rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
                                                    b->env_noise ? b->env_noise : b->env, b->phi, ld, b->params, b->seed, row_src,
-                                                   b->env_noise != nullptr, st)))
+                                                   b->env_noise != nullptr, nullptr, st)))
             return rc;
         MARK();   // 10, 11
         if (!ola_one && (rc = launch_irfft_frames(ctx, S_br, ldc, F, frames_b, st))) return rc;
@@ -1545,11 +1565,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     MARK();   // 12: decimated + smoothed voicing mask
     if (!side_on && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
     MARK();   // 13: (irFFT of the three stems +) overlap-add + gains + per-note peak, one pass
-    // n_fft 2048: one stem per wave (two waves per SIMD instead of one), then the per-note finish of the stem-split path
-    const bool ola_split = ola_one && ctx->stems && ola_split_supported(p) && !jit_vol;
     if (ola_split) {
         if ((rc = launch_irfft_ola1(ctx, S_h, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, n, short_s, note_steps,
-                                    b->params, b->harm, b->uv, b->bre, st)))
+                                    b->params, b->harm, b->uv, b->bre, frame_skip, st)))
             return rc;
         MARK();   // 14
         if ((rc = launch_note_finish(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, b->params, note_mag, note_peak,

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
                                                        const float *__restrict__ freqs, const float *__restrict__ bright,
                                                        const double *__restrict__ taps5, int n_bins, int hop,
                                                        const int64_t *__restrict__ row_src, const double *__restrict__ taps175,
-                                                       const float2 *__restrict__ picks)
+                                                       const float2 *__restrict__ picks, const unsigned char *__restrict__ frame_skip)
 {
     // env_noise is either the already-blurred [frames x ld] matrix (row_src == nullptr) or the source rows, in
     // which case the sigma-1.75 bin blur (GOOFER.py:993) runs here from the LDS row.
@@ -301,6 +301,10 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int64_t f = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
     if (f >= total_frames) return;
+    // bit 0 / 1: the frame's unvoiced / breath spectrum cannot reach a non-zero sample (k_frame_skip): not written, and the
+    // overlap-add kernel will not read it
+    const unsigned sk = frame_skip ? (unsigned)frame_skip[f] : 0u;
+    if (sk == 3u) return;
     const int rowf = (n_bins + 1) & ~1;
     float2 *r = reinterpret_cast<float2 *>(smem) + (size_t)wave * (n_bins + rowf / 2 + 1);
     float *ra = reinterpret_cast<float *>(r + n_bins);
@@ -386,13 +390,14 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
             e = ev[i];
         }
         float2 u2 = make_float2(c * e, s * e);
-        ru[k] = u2;
+        if (!(sk & 1u)) ru[k] = u2;
+        if (sk & 2u) continue;
         float h = hp_mask(fq[i], f0f);
         float2 b = make_float2(u2.x * h, u2.y * h);
         if (voiced) { b.x *= br[i]; b.y *= br[i]; r[k] = b; }
         else rb[k] = b;
     }
-    if (voiced) {
+    if (voiced && !(sk & 2u)) {
         wave_lds_sync();
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
 int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, int64_t total_frames, const int *frame_note,
                          const int64_t *frame_off, const int64_t *sample_off, const float *f0, const float *mask,
                          const float *env_noise, const float *phi, int ld, const goofer_note_params *params, uint64_t seed,
-                         const int64_t *row_src, bool preblurred, hipStream_t st)
+                         const int64_t *row_src, bool preblurred, const unsigned char *frame_skip, hipStream_t st)
 {
     if (total_frames <= 0) return GOOFER_OK;
     const goofer_plan_t &pl = ctx->plan;
@@ -415,7 +420,7 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
 #define NOISE_SPECTRA(IT)                                                                                                          \
     hipLaunchKernelGGL(k_noise_spectra<IT>, grid, dim3(256), lds, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,        \
                        sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins, pl.hop, \
-                       row_src, preblurred ? (const double *)nullptr : pl.blur175, ctx->frame_picks)
+                       row_src, preblurred ? (const double *)nullptr : pl.blur175, ctx->frame_picks, frame_skip)
     switch ((pl.n_bins + WAVE - 1) / WAVE) {
     case 5: NOISE_SPECTRA(5); break;
     case 7: NOISE_SPECTRA(7); break;

@@ -566,7 +566,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
                                                     const double *__restrict__ short_s, const double *__restrict__ steps,
                                                     const goofer_note_params *__restrict__ params, float *__restrict__ harm,
                                                     float *__restrict__ uv, float *__restrict__ bre, const float2 *__restrict__ g_tw,
-                                                    const float2 *__restrict__ g_twh, const float *__restrict__ g_win)
+                                                    const float2 *__restrict__ g_twh, const float *__restrict__ g_win,
+                                                    const unsigned char *__restrict__ frame_skip)
 {
     constexpr int R = fft_cfg<M>::R, NF = 2 * M, BUF = fft_cfg<M>::BUF;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -581,10 +582,26 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2 *buf = bufs + wave * BUF;
     float *ring = rings + (size_t)wave * NF;
-    const int64_t job = (int64_t)blockIdx.x * WPB + wave;
-    const int stem = (int)(job % 3);                          // wave-uniform
-    const int64_t f0 = (job / 3) * run;
+    // A workgroup holds runs of ONE stem (stems interleaved workgroup by workgroup): where a stem's transforms are skipped
+    // (frame_skip: its gain is exactly zero over everything the frame reaches) whole workgroups retire early and the
+    // dispatcher hands their CU to the next one — with the three stems of a run side by side in one workgroup the skipped
+    // waves only idled beside the others.
+    const int stem = (int)(blockIdx.x % 3);                   // workgroup-uniform
+    const int64_t f0 = ((int64_t)(blockIdx.x / 3) * WPB + wave) * run;
     if (f0 >= total_frames) return;                           // no block barrier below
+    const unsigned skip_bit = frame_skip ? (unsigned)stem : 0u;   // bit 0 (1): unvoiced stem, bit 1 (2): breath stem; harmonic: never
+    // the skip bits of 64 consecutive frames as one ballot (a byte load per frame would sit on the loop's critical path)
+    uint64_t skip_mask = 0;
+    int64_t skip_base = -(int64_t)WAVE;
+    auto skipped = [&](int64_t f) {
+        if (skip_bit == 0u) return false;
+        if (f >= skip_base + WAVE || f < skip_base) {
+            skip_base = f;
+            const int64_t g = f + lane;
+            skip_mask = __ballot(g < total_frames && (frame_skip[g] & skip_bit) != 0);
+        }
+        return ((skip_mask >> (int)(f - skip_base)) & 1ull) != 0;
+    };
     const int64_t f1 = f0 + run < total_frames ? f0 + run : total_frames;
     const float inv_m = 0.5f / (float)M;                     // 1/M of the transform and the 1/2 of the input stage (irfft_pre)
     const float2 *S = stem == 0 ? S_h : (stem == 1 ? S_u : S_b);
@@ -596,17 +613,18 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
         const int64_t t0 = f0 - frame_off[nt];
         fs = f0 - (t0 < halo ? t0 : halo);
     }
-    float2 nk[R], nm[R];                                      // spectrum rows of the next frame, fetched during the transform
+    // spectrum row of the next frame, fetched during the transform: bins lane + 64 r and the Nyquist bin; the mirrored bins
+    // X[M - k] of the inverse transform's input stage come from the row itself through the (idle) exchange buffer — a second
+    // set of loads would hold 32 more registers across the whole frame
+    float2 nk[R], ny;
     auto fetch = [&](int64_t f) {
         const float2 *row = S + f * (int64_t)ldc;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int k = lane + WAVE * r;
-            nk[r] = row[k];
-            nm[r] = row[M - k];
-        }
+        for (int r = 0; r < R; ++r) nk[r] = row[lane + WAVE * r];
+        ny = row[M];
     };
-    fetch(fs);
+    bool skip_cur = skipped(fs);
+    if (!skip_cur) fetch(fs);
 
     int note = -1;
     int64_t base = 0, fbase = 0;
@@ -618,6 +636,22 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
     auto wc_of = [&](int k) { return (k <= M / 2) ? cconj(twh[k]) : make_float2(-twh[M - k].x, -twh[M - k].y); };
     auto win_of = [&](int k) { return make_float2(win[2 * k] * inv_m, -(win[2 * k + 1] * inv_m)); };
 
+    // summed squared window of this lane's hop samples j = lane + 64 u for interior hops (every covering frame exists): a
+    // constant per lane, with its correctly rounded reciprocal (div_by); the first two slots only — wider hops take the loop
+    float ws_c[2] = {0.f, 0.f}, rws_c[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = lane + WAVE * u;
+        if (j < hop) {
+            float ws = 0.f;
+            for (int q = (NF - 1 - j) / hop; q >= 0; --q) {   // ascending frame order = descending offset
+                const float w = win[j + q * hop];
+                ws += w * w;
+            }
+            ws_c[u] = ws;
+            rws_c[u] = 1.0f / ws;
+        }
+    }
     const int KN = hop / MASK_DS + KNOT_MARGIN;
     double *kbuf = knots + (size_t)wave * (512 / MASK_DS + KNOT_MARGIN);
     constexpr int KPL = (512 / MASK_DS + KNOT_MARGIN + WAVE - 1) / WAVE;
@@ -645,20 +679,26 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
             return kbuf[e < e_hi ? e : e_hi];
         };
         auto knot_g = [&](int k) { return ss[k]; };
-        for (int j = lane; j < hop; j += WAVE) {
+        const bool inner = h >= max_back && h <= T - 1;       // every covering frame exists
+        for (int j = lane, u = 0; j < hop; j += WAVE, ++u) {
             const int i = h * hop + j - M;
             if (i < 0 || i >= n) continue;
             float x = 0.f;
             if (i < out_len) {
-                const int back = (NF - 1 - j) / hop;
-                const int flo = h - back < 0 ? 0 : h - back, fhi = h > T - 1 ? T - 1 : h;
-                float ws = 0.f;
-                for (int fr = flo; fr <= fhi; ++fr) {
-                    const float w = win[j + (h - fr) * hop];
-                    ws += w * w;
-                }
                 x = ring[(h * hop + j) & (NF - 1)];
-                if (ws > 1e-9f) x /= ws;
+                if (inner && u < 2) {
+                    const float ws = u == 0 ? ws_c[0] : ws_c[1], rw = u == 0 ? rws_c[0] : rws_c[1];
+                    if (ws > 1e-9f) x = div_by(x, ws, rw);
+                } else {
+                    const int back = (NF - 1 - j) / hop;
+                    const int flo = h - back < 0 ? 0 : h - back, fhi = h > T - 1 ? T - 1 : h;
+                    float ws = 0.f;
+                    for (int fr = flo; fr <= fhi; ++fr) {
+                        const float w = win[j + (h - fr) * hop];
+                        ws += w * w;
+                    }
+                    if (ws > 1e-9f) x /= ws;
+                }
             }
             if (stem != 0) {
                 const float ms = slots_ok ? smooth_mask_at32(knot_l, ns, i, n, step_n, step_s, kps)
@@ -668,7 +708,6 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
             out[base + i] = x;
         }
     };
-    (void)max_back;
 
     for (int64_t f = fs; f < f1; ++f) {
         const int nt = frame_note[f];
@@ -687,17 +726,33 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
             ss = short_s + short_base(sample_off, note);
         }
         const int t = (int)(f - fbase);
-        if (f >= f0 && slots_ok) knots_fetch(t);
+        const int shift = (t * hop) & (NF - 1);
+        const bool skip_this = skip_cur;
+        if (f >= f0 && slots_ok && !skip_this) knots_fetch(t);
+        skip_cur = f + 1 < f1 && skipped(f + 1);
+        if (skip_this) {
+            // no transform: the slots this frame would have started from zero are zeroed, the others keep their sums
+            if (f + 1 < f1 && !skip_cur) fetch(f + 1);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int m = lane + WAVE * r;
+                if (t == 0 || 2 * m >= NF - hop) *reinterpret_cast<float2 *>(ring + ((2 * m + shift) & (NF - 1))) = make_float2(0.f, 0.f);
+            }
+        } else {
         float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) buf[lane + WAVE * r] = nk[r];
+        if (lane == 0) buf[M] = ny;
+        wave_lds_sync();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int k = lane + WAVE * r;
-            float2 xk = nk[r], xm = nm[r];
+            float2 xk = nk[r], xm = buf[M - k];
             if (k == 0) { xk.y = 0.f; xm.y = 0.f; }           // irfft ignores Im of DC and Nyquist
             v[r] = irfft_pre(xk, xm, wc_of(k));
         }
-        if (f + 1 < f1) fetch(f + 1);
-        const int shift = (t * hop) & (NF - 1);
+        wave_lds_sync();                                      // the row is read before the transform reuses buf
+        if (f + 1 < f1 && !skip_cur) fetch(f + 1);
         float2 z[R];
         wave_fft_keep<M>(v, buf, tw, lane, z);                // the lane's output points stay in registers
         // ring reads ahead of ring writes, eight slots at a time (the R slots of a lane are distinct)
@@ -718,10 +773,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
                 *reinterpret_cast<float2 *>(ring + ((2 * m + shift) & (NF - 1))) = make_float2(first ? a : o[q].x + a, first ? b : o[q].y + b);
             }
         }
+        }
         wave_lds_sync();
         if (f >= f0) {
             for (int h = t;;) {
-                if (slots_ok) {
+                if (slots_ok && !skip_this) {
 #pragma unroll
                     for (int c = 0; c < KPL; ++c) {
                         const int e = lane + WAVE * c;
@@ -729,10 +785,18 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
                     }
                     wave_lds_sync();
                 }
-                emit(h);
+                if (skip_this) {
+                    // every hop this frame reaches has a gain of exactly zero: the hop (and the flush hops behind a last frame) is zeros
+                    for (int j = lane; j < hop; j += WAVE) {
+                        const int i = h * hop + j - M;
+                        if (i >= 0 && i < n) out[base + i] = 0.f;
+                    }
+                } else {
+                    emit(h);
+                }
                 ++h;
                 if (t != T - 1 || h * hop - M >= n) break;
-                if (slots_ok) knots_fetch(h);
+                if (slots_ok && !skip_this) knots_fetch(h);
             }
         }
         wave_lds_sync();
@@ -742,7 +806,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
 template <int M>
 static int irfft_ola1_impl(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u, const float2 *S_b, int ldc, int64_t total_frames,
                            const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, const double *short_s,
-                           const double *steps, const goofer_note_params *params, float *harm, float *uv, float *bre, hipStream_t st)
+                           const double *steps, const goofer_note_params *params, float *harm, float *uv, float *bre,
+                           const unsigned char *frame_skip, hipStream_t st)
 {
     constexpr int WPB = 8;
     const goofer_plan_t &p = ctx->plan;
@@ -761,10 +826,10 @@ static int irfft_ola1_impl(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u
     const int64_t rounds = (3 * total_frames + slots * 256 - 1) / (slots * 256);
     int64_t fit = (3 * total_frames + rounds * slots - 1) / (rounds * slots);
     const int run = (int)(fit > min_run ? fit : min_run);
-    const int64_t runs = (total_frames + run - 1) / run, jobs = 3 * runs;
-    hipLaunchKernelGGL((k_irfft_ola1<M, WPB>), dim3((unsigned)((jobs + WPB - 1) / WPB)), dim3(64 * WPB), lds, st, S_h, S_u, S_b, ldc,
+    const int64_t runs = (total_frames + run - 1) / run;
+    hipLaunchKernelGGL((k_irfft_ola1<M, WPB>), dim3((unsigned)(3 * ((runs + WPB - 1) / WPB))), dim3(64 * WPB), lds, st, S_h, S_u, S_b, ldc,
                        total_frames, frame_note, frame_off, sample_off, p.hop, run, halo, short_s, steps, params, harm, uv, bre,
-                       p.tw_full, p.tw_half, p.window);
+                       p.tw_full, p.tw_half, p.window, frame_skip);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
@@ -774,14 +839,82 @@ bool ola_split_supported(const goofer_plan_t &p) { return p.n_fft == 2048 && (p.
 
 int launch_irfft_ola1(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u, const float2 *S_b, int ldc, int64_t total_frames,
                       const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, int n_notes, const double *short_s,
-                      double *steps, const goofer_note_params *params, float *harm, float *uv, float *bre, hipStream_t st)
+                      double *steps, const goofer_note_params *params, float *harm, float *uv, float *bre,
+                      const unsigned char *frame_skip, hipStream_t st)
 {
     if (total_frames <= 0) return GOOFER_OK;
     if (!ola_split_supported(ctx->plan)) return goofer_fail(ctx, GOOFER_EINVAL, "one-stem overlap-add is built for n_fft 2048");
     hipLaunchKernelGGL(k_note_steps, dim3((n_notes + 255) / 256), dim3(256), 0, st, sample_off, n_notes, steps);
     LAUNCH_CHECK(ctx);
     return irfft_ola1_impl<1024>(ctx, S_h, S_u, S_b, ldc, total_frames, frame_note, frame_off, sample_off, short_s, steps, params,
-                                 harm, uv, bre, st);
+                                 harm, uv, bre, frame_skip, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact sparsity of the noise stems for the LDS-ring pipeline (the walkers of stems.hip decide the same thing per hop inside
+// their frame loop): where the smoothed mask is flat at (float) 1 over every knot a hop's samples can read, the unvoiced stem
+// of that hop is multiplied by exactly 0 (GOOFER.py:1181), where it is flat at 0 the breath stem is (:1180).  A frame whose
+// every hop is such a hop cannot reach a non-zero sample of that stem: its spectrum is neither written nor transformed.
+// hop_flat[frame_off[note] + reach * note + h], h < T + reach: bit 0 flat at one, bit 1 flat at zero (hops without an
+// output sample count as both); the knot window is the one k_irfft_ola1 stages for the hop (knots_fetch).
+__global__ void k_hop_flat(const double *__restrict__ short_s, const int64_t *__restrict__ sample_off, const int64_t *__restrict__ frame_off,
+                           int n_notes, int hop, int M, int reach, unsigned char *__restrict__ hop_flat)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= frame_off[n_notes] + (int64_t)reach * n_notes) return;
+    int lo = 0, hi = n_notes;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (frame_off[mid] + (int64_t)reach * mid <= g) lo = mid; else hi = mid;
+    }
+    const int note = lo;
+    const int h = (int)(g - (frame_off[note] + (int64_t)reach * note));
+    const int n = (int)(sample_off[note + 1] - sample_off[note]);
+    const int ns = (n + MASK_DS - 1) / MASK_DS;
+    const int i_lo = h * hop - M, i_hi = i_lo + hop - 1;
+    unsigned flags = 3u;
+    if (!(i_hi < 0 || i_lo >= n || ns <= 0)) {
+        const double *ss = short_s + short_base(sample_off, note);
+        const float kps = n > 1 ? (float)(ns - 1) / (float)(n - 1) : 0.f;
+        int k0 = (int)((float)(i_lo < 0 ? 0 : i_lo) * kps) - 4;
+        k0 = k0 < 0 ? 0 : (k0 > ns - 1 ? ns - 1 : k0);
+        int k1 = k0 + hop / MASK_DS + KNOT_MARGIN - 1;
+        k1 = k1 > ns - 1 ? ns - 1 : k1;
+        const double c = ss[k0];
+        bool same = true;
+        for (int k = k0 + 1; k <= k1; ++k) same = same && ss[k] == c;
+        const float cf = (float)c;
+        flags = same ? ((1.0f - cf == 0.0f ? 1u : 0u) | (cf == 0.0f ? 2u : 0u)) : 0u;
+    }
+    hop_flat[g] = (unsigned char)flags;
+}
+
+__global__ void k_frame_skip(const unsigned char *__restrict__ hop_flat, const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
+                             int64_t total_frames, int reach, unsigned char *__restrict__ frame_skip)
+{
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= total_frames) return;
+    const int note = frame_note[f];
+    const unsigned char *hf = hop_flat + f + (int64_t)reach * note;      // (= frame_off[note] + reach * note + t)
+    unsigned acc = 3u;
+    for (int q = 0; q < reach; ++q) acc &= hf[q];
+    frame_skip[f] = (unsigned char)acc;
+}
+
+int launch_frame_skip(goofer_ctx *ctx, const double *short_s, const int64_t *sample_off, const int64_t *frame_off, const int *frame_note,
+                      int n_notes, int64_t total_frames, unsigned char *hop_flat, unsigned char *frame_skip, hipStream_t st)
+{
+    if (total_frames <= 0) return GOOFER_OK;
+    const goofer_plan_t &p = ctx->plan;
+    const int reach = (p.n_fft + p.hop - 1) / p.hop;
+    const int64_t hops = total_frames + (int64_t)reach * n_notes;
+    hipLaunchKernelGGL(k_hop_flat, dim3((unsigned)((hops + 255) / 256)), dim3(256), 0, st, short_s, sample_off, frame_off, n_notes, p.hop,
+                       p.n_fft / 2, reach, hop_flat);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_frame_skip, dim3((unsigned)((total_frames + 255) / 256)), dim3(256), 0, st, hop_flat, frame_note, frame_off,
+                       total_frames, reach, frame_skip);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
 }
 
 template <int M>

@@ -108,3 +108,40 @@ def test_config5_batch_full_size():
         _oracle_notes(ctx, 5, [ids[0], ids[1], ids[-1]], 2e-5)
     finally:
         ctx.close()
+
+
+def test_config5_frame_skipping_changes_no_bit():
+    """hop != n_fft / 4 (BASELINE config 5: n_fft 2048, hop 96): the noise stems' transforms are skipped where the smoothed
+    voicing mask makes the stem gain exactly zero over every hop a frame reaches (k_frame_skip; neither written by
+    k_noise_spectra nor transformed by k_irfft_ola1).  With the skipping off every frame is transformed: the stems and the
+    mix must be the same bits — on sources with unvoiced stretches, so that both stems have skipped and live frames."""
+    from goofer_amd import sampler as S
+    from goofer_amd import synthetic as syn
+    from goofer_amd.device import Context
+    from goofer_amd.render import Renderer, Source
+    geo = syn.config_geometry(5)
+    ctx = Context(0)
+    try:
+        r = Renderer(ctx, hop=geo["hop"])
+        jobs = []
+        for k, i in enumerate([3, 11, 40, 77, 130, 500]):
+            src, req, _ = syn.config_note(5, i)
+            if k % 2 == 0:
+                src = syn.with_unvoiced_gaps(src, 0.35, 4000 + i)
+            jobs.append((Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]),
+                         S.decode_request(*syn.request_args(req))))
+        prep = r.prepare(jobs, note_ids=list(range(len(jobs))))
+        outs = {}
+        for skip in (1, 0):
+            ctx.set_option("skip_zero", skip)
+            o = r.run(prep, seed=5, keep_stems=True)
+            ctx.check()
+            outs[skip] = {k: o[k].cpu().numpy().copy() for k in ("harm", "uv", "bre", "mix")}
+        ctx.set_option("skip_zero", 1)
+        for k in ("harm", "uv", "bre", "mix"):
+            assert np.array_equal(outs[1][k], outs[0][k]), k
+        uv, bre = outs[1]["uv"], outs[1]["bre"]
+        assert np.isfinite(outs[1]["mix"]).all() and np.abs(uv).max() > 0 and np.abs(bre).max() > 0
+        assert (uv == 0).mean() > 0.2 and (bre == 0).mean() > 0.02        # both kinds of silence occur
+    finally:
+        ctx.close()
