@@ -745,6 +745,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "walk_lds_kb")) { ctx->walk_lds_kb = value < 32 ? 32 : (value > 160 ? 160 : value); return GOOFER_OK; }
     if (!strcmp(name, "finish_lds_kb")) { ctx->finish_lds_kb = value < 0 ? 0 : (value > 160 ? 160 : value); return GOOFER_OK; }
     if (!strcmp(name, "maps_side")) { ctx->maps_side = value != 0; return GOOFER_OK; }
+    if (!strcmp(name, "f0_side")) { ctx->f0_side = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "walk_npw")) { ctx->walk_npw = (value == 1 || value == 2 || value == 4) ? value : 0; return GOOFER_OK; }
     if (!strcmp(name, "sa_spt")) { ctx->sa_spt = value >= 16 ? 16 : (value >= 8 ? 8 : 4); return GOOFER_OK; }
     return goofer_fail(ctx, GOOFER_EINVAL, "unknown option %s", name);
@@ -1354,6 +1355,11 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // and the mask smoothing (0.07 ms of the critical path).
     const bool maps_side = early && f0_alias && stem_path && ctx->maps_side;
     hipStream_t mst = maps_side ? ctx->side : st;
+    // goofer_render_batch ran the f0 / mask kernel on the side stream: the caller's stream reads them from here on
+    if (ctx->f0_on_side) {
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_f0, 0));
+        ctx->f0_on_side = false;
+    }
     // one launch for all the maps when they stay on the caller's stream
     const bool maps_fused = stem_path && !maps_side;
     if (!maps_side && !maps_fused) HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), st));
@@ -1660,6 +1666,10 @@ int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *asmb, const goof
     ctx->warp_out = nullptr;
     if (!rc) rc = goofer_synth_batch(ctx, b, stream);
     ctx->warp_done = false;
+    if (ctx->f0_on_side) {                                    // (the synthesis returned before it placed the wait)
+        (void)hipStreamWaitEvent(st, ctx->ev_f0, 0);
+        ctx->f0_on_side = false;
+    }
     ctx->early_req = false;
     ctx->early_f0 = nullptr;
     return rc;

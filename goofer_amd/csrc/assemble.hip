@@ -562,16 +562,25 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
     // f0 and voicing mask first: the pulse chain of the synthesis (a long sequential walk) depends on nothing else, and
     // goofer_render_batch starts it on the side stream while the envelope kernels below are still running
     ctx->early_f0 = nullptr;
+    ctx->f0_on_side = false;
     if (a->total_samples > 0) {
+        // goofer_render_batch: the kernel goes to the side stream itself — the only consumers of f0 / mask before the frame maps
+        // are the pulse walk and placement queued behind it there, and the envelope kernels below then run BESIDE it on the
+        // caller's stream instead of behind it (it is 0.3 ms at the head of a 2.6 ms step).  The caller's stream waits for
+        // ev_f0 where it first reads f0 / mask (goofer_synth_batch).  Not with the fry edit, which reads them here.
+        const bool on_side = ctx->early_req && ctx->ev_f0 && ctx->side && ctx->f0_side && !a->any_fry;
+        hipStream_t fst = on_side ? ctx->side : st;
+        if (on_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_entry, 0));
         const int spt = ctx->sa_spt;
         const dim3 sgrid((unsigned)((a->total_samples + 256 * spt - 1) / (256 * spt)));
-        if (spt == 16) hipLaunchKernelGGL(k_sample_assemble<16>, sgrid, dim3(256), 0, st, *a, a->total_samples);
-        else if (spt == 8) hipLaunchKernelGGL(k_sample_assemble<8>, sgrid, dim3(256), 0, st, *a, a->total_samples);
-        else hipLaunchKernelGGL(k_sample_assemble<4>, sgrid, dim3(256), 0, st, *a, a->total_samples);
+        if (spt == 16) hipLaunchKernelGGL(k_sample_assemble<16>, sgrid, dim3(256), 0, fst, *a, a->total_samples);
+        else if (spt == 8) hipLaunchKernelGGL(k_sample_assemble<8>, sgrid, dim3(256), 0, fst, *a, a->total_samples);
+        else hipLaunchKernelGGL(k_sample_assemble<4>, sgrid, dim3(256), 0, fst, *a, a->total_samples);
         LAUNCH_CHECK(ctx);
         if (ctx->early_req && ctx->ev_f0) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_f0, st));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_f0, fst));
             ctx->early_f0 = a->f0_out;
+            ctx->f0_on_side = on_side;
         }
     }
     {

@@ -63,6 +63,8 @@ struct goofer_ctx {
     const float2 *frame_picks = nullptr;   // per-frame (f0, mask) picks of the running goofer_synth_batch, or null
     bool early_req = false;           // set for the duration of one goofer_render_batch
     const float *early_f0 = nullptr;  // f0 array ev_f0 stands for (null: no event recorded)
+    bool f0_side = true;              // goofer_render_batch: the f0 / mask kernel runs on the side stream, in front of the pulse chain it feeds (option "f0_side")
+    bool f0_on_side = false;          // ... and did so in the assembly of the current call: the caller's stream waits for ev_f0 before it reads f0 / mask
     hipEvent_t *prof_side = nullptr;    // [prof_cap][4]: boundaries of the pulse chain on the side stream
     hipEvent_t *prof_main2 = nullptr;   // [prof_cap][2]: ends of noise_spectra / mask_short when they run beside it
     bool prof_side_used = false;
