@@ -37,12 +37,12 @@ meta = {"csrc_sha256": source_hash(), "workload": bench["config"]["workload"], "
 # plan kernels pro rata, and the kernels that only the extra stages launch are left out.
 steps = max(1, res.get("k_note_finish", res.get("k_sample_assemble", {})).get("launches_sampled", 1))
 stems = any(k.startswith("void k_harm_stem") for k in res)
-fused_warp = any(k.startswith("void k_env_loop<true>") for k in res)
+fused_warp = any(k.startswith("void k_env_loop<true") for k in res)
 tot, per_kernel = 0.0, {}
 for k, v in res.items():
     if not k.startswith(("k_", "void k_")) or "FETCH_SIZE_KB" not in v or "WRITE_SIZE_KB" not in v:
         continue
-    if (stems and k.startswith("void k_rfft_frames")) or (fused_warp and k.startswith("void k_env_loop<false>")):
+    if (stems and k.startswith("void k_rfft_frames")) or (fused_warp and k.startswith("void k_env_loop<false")):
         continue
     per_step = min(1.0, v["launches_sampled"] / steps)
     per_kernel[k] = (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 * per_step
