@@ -9,6 +9,7 @@ construct-to-render, one-note call surface (SillySampler.py:285-413) on top of i
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -126,7 +127,7 @@ class SourceArena:
         self._reset()
 
     def _reset(self):
-        self.where = {}                                        # id(Source) -> (Source, knot_off, sample_off)
+        self.where = {}                                        # id(Source) -> (weak reference, knot_off, sample_off)
         self.knots = torch.empty(0, dtype=torch.int16, device=self.ctx.device)
         self.mask = torch.empty(0, dtype=torch.float32, device=self.ctx.device)
         self.k_used = self.m_used = 0
@@ -157,7 +158,11 @@ class SourceArena:
                 self.knots[self.k_used:self.k_used + nk].copy_(torch.from_numpy(kc))
                 self.mask[self.m_used:self.m_used + nm].copy_(torch.from_numpy(mc))
                 for sc in fresh:
-                    self.where[id(sc)] = (sc, self.k_used, self.m_used)
+                    # weakly: a Source its owner has dropped (the server's LRU of 512) must not stay alive in host memory here;
+                    # its entry goes with it (its device bytes stay until the arena starts over), so a recycled id cannot alias it
+                    where = self.where
+                    ref = weakref.ref(sc, lambda _r, key=id(sc), where=where: where.pop(key, None))
+                    self.where[id(sc)] = (ref, self.k_used, self.m_used)
                     self.k_used += sc.knots.size
                     self.m_used += sc.ylen
             at = [self.where[id(sc)] for sc in sources]

@@ -520,3 +520,50 @@ def test_notes_sharing_a_source_render_like_single_notes(renderer):
     for k, job in enumerate(jobs):
         (one,) = renderer.render([job], phi_seeds=[seeds[k]])
         assert np.array_equal(one, batch[k]), k
+
+
+def test_source_arena_keeps_samples_resident(renderer):
+    """Renderer.sources (render.SourceArena): a Source is uploaded the first time a batch names it and found resident afterwards;
+    the audio does not depend on where in the arena it sits; a Source nobody holds any more leaves the arena's table (its id may
+    be recycled); past the budget the arena starts over in fresh arrays and batches prepared before keep theirs."""
+    import gc
+    from goofer_amd.render import Renderer, Source, SourceArena
+    from goofer_amd import sampler as S
+    r = Renderer(renderer.ctx)
+    def make(k):
+        src = syn.make_source(93000 + k, seconds=0.4)
+        return Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+    srcs = [make(k) for k in range(4)]
+    req = S.decode_request("C4", "100", "L1g-5", "20", "600", "60", "30", "100", "0", "!120", "AA#8#AK")
+    jobs = [(s, req) for s in srcs]
+    a = r.render(jobs, seed=11)
+    used = (r.sources.k_used, r.sources.m_used)
+    assert used[0] == sum(s.knots.size for s in srcs) and used[1] == sum(s.ylen for s in srcs) and len(r.sources.where) == 4
+    b = r.render(list(reversed(jobs)), seed=11)              # resident: nothing uploaded, other batch order
+    assert (r.sources.k_used, r.sources.m_used) == used
+    # (the Philox stream of a note is keyed by its position here, so compare position by position through a second render)
+    c = r.render(jobs, seed=11)
+    assert all(np.array_equal(x, y) for x, y in zip(a, c)) and len(b) == 4
+    # a fresh arena places the same sources elsewhere (two fillers in front): same audio
+    r2 = Renderer(renderer.ctx)
+    fill = [make(10), make(11)]
+    r2.render([(f, req) for f in fill], seed=1)
+    d = r2.render(jobs, seed=11)
+    assert all(np.array_equal(x, y) for x, y in zip(a, d))
+    del fill
+    gc.collect()
+    assert len(r2.sources.where) == 4                        # the fillers' entries went with them
+    # budget: the third source does not fit beside the first two -> fresh arrays, earlier batches keep the old ones
+    small = Renderer(renderer.ctx)
+    per = 2 * srcs[0].knots.size + 4 * srcs[0].ylen
+    small.sources = SourceArena(renderer.ctx, budget_bytes=int(2.5 * per))
+    prep01 = small.prepare(jobs[:2], note_ids=[0, 1])
+    old_knots = small.sources.knots
+    e = small.render(jobs[2:], seed=11)                      # resets the arena
+    assert small.sources.knots is not old_knots and len(small.sources.where) == 2
+    out01 = small.run(prep01, seed=11)["mix"].cpu().numpy()  # prepared against the old arrays: still valid
+    small.ctx.check()
+    so = prep01["sample_off"]
+    assert np.array_equal(out01[so[0]:so[1]], a[0]) and np.array_equal(out01[so[1]:so[2]], a[1])
+    f = r.render(jobs[2:], seed=11)
+    assert all(np.array_equal(x, y) for x, y in zip(e, f))
