@@ -279,17 +279,24 @@ def host_inclusive(wl, ctx, step_s):
     best["first_batch"] = {"total_ms": first["total_ms"], "plan_upload_ms": first["plan_upload_ms"], "frames_per_s": first["frames_per_s"],
                            "note": "the same batch when none of its 1024 voicebank samples is resident in HBM yet (knot tables + voicing masks uploaded)"}
     # double-buffered: prepare(k + 1) beside run(k)
-    rounds, box = 8, {}
+    rounds, lead, box = 8, 4, {}                               # `lead` untimed rounds first: the two threads take a few batches to fall into step
 
     def worker():
         box["prep"] = prepare()[0]
 
     prep = prepare()[0]
     torch.cuda.synchronize()
+    # The preparing thread is interpreter-bound; the rendering thread needs the interpreter lock back after each of its (lock-free)
+    # device waits, and by default may wait 5 ms for it each time.  A short switch interval keeps those hand-overs short.
+    import sys as _sys
+    old_interval = _sys.getswitchinterval()
+    _sys.setswitchinterval(1e-4)
     t0 = time.perf_counter()
-    for k in range(rounds):
+    for k in range(lead + rounds):
+        if k == lead:
+            t0 = time.perf_counter()
         th = None
-        if k + 1 < rounds:
+        if k + 1 < lead + rounds:
             th = threading.Thread(target=worker)
             th.start()
         run(prep)
@@ -297,8 +304,10 @@ def host_inclusive(wl, ctx, step_s):
             th.join()
             prep = box.pop("prep")
     dt = (time.perf_counter() - t0) / rounds
+    _sys.setswitchinterval(old_interval)
     best["pipelined"] = {"ms_per_batch": 1e3 * dt, "frames_per_s": frames / dt, "batches": rounds,
-                         "note": "prepare(k + 1) on a second host thread while batch k runs and downloads"}
+                         "note": "prepare(k + 1) on a second host thread while batch k runs and downloads (sys.setswitchinterval(1e-4): the "
+                                 "rendering thread re-takes the interpreter lock after every device wait)"}
     best["note"] = ("serial, one host thread: 13 argument strings -> Requests (decode_requests), plans in the library's host planner + "
                     "tables + H2D of the plans (Renderer.prepare; the voicebank samples are resident in HBM, see first_batch), device step, "
                     "D2H of the mix into pinned memory; the best of three passes; the device step alone is ms_per_step")

@@ -483,9 +483,13 @@ int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop,
                            int gauss_radius, int n_threads, goofer_host_plans **out)
 {
     if (!req || !out || n_notes < 0 || hop <= 0 || !gauss_taps || gauss_radius < 0) return GOOFER_EINVAL;
-    for (int i = 0; i < n_notes; ++i)
-        if (req[i].sr <= 0 || req[i].ylen < 0 || (req[i].track_len[0] > 0 && !req[i].tracks[0]) || req[i].n_src_frames < 0 || req[i].ylen > INT32_MAX || req[i].loop_mode < 0 || req[i].loop_mode > 2)
+    for (int i = 0; i < n_notes; ++i) {
+        const goofer_plan_request &q = req[i];
+        if (q.sr <= 0 || q.ylen < 0 || q.n_src_frames < 0 || q.ylen > INT32_MAX || q.loop_mode < 0 || q.loop_mode > 2 || !(q.vel_factor > 0.0))
             return GOOFER_EINVAL;
+        for (int c = 0; c < 4; ++c)
+            if (q.track_len[c] > 0 && !q.tracks[c]) return GOOFER_EINVAL;
+    }
     std::vector<note_out> notes((size_t)n_notes);
     int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
     nt = std::max(1, std::min(nt, (n_notes + 63) / 64));

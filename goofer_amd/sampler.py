@@ -782,7 +782,14 @@ def source_tracks64(formants: dict):
         if a.ndim != 1 or a.dtype != np.float64:
             return None
         out.append(np.ascontiguousarray(a))
-    return tuple(out)
+    t = _Tracks(out)
+    t.ptrs = [a.ctypes.data if a.size else 0 for a in out]     # made once per source (ctypes objects are slow to make)
+    t.lens = [a.size for a in out]
+    return t
+
+
+class _Tracks(tuple):
+    """Four fp64 track arrays + their addresses / lengths as the planner records want them."""
 
 
 def plan_native(records, hop: int, trim_rows: bool, keep=None, threads: int = 0):
@@ -833,13 +840,8 @@ def plan_records(reqs, srs, ylens, n_src_frames, tracks):
     rec["vel_factor"] = [float(2.0 ** (1.0 - (r.velocity / 100.0))) for r in reqs]     # Python's pow, like the reference (:765)
     rec["loop_mode"] = [_LOOP_CODE[r.loop_mode] for r in reqs]
     rec["sr"], rec["ylen"], rec["n_src_frames"] = srs, ylens, n_src_frames
-    ptr_of, len_of = {}, {}
-    for t in tracks:                                           # few distinct sources, many notes
-        if id(t) not in ptr_of:
-            ptr_of[id(t)] = [a.ctypes.data if a.size else 0 for a in t]
-            len_of[id(t)] = [a.size for a in t]
-    rec["tracks"] = [ptr_of[id(t)] for t in tracks]
-    rec["track_len"] = [len_of[id(t)] for t in tracks]
+    rec["tracks"] = [t.ptrs for t in tracks]
+    rec["track_len"] = [t.lens for t in tracks]
     return rec
 
 
@@ -850,7 +852,7 @@ def plan_notes_arrays(jobs, hop: int = HOP, trim_rows: bool = False, threads: in
     tracks = [source_tracks64(j[4]) for j in jobs]
     if jobs and all(t is not None for t in tracks):
         uniq = {}
-        tracks = [uniq.setdefault(tuple(a.ctypes.data for a in t) + tuple(a.size for a in t), t) for t in tracks]
+        tracks = [uniq.setdefault(tuple(t.ptrs) + tuple(t.lens), t) for t in tracks]
         rec = plan_records([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], [j[3] for j in jobs], tracks)
         pb = plan_native(rec, hop, trim_rows, keep=(tracks, rec), threads=threads)
         if pb is not None:
