@@ -11,16 +11,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgoofer_hip.so")
 SOURCES = ["api.hip", "fft.hip", "pulse.hip", "binops.hip", "samples.hip", "assemble.hip", "stems.hip", "analysis.hip", "jitter.hip", "post.hip", "resample.hip", "planner.hip"]
+HOST_ONLY = ("planner.hip",)      # host code in the library: no kernel, cannot change what a counter pass measures
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-align-mismatch"]
 
 
 def source_hash() -> str:
-    """sha256 over the kernel sources the library is built from (goofer_amd/csrc/*.hip, *.h and include/goofer_hip.h, names
+    """sha256 over the kernel sources the library is built from (goofer_amd/csrc/*.hip, *.h without the host-only files, and include/goofer_hip.h, names
     and contents in sorted order).  The counter files under profiles/ carry the hash of the tree they were measured on;
     bench.py prints their numbers only beside the same hash."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and f not in HOST_ONLY)
     for f in files + [os.path.join("..", "..", "include", "goofer_hip.h")]:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(os.path.join(CSRC, f), "rb") as fh:
