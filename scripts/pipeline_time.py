@@ -10,7 +10,8 @@ from goofer_amd.workload import SamplerWorkload
 notes = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ctxs = [Context(0), Context(0)]
-wls = [SamplerWorkload(c, 3, list(range(notes))) for c in ctxs]
+split = "--split" in sys.argv       # the two handles hold the two HALVES of one batch of `notes` notes (ids 0..n/2, n/2..n)
+wls = [SamplerWorkload(c, 3, list(range(notes // 2 * i, notes // 2 * (i + 1))) if split else list(range(notes))) for i, c in enumerate(ctxs)]
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 
 
@@ -33,4 +34,5 @@ def run(n, depth):
 
 for depth in (1, 2, 1, 2):
     run(4, depth)
-    print(f"depth {depth}: {run(steps, depth):.3f} ms per step")
+    ms = run(steps, depth)
+    print(f"depth {depth}: {ms:.3f} ms per launch" + (f" = {2 * ms:.3f} ms per {notes}-note batch" if split else ""))
