@@ -402,7 +402,8 @@ template <typename T> static int upload(goofer_ctx *ctx, T **dst, const std::vec
 
 static void free_plan(goofer_plan_t &p)
 {
-    void *ptrs[] = {p.window, p.window_blur, p.blur_edge, p.win_sq, p.freqs, p.boost, p.bright_h, p.bright_b, p.tw_full, p.tw_half, p.pulse_peak, p.pulse_shape, p.blur5, p.blur175};
+    void *ptrs[] = {p.window, p.window_blur, p.blur_edge, p.win_sq, p.freqs, p.boost, p.bright_h, p.bright_b, p.tw_full, p.tw_half, p.pulse_peak, p.pulse_shape, p.blur5, p.blur175,
+                    p.bl_chirp, p.bl_bhat, p.bl_tw, p.bl_twh};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     p = goofer_plan_t();
@@ -464,8 +465,9 @@ const char *goofer_last_error(const goofer_ctx *ctx) { return ctx ? ctx->err : "
 int goofer_plan(goofer_ctx *ctx, int sr, int n_fft, int hop)
 {
     if (!ctx) return GOOFER_EINVAL;
-    if (n_fft != 512 && n_fft != 768 && n_fft != 1024 && n_fft != 1536 && n_fft != 2048)
-        return goofer_fail(ctx, GOOFER_EINVAL, "n_fft must be 512, 768, 1024, 1536 or 2048 (got %d)", n_fft);
+    const bool native = n_fft == 512 || n_fft == 768 || n_fft == 1024 || n_fft == 1536 || n_fft == 2048;
+    if (!native && (n_fft < 64 || n_fft > 1024 || (n_fft & 1)))
+        return goofer_fail(ctx, GOOFER_EINVAL, "n_fft must be 1536, 2048 or an even number in [64, 1024] (got %d)", n_fft);
     if (hop <= 0 || hop > n_fft || sr <= 0) return goofer_fail(ctx, GOOFER_EINVAL, "bad sr/hop (%d, %d)", sr, hop);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());
@@ -549,6 +551,39 @@ int goofer_plan(goofer_ctx *ctx, int sr, int n_fft, int hop)
         }
     }
     int rc;
+    if (!native) {
+        // Bluestein: X[k] = conj(c_k) sum_n (x_n conj(c_n)) c_{k-n}, c_n = exp(i pi n^2 / M): a circular convolution of length
+        // L >= 2 M - 1 with the wrapped chirp, whose transform is made here in fp64 (n^2 mod 2 M keeps the phases exact)
+        int L = 256;
+        while (L < 2 * M - 1) L *= 2;
+        std::vector<float2> chirp(M), bhat(L), twl(L), twhf(M + 1);
+        std::vector<double> br(L, 0.0), bi(L, 0.0);
+        for (int k = 0; k < M; ++k) {
+            const long long q = ((long long)k * k) % (2LL * M);
+            const double ang = PI * (double)q / (double)M;
+            chirp[k] = make_float2((float)cos(ang), (float)sin(ang));
+            br[k] = cos(ang); bi[k] = sin(ang);
+            if (k) { br[L - k] = cos(ang); bi[L - k] = sin(ang); }
+        }
+        std::vector<double> cr(L), ci(L);
+        for (int k = 0; k < L; ++k) { cr[k] = cos(-2.0 * PI * k / L); ci[k] = sin(-2.0 * PI * k / L); twl[k] = make_float2((float)cr[k], (float)ci[k]); }
+        for (int k = 0; k < L; ++k) {
+            double sr_ = 0.0, si_ = 0.0;
+            for (int j = 0; j < L; ++j) {
+                if (br[j] == 0.0 && bi[j] == 0.0) continue;
+                const int t = (int)(((long long)k * j) & (L - 1));
+                sr_ += br[j] * cr[t] - bi[j] * ci[t];
+                si_ += br[j] * ci[t] + bi[j] * cr[t];
+            }
+            bhat[k] = make_float2((float)sr_, (float)si_);
+        }
+        for (int k = 0; k <= M; ++k) twhf[k] = make_float2((float)cos(-PI * k / M), (float)sin(-PI * k / M));
+        if ((rc = upload(ctx, &p.bl_chirp, chirp))) return rc;
+        if ((rc = upload(ctx, &p.bl_bhat, bhat))) return rc;
+        if ((rc = upload(ctx, &p.bl_tw, twl))) return rc;
+        if ((rc = upload(ctx, &p.bl_twh, twhf))) return rc;
+        p.bl_L = L;
+    }
     if ((rc = upload(ctx, &p.blur_edge, edge))) return rc;
     if ((rc = upload(ctx, &p.window_blur, winb))) return rc;
     if ((rc = upload(ctx, &p.window, win))) return rc;
@@ -1331,7 +1366,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
 
     // the fused overlap-add rings index by position mod n_fft with a mask: power-of-two transforms only (768 / 1536 take the
     // separate irFFT + gather kernels)
-    const bool ola_one = ctx->ola_fused && (p.hop % 2 == 0) && (p.n_fft & (p.n_fft - 1)) == 0;
+    const bool ola_one = ctx->ola_fused && (p.hop % 2 == 0) && (p.n_fft & (p.n_fft - 1)) == 0 && p.bl_L == 0;   // (64 .. 256: Bluestein plans)
     unsigned fb = (unsigned)((F + 255) / 256);
     // goofer_render_batch: the assembly recorded ev_f0 right after the f0 / mask kernel.  The pulse chain (f0 scaling,
     // sequential walk, placement) then runs on the side stream from that point on, beside the envelope assembly and the

@@ -268,14 +268,14 @@ int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames,
     hipLaunchKernelGGL(k_harm_shape<IT>, grid, dim3(256), lds, st, S, ldc, total_frames, frame_note, frame_off, sample_off, f0,   \
                        mask, env, ld, params, note_mag, pl.freqs, pl.boost, pl.bright_h, pl.blur5, pl.n_bins, pl.hop, row_src,    \
                        formants, make_warp_grid(pl.sr, pl.n_bins), ctx->frame_picks)
-    switch ((pl.n_bins + WAVE - 1) / WAVE) {
-    case 5: HARM_SHAPE(5); break;
-    case 7: HARM_SHAPE(7); break;
-    case 13: HARM_SHAPE(13); break;
-    case 9: HARM_SHAPE(9); break;
-    case 17: HARM_SHAPE(17); break;
-    default: return goofer_fail(ctx, GOOFER_EINVAL, "unsupported bin count %d", pl.n_bins);
-    }
+    // bins per lane: the instantiation with the smallest count that covers the row (the kernels test k < n_bins per bin)
+    const int chunks = (pl.n_bins + WAVE - 1) / WAVE;
+    if (chunks <= 5) HARM_SHAPE(5);
+    else if (chunks <= 7) HARM_SHAPE(7);
+    else if (chunks <= 9) HARM_SHAPE(9);
+    else if (chunks <= 13) HARM_SHAPE(13);
+    else if (chunks <= 17) HARM_SHAPE(17);
+    else return goofer_fail(ctx, GOOFER_EINVAL, "unsupported bin count %d", pl.n_bins);
 #undef HARM_SHAPE
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
@@ -421,14 +421,14 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
     hipLaunchKernelGGL(k_noise_spectra<IT>, grid, dim3(256), lds, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,        \
                        sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins, pl.hop, \
                        row_src, preblurred ? (const double *)nullptr : pl.blur175, ctx->frame_picks, frame_skip)
-    switch ((pl.n_bins + WAVE - 1) / WAVE) {
-    case 5: NOISE_SPECTRA(5); break;
-    case 7: NOISE_SPECTRA(7); break;
-    case 13: NOISE_SPECTRA(13); break;
-    case 9: NOISE_SPECTRA(9); break;
-    case 17: NOISE_SPECTRA(17); break;
-    default: return goofer_fail(ctx, GOOFER_EINVAL, "unsupported bin count %d", pl.n_bins);
-    }
+    // bins per lane: the instantiation with the smallest count that covers the row (the kernels test k < n_bins per bin)
+    const int chunks = (pl.n_bins + WAVE - 1) / WAVE;
+    if (chunks <= 5) NOISE_SPECTRA(5);
+    else if (chunks <= 7) NOISE_SPECTRA(7);
+    else if (chunks <= 9) NOISE_SPECTRA(9);
+    else if (chunks <= 13) NOISE_SPECTRA(13);
+    else if (chunks <= 17) NOISE_SPECTRA(17);
+    else return goofer_fail(ctx, GOOFER_EINVAL, "unsupported bin count %d", pl.n_bins);
 #undef NOISE_SPECTRA
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;

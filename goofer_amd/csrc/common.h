@@ -24,6 +24,13 @@ struct goofer_plan_t {
     float *bright_b = nullptr;    // [n_bins] breath brightness                   GOOFER.py:43
     float2 *tw_full = nullptr;    // [n_fft/2]   exp(-2 pi i k / (n_fft/2))
     float2 *tw_half = nullptr;    // [n_fft/4+1] exp(-2 pi i k / n_fft)
+    // transform sizes without a native radix plan (any even n_fft up to 1024 besides 512 / 768 / 1024): Bluestein's chirp-z
+    // transform of the n_fft/2-point complex DFT through power-of-two transforms of length bl_L >= n_fft - 1 (fft.hip)
+    int bl_L = 0;                 // 0: native
+    float2 *bl_chirp = nullptr;   // [M]     exp(+i pi n^2 / M)
+    float2 *bl_bhat = nullptr;    // [bl_L]  FFT of the wrapped chirp
+    float2 *bl_tw = nullptr;      // [bl_L]  exp(-2 pi i k / bl_L)
+    float2 *bl_twh = nullptr;     // [M + 1] exp(-i pi k / M)
     float *pulse_peak = nullptr;  // [8193] 1/peak-normaliser of the LF shape per T0 (fp64 math)
     float *pulse_shape = nullptr; // normalised LF pulses for T0 = 3..PULSE_TAB_MAX back to back (row T0 at T0(T0-1)/2 - 3)
     double *blur5 = nullptr;      // [5] sigma=0.5 taps (brightness blur)         GOOFER.py:1143

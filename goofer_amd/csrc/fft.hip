@@ -226,6 +226,186 @@ __global__ __launch_bounds__(256) void k_ola_gather(const float *__restrict__ fr
 }
 
 // ---------------------------------------------------------------------------------------------
+// Transform sizes without a radix plan (any even n_fft up to 1024): Bluestein's chirp-z form of the M = n_fft / 2 point
+// complex DFT, Z_k = conj(c_k) sum_n (z_n conj(c_n)) c_{k-n} with c_n = exp(i pi n^2 / M) — a circular convolution of length
+// L >= 2 M - 1 (a power of two: wave_fft<L>) with the wrapped chirp, whose transform goofer_plan made in fp64.  Two L-point
+// transforms and three complex products per point; fp32 error ~4e-7 relative.  The real-input split / conj-trick stages around
+// it are the ones of the native kernels.
+//
+// v[r] = z[lane + 64 r] (anything for indices >= M) on entry; Z[k], k < M, in natural order in buf[k] (un-padded) on exit.
+template <int L>
+__device__ __forceinline__ void bluestein_dft(float2 (&v)[L / 64], int M, float2 *buf, const float2 *twl, const float2 *chirp,
+                                              const float2 *bhat, int lane)
+{
+    constexpr int R = L / 64;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int n = lane + WAVE * r;
+        v[r] = n < M ? cmul(v[r], cconj(chirp[n])) : make_float2(0.f, 0.f);
+    }
+    wave_fft<L>(v, buf, twl, lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int n = lane + WAVE * r;
+        v[r] = cconj(cmul(buf[lds_pad(n)], bhat[n]));          // inverse transform = conj(FFT(conj .)) / L
+    }
+    wave_lds_sync();
+    wave_fft<L>(v, buf, twl, lane);
+    const float inv_l = 1.0f / (float)L;
+    float2 z[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = lane + WAVE * r;
+        const float2 y = buf[lds_pad(k < M ? k : 0)];
+        z[r] = cmul(make_float2(y.x * inv_l, -(y.y * inv_l)), cconj(chirp[k < M ? k : 0]));
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = lane + WAVE * r;
+        if (k < M) buf[k] = z[r];
+    }
+    wave_lds_sync();
+}
+
+template <int L> struct bluestein_lds {
+    static constexpr size_t bytes = sizeof(float2) * (2 * L + L / 2 + (L / 2 + 2) + WAVES_PER_BLOCK * fft_cfg<L>::BUF) + sizeof(float) * L;
+    float2 *twl, *bhat, *chirp, *twh, *bufs;
+    float *win;
+    __device__ __forceinline__ void carve(unsigned char *smem, int M, const float2 *g_twl, const float2 *g_bhat, const float2 *g_chirp,
+                                          const float2 *g_twh, const float *g_win)
+    {
+        twl = reinterpret_cast<float2 *>(smem);
+        bhat = twl + L;
+        chirp = bhat + L;
+        twh = chirp + L / 2;
+        bufs = twh + (L / 2 + 2);
+        win = reinterpret_cast<float *>(bufs + WAVES_PER_BLOCK * fft_cfg<L>::BUF);
+        for (int i = threadIdx.x; i < L; i += blockDim.x) { twl[i] = g_twl[i]; bhat[i] = g_bhat[i]; }
+        for (int i = threadIdx.x; i < M; i += blockDim.x) chirp[i] = g_chirp[i];
+        for (int i = threadIdx.x; i <= M; i += blockDim.x) twh[i] = g_twh[i];
+        for (int i = threadIdx.x; i < 2 * M; i += blockDim.x) win[i] = g_win[i];
+        __syncthreads();
+    }
+};
+
+template <int L>
+__global__ __launch_bounds__(256) void k_rfft_bluestein(const float *__restrict__ x, const int64_t *__restrict__ sample_off,
+                                                        const int64_t *__restrict__ frame_off, const int *__restrict__ frame_note,
+                                                        int64_t total_frames, float2 *__restrict__ S, int ldc, int hop, int M,
+                                                        const float2 *__restrict__ g_twl, const float2 *__restrict__ g_bhat,
+                                                        const float2 *__restrict__ g_chirp, const float2 *__restrict__ g_twh,
+                                                        const float *__restrict__ g_win)
+{
+    constexpr int R = L / 64;
+    extern __shared__ __align__(16) unsigned char smem[];
+    bluestein_lds<L> t;
+    t.carve(smem, M, g_twl, g_bhat, g_chirp, g_twh, g_win);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float2 *buf = t.bufs + wave * fft_cfg<L>::BUF;
+    const int64_t f_begin = (int64_t)blockIdx.x * FRAMES_PER_BLOCK;
+    for (int i = wave; i < FRAMES_PER_BLOCK; i += WAVES_PER_BLOCK) {
+        const int64_t f = f_begin + i;
+        if (f >= total_frames) break;                         // wave-uniform; no block barrier below
+        const int note = frame_note[f];
+        const int64_t base = sample_off[note], n = sample_off[note + 1] - base;
+        const int64_t start = (f - frame_off[note]) * hop - M;   // first sample of the frame, un-padded coordinates
+        const float *xs = x + base;
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int m = lane + WAVE * r;
+            float a = 0.f, b = 0.f;
+            if (m < M && n > 0) {
+                a = xs[reflect_index(start + 2 * m, n)];
+                b = xs[reflect_index(start + 2 * m + 1, n)];
+            }
+            v[r] = m < M ? make_float2(a * t.win[2 * m], b * t.win[2 * m + 1]) : make_float2(0.f, 0.f);
+        }
+        bluestein_dft<L>(v, M, buf, t.twl, t.chirp, t.bhat, lane);
+        // even/odd split: X[k] = (Z[k] + conj Z[M-k])/2 - i/2 e^{-i pi k/M} (Z[k] - conj Z[M-k]); X[M] from Z[0]
+        float2 *row = S + f * (int64_t)ldc;
+        for (int k = lane; k <= M; k += WAVE) {
+            float2 X;
+            if (k == M) {
+                const float2 z0 = buf[0];
+                X = make_float2(z0.x - z0.y, 0.f);
+            } else {
+                const float2 zk = buf[k], zm = buf[k == 0 ? 0 : M - k], w = t.twh[k];
+                const float2 A = make_float2(zk.x + zm.x, zk.y - zm.y), B = make_float2(zk.x - zm.x, zk.y + zm.y);
+                const float2 C = cmul(w, B);
+                X = make_float2(0.5f * (A.x + C.y), 0.5f * (A.y - C.x));
+            }
+            row[k] = X;
+        }
+        wave_lds_sync();
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void k_irfft_bluestein(const float2 *__restrict__ S, int ldc, int64_t total_frames, float *__restrict__ frames,
+                                                         int M, const float2 *__restrict__ g_twl, const float2 *__restrict__ g_bhat,
+                                                         const float2 *__restrict__ g_chirp, const float2 *__restrict__ g_twh,
+                                                         const float *__restrict__ g_win)
+{
+    constexpr int R = L / 64;
+    extern __shared__ __align__(16) unsigned char smem[];
+    bluestein_lds<L> t;
+    t.carve(smem, M, g_twl, g_bhat, g_chirp, g_twh, g_win);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float2 *buf = t.bufs + wave * fft_cfg<L>::BUF;
+    const int64_t f_begin = (int64_t)blockIdx.x * FRAMES_PER_BLOCK;
+    const float inv_m = 0.5f / (float)M;                     // 1/M of the transform and the 1/2 of the input stage (irfft_pre)
+    for (int i = wave; i < FRAMES_PER_BLOCK; i += WAVES_PER_BLOCK) {
+        const int64_t f = f_begin + i;
+        if (f >= total_frames) break;
+        const float2 *row = S + f * (int64_t)ldc;
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int k = lane + WAVE * r;
+            v[r] = make_float2(0.f, 0.f);
+            if (k < M) {
+                float2 xk = row[k], xm = row[M - k];
+                if (k == 0) { xk.y = 0.f; xm.y = 0.f; }       // irfft ignores Im of DC and Nyquist
+                v[r] = irfft_pre(xk, xm, cconj(t.twh[k]));     // Z = (A + i C)/2 ; inverse FFT = conj(FFT(conj Z))
+            }
+        }
+        bluestein_dft<L>(v, M, buf, t.twl, t.chirp, t.bhat, lane);
+        float2 *out = reinterpret_cast<float2 *>(frames + f * (int64_t)(2 * M));
+        for (int m = lane; m < M; m += WAVE) {
+            const float2 z = buf[m];
+            const float a = z.x * inv_m, b = -z.y * inv_m;
+            out[m] = make_float2(a * t.win[2 * m], b * t.win[2 * m + 1]);
+        }
+        wave_lds_sync();
+    }
+}
+
+template <int L>
+static int rfft_bluestein_impl(goofer_ctx *ctx, const float *x, const int64_t *sample_off, const int64_t *frame_off, const int *frame_note,
+                               int64_t total_frames, float2 *S, int ldc, hipStream_t st)
+{
+    const goofer_plan_t &p = ctx->plan;
+    const unsigned blocks = (unsigned)((total_frames + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK);
+    hipLaunchKernelGGL(k_rfft_bluestein<L>, dim3(blocks), dim3(256), bluestein_lds<L>::bytes, st, x, sample_off, frame_off, frame_note,
+                       total_frames, S, ldc, p.hop, p.n_fft / 2, p.bl_tw, p.bl_bhat, p.bl_chirp, p.bl_twh, p.window);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+template <int L>
+static int irfft_bluestein_impl(goofer_ctx *ctx, const float2 *S, int ldc, int64_t total_frames, float *frames, hipStream_t st)
+{
+    const goofer_plan_t &p = ctx->plan;
+    const unsigned blocks = (unsigned)((total_frames + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK);
+    hipLaunchKernelGGL(k_irfft_bluestein<L>, dim3(blocks), dim3(256), bluestein_lds<L>::bytes, st, S, ldc, total_frames, frames,
+                       p.n_fft / 2, p.bl_tw, p.bl_bhat, p.bl_chirp, p.bl_twh, p.window);
+    LAUNCH_CHECK(ctx);
+    return GOOFER_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 __global__ void k_frame_note(const int64_t *__restrict__ frame_off, int n_notes, int64_t total_frames, int *__restrict__ frame_note)
 {
     int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,6 +437,13 @@ int launch_rfft_frames_mapped(goofer_ctx *ctx, const float *x, const int64_t *sa
                               const int *frame_note, int64_t total_frames, float2 *S, int ldc, hipStream_t st)
 {
     if (total_frames <= 0) return GOOFER_OK;
+    switch (ctx->plan.bl_L) {
+    case 0: break;
+    case 256: return rfft_bluestein_impl<256>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
+    case 512: return rfft_bluestein_impl<512>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
+    case 1024: return rfft_bluestein_impl<1024>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
+    default: return goofer_fail(ctx, GOOFER_EINVAL, "bad Bluestein length %d", ctx->plan.bl_L);
+    }
     switch (ctx->plan.n_fft) {
     case 512: return rfft_impl<256>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
     case 1024: return rfft_impl<512>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
@@ -281,6 +468,13 @@ static int irfft_impl(goofer_ctx *ctx, const float2 *S, int ldc, int64_t total_f
 int launch_irfft_frames(goofer_ctx *ctx, const float2 *S, int ldc, int64_t total_frames, float *frames, hipStream_t st)
 {
     if (total_frames <= 0) return GOOFER_OK;
+    switch (ctx->plan.bl_L) {
+    case 0: break;
+    case 256: return irfft_bluestein_impl<256>(ctx, S, ldc, total_frames, frames, st);
+    case 512: return irfft_bluestein_impl<512>(ctx, S, ldc, total_frames, frames, st);
+    case 1024: return irfft_bluestein_impl<1024>(ctx, S, ldc, total_frames, frames, st);
+    default: return goofer_fail(ctx, GOOFER_EINVAL, "bad Bluestein length %d", ctx->plan.bl_L);
+    }
     switch (ctx->plan.n_fft) {
     case 512: return irfft_impl<256>(ctx, S, ldc, total_frames, frames, st);
     case 1024: return irfft_impl<512>(ctx, S, ldc, total_frames, frames, st);

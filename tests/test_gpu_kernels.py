@@ -428,3 +428,52 @@ def test_transform_sizes_with_a_factor_three(ctx, n_fft, hop):
     for a, b, name in zip(got, ref, ("rec", "harm", "uv", "bre")):
         assert rms_err(a, b) < 2e-5, (n_fft, hop, name, rms_err(a, b))
     ctx.plan(44100, 1024, 256)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(1000, 250), (600, 150), (882, 147), (320, 80), (64, 16), (130, 40), (1022, 300)])
+def test_transform_sizes_without_a_radix_plan(ctx, n_fft, hop):
+    """Any even n_fft up to 1024 (GOOFER.py:355, 392, 972 take whatever the caller passes): Bluestein's chirp-z form of the
+    n_fft / 2-point transform through power-of-two transforms (k_rfft_bluestein / k_irfft_bluestein), incl. odd half sizes
+    (882 -> 441, 130 -> 65) and bin counts that are not 64 k + 1: spectra, inverse + overlap-add and the whole synthesis against
+    the oracle (numpy pocketfft at those sizes).  Three transforms' worth of fp32 rounding instead of one: 2e-6 on the spectra."""
+    from goofer_amd import core
+    from oracle import goofer_ref as R
+    sr = 44100
+    rng = np.random.default_rng(n_fft + hop)
+    lens = [5000, 3, n_fft - 1, 2 * n_fft + 17]
+    win = R.sqrt_hann(n_fft)
+    ctx.plan(sr, n_fft, hop)
+    xs = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    Ts = [1 + n // hop for n in lens]
+    S = ctx.rfft_frames(ctx.tensor(np.concatenate(xs)), _off(ctx, lens), _off(ctx, Ts), sum(Ts)).cpu().numpy()
+    o = 0
+    for x, T in zip(xs, Ts):
+        ref = R.stft(x, n_fft, hop, win).T
+        assert ref.shape == (T, n_fft // 2 + 1)
+        assert rel_rms(S[o:o + T], ref) < 2e-6, (n_fft, hop, len(x), rel_rms(S[o:o + T], ref))
+        o += T
+        if T < 2:
+            continue
+        y = core.istft(ref.T, hop_length=hop, sr=sr, ctx=ctx)
+        y_ref = R.istft(ref.T, hop, win)
+        assert y.shape == y_ref.shape and rms_err(y, y_ref) < 1.5e-6 * max(1.0, float(np.abs(y_ref).max())), (n_fft, hop, len(x))
+    n = 6000
+    B, T = n_fft // 2 + 1, 1 + n // hop
+    f = np.arange(B) * (sr / n_fft)
+    env = (np.exp(-f / 3000.0)[:, None] * (1.0 + 0.2 * np.sin(np.arange(T) / 5.0))[None, :]).astype(np.float32)
+    f0 = (200.0 + 20.0 * np.sin(np.arange(n) / 900.0)).astype(np.float32)
+    mask = np.ones(n, dtype=np.float32)
+    mask[:700] = 0.0
+    f0 = f0 * mask
+    phi = rng.uniform(0.0, 2.0 * np.pi, size=(B, T)).astype(np.float32)
+    forms = {k: np.full(T, 600.0 * k) for k in (1, 2, 3, 4)}
+    kw = dict(n_fft=n_fft, hop_length=hop, formants=forms, F1_shift=1.2, formant_shift=0.9)
+    ref = R.synthesize(env, f0.astype(np.float64), mask, np.empty(n, bool), sr, phi=phi, **kw)
+    got = core.synthesize(env, f0, mask, np.empty(n, bool), sr, phi=phi, ctx=ctx, **kw)
+    for a, b, name in zip(got, ref, ("rec", "harm", "uv", "bre")):
+        assert rms_err(a, b) < 2e-5, (n_fft, hop, name, rms_err(a, b))
+    with pytest.raises(Exception):
+        ctx.plan(sr, 1001, 250)                               # odd sizes and sizes between 1024 and 2048 other than 1536 stay refused
+    with pytest.raises(Exception):
+        ctx.plan(sr, 1200, 300)
+    ctx.plan(44100, 1024, 256)
