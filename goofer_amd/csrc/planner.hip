@@ -450,14 +450,21 @@ void plan_one(const goofer_plan_request &r, int hop, int trim_rows, const double
                 m = m < T_full ? m : period - m;
                 pad[q + gradius] = all_bad ? 300.0 : (double)wp[m];
             }
-            for (int64_t t = 0; t < T_env; ++t) {
-                double acc = gtaps[0] * pad[t];
-                for (int j = 1; j < 2 * gradius + 1; ++j) {
-                    const double prod = gtaps[j] * pad[t + j];
-                    acc = acc + prod;
+            // taps outside, frames inside: every frame still adds its products in ascending tap order (the sums are the same
+            // bits), and the inner loop is a plain vector loop over t instead of a reduction over j
+            std::vector<double> &acc = s.tmp;
+            acc.resize((size_t)T_env);
+            const double *pp = pad.data();
+            for (int64_t t = 0; t < T_env; ++t) acc[t] = gtaps[0] * pp[t];
+            for (int j = 1; j < 2 * gradius + 1; ++j) {
+                const double kj = gtaps[j];
+                const double *pj = pp + j;
+                for (int64_t t = 0; t < T_env; ++t) {
+                    const double prod = kj * pj[t];
+                    acc[t] = acc[t] + prod;
                 }
-                o.fst[(size_t)t * 4 + c] = (float)acc;
             }
+            for (int64_t t = 0; t < T_env; ++t) o.fst[(size_t)t * 4 + c] = (float)acc[t];
         }
         if (have) {
             const int64_t Lc = (int64_t)canon.size();
@@ -491,8 +498,8 @@ int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop,
             if (q.track_len[c] > 0 && !q.tracks[c]) return GOOFER_EINVAL;
     }
     std::vector<note_out> notes((size_t)n_notes);
-    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-    nt = std::max(1, std::min(nt, (n_notes + 63) / 64));
+    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    nt = std::max(1, std::min(nt, (n_notes + 31) / 32));
     auto work = [&](int t) {
         std::fesetround(FE_TONEAREST);
         scratch s;
