@@ -498,7 +498,7 @@ int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop,
             if (q.track_len[c] > 0 && !q.tracks[c]) return GOOFER_EINVAL;
     }
     std::vector<note_out> notes((size_t)n_notes);
-    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
     nt = std::max(1, std::min(nt, (n_notes + 31) / 32));
     auto work = [&](int t) {
         std::fesetround(FE_TONEAREST);

@@ -346,7 +346,7 @@ typedef struct goofer_host_plans goofer_host_plans;
 
 /* Plan n_notes notes.  gauss_taps[2 * gauss_radius + 1]: the sigma-4 taps of sanitize_smooth_formant (:281), made by the
  * caller the way numpy makes them.  trim_rows != 0: plan only the envelope rows gf.synthesize can reach (GOOFER.py:1115-1119).
- * n_threads <= 0: up to sixteen host threads.  The result is freed with goofer_host_plans_free. */
+ * n_threads <= 0: up to eight host threads.  The result is freed with goofer_host_plans_free. */
 int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps,
                            int gauss_radius, int n_threads, goofer_host_plans **out);
 /* The planned batch: geometry[n_notes]; rows = sum of n_out_rows over the notes with status 0; tap_idx / tap_w [rows x 4]
