@@ -466,8 +466,8 @@ int goofer_plan(goofer_ctx *ctx, int sr, int n_fft, int hop)
 {
     if (!ctx) return GOOFER_EINVAL;
     const bool native = n_fft == 512 || n_fft == 768 || n_fft == 1024 || n_fft == 1536 || n_fft == 2048;
-    if (!native && (n_fft < 64 || n_fft > 1024 || (n_fft & 1)))
-        return goofer_fail(ctx, GOOFER_EINVAL, "n_fft must be 1536, 2048 or an even number in [64, 1024] (got %d)", n_fft);
+    if (!native && (n_fft < 64 || n_fft > 2048 || (n_fft & 1)))
+        return goofer_fail(ctx, GOOFER_EINVAL, "n_fft must be an even number in [64, 2048] (got %d)", n_fft);
     if (hop <= 0 || hop > n_fft || sr <= 0) return goofer_fail(ctx, GOOFER_EINVAL, "bad sr/hop (%d, %d)", sr, hop);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());

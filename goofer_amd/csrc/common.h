@@ -24,7 +24,7 @@ struct goofer_plan_t {
     float *bright_b = nullptr;    // [n_bins] breath brightness                   GOOFER.py:43
     float2 *tw_full = nullptr;    // [n_fft/2]   exp(-2 pi i k / (n_fft/2))
     float2 *tw_half = nullptr;    // [n_fft/4+1] exp(-2 pi i k / n_fft)
-    // transform sizes without a native radix plan (any even n_fft up to 1024 besides 512 / 768 / 1024): Bluestein's chirp-z
+    // transform sizes without a native radix plan (any other even n_fft in [64, 2048]): Bluestein's chirp-z
     // transform of the n_fft/2-point complex DFT through power-of-two transforms of length bl_L >= n_fft - 1 (fft.hip)
     int bl_L = 0;                 // 0: native
     float2 *bl_chirp = nullptr;   // [M]     exp(+i pi n^2 / M)

@@ -226,9 +226,9 @@ __global__ __launch_bounds__(256) void k_ola_gather(const float *__restrict__ fr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Transform sizes without a radix plan (any even n_fft up to 1024): Bluestein's chirp-z form of the M = n_fft / 2 point
+// Transform sizes without a radix plan (any even n_fft up to 2048): Bluestein's chirp-z form of the M = n_fft / 2 point
 // complex DFT, Z_k = conj(c_k) sum_n (z_n conj(c_n)) c_{k-n} with c_n = exp(i pi n^2 / M) — a circular convolution of length
-// L >= 2 M - 1 (a power of two: wave_fft<L>) with the wrapped chirp, whose transform goofer_plan made in fp64.  Two L-point
+// L >= 2 M - 1 (a power of two up to 2048: wave_fft<L>) with the wrapped chirp, whose transform goofer_plan made in fp64.  Two L-point
 // transforms and three complex products per point; fp32 error ~4e-7 relative.  The real-input split / conj-trick stages around
 // it are the ones of the native kernels.
 //
@@ -388,6 +388,8 @@ static int rfft_bluestein_impl(goofer_ctx *ctx, const float *x, const int64_t *s
 {
     const goofer_plan_t &p = ctx->plan;
     const unsigned blocks = (unsigned)((total_frames + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK);
+    if (bluestein_lds<L>::bytes > 64 * 1024)
+        if (int rc = kernel_allow_max_lds(ctx, (const void *)k_rfft_bluestein<L>)) return rc;
     hipLaunchKernelGGL(k_rfft_bluestein<L>, dim3(blocks), dim3(256), bluestein_lds<L>::bytes, st, x, sample_off, frame_off, frame_note,
                        total_frames, S, ldc, p.hop, p.n_fft / 2, p.bl_tw, p.bl_bhat, p.bl_chirp, p.bl_twh, p.window);
     LAUNCH_CHECK(ctx);
@@ -399,6 +401,8 @@ static int irfft_bluestein_impl(goofer_ctx *ctx, const float2 *S, int ldc, int64
 {
     const goofer_plan_t &p = ctx->plan;
     const unsigned blocks = (unsigned)((total_frames + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK);
+    if (bluestein_lds<L>::bytes > 64 * 1024)
+        if (int rc = kernel_allow_max_lds(ctx, (const void *)k_irfft_bluestein<L>)) return rc;
     hipLaunchKernelGGL(k_irfft_bluestein<L>, dim3(blocks), dim3(256), bluestein_lds<L>::bytes, st, S, ldc, total_frames, frames,
                        p.n_fft / 2, p.bl_tw, p.bl_bhat, p.bl_chirp, p.bl_twh, p.window);
     LAUNCH_CHECK(ctx);
@@ -442,6 +446,7 @@ int launch_rfft_frames_mapped(goofer_ctx *ctx, const float *x, const int64_t *sa
     case 256: return rfft_bluestein_impl<256>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
     case 512: return rfft_bluestein_impl<512>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
     case 1024: return rfft_bluestein_impl<1024>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
+    case 2048: return rfft_bluestein_impl<2048>(ctx, x, sample_off, frame_off, frame_note, total_frames, S, ldc, st);
     default: return goofer_fail(ctx, GOOFER_EINVAL, "bad Bluestein length %d", ctx->plan.bl_L);
     }
     switch (ctx->plan.n_fft) {
@@ -473,6 +478,7 @@ int launch_irfft_frames(goofer_ctx *ctx, const float2 *S, int ldc, int64_t total
     case 256: return irfft_bluestein_impl<256>(ctx, S, ldc, total_frames, frames, st);
     case 512: return irfft_bluestein_impl<512>(ctx, S, ldc, total_frames, frames, st);
     case 1024: return irfft_bluestein_impl<1024>(ctx, S, ldc, total_frames, frames, st);
+    case 2048: return irfft_bluestein_impl<2048>(ctx, S, ldc, total_frames, frames, st);
     default: return goofer_fail(ctx, GOOFER_EINVAL, "bad Bluestein length %d", ctx->plan.bl_L);
     }
     switch (ctx->plan.n_fft) {

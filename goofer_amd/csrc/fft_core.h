@@ -166,6 +166,44 @@ template <> struct dft<16> {
     }
 };
 
+// 32 points per lane: the 2048-point transform of the Bluestein path for even n_fft between 1024 and 2048 (one more
+// decimation-in-frequency split in front of two 16-point transforms)
+template <> struct dft<32> {
+    __device__ __forceinline__ static void run(float2 *v)
+    {
+        const float2 w[16] = {{1.f, 0.f},
+                              {0.98078528040323043f, -0.19509032201612825f},
+                              {0.92387953251128674f, -0.38268343236508978f},
+                              {0.83146961230254524f, -0.55557023301960218f},
+                              {0.70710678118654757f, -0.70710678118654746f},
+                              {0.55557023301960229f, -0.83146961230254524f},
+                              {0.38268343236508984f, -0.92387953251128674f},
+                              {0.19509032201612833f, -0.98078528040323043f},
+                              {0.f, -1.f},
+                              {-0.19509032201612819f, -0.98078528040323043f},
+                              {-0.38268343236508973f, -0.92387953251128674f},
+                              {-0.55557023301960196f, -0.83146961230254546f},
+                              {-0.70710678118654746f, -0.70710678118654757f},
+                              {-0.83146961230254535f, -0.55557023301960218f},
+                              {-0.92387953251128674f, -0.38268343236508989f},
+                              {-0.98078528040323043f, -0.19509032201612861f}};   // W32^n, n = 0..15
+        float2 e[16], o[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            e[n] = cadd(v[n], v[n + 16]);
+            const float2 d = make_float2(v[n].x - v[n + 16].x, v[n].y - v[n + 16].y);
+            o[n] = n == 0 ? d : cmul(d, w[n]);
+        }
+        dft<16>::run(e);
+        dft<16>::run(o);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            v[2 * m] = e[m];
+            v[2 * m + 1] = o[m];
+        }
+    }
+};
+
 // Sizes with a factor 3 (n_fft 768 / 1536: M = 384 / 768 = 64 x 6 / 64 x 12): the first pass is a 6- or 12-point DFT, written
 // as the plain sum over a table of the twelfth roots of unity (R^2 complex products: these sizes are entry-point
 // conveniences — gf.synthesize / stft / istft take any n_fft, GOOFER.py:972 — not the hot geometry).

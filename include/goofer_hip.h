@@ -227,7 +227,7 @@ const char *goofer_version(void);
 
 /* Tables per (sr, n_fft, hop): sqrt-Hann window, bin freqs, boost, brightness curves, FFT twiddles
  * (GOOFER.py:12-46, 585-595).  n_fft: 512, 768, 1024, 1536, 2048 (radix plans; the stem walkers run at 1024 with hop 256, the
- * fused overlap-add at the three powers of two) or any other even size in [64, 1024] (Bluestein's chirp-z transform through
+ * fused overlap-add at the three powers of two) or any other even size in [64, 2048] (Bluestein's chirp-z transform through
  * power-of-two transforms, one kernel per reference step); re-planning replaces the tables. */
 int goofer_plan(goofer_ctx *ctx, int sr, int n_fft, int hop);
 

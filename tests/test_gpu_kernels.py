@@ -430,10 +430,10 @@ def test_transform_sizes_with_a_factor_three(ctx, n_fft, hop):
     ctx.plan(44100, 1024, 256)
 
 
-@pytest.mark.parametrize("n_fft,hop", [(1000, 250), (600, 150), (882, 147), (320, 80), (64, 16), (130, 40), (1022, 300)])
+@pytest.mark.parametrize("n_fft,hop", [(1000, 250), (600, 150), (882, 147), (320, 80), (64, 16), (130, 40), (1022, 300), (1200, 300), (2000, 500), (1026, 256)])
 def test_transform_sizes_without_a_radix_plan(ctx, n_fft, hop):
-    """Any even n_fft up to 1024 (GOOFER.py:355, 392, 972 take whatever the caller passes): Bluestein's chirp-z form of the
-    n_fft / 2-point transform through power-of-two transforms (k_rfft_bluestein / k_irfft_bluestein), incl. odd half sizes
+    """Any even n_fft up to 2048 (GOOFER.py:355, 392, 972 take whatever the caller passes): Bluestein's chirp-z form of the
+    n_fft / 2-point transform through power-of-two transforms of 256 .. 2048 points (k_rfft_bluestein / k_irfft_bluestein), incl. odd half sizes
     (882 -> 441, 130 -> 65) and bin counts that are not 64 k + 1: spectra, inverse + overlap-add and the whole synthesis against
     the oracle (numpy pocketfft at those sizes).  Three transforms' worth of fp32 rounding instead of one: 2e-6 on the spectra."""
     from goofer_amd import core
@@ -473,7 +473,7 @@ def test_transform_sizes_without_a_radix_plan(ctx, n_fft, hop):
     for a, b, name in zip(got, ref, ("rec", "harm", "uv", "bre")):
         assert rms_err(a, b) < 2e-5, (n_fft, hop, name, rms_err(a, b))
     with pytest.raises(Exception):
-        ctx.plan(sr, 1001, 250)                               # odd sizes and sizes between 1024 and 2048 other than 1536 stay refused
+        ctx.plan(sr, 1001, 250)                               # odd sizes stay refused
     with pytest.raises(Exception):
-        ctx.plan(sr, 1200, 300)
+        ctx.plan(sr, 2050, 512)
     ctx.plan(44100, 1024, 256)
