@@ -76,6 +76,54 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
             }
             wave_lds_sync();
         }
+        // A lane blurs NB CONSECUTIVE bins.  The NB + 2 rad values they need are a window that slides by one per tap: it lives
+        // in NB registers as a ring (slot = window index mod NB: with the tap loop unrolled NB times every slot index is a
+        // constant), so a tap costs one LDS read, one conversion and one scalar load for the whole lane instead of one of each
+        // per bin (the lane-strided layout re-read and re-converted every value for every tap: three instructions per
+        // product).  Every bin still adds its products in ascending tap order: the same sums, bit for bit.
+        auto blur_rows = [&](auto nb_tag) {
+            constexpr int NB = decltype(nb_tag)::value;
+            const int b0 = NB * lane;
+            const bool live = b0 < B;
+            const float *x0 = row + (live ? b0 : 0) - rad;      // window element e = x0[e], e < NB + 2 rad (inside the halo)
+            double acc[NB], xw[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                acc[i] = 0.0;
+                xw[i] = (double)x0[i];
+            }
+            // the taps (at most 2 * 28 + 1) one per lane, read back with v_readlane: a scalar load per tap would share its
+            // counter with the window's LDS reads and put a memory round trip into every step of the loop
+            const double tapv = lane <= 2 * rad ? taps[lane] : 0.0;
+            const int tap_lo = (int)(uint32_t)__double_as_longlong(tapv), tap_hi = (int)(__double_as_longlong(tapv) >> 32);
+            for (int jb = 0; jb <= 2 * rad; jb += NB) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int j = jb + u;
+                    if (j <= 2 * rad) {                         // (wave-uniform)
+                        const double tj = __longlong_as_double(((long long)__builtin_amdgcn_readlane(tap_hi, j) << 32) |
+                                                               (uint32_t)__builtin_amdgcn_readlane(tap_lo, j));
+#pragma unroll
+                        for (int i = 0; i < NB; ++i) acc[i] += tj * xw[(i + u) % NB];
+                        xw[u] = (double)x0[j + NB];              // element j is done with; its slot takes element j + NB
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int b = b0 + i;
+                if (live && b < B) {
+                    const double src = (double)row[b];
+                    tmp[b] = p.es_mode == 1 ? acc[i] : fmax(0.0, src + p.es_amount * (src - acc[i]));
+                }
+            }
+            wave_lds_sync();
+            // the two row sums in the order the strided layout took them (bin lane + 64 i per lane, then across the wave)
+            for (int b = lane; b < B; b += WAVE) {
+                s_src += (double)row[b];
+                s_mod += tmp[b];
+            }
+        };
         auto finish_bin = [&](int b, double acc) {
             double src = (double)row[b];
             double mod = p.es_mode == 1 ? acc : fmax(0.0, src + p.es_amount * (src - acc));
@@ -83,33 +131,11 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
             s_src += src;
             s_mod += mod;
         };
-        // Taps outside, the lane's bins inside: a tap is fetched once per row (it is a wave-uniform scalar load — inside the
-        // per-bin loop it came back for every bin and, sharing its counter with the LDS reads, serialised them) and the
-        // CHUNKS reads of a tap are independent.  Every bin still sums its products in ascending tap order.
-        auto blur_rows = [&](auto chunks_tag) {
-            constexpr int CHUNKS = decltype(chunks_tag)::value;
-            double acc[CHUNKS];
-#pragma unroll
-            for (int i = 0; i < CHUNKS; ++i) acc[i] = 0.0;
-            const float *x0 = row + lane - rad;
-            for (int j = 0; j <= 2 * rad; ++j) {
-                const double tj = taps[j];
-#pragma unroll
-                for (int i = 0; i < CHUNKS; ++i) {
-                    const int b = lane + WAVE * i;
-                    if (i < CHUNKS - 1 || b < B) acc[i] += tj * (double)x0[WAVE * i + j];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < CHUNKS; ++i) {
-                const int b = lane + WAVE * i;
-                if (i < CHUNKS - 1 || b < B) finish_bin(b, acc[i]);
-            }
-        };
         const int chunks = (B + WAVE - 1) / WAVE;
-        if (halo && chunks == 17) blur_rows(std::integral_constant<int, 17>{});
-        else if (halo && chunks == 9) blur_rows(std::integral_constant<int, 9>{});
-        else if (halo && chunks == 5) blur_rows(std::integral_constant<int, 5>{});
+        // (a live lane starts below bin B, so its window and the one prefetch past it end below B + NB + rad: inside the halo)
+        if (halo && chunks == 17 && 17 + rad <= ES_HALO) blur_rows(std::integral_constant<int, 17>{});
+        else if (halo && chunks == 9 && 9 + rad <= ES_HALO) blur_rows(std::integral_constant<int, 9>{});
+        else if (halo && chunks == 5 && 5 + rad <= ES_HALO) blur_rows(std::integral_constant<int, 5>{});
         else
             for (int b = lane; b < B; b += WAVE) {
                 double acc = 0.0;
