@@ -37,8 +37,8 @@ int launch_harm_shape(goofer_ctx *, float2 *, int, int64_t, const int *, const i
 int launch_noise_spectra(goofer_ctx *, float2 *, float2 *, int, int64_t, const int *, const int64_t *, const int64_t *,
                          const float *, const float *, const float *, const float *, int, const goofer_note_params *, uint64_t,
                          const int64_t *, bool, const unsigned char *, hipStream_t);
-int launch_frame_skip(goofer_ctx *, const double *, const int64_t *, const int64_t *, const int *, int, int64_t, unsigned char *,
-                      unsigned char *, hipStream_t);
+int launch_frame_skip(goofer_ctx *, const double *, int64_t, const int64_t *, const int64_t *, const int *, int, int64_t, unsigned char *,
+                      unsigned char *, unsigned char *, hipStream_t);
 int launch_mask_short(goofer_ctx *, const float *, const int64_t *, int, int64_t, const double *, int, double, double *, hipStream_t);
 int launch_assemble(goofer_ctx *, const goofer_assembly *, int *, int *, hipStream_t);
 int launch_mag_rows(goofer_ctx *, const float2 *, int, int64_t, int, float *, int, hipStream_t);
@@ -328,6 +328,7 @@ static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t sampl
         const int64_t reach = (p.n_fft + p.hop - 1) / p.hop;
         add((size_t)(frames + reach * notes) + 64);
         add((size_t)frames + 64);
+        add((size_t)(samples / 4 + notes + 16) + 64);
     }
     return b + 4096;
 }
@@ -1299,7 +1300,8 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     const bool skip_frames = ola_split && ctx->skip_zero && ctx->overlap && !sub_on && p.hop <= 512;
     unsigned char *hop_flat = skip_frames ? a.take<unsigned char>((size_t)F + (size_t)((p.n_fft + p.hop - 1) / p.hop) * n + 16) : nullptr;
     unsigned char *frame_skip = skip_frames ? a.take<unsigned char>((size_t)F + 16) : nullptr;
-    if (skip_frames && (!hop_flat || !frame_skip)) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
+    unsigned char *knot_eq = skip_frames ? a.take<unsigned char>((size_t)(N / 4 + n + 16)) : nullptr;
+    if (skip_frames && (!hop_flat || !frame_skip || !knot_eq)) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     if (!picks || !frames_u || !frames_b || !frame_note || !row_src || !f0s || (sub_on && !inc) || !onsets || !onset_idx || !onset_cnt || !ovf || !pulse || !S_h || !S_uv || !S_br || !frames ||
         !env_h || !env_n || !short_s || !note_mag || !note_steps)
         return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
@@ -1513,7 +1515,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
             // (the skip bits need the smoothed mask: it goes first then)
             if (skip_frames) {
                 if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
-                if ((rc = launch_frame_skip(ctx, short_s, b->sample_off, b->frame_off, frame_note, n, F, hop_flat, frame_skip, st))) return rc;
+                if ((rc = launch_frame_skip(ctx, short_s, N / 4 + n, b->sample_off, b->frame_off, frame_note, n, F, knot_eq, hop_flat, frame_skip, st))) return rc;
             }
             if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
                                            b->env_noise ? b->env_noise : b->env, b->phi, ld, b->params, b->seed, row_src,

@@ -857,8 +857,17 @@ int launch_irfft_ola1(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u, con
 // every hop is such a hop cannot reach a non-zero sample of that stem: its spectrum is neither written nor transformed.
 // hop_flat[frame_off[note] + reach * note + h], h < T + reach: bit 0 flat at one, bit 1 flat at zero (hops without an
 // output sample count as both); the knot window is the one k_irfft_ola1 stages for the hop (knots_fetch).
-__global__ void k_hop_flat(const double *__restrict__ short_s, const int64_t *__restrict__ sample_off, const int64_t *__restrict__ frame_off,
-                           int n_notes, int hop, int M, int reach, unsigned char *__restrict__ hop_flat)
+// eq[k] = (short_s[k] == short_s[k + 1]) over the whole smoothed-mask array: a hop's knots are one constant iff the eq bytes of
+// its window are all set, and a hop then reads 35 bytes instead of 36 doubles (its neighbours' windows overlap it by a third:
+// read as doubles, thread by thread, they cost eight times the unique bytes)
+__global__ void k_knot_eq(const double *__restrict__ short_s, int64_t count, unsigned char *__restrict__ eq)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < count) eq[k] = k + 1 < count && short_s[k] == short_s[k + 1] ? 1 : 0;
+}
+
+__global__ void k_hop_flat(const double *__restrict__ short_s, const unsigned char *__restrict__ eq, const int64_t *__restrict__ sample_off,
+                           const int64_t *__restrict__ frame_off, int n_notes, int hop, int M, int reach, unsigned char *__restrict__ hop_flat)
 {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= frame_off[n_notes] + (int64_t)reach * n_notes) return;
@@ -874,7 +883,9 @@ __global__ void k_hop_flat(const double *__restrict__ short_s, const int64_t *__
     const int i_lo = h * hop - M, i_hi = i_lo + hop - 1;
     unsigned flags = 3u;
     if (!(i_hi < 0 || i_lo >= n || ns <= 0)) {
-        const double *ss = short_s + short_base(sample_off, note);
+        const int64_t sb = short_base(sample_off, note);
+        const double *ss = short_s + sb;
+        const unsigned char *eqn = eq + sb;
         const float kps = n > 1 ? (float)(ns - 1) / (float)(n - 1) : 0.f;
         int k0 = (int)((float)(i_lo < 0 ? 0 : i_lo) * kps) - 4;
         k0 = k0 < 0 ? 0 : (k0 > ns - 1 ? ns - 1 : k0);
@@ -882,7 +893,7 @@ __global__ void k_hop_flat(const double *__restrict__ short_s, const int64_t *__
         k1 = k1 > ns - 1 ? ns - 1 : k1;
         const double c = ss[k0];
         bool same = true;
-        for (int k = k0 + 1; k <= k1; ++k) same = same && ss[k] == c;
+        for (int k = k0; k < k1; ++k) same = same && eqn[k] != 0;      // ss[k0] == ss[k0 + 1] == ... == ss[k1]
         const float cf = (float)c;
         flags = same ? ((1.0f - cf == 0.0f ? 1u : 0u) | (cf == 0.0f ? 2u : 0u)) : 0u;
     }
@@ -901,14 +912,17 @@ __global__ void k_frame_skip(const unsigned char *__restrict__ hop_flat, const i
     frame_skip[f] = (unsigned char)acc;
 }
 
-int launch_frame_skip(goofer_ctx *ctx, const double *short_s, const int64_t *sample_off, const int64_t *frame_off, const int *frame_note,
-                      int n_notes, int64_t total_frames, unsigned char *hop_flat, unsigned char *frame_skip, hipStream_t st)
+int launch_frame_skip(goofer_ctx *ctx, const double *short_s, int64_t short_count, const int64_t *sample_off, const int64_t *frame_off,
+                      const int *frame_note, int n_notes, int64_t total_frames, unsigned char *knot_eq, unsigned char *hop_flat,
+                      unsigned char *frame_skip, hipStream_t st)
 {
     if (total_frames <= 0) return GOOFER_OK;
     const goofer_plan_t &p = ctx->plan;
     const int reach = (p.n_fft + p.hop - 1) / p.hop;
     const int64_t hops = total_frames + (int64_t)reach * n_notes;
-    hipLaunchKernelGGL(k_hop_flat, dim3((unsigned)((hops + 255) / 256)), dim3(256), 0, st, short_s, sample_off, frame_off, n_notes, p.hop,
+    hipLaunchKernelGGL(k_knot_eq, dim3((unsigned)((short_count + 255) / 256)), dim3(256), 0, st, short_s, short_count, knot_eq);
+    LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(k_hop_flat, dim3((unsigned)((hops + 255) / 256)), dim3(256), 0, st, short_s, knot_eq, sample_off, frame_off, n_notes, p.hop,
                        p.n_fft / 2, reach, hop_flat);
     LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(k_frame_skip, dim3((unsigned)((total_frames + 255) / 256)), dim3(256), 0, st, hop_flat, frame_note, frame_off,

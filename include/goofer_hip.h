@@ -405,13 +405,17 @@ int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages);
 const char *goofer_profile_stage_name(int stage);
 const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage);   /* names of the path the last profiled batch took */
 
-/* Options (all exist for A/B parity runs; every setting produces the same stems):
+/* Options (all exist for A/B parity runs; every setting but td_blur produces the same stems):
  *   "fused_ola" 1 (default): irFFT of the three stems + overlap-add + gains in one kernel; 0: separate kernels
  *   "overlap"   1 (default): pulse chain on the handle's side stream beside the aperiodic branch; 0: one stream
  *   "stems"     1 (default): stem-split walker kernels where the geometry allows (hop == n_fft / 4); 0: one kernel per
  *               reference step up to the spectra, then the fused overlap-add
- *   "skip_zero" 1 (default): the noise walker skips a transform whose stem gain is exactly zero over every sample it
- *               reaches; 0: every frame runs both inverse transforms                                              */
+ *   "skip_zero" 1 (default): a noise-stem transform whose stem gain is exactly zero over every sample it reaches is skipped
+ *               (the walkers decide per hop; the n_fft 2048 pipeline per frame up front); 0: every frame runs every transform
+ *   "td_blur"   1 (default): the stem walkers fold the voiced frames' 5-tap bin blur into the synthesis window (agrees with
+ *               0, the blur over the bins, to fp32 rounding — the only option that is not bit-identical)
+ *   "f0_side"   1 (default): goofer_render_batch runs the f0 / mask kernel on the handle's side stream
+ *   tuning knobs kept for A/B runs: "walk_lds_kb", "finish_lds_kb", "sa_spt", "walk_npw", "maps_side"       */
 int goofer_set_option(goofer_ctx *ctx, const char *name, int value);
 
 /* Copy a plan table (0 window, 1 freqs, 2 boost, 3 bright_harm, 4 bright_breath, 5 pulse peak) or an

@@ -22,13 +22,14 @@ for cfg in 4 5; do
   args="--config $cfg --job-notes $notes --sub-batch 4096 --no-cpu-baseline"
   python3 bench.py $args --steps 5 --warmup 2 > "$out/bench.json" 2> "$out/bench.err"
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats -d "$out/trace" -o r --output-format csv -- python3 "$root/bench.py" $args --steps 2 --warmup 1 > "$out/trace.log" 2>&1
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$out/fetch" -o r --output-format csv -- python3 "$root/bench.py" $args --steps 1 --warmup 1 > "$out/fetch.log" 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$out/write" -o r --output-format csv -- python3 "$root/bench.py" $args --steps 1 --warmup 1 > "$out/write.log" 2>&1
+  # (traced / counted runs without the two-in-flight variant: its overlapped launches would sit in the per-kernel averages)
+  rocprofv3 --kernel-trace --stats -d "$out/trace" -o r --output-format csv -- python3 "$root/bench.py" $args --no-variants --steps 2 --warmup 1 > "$out/trace.log" 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$out/fetch" -o r --output-format csv -- python3 "$root/bench.py" $args --no-variants --steps 1 --warmup 1 > "$out/fetch.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$out/write" -o r --output-format csv -- python3 "$root/bench.py" $args --no-variants --steps 1 --warmup 1 > "$out/write.log" 2>&1
   cd "$root"
   python3 scripts/pmc_traffic_json.py "$out" "$jt"
   cp gpurun_out/profiles_$jt/* "$dst/"
-  bash scripts/pmc_script.sh "${jt}_sq" bench.py "${args// /,},--steps,1,--warmup,1" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY > "$dst/${jt}_sq_counters.txt"
+  bash scripts/pmc_script.sh "${jt}_sq" bench.py "${args// /,},--no-variants,--steps,1,--warmup,1" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY > "$dst/${jt}_sq_counters.txt"
   echo "config $cfg done"
 done
 cp gpurun_out/profiles_$tag/* "$dst/" 2>/dev/null || true
