@@ -397,6 +397,7 @@ def main():
         step()
     barrier()
     ctx.profile_begin(args.steps * len(subs))
+    scan0 = (ctx.counter("pulse_scanned_notes"), ctx.counter("pulse_fallback_notes"))
     t0 = time.perf_counter()
     for k in range(args.steps):
         last = step()
@@ -405,6 +406,7 @@ def main():
     barrier()
     elapsed = t1 - t0
     prof = ctx.profile_end()
+    scan1 = (ctx.counter("pulse_scanned_notes"), ctx.counter("pulse_fallback_notes"))
     # the timed path must have produced audio: finite, not silent (the last sub-batch of the last step)
     mix = last["mix"]
     assert bool(torch.isfinite(mix).all()) and float(mix.abs().max()) > 0.0, "the timed steps produced no valid audio"
@@ -575,6 +577,9 @@ def main():
                        "sub_batches_per_gpu": len(subs),
                        "sharding": "independent notes, no data-path collective"},
             "stage_ms": per,
+            # pulse onsets (GOOFER.py:487-493): notes of the timed steps settled by the parallel phase scan, and those it had to
+            # walk sequentially (a phase within the scan's rounding band of an integer) — rank 0's share
+            "pulse_scan": {"notes": scan1[0] - scan0[0], "fallback_notes": scan1[1] - scan0[1]},
             "roofline": roof(dom),                # the longest kernel of the step (the noise walker on the default workload)
             "roofline_noise": roof("noise_stems") if per.get("noise_stems", 0) > 0 else None,
             "roofline_harm": roof("harm_stem") if per.get("harm_stem", 0) > 0 else None,

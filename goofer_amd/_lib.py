@@ -155,6 +155,7 @@ EXPORTS = {
     "goofer_profile_stage_name_ex": (C.c_char_p, [C.c_void_p, C.c_int]),
     "goofer_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "goofer_check": (C.c_int, [C.c_void_p]),
+    "goofer_counter": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "goofer_host_gauss_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "goofer_host_plan_notes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "goofer_host_plans_view": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),

@@ -633,7 +633,8 @@ int goofer_debug_table(goofer_ctx *ctx, int which, float *host_out, int capacity
 
 // copy intermediate `which` of the last goofer_synth_batch to host memory (tests / debugging):
 // 0 frame_note 1 row_src 2 f0_scaled 3 pulse 4 S_harm 5 S_uv 6 S_breath 7 frames(last stem) 8 env_harm
-// 9 env_noise 10 mask_short 11 note_mag 12 note_peak 13 onset_cnt.  Returns the byte size.
+// 9 env_noise 10 mask_short 11 note_mag 12 note_peak 13 onset_cnt 14 onset_idx (13, 14: also of the last goofer_pulse_train).
+// Returns the byte size.
 /* Host helper of the note planner (goofer_amd/sampler.py, SillySampler.py:264-283): Gaussian FIR along the rows of a small
  * fp64 matrix with numpy 'reflect' padding, accumulated tap by tap in ascending order (product rounded, then added: the
  * arithmetic of the planner's numpy loop, so the tracks are the same bits either way).  Pure CPU code: no device is touched. */
@@ -681,6 +682,22 @@ int goofer_check(goofer_ctx *ctx)
         return goofer_fail(ctx, GOOFER_EINVAL, "note %d of a batch since the last check has more pulse onsets than n / 2 + 16 (f0 above "
                            "sr / 2?): the pulses beyond its onset slots were dropped", v - 1);
     }
+    return GOOFER_OK;
+}
+
+/* Cumulative counters of the handle (device words beside the overflow flag; the call synchronises the device):
+ *   "pulse_scanned_notes"   notes whose onsets went through the parallel phase scan (k_pulse_onsets_par)
+ *   "pulse_fallback_notes"  ... of which were walked sequentially afterwards (a sample within the error band of an integer
+ *                           phase, a negative / non-finite increment, or option pulse_scan = 2) */
+int goofer_counter(goofer_ctx *ctx, const char *name, int64_t *value)
+{
+    if (!ctx || !name || !value) return GOOFER_EINVAL;
+    int which = !strcmp(name, "pulse_fallback_notes") ? 1 : (!strcmp(name, "pulse_scanned_notes") ? 2 : -1);
+    if (which < 0) return goofer_fail(ctx, GOOFER_EINVAL, "unknown counter %s", name);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    int32_t v = 0;
+    HIP_TRY(ctx, hipMemcpy(&v, ctx->ovf_flag + which, sizeof(v), hipMemcpyDeviceToHost));
+    *value = (int64_t)(uint32_t)v;
     return GOOFER_OK;
 }
 
@@ -782,6 +799,17 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "finish_lds_kb")) { ctx->finish_lds_kb = value < 0 ? 0 : (value > 160 ? 160 : value); return GOOFER_OK; }
     if (!strcmp(name, "maps_side")) { ctx->maps_side = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "f0_side")) { ctx->f0_side = value != 0; return GOOFER_OK; }
+    if (!strcmp(name, "side_prio")) {
+        const int v = value > 0 ? 1 : (value < 0 ? -1 : 0);
+        if (v != ctx->side_prio && ctx->side) {                // the side stream is made again with the other priority
+            HIP_TRY(ctx, hipDeviceSynchronize());
+            HIP_TRY(ctx, hipStreamDestroy(ctx->side));
+            ctx->side = nullptr;
+        }
+        ctx->side_prio = v;
+        return GOOFER_OK;
+    }
+    if (!strcmp(name, "pulse_scan")) { ctx->pulse_scan = value < 0 ? 0 : (value > 2 ? 2 : value); return GOOFER_OK; }
     if (!strcmp(name, "walk_npw")) { ctx->walk_npw = (value == 1 || value == 2 || value == 4) ? value : 0; return GOOFER_OK; }
     if (!strcmp(name, "sa_spt")) { ctx->sa_spt = value >= 16 ? 16 : (value >= 8 ? 8 : 4); return GOOFER_OK; }
     return goofer_fail(ctx, GOOFER_EINVAL, "unknown option %s", name);
@@ -848,6 +876,9 @@ int goofer_pulse_train(goofer_ctx *ctx, const float *f0, const int64_t *sample_o
     int32_t *cnt = a.take<int32_t>(n_notes + 16);
     int32_t *ovf = ctx->ovf_flag;
     if (!inc || !onsets || !oidx || !cnt) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
+    for (int i = 0; i < 16; ++i) ctx->dbg_ptr[i] = nullptr;
+    ctx->dbg_ptr[13] = cnt; ctx->dbg_bytes[13] = n_notes * sizeof(int32_t);
+    ctx->dbg_ptr[14] = oidx; ctx->dbg_bytes[14] = (total_samples / 2 + 16 * (size_t)n_notes) * sizeof(int32_t);
     return launch_pulse_train(ctx, f0, 1.0f, sample_off, n_notes, total_samples, pulse, inc, (onset_t *)onsets, oidx, cnt, ovf, st);
 }
 
@@ -1239,13 +1270,18 @@ int goofer_post_batch(goofer_ctx *ctx, const goofer_post *p, void *stream)
 static int ensure_side_stream(goofer_ctx *ctx)
 {
     if (ctx->side) return GOOFER_OK;
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_maps, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_entry, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_f0, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_f0s, hipEventDisableTiming));
+    if (ctx->side_prio) {
+        // the pulse chain (f0 kernel -> onsets -> placement) is the longest dependency chain of a step and shares the chip with
+        // the envelope kernels and the noise walker of the caller's stream: its workgroups go first
+        int least = 0, greatest = 0;
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, ctx->side_prio > 0 ? greatest : least));
+    } else {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    }
+    hipEvent_t *evs[] = {&ctx->ev_fork, &ctx->ev_join, &ctx->ev_maps, &ctx->ev_entry, &ctx->ev_f0, &ctx->ev_f0s};
+    for (hipEvent_t *e : evs)
+        if (!*e) HIP_TRY(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     return GOOFER_OK;
 }
 
@@ -1332,6 +1368,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                           (size_t)F * ld * sizeof(float), walkers ? 0 : (size_t)F * ld * sizeof(float), (N / 4 + n) * sizeof(double),
                           n * sizeof(float), n * sizeof(float), n * sizeof(int32_t)};
         for (int i = 0; i < 14; ++i) { ctx->dbg_ptr[i] = ptrs[i]; ctx->dbg_bytes[i] = bytes[i]; }
+        ctx->dbg_ptr[14] = onset_idx; ctx->dbg_bytes[14] = (N / 2 + 16 * (size_t)n) * sizeof(int32_t);
     }
 
     // mask-smoothing taps for this call's sigma; device copy cached on the handle (steady state:

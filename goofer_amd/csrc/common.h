@@ -54,10 +54,12 @@ struct goofer_ctx {
     size_t dbg_bytes[16] = {0};
     bool overlap = true;          // noise spectra + mask smoothing on a side stream, beside the latency-bound pulse walk
     hipStream_t side = nullptr;   // created on first use
+    int side_prio = 1;            // ... with the highest (1) / lowest (-1) stream priority (option "side_prio"; 0: default priority).  Measured
+                                  // with the parallel phase scan in place: 2.41 ms per step against 2.50 (0) and 2.54 (-1) on one box
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_maps = nullptr;
     // goofer_render_batch: the pulse chain forks as soon as the assembled f0 exists, not when the synthesis call starts
     hipEvent_t ev_entry = nullptr, ev_f0 = nullptr, ev_f0s = nullptr;
-    int32_t *ovf_flag = nullptr;           // handle-owned device word, sticky between goofer_check calls: 1 + index (inside its batch) of a
+    int32_t *ovf_flag = nullptr;           // handle-owned device words ([1], [2]: cumulative counters, goofer_counter); [0] sticky between goofer_check calls: 1 + index (inside its batch) of a
                                            // note whose pulse onsets overflowed their slots, written with atomicMax by every pulse-chain launch
     // goofer_render_batch, stem-split path: the assembly's frame-gather kernel also writes the rows the harmonic walker needs
     // (formant-anchored + uniform warp), into a buffer the handle owns
@@ -86,6 +88,8 @@ struct goofer_ctx {
     int finish_lds_kb = 0;        // LDS k_note_finish reserves per workgroup (0: none) — caps the notes in flight per CU
     int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
     int walk_npw = 0;             // notes per wave of the phase walk: 1, 2, 4; 0 = by batch size
+    int pulse_scan = 1;           // 1: onsets from the parallel phase scan, the sequential walk only for the notes it cannot settle;
+                                  // 0: the sequential walk kernel for every note; 2: the scan kernel walks every note (tests)
     int maps_side = 0;            // goofer_render_batch: frame maps on the side stream in front of the pulse chain (A/B: +0.4 %, off)
     // per-context kernel state: hipFuncSetAttribute is per device, and a handle belongs to one device, so what was set /
     // queried is remembered here and never in process-wide statics

@@ -291,27 +291,22 @@ __device__ __forceinline__ int32_t note_scan_incl(int32_t x, Op op)
 // shrinks is the vector-issue and LDS bandwidth it takes from the kernels running beside it (94 M -> 30 M wave
 // instructions per 1024-note batch).  The notes of a wave are walked to the longest one's length (padding adds +0.0).
 template <int NPW>
-__global__ __launch_bounds__(256) void k_pulse_onsets_scan(const float *__restrict__ f0, double sr, const int64_t *__restrict__ sample_off,
-                                                           int n_notes, int32_t *__restrict__ onset_idx,
-                                                           int32_t *__restrict__ onset_cnt, int32_t *__restrict__ overflow)
+__device__ __forceinline__ void onset_walk(double *tiles, int group, const float *__restrict__ f0, double sr, const int64_t *__restrict__ sample_off,
+                                           int n_notes, int32_t *__restrict__ onset_idx, int32_t *__restrict__ onset_cnt,
+                                           int32_t *__restrict__ overflow)
 {
     constexpr int LPN = WAVE / NPW;                           // lanes per note
     constexpr int SPL = OC / LPN;                             // samples of a chunk per lane
     constexpr int BPL = SPL / OB > 0 ? SPL / OB : 1;          // walk blocks per lane (NPW = 4: 2), or lanes per block (NPW = 1: 2)
     static_assert(NPW == 1 || NPW == 2 || NPW == 4, "a note's lanes are whole DPP rows");
-    extern __shared__ __align__(16) unsigned char smem[];
     __builtin_amdgcn_s_setprio(3);                            // see k_pulse_onsets_wrap
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int sub = lane / LPN, ln = lane % LPN;              // which note of the wave, lane inside the note
-    // a workgroup is 4 / NPW waves = four notes either way: the same 32 KiB of tiles per workgroup (and, with the launcher's
-    // padded LDS request, one workgroup per CU)
-    const int group = blockIdx.x * (4 / NPW) + wv;
     const int note_raw = group * NPW + sub;
     if (__builtin_amdgcn_readfirstlane(group * NPW) >= n_notes) return;   // whole wave; no block barrier below
     const bool live = note_raw < n_notes;
     const int note = live ? note_raw : n_notes - 1;
-    // [buffer][note of the wave][OC] increments
-    double *tiles = reinterpret_cast<double *>(smem) + (size_t)wv * 2 * NPW * OC;
+    // tiles: [buffer][note of the wave][OC] increments of this wave
     const int64_t base = sample_off[note];
     const int64_t n = live ? sample_off[note + 1] - base : 0;
     const int64_t obase = base / 2 + 16 * (int64_t)note;
@@ -438,6 +433,185 @@ __global__ __launch_bounds__(256) void k_pulse_onsets_scan(const float *__restri
         emit(t_last, kept_prev, (int32_t)c_last, n - c_last);
     }
     if (ln == 0 && live) {
+        onset_cnt[note] = cnt < cap ? cnt : cap;
+        if (cnt > cap) atomicMax(overflow, note + 1);          // reported at the next synchronising call (goofer_check)
+    }
+}
+
+// a workgroup is 4 / NPW waves = four notes either way: the same 32 KiB of tiles per workgroup (and, with the launcher's
+// padded LDS request, one workgroup per CU)
+template <int NPW>
+__global__ __launch_bounds__(256) void k_pulse_onsets_scan(const float *__restrict__ f0, double sr, const int64_t *__restrict__ sample_off,
+                                                           int n_notes, int32_t *__restrict__ onset_idx,
+                                                           int32_t *__restrict__ onset_cnt, int32_t *__restrict__ overflow)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int wv = threadIdx.x >> 6;
+    onset_walk<NPW>(reinterpret_cast<double *>(smem) + (size_t)wv * 2 * NPW * OC, blockIdx.x * (4 / NPW) + wv, f0, sr, sample_off, n_notes,
+                    onset_idx, onset_cnt, overflow);
+}
+
+// Inclusive fp64 sum scan across the wave on the DPP path (see wave_scan_incl): lanes without a source add +0.0.  Any
+// association is as good as another here: see k_pulse_onsets_par.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_scan_add_f64(double x)
+{
+    x = x + dpp_f64<0x111, 0xf>(x);   // row_shr:1
+    x = x + dpp_f64<0x112, 0xf>(x);   // row_shr:2
+    x = x + dpp_f64<0x114, 0xf>(x);   // row_shr:4
+    x = x + dpp_f64<0x118, 0xf>(x);   // row_shr:8
+    x = x + dpp_f64<0x142, 0xa>(x);   // row_bcast:15 -> rows 1, 3
+    x = x + dpp_f64<0x143, 0xc>(x);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+// The onsets WITHOUT the sequential walk, wherever that is provably the same thing.
+//
+// The reference's phase after sample i is the fp64 running sum p_i = fl(p_{i-1} + x_i), x_i = f0[i] / sr (GOOFER.py:491), and
+// the onsets depend on it only through floor(p_i) (R_i = max(R_{i-1}, floor(p_i)), see onset_walk).  A blocked parallel scan
+// S_i adds the same x_1 .. x_i in another order.  For ANY order of fp64 additions of i terms the computed sum differs from
+// the exact one by at most gamma_{i-1} sum|x_j|, gamma_k = k u / (1 - k u), u = 2^-53 (Higham, Accuracy and Stability of
+// Numerical Algorithms, 4.2), so |p_i - S_i| <= 2 gamma_{i-1} A_i with A_i = sum_{j<=i} |x_j|.  With every x_j >= 0
+// (checked), A_i is the exact sum itself, A_i <= S_i / (1 - gamma), and
+//     tol_i = 2.3e-16 (c0 + 2048) S_i   >=   2 gamma_{i-1} A_i       (2 u = 2.2205e-16; c0 + 2048 > i; i < 2^31)
+// with 3.5 % to spare for the second-order terms and the rounding of tol_i itself.  If no integer lies within tol_i of S_i
+// then floor(p_i) = floor(S_i).  A note for which that holds at every sample gets its onsets from the scan: the same
+// integers the walk would have produced, hence the same onset list.  A note with a sample inside the band (f0 an exact
+// divisor of sr from phase 0 on, as in the 441 Hz vector; about one ordinary note in 10^4), a negative, non-finite or huge
+// increment is walked sequentially by the first wave of its workgroup right here (onset_walk), as before.  S_i == 0 means
+// every term so far was +0: exact, never in the band.
+//
+// One workgroup of four waves per note, 2048 samples per round: wave w takes samples 512 w .. 512 w + 511 of the round, lane l
+// of it samples 8 l .. 8 l + 7.  A sample's S is (carry of the rounds before + totals of the waves before) + (scan of the lane
+// totals before + the lane's own running sum): one summation tree over x_1 .. x_i.  Two workgroup barriers per round: the
+// wave totals, then the waves' largest floor (the onset count in front of a wave) and the band flags.
+#define PAR_TOL 2.3e-16
+#define PAR_ROUND (4 * OC)
+__global__ __launch_bounds__(256) void k_pulse_onsets_par(const float *__restrict__ f0, double sr, const int64_t *__restrict__ sample_off,
+                                                          int n_notes, int32_t *__restrict__ onset_idx,
+                                                          int32_t *__restrict__ onset_cnt, int32_t *__restrict__ overflow,
+                                                          int32_t *__restrict__ stats, int force)
+{
+    constexpr int SPL = OC / WAVE;
+    extern __shared__ __align__(16) unsigned char smem[];     // the walk's tiles (one wave: 2 x OC doubles)
+    __shared__ double s_tot[2][4];
+    __shared__ int32_t s_top[2][4], s_bad[2][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int note = blockIdx.x;
+    const int64_t base = sample_off[note];
+    const int64_t n = sample_off[note + 1] - base;
+    const int64_t obase = base / 2 + 16 * (int64_t)note;
+    const int32_t cap = (int32_t)((sample_off[note + 1] / 2 + 16 * (int64_t)(note + 1)) - obase);
+    const float *__restrict__ a = f0 + base;
+    const double rsr = 1.0 / sr;
+    int32_t *__restrict__ out = onset_idx + obase;
+    double carry = 0.0;                                       // the scan's phase in front of the round (uniform)
+    int32_t cnt = 0;                                          // onsets in front of the round (uniform)
+    bool unsure = force != 0;
+
+    float r[SPL];
+    auto fetch = [&](int64_t w0) {                            // w0: first sample of this wave's part of a round
+        const int64_t s = w0 + (int64_t)lane * SPL;
+        if (w0 + OC <= n) {
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) r[k] = a[s + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) {
+                const int64_t i = s + k;
+                const float v = n > 0 ? a[i < n ? i : n - 1] : 0.f;
+                r[k] = i < n ? v : 0.f;                       // 0 / sr = +0.0: the padding leaves the phase alone
+            }
+        }
+    };
+    if (!unsure) fetch((int64_t)wv * OC);
+    int par = 0;
+    for (int64_t c0 = 0; c0 < n && !unsure; c0 += PAR_ROUND, par ^= 1) {
+        const int64_t w0 = c0 + (int64_t)wv * OC;
+        double l[SPL];
+        bool nb = false;
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) {
+            const double x = (double)r[k], q = x * rsr;
+            const double inc = fma(fma(-q, sr, x), rsr, q);   // RN(x / sr), as in onset_walk
+            nb |= !(inc >= 0.0);                              // negative or NaN
+            l[k] = k ? l[k - 1] + inc : inc;
+        }
+        if (c0 + PAR_ROUND < n) fetch(w0 + PAR_ROUND);
+        const double incl = wave_scan_add_f64(l[SPL - 1]);
+        double excl = __shfl_up(incl, 1, WAVE);
+        excl = lane == 0 ? 0.0 : excl;
+        if (lane == WAVE - 1) s_tot[par][wv] = incl;
+        __syncthreads();
+        double before_w = carry, total = carry;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double t = s_tot[par][q];
+            total = total + t;
+            before_w = q < wv ? total : before_w;
+        }
+        const double p0 = before_w + excl;
+        const double tolf = PAR_TOL * (double)(c0 + PAR_ROUND);
+        const int64_t left = n - w0;
+        const int valid = left >= OC ? OC : (left > 0 ? (int)left : 0);
+        int32_t m[SPL];
+        int32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < SPL; ++k) {
+            const int i = lane * SPL + k;
+            const double S = p0 + l[k];
+            const double d = S - rint(S), tol = S * tolf;
+            nb |= (fabs(d) <= tol) && (tol > 0.0);
+            nb |= !(S < 1073741824.0);                        // (also inf / NaN)
+            const int32_t f = i < valid ? (int32_t)S : 0;     // S >= 0: trunc == floor
+            run = max(run, f);
+            m[k] = run;
+        }
+        const int32_t upto = wave_scan_incl(run, [](int32_t x, int32_t y) { return max(x, y); });
+        const bool wave_bad = __any(nb);
+        if (lane == WAVE - 1) { s_top[par][wv] = upto; s_bad[par][wv] = wave_bad ? 1 : 0; }
+        __syncthreads();
+        int32_t cnt_w = cnt, cnt_all = cnt;                   // onsets in front of this wave's samples / behind the round
+        int bad = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cnt_all = max(cnt_all, s_top[par][q]);
+            cnt_w = q < wv ? cnt_all : cnt_w;
+            bad |= s_bad[par][q];
+        }
+        if (bad) { unsure = true; break; }
+        // onsets of the wave's samples: as onset_walk's emit
+        int32_t before = __shfl_up(upto, 1);
+        if (lane == 0) before = 0;
+        const int32_t start = max(cnt_w, before);             // R in front of this lane's first sample
+        const int32_t mine = max(run, start) - start;
+        if (mine > 0) {
+            int32_t at = start, prev = start;                 // the slot of onset number k + 1 is k
+#pragma unroll
+            for (int k = 0; k < SPL; ++k) {
+                const int32_t c = max(prev, m[k]);
+                for (; prev < c; ++prev, ++at)
+                    if (at < cap) out[at] = (int32_t)w0 + lane * SPL + k;
+            }
+        }
+        cnt = cnt_all;
+        carry = total;
+    }
+    if (threadIdx.x == 0 && stats) {
+        atomicAdd(stats + 2, 1);
+        if (unsure) atomicAdd(stats + 1, 1);
+    }
+    if (unsure) {
+        if (wv == 0) onset_walk<1>(reinterpret_cast<double *>(smem), note, f0, sr, sample_off, n_notes, onset_idx, onset_cnt, overflow);
+        return;
+    }
+    if (threadIdx.x == 0) {
         onset_cnt[note] = cnt < cap ? cnt : cap;
         if (cnt > cap) atomicMax(overflow, note + 1);          // reported at the next synchronising call (goofer_check)
     }
@@ -626,7 +800,13 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
 {
     if (n_notes <= 0) return GOOFER_OK;
     if (f0_scale != 1.0f) return goofer_fail(ctx, GOOFER_EINVAL, "pulse onsets expect pre-scaled f0");
-    {
+    if (ctx->pulse_scan != 0) {
+        // parallel phase scan, the sequential walk inside it for the notes it cannot settle; `overflow` is the handle's block of
+        // sticky words: [0] overflow, [1] notes walked, [2] notes scanned
+        hipLaunchKernelGGL(k_pulse_onsets_par, dim3(n_notes), dim3(256), 2 * OC * sizeof(double), st, f0, (double)ctx->plan.sr, sample_off,
+                           n_notes, onset_idx, onset_cnt, overflow, overflow, ctx->pulse_scan == 2 ? 1 : 0);
+        LAUNCH_CHECK(ctx);
+    } else {
         // One note per wave.  Two or four per wave (option walk_npw) cut the walk's vector instructions to a half / a third —
         // 94 M -> 30 M per 1024-note batch — and make the STEP slower (2.77 -> 2.78 / 2.89 ms, A/B in one run): a lane then
         // replays 16 / 32 samples per chunk when the onsets are extracted, the walk takes longer, the pulse placement behind

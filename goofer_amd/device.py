@@ -96,10 +96,12 @@ class Context:
     _DBG = {"frame_note": (0, np.int32), "row_src": (1, np.int64), "f0": (2, np.float32), "pulse": (3, np.float32),
             "S_harm": (4, np.complex64), "S_uv": (5, np.complex64), "S_breath": (6, np.complex64), "frames": (7, np.float32),
             "env_harm": (8, np.float32), "env_noise": (9, np.float32), "mask_short": (10, np.float64),
-            "note_mag": (11, np.float32), "note_peak": (12, np.float32), "onset_cnt": (13, np.int32)}
+            "note_mag": (11, np.float32), "note_peak": (12, np.float32), "onset_cnt": (13, np.int32),
+            "onset_idx": (14, np.int32)}
 
     def debug_fetch(self, name: str) -> np.ndarray:
-        """Intermediate of the last synth_batch as a flat host array (tests / debugging only)."""
+        """Intermediate of the last synth_batch (onset_cnt / onset_idx: also of the last pulse_train) as a flat host array
+        (tests / debugging only).  onset_idx: note k's onset samples start at sample_off[k] // 2 + 16 k."""
         which, dt = self._DBG[name]
         size = self.lib.goofer_debug_fetch(self.h, which, None, 0)
         if size < 0:
@@ -126,6 +128,12 @@ class Context:
 
     def set_option(self, name: str, value: int):
         self._check(self.lib.goofer_set_option(self.h, name.encode(), int(value)))
+
+    def counter(self, name: str) -> int:
+        """Cumulative device-side counter of the handle (goofer_counter): 'pulse_scanned_notes', 'pulse_fallback_notes'."""
+        v = C.c_int64(0)
+        self._check(self.lib.goofer_counter(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     # -- CSR helpers ---------------------------------------------------------------------------
     def offsets(self, lengths):

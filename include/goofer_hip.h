@@ -365,6 +365,11 @@ int64_t goofer_host_decode_bends(const char *text, const int64_t *text_off, int 
  * pulse onsets than its n / 2 + 16 onset slots, GOOFER.py:493 with f0 above sr / 2).  0, or GOOFER_EINVAL + goofer_last_error. */
 int goofer_check(goofer_ctx *ctx);
 
+/* Cumulative per-handle counters kept on the device (the call synchronises): "pulse_scanned_notes" = notes whose pulse onsets
+ * (GOOFER.py:487-493) were taken from the parallel phase scan, "pulse_fallback_notes" = those of them that had to be walked
+ * sequentially afterwards because a sample's phase lay within the scan's rounding band of an integer. */
+int goofer_counter(goofer_ctx *ctx, const char *name, int64_t *value);
+
 /* gf.smooth_mask_ds (GOOFER.py:556-569) on its own, for a ragged batch of voicing masks (sample_off[n_notes + 1]): decimate by
  * 4, Gaussian max(1, sigma / 4) in fp64, np.interp back on float32 linspace grids -> out[total_samples] fp32.
  * fast_interp != 0 selects the interpolant form the stem walkers use (must give the same bits). */
@@ -415,6 +420,9 @@ const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage);   /*
  *   "td_blur"   1 (default): the stem walkers fold the voiced frames' 5-tap bin blur into the synthesis window (agrees with
  *               0, the blur over the bins, to fp32 rounding — the only option that is not bit-identical)
  *   "f0_side"   1 (default): goofer_render_batch runs the f0 / mask kernel on the handle's side stream
+ *   "pulse_scan" 1 (default): pulse onsets from a parallel fp64 phase scan wherever its rounding band provably cannot move
+ *               floor(phase), the sequential walk only for the remaining notes; 0: the sequential walk for every note;
+ *               2: the scan kernel walks every note (tests the hand-over)
  *   tuning knobs kept for A/B runs: "walk_lds_kb", "finish_lds_kb", "sa_spt", "walk_npw", "maps_side"       */
 int goofer_set_option(goofer_ctx *ctx, const char *name, int value);
 

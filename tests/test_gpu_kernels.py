@@ -155,6 +155,71 @@ def test_pulse_walk_packed_notes_equal_one_note_per_wave(ctx):
         ctx.set_option("walk_npw", 0)
 
 
+def _onset_lists(c, lens):
+    cnt = c.debug_fetch("onset_cnt")
+    idx = c.debug_fetch("onset_idx")
+    off = np.concatenate([[0], np.cumsum(lens)])
+    return [idx[off[k] // 2 + 16 * k: off[k] // 2 + 16 * k + cnt[k]].copy() for k in range(len(lens))]
+
+
+def test_pulse_onsets_parallel_scan_equals_sequential_walk(ctx):
+    """Option pulse_scan: 1 (default) takes the onsets from the parallel fp64 phase scan wherever its rounding band cannot move
+    floor(phase) and walks the other notes sequentially inside the same kernel; 0 runs the sequential walk kernel on every
+    note; 2 makes the scan kernel walk every note.  The three give the same onset samples (array_equal) and the same pulse bits on long ordinary notes, exact-rational
+    f0 (every crossing lands on an integer phase: all of those notes must take the walk), negative and oversized increments,
+    all-zero notes, unvoiced heads, and lengths around the 512-sample round."""
+    from oracle import goofer_ref as R
+    ctx.plan(44100, 1024, 256)
+    rng = np.random.default_rng(41)
+    f0s, must_walk = [], []
+    for i in range(44):
+        n = int(rng.integers(20000, 70000)) if i < 30 else [1, 2, 511, 512, 513, 1023, 1024, 1025, 7, 64, 4096, 4097, 3000, 5000][i - 30]
+        t = np.arange(n) / 44100
+        f = rng.uniform(60, 900) * 2 ** (rng.uniform(-0.5, 0.5) * np.sin(2 * np.pi * rng.uniform(0.2, 9) * t))
+        f[:int(0.08 * n)] = 0                                  # unvoiced head: the phase stays exactly 0
+        f[rng.uniform(size=n) < 0.01] = 0
+        walk = False
+        if i % 6 == 0:
+            f[:] = [441.0, 220.5, 882.0, 110.25, 440.0][(i // 6) % 5]
+            walk = n >= 401                                    # at least one onset on an integer phase (440 Hz: 2205 samples)
+            if (i // 6) % 5 == 4:
+                walk = n >= 2205
+        if i % 6 == 1:
+            f[n // 3:n // 3 + 20] = -500.0
+            walk = True
+        if i % 6 == 2 and n > 100:
+            f[int(rng.integers(50, n))] = 90000.0
+        if i == 9:
+            f[:] = 0
+        f0s.append(f.astype(np.float32))
+        must_walk.append(walk)
+    lens = [len(f) for f in f0s]
+    d_f0, off = ctx.tensor(np.concatenate(f0s)), _off(ctx, lens)
+    res = {}
+    try:
+        for mode in (0, 1, 2):
+            ctx.set_option("pulse_scan", mode)
+            s0, w0 = ctx.counter("pulse_scanned_notes"), ctx.counter("pulse_fallback_notes")
+            pulse = ctx.pulse_train(d_f0, off).cpu().numpy()
+            res[mode] = (pulse, _onset_lists(ctx, lens), ctx.counter("pulse_scanned_notes") - s0, ctx.counter("pulse_fallback_notes") - w0)
+    finally:
+        ctx.set_option("pulse_scan", 1)
+    assert res[0][2:] == (0, 0)
+    assert res[2][2:] == (len(lens), len(lens))
+    assert res[1][2] == len(lens)
+    assert sum(must_walk) <= res[1][3] <= sum(must_walk) + 3, (res[1][3], sum(must_walk))   # both branches taken in one batch
+    for mode in (1, 2):
+        assert np.array_equal(res[mode][0], res[0][0]), mode
+        for k, (a, b) in enumerate(zip(res[mode][1], res[0][1])):
+            assert np.array_equal(a, b), (mode, k)
+    assert sum(len(a) for a in res[0][1]) > 5000
+    o = 0
+    for k, (f, n) in enumerate(zip(f0s, lens)):                 # ... and they are the reference's onsets
+        if k % 3 == 0:
+            assert np.max(np.abs(res[1][0][o:o + n] - R.pulse_train(f, 44100))) < 4e-6, k
+        o += n
+
+
 def test_pulse_train_negative_and_oversized_increments(ctx):
     """R_i = max(R_{i-1}, floor(phase_i)): a falling phase records nothing until it passes the old maximum again, and an
     increment above 1 records several onsets on one sample (the reference's `while`, GOOFER.py:492)."""
