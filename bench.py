@@ -107,7 +107,7 @@ def pmc_step_traffic(frames):
             return {"bytes": None, "source": src, "stale": True}
         return {"bytes": d["_meta"]["step_hbm_bytes"], "source": src, "stale": False}
     except Exception:
-        return None
+        return {"bytes": None, "source": None, "stale": None}
 
 
 def sq_valu_issue(stage, ms, frames):
@@ -291,20 +291,22 @@ def host_inclusive(wl, ctx, step_s):
     import sys as _sys
     old_interval = _sys.getswitchinterval()
     _sys.setswitchinterval(1e-4)
-    t0 = time.perf_counter()
-    for k in range(lead + rounds):
-        if k == lead:
-            t0 = time.perf_counter()
-        th = None
-        if k + 1 < lead + rounds:
-            th = threading.Thread(target=worker)
-            th.start()
-        run(prep)
-        if th is not None:
-            th.join()
-            prep = box.pop("prep")
-    dt = (time.perf_counter() - t0) / rounds
-    _sys.setswitchinterval(old_interval)
+    try:
+        t0 = time.perf_counter()
+        for k in range(lead + rounds):
+            if k == lead:
+                t0 = time.perf_counter()
+            th = None
+            if k + 1 < lead + rounds:
+                th = threading.Thread(target=worker)
+                th.start()
+            run(prep)
+            if th is not None:
+                th.join()
+                prep = box.pop("prep")
+        dt = (time.perf_counter() - t0) / rounds
+    finally:
+        _sys.setswitchinterval(old_interval)
     best["pipelined"] = {"ms_per_batch": 1e3 * dt, "frames_per_s": frames / dt, "batches": rounds,
                          "note": "prepare(k + 1) on a second host thread while batch k runs and downloads (sys.setswitchinterval(1e-4): the "
                                  "rendering thread re-takes the interpreter lock after every device wait)"}

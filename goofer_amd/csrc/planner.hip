@@ -490,66 +490,104 @@ int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop,
                            int gauss_radius, int n_threads, goofer_host_plans **out)
 {
     if (!req || !out || n_notes < 0 || hop <= 0 || !gauss_taps || gauss_radius < 0) return GOOFER_EINVAL;
+    *out = nullptr;
     for (int i = 0; i < n_notes; ++i) {
         const goofer_plan_request &q = req[i];
         if (q.sr <= 0 || q.ylen < 0 || q.n_src_frames < 0 || q.ylen > INT32_MAX || q.loop_mode < 0 || q.loop_mode > 2 || !(q.vel_factor > 0.0))
             return GOOFER_EINVAL;
+        // Times that are not finite, or whose sample counts leave int32 (a length above ~13 h at 44.1 kHz): the double -> int64
+        // casts below would be undefined and the int32 geometry fields would wrap.  EINVAL sends the caller to the numpy
+        // planner, which raises what the reference raises for such a request (ValueError / MemoryError per note).
+        const double sr = (double)q.sr, lim = (double)INT32_MAX - 8.0;
+        const double times[] = {q.offset, q.length, q.consonant, q.cutoff, q.vel_factor};
+        for (double v : times)
+            if (!std::isfinite(v)) return GOOFER_EINVAL;
+        const double total = (double)q.ylen / sr;
+        if (!(std::fabs(q.offset) * sr < lim) || !(std::fabs(q.cutoff) * sr < lim) || !(std::fabs(q.consonant) * sr < lim) ||
+            !(std::fabs(q.length) * sr < lim) || !((std::fabs(q.offset) + std::fabs(q.consonant) + std::fabs(q.cutoff) + total) * sr < lim) ||
+            !(((double)q.ylen + std::fabs(q.length) * sr) * std::max(1.0, q.vel_factor) < lim))
+            return GOOFER_EINVAL;
         for (int c = 0; c < 4; ++c)
             if (q.track_len[c] > 0 && !q.tracks[c]) return GOOFER_EINVAL;
     }
-    std::vector<note_out> notes((size_t)n_notes);
+    // No exception may leave a worker thread (std::terminate: the whole render server would go down) or this extern "C"
+    // function: each thread records its failure, allocation failures come back as GOOFER_ENOMEM.
+    std::vector<note_out> notes;
+    goofer_host_plans *h = nullptr;
     int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
     nt = std::max(1, std::min(nt, (n_notes + 31) / 32));
-    auto work = [&](int t) {
-        std::fesetround(FE_TONEAREST);
-        scratch s;
-        for (int i = t; i < n_notes; i += nt) plan_one(req[i], hop, trim_rows, gauss_taps, gauss_radius, notes[i], s);
-    };
-    if (nt == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto &x : th) x.join();
-    }
-    goofer_host_plans *h = new (std::nothrow) goofer_host_plans;
-    if (!h) return GOOFER_ENOMEM;
-    h->geo.resize((size_t)n_notes);
-    int64_t rows = 0;
-    for (int i = 0; i < n_notes; ++i) {
-        notes[i].g.tap_off = rows;
-        h->geo[i] = notes[i].g;
-        if (notes[i].g.status == 0) rows += notes[i].g.n_out_rows;
-    }
-    h->rows = rows;
-    h->tap_idx.resize((size_t)rows * 4);
-    h->tap_w.resize((size_t)rows * 4);
-    h->F.resize((size_t)rows * 4);
-    h->fst.resize((size_t)rows * 4);
-    auto gather = [&](int t) {
-        for (int i = t; i < n_notes; i += nt) {
-            const note_out &o = notes[i];
-            if (o.g.status != 0) continue;
-            const int64_t r0 = o.g.tap_off, T = o.g.n_out_rows;
-            for (int64_t q = 0; q < T; ++q)
-                for (int c = 0; c < 4; ++c) {
-                    h->tap_idx[(size_t)(r0 + q) * 4 + c] = o.taps[q].i[c];
-                    h->tap_w[(size_t)(r0 + q) * 4 + c] = o.taps[q].w[c];
-                }
-            if (T > 0) {
-                std::memcpy(&h->F[(size_t)r0 * 4], o.F.data(), (size_t)T * 4 * sizeof(double));
-                std::memcpy(&h->fst[(size_t)r0 * 4], o.fst.data(), (size_t)T * 4 * sizeof(float));
+    std::vector<int> failed;
+    auto run_threads = [&](auto &&fn) -> bool {
+        failed.assign((size_t)nt, 0);
+        auto guarded = [&](int t) {
+            try {
+                fn(t);
+            } catch (...) {
+                failed[(size_t)t] = 1;
             }
+        };
+        if (nt == 1) {
+            guarded(0);
+        } else {
+            std::vector<std::thread> th;
+            int started = 1;
+            try {
+                for (int t = 1; t < nt; ++t, ++started) th.emplace_back(guarded, t);
+            } catch (...) {                                    // a thread could not be started: its share runs on this one below
+            }
+            guarded(0);
+            for (int t = started; t < nt; ++t) guarded(t);
+            for (auto &x : th) x.join();
         }
+        for (int f : failed)
+            if (f) return false;
+        return true;
     };
-    if (nt == 1) {
-        gather(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(gather, t);
-        gather(0);
-        for (auto &x : th) x.join();
+    try {
+        notes.resize((size_t)n_notes);
+        auto work = [&](int t) {
+            std::fesetround(FE_TONEAREST);
+            scratch s;
+            for (int i = t; i < n_notes; i += nt) plan_one(req[i], hop, trim_rows, gauss_taps, gauss_radius, notes[i], s);
+        };
+        if (!run_threads(work)) return GOOFER_ENOMEM;
+        h = new (std::nothrow) goofer_host_plans;
+        if (!h) return GOOFER_ENOMEM;
+        h->geo.resize((size_t)n_notes);
+        int64_t rows = 0;
+        for (int i = 0; i < n_notes; ++i) {
+            notes[i].g.tap_off = rows;
+            h->geo[i] = notes[i].g;
+            if (notes[i].g.status == 0) rows += notes[i].g.n_out_rows;
+        }
+        h->rows = rows;
+        h->tap_idx.resize((size_t)rows * 4);
+        h->tap_w.resize((size_t)rows * 4);
+        h->F.resize((size_t)rows * 4);
+        h->fst.resize((size_t)rows * 4);
+        auto gather = [&](int t) {
+            for (int i = t; i < n_notes; i += nt) {
+                const note_out &o = notes[i];
+                if (o.g.status != 0) continue;
+                const int64_t r0 = o.g.tap_off, T = o.g.n_out_rows;
+                for (int64_t q = 0; q < T; ++q)
+                    for (int c = 0; c < 4; ++c) {
+                        h->tap_idx[(size_t)(r0 + q) * 4 + c] = o.taps[q].i[c];
+                        h->tap_w[(size_t)(r0 + q) * 4 + c] = o.taps[q].w[c];
+                    }
+                if (T > 0) {
+                    std::memcpy(&h->F[(size_t)r0 * 4], o.F.data(), (size_t)T * 4 * sizeof(double));
+                    std::memcpy(&h->fst[(size_t)r0 * 4], o.fst.data(), (size_t)T * 4 * sizeof(float));
+                }
+            }
+        };
+        if (!run_threads(gather)) {
+            delete h;
+            return GOOFER_ENOMEM;
+        }
+    } catch (...) {
+        delete h;
+        return GOOFER_ENOMEM;
     }
     *out = h;
     return GOOFER_OK;

@@ -117,11 +117,19 @@ class SourceArena:
     """Voicebank samples resident in HBM: the fp16 knot tables (frame-major) and the voicing masks of every Source a Renderer has
     seen, back to back in two device arrays that only grow.  A render job touches a few hundred samples thousands of times; each
     is uploaded once and the notes' plans carry element offsets into the arrays (goofer_note_plan.knot_off / src_sample_off).
-    288 GB of HBM holds any voicebank: ``budget_bytes`` (default 48 GiB) only bounds a process that streams unrelated
-    sources for days — past it the arena starts over in fresh arrays (batches already prepared keep the old ones alive)."""
+    288 GB of HBM holds any voicebank: ``budget_bytes`` only bounds a process that streams unrelated sources for days — past
+    it, or once the bytes of Sources their owners have dropped (the server's LRU) exceed half of what is used, the arena
+    starts over in fresh arrays (batches already prepared keep the old ones alive).  Default budget: a quarter of the device
+    memory that is free when the arena is made, 48 GiB at most — several handles, ranks or a two-in-flight pair share a GPU."""
 
-    def __init__(self, ctx: Context, budget_bytes: int = 48 << 30):
+    def __init__(self, ctx: Context, budget_bytes: int | None = None):
         import threading
+        if budget_bytes is None:
+            try:
+                free, _total = torch.cuda.mem_get_info(ctx.device)
+                budget_bytes = min(48 << 30, max(1 << 30, free // 4))
+            except Exception:                                  # noqa: BLE001 - no device query: the fixed default
+                budget_bytes = 48 << 30
         self.ctx, self.budget = ctx, int(budget_bytes)
         self.lock = threading.Lock()
         self._reset()
@@ -131,12 +139,14 @@ class SourceArena:
         self.knots = torch.empty(0, dtype=torch.int16, device=self.ctx.device)
         self.mask = torch.empty(0, dtype=torch.float32, device=self.ctx.device)
         self.k_used = self.m_used = 0
+        self.dead = [0]                                        # bytes of dropped Sources still held (a list: the weakref callbacks add to it)
 
-    @staticmethod
-    def _grown(t, used, need):
+    def _grown(self, t, used, need):
         if used + need <= t.numel():
             return t
-        new = torch.empty(max(2 * t.numel(), used + need, 1 << 20), dtype=t.dtype, device=t.device)
+        # doubling, but never past what the budget leaves for this array (the old array lives on in prepared batches for a while)
+        cap = max(used + need, self.budget // (2 * t.element_size()))
+        new = torch.empty(max(min(2 * t.numel(), cap), used + need, 1 << 20), dtype=t.dtype, device=t.device)
         new[:used].copy_(t[:used])
         return new
 
@@ -147,7 +157,8 @@ class SourceArena:
             fresh = [sc for sc in {id(sc): sc for sc in sources}.values() if id(sc) not in self.where]
             if fresh:
                 nk, nm = sum(sc.knots.size for sc in fresh), sum(sc.ylen for sc in fresh)
-                if 2 * (self.k_used + nk) + 4 * (self.m_used + nm) > self.budget and self.where:
+                used = 2 * self.k_used + 4 * self.m_used
+                if (used + 2 * nk + 4 * nm > self.budget or (self.dead[0] > (64 << 20) and 2 * self.dead[0] > used)) and self.where:
                     self._reset()
                     fresh = list({id(sc): sc for sc in sources}.values())
                     nk, nm = sum(sc.knots.size for sc in fresh), sum(sc.ylen for sc in fresh)
@@ -160,8 +171,12 @@ class SourceArena:
                 for sc in fresh:
                     # weakly: a Source its owner has dropped (the server's LRU of 512) must not stay alive in host memory here;
                     # its entry goes with it (its device bytes stay until the arena starts over), so a recycled id cannot alias it
-                    where = self.where
-                    ref = weakref.ref(sc, lambda _r, key=id(sc), where=where: where.pop(key, None))
+                    where, dead, nbytes = self.where, self.dead, 2 * sc.knots.size + 4 * sc.ylen
+
+                    def gone(_r, key=id(sc), where=where, dead=dead, nbytes=nbytes):
+                        if where.pop(key, None) is not None:
+                            dead[0] += nbytes
+                    ref = weakref.ref(sc, gone)
                     self.where[id(sc)] = (ref, self.k_used, self.m_used)
                     self.k_used += sc.knots.size
                     self.m_used += sc.ylen

@@ -4,8 +4,8 @@
 ``assign_lpt``   a fixed job (e.g. the 10 k-note render): greedy longest-processing-time assignment by
                  frame count, deterministic, so every rank computes the same plan without communicating.
 ``reduce_timing`` the only collectives of a run: MAX of the elapsed time, SUM of the frames rendered.
-``gather_audio``  optional: ragged gather of the finished notes to one rank (RCCL over xGMI on the GPU box) — a job that
-                 wants one process to write every wav; never part of the timed render.
+``gather_audio``  optional: ragged gather of the finished notes to one rank (grouped send / recv: RCCL over xGMI on the GPU
+                 box) — a job that wants one process to write every wav; never part of the timed render.
 """
 from __future__ import annotations
 
@@ -33,12 +33,13 @@ def assign_lpt(frame_counts, world: int) -> list:
     return [sorted(x) for x in out]
 
 
-def reduce_timing(elapsed_s: float, frames: int, device=None):
+def reduce_timing(elapsed_s: float, frames: int, device=None, always: bool = False):
     """(max elapsed over ranks, total frames).  Works on any initialised process group (nccl = RCCL on
-    the GPU box, gloo in the CPU tests); a single process returns its own numbers."""
+    the GPU box, gloo in the CPU tests); a single process returns its own numbers — unless ``always`` asks for the two
+    all-reduces anyway (the one-GPU test of the RCCL path: the same calls the 8-GPU run makes)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not always):
         return float(elapsed_s), int(frames)
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     f = torch.tensor([float(frames)], dtype=torch.float64, device=device)
@@ -47,15 +48,17 @@ def reduce_timing(elapsed_s: float, frames: int, device=None):
     return float(t.item()), int(round(f.item()))
 
 
-def gather_audio(mix, lengths, dst: int = 0, group=None):
+def gather_audio(mix, lengths, dst: int = 0, group=None, always: bool = False):
     """Ragged gather of finished audio to rank ``dst`` (SURVEY.md §8 e, "optional"): ``mix`` is this rank's concatenated
     fp32 notes, ``lengths`` their sample counts.  Returns on ``dst`` a list over ranks of (mix, lengths) and None elsewhere.
-    Two collectives: an all-gather of the per-rank sizes (so every rank knows the padded shape) and one gather of the audio
-    padded to the largest rank — point-to-point traffic into ``dst`` over its direct xGMI links, no ring."""
+    One all-gather of the per-rank sizes (sample count, note count), then grouped point-to-point transfers of exactly those
+    sizes: every other rank sends its audio and its note lengths straight to ``dst``, which posts the matching receives in
+    one batch (ncclGroupStart / End under RCCL: seven concurrent transfers over the seven direct xGMI links of ``dst`` on an
+    8-GPU node, no ring, nothing padded)."""
     import torch
     import torch.distributed as dist
     lengths = [int(v) for v in lengths]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not always):
         return [(mix, lengths)]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = mix.device
@@ -63,15 +66,29 @@ def gather_audio(mix, lengths, dst: int = 0, group=None):
     all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)
     all_sizes = [tuple(int(v) for v in t.tolist()) for t in all_sizes]
-    max_n, max_k = max(s[0] for s in all_sizes), max(s[1] for s in all_sizes)
-    pad = torch.zeros(max_n, dtype=mix.dtype, device=dev)
-    pad[:mix.numel()] = mix
-    lens = torch.zeros(max_k, dtype=torch.int64, device=dev)
-    lens[:len(lengths)] = torch.tensor(lengths, dtype=torch.int64, device=dev)
-    got_a = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    got_l = [torch.empty_like(lens) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, got_a, dst=dst, group=group)
-    dist.gather(lens, got_l, dst=dst, group=group)
+    lens = torch.tensor(lengths, dtype=torch.int64, device=dev)
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
     if rank != dst:
+        ops = []
+        if mix.numel():
+            ops.append(dist.P2POp(dist.isend, mix.contiguous(), peer(dst), group))
+        if lens.numel():
+            ops.append(dist.P2POp(dist.isend, lens, peer(dst), group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
         return None
-    return [(got_a[r][:all_sizes[r][0]], [int(v) for v in got_l[r][:all_sizes[r][1]].tolist()]) for r in range(world)]
+    got_a = [mix if r == dst else torch.empty(all_sizes[r][0], dtype=mix.dtype, device=dev) for r in range(world)]
+    got_l = [lens if r == dst else torch.empty(all_sizes[r][1], dtype=torch.int64, device=dev) for r in range(world)]
+    ops = []
+    for r in range(world):
+        if r == dst:
+            continue
+        if all_sizes[r][0]:
+            ops.append(dist.P2POp(dist.irecv, got_a[r], peer(r), group))
+        if all_sizes[r][1]:
+            ops.append(dist.P2POp(dist.irecv, got_l[r], peer(r), group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return [(got_a[r], [int(v) for v in got_l[r].tolist()]) for r in range(world)]

@@ -196,9 +196,17 @@ def ensure_features(audio_path, n_fft=1024, hop_length=256, tracker=None, ctx=No
     logging.info("Extracting features")
     y, sr = read_audio(audio_path)
     _, f0, vmask, forms, knots = analyse(y, sr, n_fft, hop_length, tracker=track_fn, ctx=ctx)
-    tmp = feat.with_name(feat.name + f".tmp{os.getpid()}")
-    core.save_features(tmp, knots, f0, vmask, forms, sr, len(y))
-    os.replace(tmp, feat)
+    # a name of its own per writer (two threads of one process may analyse the same cold sample), gone again if anything fails
+    import tempfile
+    fd, tmp_name = tempfile.mkstemp(prefix=feat.name + ".tmp", dir=str(feat.parent))
+    os.close(fd)
+    tmp = Path(tmp_name)
+    try:
+        core.save_features(tmp, knots, f0, vmask, forms, sr, len(y))
+        os.replace(tmp, feat)
+    finally:
+        if tmp.exists():
+            tmp.unlink()
     return feat
 
 

@@ -164,3 +164,24 @@ def test_batch_decode_of_pitch_strings():
     one = S.decode_request("C4", "100", "L1g-10", "30", "700", "80", "40", "100", "0", "!120", "AA#5#AF#3#/+")
     assert reqs[0].loop_mode == "avg" and np.array_equal(reqs[0].bend, one.bend) and reqs[0].formant_shift == one.formant_shift
     assert reqs[1].pitch_m == S.note_to_midi("A#3") and reqs[1].length == 1.0
+
+
+def test_native_planner_steps_aside_for_times_it_cannot_hold():
+    """A request whose times are not finite, or whose sample counts would leave int32 (the geometry fields), is not planned by
+    the library (undefined double -> int64 casts, wrapped counts, allocations that throw inside a worker thread): plan_native
+    answers None and the numpy planner gets the note, as for the cases the reference refuses."""
+    import ctypes as C
+    jobs = _plannable(_random_jobs(11, 12), 256)
+    tracks = [S.source_tracks64(j[4]) for j in jobs]
+    rec = S.plan_records([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], [j[3] for j in jobs], tracks)
+    assert S.plan_native(rec, 256, True, keep=(tracks, rec)) is not None
+    for field, value in (("length", float("nan")), ("length", float("inf")), ("offset", float("nan")), ("cutoff", -float("inf")),
+                         ("consonant", float("inf")), ("length", 60000.0), ("offset", 1e12), ("cutoff", -1e15), ("consonant", 1e300),
+                         ("vel_factor", float("inf")), ("vel_factor", float("nan"))):
+        bad = rec.copy()
+        bad[field][5] = value
+        assert S.plan_native(bad, 256, True, keep=(tracks, bad)) is None, (field, value)
+        h = C.c_void_p(123)
+        taps = np.ascontiguousarray(S._gauss_taps_cached(4.0))
+        rc = S._host_lib().goofer_host_plan_notes(bad.ctypes.data, bad.shape[0], 256, 1, taps.ctypes.data, (taps.size - 1) // 2, 3, C.byref(h))
+        assert rc == -1 and not h.value                       # GOOFER_EINVAL, no handle left behind
