@@ -35,7 +35,10 @@ meta = {"csrc_sha256": source_hash(), "workload": bench["config"]["workload"], "
 # HBM bytes of one step (= one goofer_render_batch).  The profiled command also times the assembly alone and the stand-alone
 # rFFT, so launches are not simply "per step": a kernel launched at least once per step counts once, the once-per-process
 # plan kernels pro rata, and the kernels that only the extra stages launch are left out.
-steps = max(1, res.get("k_note_finish", res.get("k_sample_assemble", {})).get("launches_sampled", 1))
+# A fixed job (configs 4 / 5 with --job-notes) runs `subs` sub-batches per pass: a per-step kernel is launched `subs` times per
+# pass, and the pass moves the SUM of those launches (round 3 reported the mean sub-batch as "per pass").
+subs = max(1, int(bench["config"].get("sub_batches_per_gpu", 1)))
+steps = max(1, res.get("k_note_finish", res.get("k_sample_assemble", {})).get("launches_sampled", 1)) / subs
 stems = any(k.startswith("void k_harm_stem") for k in res)
 fused_warp = any(k.startswith("void k_env_loop<true") for k in res)
 tot, per_kernel = 0.0, {}
@@ -44,12 +47,13 @@ for k, v in res.items():
         continue
     if (stems and k.startswith("void k_rfft_frames")) or (fused_warp and k.startswith("void k_env_loop<false")):
         continue
-    per_step = min(1.0, v["launches_sampled"] / steps)
+    per_step = min(float(subs), v["launches_sampled"] / steps)            # launches of this kernel inside one pass
     per_kernel[k] = (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 * per_step
     tot += per_kernel[k]
 meta["step_hbm_bytes"] = tot
 meta["step_hbm_bytes_by_kernel"] = {k: round(v) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1])}
-meta["step_hbm_bytes_note"] = ("sum over the kernels of one goofer_render_batch of (2*FETCH + WRITE)*1024 per launch; kernels the bench launches "
+meta["sub_batches_per_pass"] = subs
+meta["step_hbm_bytes_note"] = ("sum over the kernels of one pass (= one goofer_render_batch per sub-batch, sub_batches_per_pass of them) of (2*FETCH + WRITE)*1024 per launch x launches per pass; kernels the bench launches "
                                "outside the step (stand-alone rFFT, assembly-only timing) are left out, plan-time kernels counted pro rata")
 json.dump({"_meta": meta, "kernels": {k: v for k, v in sorted(res.items()) if k.startswith(("k_", "void k_"))}},
           open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)

@@ -125,10 +125,11 @@ def test_resampler_call_surface(renderer, tmp_path):
         GooferResampler(str(tmp_path / "none.wav"), str(out), *syn.request_args(req), renderer=renderer)
 
 
-@pytest.mark.parametrize("config,ids", [(4, [0, 1, 2, 5, 7]), (5, [0, 1, 2]), (2, [0, 1, 2, 3]), (3, [0, 1])])
+@pytest.mark.parametrize("config,ids", [(1, [0]), (4, [0, 1, 2, 5, 7]), (5, [0, 1, 2]), (2, [0, 1, 2, 3]), (3, [0, 257, 640, 1023])])
 def test_baseline_config_notes_vs_oracle(config, ids):
-    """Notes of the BASELINE configs (incl. 96 kHz / n_fft 2048 / hop 96 with br+es, and L0/L1/L2 with random
-    lengths) rendered as one batch vs the CPU oracle's full render, same injected phases."""
+    """Notes of the BASELINE configs (config 1: the single 1 s note with default flags; 96 kHz / n_fft 2048 / hop 96 with
+    br+es; L0/L1/L2 with random lengths; config 3 at ids spread over the 1024-note batch) rendered as one batch vs the CPU
+    oracle's full render, same injected phases."""
     from goofer_amd.device import Context
     from goofer_amd.render import Renderer, Source
     from goofer_amd import sampler as S
@@ -269,10 +270,11 @@ def test_dense_feature_source_vs_oracle(renderer):
 _random_flags = syn.random_flags
 
 
+_FUZZ_DEFAULT = "480"   # the driver-run suite: 480 random flag strings, 40 mixed batches, 30 / 60 at other geometries / extreme requests
 _FUZZ_FIRST = int(os.environ.get("GOOFER_FUZZ_FIRST", "0"))          # a soak run: GOOFER_FUZZ_FIRST=3000 GOOFER_FUZZ_CASES=9000
 
 
-@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + int(os.environ.get("GOOFER_FUZZ_CASES", "48"))))
+@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + int(os.environ.get("GOOFER_FUZZ_CASES", _FUZZ_DEFAULT))))
 def test_random_flag_combinations_vs_oracle(renderer, case):
     """Flag interactions: random subsets of the whole vocabulary (assembly edits, jitter / sub-harmonic layers, post chain
     together), one note at a time so the legacy-RNG draw order matches, against the oracle's full render."""
@@ -303,7 +305,7 @@ def test_random_flag_combinations_vs_oracle(renderer, case):
 COMBOS = [str(n) for n in golden("combo_index")["names"]]
 
 
-@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + max(4, int(os.environ.get("GOOFER_FUZZ_CASES", "48")) // 12)))
+@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + max(4, int(os.environ.get("GOOFER_FUZZ_CASES", _FUZZ_DEFAULT)) // 12)))
 def test_random_mixed_batch_equals_single_notes(renderer, case):
     """Six notes with unrelated random flag strings (assembly edits, jitter / sub-harmonic layers, post chain) rendered as ONE
     ragged batch against the same notes rendered one at a time: bit for bit.  The legacy-RNG draws are made note by note in
@@ -347,7 +349,7 @@ def geo_renderer(request):
     c.close()
 
 
-@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + max(3, int(os.environ.get("GOOFER_FUZZ_CASES", "48")) // 16)))
+@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + max(3, int(os.environ.get("GOOFER_FUZZ_CASES", _FUZZ_DEFAULT)) // 16)))
 def test_random_flags_other_geometries_vs_oracle(geo_renderer, case):
     """The random flag vocabulary at other sample rates / transform sizes / hops (the 2048-point and 512-point kernels, a hop
     that is not a multiple of 64, eight output slots per hop) against the oracle's full render."""
@@ -379,7 +381,7 @@ def test_random_flags_other_geometries_vs_oracle(geo_renderer, case):
     assert e < TOL, (sr, n_fft, hop, flags, args, e)
 
 
-@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + max(6, int(os.environ.get("GOOFER_FUZZ_CASES", "48")) // 8)))
+@pytest.mark.parametrize("case", range(_FUZZ_FIRST, _FUZZ_FIRST + max(6, int(os.environ.get("GOOFER_FUZZ_CASES", _FUZZ_DEFAULT)) // 8)))
 def test_random_extreme_requests_vs_oracle(renderer, case):
     """The request arguments at their edges: notes of 5-120 ms (shorter than a window, a hop, a pitch-bend tick), no
     consonant, negative and large cutoffs, velocities 0 and 200, extreme tempi, long pitch-bend strings with runs, notes far
