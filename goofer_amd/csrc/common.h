@@ -87,6 +87,7 @@ struct goofer_ctx {
     int walk_lds_kb = 81;         // LDS the sequential phase walk reserves per workgroup (what it uses: 32 KiB)
     int finish_lds_kb = 0;        // LDS k_note_finish reserves per workgroup (0: none) — caps the notes in flight per CU
     int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
+    int stem_lds_kb = 0;          // stem walkers: LDS to reserve per workgroup beyond what they use (tuning: 100 -> one workgroup per CU)
     int walk_npw = 0;             // notes per wave of the phase walk: 1, 2, 4; 0 = by batch size
     int pulse_scan = 1;           // 1: onsets from the parallel phase scan, the sequential walk only for the notes it cannot settle;
                                   // 0: the sequential walk kernel for every note; 2: the scan kernel walks every note (tests)

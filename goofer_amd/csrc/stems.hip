@@ -27,10 +27,18 @@
 
 typedef float2 __attribute__((aligned(4))) float2_u;   // stems start at arbitrary sample offsets: pair stores are 4-byte aligned
 
-struct stem_taps {
-    float t5[5];               // sigma = 0.5 taps of the brightness blur (GOOFER.py:1143), fp32
-    float t175[15];            // sigma = 1.75 taps of the noise-envelope blur (GOOFER.py:993), fp32
-};
+// The two sigmas are constants of the reference (gaussian_filter1d(env, 1.75), GOOFER.py:993; sigma = 0.5, :1143 / :1171), so
+// the walkers carry the taps as literals: twenty scalar registers fewer in a frame loop that was spilling them (the noise
+// walker: 40 -> 16 SGPR spills, 0.506 -> 0.48 ms), and the products become v_fmamk / v_fmaak with the tap in the instruction.
+// The launchers compare them bit for bit with the taps goofer_plan computes (exp, normalised in fp64, rounded to fp32) and
+// refuse to run on a mismatch.
+#define STEM_T5 {0x1.14aebe0000000p-12f, 0x1.b405ba0000000p-4f, 0x1.92b9660000000p-1f, 0x1.b405ba0000000p-4f, 0x1.14aebe0000000p-12f}
+#define STEM_T175 {0x1.40c2ee0000000p-14f, 0x1.4edb880000000p-11f, 0x1.f8612e0000000p-9f, 0x1.120a540000000p-6f, 0x1.ada7fc0000000p-5f, 0x1.e5fa880000000p-4f, 0x1.8c8df20000000p-3f, 0x1.d2e20e0000000p-3f, 0x1.8c8df20000000p-3f, 0x1.e5fa880000000p-4f, 0x1.ada7fc0000000p-5f, 0x1.120a540000000p-6f, 0x1.f8612e0000000p-9f, 0x1.4edb880000000p-11f, 0x1.40c2ee0000000p-14f}
+static bool stem_taps_match(const goofer_plan_t &p)
+{
+    const float t5[5] = STEM_T5, t175[15] = STEM_T175;
+    return memcmp(t5, p.taps5_f, sizeof(t5)) == 0 && memcmp(t175, p.taps175_f, sizeof(t175)) == 0;
+}
 
 // Read a kernel argument from the kernarg segment at the point of use.  The walkers keep ~40 scalars of wave state across
 // their frame loop; arguments that are only needed every 64 frames (the frame-record arrays) or once per note kept live
@@ -309,7 +317,6 @@ struct noise_args {
     const double *short_s;
     int ld, mode, run;             // mode bit 0: blur the rows here; bit 1: never skip a transform (A/B); bit 2: the 5-tap bin blur
                                    // of voiced frames as a window on the samples
-    float t5[3], t175[8];          // first halves of the two (symmetric) tap sets
     // set-up, frame records (every 64 frames), note entry: read where they are used (cold_arg)
     int64_t total_frames;
     uint64_t seed;
@@ -360,12 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
 #pragma unroll
         for (int q = 0; q < 4; ++q) ec[q] = g_edge[q * WAVE + lane];
     }
-    // the two tap sets are symmetric (gauss_taps_host): tap q of the second half is tap len - 1 - q
-    float t5[5], t175[15];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) t5[q] = A.t5[q < 3 ? q : 4 - q];
-#pragma unroll
-    for (int q = 0; q < 15; ++q) t175[q] = A.t175[q < 8 ? q : 14 - q];
+    constexpr float t5[5] = STEM_T5, t175[15] = STEM_T175;
 
     // the next frame's envelope row is in flight while the current one is transformed: bins 8 lane .. 8 lane + 7 as two
     // 16-byte loads, the Nyquist bin beside them
@@ -669,13 +671,14 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
                                                       const int64_t *__restrict__ sample_off, const float2 *__restrict__ picks,
                                                       const goofer_note_params *__restrict__ params, const float *__restrict__ freqs,
                                                       const float *__restrict__ boost, const float *__restrict__ bright,
-                                                      const stem_taps taps, float *__restrict__ harm, float *__restrict__ note_mag,
+                                                      float *__restrict__ harm, float *__restrict__ note_mag,
                                                       int run, const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twh,
                                                       const float *__restrict__ g_win, const float *__restrict__ g_winb, const float *__restrict__ g_edge, int td_blur)
 {
     using C = stem_cfg<M>;
     constexpr int R = C::R, G = C::G, HOP = C::HOP, B = C::B, PER = C::PER, ROWF = C::ROWF;
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr float t5[5] = STEM_T5;
     walker<M, 3, true> w;
     w.init(smem, g_tw, g_twh, g_win, g_winb, freqs, boost, bright);
     const int lane = w.lane;
@@ -817,14 +820,14 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int k = lane + WAVE * i;
-                if (k < B) X[i] = blur5f(w.buf, k, B, taps.t5);
+                if (k < B) X[i] = blur5f(w.buf, k, B, t5);
             }
             wave_lds_sync();
         }
 
         // 4. inverse transform + overlap-add; hop t leaves un-normalised by the note's spectrum maximum
         float2 e[G];
-        if (voiced && td_blur) w.blur_edges(X, ec, taps.t5[0], taps.t5[1]);
+        if (voiced && td_blur) w.blur_edges(X, ec, t5[0], t5[1]);
         w.inverse_ola(X, t, carry, e, (voiced && td_blur) ? w.wsv : w.wsc);   // voiced: the bin blur rides on the window
         if (f >= f0) {
             for (int h = t;;) {
@@ -982,14 +985,6 @@ static int run_length(int64_t total_frames, int slots)
     return (int)(fit > 32 ? fit : 32);
 }
 
-static stem_taps plan_taps(const goofer_plan_t &p)
-{
-    stem_taps t;
-    for (int j = 0; j < 5; ++j) t.t5[j] = p.taps5_f[j];
-    for (int j = 0; j < 15; ++j) t.t175[j] = p.taps175_f[j];
-    return t;
-}
-
 bool stems_supported(const goofer_plan_t &p) { return p.n_fft == 1024 && p.hop * 4 == p.n_fft; }
 
 int launch_frame_picks(goofer_ctx *ctx, const int64_t *frame_off, const int *frame_note, int64_t F, const int64_t *sample_off,
@@ -1011,9 +1006,11 @@ int launch_noise_stems(goofer_ctx *ctx, const float *env, int ld, const int64_t 
     const goofer_plan_t &p = ctx->plan;
     if (!stems_supported(p)) return goofer_fail(ctx, GOOFER_EINVAL, "the stem walkers need n_fft 1024 and hop == n_fft / 4");
     if ((ld & 3) || ((uintptr_t)env & 15)) return goofer_fail(ctx, GOOFER_EINVAL, "envelope rows must be 16-byte aligned");
+    if (!stem_taps_match(p)) return goofer_fail(ctx, GOOFER_EINVAL, "the plan's blur taps differ from the walkers' literals");
     constexpr int M = 512;
     const void *fn = phi ? (const void *)k_noise_stems<M, true> : (const void *)k_noise_stems<M, false>;
-    const size_t lds = stem_cfg<M>::lds_bytes<2, false>();
+    size_t lds = stem_cfg<M>::lds_bytes<2, false>();
+    if (lds < (size_t)ctx->stem_lds_kb * 1024) lds = (size_t)ctx->stem_lds_kb * 1024;   // (tuning: fewer workgroups per CU)
     int rc, slots = 0;
     if ((rc = kernel_allow_max_lds(ctx, fn))) return rc;
     if ((rc = kernel_resident_waves(ctx, fn, lds, &slots))) return rc;
@@ -1023,8 +1020,6 @@ int launch_noise_stems(goofer_ctx *ctx, const float *env, int ld, const int64_t 
     noise_args A;
     A.env = env; A.phi = phi; A.uv = uv; A.bre = bre; A.short_s = short_s;
     A.ld = ld; A.mode = (preblurred ? 0 : 1) | (ctx->skip_zero ? 0 : 2) | (ctx->td_blur ? 4 : 0); A.run = run;
-    for (int q = 0; q < 3; ++q) A.t5[q] = p.taps5_f[q];
-    for (int q = 0; q < 8; ++q) A.t175[q] = p.taps175_f[q];
     A.total_frames = F; A.seed = seed; A.row_src = row_src; A.frame_note = frame_note; A.frame_off = frame_off;
     A.sample_off = sample_off; A.picks = picks; A.params = params; A.steps = steps; A.freqs = p.freqs; A.bright = p.bright_b;
     A.g_tw = p.tw_full; A.g_twh = p.tw_half; A.g_win = p.window; A.g_winb = p.window_blur; A.g_edge = p.blur_edge;
@@ -1042,16 +1037,18 @@ int launch_harm_stem(goofer_ctx *ctx, const float *pulse, const float *env, int 
     if (F <= 0) return GOOFER_OK;
     const goofer_plan_t &p = ctx->plan;
     if (!stems_supported(p)) return goofer_fail(ctx, GOOFER_EINVAL, "the stem walkers need n_fft 1024 and hop == n_fft / 4");
+    if (!stem_taps_match(p)) return goofer_fail(ctx, GOOFER_EINVAL, "the plan's blur taps differ from the walkers' literals");
     constexpr int M = 512;
     const void *fn = (const void *)k_harm_stem<M>;
-    const size_t lds = stem_cfg<M>::lds_bytes<3, true>();
+    size_t lds = stem_cfg<M>::lds_bytes<3, true>();
+    if (lds < (size_t)ctx->stem_lds_kb * 1024) lds = (size_t)ctx->stem_lds_kb * 1024;
     int rc, slots = 0;
     if ((rc = kernel_allow_max_lds(ctx, fn))) return rc;
     if ((rc = kernel_resident_waves(ctx, fn, lds, &slots))) return rc;
     const int run = run_length(F, slots);
     const int64_t runs = (F + run - 1) / run;
     hipLaunchKernelGGL(k_harm_stem<M>, dim3((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), dim3(256), lds, st, pulse, env, ld,
-                       row_src, F, frame_note, frame_off, sample_off, picks, params, p.freqs, p.boost, p.bright_h, plan_taps(p), harm,
+                       row_src, F, frame_note, frame_off, sample_off, picks, params, p.freqs, p.boost, p.bright_h, harm,
                        note_mag, run, p.tw_full, p.tw_half, p.window, p.window_blur, p.blur_edge, ctx->td_blur ? 1 : 0);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
