@@ -184,6 +184,7 @@ struct env_loop_grid {
     double fstep;            // np.linspace(0, sr/2, B) spacing of the bell frequencies
     float inv_fstep, nyq_f;
     warp_grid warp;
+    int nt;                  // rows leave as non-temporal stores
 };
 
 template <bool WARP, int CH>
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
             }
         }
         const float o = copy ? vf * gain : (env_f64 ? (float)(v * (double)gain) : ((float)v) * gain);
-        out[b] = o;
+        store_f1(out + b, o, eg.nt != 0);
         if (WARP) ra[b] = o;
     };
     if (CH > 0) {
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const int b = c * WAVE + lane;
-                if (b < B) wo[b] = cur[b];
+                if (b < B) store_f1(wo + b, cur[b], eg.nt != 0);
             }
         } else {
             for (int b = lane; b < B; b += WAVE) wo[b] = cur[b];
@@ -636,6 +637,7 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         const goofer_note_params *wp = fused_warp ? ctx->warp_params : nullptr;
         float *wo = fused_warp ? ctx->warp_out : nullptr;
         env_loop_grid eg;
+        eg.nt = (ctx->nt_mask & 2) ? 1 : 0;
         eg.fstep = ((double)a->sr / 2.0) / (double)(B - 1);
         eg.inv_fstep = (float)(1.0 / eg.fstep);
         eg.nyq_f = (float)((double)a->sr * 0.5);

@@ -145,7 +145,7 @@ int launch_knot_decode(goofer_ctx *ctx, const uint16_t *knots, int K, int64_t ro
 // In place on S: optional high-pass, per-note max(|S| + 1e-8), then * env * boost, and on voiced
 // frames * brightness followed by the 5-tap blur.  The 1/max normalisation commutes with the
 // (linear) rest of the chain and is applied after the overlap-add.
-template <int ITERS>
+template <int ITERS, bool NT>
 __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *__restrict__ S, int ldc, int64_t total_frames,
                                                     const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
                                                     const int64_t *__restrict__ sample_off, const float *__restrict__ f0,
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
             s.x = (s.x * g) * bo[i];
             s.y = (s.y * g) * bo[i];
             if (voiced) { s.x *= br[i]; s.y *= br[i]; r[k] = s; }
-            else row[k] = s;
+            else store_f2(row + k, s, NT);
         }
     }
     mx = __builtin_amdgcn_sqrtf(wave_max(mx)) + 1e-8f;              // max(|s| + 1e-8) = sqrt(max |s|^2) + 1e-8: sqrt is monotone
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
             const int k = lane + WAVE * i;
-            if (k < n_bins) row[k] = blur5(r, k, n_bins, t5);
+            if (k < n_bins) store_f2(row + k, blur5(r, k, n_bins, t5), NT);
         }
     }
 }
@@ -264,10 +264,16 @@ int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames,
     const int rowf = (pl.n_bins + 1) & ~1;
     const dim3 grid((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
     const size_t lds = sizeof(float2) * ROWS_PER_BLOCK * (pl.n_bins + rowf);
-#define HARM_SHAPE(IT)                                                                                                             \
-    hipLaunchKernelGGL(k_harm_shape<IT>, grid, dim3(256), lds, st, S, ldc, total_frames, frame_note, frame_off, sample_off, f0,   \
+#define HARM_SHAPE_NT(IT, NT)                                                                                                      \
+    hipLaunchKernelGGL((k_harm_shape<IT, NT>), grid, dim3(256), lds, st, S, ldc, total_frames, frame_note, frame_off, sample_off, f0, \
                        mask, env, ld, params, note_mag, pl.freqs, pl.boost, pl.bright_h, pl.blur5, pl.n_bins, pl.hop, row_src,    \
                        formants, make_warp_grid(pl.sr, pl.n_bins), ctx->frame_picks)
+    // (the shaped rows are written once and read once, by the inverse transform: non-temporal stores, option "nt_spectra")
+#define HARM_SHAPE(IT)                                                                                                             \
+    do {                                                                                                                           \
+        if (ctx->nt_spectra) HARM_SHAPE_NT(IT, true);                                                                              \
+        else HARM_SHAPE_NT(IT, false);                                                                                             \
+    } while (0)
     // bins per lane: the instantiation with the smallest count that covers the row (the kernels test k < n_bins per bin)
     const int chunks = (pl.n_bins + WAVE - 1) / WAVE;
     if (chunks <= 5) HARM_SHAPE(5);
@@ -277,13 +283,14 @@ int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames,
     else if (chunks <= 17) HARM_SHAPE(17);
     else return goofer_fail(ctx, GOOFER_EINVAL, "unsupported bin count %d", pl.n_bins);
 #undef HARM_SHAPE
+#undef HARM_SHAPE_NT
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // S_uv = U * env_noise ; S_br = (U * env_noise) * HP, brightened + blurred on voiced frames.
-template <int ITERS>
+template <int ITERS, bool NT>
 __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv, float2 *__restrict__ S_br, int ldc,
                                                        int64_t total_frames, const int *__restrict__ frame_note,
                                                        const int64_t *__restrict__ frame_off, const int64_t *__restrict__ sample_off,
@@ -390,19 +397,19 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
             e = ev[i];
         }
         float2 u2 = make_float2(c * e, s * e);
-        if (!(sk & 1u)) ru[k] = u2;
+        if (!(sk & 1u)) store_f2(ru + k, u2, NT);
         if (sk & 2u) continue;
         float h = hp_mask(fq[i], f0f);
         float2 b = make_float2(u2.x * h, u2.y * h);
         if (voiced) { b.x *= br[i]; b.y *= br[i]; r[k] = b; }
-        else rb[k] = b;
+        else store_f2(rb + k, b, NT);
     }
     if (voiced && !(sk & 2u)) {
         wave_lds_sync();
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
             const int k = lane + WAVE * i;
-            if (k < n_bins) rb[k] = blur5(r, k, n_bins, t5);
+            if (k < n_bins) store_f2(rb + k, blur5(r, k, n_bins, t5), NT);
         }
     }
 }
@@ -417,10 +424,15 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
     const int rowf = (pl.n_bins + 1) & ~1;
     const dim3 grid((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
     const size_t lds = sizeof(float2) * ROWS_PER_BLOCK * (pl.n_bins + rowf / 2 + 1);
-#define NOISE_SPECTRA(IT)                                                                                                          \
-    hipLaunchKernelGGL(k_noise_spectra<IT>, grid, dim3(256), lds, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,        \
+#define NOISE_SPECTRA_NT(IT, NT)                                                                                                   \
+    hipLaunchKernelGGL((k_noise_spectra<IT, NT>), grid, dim3(256), lds, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,  \
                        sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins, pl.hop, \
                        row_src, preblurred ? (const double *)nullptr : pl.blur175, ctx->frame_picks, frame_skip)
+#define NOISE_SPECTRA(IT)                                                                                                          \
+    do {                                                                                                                           \
+        if (ctx->nt_spectra) NOISE_SPECTRA_NT(IT, true);                                                                           \
+        else NOISE_SPECTRA_NT(IT, false);                                                                                          \
+    } while (0)
     // bins per lane: the instantiation with the smallest count that covers the row (the kernels test k < n_bins per bin)
     const int chunks = (pl.n_bins + WAVE - 1) / WAVE;
     if (chunks <= 5) NOISE_SPECTRA(5);
@@ -430,6 +442,7 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
     else if (chunks <= 17) NOISE_SPECTRA(17);
     else return goofer_fail(ctx, GOOFER_EINVAL, "unsupported bin count %d", pl.n_bins);
 #undef NOISE_SPECTRA
+#undef NOISE_SPECTRA_NT
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

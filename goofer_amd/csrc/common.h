@@ -87,6 +87,8 @@ struct goofer_ctx {
     int walk_lds_kb = 81;         // LDS the sequential phase walk reserves per workgroup (what it uses: 32 KiB)
     int finish_lds_kb = 0;        // LDS k_note_finish reserves per workgroup (0: none) — caps the notes in flight per CU
     int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
+    int nt_mask = 1;              // non-temporal stores: 1 note_finish mix / rec (the final output: -0.7 % per step), 2 env_loop rows (measured: nothing)
+    int nt_spectra = 1;           // framewise rFFT: spectrum rows leave as non-temporal stores (option "nt_spectra")
     int stem_lds_kb = 0;          // stem walkers: LDS to reserve per workgroup beyond what they use (tuning: 100 -> one workgroup per CU)
     int walk_npw = 0;             // notes per wave of the phase walk: 1, 2, 4; 0 = by batch size
     int pulse_scan = 1;           // 1: onsets from the parallel phase scan, the sequential walk only for the notes it cannot settle;
@@ -222,6 +224,25 @@ __device__ __forceinline__ float wave_max(float v)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// write-once data: a store with the non-temporal hint (global_store ... nt) when `nt`
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+typedef float v2f_nt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_f4(float *p, float4 v, bool nt)
+{
+    if (nt) __builtin_nontemporal_store(v4f_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f_nt *>(p));
+    else *reinterpret_cast<float4 *>(p) = v;
+}
+__device__ __forceinline__ void store_f2(float2 *p, float2 v, bool nt)
+{
+    if (nt) __builtin_nontemporal_store(v2f_nt{v.x, v.y}, reinterpret_cast<v2f_nt *>(p));
+    else *p = v;
+}
+__device__ __forceinline__ void store_f1(float *p, float v, bool nt)
+{
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
 }
 
 // ~1e-16-accurate reciprocal (v_rcp_f64 + two Newton steps), used where the reference divides but

@@ -13,7 +13,7 @@
 
 // ---------------------------------------------------------------------------------------------
 // register budget: two frames of M / 64 sample pairs in flight; the 2048-point frame takes the 256-VGPR budget
-template <int M>
+template <int M, bool NT = false>
 __global__ __launch_bounds__(256, M <= 512 ? 4 : 2) void k_rfft_frames(const float *__restrict__ x, const int64_t *__restrict__ sample_off,
                                                      const int64_t *__restrict__ frame_off, const int *__restrict__ frame_note,
                                                      int64_t total_frames, float2 *__restrict__ S, int ldc, int hop,
@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256, M <= 512 ? 4 : 2) void k_rfft_frames(const flo
                 recv.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send.y), 0xB1, 0xF, 0xF, false));
                 const float4 o = odd ? make_float4(recv.x, recv.y, xb.x, xb.y) : make_float4(xa.x, xa.y, recv.x, recv.y);
                 const int k0 = odd ? lane - 1 + WAVE * (r + 1) : lane + WAVE * r;
-                *reinterpret_cast<float4 *>(row + k0) = o;
+                typedef float v4f_t __attribute__((ext_vector_type(4)));
+                if (NT) __builtin_nontemporal_store(v4f_t{o.x, o.y, o.z, o.w}, reinterpret_cast<v4f_t *>(row + k0));   // write-once rows: not kept in L2
+                else *reinterpret_cast<float4 *>(row + k0) = o;
             }
         } else {
 #pragma unroll
@@ -431,8 +433,12 @@ static int rfft_impl(goofer_ctx *ctx, const float *x, const int64_t *sample_off,
 {
     const goofer_plan_t &p = ctx->plan;
     unsigned blocks = (unsigned)((total_frames + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK);
-    hipLaunchKernelGGL(k_rfft_frames<M>, dim3(blocks), dim3(256), fft_lds_bytes<M>(), st, x, sample_off, frame_off, frame_note,
-                       total_frames, S, ldc, p.hop, p.tw_full, p.tw_half, p.window);
+    if (ctx->nt_spectra)
+        hipLaunchKernelGGL((k_rfft_frames<M, true>), dim3(blocks), dim3(256), fft_lds_bytes<M>(), st, x, sample_off, frame_off, frame_note,
+                           total_frames, S, ldc, p.hop, p.tw_full, p.tw_half, p.window);
+    else
+        hipLaunchKernelGGL((k_rfft_frames<M, false>), dim3(blocks), dim3(256), fft_lds_bytes<M>(), st, x, sample_off, frame_off, frame_note,
+                           total_frames, S, ldc, p.hop, p.tw_full, p.tw_half, p.window);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

@@ -937,20 +937,20 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
             one(h.y, u.y, b.y, ho.y, uo.y, bo.y, ro.y, mo.y);
             one(h.z, u.z, b.z, ho.z, uo.z, bo.z, ro.z, mo.z);
             one(h.w, u.w, b.w, ho.w, uo.w, bo.w, ro.w, mo.w);
-            if (write_stems) {
+            if (write_stems & 1) {
                 *reinterpret_cast<float4 *>(h_ + i) = ho;
                 *reinterpret_cast<float4 *>(u_ + i) = uo;
                 *reinterpret_cast<float4 *>(b_ + i) = bo;
             }
-            if (rec) *reinterpret_cast<float4 *>(rec + base + i) = ro;
-            if (mix) *reinterpret_cast<float4 *>(mix + base + i) = mo;
+            if (rec) store_f4(rec + base + i, ro, (write_stems & 2) != 0);
+            if (mix) store_f4(mix + base + i, mo, (write_stems & 2) != 0);
         }
     }
     for (int i = (int)threadIdx.x; i < n; i += FIN_THREADS) {
         if (vec && i >= a0 && i < a1) continue;
         float ho, uo, bo, ro, mo;
         one(h_[i], u_[i], b_[i], ho, uo, bo, ro, mo);
-        if (write_stems) { h_[i] = ho; u_[i] = uo; b_[i] = bo; }
+        if (write_stems & 1) { h_[i] = ho; u_[i] = uo; b_[i] = bo; }
         if (rec) rec[base + i] = ro;
         if (mix) mix[base + i] = mo;
     }
@@ -1063,7 +1063,7 @@ int launch_note_finish(goofer_ctx *ctx, float *harm, float *uv, float *bre, floa
     if (lds > 64 * 1024)
         if (int arc = kernel_allow_max_lds(ctx, (const void *)k_note_finish)) return arc;
     hipLaunchKernelGGL(k_note_finish, dim3((unsigned)n_notes), dim3(FIN_THREADS), lds, st, harm, uv, bre, rec, mix, sample_off, params,
-                       note_mag, note_peak, write_stems ? 1 : 0);
+                       note_mag, note_peak, (write_stems ? 1 : 0) | ((ctx->nt_mask & 1) ? 2 : 0));
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

@@ -11,6 +11,9 @@ notes = 1024
 n = 48510
 ctx = Context(0)
 ctx.plan(44100, 1024, 256)
+for a in sys.argv[2:]:
+    if "=" in a:
+        ctx.set_option(a.split("=")[0], int(a.split("=")[1]))
 s_off = ctx.tensor(np.arange(notes + 1, dtype=np.int64) * n)
 T = 1 + n // 256
 f_off = ctx.tensor(np.arange(notes + 1, dtype=np.int64) * T)
