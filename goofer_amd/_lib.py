@@ -158,9 +158,12 @@ EXPORTS = {
     "goofer_counter": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "goofer_host_gauss_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "goofer_host_plan_notes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "goofer_host_plan_into": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "goofer_host_plans_view": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "goofer_host_plans_free": (None, [C.c_void_p]),
+    "goofer_host_parse_floats": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "goofer_host_decode_bends": (C.c_int64, [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "goofer_smooth_mask_ds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p,
                                         C.c_void_p]),

@@ -44,13 +44,21 @@ class _Pending:
 
 
 class BatchCollector:
-    """Gathers concurrent render requests and runs them as one device batch."""
+    """Gathers concurrent render requests and runs them as device batches — up to ``lanes`` batches in flight: each lane is a
+    Renderer with its own library handle and HIP stream (the voicebank arena is shared), so while one batch is on the device
+    or being written out, the requests that arrived meanwhile are decoded, planned and rendered on the other lane
+    (SillySampler.py:1196-1224 answers every request with its own render; a song is thousands of them)."""
 
-    def __init__(self, renderer=None, window_s: float = 0.005, max_batch: int = 4096, max_sources: int = 512, tracker=None):
-        self._renderer = renderer
+    def __init__(self, renderer=None, window_s: float = 0.005, max_batch: int = 4096, max_sources: int = 512, tracker=None,
+                 lanes: int = 2):
+        self._renderer = renderer                           # an injected renderer is the only lane
+        self._n_lanes = 1 if renderer is not None else max(1, int(lanes))
+        self._lanes = None                                  # made on first use: [(Renderer, stream or None)]
+        self._free = None
         self.tracker = tracker                              # f0 / formant tracker of the cold-cache path (goofer_amd.trackers.get)
         self.window_s, self.max_batch, self.max_sources = window_s, max_batch, max_sources
         self._sources = collections.OrderedDict()          # feature cache: path -> ((mtime_ns, size), Source)
+        self._src_lock = threading.Lock()
         self._lock = threading.Condition()
         self._queue = []
         self._stop = False
@@ -60,10 +68,27 @@ class BatchCollector:
 
     @property
     def renderer(self):
-        if self._renderer is None:
-            from .render import Renderer
-            self._renderer = Renderer()
-        return self._renderer
+        return self._lane_list()[0][0]
+
+    def _lane_list(self):
+        if self._lanes is None:
+            import queue
+            if self._renderer is not None:
+                self._lanes = [(self._renderer, None)]
+            else:
+                import torch
+                from .device import Context
+                from .render import Renderer
+                first = Renderer()
+                self._lanes = [(first, torch.cuda.Stream(first.ctx.device))]
+                for _ in range(self._n_lanes - 1):
+                    r = Renderer(Context(first.ctx.device.index if first.ctx.device.index is not None else 0), hop=first.hop)
+                    r.sources = first.sources
+                    self._lanes.append((r, torch.cuda.Stream(r.ctx.device)))
+            self._free = queue.Queue()
+            for ln in self._lanes:
+                self._free.put(ln)
+        return self._lanes
 
     def submit(self, args) -> None:
         """Blocks until the note is written; raises what the render raised."""
@@ -82,6 +107,16 @@ class BatchCollector:
             self._stop = True
             self._lock.notify_all()
         self._thread.join(5)
+        if self._lanes is not None:                         # batches still on a lane finish (their waiters get their answers)
+            import queue
+            held = []
+            try:
+                for _ in self._lanes:
+                    held.append(self._free.get(timeout=30))
+            except queue.Empty:
+                pass
+            for ln in held:
+                self._free.put(ln)
 
     def _loop(self):
         while True:
@@ -93,14 +128,34 @@ class BatchCollector:
                 self._lock.wait(self.window_s)            # let a burst accumulate
                 batch, self._queue = self._queue[:self.max_batch], self._queue[self.max_batch:]
             try:
-                self._render(batch)
-            except BaseException as e:   # noqa: BLE001 - nothing may kill the worker: every waiter gets an answer
-                for p in batch:
-                    if not p.done.is_set():
-                        p.error = e if isinstance(e, Exception) else RuntimeError(f"render worker: {e!r}")
-                        p.done.set()
-                if not isinstance(e, Exception):
-                    raise
+                self._lane_list()
+                lane = self._free.get()                    # waits while every lane holds a batch
+            except BaseException as e:   # noqa: BLE001
+                self._fail(batch, e)
+                continue
+            if len(self._lanes) == 1:
+                self._run_on(lane, batch)
+            else:
+                threading.Thread(target=self._run_on, args=(lane, batch), name="goofer-lane", daemon=True).start()
+
+    def _fail(self, batch, e):
+        for p in batch:
+            if not p.done.is_set():
+                p.error = e if isinstance(e, Exception) else RuntimeError(f"render worker: {e!r}")
+                p.done.set()
+
+    def _run_on(self, lane, batch):
+        try:
+            if lane[1] is not None:
+                import torch
+                with torch.cuda.stream(lane[1]):
+                    self._render(batch, lane[0])
+            else:
+                self._render(batch, lane[0])
+        except BaseException as e:       # noqa: BLE001 - nothing may kill the worker: every waiter gets an answer
+            self._fail(batch, e)
+        finally:
+            self._free.put(lane)
 
     def _source(self, feat: Path):
         """Features of one voicebank sample, kept across requests (a song asks for the same samples over and over): keyed by
@@ -110,19 +165,22 @@ class BatchCollector:
         from .render import Source
         st = feat.stat()
         key, stamp = str(feat), (st.st_mtime_ns, st.st_size)
-        hit = self._sources.get(key)
-        if hit is not None and hit[0] == stamp:
-            self._sources.move_to_end(key)
-            return hit[1]
+        with self._src_lock:
+            hit = self._sources.get(key)
+            if hit is not None and hit[0] == stamp:
+                self._sources.move_to_end(key)
+                return hit[1]
         env, f0, mask, forms, sr, ylen = core.load_features(feat)
         src = Source.from_pack(env, f0, mask, forms, sr, ylen)
-        self._sources[key] = (stamp, src)
-        while len(self._sources) > self.max_sources:
-            self._sources.popitem(last=False)
+        with self._src_lock:
+            self._sources[key] = (stamp, src)
+            while len(self._sources) > self.max_sources:
+                self._sources.popitem(last=False)
         return src
 
-    def _render(self, batch):
+    def _render(self, batch, renderer=None):
         from .render import write_wav
+        renderer = renderer or self.renderer
         jobs, owners = [], []
         for p in batch:                                    # per-note decode / feature load: errors stay per note
             try:
@@ -133,7 +191,7 @@ class BatchCollector:
                 # cached features, or analysed from the wav and cached on the first request for a sample (SillySampler.py:415-432)
                 feat = trackers.features_path(in_file)
                 if not feat.exists():
-                    feat = trackers.ensure_features(in_file, hop_length=self.renderer.hop, tracker=self.tracker, ctx=self.renderer.ctx)
+                    feat = trackers.ensure_features(in_file, hop_length=renderer.hop, tracker=self.tracker, ctx=renderer.ctx)
                 src = self._source(feat)
                 jobs.append((src, req))
                 owners.append((p, out_file, src.sr))
@@ -145,14 +203,14 @@ class BatchCollector:
             groups.setdefault((job[0].sr, job[0].n_fft), []).append(j)
         for idxs in groups.values():
             try:
-                outs = self.renderer.render([jobs[j] for j in idxs], seed=int(np.random.SeedSequence().generate_state(1)[0]))
+                outs = renderer.render([jobs[j] for j in idxs], seed=int(np.random.SeedSequence().generate_state(1)[0]))
                 results = dict(zip(idxs, outs))
                 errors = {}
             except Exception:           # noqa: BLE001 - isolate the offender by rendering one by one
                 results, errors = {}, {}
                 for j in idxs:
                     try:
-                        results[j] = self.renderer.render([jobs[j]], seed=int(np.random.SeedSequence().generate_state(1)[0]))[0]
+                        results[j] = renderer.render([jobs[j]], seed=int(np.random.SeedSequence().generate_state(1)[0]))[0]
                     except Exception as e:   # noqa: BLE001
                         errors[j] = e
             self.batches.append(len(idxs))

@@ -20,7 +20,9 @@
 #include <algorithm>
 #include <cfenv>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -486,11 +488,41 @@ struct goofer_host_plans {
 
 extern "C" {
 
-int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps,
-                           int gauss_radius, int n_threads, goofer_host_plans **out)
+// Validation + the threaded per-note planning shared by the two entry points.  No exception leaves a worker thread
+// (std::terminate: the whole render server would go down) or the extern "C" functions: each thread records its failure,
+// allocation failures come back as GOOFER_ENOMEM.
+static int run_threads(int nt, const std::function<void(int)> &fn)
 {
-    if (!req || !out || n_notes < 0 || hop <= 0 || !gauss_taps || gauss_radius < 0) return GOOFER_EINVAL;
-    *out = nullptr;
+    std::vector<int> failed((size_t)nt, 0);
+    auto guarded = [&](int t) {
+        try {
+            fn(t);
+        } catch (...) {
+            failed[(size_t)t] = 1;
+        }
+    };
+    if (nt == 1) {
+        guarded(0);
+    } else {
+        std::vector<std::thread> th;
+        int started = 1;
+        try {
+            for (int t = 1; t < nt; ++t, ++started) th.emplace_back(guarded, t);
+        } catch (...) {                                        // a thread could not be started: its share runs on this one below
+        }
+        guarded(0);
+        for (int t = started; t < nt; ++t) guarded(t);
+        for (auto &x : th) x.join();
+    }
+    for (int f : failed)
+        if (f) return GOOFER_ENOMEM;
+    return GOOFER_OK;
+}
+
+static int plan_all(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps, int gauss_radius,
+                    int n_threads, std::vector<note_out> &notes, int &nt)
+{
+    if (!req || n_notes < 0 || hop <= 0 || !gauss_taps || gauss_radius < 0) return GOOFER_EINVAL;
     for (int i = 0; i < n_notes; ++i) {
         const goofer_plan_request &q = req[i];
         if (q.sr <= 0 || q.ylen < 0 || q.n_src_frames < 0 || q.ylen > INT32_MAX || q.loop_mode < 0 || q.loop_mode > 2 || !(q.vel_factor > 0.0))
@@ -510,47 +542,54 @@ int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop,
         for (int c = 0; c < 4; ++c)
             if (q.track_len[c] > 0 && !q.tracks[c]) return GOOFER_EINVAL;
     }
-    // No exception may leave a worker thread (std::terminate: the whole render server would go down) or this extern "C"
-    // function: each thread records its failure, allocation failures come back as GOOFER_ENOMEM.
-    std::vector<note_out> notes;
-    goofer_host_plans *h = nullptr;
-    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
     nt = std::max(1, std::min(nt, (n_notes + 31) / 32));
-    std::vector<int> failed;
-    auto run_threads = [&](auto &&fn) -> bool {
-        failed.assign((size_t)nt, 0);
-        auto guarded = [&](int t) {
-            try {
-                fn(t);
-            } catch (...) {
-                failed[(size_t)t] = 1;
-            }
-        };
-        if (nt == 1) {
-            guarded(0);
-        } else {
-            std::vector<std::thread> th;
-            int started = 1;
-            try {
-                for (int t = 1; t < nt; ++t, ++started) th.emplace_back(guarded, t);
-            } catch (...) {                                    // a thread could not be started: its share runs on this one below
-            }
-            guarded(0);
-            for (int t = started; t < nt; ++t) guarded(t);
-            for (auto &x : th) x.join();
-        }
-        for (int f : failed)
-            if (f) return false;
-        return true;
-    };
     try {
         notes.resize((size_t)n_notes);
-        auto work = [&](int t) {
-            std::fesetround(FE_TONEAREST);
-            scratch s;
-            for (int i = t; i < n_notes; i += nt) plan_one(req[i], hop, trim_rows, gauss_taps, gauss_radius, notes[i], s);
-        };
-        if (!run_threads(work)) return GOOFER_ENOMEM;
+    } catch (...) {
+        return GOOFER_ENOMEM;
+    }
+    const int nth = nt;
+    return run_threads(nt, [&](int t) {
+        std::fesetround(FE_TONEAREST);
+        scratch s;
+        for (int i = t; i < n_notes; i += nth) plan_one(req[i], hop, trim_rows, gauss_taps, gauss_radius, notes[i], s);
+    });
+}
+
+// rows of the planned notes into four arrays (any of them may be the caller's pinned staging memory)
+static int gather_rows(const std::vector<note_out> &notes, int nt, int32_t *tap_idx, double *tap_w, double *F, float *fst)
+{
+    const int n_notes = (int)notes.size();
+    return run_threads(nt, [&](int t) {
+        for (int i = t; i < n_notes; i += nt) {
+            const note_out &o = notes[i];
+            if (o.g.status != 0) continue;
+            const int64_t r0 = o.g.tap_off, T = o.g.n_out_rows;
+            for (int64_t q = 0; q < T; ++q)
+                for (int c = 0; c < 4; ++c) {
+                    tap_idx[(size_t)(r0 + q) * 4 + c] = o.taps[q].i[c];
+                    tap_w[(size_t)(r0 + q) * 4 + c] = o.taps[q].w[c];
+                }
+            if (T > 0) {
+                std::memcpy(&F[(size_t)r0 * 4], o.F.data(), (size_t)T * 4 * sizeof(double));
+                std::memcpy(&fst[(size_t)r0 * 4], o.fst.data(), (size_t)T * 4 * sizeof(float));
+            }
+        }
+    });
+}
+
+int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps,
+                           int gauss_radius, int n_threads, goofer_host_plans **out)
+{
+    if (!out) return GOOFER_EINVAL;
+    *out = nullptr;
+    std::vector<note_out> notes;
+    int nt = 1;
+    int rc = plan_all(req, n_notes, hop, trim_rows, gauss_taps, gauss_radius, n_threads, notes, nt);
+    if (rc) return rc;
+    goofer_host_plans *h = nullptr;
+    try {
         h = new (std::nothrow) goofer_host_plans;
         if (!h) return GOOFER_ENOMEM;
         h->geo.resize((size_t)n_notes);
@@ -565,25 +604,9 @@ int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop,
         h->tap_w.resize((size_t)rows * 4);
         h->F.resize((size_t)rows * 4);
         h->fst.resize((size_t)rows * 4);
-        auto gather = [&](int t) {
-            for (int i = t; i < n_notes; i += nt) {
-                const note_out &o = notes[i];
-                if (o.g.status != 0) continue;
-                const int64_t r0 = o.g.tap_off, T = o.g.n_out_rows;
-                for (int64_t q = 0; q < T; ++q)
-                    for (int c = 0; c < 4; ++c) {
-                        h->tap_idx[(size_t)(r0 + q) * 4 + c] = o.taps[q].i[c];
-                        h->tap_w[(size_t)(r0 + q) * 4 + c] = o.taps[q].w[c];
-                    }
-                if (T > 0) {
-                    std::memcpy(&h->F[(size_t)r0 * 4], o.F.data(), (size_t)T * 4 * sizeof(double));
-                    std::memcpy(&h->fst[(size_t)r0 * 4], o.fst.data(), (size_t)T * 4 * sizeof(float));
-                }
-            }
-        };
-        if (!run_threads(gather)) {
+        if ((rc = gather_rows(notes, nt, h->tap_idx.data(), h->tap_w.data(), h->F.data(), h->fst.data()))) {
             delete h;
-            return GOOFER_ENOMEM;
+            return rc;
         }
     } catch (...) {
         delete h;
@@ -591,6 +614,30 @@ int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop,
     }
     *out = h;
     return GOOFER_OK;
+}
+
+/* The same plans written straight into memory of the caller (pinned staging buffers that one H2D copy then ships, re-used from
+ * batch to batch: no allocation, no page faults, no second copy).  geometry[n_notes]; the four row arrays hold row_capacity
+ * rows x 4.  *rows_out = rows of the batch (sum of n_out_rows over the notes with status 0).  Returns GOOFER_OK with the arrays
+ * filled; 1 when row_capacity is too small (only geometry and *rows_out are written: grow and call again); an error code. */
+int goofer_host_plan_into(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps,
+                          int gauss_radius, int n_threads, goofer_plan_geometry *geometry, int64_t row_capacity, int32_t *tap_idx,
+                          double *tap_w, double *formants, float *fst_tracks, int64_t *rows_out)
+{
+    if (!geometry || !rows_out || row_capacity < 0 || (row_capacity > 0 && (!tap_idx || !tap_w || !formants || !fst_tracks))) return GOOFER_EINVAL;
+    std::vector<note_out> notes;
+    int nt = 1;
+    int rc = plan_all(req, n_notes, hop, trim_rows, gauss_taps, gauss_radius, n_threads, notes, nt);
+    if (rc) return rc;
+    int64_t rows = 0;
+    for (int i = 0; i < n_notes; ++i) {
+        notes[i].g.tap_off = rows;
+        geometry[i] = notes[i].g;
+        if (notes[i].g.status == 0) rows += notes[i].g.n_out_rows;
+    }
+    *rows_out = rows;
+    if (rows > row_capacity) return 1;
+    return gather_rows(notes, nt, tap_idx, tap_w, formants, fst_tracks);
 }
 
 int goofer_host_plans_view(const goofer_host_plans *h, const goofer_plan_geometry **geometry, int64_t *rows, const int32_t **tap_idx,
@@ -671,6 +718,55 @@ int64_t goofer_host_decode_bends(const char *text, const int64_t *text_off, int 
     }
     out_off[n] = total;
     return total;
+}
+
+/* float(text) for n short decimal strings back to back (text_off[n + 1]): out[i] = the correctly rounded double of string i
+ * (strtod), ok[i] = 1 — for plain decimal literals only: [+-]digits[.digits][e[+-]digits], at most 63 characters, no spaces,
+ * underscores, hex, inf or nan.  Anything else gets ok[i] = 0 and the caller lets Python's float() answer (or raise).  With
+ * strip_bang != 0 leading '!' characters are skipped first (the tempo argument, SillySampler.py:298).  Returns the number of
+ * strings that were not taken. */
+int goofer_host_parse_floats(const char *text, const int64_t *text_off, int n, int strip_bang, double *out, unsigned char *ok)
+{
+    if (!text || !text_off || n < 0 || !out || !ok) return -1;
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        const char *p = text + text_off[i], *e = text + text_off[i + 1];
+        if (strip_bang)
+            while (p < e && *p == '!') ++p;
+        char buf[64];
+        const int64_t len = e - p;
+        bool good = len > 0 && len < 64;
+        if (good) {
+            const char *q = p;
+            if (*q == '+' || *q == '-') ++q;
+            int digits = 0;
+            while (q < e && *q >= '0' && *q <= '9') { ++q; ++digits; }
+            if (q < e && *q == '.') {
+                ++q;
+                while (q < e && *q >= '0' && *q <= '9') { ++q; ++digits; }
+            }
+            if (digits == 0) good = false;
+            if (good && q < e && (*q == 'e' || *q == 'E')) {
+                ++q;
+                if (q < e && (*q == '+' || *q == '-')) ++q;
+                int ed = 0;
+                while (q < e && *q >= '0' && *q <= '9') { ++q; ++ed; }
+                if (ed == 0) good = false;
+            }
+            if (q != e) good = false;
+        }
+        if (good) {
+            std::memcpy(buf, p, (size_t)len);
+            buf[len] = 0;
+            out[i] = strtod(buf, nullptr);                     // "C" locale in this process: '.' is the decimal point
+            ok[i] = 1;
+        } else {
+            out[i] = 0.0;
+            ok[i] = 0;
+            ++bad;
+        }
+    }
+    return bad;
 }
 
 }  // extern "C"

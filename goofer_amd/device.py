@@ -141,8 +141,8 @@ class Context:
         np.cumsum(np.asarray(lengths, dtype=np.int64), out=off[1:])
         return off
 
-    def frame_counts(self, sample_lengths):
-        hop = self.geom[2]
+    def frame_counts(self, sample_lengths, hop=None):
+        hop = self.geom[2] if hop is None else int(hop)
         return [1 + int(n) // hop for n in sample_lengths]
 
     # -- single-kernel entry points -------------------------------------------------------------
@@ -313,14 +313,15 @@ class Context:
         return y
 
     # -- the batch ------------------------------------------------------------------------------
-    def device_offsets(self, env_lengths, sample_lengths, params: np.ndarray):
+    def device_offsets(self, env_lengths, sample_lengths, params: np.ndarray, put=None, hop=None):
         """Upload the CSR offsets and the per-note parameter array once (reused by every step of a resident batch)."""
         params = self._c_params(params)
         s_off = self.offsets(sample_lengths)
-        f_off = self.offsets(self.frame_counts(sample_lengths))
+        f_off = self.offsets(self.frame_counts(sample_lengths, hop))
         e_off = self.offsets(env_lengths)
-        return {"s_off": s_off, "f_off": f_off, "e_off": e_off, "d_s": self.tensor(s_off), "d_f": self.tensor(f_off),
-                "d_e": self.tensor(e_off), "d_par": self.tensor(params.view(np.uint8))}
+        put = put or self.tensor
+        return {"s_off": s_off, "f_off": f_off, "e_off": e_off, "d_s": put(s_off), "d_f": put(f_off),
+                "d_e": put(e_off), "d_par": put(params.view(np.uint8))}
 
     def _c_params(self, params: np.ndarray) -> np.ndarray:
         if params.dtype != _lib.NOTE_PARAMS or params.dtype.itemsize != _lib.NOTE_PARAMS.itemsize:

@@ -113,6 +113,76 @@ def _fw_plan(n_bins, amount):
     return lo.astype(np.int32), np.minimum(lo + 1, n_bins - 1).astype(np.int32), (w - lo)
 
 
+class Staging:
+    """What a batch uploads, laid out in ONE pinned host block and shipped by one H2D copy into a device block of the same
+    size: the planner's rows (written there by the library itself, goofer_host_plan_into), the note plans, tables, pitch bends,
+    parameters and offsets.  Sixteen small uploads from pageable memory were a millisecond of every batch, and the planner's
+    freshly allocated result arrays cost more in page faults than in planning.  Blocks are re-used from batch to batch
+    (``Renderer`` keeps the free ones); ``ready`` is the event behind the last copy out of the host block."""
+
+    def __init__(self, device, nbytes: int):
+        self.nbytes = int(nbytes)
+        self.host = torch.empty(self.nbytes, dtype=torch.uint8).pin_memory()
+        self.dev = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+        self.np = self.host.numpy()
+        self.used = 0
+        self.ready = None
+
+    def reset(self):
+        if self.ready is not None:                             # the previous batch's copy out of the host block
+            self.ready.synchronize()
+            self.ready = None
+        self.used = 0
+
+    def reserve(self, shape, dtype):
+        """(host numpy view, device tensor view) of a fresh 256-byte aligned piece."""
+        dtype = np.dtype(dtype)
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        off = self.used
+        end = off + ((nbytes + 255) & ~255)
+        if end > self.nbytes:
+            raise S.StagingFull(end)
+        self.used = end
+        h = self.np[off:off + nbytes].view(dtype).reshape(shape)
+        tdt = {"float32": torch.float32, "float64": torch.float64, "int32": torch.int32, "int64": torch.int64, "uint8": torch.uint8,
+               "int16": torch.int16}.get(dtype.name)
+        d = self.dev[off:off + nbytes]
+        if tdt is not None and tdt != torch.uint8:
+            d = d.view(tdt)
+        if tdt is not None and len(shape) > 1:
+            d = d.view(*shape)
+        return h, d
+
+    def put(self, a, dtype=None):
+        """Copy ``a`` into the block; the device view of it (valid once ``ship`` has run)."""
+        a = np.asarray(a) if dtype is None else np.asarray(a, dtype=dtype)
+        if a.dtype.fields is not None:                         # structured records travel as bytes
+            a = np.ascontiguousarray(a).view(np.uint8)
+        h, d = self.reserve(a.shape, a.dtype)
+        h[...] = a
+        return d
+
+    def ship(self):
+        if self.used:
+            self.dev[:self.used].copy_(self.host[:self.used], non_blocking=True)
+        self.ready = torch.cuda.Event()
+        self.ready.record()
+
+
+class _StagingLease:
+    """Keeps a Staging block out of the free list for as long as a prepared batch refers to it."""
+
+    def __init__(self, stg, pool):
+        self.stg, self.pool = stg, pool
+
+    def __del__(self):
+        try:
+            self.pool.append(self.stg)
+        except Exception:                                      # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 class SourceArena:
     """Voicebank samples resident in HBM: the fp16 knot tables (frame-major) and the voicing masks of every Source a Renderer has
     seen, back to back in two device arrays that only grow.  A render job touches a few hundred samples thousands of times; each
@@ -150,9 +220,36 @@ class SourceArena:
         new[:used].copy_(t[:used])
         return new
 
-    def place(self, sources):
+    @staticmethod
+    def _upload(stg, pieces, dst, at):
+        """``pieces`` (host arrays of dst's dtype) back to back into dst[at:], through the pinned block of ``stg``."""
+        item = dst.element_size()
+        room = stg.nbytes // item
+        view = stg.np.view(pieces[0].dtype) if pieces else None
+        fill = 0
+
+        def flush():
+            nonlocal fill, at
+            if fill:
+                dst[at:at + fill].copy_(stg.host[:fill * item].view(dst.dtype), non_blocking=True)
+                torch.cuda.current_stream(dst.device).synchronize()   # the block is refilled next
+                at += fill
+                fill = 0
+        for p in pieces:
+            p = p.reshape(-1)
+            done = 0
+            while done < p.size:
+                take = min(p.size - done, room - fill)
+                view[fill:fill + take] = p[done:done + take]
+                fill += take
+                done += take
+                if fill == room:
+                    flush()
+        flush()
+
+    def place(self, sources, stg=None):
         """(knot_off, sample_off) int64 arrays for ``sources``, uploading the ones not resident yet; also the two device
-        arrays those offsets index (to be kept alive with the batch)."""
+        arrays those offsets index (to be kept alive with the batch).  ``stg``: an (empty) Staging block to upload through."""
         with self.lock:
             fresh = [sc for sc in {id(sc): sc for sc in sources}.values() if id(sc) not in self.where]
             if fresh:
@@ -164,10 +261,18 @@ class SourceArena:
                     nk, nm = sum(sc.knots.size for sc in fresh), sum(sc.ylen for sc in fresh)
                 self.knots = self._grown(self.knots, self.k_used, nk)
                 self.mask = self._grown(self.mask, self.m_used, nm)
-                kc = np.concatenate([sc.knot_rows() for sc in fresh]).view(np.int16)
-                mc = np.concatenate([sc.mask[:sc.ylen] for sc in fresh]).astype(np.float32, copy=False)
-                self.knots[self.k_used:self.k_used + nk].copy_(torch.from_numpy(kc))
-                self.mask[self.m_used:self.m_used + nm].copy_(torch.from_numpy(mc))
+                if stg is not None:
+                    # through the batch's pinned staging block (still empty at this point of prepare), a block's worth at a time:
+                    # the copy into pinned memory is what costs (the DMA runs at PCIe speed), a pageable source costs a second
+                    # copy inside the driver and np.concatenate a third
+                    self._upload(stg, [sc.knot_rows().view(np.int16) for sc in fresh], self.knots, self.k_used)
+                    self._upload(stg, [sc.mask[:sc.ylen] for sc in fresh], self.mask, self.m_used)
+                else:
+                    kc = np.concatenate([sc.knot_rows() for sc in fresh]).view(np.int16)
+                    mc = np.concatenate([sc.mask[:sc.ylen] for sc in fresh]).astype(np.float32, copy=False)
+                    self.knots[self.k_used:self.k_used + nk].copy_(torch.from_numpy(kc))
+                    self.mask[self.m_used:self.m_used + nm].copy_(torch.from_numpy(mc))
+                torch.cuda.current_stream(self.ctx.device).synchronize()   # batches on other streams (PipelinedRenderer) read these arrays
                 for sc in fresh:
                     # weakly: a Source its owner has dropped (the server's LRU of 512) must not stay alive in host memory here;
                     # its entry goes with it (its device bytes stay until the arena starts over), so a recycled id cannot alias it
@@ -189,6 +294,8 @@ class Renderer:
         self.ctx = ctx or default_context()
         self.hop = hop
         self.sources = SourceArena(self.ctx)
+        self._stagings = []                                    # free Staging blocks (see prepare)
+        self.plan_threads = 0                                  # host threads of the library's planner (0: up to eight)
 
     def render(self, jobs, seed: int = 0, phi_seeds=None, return_parts: bool = False):
         """jobs: list of (Source, Request).  Returns a list of fp32 arrays (the mix the reference writes to
@@ -301,12 +408,12 @@ class Renderer:
         return out, np.concatenate([[0], np.cumsum(lens)])
 
     def _post_chain(self, prep, out, seed):
-        ctx, post, jobs = self.ctx, prep["post"].copy(), prep["jobs"]
-        n = len(jobs)
+        ctx, post, rb = self.ctx, prep["post"].copy(), prep["requests"]
+        n = rb.n
         extra = {}
-        su = [i for i, (_, r) in enumerate(jobs) if r.subharm_gain > 0.0]
-        sj = [i for i, (_, r) in enumerate(jobs) if r.growl_mix > 0.0]
-        sa = [i for i, (_, r) in enumerate(jobs) if r.aperiodic_mix > 0.0]
+        su = [int(i) for i in np.nonzero(rb.col["subharm_gain"] > 0.0)[0]]
+        sj = [int(i) for i in np.nonzero(rb.col["growl_mix"] > 0.0)[0]]
+        sa = [int(i) for i in np.nonzero(rb.col["aperiodic_mix"] > 0.0)[0]]
         if su:                                                  # f0 * 0.5 == pitch_shift 0.5 on the fp32 f0          :1038-1049
             def half(sub, par):
                 par["pitch_shift"] = 0.5
@@ -336,8 +443,13 @@ class Renderer:
         ctx._check(ctx.lib.goofer_post_batch(ctx.h, C.byref(P), ctx._stream()))
         out["_keep_post"] = (extra, post, s_host)
 
-    def prepare(self, jobs, phi_seeds=None, note_ids=None, trim_rows: bool = True):
+    def prepare(self, jobs, phi_seeds=None, note_ids=None, trim_rows: bool = True, device_calls: bool = True):
         """Plan every note on the host and make the batch resident in HBM (plans, tables, sources).
+        ``device_calls=False`` (PipelinedRenderer: this runs on a worker thread while the handle is rendering another batch):
+        nothing here touches the library handle or waits for the device — the caller plans / reserves on the handle
+        (``prep["geometry"]``) before it runs the batch.
+        ``jobs``: a list of (Source, Request) pairs, or the pair (list of Sources, sampler.RequestBatch) — the requests of the
+        batch as columns, what ``sampler.decode_request_batch`` makes of the argument strings without a Python object per note.
         ``note_ids`` key the on-device noise phases (default: the position in ``jobs``), so a note can render to the
         same bits whatever batch or rank it lands in.
         ``trim_rows``: assemble only the envelope rows synthesize can reach.  The reference's L0 loop hands over more
@@ -347,11 +459,34 @@ class Renderer:
 
         Host cost: the per-note decisions run in the library's host planner (a batch per call, csrc/planner.hip) and everything
         here is column arithmetic over the batch — no per-note Python except a handful of attribute reads."""
+        need = 0
+        while True:
+            stg = None
+            while self._stagings and stg is None:
+                cand = self._stagings.pop()
+                if cand.nbytes >= need:
+                    stg = cand
+            if stg is None:
+                stg = Staging(self.ctx.device, max(need, 48 << 20))
+            stg.reset()
+            try:
+                return self._prepare(stg, jobs, phi_seeds, note_ids, trim_rows, device_calls)
+            except S.StagingFull as e:
+                need = max(int(stg.nbytes * 3 // 2), 2 * int(e.args[0]) if e.args[0] > stg.nbytes else 0, stg.nbytes + (16 << 20))
+                del stg
+
+    def _prepare(self, stg, jobs, phi_seeds, note_ids, trim_rows, device_calls=True):
         ctx = self.ctx
-        sr, n_fft = jobs[0][0].sr, jobs[0][0].n_fft
-        n = len(jobs)
-        srcs = [j[0] for j in jobs]
-        reqs = [j[1] for j in jobs]
+        if isinstance(jobs, tuple) and len(jobs) == 2 and isinstance(jobs[1], S.RequestBatch):
+            srcs, rb = list(jobs[0]), jobs[1]
+            if len(srcs) != rb.n:
+                raise ValueError("one Source per request")
+        else:
+            srcs = [j[0] for j in jobs]
+            rb = S.RequestBatch.from_requests([j[1] for j in jobs])
+        sr, n_fft = srcs[0].sr, srcs[0].n_fft
+        n = rb.n
+        c = rb.col
         # distinct sources (a voicebank sample rendered by several notes is uploaded once: same Source object)
         uniq, src_ix = {}, np.empty(n, dtype=np.int64)
         for i, sc in enumerate(srcs):
@@ -361,8 +496,10 @@ class Renderer:
             usrc[uniq[id(sc)]] = sc
         if any(sc.sr != sr or sc.n_fft != n_fft for sc in usrc):
             raise ValueError("one batch must share sr / n_fft")
-        ctx.plan(sr, n_fft, self.hop)
-        B, ld = ctx.n_bins, row_stride(ctx.n_bins)
+        if device_calls:
+            ctx.plan(sr, n_fft, self.hop)
+        B = n_fft // 2 + 1
+        ld = row_stride(B)
         for sc in usrc:
             T_src = sc.knots.shape[1]
             if T_src != 1 + sc.ylen // self.hop:               # frames of the analysis STFT (GOOFER.py:355-370)
@@ -371,7 +508,7 @@ class Renderer:
         u_K = np.array([sc.knots.shape[0] for sc in usrc], dtype=np.int64)
         u_T = np.array([sc.knots.shape[1] for sc in usrc], dtype=np.int64)
         u_ylen = np.array([sc.ylen for sc in usrc], dtype=np.int64)
-        u_koff, u_soff, d_knots, d_mask_src = self.sources.place(usrc)   # resident in HBM; new samples are uploaded here
+        u_koff, u_soff, d_knots, d_mask_src = self.sources.place(usrc, stg)   # resident in HBM; new samples are uploaded here
         lerp_keys, lerp_tabs, u_lerp = {}, [], np.full(len(usrc), -1, dtype=np.int64)
         for k, sc in enumerate(usrc):
             if sc.hz_knots is None:                            # dense source: rows are the envelope, no lerp plan
@@ -388,11 +525,23 @@ class Renderer:
         tracks = [sc.tracks64() for sc in usrc]
         pb = None
         if all(t is not None for t in tracks):
-            rec = S.plan_records(reqs, sr, u_ylen[src_ix], u_T[src_ix], [tracks[k] for k in src_ix])
-            pb = S.plan_native(rec, self.hop, trim_rows, keep=(tracks, rec))
+            rec = S.plan_records(rb, sr, u_ylen[src_ix], u_T[src_ix], [tracks[k] for k in src_ix])
+            # the rows go straight into the staging block: whatever the block has left after ~2 MiB for the small pieces
+            geo_h, _ = stg.reserve(n, _lib.PLAN_GEOMETRY)
+            cap = max(0, (stg.nbytes - stg.used - (2 << 20) - 600 * n - 8 * int(rb.bend.size)) // 96 - 8)
+            (ti_h, ti_d), (tw_h, tw_d), (fo_h, fo_d), (fs_h, fs_d) = (stg.reserve((cap, 4), np.int32), stg.reserve((cap, 4), np.float64),
+                                                                      stg.reserve((cap, 4), np.float64), stg.reserve((cap, 4), np.float32))
+            try:
+                pb = S.plan_native_into(rec, self.hop, trim_rows, geo_h, cap, ti_h, tw_h, fo_h, fs_h, keep=(tracks, rec),
+                                        threads=self.plan_threads)
+            except S.StagingFull as e:
+                raise S.StagingFull(stg.nbytes + 96 * (int(e.args[0]) - cap) + (4 << 20)) from None
+            if pb is not None:
+                pb.device = {"tap_idx": ti_d[:pb.tap_idx.shape[0]], "tap_w": tw_d[:pb.tap_idx.shape[0]],
+                             "formants": fo_d[:pb.tap_idx.shape[0]], "fst": fs_d[:pb.tap_idx.shape[0]]}
         if pb is None:                                         # odd formant dicts, or a note the reference refuses (raises here)
-            pb = S.plans_to_arrays(S.plan_notes([(r, sc.sr, sc.ylen, sc.knots.shape[1], sc.formants) for sc, r in jobs], self.hop),
-                                   self.hop, trim_rows)
+            pb = S.plans_to_arrays(S.plan_notes([(rb.request(i), sc.sr, sc.ylen, sc.knots.shape[1], sc.formants)
+                                                 for i, sc in enumerate(srcs)], self.hop), self.hop, trim_rows)
         geo = pb.geo
         if (geo["n_out"] <= 0).any():
             raise ValueError("a note assembles to zero samples")
@@ -404,16 +553,17 @@ class Renderer:
         t_off, o_off, e_off = int(env_off[-1]), int(sample_off[-1]), int(edit_off[-1])
 
         # -- request scalars as columns
-        rq = np.array([(r.reverse, r.brightness_env, r.env_shape, r.formant_width, r.force_voiced, r.pitch_m, r.tempo, r.fry_hz,
-                        r.pitch_dyn, r.formant_shift, r.normalize, r.harmonic_mix, r.breathiness_mix, r.unvoiced_mix, r.volume,
-                        r.f0_jitter_strength if r.f0_jitter else 0.0, r.volume_jitter_strength if r.volume_jitter else 0.0,
-                        r.subharm_weight if r.add_subharm else 0.0, r.subharm_gain, r.growl_mix, r.aperiodic_mix, r.sd_strength,
-                        r.tension) for r in reqs], dtype=np.float64).reshape(n, 23)
-        (c_rev, c_be, c_es, c_fw, c_fv, c_pm, c_tempo, c_fhz, c_pd, c_fs, c_norm, c_hm, c_bm, c_um, c_vol, c_f0j, c_vj, c_sub, c_su, c_sj,
-         c_sa, c_sd, c_st) = rq.T
-        c_tc = np.array([r.flags.get("t", 0) or 0 for r in reqs], dtype=np.float64)
-        n_bend = np.array([len(r.bend) for r in reqs], dtype=np.int64)
-        bend_off = csum0(n_bend)
+        c_rev, c_be, c_es, c_fw, c_fv, c_pm, c_tempo, c_fhz = (c["reverse"], c["brightness_env"], c["env_shape"], c["formant_width"],
+                                                                c["force_voiced"], c["pitch_m"], c["tempo"], c["fry_hz"])
+        c_pd, c_fs, c_norm, c_hm, c_bm, c_um, c_vol = (c["pitch_dyn"], c["formant_shift"], c["normalize"], c["harmonic_mix"],
+                                                        c["breathiness_mix"], c["unvoiced_mix"], c["volume"])
+        c_f0j = np.where(c["f0_jitter"] != 0, c["f0_jitter_strength"], 0.0)
+        c_vj = np.where(c["volume_jitter"] != 0, c["volume_jitter_strength"], 0.0)
+        c_sub = np.where(c["add_subharm"] != 0, c["subharm_weight"], 0.0)
+        c_su, c_sj, c_sa, c_sd, c_st = c["subharm_gain"], c["growl_mix"], c["aperiodic_mix"], c["sd_strength"], c["tension"]
+        c_tc = rb.t_cents
+        bend_off = rb.bend_off
+        n_bend = np.diff(bend_off)
 
         def table_ids(col, off_value, make):
             """Index of every note's table among the tables of the distinct values of ``col`` (-1 where col == off_value)."""
@@ -441,7 +591,7 @@ class Renderer:
         P["es_radius"] = np.where(es_on, es_rad[np.maximum(es_id, 0)], 0) if es_tabs else 0
         P["row_lo"], P["n_edit"], P["edit_off"] = geo["row_lo"], n_edit, edit_off[:-1]
         P["tap_off"], P["env_off"], P["n_out_rows"], P["env_f64"] = env_off[:-1], env_off[:-1], env_lens, geo["env_f64"]
-        P["fst"] = [r.formant_strength for r in reqs]
+        P["fst"] = rb.formant_strength
         P["src_sample_off"], P["ylen"], P["out_sample_off"] = u_soff[src_ix], u_ylen[src_ix], sample_off[:-1]
         for k in ("n_out", "n_pre", "s_pre", "s_tail", "tail_len", "want_samples", "n_before_vel", "vel_active", "vel_factor", "pre_new",
                   "fry_dir", "fry_const_lo", "fry_const_hi", "fry_glide_lo", "fry_glide_hi", "fry_a", "fry_b", "fry_fade"):
@@ -451,25 +601,29 @@ class Renderer:
         P["tick_dt"] = 60.0 / (c_tempo * 96.0)
         P["fry_hz"], P["pd_on"], P["pd_base"] = c_fhz, c_pd != 0.0, c_pm + c_tc / 100.0
         # pitch curve per tick in MIDI semitones: bend / 100 + pitch_m (+ t / 100 where the flag is set)   SillySampler.py:838-846
-        bend = np.concatenate([r.bend for r in reqs]).astype(np.float64) / 100.0 + np.repeat(c_pm, n_bend)
+        bend = rb.bend.astype(np.float64) / 100.0 + np.repeat(c_pm, n_bend)
         if c_tc.any():
             sel = np.repeat(c_tc != 0.0, n_bend)
             bend[sel] = bend[sel] + np.repeat(c_tc / 100.0, n_bend)[sel]
 
         def cat_tab(tabs, k, dtype):
-            return ctx.tensor(np.concatenate([t[k] for t in tabs]).astype(dtype)) if tabs else None
+            return stg.put(np.concatenate([t[k] for t in tabs]), dtype) if tabs else None
 
+        on_dev = getattr(pb, "device", None)                   # the library planner wrote the rows into the staging block
         d = dict(
-            notes=ctx.tensor(P.view(np.uint8)),
+            notes=stg.put(P),
             knots=d_knots, mask_src=d_mask_src,
             lerp_idx=cat_tab(lerp_tabs, 0, np.int32), lerp_w0=cat_tab(lerp_tabs, 1, np.float32), lerp_w1=cat_tab(lerp_tabs, 2, np.float32),
-            tilts=ctx.tensor(np.concatenate(tilt_tabs)) if tilt_tabs else None,
-            es_taps=ctx.tensor(np.concatenate(es_tabs)) if es_tabs else None,
+            tilts=stg.put(np.concatenate(tilt_tabs)) if tilt_tabs else None,
+            es_taps=stg.put(np.concatenate(es_tabs)) if es_tabs else None,
             fw_lo=cat_tab(fw_tabs, 0, np.int32), fw_hi=cat_tab(fw_tabs, 1, np.int32), fw_frac=cat_tab(fw_tabs, 2, np.float64),
-            tap_idx=ctx.tensor(pb.tap_idx), tap_w=ctx.tensor(pb.tap_w), fst_tracks=ctx.tensor(pb.fst),
-            bend=ctx.tensor(bend),
+            tap_idx=on_dev["tap_idx"] if on_dev else stg.put(pb.tap_idx), tap_w=on_dev["tap_w"] if on_dev else stg.put(pb.tap_w),
+            fst_tracks=on_dev["fst"] if on_dev else stg.put(pb.fst),
+            bend=stg.put(bend),
+            lease=_StagingLease(stg, self._stagings),
         )
-        env = ctx.rows(t_off, B)
+        d_formants = on_dev["formants"] if on_dev else stg.put(pb.formants)
+        env = torch.empty((t_off, ld), dtype=torch.float32, device=ctx.device)[:, :B]   # (= ctx.rows, without asking the handle for B)
         f0 = torch.empty(o_off, dtype=torch.float32, device=ctx.device)
         mask = torch.empty(o_off, dtype=torch.float32, device=ctx.device)
         ptr = lambda t: t.data_ptr() if t is not None else None
@@ -487,7 +641,7 @@ class Renderer:
         # per-note synthesize parameters
         par = default_params(n)
         par["formant_shift"], par["normalize"] = c_fs, c_norm
-        par["f_shift"] = [r.f_shift for r in reqs]
+        par["f_shift"] = rb.f_shift
         par["mix_harm"], par["mix_breath"], par["mix_unvoiced"], par["volume"] = c_hm, c_bm, c_um, c_vol
         nids = np.asarray(note_ids if note_ids is not None else range(n), dtype=np.uint64)   # Philox stream of the note: its id, not its batch position
         par["seed"] = np.stack([nids & np.uint64(0xFFFFFFFF), (nids >> np.uint64(32)) & np.uint64(0xFFFFFFFF)], axis=1)
@@ -497,13 +651,13 @@ class Renderer:
         # sh / sr draws come from the legacy global np.random stream, note by note, in the reference's order
         # (f0 jitter, harmonic volume, breath volume: GOOFER.py:666, 653)
         noise_f0 = noise_vol = None
-        any_f0j, any_vj = any(r.f0_jitter for r in reqs), any(r.volume_jitter for r in reqs)
+        any_f0j, any_vj = bool((c["f0_jitter"] != 0).any()), bool((c["volume_jitter"] != 0).any())
         if any_f0j or any_vj:
             nf, nh, nb = [], [], []
-            for req, n_ in zip(reqs, lens_l):
-                nf.append(np.random.randn(n_) if req.f0_jitter else np.zeros(n_))
-                nh.append(np.random.randn(n_) if req.volume_jitter else np.zeros(n_))
-                nb.append(np.random.randn(n_) if req.volume_jitter else np.zeros(n_))
+            for jf, jv, n_ in zip(c["f0_jitter"] != 0, c["volume_jitter"] != 0, lens_l):
+                nf.append(np.random.randn(n_) if jf else np.zeros(n_))
+                nh.append(np.random.randn(n_) if jv else np.zeros(n_))
+                nb.append(np.random.randn(n_) if jv else np.zeros(n_))
             if any_f0j:
                 noise_f0 = ctx.tensor(np.concatenate(nf))
             if any_vj:
@@ -516,7 +670,7 @@ class Renderer:
         growl = {}
         for i in np.nonzero(c_sj > 0.0)[0]:                    # 'sj': f0 * 0.5 * 2^N(0, mix^2), a fresh generator per call  :1063-1065
             rng = np.random.default_rng(phi_seeds[i]) if phi_seeds is not None else np.random.default_rng()
-            growl[int(i)] = 0.5 * (2.0 ** rng.normal(loc=0.0, scale=reqs[i].growl_mix ** 2, size=lens_l[i]))
+            growl[int(i)] = 0.5 * (2.0 ** rng.normal(loc=0.0, scale=float(c_sj[i]) ** 2, size=lens_l[i]))
         f0_growl = None
         if growl:
             # the layer's f0 is the fp64 pitch curve times the factor, rounded to fp32 once (SillySampler.py:1065): the
@@ -535,14 +689,16 @@ class Renderer:
                 T = 1 + n_ // self.hop
                 mats.append(np.random.default_rng(sd).uniform(0.0, 2.0 * np.pi, size=(B, T)).astype(np.float32).T)
             phi = ctx.rows_from(np.concatenate(mats))
-        offsets = ctx.device_offsets(env_lens_l, lens_l, par)
-        frames = int(sum(ctx.frame_counts(lens_l)))
-        ctx.reserve(frames, o_off, n)
-        torch.cuda.synchronize(ctx.device)
+        offsets = ctx.device_offsets(env_lens_l, lens_l, par, put=stg.put, hop=self.hop)
+        frames = int(offsets["f_off"][-1])
+        stg.ship()                                             # one H2D copy for everything above
+        if device_calls:
+            ctx.reserve(frames, o_off, n)
+            torch.cuda.current_stream(ctx.device).synchronize()   # (this batch's uploads; other lanes' streams are not waited for)
         return {"assembly": a, "keep": d, "env": env, "f0": f0, "mask": mask, "params": par, "lens": lens_l, "env_lens": env_lens_l,
                 "noise_f0": noise_f0, "noise_vol": noise_vol, "subharm": bool((c_sub > 0).any()),
-                "post": post if has_post else None, "growl": growl, "f0_growl": f0_growl, "bend_out": bend_out, "jobs": jobs,
-                "formants": ctx.tensor(pb.formants), "phi": phi, "planned": pb, "offsets": offsets,
+                "post": post if has_post else None, "growl": growl, "f0_growl": f0_growl, "bend_out": bend_out, "requests": rb, "sources": srcs, "geometry": (sr, n_fft, self.hop, frames, o_off, n),
+                "formants": d_formants, "phi": phi, "planned": pb, "offsets": offsets,
                 "sample_off": sample_off, "env_off": env_off, "frames": frames, "samples": o_off, "edit_rows": e_off}
 
 
@@ -587,3 +743,107 @@ def write_wav(path, x, sr):
         w.setsampwidth(2)
         w.setframerate(int(sr))
         w.writeframes(pcm.tobytes())
+
+
+# ---------------------------------------------------------------------------------------------
+# long jobs: two batches in flight
+# ---------------------------------------------------------------------------------------------
+class PipelinedRenderer:
+    """A stream of batches with ``depth`` of them in flight on one GPU (SillySampler.py:1196-1224 is the entry this stands
+    behind: the reference renders a note per request; a render job is thousands of them).
+
+    ``depth`` lanes, each a ``Renderer`` with its own library handle (scratch arena, side stream) and its own HIP stream; the
+    voicebank arena is shared.  Host threads decode and plan batches k + 1, k + 2 (``Renderer.prepare(device_calls=False)``:
+    numpy + the library's planner, both outside the interpreter lock for most of their time) while batch k runs; the finished
+    mix of batch k - 1 crosses PCIe on a copy stream into a pinned buffer of its lane under step k.  Per batch the job then
+    costs max(host planning / workers, device step, D2H of the mix) instead of their sum.
+
+    ``render_iter`` yields ``(mix, sample_off)`` per batch, in order: ``mix`` is a float32 numpy view of the lane's pinned
+    buffer, valid until ``depth`` more batches have been taken from the iterator (copy what must live longer)."""
+
+    def __init__(self, device: int = 0, hop: int = S.HOP, depth: int = 2, workers: int = 2):
+        from concurrent.futures import ThreadPoolExecutor
+        self.device = torch.device("cuda", device)
+        self.lanes = []
+        arena = None
+        for _ in range(max(1, depth)):
+            r = Renderer(Context(device), hop=hop)
+            if arena is None:
+                arena = r.sources
+            r.sources = arena
+            self.lanes.append({"r": r, "stream": torch.cuda.Stream(self.device), "host": None})
+        self.copy_stream = torch.cuda.Stream(self.device)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="goofer-prepare")
+        self.workers = max(1, workers)
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+        for ln in self.lanes:
+            ln["r"].ctx.close()
+        self.lanes = []
+
+    def _prepare(self, k, batch, note_ids):
+        ln = self.lanes[k % len(self.lanes)]
+        srcs, reqs = batch
+        if not isinstance(reqs, S.RequestBatch):
+            reqs = list(reqs)
+            reqs = S.RequestBatch.from_requests(reqs) if (reqs and isinstance(reqs[0], S.Request)) else S.decode_request_batch(reqs)
+        with torch.cuda.stream(ln["stream"]):
+            return ln["r"].prepare((srcs, reqs), note_ids=note_ids(k, len(reqs)) if note_ids else None, device_calls=False)
+
+    def render_iter(self, batches, seed: int = 0, note_ids=None):
+        """``batches``: an iterable of (sources, requests) — requests as a ``RequestBatch``, a list of ``Request`` or a list of
+        argument lists (decoded on the worker threads).  ``note_ids(k, n)``: the Philox ids of batch k's notes (default: the
+        position in the batch)."""
+        import collections
+        it = iter(enumerate(batches))
+        ahead = collections.deque()                           # futures of prepared batches, in order
+
+        def feed():
+            while len(ahead) < len(self.lanes) + self.workers:
+                nxt = next(it, None)
+                if nxt is None:
+                    return
+                ahead.append(self.pool.submit(self._prepare, nxt[0], nxt[1], note_ids))
+
+        flying = collections.deque()                           # (lane, event, prep, out, samples)
+        k = 0
+        feed()
+        while ahead or flying:
+            if ahead:
+                prep = ahead.popleft().result()
+                feed()
+                ln = self.lanes[k % len(self.lanes)]
+                k += 1
+                r = ln["r"]
+                sr, n_fft, hop, frames, samples, n = prep["geometry"]
+                with torch.cuda.stream(ln["stream"]):
+                    r.ctx.plan(sr, n_fft, hop)                 # no-ops once the lane has seen the geometry / the sizes
+                    r.ctx.reserve(frames, samples, n)
+                    out = r.run(prep, seed=seed)
+                    done = torch.cuda.Event()
+                    done.record()
+                if ln["host"] is None or ln["host"].numel() < samples:
+                    ln["host"] = torch.empty(max(samples, int(1.25 * samples)), dtype=torch.float32).pin_memory()
+                mix = out["mix"]
+                mix.record_stream(self.copy_stream)
+                with torch.cuda.stream(self.copy_stream):
+                    self.copy_stream.wait_event(done)
+                    ln["host"][:samples].copy_(mix, non_blocking=True)
+                    home = torch.cuda.Event()
+                    home.record()
+                flying.append((ln, home, prep, out, samples))
+            if flying and (len(flying) >= len(self.lanes) or not ahead):
+                ln, home, prep, out, samples = flying.popleft()
+                home.synchronize()
+                yield ln["host"][:samples].numpy(), prep["sample_off"]
+                del prep, out
+        for ln in self.lanes:                                  # the device is idle now: what the asynchronous calls flagged
+            ln["r"].ctx.check()
+
+    def render_all(self, batches, seed: int = 0, note_ids=None):
+        """Every note of every batch as its own float32 array (copies), batch by batch."""
+        res = []
+        for mix, off in self.render_iter(batches, seed=seed, note_ids=note_ids):
+            res.append([mix[off[i]:off[i + 1]].copy() for i in range(len(off) - 1)])
+        return res

@@ -262,6 +262,148 @@ _REQ_DEFAULTS = ("", 0, 1000, 0, 0, 100, 0, "!120", "AA")       # flags .. pitch
 
 
 # ---------------------------------------------------------------------------------------------
+# a batch of requests as columns
+# ---------------------------------------------------------------------------------------------
+_SCALAR_FIELDS = ("pitch_m", "velocity", "offset", "length", "consonant", "cutoff", "volume", "modulation", "tempo", "formant_shift",
+                  "brightness_env", "breathiness_mix", "unvoiced_mix", "harmonic_mix", "reverse", "normalize", "env_shape",
+                  "force_voiced", "formant_width", "use_editor", "f0_jitter", "f0_jitter_strength", "volume_jitter",
+                  "volume_jitter_strength", "add_subharm", "subharm_weight", "sd_strength", "tension", "growl_mix", "aperiodic_mix",
+                  "subharm_gain", "pitch_dyn", "fry", "fry_hz", "fry_glide")
+_FLAG_SCALARS = tuple(f for f in _SCALAR_FIELDS if f not in ("pitch_m", "velocity", "offset", "length", "consonant", "cutoff", "volume",
+                                                             "modulation", "tempo"))
+_LOOP_NAMES = ("concat", "avg", "stretch")
+
+
+class RequestBatch:
+    """n requests after flag scaling (what n ``Request`` objects hold) as columns: ``col[name]`` is a float64 array per scalar
+    field of ``Request`` (booleans as 0 / 1), ``f_shift`` / ``formant_strength`` are [n, 4], ``loop_code`` the loop mode as the
+    planner's code (0 concat, 1 avg, 2 stretch), ``t_cents`` the ``t`` flag (0 where absent), ``bend`` the notes' pitch bends
+    back to back (float32) with ``bend_off`` [n + 1].  A render job plans, assembles and synthesises whole batches; nothing
+    in that path wants a Python object per note."""
+
+    __slots__ = ("n", "col", "f_shift", "formant_strength", "loop_code", "t_cents", "bend", "bend_off")
+
+    def __len__(self):
+        return self.n
+
+    @classmethod
+    def from_requests(cls, reqs):
+        b = cls()
+        b.n = n = len(reqs)
+        b.col = {f: np.array([getattr(r, f) for r in reqs], dtype=np.float64).reshape(n) for f in _SCALAR_FIELDS}
+        b.f_shift = np.array([r.f_shift for r in reqs], dtype=np.float64).reshape(n, 4)
+        b.formant_strength = np.array([r.formant_strength for r in reqs], dtype=np.float64).reshape(n, 4)
+        b.loop_code = np.array([_LOOP_NAMES.index(r.loop_mode) for r in reqs], dtype=np.int32).reshape(n)
+        b.t_cents = np.array([r.flags.get("t", 0) or 0 for r in reqs], dtype=np.float64).reshape(n)
+        lens = np.array([len(r.bend) for r in reqs], dtype=np.int64).reshape(n)
+        b.bend_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        b.bend = np.concatenate([np.asarray(r.bend, dtype=np.float32) for r in reqs]) if n else np.zeros(0, np.float32)
+        return b
+
+    def request(self, i: int) -> Request:
+        """Note i as a ``Request`` (flags dict: only ``t`` is carried)."""
+        c = self.col
+        kw = {f: c[f][i] for f in _SCALAR_FIELDS}
+        for f in ("reverse", "force_voiced", "use_editor", "f0_jitter", "volume_jitter", "add_subharm"):
+            kw[f] = bool(kw[f])
+        for f in _SCALAR_FIELDS:
+            if f not in ("reverse", "force_voiced", "use_editor", "f0_jitter", "volume_jitter", "add_subharm"):
+                kw[f] = float(kw[f])
+        kw["pitch_m"] = int(kw["pitch_m"])
+        t = self.t_cents[i]
+        return Request(flags={"t": int(t)} if t else {}, bend=self.bend[self.bend_off[i]:self.bend_off[i + 1]],
+                       f_shift=tuple(float(v) for v in self.f_shift[i]), formant_strength=tuple(float(v) for v in self.formant_strength[i]),
+                       loop_mode=_LOOP_NAMES[int(self.loop_code[i])], **kw)
+
+
+def _text_blob(vals):
+    """(ascii bytes of the strings back to back, offsets[n + 1]) or None when something is not a plain ASCII string."""
+    try:
+        blob = "".join(vals).encode("ascii")
+    except (TypeError, UnicodeEncodeError):
+        return None
+    off = np.zeros(len(vals) + 1, dtype=np.int64)
+    np.cumsum(np.fromiter(map(len, vals), dtype=np.int64, count=len(vals)), out=off[1:])
+    return blob, off
+
+
+def _float_column(vals, strip_bang: bool = False):
+    """float(v) of every element (strings as the CLI / HTTP front ends hand them over, or numbers): plain decimal literals in
+    one call of the library's parser (strtod: correctly rounded, like float()), everything else — and everything when the
+    library is not built — through float() itself, which answers or raises what the reference does."""
+    n = len(vals)
+    lib = _host_lib()
+    tb = _text_blob(vals) if lib is not None and n else None
+    if tb is None:
+        return np.array([float(v.lstrip("!") if strip_bang else v) for v in vals], dtype=np.float64)
+    out = np.empty(n, dtype=np.float64)
+    ok = np.empty(n, dtype=np.uint8)
+    bad = lib.goofer_host_parse_floats(tb[0], tb[1].ctypes.data, n, int(strip_bang), out.ctypes.data, ok.ctypes.data)
+    if bad:
+        for i in np.nonzero(ok == 0)[0]:
+            out[i] = float(vals[i].lstrip("!") if strip_bang else vals[i])
+    return out
+
+
+def _bend_columns(texts):
+    """The batch's pitch strings decoded back to back: (float32 values, offsets[n + 1]).  One pass of the library's decoder
+    into a buffer sized for the usual case (two characters per value), a second only when run-length counts overflow it."""
+    n = len(texts)
+    lib = _host_lib()
+    tb = _text_blob(texts) if lib is not None and n else None
+    if tb is not None:
+        out_off = np.empty(n + 1, dtype=np.int64)
+        cap = len(tb[0]) + 64
+        vals = np.empty(cap, dtype=np.float32)
+        total = lib.goofer_host_decode_bends(tb[0], tb[1].ctypes.data, n, vals.ctypes.data, cap, out_off.ctypes.data)
+        if total > cap:
+            vals = np.empty(total, dtype=np.float32)
+            lib.goofer_host_decode_bends(tb[0], tb[1].ctypes.data, n, vals.ctypes.data, total, out_off.ctypes.data)
+        if total >= 0:
+            return vals[:total], out_off
+    bends = [pitch_string_to_cents(t) for t in texts]          # malformed / non-ASCII / no library: one by one (raises like the reference)
+    lens = np.fromiter((len(v) for v in bends), dtype=np.int64, count=n)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    return (np.concatenate([np.asarray(v, dtype=np.float32) for v in bends]) if n else np.zeros(0, np.float32)), off
+
+
+def decode_request_batch(arg_lists) -> RequestBatch:
+    """``decode_request`` for a batch of argument lists, straight to columns: the numeric strings are parsed per column, the
+    flag strings and the note names once per distinct string (``_decode_flags`` cache), the pitch strings in one library call.
+    Same values as ``RequestBatch.from_requests(decode_requests(arg_lists))`` (tested); an argument the reference would refuse
+    raises here what ``decode_request`` raises."""
+    arg_lists = [tuple(a) for a in arg_lists]
+    full = [a + _REQ_DEFAULTS[len(a) - 2:] if len(a) < 11 else a for a in arg_lists]
+    n = len(full)
+    b = RequestBatch()
+    b.n = n
+    cols = list(zip(*full)) if n else [()] * 11
+    notes_u = {}
+    note_ix = np.fromiter((notes_u.setdefault(v, len(notes_u)) for v in cols[0]), dtype=np.int64, count=n)
+    midi = np.array([note_to_midi(v) for v in notes_u], dtype=np.float64)
+    flags_u = {}
+    flag_ix = np.fromiter((flags_u.setdefault(v, len(flags_u)) for v in cols[2]), dtype=np.int64, count=n)
+    dec = [_decode_flags(v) for v in flags_u]
+    c = {}
+    c["pitch_m"] = midi[note_ix] if n else np.zeros(0)
+    c["velocity"] = _float_column(cols[1])
+    for name, k, div in (("offset", 3, 1000.0), ("length", 4, 1000.0), ("consonant", 5, 1000.0), ("cutoff", 6, 1000.0),
+                         ("volume", 7, 100.0), ("modulation", 8, 100.0)):
+        c[name] = _float_column(cols[k]) / div
+    c["tempo"] = _float_column(cols[9], strip_bang=True)
+    for f in _FLAG_SCALARS:
+        c[f] = np.array([float(d["fields"][f]) for d in dec], dtype=np.float64)[flag_ix] if n else np.zeros(0)
+    b.col = c
+    take = lambda vals, width: (np.array(vals, dtype=np.float64).reshape(len(dec), width)[flag_ix] if n else np.zeros((0, width)))
+    b.f_shift = take([d["fields"]["f_shift"] for d in dec], 4)
+    b.formant_strength = take([d["fields"]["formant_strength"] for d in dec], 4)
+    b.loop_code = (np.array([_LOOP_NAMES.index(d["fields"]["loop_mode"]) for d in dec], dtype=np.int32)[flag_ix] if n else np.zeros(0, np.int32))
+    b.t_cents = (np.array([float(d["flags"].get("t", 0) or 0) for d in dec], dtype=np.float64)[flag_ix] if n else np.zeros(0))
+    b.bend, b.bend_off = _bend_columns(cols[10])
+    return b
+
+
+# ---------------------------------------------------------------------------------------------
 # planning
 # ---------------------------------------------------------------------------------------------
 def segment_indices(r: Request, sr: int, ylen: int, hop: int = HOP) -> dict:
@@ -827,18 +969,48 @@ def plan_native(records, hop: int, trim_rows: bool, keep=None, threads: int = 0)
                         view(f_p, R * 4, np.float64).reshape(-1, 4), view(fs_p, R * 4, np.float32).reshape(-1, 4), owner=(owner, keep))
 
 
-def plan_records(reqs, srs, ylens, n_src_frames, tracks):
-    """``_lib.PLAN_REQUEST`` records of a batch: the requests' scalars as columns, ``tracks`` = per note the tuple of
-    ``source_tracks64`` (kept alive by the caller)."""
+def plan_native_into(records, hop: int, trim_rows: bool, geo_out, row_capacity: int, tap_idx, tap_w, formants, fst, keep=None, threads: int = 0):
+    """goofer_host_plan_into: the batch's plans written into the caller's arrays (pinned staging memory).  Returns the
+    PlannedBatch over those arrays; None when the library steps aside (not built, a note the reference refuses: the caller runs
+    the numpy planner); raises ``StagingFull(rows)`` when ``row_capacity`` rows do not hold the batch."""
+    import ctypes as C
     from . import _lib
-    n = len(reqs)
+    lib = _host_lib()
+    if lib is None:
+        return None
+    records = np.ascontiguousarray(records, dtype=_lib.PLAN_REQUEST)
+    n = records.shape[0]
+    taps = _gauss_taps_cached(4.0)
+    rows = C.c_int64(0)
+    rc = lib.goofer_host_plan_into(records.ctypes.data, n, int(hop), int(bool(trim_rows)), taps.ctypes.data, (taps.size - 1) // 2,
+                                   int(threads), geo_out.ctypes.data, int(row_capacity), tap_idx.ctypes.data, tap_w.ctypes.data,
+                                   formants.ctypes.data, fst.ctypes.data, C.byref(rows))
+    if rc == 1:
+        raise StagingFull(int(rows.value))
+    if rc != 0 or (n and (geo_out["status"] != 0).any()):
+        return None
+    R = int(rows.value)
+    return PlannedBatch(geo_out, tap_idx[:R], tap_w[:R], formants[:R], fst[:R], owner=keep)
+
+
+class StagingFull(Exception):
+    """The staging block handed to the planner is too small: args[0] = rows (or bytes) needed."""
+
+
+def plan_records(reqs, srs, ylens, n_src_frames, tracks):
+    """``_lib.PLAN_REQUEST`` records of a batch: the requests' scalars as columns (``reqs``: a RequestBatch or a list of
+    Requests), ``tracks`` = per note the tuple of ``source_tracks64`` (kept alive by the caller)."""
+    from . import _lib
+    rb = reqs if isinstance(reqs, RequestBatch) else RequestBatch.from_requests(reqs)
+    n = rb.n
+    c = rb.col
     rec = np.zeros(n, dtype=_lib.PLAN_REQUEST)
-    cols = np.array([(r.offset, r.length, r.consonant, r.cutoff, r.fry, r.fry_glide, float(bool(r.reverse))) for r in reqs],
-                    dtype=np.float64).reshape(n, 7)
-    rec["offset"], rec["length"], rec["consonant"], rec["cutoff"] = cols[:, 0], cols[:, 1], cols[:, 2], cols[:, 3]
-    rec["fry"], rec["fry_glide"], rec["reverse"] = cols[:, 4], cols[:, 5], cols[:, 6]
-    rec["vel_factor"] = [float(2.0 ** (1.0 - (r.velocity / 100.0))) for r in reqs]     # Python's pow, like the reference (:765)
-    rec["loop_mode"] = [_LOOP_CODE[r.loop_mode] for r in reqs]
+    rec["offset"], rec["length"], rec["consonant"], rec["cutoff"] = c["offset"], c["length"], c["consonant"], c["cutoff"]
+    rec["fry"], rec["fry_glide"], rec["reverse"] = c["fry"], c["fry_glide"], c["reverse"]
+    # Python's pow, like the reference (:765) — once per distinct velocity
+    vel, inv = np.unique(c["velocity"], return_inverse=True)
+    rec["vel_factor"] = np.array([float(2.0 ** (1.0 - (float(v) / 100.0))) for v in vel], dtype=np.float64)[inv] if n else 0.0
+    rec["loop_mode"] = rb.loop_code
     rec["sr"], rec["ylen"], rec["n_src_frames"] = srs, ylens, n_src_frames
     rec["tracks"] = [t.ptrs for t in tracks]
     rec["track_len"] = [t.lens for t in tracks]

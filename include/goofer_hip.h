@@ -349,6 +349,13 @@ typedef struct goofer_host_plans goofer_host_plans;
  * n_threads <= 0: up to eight host threads.  The result is freed with goofer_host_plans_free. */
 int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps,
                            int gauss_radius, int n_threads, goofer_host_plans **out);
+/* The same plans written into memory of the caller — pinned staging buffers one H2D copy ships, re-used from batch to batch.
+ * geometry[n_notes]; the four row arrays hold row_capacity rows x 4 (layout as goofer_host_plans_view); *rows_out = rows of the
+ * batch.  Returns 0 with the arrays filled, 1 when row_capacity is too small (geometry and *rows_out are written: grow, call
+ * again), or a negative error code as goofer_host_plan_notes. */
+int goofer_host_plan_into(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps,
+                          int gauss_radius, int n_threads, goofer_plan_geometry *geometry, int64_t row_capacity, int32_t *tap_idx,
+                          double *tap_w, double *formants, float *fst_tracks, int64_t *rows_out);
 /* The planned batch: geometry[n_notes]; rows = sum of n_out_rows over the notes with status 0; tap_idx / tap_w [rows x 4]
  * (goofer_assembly.tap_idx / tap_w), formants [rows x 4] fp64 (goofer_batch.formants), fst_tracks [rows x 4] fp32
  * (goofer_assembly.fst_tracks).  HOST memory owned by the handle.  Any out pointer may be NULL. */
@@ -360,6 +367,11 @@ void goofer_host_plans_free(goofer_host_plans *plans);
  * Writes out_off[n + 1] and, when out != NULL, the decoded cents (at most `capacity` values); returns the number of values,
  * or -(i + 1) when string i is not well formed (the caller's character loop then raises what the reference raises). */
 int64_t goofer_host_decode_bends(const char *text, const int64_t *text_off, int n, float *out, int64_t capacity, int64_t *out_off);
+
+/* float() of n plain decimal strings back to back (the numeric resampler arguments of a batch, SillySampler.py:289-298):
+ * out[i] / ok[i] = 1 for [+-]digits[.digits][e[+-]digits]; ok[i] = 0 for anything else (the caller asks Python's float()).
+ * strip_bang: skip leading '!' (the tempo argument).  Returns how many strings were not taken, or -1 on a null argument. */
+int goofer_host_parse_floats(const char *text, const int64_t *text_off, int n, int strip_bang, double *out, unsigned char *ok);
 
 /* Synchronise the device and report errors the asynchronous batch calls detect on the device (today: a note with more
  * pulse onsets than its n / 2 + 16 onset slots, GOOFER.py:493 with f0 above sr / 2).  0, or GOOFER_EINVAL + goofer_last_error. */

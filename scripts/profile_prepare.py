@@ -29,10 +29,9 @@ srcs = [Source.from_pack(s["env_pack"], s["f0"], s["mask"], s["formants"], s["sr
 
 def once():
     t0 = time.perf_counter()
-    reqs = S.decode_requests(args)
+    reqs = S.decode_request_batch(args)
     t1 = time.perf_counter()
-    jobs = list(zip(srcs, reqs))
-    prep = ren.prepare(jobs, note_ids=list(range(notes)))
+    prep = ren.prepare((srcs, reqs), note_ids=list(range(notes)))
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     return 1e3 * (t1 - t0), 1e3 * (t2 - t1), prep

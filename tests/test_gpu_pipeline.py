@@ -1,0 +1,84 @@
+"""GPU: the batch pipeline of long jobs (goofer_amd.render.PipelinedRenderer: two batches in flight on two handles, host
+planning on worker threads, the mix downloaded under the next step) against the one-batch-at-a-time Renderer, bit for bit;
+and the columnar request path (sampler.decode_request_batch -> Renderer.prepare) against the per-note Request objects."""
+import numpy as np
+import pytest
+
+from goofer_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _batches(config, sizes, first=0):
+    from goofer_amd.render import Source
+    out, i = [], first
+    for n in sizes:
+        srcs, args = [], []
+        for _ in range(n):
+            src, req, _ = syn.config_note(config, i)
+            srcs.append(Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]))
+            args.append(syn.request_args(req))
+            i += 1
+        out.append((srcs, args))
+    return out
+
+
+@pytest.mark.parametrize("config,sizes", [(3, [40, 7, 64, 1, 33, 20]), (4, [50, 50, 50])])
+def test_pipelined_batches_equal_single_batches(config, sizes):
+    from goofer_amd import sampler as S
+    from goofer_amd.device import Context
+    from goofer_amd.render import PipelinedRenderer, Renderer
+    geo = syn.config_geometry(config)
+    batches = _batches(config, sizes)
+    ctx = Context(0)
+    try:
+        r = Renderer(ctx, hop=geo["hop"])
+        want = []
+        for srcs, args in batches:
+            reqs = S.decode_requests(args)
+            want.append(r.render(list(zip(srcs, reqs)), seed=11))
+    finally:
+        ctx.close()
+    for depth, workers in ((2, 2), (1, 1), (3, 1)):
+        p = PipelinedRenderer(0, hop=geo["hop"], depth=depth, workers=workers)
+        try:
+            got = p.render_all(batches, seed=11)
+        finally:
+            p.close()
+        assert len(got) == len(want)
+        for b, (g, w) in enumerate(zip(got, want)):
+            assert len(g) == len(w)
+            for i, (a, c) in enumerate(zip(g, w)):
+                assert np.array_equal(a, c), (depth, b, i)
+
+
+def test_prepare_from_columns_equals_prepare_from_requests():
+    """(sources, RequestBatch) — the argument strings decoded straight to columns — against the list of (Source, Request)
+    pairs: the same plans, the same render, for the whole flag vocabulary."""
+    from goofer_amd import sampler as S
+    from goofer_amd.device import Context
+    from goofer_amd.render import Renderer, Source
+    rng = np.random.default_rng(77)
+    srcs, args = [], []
+    for i in range(48):
+        src, req, _ = syn.config_note(3, i)
+        srcs.append(Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]))
+        flags = syn.random_flags(rng)
+        for bad in ("sh", "sr", "sj"):                          # the legacy-RNG / fresh-generator draws differ from call to call
+            flags = __import__("re").sub(bad + r"-?\d+", "", flags)
+        args.append(syn.request_args(syn.make_request(3000 + i, flags, length_ms=int(rng.integers(80, 1500)))))
+    ctx = Context(0)
+    try:
+        r = Renderer(ctx)
+        a = r.render(list(zip(srcs, S.decode_requests(args))), seed=5)
+        prep = r.prepare((srcs, S.decode_request_batch(args)))
+        out = r.run(prep, seed=5)
+        ctx.check()
+        mix = out["mix"].cpu().numpy()
+        off = prep["sample_off"]
+        for i in range(len(srcs)):
+            assert np.array_equal(mix[off[i]:off[i + 1]], a[i]), i
+    finally:
+        ctx.close()

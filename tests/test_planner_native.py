@@ -185,3 +185,56 @@ def test_native_planner_steps_aside_for_times_it_cannot_hold():
         taps = np.ascontiguousarray(S._gauss_taps_cached(4.0))
         rc = S._host_lib().goofer_host_plan_notes(bad.ctypes.data, bad.shape[0], 256, 1, taps.ctypes.data, (taps.size - 1) // 2, 3, C.byref(h))
         assert rc == -1 and not h.value                       # GOOFER_EINVAL, no handle left behind
+
+
+def test_request_columns_equal_request_objects():
+    """sampler.decode_request_batch (argument strings -> columns: numeric strings through the library's strtod parser, flag
+    strings and note names once per distinct string, pitch strings in one decoder call) against the per-note decode_request."""
+    from goofer_amd import synthetic as syn
+    rng = np.random.default_rng(1)
+    args = [syn.request_args(syn.config_note(c, i)[1]) for c in (3, 4, 5) for i in range(60)]
+    for i in range(200):
+        args.append(syn.request_args(syn.make_request(2000 + i, syn.random_flags(rng), length_ms=int(rng.integers(50, 2000)))))
+    # literals the strict native parser hands back to float(): spaces, underscores, exponents, signs, several '!'
+    args.append(("C4", " 100 ", "g10", "1_0", "1e3", "5.5", "-3", "+100", "0", "!!120.5", "AA#3#"))
+    args.append(("A#3", "80"))                                  # defaults
+    args.append(("F#2", "1e2", "", ".5", "5.", "-0", "0.0", "1E2", "00", "!060", "AA"))
+    A = S.RequestBatch.from_requests(S.decode_requests(args))
+    B = S.decode_request_batch(args)
+    for f in S._SCALAR_FIELDS:
+        assert np.array_equal(A.col[f], B.col[f]), f
+    for f in ("f_shift", "formant_strength", "loop_code", "t_cents", "bend", "bend_off"):
+        a, b = getattr(A, f), getattr(B, f)
+        assert a.dtype == b.dtype and np.array_equal(a, b), f
+    one = S.decode_request(*args[7])
+    back = B.request(7)
+    for f in S._SCALAR_FIELDS:
+        assert getattr(one, f) == getattr(back, f), f
+    assert np.array_equal(one.bend, back.bend) and one.f_shift == back.f_shift and one.loop_mode == back.loop_mode
+    for bad in (("C4", "abc"), ("H9", "100"), ("C4", "100", "g"), ("C4", "100", "", "nope")):
+        with pytest.raises((ValueError, TypeError)):
+            S.decode_request(*bad)
+        with pytest.raises((ValueError, TypeError)):
+            S.decode_request_batch([("A#3", "80"), bad])
+    assert len(S.decode_request_batch([])) == 0
+
+
+def test_plans_written_into_the_callers_arrays():
+    """goofer_host_plan_into (the planner writing into pinned staging memory of the caller) = goofer_host_plan_notes; a
+    capacity that is too small is reported with the row count, nothing half-written is handed out."""
+    from goofer_amd import _lib
+    jobs = _plannable(_random_jobs(21, 200), 256)
+    tracks = [S.source_tracks64(j[4]) for j in jobs]
+    rec = S.plan_records([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], [j[3] for j in jobs], tracks)
+    ref = S.plan_native(rec, 256, True, keep=(tracks, rec))
+    rows = ref.tap_idx.shape[0]
+    cap = rows + 100
+    geo = np.zeros(len(jobs), dtype=_lib.PLAN_GEOMETRY)
+    ti, tw = np.full((cap, 4), -7, np.int32), np.zeros((cap, 4))
+    fo, fs = np.zeros((cap, 4)), np.zeros((cap, 4), np.float32)
+    got = S.plan_native_into(rec, 256, True, geo, cap, ti, tw, fo, fs, keep=(tracks, rec))
+    _same(ref, got)
+    assert (ti[rows:] == -7).all()
+    with pytest.raises(S.StagingFull) as e:
+        S.plan_native_into(rec, 256, True, geo, rows - 1, ti, tw, fo, fs, keep=(tracks, rec))
+    assert e.value.args[0] == rows
