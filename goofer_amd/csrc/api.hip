@@ -811,7 +811,6 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     }
     if (!strcmp(name, "nt_mask")) { ctx->nt_mask = value; return GOOFER_OK; }
     if (!strcmp(name, "nt_spectra")) { ctx->nt_spectra = value != 0; return GOOFER_OK; }
-    if (!strcmp(name, "stem_pairs")) { ctx->stem_pairs = value; return GOOFER_OK; }
     if (!strcmp(name, "stem_lds_kb")) { ctx->stem_lds_kb = value < 0 ? 0 : (value > 160 ? 160 : value); return GOOFER_OK; }
     if (!strcmp(name, "pulse_scan")) { ctx->pulse_scan = value < 0 ? 0 : (value > 2 ? 2 : value); return GOOFER_OK; }
     if (!strcmp(name, "walk_npw")) { ctx->walk_npw = (value == 1 || value == 2 || value == 4) ? value : 0; return GOOFER_OK; }

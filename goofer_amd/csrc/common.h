@@ -89,7 +89,6 @@ struct goofer_ctx {
     int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
     int nt_mask = 1;              // non-temporal stores: 1 note_finish mix / rec (the final output: -0.7 % per step), 2 env_loop rows (measured: nothing)
     int nt_spectra = 1;           // framewise rFFT: spectrum rows leave as non-temporal stores (option "nt_spectra")
-    int stem_pairs = 0;           // noise walker as producer / consumer pairs of waves (k_noise_pairs; option "stem_pairs")
     int stem_lds_kb = 0;          // stem walkers: LDS to reserve per workgroup beyond what they use (tuning: 100 -> one workgroup per CU)
     int walk_npw = 0;             // notes per wave of the phase walk: 1, 2, 4; 0 = by batch size
     int pulse_scan = 1;           // 1: onsets from the parallel phase scan, the sequential walk only for the notes it cannot settle;

@@ -662,390 +662,6 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
 }
 
 // ---------------------------------------------------------------------------------------------
-// The noise walker as PAIRS of waves (option "stem_pairs").  k_noise_stems runs at two waves per SIMD (244 VGPRs: the
-// blur window, two spectra and the transform's butterflies live beside two overlap-add rings) and is bound by the latency
-// of its own dependency chain — one workgroup per CU is 1.57x slower than two, nothing on the chip is near saturation.
-// Here the frame work is split between two waves that hand the random-phase spectrum U * env_noise over through LDS:
-//   producer  row fetch, sigma-1.75 blur, Philox, sin / cos, U * env_noise -> slot[(frame) & 1]          (no rings, no transform)
-//   consumer  flatness checks, high-pass / brightness (the breath spectrum from the slot's), both inverse transforms,
-//             overlap-add rings, mask gains, stores                                      (no blur window, no Philox state)
-// The slots are double buffered: the producer fills frame i + 1 while the consumer transforms frame i, one workgroup barrier
-// per frame.  Each role fits 168 registers, so three waves share a SIMD, and a CU holds six pairs = twelve frame stages in
-// flight instead of eight.  Same operations on the same values in the same order as k_noise_stems: bit-identical (tested).
-// Every wave of the grid executes the same number of barriers (run + halo + 1 iterations, idle ones included).
-template <int M> struct pair_cfg {
-    using C = stem_cfg<M>;
-    static constexpr int SLOT = (C::B + 7) & ~7;                                   // float2 per spectrum slot
-    static constexpr int ROWP = 544;                                               // floats of the producer's row staging (8 + 512 + 24)
-    static constexpr size_t pair_bytes = sizeof(float2) * (2 * SLOT + fft_cfg<M>::BUF) + sizeof(float) * ROWP + sizeof(double) * C::KN;
-    static constexpr int PAIRS = 2;                                                // per workgroup of 256 threads
-    static constexpr size_t lds_bytes() { return C::template table_bytes<2, false>() + PAIRS * pair_bytes; }
-    static_assert(pair_bytes % 16 == 0, "16-byte aligned LDS carving");
-};
-
-template <int M, bool PHI>
-__global__ __launch_bounds__(256, 2) void k_noise_pairs(const noise_args A)
-{
-    using C = stem_cfg<M>;
-    using P = pair_cfg<M>;
-    constexpr int R = C::R, G = C::G, HOP = C::HOP, B = C::B, PER = C::PER, KN = C::KN, KPL = C::KPL, ROWF = C::ROWF;
-    static_assert(R == 8, "the row staging below moves two 16-byte pieces per lane");
-    extern __shared__ __align__(16) unsigned char smem[];
-    walker<M, 2, false> w;
-    w.init(smem, NCOLD(g_tw), NCOLD(g_twh), NCOLD(g_win), NCOLD(g_winb), NCOLD(freqs), NCOLD(bright), nullptr);
-    const int lane = w.lane;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = wave >> 1;
-    const bool producer = (wave & 1) == 0;
-    unsigned char *per = smem + C::template table_bytes<2, false>() + (size_t)pair * P::pair_bytes;
-    float2 *slot = reinterpret_cast<float2 *>(per);                               // [2][SLOT]
-    w.buf = slot + 2 * P::SLOT;                                                    // the consumer's transform buffer
-    float *rp = reinterpret_cast<float *>(w.buf + fft_cfg<M>::BUF);                // the producer's row staging
-    w.kbuf = reinterpret_cast<double *>(rp + P::ROWP);
-    const float *t_fq = w.tab, *t_br = w.tab + ROWF;
-    const int ld = A.ld, mode = A.mode, run = A.run;
-    // the pair's run of frames; a pair behind the last run idles through the barriers
-    int64_t fs = 0, f0 = 0, f1 = 0;
-    {
-        const int64_t total_frames = NCOLD(total_frames);
-        f0 = ((int64_t)blockIdx.x * P::PAIRS + pair) * run;
-        if (f0 < total_frames) {
-            f1 = f0 + run < total_frames ? f0 + run : total_frames;
-            const int *frame_note = NCOLD(frame_note);
-            const int64_t t0 = f0 - NCOLD(frame_off)[frame_note[f0]];
-            constexpr int halo = C::NF / HOP - 1;
-            fs = f0 - (t0 < halo ? t0 : halo);
-        } else {
-            f0 = f1 = fs = 0;
-        }
-    }
-    const int iters = run + (C::NF / HOP - 1) + 1;                                 // the same for every wave of the grid
-    frame_block fb;
-    auto load_block = [&](int64_t first) {
-        fb.load(first, NCOLD(total_frames), NCOLD(frame_note), NCOLD(frame_off), NCOLD(sample_off), NCOLD(row_src), NCOLD(picks), lane);
-        if constexpr (!PHI)
-            if (producer) fb.load_nyquist(NCOLD(params), NCOLD(seed), M);
-    };
-    if (fs < f1) load_block(fs);
-
-    if (producer) {
-        // ---- producer: U * env_noise of frame fs + it into slot[it & 1] ----------------------------------------------
-        const float *__restrict__ env = A.env;
-        const float *__restrict__ phi = A.phi;
-        constexpr float t175[15] = STEM_T175;
-        float4 ea = make_float4(0.f, 0.f, 0.f, 0.f), eb4 = ea;
-        float e_ny = 0.f;
-        auto fetch = [&](int src) {
-            const float *er = env + (int64_t)src * ld;
-            ea = *reinterpret_cast<const float4 *>(er + 8 * lane);
-            eb4 = *reinterpret_cast<const float4 *>(er + 8 * lane + 4);
-            e_ny = er[B - 1];
-        };
-        if (fs < f1) fetch(FB_GET(fb, src, 0));
-        int note = -1;
-        uint64_t key = 0;
-        for (int it = 0; it < iters; ++it) {
-            const int64_t f = fs + it;
-            if (f < f1) {
-                const int idx = (int)(f - fb.blk0);
-                const int t = FB_GET(fb, t, idx);
-                if (FB_GET(fb, note, idx) != note) {
-                    note = FB_GET(fb, note, idx);
-                    const goofer_note_params &p = NCOLD(params)[note];
-                    key = NCOLD(seed) ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
-                }
-                const uint32_t ny_u = PHI ? 0u : (uint32_t)FB_GET(fb, ny_u, idx);
-                // 1. noise envelope: sigma-1.75 blur of the un-warped row (GOOFER.py:993), as in k_noise_stems
-                float en[PER];
-                {
-                    float o9[9];
-                    if (mode & 1) {
-                        *reinterpret_cast<float4 *>(rp + 8 + 8 * lane) = ea;
-                        *reinterpret_cast<float4 *>(rp + 8 + 8 * lane + 4) = eb4;
-                        wave_lds_sync();
-                        float x[24];
-                        {
-                            const float4 l0 = *reinterpret_cast<const float4 *>(rp + 8 * lane), l1 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 4);
-                            const float4 r0 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 16), r1 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 20);
-                            x[0] = l0.x; x[1] = l0.y; x[2] = l0.z; x[3] = l0.w; x[4] = l1.x; x[5] = l1.y; x[6] = l1.z; x[7] = l1.w;
-                            x[16] = r0.x; x[17] = r0.y; x[18] = r0.z; x[19] = r0.w; x[20] = r1.x; x[21] = r1.y; x[22] = r1.z; x[23] = r1.w;
-                        }
-                        const float ec[8] = {ea.x, ea.y, ea.z, ea.w, eb4.x, eb4.y, eb4.z, eb4.w};
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) x[8 + j] = ec[j];
-#pragma unroll
-                        for (int j = 1; j < 8; ++j) {
-                            x[8 - j] = lane == 0 ? ec[j] : x[8 - j];
-                            x[16 + j] = lane == 63 ? ec[8 - j] : x[16 + j];
-                        }
-                        x[16] = lane == 63 ? e_ny : x[16];
-#pragma unroll
-                        for (int j = 0; j < 9; ++j) {
-                            float acc = t175[0] * x[j + 1];
-#pragma unroll
-                            for (int q = 1; q < 15; ++q) acc = fmaf(t175[q], x[j + 1 + q], acc);
-                            o9[j] = acc;
-                        }
-                        wave_lds_sync();
-                    } else {
-                        o9[0] = ea.x; o9[1] = ea.y; o9[2] = ea.z; o9[3] = ea.w; o9[4] = eb4.x; o9[5] = eb4.y; o9[6] = eb4.z; o9[7] = eb4.w;
-                        o9[8] = e_ny;
-                    }
-                    *reinterpret_cast<float4 *>(rp + 8 * lane) = make_float4(o9[0], o9[1], o9[2], o9[3]);
-                    *reinterpret_cast<float4 *>(rp + 8 * lane + 4) = make_float4(o9[4], o9[5], o9[6], o9[7]);
-                    if (lane == 63) rp[B - 1] = o9[8];
-                    wave_lds_sync();
-#pragma unroll
-                    for (int i = 0; i < PER; ++i) en[i] = rp[lane + WAVE * i < B ? lane + WAVE * i : B - 1];
-                    wave_lds_sync();
-                }
-                if (f + 1 < f1) {                                 // the row registers are consumed: start the next frame's row
-                    if (!fb.holds(f + 1)) load_block(f + 1);
-                    fetch(FB_GET(fb, src, (int)(f + 1 - fb.blk0)));
-                }
-                // 2. U * env_n (GOOFER.py:1148-1157) -> the slot, in the transform's layout (bin k = lane + 64 i)
-                float2 *sl = slot + (it & 1) * P::SLOT;
-                uint4 rnd = make_uint4(0, 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < PER; ++i) {
-                    const int k = lane + WAVE * i;
-                    if (k >= B) continue;
-                    float c, sn;
-                    if constexpr (PHI) {
-                        const float ph = phi[f * (int64_t)ld + k];
-                        c = cosf(ph);
-                        sn = sinf(ph);
-                    } else {
-                        if (i == 0) rnd = philox_4x32(key, (uint64_t)t, (uint32_t)lane);
-                        const uint32_t u = i == R ? ny_u : philox_half(rnd, i);
-                        const float rev = (float)u * (1.0f / 65536.0f);
-                        c = __builtin_amdgcn_cosf(rev);
-                        sn = __builtin_amdgcn_sinf(rev);
-                    }
-                    sl[k] = make_float2(c * en[i], sn * en[i]);
-                }
-            }
-            __syncthreads();
-        }
-        return;
-    }
-
-    // ---- consumer: frame fs + it - 1 from slot[(it - 1) & 1] --------------------------------------------------------------
-    float *__restrict__ uv = A.uv, *__restrict__ bre = A.bre;
-    constexpr float t5[5] = STEM_T5;
-    const float fq64 = w.tab[WAVE];
-    float ec[4];
-    {
-        const float *g_edge = NCOLD(g_edge);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ec[q] = g_edge[q * WAVE + lane];
-    }
-    float2 carry_u[R - G], carry_b[R - G];
-#pragma unroll
-    for (int r = 0; r < R - G; ++r) carry_u[r] = carry_b[r] = make_float2(0.f, 0.f);
-    int ns = 0;
-    float g_b = 0.f, g_u = 0.f, kps = 0.f;
-    double step_n = 0.0, step_s = 0.0;
-    const double *ss = nullptr;
-    int apply_bright = 0;
-    double kn_r[KPL];
-    int kn_lo = 0;
-    auto knots_fetch = [&](int h) {
-        int i0 = h * HOP - M;
-        i0 = i0 < 0 ? 0 : i0;
-        int lo = (int)((float)i0 * kps) - 4;
-        lo = lo < 0 ? 0 : lo;
-#pragma unroll
-        for (int c = 0; c < KPL; ++c) {
-            const int e = lane + WAVE * c;
-            const int k = lo + e < ns - 1 ? lo + e : ns - 1;
-            kn_r[c] = (e < KN && ns > 0) ? ss[k] : 0.0;
-        }
-        kn_lo = lo;
-    };
-    unsigned one_bits = 0, zero_bits = 0;
-    double hk[2] = {0.0, 0.0}, hk_c = 0.0;
-    int hk_lo = 0, hk_hi = -1;
-    bool hk_none = false;
-    auto hop_check_issue = [&](int h) {
-        int i_lo = (h - 2) * HOP, i_hi = (h - 1) * HOP - 1;
-        hk_none = i_hi < 0 || i_lo >= w.n || ns <= 0;
-        i_lo = i_lo < 0 ? 0 : i_lo;
-        i_hi = i_hi > w.n - 1 ? w.n - 1 : i_hi;
-        int lo = (int)((float)i_lo * kps) - 4, hi = (int)((float)i_hi * kps) + 6;
-        lo = lo < 0 ? 0 : lo;
-        hi = hi > ns - 1 ? ns - 1 : hi;
-        hk_lo = lo;
-        hk_hi = hk_none ? lo - 1 : hi;
-        if (!hk_none) {
-            hk_c = ss[lo];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int k = lo + lane + WAVE * c;
-                hk[c] = ss[k <= hi ? k : hi];
-            }
-        }
-    };
-    auto hop_check_done = [&]() {
-        bool one = !(mode & 2), zero = one;
-        if (!hk_none) {
-            const bool same = hk[0] == hk_c && hk[1] == hk_c && hk_hi - hk_lo < 2 * WAVE;
-            const bool flat = __all(same);
-            const float cf = (float)hk_c;
-            one = one && flat && (1.0f - cf) == 0.0f;
-            zero = zero && flat && cf == 0.0f;
-        }
-        one_bits = (one_bits >> 1) | (one ? 8u : 0u);
-        zero_bits = (zero_bits >> 1) | (zero ? 8u : 0u);
-    };
-
-    for (int it = 0; it < iters; ++it) {
-        const int64_t f = fs + it - 1;
-        if (it >= 1 && f < f1) {
-            if (!fb.holds(f)) load_block(f);
-            const float2 *sl = slot + ((it - 1) & 1) * P::SLOT;
-            const int idx = (int)(f - fb.blk0);
-            const int t = FB_GET(fb, t, idx);
-            if (FB_GET(fb, note, idx) != w.note) {
-                one_bits = zero_bits = 0;
-                w.enter_note(fb, idx);
-                const int nt = w.note;
-                const goofer_note_params &p = NCOLD(params)[nt];
-                ns = (w.n + MASK_DS - 1) / MASK_DS;
-                g_b = p.breath_strength;
-                g_u = p.uv_strength;
-                const double *steps = NCOLD(steps);
-                step_n = steps[2 * nt];
-                step_s = steps[2 * nt + 1];
-                kps = w.n > 1 ? (float)(ns - 1) / (float)(w.n - 1) : 0.f;
-                ss = A.short_s + (w.base / MASK_DS + nt);
-                apply_bright = p.apply_brightness;
-            }
-            const float f0f = FB_GETF(fb, f0, idx);
-            const bool voiced = apply_bright && FB_GETF(fb, mk, idx) > 0.f;
-            const bool flat_t = (((one_bits | zero_bits) >> 1) & 1u) != 0;
-            if (f >= f0 && !flat_t) knots_fetch(t);
-            hop_check_issue(t + 3);
-            const bool hp_low_only = fq64 - f0f > 100.0f;
-            const bool td_blur = (mode & 4) != 0;
-            hop_check_done();
-
-            // breath spectrum from the slot's U * env_n: * HP (* brightness) (GOOFER.py:1155-1173), then its transform
-            float2 ob[G], ou[G];
-            if (zero_bits == 15u) {
-                w.skip_ola(t, carry_b, ob);
-            } else {
-                float2 sb[PER];
-#pragma unroll
-                for (int i = 0; i < PER; ++i) {
-                    const int k = lane + WAVE * i;
-                    sb[i] = make_float2(0.f, 0.f);
-                    if (k >= B) continue;
-                    const float2 su = sl[k];
-                    const float h = (i == 0 || !hp_low_only) ? hp_mask(t_fq[k], f0f) : 1.0f;
-                    sb[i] = make_float2(su.x * h, su.y * h);
-                    if (voiced) {
-                        const float b = t_br[k];
-                        sb[i].x *= b; sb[i].y *= b;
-                    }
-                }
-                if (voiced && !td_blur) {
-#pragma unroll
-                    for (int i = 0; i < PER; ++i) {
-                        const int k = lane + WAVE * i;
-                        if (k < B) w.buf[k] = sb[i];
-                    }
-                    wave_lds_sync();
-#pragma unroll
-                    for (int i = 0; i < PER; ++i) {
-                        const int k = lane + WAVE * i;
-                        if (k < B) sb[i] = blur5f(w.buf, k, B, t5);
-                    }
-                    wave_lds_sync();
-                }
-                if (voiced && td_blur) w.blur_edges(sb, ec, t5[0], t5[1]);
-                w.inverse_ola(sb, t, carry_b, ob, (voiced && td_blur) ? w.wsv : w.wsc);
-            }
-            if (one_bits == 15u) {
-                w.skip_ola(t, carry_u, ou);
-            } else {
-                float2 su[PER];
-#pragma unroll
-                for (int i = 0; i < PER; ++i) {
-                    const int k = lane + WAVE * i;
-                    su[i] = k < B ? sl[k] : make_float2(0.f, 0.f);
-                }
-                w.inverse_ola(su, t, carry_u, ou, w.wsc);
-            }
-
-            if (f >= f0) {
-                // hop t -> window-sum quotient -> mask upsample -> stem gains -> out: as k_noise_stems
-                for (int h = t;;) {
-                    const int sh = h - t;
-                    const bool flat1 = sh < 4 && ((one_bits >> sh) & 1u), flat0 = sh < 4 && ((zero_bits >> sh) & 1u);
-                    const bool flat = flat1 || flat0;
-                    const float ms_flat = flat1 ? 1.0f : 0.0f;
-                    if (!flat) {
-#pragma unroll
-                        for (int c = 0; c < KPL; ++c) {
-                            const int e = lane + WAVE * c;
-                            if (e < KN) w.kbuf[e] = kn_r[c];
-                        }
-                        wave_lds_sync();
-                    }
-                    const int p0 = h * HOP - M;
-                    const int e_hi = KN - 1, lo = kn_lo;
-                    auto knot = [&](int k) {
-                        const int e = k - lo;
-                        return w.kbuf[e < e_hi ? e : e_hi];
-                    };
-                    const bool inner = w.interior(h);
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        const int i0 = p0 + 2 * (lane + WAVE * g);
-                        if (i0 < 0 || i0 >= w.n) continue;
-                        float xu[2] = {ou[g].x, ou[g].y}, xb[2] = {ob[g].x, ob[g].y};
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            const int i = i0 + c;
-                            if (i < w.out_len) {
-                                if (inner) {
-                                    const float ws = w.ws_c[g][c], rw = w.rws_c[g][c];
-                                    if (ws > 1e-9f) { xu[c] = div_by(xu[c], ws, rw); xb[c] = div_by(xb[c], ws, rw); }
-                                } else {
-                                    const float ws = w.partial_ws(h, g, c, NCOLD(g_win));
-                                    if (ws > 1e-9f) { xu[c] /= ws; xb[c] /= ws; }
-                                }
-                            } else {
-                                xu[c] = 0.f;
-                                xb[c] = 0.f;
-                            }
-                            const float ms = flat ? ms_flat : smooth_mask_at32(knot, ns, i < w.n ? i : w.n - 1, w.n, step_n, step_s, kps);
-                            xb[c] = (xb[c] * ms) * g_b;
-                            xu[c] = (xu[c] * (1.0f - ms)) * g_u;
-                        }
-                        if (i0 + 1 < w.n) {
-                            *reinterpret_cast<float2_u *>(uv + w.base + i0) = make_float2(xu[0], xu[1]);
-                            *reinterpret_cast<float2_u *>(bre + w.base + i0) = make_float2(xb[0], xb[1]);
-                        } else {
-                            uv[w.base + i0] = xu[0];
-                            bre[w.base + i0] = xb[0];
-                        }
-                    }
-                    ++h;
-                    if (t != w.T - 1 || h * HOP - M >= w.n) break;
-#pragma unroll
-                    for (int g = 0; g < G; ++g) { ou[g] = carry_u[g]; ob[g] = carry_b[g]; }
-                    if (!(h - t < 4 && (((one_bits | zero_bits) >> (h - t)) & 1u))) knots_fetch(h);
-                }
-            }
-            wave_lds_sync();
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // `env` holds the harmonic envelope rows as the shaping step needs them: already warped (k_warp_bins, one row per frame)
 // or, when no note of the batch warps, the source rows addressed through row_src.
 template <int M>
@@ -1392,27 +1008,6 @@ int launch_noise_stems(goofer_ctx *ctx, const float *env, int ld, const int64_t 
     if ((ld & 3) || ((uintptr_t)env & 15)) return goofer_fail(ctx, GOOFER_EINVAL, "envelope rows must be 16-byte aligned");
     if (!stem_taps_match(p)) return goofer_fail(ctx, GOOFER_EINVAL, "the plan's blur taps differ from the walkers' literals");
     constexpr int M = 512;
-    if (ctx->stem_pairs) {
-        // pairs of waves (producer / consumer): three waves per SIMD
-        const void *fnp = phi ? (const void *)k_noise_pairs<M, true> : (const void *)k_noise_pairs<M, false>;
-        const size_t ldsp = pair_cfg<M>::lds_bytes();
-        int rcp, slots_p = 0;
-        if ((rcp = kernel_allow_max_lds(ctx, fnp))) return rcp;
-        if ((rcp = kernel_resident_waves(ctx, fnp, ldsp, &slots_p))) return rcp;
-        const int run_p = run_length(F, slots_p / 2);
-        const int64_t runs_p = (F + run_p - 1) / run_p;
-        const dim3 grid_p((unsigned)((runs_p + pair_cfg<M>::PAIRS - 1) / pair_cfg<M>::PAIRS));
-        noise_args Ap;
-        Ap.env = env; Ap.phi = phi; Ap.uv = uv; Ap.bre = bre; Ap.short_s = short_s;
-        Ap.ld = ld; Ap.mode = (preblurred ? 0 : 1) | (ctx->skip_zero ? 0 : 2) | (ctx->td_blur ? 4 : 0); Ap.run = run_p;
-        Ap.total_frames = F; Ap.seed = seed; Ap.row_src = row_src; Ap.frame_note = frame_note; Ap.frame_off = frame_off;
-        Ap.sample_off = sample_off; Ap.picks = picks; Ap.params = params; Ap.steps = steps; Ap.freqs = p.freqs; Ap.bright = p.bright_b;
-        Ap.g_tw = p.tw_full; Ap.g_twh = p.tw_half; Ap.g_win = p.window; Ap.g_winb = p.window_blur; Ap.g_edge = p.blur_edge;
-        if (phi) hipLaunchKernelGGL((k_noise_pairs<M, true>), grid_p, dim3(256), ldsp, st, Ap);
-        else hipLaunchKernelGGL((k_noise_pairs<M, false>), grid_p, dim3(256), ldsp, st, Ap);
-        LAUNCH_CHECK(ctx);
-        return GOOFER_OK;
-    }
     const void *fn = phi ? (const void *)k_noise_stems<M, true> : (const void *)k_noise_stems<M, false>;
     size_t lds = stem_cfg<M>::lds_bytes<2, false>();
     if (lds < (size_t)ctx->stem_lds_kb * 1024) lds = (size_t)ctx->stem_lds_kb * 1024;   // (tuning: fewer workgroups per CU)
