@@ -38,15 +38,17 @@ sys.path.insert(0, HERE)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured ceiling
 
 
-def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int) -> float:
+def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int, executed: float = 1.0) -> float:
     """Algorithmic HBM bytes of one launch of each stage: unique bytes that must
-    cross HBM if nothing were re-read.  F frames, N samples, B bins."""
+    cross HBM if nothing were re-read.  F frames, N samples, B bins.  ``executed``: share of the 3 F stem transforms the
+    overlap-add kernel of the spectra-in-HBM pipeline really ran (per-frame exact-zero skipping): a skipped frame's spectrum is
+    neither written nor read, and is not credited."""
     fft = (4 * hop + 8 * B) * F                      # SURVEY.md §8(d) ALG_BYTES_FFT per frame-transform
     table = {
         "rfft_frames": fft, "rfft_frames_standalone": fft, "irfft_harm": fft, "irfft_breath": fft, "irfft_unvoiced": fft,
         "ola_harm": 4 * n_fft * F + 4 * N, "ola_breath": 4 * n_fft * F + 4 * N, "ola_unvoiced": 4 * n_fft * F + 4 * N,
         "ola3_gains": 3 * 4 * n_fft * F + 12 * N,     # three windowed-frame buffers in, three stems out
-        "irfft_ola3": 3 * 8 * B * F + 12 * N,         # three spectra in, three stems out (frames stay in LDS)
+        "irfft_ola3": 3 * 8 * B * F * executed + 12 * N,   # three spectra in (the executed ones), three stems out (frames stay in LDS)
         "harm_shape": (16 * B + 4 * B) * F,          # S in+out, env in
         "noise_spectra": (16 * B + 4 * B) * F,       # two spectra out, env in (+4B when phi is injected)
         "gauss_env": 8 * B * F, "warp_env": 8 * B * F, "assemble": 12 * B * F + 12 * N,
@@ -543,16 +545,26 @@ def main():
         per["rfft_frames_standalone"] = rfft_ms
         Fb, Nb = my_frames / len(subs), my_samples / len(subs)           # frames / samples per launch (mean sub-batch)
 
+        # share of the stem transforms the overlap-add kernel executed (configs with per-frame skipping: the last sub-batch's bits)
+        executed = 1.0
+        try:
+            fsk = ctx.debug_fetch("frame_skip")
+            if fsk.size:
+                executed = 1.0 - float(((fsk & 1) != 0).sum() + ((fsk & 2) != 0).sum()) / (3.0 * fsk.size)
+        except Exception:
+            pass
+
         def roof(stage, frames=None, samples=None):
             frames = Fb if frames is None else frames
             samples = Nb if samples is None else samples
             ms = per[stage]
-            alg = stage_alg_bytes(stage, frames, samples, B, hop, n_fft)
+            alg = stage_alg_bytes(stage, frames, samples, B, hop, n_fft, executed)
             a = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             tr = pmc_traffic(stage, wl.frames) if not job else {"bytes": None, "source": None, "stale": None}
             return {"kernel": stage, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": a / HBM_PEAK_GBS, "traffic": tr["bytes"], "traffic_source": tr["source"], "stale": tr["stale"],
-                    "ms_per_launch": ms, "alg_bytes_per_launch": alg, "shared_with": shared_with.get(stage),
+                    "ms_per_launch": ms, "alg_bytes_per_launch": alg, "transforms_executed": executed if stage == "irfft_ola3" else None,
+                    "shared_with": shared_with.get(stage),
                     "valu": sq_valu_issue(stage, ms, wl.frames) if not job else None}
 
         step_ms = elapsed / args.steps * 1e3

@@ -633,7 +633,8 @@ int goofer_debug_table(goofer_ctx *ctx, int which, float *host_out, int capacity
 
 // copy intermediate `which` of the last goofer_synth_batch to host memory (tests / debugging):
 // 0 frame_note 1 row_src 2 f0_scaled 3 pulse 4 S_harm 5 S_uv 6 S_breath 7 frames(last stem) 8 env_harm
-// 9 env_noise 10 mask_short 11 note_mag 12 note_peak 13 onset_cnt 14 onset_idx (13, 14: also of the last goofer_pulse_train).
+// 9 env_noise 10 mask_short 11 note_mag 12 note_peak 13 onset_cnt 14 onset_idx (13, 14: also of the last goofer_pulse_train)
+// 15 frame_skip (the spectra-in-HBM pipeline with per-frame skipping: one byte per frame).
 // Returns the byte size.
 /* Host helper of the note planner (goofer_amd/sampler.py, SillySampler.py:264-283): Gaussian FIR along the rows of a small
  * fp64 matrix with numpy 'reflect' padding, accumulated tap by tap in ascending order (product rounded, then added: the
@@ -1372,6 +1373,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                           n * sizeof(float), n * sizeof(float), n * sizeof(int32_t)};
         for (int i = 0; i < 14; ++i) { ctx->dbg_ptr[i] = ptrs[i]; ctx->dbg_bytes[i] = bytes[i]; }
         ctx->dbg_ptr[14] = onset_idx; ctx->dbg_bytes[14] = (N / 2 + 16 * (size_t)n) * sizeof(int32_t);
+        ctx->dbg_ptr[15] = frame_skip; ctx->dbg_bytes[15] = frame_skip ? (size_t)F : 0;   // per frame: bit 0 unvoiced, bit 1 breath transform skipped
     }
 
     // mask-smoothing taps for this call's sigma; device copy cached on the handle (steady state:

@@ -558,17 +558,38 @@ __global__ __launch_bounds__(256, M <= 512 ? 2 : 1) void k_irfft_ola3(const floa
 // eight waves per CU), and leaves its stem the way the stem walkers of stems.hip do: the harmonic stem divided by the
 // window sum only (1 / max|S| is applied by k_note_finish, which also takes the peak), the noise stems with their
 // mask gains.  Same transforms, same ascending-frame accumulation: bit-identical to k_irfft_ola3 + k_apply_gain (tested).
-template <int M, int WPB>
-__global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__restrict__ S_h, const float2 *__restrict__ S_u,
-                                                    const float2 *__restrict__ S_b, int ldc, int64_t total_frames,
-                                                    const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
-                                                    const int64_t *__restrict__ sample_off, int hop, int run, int halo,
-                                                    const double *__restrict__ short_s, const double *__restrict__ steps,
-                                                    const goofer_note_params *__restrict__ params, float *__restrict__ harm,
-                                                    float *__restrict__ uv, float *__restrict__ bre, const float2 *__restrict__ g_tw,
-                                                    const float2 *__restrict__ g_twh, const float *__restrict__ g_win,
-                                                    const unsigned char *__restrict__ frame_skip)
+// Arguments needed once per note, once per 64 frames or at set-up are read from the kernarg segment where they are used
+// (cold_arg, as in the stem walkers): the frame loop holds ~60 scalars of wave state, and with 22 arguments live beside them
+// the compiler spilled 142 SGPRs (a v_writelane / v_readlane pair each) and a vector register to scratch.
+struct ola1_args {
+    // every frame
+    const float2 *S_h, *S_u, *S_b;
+    const int *frame_note;
+    int ldc, hop, run, halo;
+    // cold
+    int64_t total_frames;
+    const int64_t *frame_off, *sample_off;
+    const double *short_s, *steps;
+    const goofer_note_params *params;
+    float *harm, *uv, *bre;
+    const float2 *g_tw, *g_twh;
+    const float *g_win;
+    const unsigned char *frame_skip;
+};
+template <typename T>
+__device__ __forceinline__ T ola1_cold(size_t offset)
 {
+    const char __attribute__((address_space(4))) *ka = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return *reinterpret_cast<const T __attribute__((address_space(4))) *>(ka + offset);
+}
+#define OCOLD(field) ola1_cold<decltype(ola1_args::field)>(offsetof(ola1_args, field))
+
+template <int M, int WPB>
+__global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const ola1_args A)
+{
+    const int ldc = A.ldc, hop = A.hop, run = A.run, halo = A.halo;
+    const int *__restrict__ frame_note = A.frame_note;
     constexpr int R = fft_cfg<M>::R, NF = 2 * M, BUF = fft_cfg<M>::BUF;
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *tw = reinterpret_cast<float2 *>(smem);
@@ -577,7 +598,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
     float *win = reinterpret_cast<float *>(bufs + WPB * BUF);
     float *rings = win + NF;
     double *knots = reinterpret_cast<double *>(rings + (size_t)WPB * NF);
-    load_tables<M>(tw, twh, win, g_tw, g_twh, g_win);
+    load_tables<M>(tw, twh, win, OCOLD(g_tw), OCOLD(g_twh), OCOLD(g_win));
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2 *buf = bufs + wave * BUF;
@@ -588,8 +609,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
     // waves only idled beside the others.
     const int stem = (int)(blockIdx.x % 3);                   // workgroup-uniform
     const int64_t f0 = ((int64_t)(blockIdx.x / 3) * WPB + wave) * run;
-    if (f0 >= total_frames) return;                           // no block barrier below
-    const unsigned skip_bit = frame_skip ? (unsigned)stem : 0u;   // bit 0 (1): unvoiced stem, bit 1 (2): breath stem; harmonic: never
+    if (f0 >= OCOLD(total_frames)) return;                    // no block barrier below
+    const unsigned skip_bit = OCOLD(frame_skip) ? (unsigned)stem : 0u;   // bit 0 (1): unvoiced stem, bit 1 (2): breath stem; harmonic: never
     // the skip bits of 64 consecutive frames as one ballot (a byte load per frame would sit on the loop's critical path)
     uint64_t skip_mask = 0;
     int64_t skip_base = -(int64_t)WAVE;
@@ -598,19 +619,19 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
         if (f >= skip_base + WAVE || f < skip_base) {
             skip_base = f;
             const int64_t g = f + lane;
-            skip_mask = __ballot(g < total_frames && (frame_skip[g] & skip_bit) != 0);
+            skip_mask = __ballot(g < OCOLD(total_frames) && (OCOLD(frame_skip)[g] & skip_bit) != 0);
         }
         return ((skip_mask >> (int)(f - skip_base)) & 1ull) != 0;
     };
-    const int64_t f1 = f0 + run < total_frames ? f0 + run : total_frames;
+    const int64_t f1 = f0 + run < OCOLD(total_frames) ? f0 + run : OCOLD(total_frames);
     const float inv_m = 0.5f / (float)M;                     // 1/M of the transform and the 1/2 of the input stage (irfft_pre)
-    const float2 *S = stem == 0 ? S_h : (stem == 1 ? S_u : S_b);
-    float *out = stem == 0 ? harm : (stem == 1 ? uv : bre);
+    const float2 *S = stem == 0 ? A.S_h : (stem == 1 ? A.S_u : A.S_b);
+    float *out = stem == 0 ? OCOLD(harm) : (stem == 1 ? OCOLD(uv) : OCOLD(bre));
 
     int64_t fs = f0;
     {
         const int nt = frame_note[f0];
-        const int64_t t0 = f0 - frame_off[nt];
+        const int64_t t0 = f0 - OCOLD(frame_off)[nt];
         fs = f0 - (t0 < halo ? t0 : halo);
     }
     // spectrum row of the next frame, fetched during the transform: bins lane + 64 r and the Nyquist bin; the mirrored bins
@@ -713,17 +734,20 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_irfft_ola1(const float2 *__rest
         const int nt = frame_note[f];
         if (nt != note) {
             note = nt;
+            const int64_t *sample_off = OCOLD(sample_off), *frame_off = OCOLD(frame_off);
             base = sample_off[note];
             n = (int)(sample_off[note + 1] - base);
             fbase = frame_off[note];
             T = (int)(frame_off[note + 1] - fbase);
             ns = (n + MASK_DS - 1) / MASK_DS;
             out_len = hop * (T - 1);
+            const goofer_note_params *params = OCOLD(params);
+            const double *steps = OCOLD(steps);
             gain = stem == 1 ? params[note].uv_strength : params[note].breath_strength;
             step_n = steps[2 * note];
             step_s = steps[2 * note + 1];
             kps = n > 1 ? (float)(ns - 1) / (float)(n - 1) : 0.f;
-            ss = short_s + short_base(sample_off, note);
+            ss = OCOLD(short_s) + short_base(sample_off, note);
         }
         const int t = (int)(f - fbase);
         const int shift = (t * hop) & (NF - 1);
@@ -827,9 +851,12 @@ static int irfft_ola1_impl(goofer_ctx *ctx, const float2 *S_h, const float2 *S_u
     int64_t fit = (3 * total_frames + rounds * slots - 1) / (rounds * slots);
     const int run = (int)(fit > min_run ? fit : min_run);
     const int64_t runs = (total_frames + run - 1) / run;
-    hipLaunchKernelGGL((k_irfft_ola1<M, WPB>), dim3((unsigned)(3 * ((runs + WPB - 1) / WPB))), dim3(64 * WPB), lds, st, S_h, S_u, S_b, ldc,
-                       total_frames, frame_note, frame_off, sample_off, p.hop, run, halo, short_s, steps, params, harm, uv, bre,
-                       p.tw_full, p.tw_half, p.window, frame_skip);
+    ola1_args A;
+    A.S_h = S_h; A.S_u = S_u; A.S_b = S_b; A.frame_note = frame_note; A.ldc = ldc; A.hop = p.hop; A.run = run; A.halo = halo;
+    A.total_frames = total_frames; A.frame_off = frame_off; A.sample_off = sample_off; A.short_s = short_s; A.steps = steps;
+    A.params = params; A.harm = harm; A.uv = uv; A.bre = bre; A.g_tw = p.tw_full; A.g_twh = p.tw_half; A.g_win = p.window;
+    A.frame_skip = frame_skip;
+    hipLaunchKernelGGL((k_irfft_ola1<M, WPB>), dim3((unsigned)(3 * ((runs + WPB - 1) / WPB))), dim3(64 * WPB), lds, st, A);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
