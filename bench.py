@@ -66,7 +66,7 @@ def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int, ex
 STAGE_KERNEL = {"rfft_frames": "void k_rfft_frames<512>", "rfft_frames_standalone": "void k_rfft_frames<512>",
                 "irfft_harm": "void k_irfft_frames<512>", "harm_shape": "void k_harm_shape<9>",
                 "noise_spectra": "void k_noise_spectra<9>", "ola3_gains": "k_ola3_gains", "irfft_ola3": "void k_irfft_ola3<512>",
-                "apply_gain": "k_apply_gain", "pulse_onsets": "k_pulse_onsets_scan", "pulse_place": "k_pulse_place",
+                "apply_gain": "k_apply_gain", "pulse_onsets": "k_pulse_onsets_par", "pulse_place": "k_pulse_place",
                 "mask_short": "k_mask_short", "phase_inc": "k_phase_inc", "setup_maps": "k_scale_f0",
                 "noise_stems": "void k_noise_stems<512, false>", "harm_stem": "void k_harm_stem<512>", "note_finish": "k_note_finish"}
 

@@ -810,6 +810,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
         ctx->side_prio = v;
         return GOOFER_OK;
     }
+    if (!strcmp(name, "harm_side")) { ctx->harm_side = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "nt_mask")) { ctx->nt_mask = value; return GOOFER_OK; }
     if (!strcmp(name, "nt_spectra")) { ctx->nt_spectra = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "stem_lds_kb")) { ctx->stem_lds_kb = value < 0 ? 0 : (value > 160 ? 160 : value); return GOOFER_OK; }
@@ -1404,9 +1405,10 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     } while (0)
 #define MARK()                                                       \
     do {                                                             \
-        if (pev) HIP_TRY(ctx, hipEventRecord(pev[stage], st));       \
+        if (pev && !(harm_side && (stage == 9 || stage == 10))) HIP_TRY(ctx, hipEventRecord(pev[stage], st)); \
         ++stage;                                                     \
     } while (0)
+    bool harm_side = false;                                   // the harmonic walker runs on the side stream (its two marks are recorded there)
 
     // the fused overlap-add rings index by position mod n_fft with a mask: power-of-two transforms only (768 / 1536 take the
     // separate irFFT + gather kernels)
@@ -1513,7 +1515,10 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         int rc2 = ensure_side_stream(ctx);
         if (rc2) return rc2;
         if (pev) sev = ctx->prof_side + (size_t)ctx->prof_steps * 4;
-        if (stem_path && !ctx->warp_done && !maps_side) HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st));   // the frame maps and everything before them on this stream (for k_warp_bins)
+        // the harmonic walker beside the noise walker: it needs the pulse signal (side stream), the warped rows and the frame maps
+        // (caller's stream, both enqueued by now), nothing of the noise walker — on the caller's stream it only waited its turn
+        harm_side = stem_path && ctx->warp_done && ctx->harm_side && !maps_side;
+        if (stem_path && (!ctx->warp_done || harm_side) && !maps_side) HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st));   // the frame maps and everything before them on this stream (for k_warp_bins / the harmonic walker)
         if (!early) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
@@ -1547,6 +1552,14 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     }
     if (side_on) {
         if (sev) HIP_TRY(ctx, hipEventRecord(sev[3], pst));
+        if (harm_side) {
+            HIP_TRY(ctx, hipStreamWaitEvent(pst, ctx->ev_maps, 0));
+            if (pev) HIP_TRY(ctx, hipEventRecord(pev[9], pst));
+            if ((rc = launch_harm_stem(ctx, pulse, ctx->warp_rows, ld, row_src, F, frame_note, b->frame_off, b->sample_off, picks, b->params,
+                                       b->harm, note_mag, pst)))
+                return rc;
+            if (pev) HIP_TRY(ctx, hipEventRecord(pev[10], pst));
+        }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, pst));
         // meanwhile, on the caller's stream
         if (early && !f0_alias) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_f0s, 0));   // the scaled f0 comes from the side stream
@@ -1608,7 +1621,8 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         }
         MARK();   // 8
         MARK();   // 9: harm_stem = rFFT + shaping + irFFT + overlap-add of the harmonic stem
-        if ((rc = launch_harm_stem(ctx, pulse, ctx->warp_done ? ctx->warp_rows : env_h, ld, ctx->warp_done ? row_src : nullptr, F, frame_note,
+        if (!harm_side &&
+            (rc = launch_harm_stem(ctx, pulse, ctx->warp_done ? ctx->warp_rows : env_h, ld, ctx->warp_done ? row_src : nullptr, F, frame_note,
                                    b->frame_off, b->sample_off, picks, b->params, b->harm, note_mag, st)))
             return rc;
         MARK();   // 10..12

@@ -87,6 +87,7 @@ struct goofer_ctx {
     int walk_lds_kb = 81;         // LDS the sequential phase walk reserves per workgroup (what it uses: 32 KiB)
     int finish_lds_kb = 0;        // LDS k_note_finish reserves per workgroup (0: none) — caps the notes in flight per CU
     int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
+    bool harm_side = false;       // goofer_render_batch: the harmonic walker on the side stream, beside the noise walker (option "harm_side")
     int nt_mask = 1;              // non-temporal stores: 1 note_finish mix / rec (the final output: -0.7 % per step), 2 env_loop rows (measured: nothing)
     int nt_spectra = 1;           // framewise rFFT: spectrum rows leave as non-temporal stores (option "nt_spectra")
     int stem_lds_kb = 0;          // stem walkers: LDS to reserve per workgroup beyond what they use (tuning: 100 -> one workgroup per CU)
