@@ -457,6 +457,7 @@ void goofer_destroy(goofer_ctx *ctx)
     if (ctx->ev_entry) (void)hipEventDestroy(ctx->ev_entry);
     if (ctx->ev_f0) (void)hipEventDestroy(ctx->ev_f0);
     if (ctx->ev_f0s) (void)hipEventDestroy(ctx->ev_f0s);
+    if (ctx->ev_mask) (void)hipEventDestroy(ctx->ev_mask);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     delete ctx;
 }
@@ -810,6 +811,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
         ctx->side_prio = v;
         return GOOFER_OK;
     }
+    if (!strcmp(name, "mask_side")) { ctx->mask_side = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "harm_side")) { ctx->harm_side = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "nt_mask")) { ctx->nt_mask = value; return GOOFER_OK; }
     if (!strcmp(name, "nt_spectra")) { ctx->nt_spectra = value != 0; return GOOFER_OK; }
@@ -1284,7 +1286,7 @@ static int ensure_side_stream(goofer_ctx *ctx)
     } else {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     }
-    hipEvent_t *evs[] = {&ctx->ev_fork, &ctx->ev_join, &ctx->ev_maps, &ctx->ev_entry, &ctx->ev_f0, &ctx->ev_f0s};
+    hipEvent_t *evs[] = {&ctx->ev_fork, &ctx->ev_join, &ctx->ev_maps, &ctx->ev_entry, &ctx->ev_f0, &ctx->ev_f0s, &ctx->ev_mask};
     for (hipEvent_t *e : evs)
         if (!*e) HIP_TRY(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     return GOOFER_OK;
@@ -1493,10 +1495,12 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     }
     // aperiodic half of the stem-split path: smoothed mask knots, then the two noise stems straight to samples.  Needs the
     // final scaled f0 (frame picks) and nothing of the pulse chain.
+    bool mask_side = false;                                   // the mask smoothing ran on the side stream, in front of the pulse chain
     auto stems_aperiodic = [&]() -> int {
         int r2;
         if (!picks_on && (r2 = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return r2;
-        if ((r2 = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return r2;
+        if (mask_side) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_mask, 0));   // the smoothed mask comes from the side stream
+        else if ((r2 = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return r2;
         if (side_on) MARK_Q(0);
         if (!maps_side && !maps_fused && (r2 = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return r2;
         if ((r2 = launch_noise_stems(ctx, b->env_noise ? b->env_noise : b->env, ld, row_src, b->phi, F, frame_note, b->frame_off,
@@ -1532,6 +1536,14 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // (folded into k_noise_spectra / k_harm_shape: the standalone envelope kernels remain as C-ABI entry points)
     MARK();   // 2: harmonic envelope = formant-anchored + uniform warp
 
+    // The mask smoothing needs nothing but the assembled mask, which the side stream has as soon as its f0 / mask kernel is done.
+    // On the caller's stream it sat between the envelope gather and the noise walker — the longest chain of the step since the
+    // phase walk became a scan; the side stream has the slack (its chain ends half a millisecond before the noise walker does).
+    if (side_on && early && stem_path && ctx->mask_side) {
+        if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, pst))) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_mask, pst));
+        mask_side = true;
+    }
     MARK();   // 3..5: pulse train
     if (sev) HIP_TRY(ctx, hipEventRecord(sev[0], pst));
     MARK();

@@ -58,7 +58,7 @@ struct goofer_ctx {
                                   // with the parallel phase scan in place: 2.41 ms per step against 2.50 (0) and 2.54 (-1) on one box
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_maps = nullptr;
     // goofer_render_batch: the pulse chain forks as soon as the assembled f0 exists, not when the synthesis call starts
-    hipEvent_t ev_entry = nullptr, ev_f0 = nullptr, ev_f0s = nullptr;
+    hipEvent_t ev_entry = nullptr, ev_f0 = nullptr, ev_f0s = nullptr, ev_mask = nullptr;
     int32_t *ovf_flag = nullptr;           // handle-owned device words ([1], [2]: cumulative counters, goofer_counter); [0] sticky between goofer_check calls: 1 + index (inside its batch) of a
                                            // note whose pulse onsets overflowed their slots, written with atomicMax by every pulse-chain launch
     // goofer_render_batch, stem-split path: the assembly's frame-gather kernel also writes the rows the harmonic walker needs
@@ -87,6 +87,7 @@ struct goofer_ctx {
     int walk_lds_kb = 81;         // LDS the sequential phase walk reserves per workgroup (what it uses: 32 KiB)
     int finish_lds_kb = 0;        // LDS k_note_finish reserves per workgroup (0: none) — caps the notes in flight per CU
     int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
+    bool mask_side = false;       // goofer_render_batch: the mask smoothing on the side stream in front of the pulse chain (option "mask_side"; measured: -0.4 %)
     bool harm_side = false;       // goofer_render_batch: the harmonic walker on the side stream, beside the noise walker (option "harm_side")
     int nt_mask = 1;              // non-temporal stores: 1 note_finish mix / rec (the final output: -0.7 % per step), 2 env_loop rows (measured: nothing)
     int nt_spectra = 1;           // framewise rFFT: spectrum rows leave as non-temporal stores (option "nt_spectra")
