@@ -287,7 +287,12 @@ def host_inclusive(wl, ctx, step_s):
     # batch after batch (the sources resident, as in a job that renders a voicebank's samples thousands of times).
     from goofer_amd.render import PipelinedRenderer
     import sys as _sys
-    rounds, lead = 24, 6
+    rounds, lead = 32, 32                                      # steady state of a long job: the first dozens of batches run 4-6 ms (the
+                                                               # caching allocator's stream-private pools filling, threads falling into step)
+    import gc
+    gc.collect()
+    gc.freeze()                                                # a render server's usual setting: the objects of the set-up (thousands of
+                                                               # sources and plans in this process) are not traversed by later collections
     pipe = PipelinedRenderer(torch.cuda.current_device(), hop=wl.geo["hop"], depth=2, workers=2)
     old_interval = _sys.getswitchinterval()
     _sys.setswitchinterval(1e-4)                               # the threads hand the interpreter lock over in 0.1 ms, not 5 ms
@@ -303,6 +308,7 @@ def host_inclusive(wl, ctx, step_s):
     finally:
         _sys.setswitchinterval(old_interval)
         pipe.close()
+        gc.unfreeze()
     best["pipelined"] = {"ms_per_batch": 1e3 * dt, "frames_per_s": frames / dt, "batches": rounds,
                          "note": "goofer_amd.render.PipelinedRenderer(depth=2, workers=2): 13 argument strings -> audio in pinned host memory, "
                                  "two batches in flight on two handles / streams, decode + planning of the next batches on two worker "

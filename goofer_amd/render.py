@@ -761,16 +761,22 @@ class PipelinedRenderer:
     ``render_iter`` yields ``(mix, sample_off)`` per batch, in order: ``mix`` is a float32 numpy view of the lane's pinned
     buffer, valid until ``depth`` more batches have been taken from the iterator (copy what must live longer)."""
 
-    def __init__(self, device: int = 0, hop: int = S.HOP, depth: int = 2, workers: int = 2):
+    def __init__(self, device: int = 0, hop: int = S.HOP, depth: int = 2, workers: int = 2, staging_bytes: int = 48 << 20):
         from concurrent.futures import ThreadPoolExecutor
         self.device = torch.device("cuda", device)
         self.lanes = []
         arena = None
-        for _ in range(max(1, depth)):
+        depth, workers = max(1, depth), max(1, workers)
+        # batches prepared but not finished at any time: depth + workers waiting or being planned, depth on the device — each
+        # holds a staging block of its lane.  They are made here: pinning 48 MiB of host memory takes tens of milliseconds, which
+        # belongs to the start of a job and not to whichever batch first finds its lane's free list empty.
+        per_lane = (2 * depth + workers + depth - 1) // depth
+        for _ in range(depth):
             r = Renderer(Context(device), hop=hop)
             if arena is None:
                 arena = r.sources
             r.sources = arena
+            r._stagings.extend(Staging(self.device, staging_bytes) for _ in range(per_lane))
             self.lanes.append({"r": r, "stream": torch.cuda.Stream(self.device), "host": None})
         self.copy_stream = torch.cuda.Stream(self.device)
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="goofer-prepare")

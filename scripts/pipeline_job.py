@@ -1,0 +1,55 @@
+"""Per-batch intervals of goofer_amd.render.PipelinedRenderer on the default workload (the same 1024 argument lists and
+sources batch after batch).  Usage (GPU box): python scripts/pipeline_job.py [batches] [depth] [workers] [--extra]
+--extra: another resident workload in the process first (what bench.py's variants leave behind)."""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from goofer_amd import synthetic as syn
+from goofer_amd.render import PipelinedRenderer, Source
+
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+rounds = int(argv[0]) if len(argv) > 0 else 40
+depth = int(argv[1]) if len(argv) > 1 else 2
+workers = int(argv[2]) if len(argv) > 2 else 2
+raw = [syn.config_note(3, i) for i in range(1024)]
+args = [syn.request_args(q) for _, q, _ in raw]
+srcs = [Source.from_pack(s["env_pack"], s["f0"], s["mask"], s["formants"], s["sr"], s["y_len"]) for s, _, _ in raw]
+if "--extra" in sys.argv:
+    from goofer_amd.device import Context
+    from goofer_amd.workload import SamplerWorkload
+    c0 = Context(0)
+    keep = [SamplerWorkload(c0, 3, list(range(1024))), SamplerWorkload(c0, 3, list(range(1024)), unvoiced_share=0.3)]
+    for w in keep:
+        w.step()
+    torch.cuda.synchronize()
+    if "--two" in sys.argv:                                    # the two-in-flight variant of bench.py: a second handle, two more streams
+        cb = Context(0)
+        wb = SamplerWorkload(cb, 3, list(range(1024)))
+        both = [keep[0], wb]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for i in range(40):
+            with torch.cuda.stream(streams[i % 2]):
+                both[i % 2].step()
+        torch.cuda.synchronize()
+        if "--keepb" not in sys.argv:
+            del wb, both
+            cb.close()
+sys.setswitchinterval(1e-4)
+if "--nogc" in sys.argv:
+    import gc
+    gc.disable()
+pipe = PipelinedRenderer(0, depth=depth, workers=workers)
+ids = list(range(1024))
+stamps = []
+t_prev = time.perf_counter()
+for mix, off in pipe.render_iter(((srcs, args) for _ in range(rounds)), note_ids=lambda k, n: ids):
+    now = time.perf_counter()
+    stamps.append(1e3 * (now - t_prev))
+    t_prev = now
+pipe.close()
+print("intervals (ms):", " ".join("%.1f" % v for v in stamps))
+tail = stamps[len(stamps) // 2:]
+print("second half: mean %.2f ms, median %.2f, max %.2f  -> %.1f M frames/s" % (np.mean(tail), np.median(tail), max(tail), 194560 / np.mean(tail) / 1e3))
