@@ -297,14 +297,16 @@ def host_inclusive(wl, ctx, step_s):
     old_interval = _sys.getswitchinterval()
     _sys.setswitchinterval(1e-4)                               # the threads hand the interpreter lock over in 0.1 ms, not 5 ms
     try:
-        t0 = None
-        done = 0
-        for mix, off in pipe.render_iter(((srcs, args) for _ in range(lead + rounds)), seed=0, note_ids=lambda k, n: ids):
-            done += 1
-            if done == lead:
-                t0 = time.perf_counter()
-        dt = (time.perf_counter() - t0) / rounds
-        assert done == lead + rounds and float(np.abs(mix).max()) > 0.0
+        def job(pcm16, warm):
+            t0, done = None, 0
+            for mix, off in pipe.render_iter(((srcs, args) for _ in range(warm + rounds)), seed=0, note_ids=lambda k, n: ids, pcm16=pcm16):
+                done += 1
+                if done == warm:
+                    t0 = time.perf_counter()
+            assert done == warm + rounds and float(np.abs(mix).max()) > 0.0
+            return (time.perf_counter() - t0) / rounds
+        dt = job(False, lead)
+        dt16 = job(True, 8)
     finally:
         _sys.setswitchinterval(old_interval)
         pipe.close()
@@ -312,7 +314,10 @@ def host_inclusive(wl, ctx, step_s):
     best["pipelined"] = {"ms_per_batch": 1e3 * dt, "frames_per_s": frames / dt, "batches": rounds,
                          "note": "goofer_amd.render.PipelinedRenderer(depth=2, workers=2): 13 argument strings -> audio in pinned host memory, "
                                  "two batches in flight on two handles / streams, decode + planning of the next batches on two worker "
-                                 "threads, D2H of the previous mix on a copy stream under the running step"}
+                                 "threads, D2H of the previous mix on a copy stream under the running step",
+                         "pcm16": {"ms_per_batch": 1e3 * dt16, "frames_per_s": frames / dt16,
+                                   "note": "the same with the mix converted to the wav's int16 samples on the device (goofer_pcm16: what the "
+                                           "reference's PCM_16 file holds): half the bytes over PCIe"}}
     best["note"] = ("serial, one host thread: 13 argument strings -> request columns (decode_request_batch), plans written by the library's "
                     "host planner into a pinned staging block + tables, one H2D copy (Renderer.prepare; the voicebank samples are resident "
                     "in HBM, see first_batch), device step, D2H of the mix into pinned memory; the best of three passes; the device step "

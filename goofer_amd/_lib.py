@@ -146,6 +146,7 @@ EXPORTS = {
     "goofer_onepole_cascade": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "goofer_vocal_roughness": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "goofer_pcm16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "goofer_post_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "goofer_assemble_batch": (C.c_int, [C.c_void_p, C.POINTER(Assembly), C.c_void_p]),
     "goofer_render_batch": (C.c_int, [C.c_void_p, C.POINTER(Assembly), C.POINTER(Batch), C.c_void_p]),

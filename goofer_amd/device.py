@@ -129,6 +129,12 @@ class Context:
     def set_option(self, name: str, value: int):
         self._check(self.lib.goofer_set_option(self.h, name.encode(), int(value)))
 
+    def pcm16(self, x, out=None):
+        """The wav samples of fp32 audio on the device (goofer_pcm16: clip, * 32768, round half to even -> int16)."""
+        out = torch.empty(x.numel(), dtype=torch.int16, device=x.device) if out is None else out
+        self._check(self.lib.goofer_pcm16(self.h, _ptr(x), x.numel(), _ptr(out), self._stream()))
+        return out
+
     def counter(self, name: str) -> int:
         """Cumulative device-side counter of the handle (goofer_counter): 'pulse_scanned_notes', 'pulse_fallback_notes'."""
         v = C.c_int64(0)

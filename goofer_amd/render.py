@@ -735,9 +735,15 @@ class GooferResampler:
 
 
 def write_wav(path, x, sr):
+    """Mono PCM16 wav (soundfile's default subtype, what the reference writes).  int16 input (samples already converted on
+    the device, ``Context.pcm16``) is written as it is."""
     import wave
-    pcm = np.clip(np.asarray(x, dtype=np.float64), -1.0, 1.0 - 1.0 / 32768)
-    pcm = np.round(pcm * 32768.0).astype("<i2")
+    x = np.asarray(x)
+    if x.dtype == np.int16:
+        pcm = x.astype("<i2", copy=False)
+    else:
+        pcm = np.clip(x.astype(np.float64), -1.0, 1.0 - 1.0 / 32768)
+        pcm = np.round(pcm * 32768.0).astype("<i2")
     with wave.open(str(path), "wb") as w:
         w.setnchannels(1)
         w.setsampwidth(2)
@@ -797,10 +803,11 @@ class PipelinedRenderer:
         with torch.cuda.stream(ln["stream"]):
             return ln["r"].prepare((srcs, reqs), note_ids=note_ids(k, len(reqs)) if note_ids else None, device_calls=False)
 
-    def render_iter(self, batches, seed: int = 0, note_ids=None):
+    def render_iter(self, batches, seed: int = 0, note_ids=None, pcm16: bool = False):
         """``batches``: an iterable of (sources, requests) — requests as a ``RequestBatch``, a list of ``Request`` or a list of
         argument lists (decoded on the worker threads).  ``note_ids(k, n)``: the Philox ids of batch k's notes (default: the
-        position in the batch)."""
+        position in the batch).  ``pcm16``: yield the wav's int16 samples (converted on the device, goofer_pcm16: what
+        ``write_wav`` computes on the host) — half the bytes over PCIe, which is what bounds a long job."""
         import collections
         it = iter(enumerate(batches))
         ahead = collections.deque()                           # futures of prepared batches, in order
@@ -827,11 +834,14 @@ class PipelinedRenderer:
                     r.ctx.plan(sr, n_fft, hop)                 # no-ops once the lane has seen the geometry / the sizes
                     r.ctx.reserve(frames, samples, n)
                     out = r.run(prep, seed=seed)
+                    if pcm16:
+                        out["pcm"] = r.ctx.pcm16(out["mix"])
                     done = torch.cuda.Event()
                     done.record()
-                if ln["host"] is None or ln["host"].numel() < samples:
-                    ln["host"] = torch.empty(max(samples, int(1.25 * samples)), dtype=torch.float32).pin_memory()
-                mix = out["mix"]
+                want = torch.int16 if pcm16 else torch.float32
+                if ln["host"] is None or ln["host"].numel() < samples or ln["host"].dtype != want:
+                    ln["host"] = torch.empty(max(samples, int(1.25 * samples)), dtype=want).pin_memory()
+                mix = out["pcm"] if pcm16 else out["mix"]
                 mix.record_stream(self.copy_stream)
                 with torch.cuda.stream(self.copy_stream):
                     self.copy_stream.wait_event(done)

@@ -412,6 +412,11 @@ int goofer_onepole_cascade(goofer_ctx *ctx, const float *src, float *dst, const 
  * sd dryness, st tension, V/B/U mix, sa whisper blend, pd gain.  Notes without any of these keep their mix. */
 int goofer_post_batch(goofer_ctx *ctx, const goofer_post *post, void *stream);
 
+/* Finished audio as the reference's wav holds it (soundfile's default PCM_16, SillySampler.py:1184-1185): out[i] =
+ * int16(round_half_even(clip(x[i], -1, 1 - 2^-15) * 32768)), the arithmetic of goofer_amd.render.write_wav.  Two bytes per
+ * sample across PCIe instead of four. */
+int goofer_pcm16(goofer_ctx *ctx, const float *x, int64_t n, int16_t *out, void *stream);
+
 /* ---- measurement / test hooks --------------------------------------------------------------- */
 
 /* HIP-event timing of every stage of goofer_synth_batch on the caller's stream: begin() arms up to

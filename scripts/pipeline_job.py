@@ -45,7 +45,7 @@ pipe = PipelinedRenderer(0, depth=depth, workers=workers)
 ids = list(range(1024))
 stamps = []
 t_prev = time.perf_counter()
-for mix, off in pipe.render_iter(((srcs, args) for _ in range(rounds)), note_ids=lambda k, n: ids):
+for mix, off in pipe.render_iter(((srcs, args) for _ in range(rounds)), note_ids=lambda k, n: ids, pcm16="--pcm16" in sys.argv):
     now = time.perf_counter()
     stamps.append(1e3 * (now - t_prev))
     t_prev = now

@@ -82,3 +82,36 @@ def test_prepare_from_columns_equals_prepare_from_requests():
             assert np.array_equal(mix[off[i]:off[i + 1]], a[i]), i
     finally:
         ctx.close()
+
+
+def test_device_pcm16_equals_the_wav_writers_arithmetic():
+    """goofer_pcm16 (the finished audio converted on the device, two bytes per sample over PCIe) = write_wav's clip / scale /
+    round-half-even on the host, sample for sample — incl. values past full scale, exact halves and ragged lengths; and the
+    pipelined renderer's pcm16 stream = the conversion of its fp32 stream."""
+    from goofer_amd.device import Context
+    from goofer_amd.render import PipelinedRenderer
+    ctx = Context(0)
+    try:
+        rng = np.random.default_rng(3)
+        for n in (1, 7, 8, 9, 4099, 100003):
+            x = (rng.standard_normal(n) * 0.6).astype(np.float32)
+            x[::17] = (rng.integers(-32768, 32768, size=x[::17].shape) + 0.5) / 32768.0      # exact halves: ties to even
+            x[::29] = rng.choice([1.0, -1.0, 1.5, -2.0, 0.99998474, 0.9999999], size=x[::29].shape)
+            want = np.round(np.clip(x.astype(np.float64), -1.0, 1.0 - 1.0 / 32768) * 32768.0).astype(np.int16)
+            for off in (0, 1):                                  # 16-byte aligned and not
+                t = torch.zeros(n + off, dtype=torch.float32, device="cuda")
+                t[off:] = torch.from_numpy(x).cuda()
+                got = ctx.pcm16(t[off:]).cpu().numpy()
+                assert np.array_equal(got, want), (n, off)
+    finally:
+        ctx.close()
+    batches = _batches(3, [24, 5, 31])
+    p = PipelinedRenderer(0, depth=2, workers=2)
+    try:
+        f32 = [(m.copy(), o.copy()) for m, o in p.render_iter(batches, seed=4)]
+        i16 = [(m.copy(), o.copy()) for m, o in p.render_iter(batches, seed=4, pcm16=True)]
+    finally:
+        p.close()
+    for (a, oa), (b, ob) in zip(f32, i16):
+        assert b.dtype == np.int16 and np.array_equal(oa, ob)
+        assert np.array_equal(b, np.round(np.clip(a.astype(np.float64), -1.0, 1.0 - 1.0 / 32768) * 32768.0).astype(np.int16))
