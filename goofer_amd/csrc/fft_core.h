@@ -326,6 +326,62 @@ __device__ __forceinline__ void wave_fft_keep(float2 *v, float2 *buf, const floa
     wave_lds_sync();
 }
 
+// The same with the two passes' twiddles in tables of their own (M = 512: one butterfly per lane and pass).  Indexing the
+// M-entry table, pass 1 reads tw[t * (lane % 8) * 8] — eight addresses 64 t bytes apart, which fall on 4, 2 or 1 of the
+// 64 banks (t = 4: an 8-way conflict) — and the last pass tw[t * lane], a stride of 8 t bytes over 64 lanes.  tw1[t][k]
+// (7 x 8 entries) and tw2[t][lane] (7 x 64) hold the same values contiguously: every read is conflict-free.
+template <int M> struct fft_tw_tabs {
+    static constexpr int N1 = 7 * 8, N2 = 7 * WAVE;           // float2 entries
+    static constexpr int TOTAL = N1 + N2;
+};
+template <int M>
+__device__ __forceinline__ void fill_tw_tabs(float2 *tw1, float2 *tw2, const float2 *tw)
+{
+    static_assert(M == 512, "one butterfly per lane and pass");
+    constexpr int R = fft_cfg<M>::R;
+    for (int i = threadIdx.x; i < fft_tw_tabs<M>::N1; i += blockDim.x) {
+        const int t = i / 8 + 1, k = i % 8;
+        tw1[i] = tw[(t * k * (M / (8 * R))) & (M - 1)];
+    }
+    for (int i = threadIdx.x; i < fft_tw_tabs<M>::N2; i += blockDim.x) {
+        const int t = i / WAVE + 1, b = i % WAVE;
+        tw2[i] = tw[(t * b) & (M - 1)];
+    }
+}
+template <int M>
+__device__ __forceinline__ void wave_fft_keep_tab(float2 *v, float2 *buf, const float2 *tw1, const float2 *tw2, int lane, float2 *out)
+{
+    static_assert(M == 512, "one butterfly per lane and pass");
+    constexpr int R = fft_cfg<M>::R, NB = M / 8;
+    dft<R>::run(v);
+#pragma unroll
+    for (int t = 0; t < R; ++t) buf[lds_pad(lane * R + t)] = v[t];
+    wave_lds_sync();
+    {   // pass 1 (NS = R): reads x[b + t NB], writes y[(b / NS) NS 8 + b % NS + t NS]
+        float2 x[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = buf[lds_pad(lane + t * NB)];
+        wave_lds_sync();
+        const int k = lane % R;
+#pragma unroll
+        for (int t = 1; t < 8; ++t) x[t] = cmul(x[t], tw1[(t - 1) * 8 + k]);
+        dft<8>::run(x);
+        const int j0 = (lane / R) * R * 8 + k;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) buf[lds_pad(j0 + t * R)] = x[t];
+        wave_lds_sync();
+    }
+    float2 x[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = buf[lds_pad(lane + t * NB)];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) x[t] = cmul(x[t], tw2[(t - 1) * WAVE + lane]);
+    dft<8>::run(x);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) out[t] = x[t];
+    wave_lds_sync();
+}
+
 // The same with both passes' twiddles held in registers (M = 512: one butterfly per lane and pass, 2 x 7 twiddles that
 // depend on the lane only): a caller that transforms many frames loads them once and saves 14 LDS reads per transform.
 template <int M>

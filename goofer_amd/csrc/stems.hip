@@ -70,7 +70,10 @@ template <int M> struct stem_cfg {
     // Sized so that four workgroups share a CU (4 waves per SIMD): a walker is a latency-bound chain of LDS exchanges and
     // needs the waves more than it needs registers.
     static constexpr size_t wave_bytes = sizeof(float2) * fft_cfg<M>::BUF + sizeof(double) * KN;
-    template <int NTAB, bool WIN> static constexpr size_t table_bytes() { return sizeof(float2) * 4 * M + sizeof(float) * (NTAB * ROWF + (WIN ? NF : 0)); }
+    template <int NTAB, bool WIN> static constexpr size_t table_bytes()
+    {
+        return sizeof(float2) * (4 * M + fft_tw_tabs<M>::TOTAL) + sizeof(float) * (NTAB * ROWF + (WIN ? NF : 0));
+    }
     template <int NTAB, bool WIN> static constexpr size_t lds_bytes() { return table_bytes<NTAB, WIN>() + WAVES_PER_BLOCK * wave_bytes; }
     static_assert(wave_bytes % 16 == 0, "16-byte aligned LDS carving");
 };
@@ -148,7 +151,7 @@ struct frame_block {
 template <int M, int NTAB, bool WIN> struct walker {
     using C = stem_cfg<M>;
     static constexpr int R = C::R, G = C::G, NF = C::NF, HOP = C::HOP, B = C::B;
-    float2 *tw, *wct, *wsc, *wsv, *buf;
+    float2 *tw, *wct, *wsc, *wsv, *buf, *tw1, *tw2;
     float *win, *tab;
     double *kbuf;
     int lane;
@@ -164,7 +167,9 @@ template <int M, int NTAB, bool WIN> struct walker {
         wct = tw + M;
         wsc = wct + M;
         wsv = wsc + M;
-        tab = reinterpret_cast<float *>(wsv + M);
+        tw1 = wsv + M;                                         // the two passes' twiddles, contiguous per pass (fft_core.h)
+        tw2 = tw1 + fft_tw_tabs<M>::N1;
+        tab = reinterpret_cast<float *>(tw2 + fft_tw_tabs<M>::N2);
         win = tab + NTAB * C::ROWF;
         const float *tsrc[3] = {t0, t1, t2};
         for (int i = threadIdx.x; i < C::ROWF; i += blockDim.x) {
@@ -187,6 +192,8 @@ template <int M, int NTAB, bool WIN> struct walker {
         }
         if (WIN)
             for (int i = threadIdx.x; i < NF; i += blockDim.x) win[i] = g_win[i];
+        __syncthreads();
+        fill_tw_tabs<M>(tw1, tw2, tw);
         __syncthreads();
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         lane = threadIdx.x & 63;
@@ -251,7 +258,7 @@ template <int M, int NTAB, bool WIN> struct walker {
         }
         wave_lds_sync();                                             // the row is read before the transform reuses buf
         float2 z[R];
-        wave_fft_keep<M>(v, buf, tw, lane, z);
+        wave_fft_keep_tab<M>(v, buf, tw1, tw2, lane, z);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const float2 wn = wtab[lane + WAVE * r];
@@ -484,21 +491,22 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
         const bool hp_low_only = fq64 - f0f > 100.0f;
 
         // 1. noise envelope: sigma-1.75 blur of the un-warped row (GOOFER.py:993), fp32 FMAs in tap order.  A lane blurs its
-        //    eight consecutive bins from a 24-value window (its own eight, eight on either side from LDS), lane 63 also the
+        //    eight consecutive bins from a 24-value window (its own eight, eight on either side from the neighbouring lanes), lane 63 also the
         //    Nyquist bin; the blurred row then goes through LDS once more into the transform's layout k = lane + 64 i.
         float en[PER];
         {
             float o9[9];
             if (mode & 1) {
-                *reinterpret_cast<float4 *>(rp + 8 + 8 * lane) = ea;
-                *reinterpret_cast<float4 *>(rp + 8 + 8 * lane + 4) = eb4;
-                wave_lds_sync();
+                // the eight bins of the lane on either side through DPP wave shifts (lane i reads lane i -+ 1): sixteen moves on
+                // the vector pipe instead of an LDS round trip of the row (two 16-byte stores, a wait, four 16-byte loads)
                 float x[24];
                 {
-                    const float4 l0 = *reinterpret_cast<const float4 *>(rp + 8 * lane), l1 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 4);
-                    const float4 r0 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 16), r1 = *reinterpret_cast<const float4 *>(rp + 8 * lane + 20);
-                    x[0] = l0.x; x[1] = l0.y; x[2] = l0.z; x[3] = l0.w; x[4] = l1.x; x[5] = l1.y; x[6] = l1.z; x[7] = l1.w;
-                    x[16] = r0.x; x[17] = r0.y; x[18] = r0.z; x[19] = r0.w; x[20] = r1.x; x[21] = r1.y; x[22] = r1.z; x[23] = r1.w;
+                    const float own[8] = {ea.x, ea.y, ea.z, ea.w, eb4.x, eb4.y, eb4.z, eb4.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        x[j] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(own[j]), 0x138, 0xf, 0xf, false));        // wave_shr:1 <- lane - 1
+                        x[16 + j] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(own[j]), 0x130, 0xf, 0xf, false));   // wave_shl:1 <- lane + 1
+                    }
                 }
                 const float ec[8] = {ea.x, ea.y, ea.z, ea.w, eb4.x, eb4.y, eb4.z, eb4.w};
 #pragma unroll
@@ -517,7 +525,6 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
                     for (int q = 1; q < 15; ++q) acc = fmaf(t175[q], x[j + 1 + q], acc);
                     o9[j] = acc;
                 }
-                wave_lds_sync();
             } else {
                 o9[0] = ea.x; o9[1] = ea.y; o9[2] = ea.z; o9[3] = ea.w; o9[4] = eb4.x; o9[5] = eb4.y; o9[6] = eb4.z; o9[7] = eb4.w;
                 o9[8] = e_ny;
@@ -763,7 +770,7 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
                     const float2 wn = *reinterpret_cast<const float2 *>(w.win + 2 * m);
                     v[r] = make_float2(raw[r].x * wn.x, raw[r].y * wn.y);
                 }
-                wave_fft_keep<M>(v, w.buf, w.tw, lane, z);
+                wave_fft_keep_tab<M>(v, w.buf, w.tw1, w.tw2, lane, z);
             }
 #pragma unroll
             for (int i = 0; i < PER; ++i) evc[i] = ev[i];
