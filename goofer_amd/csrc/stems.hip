@@ -354,10 +354,14 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
     const float *__restrict__ phi = A.phi;
     float *__restrict__ uv = A.uv, *__restrict__ bre = A.bre;
     const int ld = A.ld, mode = A.mode;
-    int64_t fs, f0, f1;
+    // frame indices as 32-bit integers in the loop (a batch of 2^31 frames would be 4 TB of envelope rows): four scalar
+    // registers fewer in a loop that spills them
+    int fs, f0, f1;
     {
         const int64_t total_frames = NCOLD(total_frames);
-        if (!w.range(total_frames, A.run, NCOLD(frame_note), NCOLD(frame_off), fs, f0, f1)) return;   // no block barrier below
+        int64_t fs64, f064, f164;
+        if (!w.range(total_frames, A.run, NCOLD(frame_note), NCOLD(frame_off), fs64, f064, f164)) return;   // no block barrier below
+        fs = (int)fs64; f0 = (int)f064; f1 = (int)f164;
     }
     frame_block fb;
     auto load_block = [&](int64_t first) {
@@ -461,8 +465,8 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
     };
 
     float *rp = reinterpret_cast<float *>(w.buf);             // staged fp32 rows (dead before the spectra use buf)
-    for (int64_t f = fs; f < f1; ++f) {
-        const int idx = (int)(f - fb.blk0);
+    for (int f = fs; f < f1; ++f) {
+        const int idx = f - (int)fb.blk0;
         const int t = FB_GET(fb, t, idx);
         if (FB_GET(fb, note, idx) != w.note) {
             one_bits = zero_bits = 0;
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
         }
         if (f + 1 < f1) {                                     // the row registers are consumed: start the next frame's row
             if (!fb.holds(f + 1)) load_block(f + 1);
-            fetch(FB_GET(fb, src, (int)(f + 1 - fb.blk0)));
+            fetch(FB_GET(fb, src, f + 1 - (int)fb.blk0));
         }
 
         // 2. U * env_n (unvoiced spectrum; waits in registers) and U * env_n * HP (* brightness) (breath spectrum)  GOOFER.py:1148-1173
