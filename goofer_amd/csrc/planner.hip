@@ -140,6 +140,25 @@ struct scratch {
     std::vector<int32_t> rows;
 };
 
+// acc[t] = sum_j taps[j] * pp[t + j], every frame adding its products in ascending tap order (product rounded, then added: the
+// arithmetic of the numpy planner's loop, so the sums are the same bits whatever the vector width).  Taps outside, frames
+// inside: a plain vector loop over t; built for AVX2 as well (chosen at load time), four frames per instruction.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target_clones("avx2", "default")))
+#endif
+void fir_rows(const double *pp, const double *taps, int n_taps, int64_t T, double *acc)
+{
+    for (int64_t t = 0; t < T; ++t) acc[t] = taps[0] * pp[t];
+    for (int j = 1; j < n_taps; ++j) {
+        const double kj = taps[j];
+        const double *pj = pp + j;
+        for (int64_t t = 0; t < T; ++t) {
+            const double prod = kj * pj[t];
+            acc[t] = acc[t] + prod;
+        }
+    }
+}
+
 // sanitize_smooth_formant's repair (SillySampler.py:264-279) on fp32 values x[0..T): returns false when every value is bad
 bool repair_track(float *x, int64_t T, float min_hz, float max_hz, scratch &s)
 {
@@ -447,25 +466,24 @@ void plan_one(const goofer_plan_request &r, int hop, int trim_rows, const double
             std::vector<double> &pad = s.pad;
             pad.resize((size_t)(T_full + 2 * gradius));
             const int64_t period = T_full > 1 ? 2 * (T_full - 1) : 1;
+            // numpy 'reflect' as a periodic map; one reflection covers every index when the radius is below the track length
+            // (two 64-bit divisions per element were half of this function's time)
+            const bool near = gradius < T_full;
             for (int64_t q = -gradius; q < T_full + gradius; ++q) {
-                int64_t m = T_full > 1 ? ((q % period) + period) % period : 0;
-                m = m < T_full ? m : period - m;
+                int64_t m;
+                if (T_full <= 1) m = 0;
+                else if (near) m = q < 0 ? -q : (q >= T_full ? period - q : q);
+                else {
+                    m = ((q % period) + period) % period;
+                    m = m < T_full ? m : period - m;
+                }
                 pad[q + gradius] = all_bad ? 300.0 : (double)wp[m];
             }
             // taps outside, frames inside: every frame still adds its products in ascending tap order (the sums are the same
             // bits), and the inner loop is a plain vector loop over t instead of a reduction over j
             std::vector<double> &acc = s.tmp;
             acc.resize((size_t)T_env);
-            const double *pp = pad.data();
-            for (int64_t t = 0; t < T_env; ++t) acc[t] = gtaps[0] * pp[t];
-            for (int j = 1; j < 2 * gradius + 1; ++j) {
-                const double kj = gtaps[j];
-                const double *pj = pp + j;
-                for (int64_t t = 0; t < T_env; ++t) {
-                    const double prod = kj * pj[t];
-                    acc[t] = acc[t] + prod;
-                }
-            }
+            fir_rows(pad.data(), gtaps, 2 * gradius + 1, T_env, acc.data());
             for (int64_t t = 0; t < T_env; ++t) o.fst[(size_t)t * 4 + c] = (float)acc[t];
         }
         if (have) {
@@ -519,8 +537,22 @@ static int run_threads(int nt, const std::function<void(int)> &fn)
     return GOOFER_OK;
 }
 
+// What the worker threads produce: per note its geometry and where its rows sit in the buffers of the thread that planned it.
+// (A vector triple per note was 3 x n_notes allocations — and as many frees on the calling thread — per batch.)
+struct thread_rows {
+    std::vector<tap4> taps;
+    std::vector<double> F;
+    std::vector<float> fst;
+};
+struct planned {
+    std::vector<goofer_plan_geometry> geo;
+    std::vector<int64_t> at;           // first row of the note inside its thread's buffers
+    std::vector<thread_rows> rows;     // [nt]
+    int nt = 1;
+};
+
 static int plan_all(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps, int gauss_radius,
-                    int n_threads, std::vector<note_out> &notes, int &nt)
+                    int n_threads, planned &P)
 {
     if (!req || n_notes < 0 || hop <= 0 || !gauss_taps || gauss_radius < 0) return GOOFER_EINVAL;
     for (int i = 0; i < n_notes; ++i) {
@@ -542,38 +574,56 @@ static int plan_all(const goofer_plan_request *req, int n_notes, int hop, int tr
         for (int c = 0; c < 4; ++c)
             if (q.track_len[c] > 0 && !q.tracks[c]) return GOOFER_EINVAL;
     }
-    nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
     nt = std::max(1, std::min(nt, (n_notes + 31) / 32));
+    P.nt = nt;
     try {
-        notes.resize((size_t)n_notes);
+        P.geo.resize((size_t)n_notes);
+        P.at.assign((size_t)n_notes, 0);
+        P.rows.resize((size_t)nt);
     } catch (...) {
         return GOOFER_ENOMEM;
     }
-    const int nth = nt;
     return run_threads(nt, [&](int t) {
         std::fesetround(FE_TONEAREST);
         scratch s;
-        for (int i = t; i < n_notes; i += nth) plan_one(req[i], hop, trim_rows, gauss_taps, gauss_radius, notes[i], s);
+        note_out o;                                            // re-used from note to note: its vectors keep their capacity
+        thread_rows &R = P.rows[(size_t)t];
+        const size_t guess = (size_t)((n_notes + nt - 1) / nt) * 224;
+        R.taps.reserve(guess);
+        R.F.reserve(guess * 4);
+        R.fst.reserve(guess * 4);
+        for (int i = t; i < n_notes; i += nt) {
+            plan_one(req[i], hop, trim_rows, gauss_taps, gauss_radius, o, s);
+            P.geo[(size_t)i] = o.g;
+            P.at[(size_t)i] = (int64_t)R.taps.size();
+            if (o.g.status != 0) continue;
+            const size_t T = (size_t)o.g.n_out_rows;
+            R.taps.insert(R.taps.end(), o.taps.begin(), o.taps.begin() + T);
+            R.F.insert(R.F.end(), o.F.begin(), o.F.begin() + 4 * T);
+            R.fst.insert(R.fst.end(), o.fst.begin(), o.fst.begin() + 4 * T);
+        }
     });
 }
 
-// rows of the planned notes into four arrays (any of them may be the caller's pinned staging memory)
-static int gather_rows(const std::vector<note_out> &notes, int nt, int32_t *tap_idx, double *tap_w, double *F, float *fst)
+// rows of the planned notes into four arrays (any of them may be the caller's pinned staging memory); geo[i].tap_off = first row
+static int gather_rows(const planned &P, const goofer_plan_geometry *geo, int32_t *tap_idx, double *tap_w, double *F, float *fst)
 {
-    const int n_notes = (int)notes.size();
+    const int n_notes = (int)P.geo.size(), nt = P.nt;
     return run_threads(nt, [&](int t) {
+        const thread_rows &R = P.rows[(size_t)t];
         for (int i = t; i < n_notes; i += nt) {
-            const note_out &o = notes[i];
-            if (o.g.status != 0) continue;
-            const int64_t r0 = o.g.tap_off, T = o.g.n_out_rows;
+            const goofer_plan_geometry &g = geo[i];
+            if (g.status != 0) continue;
+            const int64_t r0 = g.tap_off, T = g.n_out_rows, a = P.at[(size_t)i];
             for (int64_t q = 0; q < T; ++q)
                 for (int c = 0; c < 4; ++c) {
-                    tap_idx[(size_t)(r0 + q) * 4 + c] = o.taps[q].i[c];
-                    tap_w[(size_t)(r0 + q) * 4 + c] = o.taps[q].w[c];
+                    tap_idx[(size_t)(r0 + q) * 4 + c] = R.taps[(size_t)(a + q)].i[c];
+                    tap_w[(size_t)(r0 + q) * 4 + c] = R.taps[(size_t)(a + q)].w[c];
                 }
             if (T > 0) {
-                std::memcpy(&F[(size_t)r0 * 4], o.F.data(), (size_t)T * 4 * sizeof(double));
-                std::memcpy(&fst[(size_t)r0 * 4], o.fst.data(), (size_t)T * 4 * sizeof(float));
+                std::memcpy(&F[(size_t)r0 * 4], &R.F[(size_t)a * 4], (size_t)T * 4 * sizeof(double));
+                std::memcpy(&fst[(size_t)r0 * 4], &R.fst[(size_t)a * 4], (size_t)T * 4 * sizeof(float));
             }
         }
     });
@@ -584,27 +634,25 @@ int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop,
 {
     if (!out) return GOOFER_EINVAL;
     *out = nullptr;
-    std::vector<note_out> notes;
-    int nt = 1;
-    int rc = plan_all(req, n_notes, hop, trim_rows, gauss_taps, gauss_radius, n_threads, notes, nt);
-    if (rc) return rc;
     goofer_host_plans *h = nullptr;
     try {
+        planned P;
+        int rc = plan_all(req, n_notes, hop, trim_rows, gauss_taps, gauss_radius, n_threads, P);
+        if (rc) return rc;
         h = new (std::nothrow) goofer_host_plans;
         if (!h) return GOOFER_ENOMEM;
-        h->geo.resize((size_t)n_notes);
+        h->geo = P.geo;
         int64_t rows = 0;
         for (int i = 0; i < n_notes; ++i) {
-            notes[i].g.tap_off = rows;
-            h->geo[i] = notes[i].g;
-            if (notes[i].g.status == 0) rows += notes[i].g.n_out_rows;
+            h->geo[i].tap_off = rows;
+            if (h->geo[i].status == 0) rows += h->geo[i].n_out_rows;
         }
         h->rows = rows;
         h->tap_idx.resize((size_t)rows * 4);
         h->tap_w.resize((size_t)rows * 4);
         h->F.resize((size_t)rows * 4);
         h->fst.resize((size_t)rows * 4);
-        if ((rc = gather_rows(notes, nt, h->tap_idx.data(), h->tap_w.data(), h->F.data(), h->fst.data()))) {
+        if ((rc = gather_rows(P, h->geo.data(), h->tap_idx.data(), h->tap_w.data(), h->F.data(), h->fst.data()))) {
             delete h;
             return rc;
         }
@@ -625,19 +673,22 @@ int goofer_host_plan_into(const goofer_plan_request *req, int n_notes, int hop, 
                           double *tap_w, double *formants, float *fst_tracks, int64_t *rows_out)
 {
     if (!geometry || !rows_out || row_capacity < 0 || (row_capacity > 0 && (!tap_idx || !tap_w || !formants || !fst_tracks))) return GOOFER_EINVAL;
-    std::vector<note_out> notes;
-    int nt = 1;
-    int rc = plan_all(req, n_notes, hop, trim_rows, gauss_taps, gauss_radius, n_threads, notes, nt);
-    if (rc) return rc;
-    int64_t rows = 0;
-    for (int i = 0; i < n_notes; ++i) {
-        notes[i].g.tap_off = rows;
-        geometry[i] = notes[i].g;
-        if (notes[i].g.status == 0) rows += notes[i].g.n_out_rows;
+    try {
+        planned P;
+        int rc = plan_all(req, n_notes, hop, trim_rows, gauss_taps, gauss_radius, n_threads, P);
+        if (rc) return rc;
+        int64_t rows = 0;
+        for (int i = 0; i < n_notes; ++i) {
+            geometry[i] = P.geo[(size_t)i];
+            geometry[i].tap_off = rows;
+            if (geometry[i].status == 0) rows += geometry[i].n_out_rows;
+        }
+        *rows_out = rows;
+        if (rows > row_capacity) return 1;
+        return gather_rows(P, geometry, tap_idx, tap_w, formants, fst_tracks);
+    } catch (...) {
+        return GOOFER_ENOMEM;
     }
-    *rows_out = rows;
-    if (rows > row_capacity) return 1;
-    return gather_rows(notes, nt, tap_idx, tap_w, formants, fst_tracks);
 }
 
 int goofer_host_plans_view(const goofer_host_plans *h, const goofer_plan_geometry **geometry, int64_t *rows, const int32_t **tap_idx,

@@ -47,6 +47,7 @@ if "--prof" in sys.argv:
     S._GEO_CACHE.clear()
     pr = cProfile.Profile()
     pr.enable()
-    once()
+    for _ in range(5):
+        once()
     pr.disable()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(40)
