@@ -72,7 +72,7 @@ template <int M> struct stem_cfg {
     static constexpr size_t wave_bytes = sizeof(float2) * fft_cfg<M>::BUF + sizeof(double) * KN;
     template <int NTAB, bool WIN> static constexpr size_t table_bytes()
     {
-        return sizeof(float2) * (4 * M + fft_tw_tabs<M>::TOTAL) + sizeof(float) * (NTAB * ROWF + (WIN ? NF : 0));
+        return sizeof(float2) * (4 * M + fft_tw_tabs<M>::TOTAL) + sizeof(float) * (NTAB * ROWF + (WIN ? NF : 0) + 4 * G * WAVE);
     }
     template <int NTAB, bool WIN> static constexpr size_t lds_bytes() { return table_bytes<NTAB, WIN>() + WAVES_PER_BLOCK * wave_bytes; }
     static_assert(wave_bytes % 16 == 0, "16-byte aligned LDS carving");
@@ -148,14 +148,17 @@ struct frame_block {
 #define FB_BASE(fb, idx) ((int64_t)(((uint64_t)(uint32_t)FB_GET(fb, base_hi, idx) << 32) | (uint32_t)FB_GET(fb, base_lo, idx)))
 
 // Shared state of a walker wave: tables, per-lane constants, the note it is in.
-template <int M, int NTAB, bool WIN> struct walker {
+template <int M, int NTAB, bool WIN, bool WS_LDS = false> struct walker {
     using C = stem_cfg<M>;
     static constexpr int R = C::R, G = C::G, NF = C::NF, HOP = C::HOP, B = C::B;
     float2 *tw, *wct, *wsc, *wsv, *buf, *tw1, *tw2;
-    float *win, *tab;
+    float *win, *tab, *wst;                    // wst[(2 g + c) * 64 + lane]: summed squared window of the lane's hop sample (g, c) on interior
+                                               // hops, [+ 2 G * 64]: its reciprocal — WS_LDS: read from this table where they are used
+                                               // (the harmonic walker: eight registers towards its third wave per SIMD), else copied
+                                               // into registers once (the noise walker, which has no third wave to gain)
+    float ws_r[G][2], rws_r[G][2];
     double *kbuf;
     int lane;
-    float ws_c[G][2], rws_c[G][2];             // summed squared window of this lane's hop samples (interior hops) and 1 / it
     // note state (wave-uniform)
     int note = -1, n = 0, T = 0, out_len = 0;
     int64_t base = 0;
@@ -171,6 +174,7 @@ template <int M, int NTAB, bool WIN> struct walker {
         tw2 = tw1 + fft_tw_tabs<M>::N1;
         tab = reinterpret_cast<float *>(tw2 + fft_tw_tabs<M>::N2);
         win = tab + NTAB * C::ROWF;
+        wst = win + (WIN ? NF : 0);
         const float *tsrc[3] = {t0, t1, t2};
         for (int i = threadIdx.x; i < C::ROWF; i += blockDim.x) {
             const int k = i < B ? i : B - 1;
@@ -192,6 +196,21 @@ template <int M, int NTAB, bool WIN> struct walker {
         }
         if (WIN)
             for (int i = threadIdx.x; i < NF; i += blockDim.x) win[i] = g_win[i];
+        if (threadIdx.x < WAVE) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int j = 2 * ((int)threadIdx.x + WAVE * g) + c;
+                    float ws = 0.f;
+                    for (int q = (NF - 1 - j) / HOP; q >= 0; --q) {       // ascending frame order = descending offset
+                        const float wv = g_win[j + q * HOP];
+                        ws += wv * wv;
+                    }
+                    wst[(2 * g + c) * WAVE + threadIdx.x] = ws;
+                    wst[(2 * G + 2 * g + c) * WAVE + threadIdx.x] = 1.0f / ws;
+                }
+        }
         __syncthreads();
         fill_tw_tabs<M>(tw1, tw2, tw);
         __syncthreads();
@@ -204,16 +223,13 @@ template <int M, int NTAB, bool WIN> struct walker {
         for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int j = 2 * (lane + WAVE * g) + c;
-                float ws = 0.f;
-                for (int q = (NF - 1 - j) / HOP; q >= 0; --q) {       // ascending frame order = descending offset
-                    const float w = g_win[j + q * HOP];
-                    ws += w * w;
-                }
-                ws_c[g][c] = ws;
-                rws_c[g][c] = 1.0f / ws;
+                ws_r[g][c] = WS_LDS ? 0.f : wst[(2 * g + c) * WAVE + lane];
+                rws_r[g][c] = WS_LDS ? 0.f : wst[(2 * G + 2 * g + c) * WAVE + lane];
             }
     }
+
+    __device__ __forceinline__ float ws_of(int g, int c) const { return WS_LDS ? wst[(2 * g + c) * WAVE + lane] : ws_r[g][c]; }
+    __device__ __forceinline__ float rws_of(int g, int c) const { return WS_LDS ? wst[(2 * G + 2 * g + c) * WAVE + lane] : rws_r[g][c]; }
 
     // run of frames [f0, f1) of this wave; fs = first frame to transform (the halo in front of a run that starts inside a note)
     __device__ __forceinline__ bool range(int64_t total_frames, int run, const int *frame_note, const int64_t *frame_off, int64_t &fs,
@@ -638,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
                         const int i = i0 + c;
                         if (i < w.out_len) {
                             if (inner) {
-                                const float ws = w.ws_c[g][c], rw = w.rws_c[g][c];
+                                const float ws = w.ws_of(g, c), rw = w.rws_of(g, c);
                                 if (ws > 1e-9f) { xu[c] = div_by(xu[c], ws, rw); xb[c] = div_by(xb[c], ws, rw); }
                             } else {
                                 const float ws = w.partial_ws(h, g, c, NCOLD(g_win));
@@ -676,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
 // `env` holds the harmonic envelope rows as the shaping step needs them: already warped (k_warp_bins, one row per frame)
 // or, when no note of the batch warps, the source rows addressed through row_src.
 template <int M>
-__global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ pulse, const float *__restrict__ env, int ld,
+__global__ __launch_bounds__(256, 3) void k_harm_stem(const float *__restrict__ pulse, const float *__restrict__ env, int ld,
                                                       const int64_t *__restrict__ row_src, int64_t total_frames,
                                                       const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
                                                       const int64_t *__restrict__ sample_off, const float2 *__restrict__ picks,
@@ -690,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
     constexpr int R = C::R, G = C::G, HOP = C::HOP, B = C::B, PER = C::PER, ROWF = C::ROWF;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr float t5[5] = STEM_T5;
-    walker<M, 3, true> w;
+    walker<M, 3, true, true> w;
     w.init(smem, g_tw, g_twh, g_win, g_winb, freqs, boost, bright);
     const int lane = w.lane;
     const float *t_fq = w.tab, *t_bo = w.tab + ROWF, *t_br = w.tab + 2 * ROWF;
@@ -699,11 +715,14 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
     frame_block fb;
     fb.load(fs, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
 
-    // raw sample pairs (reflect-padded at the note ends, GOOFER.py:358-360) and the envelope row of the next frame are in
-    // flight while the current frame is transformed
+    // Three waves per SIMD (168 registers): the frame's inputs — raw sample pairs (reflect-padded at the note ends,
+    // GOOFER.py:358-360) and the envelope row — are fetched at the head of the frame that uses them.  Round 3 held the NEXT
+    // frame's 25 values in registers across the whole frame (two waves per SIMD: 221 registers); at that occupancy the prefetch
+    // bought nothing (0.525 ms with and without), and without it, with the window sums in an LDS table, the kernel fits a third
+    // wave (0.525 -> 0.47 ms: a lone wave spends three quarters of its time waiting on its own dependency chain).
     float2 raw[R];
     float ev[PER];
-    auto fetch = [&](int64_t f, int idx) {
+    auto fetch = [&](int idx) {
         const int nn = FB_GET(fb, n, idx);
         const int start = FB_GET(fb, t, idx) * HOP - M;            // first sample of the frame, un-padded coordinates
         const float *xs = pulse + FB_BASE(fb, idx);
@@ -745,25 +764,22 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
 #pragma unroll
     for (int q = 0; q < 4; ++q) ec[q] = g_edge[q * WAVE + lane];
 
-    // one iteration in front of the run only starts the first fetch, so that the fetch code exists once
-    for (int64_t f = fs - 1; f < f1; ++f) {
+    for (int64_t f = fs; f < f1; ++f) {
         float2 X[PER];
         float evc[PER];
-        int t = 0;
-        float f0f = 0.f;
-        bool voiced = false;
-        if (f >= fs) {
-            const int idx = (int)(f - fb.blk0);
-            t = FB_GET(fb, t, idx);
-            if (FB_GET(fb, note, idx) != w.note) {
-                w.enter_note(fb, idx);
-                const goofer_note_params &p = params[w.note];
-                apply_bright = p.apply_brightness;
-                cut_below = p.cut_below_f0;
-            }
-            f0f = FB_GETF(fb, f0, idx);
-            voiced = apply_bright && FB_GETF(fb, mk, idx) > 0.f;
-
+        if (!fb.holds(f)) fb.load(f, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
+        const int idx = (int)(f - fb.blk0);
+        fetch(idx);
+        const int t = FB_GET(fb, t, idx);
+        if (FB_GET(fb, note, idx) != w.note) {
+            w.enter_note(fb, idx);
+            const goofer_note_params &p = params[w.note];
+            apply_bright = p.apply_brightness;
+            cut_below = p.cut_below_f0;
+        }
+        const float f0f = FB_GETF(fb, f0, idx);
+        const bool voiced = apply_bright && FB_GETF(fb, mk, idx) > 0.f;
+        {
             // 1. windowed frame -> complex FFT; the lane's points Z[lane + 64 t] stay in registers
             float2 z[R];
             {
@@ -791,11 +807,6 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
             X[R] = make_float2(z[0].x - z[0].y, 0.f);                // Nyquist bin from Z[0] (lane 0)
             wave_lds_sync();
         }
-        if (f + 1 < f1) {                                            // raw pairs and row are consumed: start the next frame's
-            if (!fb.holds(f + 1)) fb.load(f + 1, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
-            fetch(f + 1, (int)(f + 1 - fb.blk0));
-        }
-        if (f < fs) continue;
 
         // 3. shaping (GOOFER.py:1102-1144); 1 / max(|S| + 1e-8) commutes with the linear chain and is applied by k_note_finish
         const bool hp_low_only = t_fq[WAVE] - f0f > 100.0f;
@@ -853,8 +864,8 @@ __global__ __launch_bounds__(256, 2) void k_harm_stem(const float *__restrict__ 
                     for (int c = 0; c < 2; ++c) {
                         if (i0 + c < w.out_len) {
                             if (inner) {
-                                const float ws = w.ws_c[g][c];
-                                if (ws > 1e-9f) x[c] = div_by(x[c], ws, w.rws_c[g][c]);
+                                const float ws = w.ws_of(g, c);
+                                if (ws > 1e-9f) x[c] = div_by(x[c], ws, w.rws_of(g, c));
                             } else {
                                 const float ws = w.partial_ws(h, g, c, g_win);
                                 if (ws > 1e-9f) x[c] /= ws;
