@@ -91,6 +91,13 @@ int launch_note_steps(goofer_ctx *, const int64_t *, int, double *, hipStream_t)
 int launch_mask_upsample(goofer_ctx *, const double *, const int64_t *, int, int64_t, double *, bool, float *, hipStream_t);
 bool stems_supported(const goofer_plan_t &);
 bool ola_split_supported(const goofer_plan_t &);
+bool ring_walkers_supported(const goofer_plan_t &);
+bool rfft_shape_supported(const goofer_plan_t &);
+int launch_rfft_shape(goofer_ctx *, const float *, const int64_t *, const int64_t *, const int *, int64_t, float2 *, int, const float *,
+                      const float *, const float *, int, const goofer_note_params *, float *, const int64_t *, const double *, hipStream_t);
+int launch_stem_ring(goofer_ctx *, int, const float *, const float *, const float *, bool, const float *, int, const int64_t *, const double *,
+                     int64_t, const int *, const int64_t *, const int64_t *, const float2 *, const goofer_note_params *, uint64_t,
+                     const double *, const double *, float *, float *, float *, float *, const unsigned char *, hipStream_t);
 int launch_irfft_ola1(goofer_ctx *, const float2 *, const float2 *, const float2 *, int, int64_t, const int *, const int64_t *,
                       const int64_t *, int, const double *, double *, const goofer_note_params *, float *, float *, float *,
                       const unsigned char *, hipStream_t);
@@ -301,7 +308,9 @@ struct arena {
 
 // spectra: the one-kernel-per-step pipeline will run (complex spectra + windowed frames of the three stems in HBM: 24 KB per
 // frame); the stem walkers need none of it.  subharm: the 'sg' trackers' fp64 phase increments.
-static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t samples, int64_t notes, bool spectra = true, bool subharm = true)
+// spectra: 1 = the one-kernel-per-step pipeline (three spectra, windowed frames, the noise envelope), 0 = the stem walkers,
+// 2 = the ring walkers of n_fft 2048 (no spectra; the per-frame skip bits stay)
+static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t samples, int64_t notes, int spectra = 1, bool subharm = true)
 {
     size_t ldc = spec_stride(p.n_bins), ld = (p.n_bins + 3) & ~3;
     size_t b = 0;
@@ -316,11 +325,11 @@ static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t sampl
     add(notes * sizeof(int32_t) + 64);            // onset counts
     add(64);                                      // overflow flag
     add(samples * sizeof(float));                 // pulse
-    if (spectra) {
+    if (spectra == 1) {
         add(3 * frames * ldc * sizeof(float2));       // S_h, S_uv, S_br
         add(3 * frames * (size_t)p.n_fft * sizeof(float));  // windowed time frames (three stems in the fused path)
     }
-    add((spectra ? 2 : 1) * frames * ld * sizeof(float));   // env_h (, env_n)
+    add((spectra == 1 ? 2 : 1) * frames * ld * sizeof(float));   // env_h (, env_n)
     add((samples / 4 + notes + 16) * sizeof(double));  // smoothed decimated mask
     add(2 * notes * sizeof(float) + 64);          // note_mag, note_peak
     add(2 * notes * sizeof(double) + 64);         // per-note linspace steps
@@ -614,7 +623,8 @@ int goofer_reserve(goofer_ctx *ctx, int64_t max_frames, int64_t max_samples, int
     if (!ctx) return GOOFER_EINVAL;
     if (!ctx->plan.n_fft) return goofer_fail(ctx, GOOFER_ENOPLAN, "goofer_plan first");
     const bool walkers = ctx->stems && ctx->ola_fused && stems_supported(ctx->plan);   // else: room for the spectra of the one-kernel-per-step path
-    return ensure_scratch(ctx, scratch_need(ctx->plan, max_frames, max_samples, max_notes, !walkers, !walkers));
+    const bool ring = !walkers && ctx->stems && ctx->ola_fused && ctx->ring_walkers && ring_walkers_supported(ctx->plan) && (ctx->plan.hop % 2 == 0);
+    return ensure_scratch(ctx, scratch_need(ctx->plan, max_frames, max_samples, max_notes, walkers ? 0 : (ring ? 2 : 1), !walkers));
 }
 
 // copy one plan table to host memory (tests / debugging); which: 0 window 1 freqs 2 boost 3 bright_h
@@ -795,6 +805,8 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "fused_ola")) { ctx->ola_fused = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "overlap")) { ctx->overlap = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "stems")) { ctx->stems = value != 0; return GOOFER_OK; }
+    if (!strcmp(name, "rfft_shape")) { ctx->rfft_shape = value != 0; return GOOFER_OK; }   // n_fft 2048: 0 = k_rfft_frames + k_harm_shape (A/B)
+    if (!strcmp(name, "ring_walkers")) { ctx->ring_walkers = value != 0; return GOOFER_OK; }   // n_fft 2048: 0 = the spectra-in-HBM kernels (A/B)
     if (!strcmp(name, "skip_zero")) { ctx->skip_zero = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "td_blur")) { ctx->td_blur = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "walk_lds_kb")) { ctx->walk_lds_kb = value < 32 ? 32 : (value > 160 ? 160 : value); return GOOFER_OK; }
@@ -1312,7 +1324,11 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                              (sub_on ? ((size_t)N * (sizeof(double) + sizeof(float)) + 3 * 256 * (size_t)n + 8192) : 0);
     // which pipeline will run decides what the arena holds (the same predicate as `stem_path` below)
     const bool walkers = ctx->stems && ctx->ola_fused && (p.hop % 2 == 0) && stems_supported(p) && !sub_on && !jit_vol;
-    int rc = ensure_scratch(ctx, scratch_need(p, F, N, n, !walkers, sub_on) + (size_t)F * (ld - ((p.n_bins + 3) & ~3)) * 2 * sizeof(float) + jit_bytes);
+    // n_fft 2048: one stem per wave (two waves per SIMD instead of one), then the per-note finish of the stem-split path
+    const bool ola_split = !walkers && ctx->ola_fused && (p.hop % 2 == 0) && ctx->stems && ola_split_supported(p) && !jit_vol;
+    // ... and with the waves making the spectra themselves (stems_ring.hip): nothing of a frame but its inputs and its samples in HBM
+    const bool ring_path = ola_split && ctx->ring_walkers && ring_walkers_supported(p);
+    int rc = ensure_scratch(ctx, scratch_need(p, F, N, n, walkers ? 0 : (ring_path ? 2 : 1), sub_on) + (size_t)F * (ld - ((p.n_bins + 3) & ~3)) * 2 * sizeof(float) + jit_bytes);
     if (rc) return rc;
     arena a{(char *)ctx->scratch, ctx->scratch_bytes, 0};
     int *frame_note = a.take<int>(F);
@@ -1325,7 +1341,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     int32_t *onset_cnt = a.take<int32_t>(n + 16);
     int32_t *ovf = ctx->ovf_flag;
     float *pulse = a.take<float>(N);
-    const size_t spec_n = walkers ? 0 : (size_t)F * ldc, frame_n = walkers ? 0 : (size_t)F * p.n_fft;
+    const size_t spec_n = (walkers || ring_path) ? 0 : (size_t)F * ldc, frame_n = (walkers || ring_path) ? 0 : (size_t)F * p.n_fft;
     float2 *S_h = a.take<float2>(spec_n);
     float2 *S_uv = a.take<float2>(spec_n);
     float2 *S_br = a.take<float2>(spec_n);
@@ -1333,12 +1349,10 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     float *frames_u = a.take<float>(frame_n);
     float *frames_b = a.take<float>(frame_n);
     float *env_h = a.take<float>((size_t)F * ld);
-    float *env_n = a.take<float>(walkers ? 0 : (size_t)F * ld);
+    float *env_n = a.take<float>((walkers || ring_path) ? 0 : (size_t)F * ld);
     double *short_s = a.take<double>(N / 4 + n + 16);
     float *note_mag = a.take<float>(2 * (size_t)n + 16);
     double *note_steps = a.take<double>(2 * (size_t)n + 16);
-    // n_fft 2048: one stem per wave (two waves per SIMD instead of one), then the per-note finish of the stem-split path
-    const bool ola_split = !walkers && ctx->ola_fused && (p.hop % 2 == 0) && ctx->stems && ola_split_supported(p) && !jit_vol;
     // ... with the exact sparsity of the noise stems decided per frame up front (k_frame_skip)
     const bool skip_frames = ola_split && ctx->skip_zero && ctx->overlap && !sub_on && p.hop <= 512;
     unsigned char *hop_flat = skip_frames ? a.take<unsigned char>((size_t)F + (size_t)((p.n_fft + p.hop - 1) / p.hop) * n + 16) : nullptr;
@@ -1372,7 +1386,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         const void *ptrs[] = {frame_note, row_src, f0s, pulse, S_h, S_uv, S_br, frames, env_h, env_n, short_s, note_mag, note_peak, onset_cnt};
         size_t bytes[] = {F * sizeof(int), F * sizeof(int64_t), N * sizeof(float), N * sizeof(float), spec_n * sizeof(float2),
                           spec_n * sizeof(float2), spec_n * sizeof(float2), frame_n * sizeof(float),
-                          (size_t)F * ld * sizeof(float), walkers ? 0 : (size_t)F * ld * sizeof(float), (N / 4 + n) * sizeof(double),
+                          (size_t)F * ld * sizeof(float), (walkers || ring_path) ? 0 : (size_t)F * ld * sizeof(float), (N / 4 + n) * sizeof(double),
                           n * sizeof(float), n * sizeof(float), n * sizeof(int32_t)};
         for (int i = 0; i < 14; ++i) { ctx->dbg_ptr[i] = ptrs[i]; ctx->dbg_bytes[i] = bytes[i]; }
         ctx->dbg_ptr[14] = onset_idx; ctx->dbg_bytes[14] = (N / 2 + 16 * (size_t)n) * sizeof(int32_t);
@@ -1584,6 +1598,18 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                 if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
                 if ((rc = launch_frame_skip(ctx, short_s, N / 4 + n, b->sample_off, b->frame_off, frame_note, n, F, knot_eq, hop_flat, frame_skip, st))) return rc;
             }
+            if (ring_path) {
+                // the two noise stems straight to samples beside the pulse chain (stems_ring.hip): needs the smoothed mask first
+                if (!skip_frames && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
+                if (!picks_on && (rc = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return rc;
+                if ((rc = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return rc;
+                MARK_Q(0);
+                if ((rc = launch_stem_ring(ctx, 2, pulse, b->env, b->env_noise ? b->env_noise : b->env, b->env_noise != nullptr, b->phi, ld,
+                                           row_src, b->formants, F, frame_note, b->frame_off, b->sample_off, picks, b->params, b->seed,
+                                           short_s, note_steps, note_mag, b->harm, b->uv, b->bre, frame_skip, st)))
+                    return rc;
+                MARK_Q(1);
+            } else {
             if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
                                            b->env_noise ? b->env_noise : b->env, b->phi, ld, b->params, b->seed, row_src,
                                            b->env_noise != nullptr, frame_skip, st)))
@@ -1591,6 +1617,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
             MARK_Q(0);
             if (!skip_frames && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
             MARK_Q(1);
+            }
         }
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     }
@@ -1653,12 +1680,50 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         ctx->frame_picks = nullptr;
         return GOOFER_OK;
     }
+    if (ring_path) {
+        // Ring walkers (stems_ring.hip): the harmonic stem from the pulse train to samples — and, when nothing ran beside the pulse
+        // chain, the two noise stems in the same launch.  No spectrum in HBM.
+        MARK();   // 6..12
+        MARK();
+        MARK();
+        MARK();
+        MARK();
+        MARK();
+        if (!side_on) {
+            if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
+            if (!picks_on && (rc = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return rc;
+            if ((rc = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return rc;
+        }
+        MARK();
+        MARK();   // 13: the walkers
+        if ((rc = launch_stem_ring(ctx, side_on ? 1 : 3, pulse, b->env, b->env_noise ? b->env_noise : b->env, b->env_noise != nullptr, b->phi,
+                                   ld, row_src, b->formants, F, frame_note, b->frame_off, b->sample_off, picks, b->params, b->seed, short_s,
+                                   note_steps, note_mag, b->harm, b->uv, b->bre, nullptr, st)))
+            return rc;
+        MARK();   // 14
+        if ((rc = launch_note_finish(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, b->params, note_mag, note_peak,
+                                     !(b->mix_only && (b->mix || b->rec)), st)))
+            return rc;
+        MARK();   // 15..17 unused
+        MARK();
+        MARK();
+        MARK();   // end
+        if (pev) ctx->prof_steps++;
+        ctx->frame_picks = nullptr;
+        return GOOFER_OK;
+    }
     // spectra -> windowed time frames of the three stems
     {
         MARK();   // 6: framewise rFFT of the pulse train
-        if ((rc = launch_rfft_frames_mapped(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, st))) return rc;
+        // n_fft 2048: transform and shaping as one kernel (the unshaped spectrum never reaches HBM; option "rfft_shape" 0: apart)
+        const bool fused_shape = ctx->rfft_shape && rfft_shape_supported(p);
+        if (fused_shape) {
+            if ((rc = launch_rfft_shape(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, f0s, b->mask, b->env, ld, b->params,
+                                        note_mag, row_src, b->formants, st)))
+                return rc;
+        } else if ((rc = launch_rfft_frames_mapped(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, st))) return rc;
         MARK();   // 7
-        if ((rc = launch_harm_shape(ctx, S_h, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, b->env, ld, b->params,
+        if (!fused_shape && (rc = launch_harm_shape(ctx, S_h, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, b->env, ld, b->params,
                                     note_mag, row_src, b->formants, st)))
             return rc;
         MARK();   // 8

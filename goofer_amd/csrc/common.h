@@ -88,6 +88,9 @@ struct goofer_ctx {
     int finish_lds_kb = 0;        // LDS k_note_finish reserves per workgroup (0: none) — caps the notes in flight per CU
     int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
     bool mask_side = false;       // goofer_render_batch: the mask smoothing on the side stream in front of the pulse chain (option "mask_side"; measured: -0.4 %)
+    // n_fft 2048 (stems_ring.hip), both measured slower than the spectra-in-HBM kernels on BASELINE config 5 and off by default:
+    bool rfft_shape = false;    // the framewise rFFT and the harmonic shaping as one kernel (10.3 ms against 2.9 + 5.7 ms)
+    bool ring_walkers = false;  // the ring walkers: no spectrum in HBM (step 42.9 ms against 29.3 ms)
     bool harm_side = false;       // goofer_render_batch: the harmonic walker on the side stream, beside the noise walker (option "harm_side")
     int nt_mask = 1;              // non-temporal stores: 1 note_finish mix / rec (the final output: -0.7 % per step), 2 env_loop rows (measured: nothing)
     int nt_spectra = 1;           // framewise rFFT: spectrum rows leave as non-temporal stores (option "nt_spectra")
