@@ -340,7 +340,9 @@ def main():
                     "smaller batches fill the device worse, one 10 000-note batch makes the walk the critical path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inclusive", action="store_true")
-    ap.add_argument("--no-variants", action="store_true", help="skip the skip_zero-off / 30 %-unvoiced variants of the step")
+    ap.add_argument("--no-variants", action="store_true", help="skip the skip_zero-off / 30 %%-unvoiced variants of the step")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="goofer_set_option on the handle before anything runs (e.g. ring_walkers=1, rfft_shape=1: "
+                    "the fused n_fft-2048 alternatives); the line carries them as `options` and is not the headline configuration")
     ap.add_argument("--gather", action="store_true", help="also time the optional ragged gather of finished audio to rank 0 "
                     "(RCCL over xGMI; never part of `value`)")
     ap.add_argument("--rehearse", action="store_true", help="dress rehearsal of the multi-rank logic WITHOUT a GPU: gloo process "
@@ -377,6 +379,11 @@ def main():
     from goofer_amd.shard import assign_lpt, note_range, reduce_timing
 
     ctx = Context(local)
+    options = {}
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        ctx.set_option(name, int(val))
+        options[name] = int(val)
     job = args.job_notes > 0
     if job:
         # every rank derives the same assignment from the frame counts of the whole job: no communication
@@ -493,6 +500,8 @@ def main():
     # the sub-batches of a pass alternate; for the weak-scaling workload whole steps do.
     if world == 1 and not args.no_variants:
         ctx_b = Context(local)
+        for name, val in options.items():
+            ctx_b.set_option(name, val)
         if job:
             subs_b = [SamplerWorkload(ctx_b, args.config, ids[k:k + args.sub_batch]) for k in range(0, len(ids), args.sub_batch)]
         else:
@@ -641,6 +650,8 @@ def main():
             line["pcie_inclusive"] = pcie_leg(wl, elapsed / args.steps)
             if not args.no_host_inclusive:
                 line["host_inclusive"] = host_inclusive(wl, ctx, elapsed / args.steps)
+        if options:
+            line["options"] = options
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line))
