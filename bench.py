@@ -263,7 +263,8 @@ def host_inclusive(wl, ctx, step_s):
 
     from goofer_amd.render import SourceArena
     _warm = prepare()                                          # (a free staging block exists from here on: the workload's own batch holds one)
-    del _warm
+    run(_warm[0])                                              # ... and the allocator holds the outputs' blocks: first_batch measures the sample uploads,
+    del _warm                                                  # not four hipMallocs of 200 MB (25 ms on some boxes)
     wl.renderer.sources = SourceArena(ctx)                     # pass 0 uploads the batch's samples, the later passes find them resident
     best, first = None, None
     for k in range(4):

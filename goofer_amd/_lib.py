@@ -165,6 +165,7 @@ EXPORTS = {
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "goofer_host_plans_free": (None, [C.c_void_p]),
     "goofer_host_parse_floats": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "goofer_host_pack": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),
     "goofer_host_decode_bends": (C.c_int64, [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "goofer_smooth_mask_ds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p,
                                         C.c_void_p]),

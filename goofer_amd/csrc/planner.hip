@@ -820,4 +820,40 @@ int goofer_host_parse_floats(const char *text, const int64_t *text_off, int n, i
     return bad;
 }
 
+/* Host arrays back to back into one (pinned) block on several threads: piece i (nbytes[i] bytes at src[i]) lands at the sum of the
+ * sizes in front of it.  The voicing masks of a batch of fresh voicebank samples are 200 MB; one thread copies that into pinned
+ * memory at a third of the rate the DMA engine then moves it over PCIe.  The byte range is cut evenly over the threads.
+ * Returns the bytes written, or a negative error. */
+int64_t goofer_host_pack(const void *const *src, const int64_t *nbytes, int64_t count, void *dst, int64_t capacity, int threads)
+{
+    if (count < 0 || (count > 0 && (!src || !nbytes || !dst))) return GOOFER_EINVAL;
+    std::vector<int64_t> at;
+    try {
+        at.resize((size_t)count + 1);
+    } catch (...) {
+        return GOOFER_ENOMEM;
+    }
+    at[0] = 0;
+    for (int64_t i = 0; i < count; ++i) {
+        if (nbytes[i] < 0 || (nbytes[i] > 0 && !src[i])) return GOOFER_EINVAL;
+        at[(size_t)i + 1] = at[(size_t)i] + nbytes[i];
+    }
+    const int64_t total = at[(size_t)count];
+    if (total > capacity) return GOOFER_EINVAL;
+    int nt = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+    if (total < (int64_t)(4 << 20)) nt = 1;                   // not worth a thread start
+    const int64_t share = (total + nt - 1) / nt;
+    const int rc = run_threads(nt, [&](int t) {
+        const int64_t lo = (int64_t)t * share, hi = std::min(total, lo + share);
+        if (lo >= hi) return;
+        size_t i = (size_t)(std::upper_bound(at.begin(), at.end(), lo) - at.begin()) - 1;   // the piece byte `lo` is in
+        for (int64_t b = lo; b < hi; ++i) {
+            const int64_t end = std::min(hi, at[i + 1]);
+            if (end > b) std::memcpy((char *)dst + b, (const char *)src[i] + (b - at[i]), (size_t)(end - b));
+            b = end > b ? end : b;
+        }
+    });
+    return rc ? rc : total;
+}
+
 }  // extern "C"

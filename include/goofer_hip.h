@@ -373,6 +373,12 @@ int64_t goofer_host_decode_bends(const char *text, const int64_t *text_off, int 
  * strip_bang: skip leading '!' (the tempo argument).  Returns how many strings were not taken, or -1 on a null argument. */
 int goofer_host_parse_floats(const char *text, const int64_t *text_off, int n, int strip_bang, double *out, unsigned char *ok);
 
+/* Host arrays back to back into one block (pinned staging memory) on `threads` threads: piece i, nbytes[i] bytes at src[i], lands
+ * behind the pieces in front of it.  The upload path of fresh voicebank samples (goofer_amd/render.py SourceArena: the reference
+ * re-reads a sample's features from disk per note, GOOFER.py:1227-1262; here they go to HBM once).  Pure CPU code.  Returns the
+ * bytes written, or a negative error (GOOFER_EINVAL: more than `capacity` bytes, null pieces). */
+int64_t goofer_host_pack(const void *const *src, const int64_t *nbytes, int64_t count, void *dst, int64_t capacity, int threads);
+
 /* Synchronise the device and report errors the asynchronous batch calls detect on the device (today: a note with more
  * pulse onsets than its n / 2 + 16 onset slots, GOOFER.py:493 with f0 above sr / 2).  0, or GOOFER_EINVAL + goofer_last_error. */
 int goofer_check(goofer_ctx *ctx);

@@ -238,3 +238,26 @@ def test_plans_written_into_the_callers_arrays():
     with pytest.raises(S.StagingFull) as e:
         S.plan_native_into(rec, 256, True, geo, rows - 1, ti, tw, fo, fs, keep=(tracks, rec))
     assert e.value.args[0] == rows
+
+
+def test_host_pack_is_a_concatenation_on_any_thread_count():
+    """goofer_host_pack (the pinned-staging gather of the voicebank upload, render.SourceArena): pieces of any size, incl.
+    empty ones, land back to back; a block that is too small is refused."""
+    import ctypes as C
+    from goofer_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    sizes = [0, 1, 5, 4 << 20, 0, 3_000_001, 17, 2_500_000, 1]
+    pieces = [rng.integers(0, 255, n, dtype=np.uint8) for n in sizes]
+    want = np.concatenate(pieces)
+    n = len(pieces)
+    srcs = (C.c_void_p * n)(*[p.ctypes.data if p.size else None for p in pieces])
+    nbytes = (C.c_int64 * n)(*[p.nbytes for p in pieces])
+    for threads in (1, 2, 5, 8, 64):
+        dst = np.full(want.size + 64, 0xEE, np.uint8)
+        got = lib.goofer_host_pack(srcs, nbytes, n, C.c_void_p(dst.ctypes.data), dst.nbytes, threads)
+        assert got == want.size
+        assert np.array_equal(dst[:want.size], want) and np.all(dst[want.size:] == 0xEE), threads
+    dst = np.zeros(16, np.uint8)
+    assert lib.goofer_host_pack(srcs, nbytes, n, C.c_void_p(dst.ctypes.data), dst.nbytes, 4) < 0
+    assert lib.goofer_host_pack(None, None, 0, None, 0, 4) == 0
