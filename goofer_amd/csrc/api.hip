@@ -760,6 +760,10 @@ int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages)
     HIP_TRY(ctx, hipDeviceSynchronize());
     for (int s = 0; s < n_stages && s < PROF_STAGES; ++s) {
         double acc = 0.0;
+        if (ctx->prof_only >= 0 && s != ctx->prof_only) {                // (its events were not recorded)
+            ms_per_stage[s] = 0.0;
+            continue;
+        }
         for (int k = 0; k < ctx->prof_steps; ++k) {
             hipEvent_t *e = ctx->prof_ev + (size_t)k * (PROF_STAGES + 1);
             float ms = 0.f;
@@ -805,6 +809,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "fused_ola")) { ctx->ola_fused = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "overlap")) { ctx->overlap = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "stems")) { ctx->stems = value != 0; return GOOFER_OK; }
+    if (!strcmp(name, "prof_only")) { ctx->prof_only = value < 0 || value >= PROF_STAGES ? -1 : value; return GOOFER_OK; }   // stage index, -1: all
     if (!strcmp(name, "rfft_shape")) { ctx->rfft_shape = value != 0; return GOOFER_OK; }   // n_fft 2048: 0 = k_rfft_frames + k_harm_shape (A/B)
     if (!strcmp(name, "ring_walkers")) { ctx->ring_walkers = value != 0; return GOOFER_OK; }   // n_fft 2048: 0 = the spectra-in-HBM kernels (A/B)
     if (!strcmp(name, "skip_zero")) { ctx->skip_zero = value != 0; return GOOFER_OK; }
@@ -1415,13 +1420,19 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     hipEvent_t *pev = nullptr;
     if (ctx->prof_on && ctx->prof_steps < ctx->prof_cap) pev = ctx->prof_ev + (size_t)ctx->prof_steps * (PROF_STAGES + 1);
     int stage = 0;
+    // option "prof_only" = s: only the events stage s needs are recorded (bench.py's timed steps carry the dominant kernel's two
+    // events; the twenty records of the full breakdown cost 0.06 ms of a 2.3 ms step).  The two kernels launched beside the pulse
+    // chain on the caller's stream (stages 6 / 7 of the stem path, 9 / 12 of the other) are bracketed by the prof_main2 pair.
+    const int only = ctx->prof_only;
+    const bool want_q = only < 0 || only == 6 || only == 7 || only == 9 || only == 12;
 #define MARK_Q(q)                                                    \
     do {                                                             \
-        if (pev) HIP_TRY(ctx, hipEventRecord(ctx->prof_main2[(size_t)ctx->prof_steps * 2 + (q)], st)); \
+        if (pev && want_q) HIP_TRY(ctx, hipEventRecord(ctx->prof_main2[(size_t)ctx->prof_steps * 2 + (q)], st)); \
     } while (0)
 #define MARK()                                                       \
     do {                                                             \
-        if (pev && !(harm_side && (stage == 9 || stage == 10))) HIP_TRY(ctx, hipEventRecord(pev[stage], st)); \
+        if (pev && !(harm_side && (stage == 9 || stage == 10)) && (only < 0 || stage == only || stage == only + 1 || (stage == 5 && (only == 6 || only == 9)))) \
+            HIP_TRY(ctx, hipEventRecord(pev[stage], st));           \
         ++stage;                                                     \
     } while (0)
     bool harm_side = false;                                   // the harmonic walker runs on the side stream (its two marks are recorded there)
@@ -1532,7 +1543,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     if (side_on) {
         int rc2 = ensure_side_stream(ctx);
         if (rc2) return rc2;
-        if (pev) sev = ctx->prof_side + (size_t)ctx->prof_steps * 4;
+        if (pev && (only < 0 || (only >= 3 && only <= 5))) sev = ctx->prof_side + (size_t)ctx->prof_steps * 4;
         // the harmonic walker beside the noise walker: it needs the pulse signal (side stream), the warped rows and the frame maps
         // (caller's stream, both enqueued by now), nothing of the noise walker — on the caller's stream it only waited its turn
         harm_side = stem_path && ctx->warp_done && ctx->harm_side && !maps_side;
@@ -1580,11 +1591,11 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if (sev) HIP_TRY(ctx, hipEventRecord(sev[3], pst));
         if (harm_side) {
             HIP_TRY(ctx, hipStreamWaitEvent(pst, ctx->ev_maps, 0));
-            if (pev) HIP_TRY(ctx, hipEventRecord(pev[9], pst));
+            if (pev && (only < 0 || only == 9 || only == 8)) HIP_TRY(ctx, hipEventRecord(pev[9], pst));
             if ((rc = launch_harm_stem(ctx, pulse, ctx->warp_rows, ld, row_src, F, frame_note, b->frame_off, b->sample_off, picks, b->params,
                                        b->harm, note_mag, pst)))
                 return rc;
-            if (pev) HIP_TRY(ctx, hipEventRecord(pev[10], pst));
+            if (pev && (only < 0 || only == 9 || only == 10)) HIP_TRY(ctx, hipEventRecord(pev[10], pst));
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, pst));
         // meanwhile, on the caller's stream

@@ -110,6 +110,7 @@ struct goofer_ctx {
     int n_kstate = 0;
     // per-stage HIP-event timing of goofer_synth_batch (goofer_profile_begin/end)
     bool prof_on = false;
+    int prof_only = -1;           // >= 0: goofer_profile_begin .. end bracket this stage only (option "prof_only")
     int prof_steps = 0, prof_cap = 0;
     hipEvent_t *prof_ev = nullptr;      // [prof_cap][PROF_STAGES + 1]
     double *mask_taps = nullptr;  // device taps of the voicing-mask smoother, cached per sigma

@@ -113,6 +113,16 @@ class Context:
     def profile_begin(self, max_steps: int):
         self._check(self.lib.goofer_profile_begin(self.h, max_steps))
 
+    def profile_stage_names(self) -> list:
+        """Stage names by index for the pipeline the handle ran last (goofer_profile_stage_name_ex); '' = unused."""
+        return [self.lib.goofer_profile_stage_name_ex(self.h, i).decode() for i in range(18)]
+
+    def profile_only(self, stage=None):
+        """Bracket one stage only from the next profile_begin on (option "prof_only": two event records per step instead of
+        twenty); None: every stage again."""
+        idx = -1 if stage is None else self.profile_stage_names().index(stage)
+        self.set_option("prof_only", idx)
+
     def profile_end(self) -> dict:
         """{'steps': k, 'ms': {stage: summed milliseconds}} from HIP events on the launch stream."""
         ms = np.zeros(18, dtype=np.float64)
