@@ -267,24 +267,38 @@ def host_inclusive(wl, ctx, step_s):
     _warm = prepare()                                          # (a free staging block exists from here on: the workload's own batch holds one)
     run(_warm[0])                                              # ... and the allocator holds the outputs' blocks: first_batch measures the sample uploads,
     del _warm                                                  # not four hipMallocs of 200 MB (25 ms on some boxes)
-    wl.renderer.sources = SourceArena(ctx)                     # pass 0 uploads the batch's samples, the later passes find them resident
-    best, first = None, None
-    for k in range(4):
+    # "first": none of the batch's voicebank samples resident (fresh Source objects — loading them is the frontend's file read,
+    # outside the timer — and an empty arena); three trials, the fastest reported and all three listed: on some boxes the first
+    # trial spends 60 ms in the allocator growing the arena's two device arrays, which later trials find cached.
+    def one_pass():
         t0 = time.perf_counter()
         prep, dec_ms, prep_ms = prepare()
         t2 = time.perf_counter()
         run(prep)
         t3 = time.perf_counter()
-        cur = {"decode_ms": dec_ms, "plan_upload_ms": prep_ms, "step_and_download_ms": 1e3 * (t3 - t2),
-               "total_ms": 1e3 * (t3 - t0), "frames_per_s": prep["frames"] / (t3 - t0), "notes_per_s": len(raw) / (t3 - t0)}
-        if k == 0:
-            first = cur
-        elif best is None or cur["total_ms"] < best["total_ms"]:
+        return ({"decode_ms": dec_ms, "plan_upload_ms": prep_ms, "step_and_download_ms": 1e3 * (t3 - t2),
+                 "total_ms": 1e3 * (t3 - t0), "frames_per_s": prep["frames"] / (t3 - t0), "notes_per_s": len(raw) / (t3 - t0)}, prep["frames"])
+
+    import gc
+    gc.collect()
+    gc.freeze()                                                # a render server's usual setting: the objects of the set-up (thousands of
+                                                               # sources and plans in this process) are not traversed by later collections
+                                                               # (an unfrozen full collection in the middle of a batch is 50-100 ms here)
+    firsts = []
+    for _ in range(3):
+        srcs[:] = [Source.from_pack(s["env_pack"], s["f0"], s["mask"], s["formants"], s["sr"], s["y_len"]) for s, _, _ in raw]
+        wl.renderer.sources = SourceArena(ctx)
+        firsts.append(one_pass()[0])
+    first = min(firsts, key=lambda c: c["total_ms"])
+    best = None
+    for k in range(3):                                         # the samples resident from here on
+        cur, frames = one_pass()
+        if best is None or cur["total_ms"] < best["total_ms"]:
             best = cur
-        frames = prep["frames"]
-        del prep
     best["first_batch"] = {"total_ms": first["total_ms"], "plan_upload_ms": first["plan_upload_ms"], "frames_per_s": first["frames_per_s"],
-                           "note": "the same batch when none of its 1024 voicebank samples is resident in HBM yet (knot tables + voicing masks uploaded)"}
+                           "trials_total_ms": [c["total_ms"] for c in firsts],
+                           "note": "the same batch when none of its 1024 voicebank samples is resident in HBM yet (knot tables + voicing masks "
+                                   "uploaded): the fastest of three trials, each with fresh Source objects and an empty arena"}
     # Long jobs: goofer_amd.render.PipelinedRenderer — two handles / streams, batches decoded and planned on worker threads while
     # the previous ones render, the mix of batch k - 1 crossing PCIe under step k.  The same 1024 argument lists and sources as
     # batch after batch (the sources resident, as in a job that renders a voicebank's samples thousands of times).
@@ -293,10 +307,6 @@ def host_inclusive(wl, ctx, step_s):
     rounds, lead = 32, 24                                      # steady state of a long job: the first dozens of batches run 4-6 ms (the
                                                                # caching allocator's stream-private pools filling, threads falling into step);
                                                                # the better of two 32-batch jobs behind a lead-in job
-    import gc
-    gc.collect()
-    gc.freeze()                                                # a render server's usual setting: the objects of the set-up (thousands of
-                                                               # sources and plans in this process) are not traversed by later collections
     pipe = PipelinedRenderer(torch.cuda.current_device(), hop=wl.geo["hop"], depth=2, workers=2)
     old_interval = _sys.getswitchinterval()
     _sys.setswitchinterval(1e-4)                               # the threads hand the interpreter lock over in 0.1 ms, not 5 ms

@@ -176,6 +176,11 @@ class BatchCollector:
             self._sources[key] = (stamp, src)
             while len(self._sources) > self.max_sources:
                 self._sources.popitem(last=False)
+            self._fresh = getattr(self, "_fresh", 0) + 1
+            if self._fresh >= 256:                             # the cache holds them until their files change: out of the collector's way
+                self._fresh = 0                                # (see main(): a full collection over a resident voicebank stalls a batch)
+                import gc
+                gc.freeze()
         return src
 
     def _render(self, batch, renderer=None):
@@ -271,6 +276,12 @@ def main(argv=None) -> int:
     if not argv or argv[0] == "--host":
         host = argv[1] if len(argv) > 1 else "127.0.0.1"
         httpd, _ = serve(host=host)
+        # A server keeps a voicebank's samples and its own set-up alive for hours: a full collection that walks them is 50-100 ms
+        # in the middle of a batch whose device work is 2 ms.  What exists now moves to the permanent generation; the young
+        # generations still collect the per-request garbage.
+        import gc
+        gc.collect()
+        gc.freeze()
         print(f"Starting HTTP server on port 8572 ({host or 'all interfaces'})...")
         httpd.serve_forever()
         return 0

@@ -46,10 +46,11 @@ def phases_of(lines):
     ]
     harm = [
         ("set-up outside the frame loop: tables into LDS, run bounds, first frame records", [(h0, L("    float2 raw[R];", h0) - 1)]),
-        ("frame records, note entry (every frame)", [(L("    float2 raw[R];", h0), L("    auto fetch = [&](int64_t f, int idx) {", h0) - 1), (L("    float2 carry[R - G];", h0), L("// 1. windowed frame -> complex FFT", h0) - 1)]),
+        ("frame records, note entry (every frame)", [(L("    float2 raw[R];", h0), L("    auto fetch = [&](int idx) {", h0) - 1), (L("    float2 carry[R - G];", h0), L("        fetch(idx);", h0) - 1),
+                                                     (L("        fetch(idx);", h0) + 1, L("// 1. windowed frame -> complex FFT", h0) - 1)]),
         ("1. window + forward FFT (every frame)", [(L("// 1. windowed frame -> complex FFT", h0), L("// 2. even/odd split", h0) - 1)]),
-        ("2. even/odd split through LDS (every frame)", [(L("// 2. even/odd split", h0), L("if (f + 1 < f1) {                                            // raw pairs and row are consumed", h0) - 1)]),
-        ("next frame's fetch: 8 sample pairs + envelope row (+ reflect padding at note ends, record refill every 64 frames)", [(L("if (f + 1 < f1) {                                            // raw pairs and row are consumed", h0), L("// 3. shaping (GOOFER.py:1102-1144)", h0) - 1), (L("    auto fetch = [&](int64_t f, int idx) {", h0), L("    float2 carry[R - G];", h0) - 1)]),
+        ("2. even/odd split through LDS (every frame)", [(L("// 2. even/odd split", h0), L("// 3. shaping (GOOFER.py:1102-1144)", h0) - 1)]),
+        ("the frame's fetch at its head: 8 sample pairs + envelope row (the reflect padding of a note's end frames is most of the static count)", [(L("    auto fetch = [&](int idx) {", h0), L("    float2 carry[R - G];", h0) - 1), (L("        fetch(idx);", h0), L("        fetch(idx);", h0))]),
         ("3. shaping: high-pass, max|S|, env * boost, brightness (every frame)", [(L("// 3. shaping (GOOFER.py:1102-1144)", h0), L("        if (voiced && !td_blur) {\n", h0) - 1)]),
         ("3b. 5-tap blur (voiced frames, only with td_blur off)", [(L("        if (voiced && !td_blur) {\n", h0), L("// 4. inverse transform + overlap-add; hop t leaves", h0) - 1)]),
         ("4. blur edge correction + irFFT + overlap-add (every frame)", [(L("// 4. inverse transform + overlap-add; hop t leaves", h0), L("w.inverse_ola(X, t, carry, e, (voiced && td_blur) ? w.wsv : w.wsc);", h0))]),
