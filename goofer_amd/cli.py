@@ -59,6 +59,7 @@ class BatchCollector:
         self.window_s, self.max_batch, self.max_sources = window_s, max_batch, max_sources
         self._sources = collections.OrderedDict()          # feature cache: path -> ((mtime_ns, size), Source)
         self._src_lock = threading.Lock()
+        self._fresh = 0                                        # samples cached since the collector's old generation was last frozen (see _source)
         self._lock = threading.Condition()
         self._queue = []
         self._stop = False
@@ -176,7 +177,7 @@ class BatchCollector:
             self._sources[key] = (stamp, src)
             while len(self._sources) > self.max_sources:
                 self._sources.popitem(last=False)
-            self._fresh = getattr(self, "_fresh", 0) + 1
+            self._fresh += 1
             if self._fresh >= 256:                             # the cache holds them until their files change: out of the collector's way
                 self._fresh = 0                                # (see main(): a full collection over a resident voicebank stalls a batch)
                 import gc

@@ -234,6 +234,8 @@ class SourceArena:
         item = dst.element_size()
         half = (stg.nbytes // 2) // 256 * 256
         room = half // item
+        if room <= 0:
+            raise ValueError("staging block too small to upload through")
         stream = torch.cuda.current_stream(dst.device)
         done_ev = [None, None]
         base = stg.host.data_ptr()
