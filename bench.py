@@ -132,9 +132,14 @@ def sq_valu_issue(stage, ms, frames):
             return {"stale": True, "source": src}
         for ln in lines:
             if ln.startswith(name + " ") and "SQ_INSTS_VALU=" in ln:
-                insts = float(ln.split("SQ_INSTS_VALU=")[1].split()[0])
+                cnt = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in ln.split()[1:] if "=" in kv and kv.split("=")[0].startswith("SQ_INSTS_")}
+                insts = cnt["SQ_INSTS_VALU"]
                 peak = 1024 * 2.4e9 / 4.0
+                every = sum(cnt.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM"))
                 return {"insts_valu_per_launch": insts, "issue_frac": insts / (ms * 1e-3) / peak, "peak_wave_insts_per_s": peak,
+                        # every instruction a wave issues takes one of its SIMD's issue turns (one per 4 cycles); with two or three
+                        # waves per SIMD few turns carry two instructions, so this is the fraction that says how much is left
+                        "insts_all_per_launch": every, "issue_frac_all_types": every / (ms * 1e-3) / peak,
                         "source": src, "stale": False}
     except Exception:
         pass
