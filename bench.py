@@ -308,34 +308,34 @@ def host_inclusive(wl, ctx, step_s):
     # the previous ones render, the mix of batch k - 1 crossing PCIe under step k.  The same 1024 argument lists and sources as
     # batch after batch (the sources resident, as in a job that renders a voicebank's samples thousands of times).
     from goofer_amd.render import PipelinedRenderer
-    import sys as _sys
-    rounds, lead = 32, 24                                      # steady state of a long job: the first dozens of batches run 4-6 ms (the
-                                                               # caching allocator's stream-private pools filling, threads falling into step);
-                                                               # the better of two 32-batch jobs behind a lead-in job
+    rounds, lead, total = 32, 24, 120                          # one job of 120 batches per sample format; reported: the best window of 32
+                                                               # consecutive batches behind the first 24 (a job's first dozens of batches run
+                                                               # 4-8 ms: allocator pools filling, threads falling into step, and on a shared
+                                                               # host phases in which the planner threads do not get their cores) AND the
+                                                               # mean over everything behind the lead-in
     pipe = PipelinedRenderer(torch.cuda.current_device(), hop=wl.geo["hop"], depth=2, workers=2)
-    old_interval = _sys.getswitchinterval()
-    _sys.setswitchinterval(1e-4)                               # the threads hand the interpreter lock over in 0.1 ms, not 5 ms
     try:
-        def job(pcm16, warm):
-            t0, done = None, 0
-            for mix, off in pipe.render_iter(((srcs, args) for _ in range(warm + rounds)), seed=0, note_ids=lambda k, n: ids, pcm16=pcm16):
-                done += 1
-                if done == warm:
-                    t0 = time.perf_counter()
-            assert done == warm + rounds and float(np.abs(mix).max()) > 0.0
-            return (time.perf_counter() - t0) / rounds
-        job(False, lead)                                       # lead-in: allocator pools of the lanes' streams, threads in step
-        dt = min(job(False, 8), job(False, 8))
-        dt16 = min(job(True, 8), job(True, 8))
+        def job(pcm16):
+            stamps = []
+            for mix, off in pipe.render_iter(((srcs, args) for _ in range(total)), seed=0, note_ids=lambda k, n: ids, pcm16=pcm16):
+                stamps.append(time.perf_counter())
+            assert len(stamps) == total and float(np.abs(mix).max()) > 0.0
+            s = np.asarray(stamps[lead - 1:])
+            win = float(np.min(s[rounds:] - s[:-rounds])) / rounds
+            return win, float(s[-1] - s[0]) / (s.size - 1)
+        dt, dt_job = job(False)
+        dt16, dt16_job = job(True)
     finally:
-        _sys.setswitchinterval(old_interval)
         pipe.close()
         gc.unfreeze()
     best["pipelined"] = {"ms_per_batch": 1e3 * dt, "frames_per_s": frames / dt, "batches": rounds,
+                         "job_mean_ms_per_batch": 1e3 * dt_job, "job_mean_frames_per_s": frames / dt_job, "job_batches": total - lead,
                          "note": "goofer_amd.render.PipelinedRenderer(depth=2, workers=2): 13 argument strings -> audio in pinned host memory, "
                                  "two batches in flight on two handles / streams, decode + planning of the next batches on two worker "
-                                 "threads, D2H of the previous mix on a copy stream under the running step",
+                                 "threads, D2H of the previous mix on a copy stream under the running step; ms_per_batch = the best 32 "
+                                 "consecutive batches of a 120-batch job, job_mean = all of it behind the first 24",
                          "pcm16": {"ms_per_batch": 1e3 * dt16, "frames_per_s": frames / dt16,
+                                   "job_mean_ms_per_batch": 1e3 * dt16_job, "job_mean_frames_per_s": frames / dt16_job,
                                    "note": "the same with the mix converted to the wav's int16 samples on the device (goofer_pcm16: what the "
                                            "reference's PCM_16 file holds): half the bytes over PCIe"}}
     best["note"] = ("serial, one host thread: 13 argument strings -> request columns (decode_request_batch), plans written by the library's "

@@ -794,9 +794,11 @@ class PipelinedRenderer:
     ``render_iter`` yields ``(mix, sample_off)`` per batch, in order: ``mix`` is a float32 numpy view of the lane's pinned
     buffer, valid until ``depth`` more batches have been taken from the iterator (copy what must live longer)."""
 
-    def __init__(self, device: int = 0, hop: int = S.HOP, depth: int = 2, workers: int = 2, staging_bytes: int = 48 << 20):
+    def __init__(self, device: int = 0, hop: int = S.HOP, depth: int = 2, workers: int = 2, staging_bytes: int = 48 << 20,
+                 freeze_gc: bool = True):
         from concurrent.futures import ThreadPoolExecutor
         self.device = torch.device("cuda", device)
+        self.freeze_gc = bool(freeze_gc)
         self.lanes = []
         arena = None
         depth, workers = max(1, depth), max(1, workers)
@@ -814,6 +816,7 @@ class PipelinedRenderer:
         self.copy_stream = torch.cuda.Stream(self.device)
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="goofer-prepare")
         self.workers = max(1, workers)
+        self.trace = None                                      # a list: (what, batch, start, end) of the host-side phases (scripts/pipeline_job.py --trace)
 
     def close(self):
         self.pool.shutdown(wait=True)
@@ -822,6 +825,16 @@ class PipelinedRenderer:
         self.lanes = []
 
     def _prepare(self, k, batch, note_ids):
+        if self.trace is not None:
+            import time
+            t0 = time.perf_counter()
+            try:
+                return self._prepare_batch(k, batch, note_ids)
+            finally:
+                self.trace.append(("prepare", k, t0, time.perf_counter()))
+        return self._prepare_batch(k, batch, note_ids)
+
+    def _prepare_batch(self, k, batch, note_ids):
         ln = self.lanes[k % len(self.lanes)]
         srcs, reqs = batch
         if not isinstance(reqs, S.RequestBatch):
@@ -836,8 +849,29 @@ class PipelinedRenderer:
         position in the batch).  ``pcm16``: yield the wav's int16 samples (converted on the device, goofer_pcm16: what
         ``write_wav`` computes on the host) — half the bytes over PCIe, which is what bounds a long job."""
         import collections
+        import sys
         it = iter(enumerate(batches))
         ahead = collections.deque()                           # futures of prepared batches, in order
+        # the worker threads and this one hand the interpreter lock over every 0.1 ms while a job runs (the default 5 ms makes a
+        # thread that is ready to launch the next step wait for a planner's whole Python stretch)
+        old_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_interval, 1e-4))
+        # ... and what is alive when the job starts (the voicebank's Source objects, the process's set-up) is moved out of the
+        # collector's sight for its duration: a full collection that walks it is 10-100 ms in the middle of a 4 ms batch
+        # (``freeze_gc=False``: the caller manages that, e.g. a server that has frozen its heap already)
+        import gc
+        frozen = self.freeze_gc and gc.get_freeze_count() == 0
+        if frozen:
+            gc.freeze()
+        try:
+            yield from self._render_iter(it, ahead, seed, note_ids, pcm16)
+        finally:
+            sys.setswitchinterval(old_interval)
+            if frozen:
+                gc.unfreeze()
+
+    def _render_iter(self, it, ahead, seed, note_ids, pcm16):
+        import collections
 
         def feed():
             while len(ahead) < len(self.lanes) + self.workers:
@@ -851,7 +885,13 @@ class PipelinedRenderer:
         feed()
         while ahead or flying:
             if ahead:
+                if self.trace is not None:
+                    import time
+                    tw = time.perf_counter()
                 prep = ahead.popleft().result()
+                if self.trace is not None:
+                    self.trace.append(("wait_prepared", k, tw, time.perf_counter()))
+                    tw = time.perf_counter()
                 feed()
                 ln = self.lanes[k % len(self.lanes)]
                 k += 1
@@ -876,9 +916,16 @@ class PipelinedRenderer:
                     home = torch.cuda.Event()
                     home.record()
                 flying.append((ln, home, prep, out, samples))
+                if self.trace is not None:
+                    self.trace.append(("launch", k - 1, tw, time.perf_counter()))
             if flying and (len(flying) >= len(self.lanes) or not ahead):
                 ln, home, prep, out, samples = flying.popleft()
+                if self.trace is not None:
+                    import time
+                    tw = time.perf_counter()
                 home.synchronize()
+                if self.trace is not None:
+                    self.trace.append(("wait_audio", -1, tw, time.perf_counter()))
                 yield ln["host"][:samples].numpy(), prep["sample_off"]
                 del prep, out
         for ln in self.lanes:                                  # the device is idle now: what the asynchronous calls flagged

@@ -10,7 +10,7 @@ import torch
 from goofer_amd import synthetic as syn
 from goofer_amd.render import PipelinedRenderer, Source
 
-argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]   # [batches] [depth] [workers] [--pcm16] [--trace] [--plan-threads=N] [--extra] [--nogc]
 rounds = int(argv[0]) if len(argv) > 0 else 40
 depth = int(argv[1]) if len(argv) > 1 else 2
 workers = int(argv[2]) if len(argv) > 2 else 2
@@ -37,19 +37,35 @@ if "--extra" in sys.argv:
         if "--keepb" not in sys.argv:
             del wb, both
             cb.close()
-sys.setswitchinterval(1e-4)
 if "--nogc" in sys.argv:
     import gc
     gc.disable()
 pipe = PipelinedRenderer(0, depth=depth, workers=workers)
+for a in sys.argv:
+    if a.startswith("--plan-threads="):
+        for ln in pipe.lanes:
+            ln["r"].plan_threads = int(a.split("=")[1])
+if "--trace" in sys.argv:
+    pipe.trace = []
 ids = list(range(1024))
 stamps = []
+allocs = []
 t_prev = time.perf_counter()
 for mix, off in pipe.render_iter(((srcs, args) for _ in range(rounds)), note_ids=lambda k, n: ids, pcm16="--pcm16" in sys.argv):
     now = time.perf_counter()
     stamps.append(1e3 * (now - t_prev))
+    allocs.append(torch.cuda.memory_stats().get("num_device_alloc", 0))
     t_prev = now
+trace = pipe.trace
 pipe.close()
 print("intervals (ms):", " ".join("%.1f" % v for v in stamps))
+print("device allocations by the caching allocator in the second half of the job: %d; reserved %d MiB" % (allocs[-1] - allocs[len(allocs) // 2], torch.cuda.memory_stats().get("reserved_bytes.all.current", 0) >> 20))
 tail = stamps[len(stamps) // 2:]
 print("second half: mean %.2f ms, median %.2f, max %.2f  -> %.1f M frames/s" % (np.mean(tail), np.median(tail), max(tail), 194560 / np.mean(tail) / 1e3))
+
+if trace:
+    t0 = min(e[2] for e in trace)
+    for what in ("prepare", "wait_prepared", "launch", "wait_audio"):
+        ev = [e for e in trace if e[0] == what]
+        d = [1e3 * (e[3] - e[2]) for e in ev]
+        print("%-14s n %3d  mean %.2f ms  median %.2f  max %.2f   per batch over the job: %s" % (what, len(d), np.mean(d), np.median(d), max(d), " ".join("%.1f" % v for v in d[:80])))
