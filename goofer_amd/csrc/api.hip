@@ -815,7 +815,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "skip_zero")) { ctx->skip_zero = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "td_blur")) { ctx->td_blur = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "walk_lds_kb")) { ctx->walk_lds_kb = value < 32 ? 32 : (value > 160 ? 160 : value); return GOOFER_OK; }
-    if (!strcmp(name, "finish_lds_kb")) { ctx->finish_lds_kb = value < 0 ? 0 : (value > 160 ? 160 : value); return GOOFER_OK; }
+    if (!strcmp(name, "finish_lds_kb")) { ctx->finish_lds_kb = value > 160 ? 160 : value; return GOOFER_OK; }   // KB of the breath stem k_note_finish parks in LDS between its passes (0: 144, < 0: none)
     if (!strcmp(name, "maps_side")) { ctx->maps_side = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "f0_side")) { ctx->f0_side = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "side_prio")) {

@@ -85,7 +85,7 @@ struct goofer_ctx {
     bool prof_stems = false;      // the last profiled batch ran the stem-split path (stage order differs)
     // tuning knobs (goofer_set_option; the defaults are the measured optima — round 3 swept them: nothing within 1 % to gain)
     int walk_lds_kb = 81;         // LDS the sequential phase walk reserves per workgroup (what it uses: 32 KiB)
-    int finish_lds_kb = 0;        // LDS k_note_finish reserves per workgroup (0: none) — caps the notes in flight per CU
+    int finish_lds_kb = 0;        // KB of the breath stem k_note_finish parks in LDS between its passes (0: the default 144, < 0: none)
     int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
     bool mask_side = false;       // goofer_render_batch: the mask smoothing on the side stream in front of the pulse chain (option "mask_side"; measured: -0.4 %)
     // n_fft 2048 (stems_ring.hip), both measured slower than the spectra-in-HBM kernels on BASELINE config 5 and off by default:

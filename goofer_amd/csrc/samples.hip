@@ -1073,8 +1073,7 @@ __global__ __launch_bounds__(256) void k_apply_gain(float *__restrict__ harm, fl
 
     auto gain_of = [&](int note) -> float {
         const float peak = note_peak[note] + 1e-12f;                 // fp32 add, like np.float32 + 1e-12
-        const double amt = (double)fminf(fmaxf(params[note].normalize, 0.f), 1.f);
-        return (float)pow(1.0 / (double)peak, amt);
+        return peak_gain(peak, params[note].normalize);
     };
     auto mixdown = [&](int note, float h, float u, float b) -> float {
         return ((h * params[note].mix_harm + b * params[note].mix_breath) + u * params[note].mix_unvoiced) * params[note].volume;

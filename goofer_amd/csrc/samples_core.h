@@ -97,3 +97,15 @@ __device__ __forceinline__ float div_by(float x, float d, float r)
     return fmaf(fmaf(-q, d, x), r, q);
 }
 
+// gain = (1 / (peak + 1e-12))^normalize (GOOFER.py:1208-1214), `pk12` = the fp32 sum.  numpy's float64 power returns x for an
+// exponent of exactly 1 and 1 for 0 (C99 pow), which is what the sampler always passes (normalize = 1, or 0 with the 'P0' flag);
+// those two skip the library routine — 300 instructions and some forty live registers that, inlined between the two passes of
+// k_note_finish, pushed the values it keeps across them out to scratch.
+__device__ __forceinline__ float peak_gain(float pk12, float normalize)
+{
+    const double amt = (double)fminf(fmaxf(normalize, 0.f), 1.f);
+    const double x = 1.0 / (double)pk12;
+    if (amt == 1.0) return (float)x;
+    if (amt == 0.0) return 1.0f;
+    return (float)pow(x, amt);
+}

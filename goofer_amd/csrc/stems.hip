@@ -834,20 +834,25 @@ __global__ __launch_bounds__(256, 3) void k_harm_stem(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// One workgroup per note, two passes over its three stems (the second pass is served from L2: a 1.1 s note is 0.6 MB):
-// harm / max|S|, peak of harm + uv + breath, then gain = (1 / peak)^normalize on everything (GOOFER.py:1121, 1208-1218)
-// and the V/B/U mix (SillySampler.py:1142-1151).  Same operations in the same order as k_irfft_ola3's output stage +
-// k_apply_gain.
+// One workgroup per note, two passes over its three stems: harm / max|S|, peak of harm + uv + breath, then
+// gain = (1 / peak)^normalize on everything (GOOFER.py:1121, 1208-1218) and the V/B/U mix (SillySampler.py:1142-1151).  Same
+// operations in the same order as k_irfft_ola3's output stage + k_apply_gain.
+// The second pass of a note of up to FIN_KEEP * 4096 samples (1.1 s at 44.1 kHz) takes harm / max|S| and the unvoiced stem from
+// the REGISTERS the first pass left them in (2 x 48 per thread at 1024 threads) and re-reads only the breath stem: with 256
+// notes in flight nothing of the first pass is still in L2 (the pass ran at 1.4 GB per 1024 notes; now 1.0).
 constexpr int FIN_THREADS = 1024;
+constexpr int FIN_KEEP = 12;              // float4 per stem and thread kept across the peak reduction
 
 __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__ harm, float *__restrict__ uv, float *__restrict__ bre,
                                                              float *__restrict__ rec, float *__restrict__ mix,
                                                              const int64_t *__restrict__ sample_off,
                                                              const goofer_note_params *__restrict__ params,
                                                              const float *__restrict__ note_mag, float *__restrict__ note_peak,
-                                                             int write_stems)
+                                                             int write_stems, int lds_rows)
 {
     __shared__ float s_red[FIN_THREADS / WAVE];
+    extern __shared__ __align__(16) unsigned char fin_smem[];
+    float4 *sb4 = reinterpret_cast<float4 *>(fin_smem);     // [lds_rows][FIN_THREADS]: the breath stem's first rows, parked between the passes
     const int note = blockIdx.x;
     const int64_t base = sample_off[note];
     const int n = (int)(sample_off[note + 1] - base);
@@ -860,7 +865,30 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
     const bool vec = ((((uintptr_t)harm | (uintptr_t)uv | (uintptr_t)bre | (uintptr_t)rec | (uintptr_t)mix) & 15) == 0);
 
     float pk = 0.f;
-    if (vec) {
+    const bool keep = vec && a1 - a0 <= FIN_KEEP * 4 * FIN_THREADS;     // workgroup-uniform
+    float4 kh[FIN_KEEP], ku[FIN_KEEP];
+    if (keep) {
+#pragma unroll
+        for (int q = 0; q < FIN_KEEP; ++q) {
+            const int i = a0 + 4 * ((int)threadIdx.x + FIN_THREADS * q);
+            kh[q] = ku[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < a1) {
+                const float4 h = *reinterpret_cast<const float4 *>(h_ + i);
+                const float4 u = *reinterpret_cast<const float4 *>(u_ + i);
+                const float4 b = *reinterpret_cast<const float4 *>(b_ + i);
+                kh[q] = make_float4(div_by(h.x, mag, rmag), div_by(h.y, mag, rmag), div_by(h.z, mag, rmag), div_by(h.w, mag, rmag));
+                ku[q] = u;
+                if (q < lds_rows) sb4[q * FIN_THREADS + (int)threadIdx.x] = b;     // (read back by this thread only)
+                pk = fmaxf(pk, fabsf((kh[q].x + u.x) + b.x));
+                pk = fmaxf(pk, fabsf((kh[q].y + u.y) + b.y));
+                pk = fmaxf(pk, fabsf((kh[q].z + u.z) + b.z));
+                pk = fmaxf(pk, fabsf((kh[q].w + u.w) + b.w));
+            }
+            // (one group of three loads in flight per thread — 48 KB per CU at sixteen waves — not all twelve: the breath values
+            // are transient, and hoisted together they push the kept ones out to scratch)
+            if (q % 2 == 1) asm volatile("" ::: "memory");
+        }
+    } else if (vec) {
         for (int i = a0 + 4 * (int)threadIdx.x; i < a1; i += 4 * FIN_THREADS) {
             const float4 h = *reinterpret_cast<const float4 *>(h_ + i);
             const float4 u = *reinterpret_cast<const float4 *>(u_ + i);
@@ -885,8 +913,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
 
     const goofer_note_params &p = params[note];
     const float pk12 = peak + 1e-12f;                                 // fp32 add, like np.float32 + 1e-12
-    const double amt = (double)fminf(fmaxf(p.normalize, 0.f), 1.f);
-    const float gain = (float)pow(1.0 / (double)pk12, amt);
+    const float gain = peak_gain(pk12, p.normalize);
     const float m_h = p.mix_harm, m_b = p.mix_breath, m_u = p.mix_unvoiced, vol = p.volume;
     auto one = [&](float h, float u, float b, float &ho, float &uo, float &bo, float &ro, float &mo) {
         h = div_by(h, mag, rmag);
@@ -895,7 +922,36 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
         ro = comb * gain;
         mo = ((ho * m_h + bo * m_b) + uo * m_u) * vol;
     };
-    if (vec) {
+    // (the quotient harm / max|S| of the kept samples is already taken)
+    auto one_kept = [&](float h, float u, float b, float &ho, float &uo, float &bo, float &ro, float &mo) {
+        const float comb = (h + u) + b;
+        ho = h * gain; uo = u * gain; bo = b * gain;
+        ro = comb * gain;
+        mo = ((ho * m_h + bo * m_b) + uo * m_u) * vol;
+    };
+    if (keep) {
+#pragma unroll
+        for (int q = 0; q < FIN_KEEP; ++q) {
+            const int i = a0 + 4 * ((int)threadIdx.x + FIN_THREADS * q);
+            if (i < a1) {
+                const float4 h = kh[q], u = ku[q];
+                const float4 b = q < lds_rows ? sb4[q * FIN_THREADS + (int)threadIdx.x] : *reinterpret_cast<const float4 *>(b_ + i);
+                float4 ho, uo, bo, ro, mo;
+                one_kept(h.x, u.x, b.x, ho.x, uo.x, bo.x, ro.x, mo.x);
+                one_kept(h.y, u.y, b.y, ho.y, uo.y, bo.y, ro.y, mo.y);
+                one_kept(h.z, u.z, b.z, ho.z, uo.z, bo.z, ro.z, mo.z);
+                one_kept(h.w, u.w, b.w, ho.w, uo.w, bo.w, ro.w, mo.w);
+                if (write_stems & 1) {
+                    *reinterpret_cast<float4 *>(h_ + i) = ho;
+                    *reinterpret_cast<float4 *>(u_ + i) = uo;
+                    *reinterpret_cast<float4 *>(b_ + i) = bo;
+                }
+                if (rec) store_f4(rec + base + i, ro, (write_stems & 2) != 0);
+                if (mix) store_f4(mix + base + i, mo, (write_stems & 2) != 0);
+            }
+            if (q % 2 == 1) asm volatile("" ::: "memory");
+        }
+    } else if (vec) {
         for (int i = a0 + 4 * (int)threadIdx.x; i < a1; i += 4 * FIN_THREADS) {
             const float4 h = *reinterpret_cast<const float4 *>(h_ + i);
             const float4 u = *reinterpret_cast<const float4 *>(u_ + i);
@@ -1027,11 +1083,16 @@ int launch_note_finish(goofer_ctx *ctx, float *harm, float *uv, float *bre, floa
                        hipStream_t st)
 {
     if (n_notes <= 0) return GOOFER_OK;
-    const size_t lds = (size_t)ctx->finish_lds_kb * 1024;
-    if (lds > 64 * 1024)
-        if (int arc = kernel_allow_max_lds(ctx, (const void *)k_note_finish)) return arc;
+    // One 1024-thread workgroup fills a CU's register file (16 waves x 128 VGPRs), so its LDS is the workgroup's own: the first
+    // rows of the breath stem wait there between the passes (9 rows x 16 KB; option "finish_lds_kb": another size, 0 = none)
+    int rows = ctx->finish_lds_kb < 0 ? 0 : (ctx->finish_lds_kb == 0 ? 9 : ctx->finish_lds_kb / 16);
+    rows = rows > FIN_KEEP ? FIN_KEEP : rows;
+    if (rows * 16 * 1024 > 159 * 1024) rows = 9;
+    const size_t lds = (size_t)rows * FIN_THREADS * sizeof(float4);
+    if (lds > 48 * 1024)
+        if (int arc = kernel_allow_max_lds(ctx, (const void *)k_note_finish, FIN_KEEP * FIN_THREADS * (int)sizeof(float4) > 159 * 1024 ? 159 * 1024 : FIN_KEEP * FIN_THREADS * (int)sizeof(float4))) return arc;   // (beside 64 B of static LDS)
     hipLaunchKernelGGL(k_note_finish, dim3((unsigned)n_notes), dim3(FIN_THREADS), lds, st, harm, uv, bre, rec, mix, sample_off, params,
-                       note_mag, note_peak, (write_stems ? 1 : 0) | ((ctx->nt_mask & 1) ? 2 : 0));
+                       note_mag, note_peak, (write_stems ? 1 : 0) | ((ctx->nt_mask & 1) ? 2 : 0), rows);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
