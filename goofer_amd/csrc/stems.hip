@@ -837,8 +837,8 @@ __global__ __launch_bounds__(256, 3) void k_harm_stem(const float *__restrict__ 
 // One workgroup per note, two passes over its three stems: harm / max|S|, peak of harm + uv + breath, then
 // gain = (1 / peak)^normalize on everything (GOOFER.py:1121, 1208-1218) and the V/B/U mix (SillySampler.py:1142-1151).  Same
 // operations in the same order as k_irfft_ola3's output stage + k_apply_gain.
-// The second pass of a note of up to FIN_KEEP * 4096 samples (1.1 s at 44.1 kHz) takes harm / max|S| and the unvoiced stem from
-// the REGISTERS the first pass left them in (2 x 48 per thread at 1024 threads) and re-reads only the breath stem: with 256
+// For the first FIN_KEEP * 4096 samples of a note (1.1 s at 44.1 kHz) the second pass takes harm / max|S| and the unvoiced stem from
+// the REGISTERS the first pass left them in (2 x 48 per thread at 1024 threads) and re-reads only the breath stem (later samples: all three): with 256
 // notes in flight nothing of the first pass is still in L2 (the pass ran at 1.4 GB per 1024 notes; now 1.0).
 constexpr int FIN_THREADS = 1024;
 constexpr int FIN_KEEP = 12;              // float4 per stem and thread kept across the peak reduction
@@ -865,7 +865,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
     const bool vec = ((((uintptr_t)harm | (uintptr_t)uv | (uintptr_t)bre | (uintptr_t)rec | (uintptr_t)mix) & 15) == 0);
 
     float pk = 0.f;
-    const bool keep = vec && a1 - a0 <= FIN_KEEP * 4 * FIN_THREADS;     // workgroup-uniform
+    const bool keep = vec;                                              // workgroup-uniform; rows past FIN_KEEP take the re-reading loops
+    const int a_keep = a0 + 4 * FIN_THREADS * FIN_KEEP;                 // first sample past the kept rows
     float4 kh[FIN_KEEP], ku[FIN_KEEP];
     if (keep) {
 #pragma unroll
@@ -888,8 +889,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
             // are transient, and hoisted together they push the kept ones out to scratch)
             if (q % 2 == 1) asm volatile("" ::: "memory");
         }
-    } else if (vec) {
-        for (int i = a0 + 4 * (int)threadIdx.x; i < a1; i += 4 * FIN_THREADS) {
+        for (int i = a_keep + 4 * (int)threadIdx.x; i < a1; i += 4 * FIN_THREADS) {
             const float4 h = *reinterpret_cast<const float4 *>(h_ + i);
             const float4 u = *reinterpret_cast<const float4 *>(u_ + i);
             const float4 b = *reinterpret_cast<const float4 *>(b_ + i);
@@ -951,8 +951,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
             }
             if (q % 2 == 1) asm volatile("" ::: "memory");
         }
-    } else if (vec) {
-        for (int i = a0 + 4 * (int)threadIdx.x; i < a1; i += 4 * FIN_THREADS) {
+        for (int i = a_keep + 4 * (int)threadIdx.x; i < a1; i += 4 * FIN_THREADS) {
             const float4 h = *reinterpret_cast<const float4 *>(h_ + i);
             const float4 u = *reinterpret_cast<const float4 *>(u_ + i);
             const float4 b = *reinterpret_cast<const float4 *>(b_ + i);
