@@ -48,6 +48,7 @@ class Context:
         self.geom = None
 
     def close(self):
+        self._stem_scratch = None
         if getattr(self, "h", None):
             self.lib.goofer_destroy(self.h)
             self.h = None
@@ -371,7 +372,16 @@ class Context:
         d_s, d_f, d_e, d_par = o["d_s"], o["d_f"], o["d_e"], o["d_par"]
         N, F, R = int(s_off[-1]), int(f_off[-1]), int(e_off[-1])
         assert env.shape == (R, nb) and f0.numel() == N and mask.numel() == N and params.shape == (n,)
-        out = {k: torch.empty(N, dtype=torch.float32, device=self.device) for k in ("harm", "uv", "bre")}
+        if mix_only and want_mix:
+            # the three stems are scratch of this call (they hold the stems before the peak gain afterwards): one block per handle,
+            # grown as needed and re-used call after call in stream order, instead of 12 N bytes through the allocator per batch
+            st = getattr(self, "_stem_scratch", None)
+            Np = (N + 63) & ~63                                 # each stem starts on a 256-byte boundary (the finish pass's 16-byte accesses)
+            if st is None or st.numel() < 3 * Np:
+                st = self._stem_scratch = torch.empty(3 * max(Np, (int(1.25 * N) + 63) & ~63), dtype=torch.float32, device=self.device)
+            out = {k: st[i * Np:i * Np + N] for i, k in enumerate(("harm", "uv", "bre"))}
+        else:
+            out = {k: torch.empty(N, dtype=torch.float32, device=self.device) for k in ("harm", "uv", "bre")}
         if want_rec:
             out["rec"] = torch.empty(N, dtype=torch.float32, device=self.device)
         if want_mix:
