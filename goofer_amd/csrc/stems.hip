@@ -565,9 +565,29 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
         if (one_bits == 15u) w.skip_ola(t, carry_u, ou);
         else w.inverse_ola(su, t, carry_u, ou, w.wsc);
 
-        if (f >= f0) {
-            // 4. hop t -> window-sum quotient -> mask upsample -> stem gains -> out (GOOFER.py:385-389, 1179-1183); behind a note's
-            //    last frame also the hop still open in the registers and the zero tail
+        // 4. hop t -> window-sum quotient -> mask upsample -> stem gains -> out (GOOFER.py:385-389, 1179-1183).  First the common
+        //    case without a test per sample: the hop lies inside the note, every frame over it exists, the note goes on, and the
+        //    hop's mask gain is one constant (see hop_check_done) — the same quotients and products as the general loop below
+        const int p0t = t * HOP - M;
+        const bool flat1_t = (one_bits & 1u) != 0, flat0_t = (zero_bits & 1u) != 0;
+        if (f >= f0 && (flat1_t || flat0_t) && w.interior(t) && t != w.T - 1 && p0t >= 0 && p0t + HOP <= w.n && p0t + HOP <= w.out_len) {
+            const float ms = flat1_t ? 1.0f : 0.0f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int i0 = p0t + 2 * (lane + WAVE * g);
+                float xu[2] = {ou[g].x, ou[g].y}, xb[2] = {ob[g].x, ob[g].y};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float ws = w.ws_of(g, c), rw = w.rws_of(g, c);
+                    if (ws > 1e-9f) { xu[c] = div_by(xu[c], ws, rw); xb[c] = div_by(xb[c], ws, rw); }
+                    xb[c] = (xb[c] * ms) * g_b;
+                    xu[c] = (xu[c] * (1.0f - ms)) * g_u;
+                }
+                *reinterpret_cast<float2_u *>(uv + w.base + i0) = make_float2(xu[0], xu[1]);
+                *reinterpret_cast<float2_u *>(bre + w.base + i0) = make_float2(xb[0], xb[1]);
+            }
+        } else if (f >= f0) {
+            //    ... and the general case: behind a note's last frame also the hop still open in the registers and the zero tail
             for (int h = t;;) {
                 // a hop known flat (see hop_check_done; bit h - t of the masks) has ONE mask gain: 1 where the smoothed mask is
                 // flat at the tap sum, 0 where it is flat at zero — smooth_mask_at32 would return exactly that for every sample
@@ -797,7 +817,22 @@ __global__ __launch_bounds__(256, 3) void k_harm_stem(const float *__restrict__ 
         float2 e[G];
         if (voiced && td_blur) w.blur_edges(X, ec, t5[0], t5[1]);
         w.inverse_ola(X, t, carry, e, (voiced && td_blur) ? w.wsv : w.wsc);   // voiced: the bin blur rides on the window
-        if (f >= f0) {
+        // hop t lies inside the note, every frame over it exists and the note goes on: no bounds test per sample, no flush — the
+        // same quotients by the same per-lane window sums (most hops of a note; the general loop below has the rest)
+        const int p0t = t * HOP - M;
+        if (f >= f0 && w.interior(t) && t != w.T - 1 && p0t >= 0 && p0t + HOP <= w.n && p0t + HOP <= w.out_len) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int i0 = p0t + 2 * (lane + WAVE * g);
+                float x[2] = {e[g].x, e[g].y};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float ws = w.ws_of(g, c);
+                    if (ws > 1e-9f) x[c] = div_by(x[c], ws, w.rws_of(g, c));
+                }
+                *reinterpret_cast<float2_u *>(harm + w.base + i0) = make_float2(x[0], x[1]);
+            }
+        } else if (f >= f0) {
             for (int h = t;;) {
                 const int p0 = h * HOP - M;
                 const bool inner = w.interior(h);
