@@ -106,7 +106,7 @@ int launch_frame_picks(goofer_ctx *, const int64_t *, const int *, int64_t, cons
 int launch_noise_stems(goofer_ctx *, const float *, int, const int64_t *, const float *, int64_t, const int *, const int64_t *,
                        const int64_t *, const float2 *, const goofer_note_params *, uint64_t, bool, const double *, const double *, float *,
                        float *, hipStream_t);
-int launch_harm_stem(goofer_ctx *, const float *, const float *, int, const int64_t *, int64_t, const int *, const int64_t *,
+int launch_harm_stem(goofer_ctx *, const float *, const float *, const float *, bool, int, const int64_t *, int64_t, const int *, const int64_t *,
                      const int64_t *, const float2 *, const goofer_note_params *, float *, float *, hipStream_t);
 int launch_note_finish(goofer_ctx *, float *, float *, float *, float *, float *, const int64_t *, int, const goofer_note_params *,
                        const float *, float *, bool, hipStream_t);
@@ -412,7 +412,7 @@ template <typename T> static int upload(goofer_ctx *ctx, T **dst, const std::vec
 
 static void free_plan(goofer_plan_t &p)
 {
-    void *ptrs[] = {p.window, p.window_blur, p.blur_edge, p.win_sq, p.freqs, p.boost, p.bright_h, p.bright_b, p.tw_full, p.tw_half, p.pulse_peak, p.pulse_shape, p.blur5, p.blur175,
+    void *ptrs[] = {p.window, p.window_blur, p.blur_edge, p.win_sq, p.freqs, p.lin_freqs, p.boost, p.bright_h, p.bright_b, p.tw_full, p.tw_half, p.pulse_peak, p.pulse_shape, p.blur5, p.blur175,
                     p.bl_chirp, p.bl_bhat, p.bl_tw, p.bl_twh};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -600,6 +600,12 @@ int goofer_plan(goofer_ctx *ctx, int sr, int n_fft, int hop)
     if ((rc = upload(ctx, &p.window, win))) return rc;
     if ((rc = upload(ctx, &p.win_sq, wsq))) return rc;
     if ((rc = upload(ctx, &p.freqs, freqs))) return rc;
+    {
+        std::vector<float> lin(B);
+        const double fstep = ((double)sr / 2.0) / (double)(B - 1);
+        for (int k = 0; k < B; ++k) lin[k] = (float)(k >= B - 1 ? (double)sr / 2.0 : (double)k * fstep);
+        if ((rc = upload(ctx, &p.lin_freqs, lin))) return rc;
+    }
     if ((rc = upload(ctx, &p.boost, boost))) return rc;
     if ((rc = upload(ctx, &p.bright_h, bh))) return rc;
     if ((rc = upload(ctx, &p.bright_b, bb))) return rc;
@@ -835,6 +841,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "stem_lds_kb")) { ctx->stem_lds_kb = value < 0 ? 0 : (value > 160 ? 160 : value); return GOOFER_OK; }
     if (!strcmp(name, "pulse_scan")) { ctx->pulse_scan = value < 0 ? 0 : (value > 2 ? 2 : value); return GOOFER_OK; }
     if (!strcmp(name, "walk_npw")) { ctx->walk_npw = (value == 1 || value == 2 || value == 4) ? value : 0; return GOOFER_OK; }
+    if (!strcmp(name, "value_f64")) { ctx->value_f64 = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "sa_spt")) { ctx->sa_spt = value >= 16 ? 16 : (value >= 8 ? 8 : 4); return GOOFER_OK; }
     return goofer_fail(ctx, GOOFER_EINVAL, "unknown option %s", name);
 }
@@ -1592,7 +1599,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if (harm_side) {
             HIP_TRY(ctx, hipStreamWaitEvent(pst, ctx->ev_maps, 0));
             if (pev && (only < 0 || only == 9 || only == 8)) HIP_TRY(ctx, hipEventRecord(pev[9], pst));
-            if ((rc = launch_harm_stem(ctx, pulse, ctx->warp_rows, ld, row_src, F, frame_note, b->frame_off, b->sample_off, picks, b->params,
+            if ((rc = launch_harm_stem(ctx, pulse, ctx->warp_rows, b->env, b->formants != nullptr, ld, row_src, F, frame_note, b->frame_off, b->sample_off, picks, b->params,
                                        b->harm, note_mag, pst)))
                 return rc;
             if (pev && (only < 0 || only == 9 || only == 10)) HIP_TRY(ctx, hipEventRecord(pev[10], pst));
@@ -1672,7 +1679,8 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         MARK();   // 8
         MARK();   // 9: harm_stem = rFFT + shaping + irFFT + overlap-add of the harmonic stem
         if (!harm_side &&
-            (rc = launch_harm_stem(ctx, pulse, ctx->warp_done ? ctx->warp_rows : env_h, ld, ctx->warp_done ? row_src : nullptr, F, frame_note,
+            (rc = launch_harm_stem(ctx, pulse, ctx->warp_done ? ctx->warp_rows : env_h, ctx->warp_done ? b->env : nullptr, b->formants != nullptr, ld,
+                                   ctx->warp_done ? row_src : nullptr, F, frame_note,
                                    b->frame_off, b->sample_off, picks, b->params, b->harm, note_mag, st)))
             return rc;
         MARK();   // 10..12

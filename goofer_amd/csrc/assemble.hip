@@ -24,20 +24,44 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// e^x for the log-domain knot lerp (|x| < 80): x log2(e) split into the rounded product and its exact remainder (one FMA for
+// the product's rounding error, one for the constant's), the hardware exp2 of the first, a first-order correction for the
+// second — six full-rate instructions, within 2 ulp of fp32 of libm's expf (~20 instructions).
+__device__ __forceinline__ float exp_split(float x)
+{
+    const float L2E = 0x1.715476p+0f, L2E_LO = 0x1.4ae0c0p-26f, LN2 = 0x1.62e430p-1f;
+    const float hi = x * L2E;
+    float lo = __builtin_fmaf(x, L2E, -hi);
+    lo = __builtin_fmaf(x, L2E_LO, lo);
+    const float r = __builtin_amdgcn_exp2f(hi);
+    return __builtin_fmaf(r, lo * LN2, r);
+}
+
 // ---------------------------------------------------------------------------------------------
+// V64: round 4's arithmetic (fp64 'es' blur, mean match and 'fw' interpolation, libm expf) — option "value_f64", A/B and the
+// error-budget tests.  Default: the same steps in fp32 (no index or comparison depends on these values).
+template <bool V64>
 __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64_t total_edit_rows, const int *__restrict__ row_note)
 {
+    using acc_t = std::conditional_t<V64, double, float>;
     extern __shared__ __align__(16) unsigned char smem[];
     const int B = a.n_bins;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // uniform row: the note's plan comes in through scalar loads
     const int64_t er = (int64_t)blockIdx.x * A_ROWS + wave;
     if (er >= total_edit_rows) return;                       // no block barrier below
     const int stride = (3 * B + 2 * ES_HALO + a.max_K + 3) & ~3;   // floats per wave, 16-byte multiple
-    double *tmp = reinterpret_cast<double *>(reinterpret_cast<float *>(smem) + (size_t)wave * stride);   // [B] fp64 scratch
-    float *row = reinterpret_cast<float *>(tmp + B) + ES_HALO;   // [B] current row, ES_HALO floats of reflected halo either side
+    acc_t *tmp = reinterpret_cast<acc_t *>(reinterpret_cast<float *>(smem) + (size_t)wave * stride);   // [B] scratch (fp64 slots either way)
+    float *row = reinterpret_cast<float *>(reinterpret_cast<double *>(tmp) + B) + ES_HALO;   // [B] current row, ES_HALO floats of reflected halo either side
     float *kv = row + B + ES_HALO;                            // [max_K] decoded knot values
     const int note = row_note[er];
-    const goofer_note_plan p = a.notes[note];
+    const goofer_note_plan &p = a.notes[note];
     const int r = (int)(er - p.edit_off);                     // index inside the note's edited window
     const int logical = p.row_lo + r;
     const int phys = p.reverse ? p.n_src_rows - 1 - logical : logical;
@@ -56,7 +80,8 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
             v = kv[b];
         } else {
             int i = li[b];
-            v = expf(l0[b] * kv[i] + l1[b] * kv[i + 1]);
+            const float x = l0[b] * kv[i] + l1[b] * kv[i + 1];
+            v = V64 ? expf(x) : exp_split(x);
         }
         if (tilt) v *= tilt[b];                               // 2. br: env *= tilt (fp32)   :513-515
         row[b] = v;
@@ -67,7 +92,8 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
     if (p.es_mode) {
         const double *taps = a.es_taps + p.es_taps_off;
         const int rad = p.es_radius;
-        double s_src = 0.0, s_mod = 0.0;
+        acc_t s_src = 0, s_mod = 0;
+        const acc_t amount = (acc_t)p.es_amount;
         const bool halo = rad <= ES_HALO && rad < B;          // numpy 'reflect' halo parked beside the row: no index map per tap
         if (halo) {
             for (int h = lane; h < 2 * rad; h += WAVE) {
@@ -80,32 +106,39 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
         // in NB registers as a ring (slot = window index mod NB: with the tap loop unrolled NB times every slot index is a
         // constant), so a tap costs one LDS read, one conversion and one scalar load for the whole lane instead of one of each
         // per bin (the lane-strided layout re-read and re-converted every value for every tap: three instructions per
-        // product).  Every bin still adds its products in ascending tap order: the same sums, bit for bit.
+        // product).  Every bin still adds its products in ascending tap order (fp64: the same sums, bit for bit; fp32: FMAs).
         auto blur_rows = [&](auto nb_tag) {
             constexpr int NB = decltype(nb_tag)::value;
             const int b0 = NB * lane;
             const bool live = b0 < B;
             const float *x0 = row + (live ? b0 : 0) - rad;      // window element e = x0[e], e < NB + 2 rad (inside the halo)
-            double acc[NB], xw[NB];
+            acc_t acc[NB], xw[NB];
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                acc[i] = 0.0;
-                xw[i] = (double)x0[i];
+                acc[i] = 0;
+                xw[i] = (acc_t)x0[i];
             }
             // the taps (at most 2 * 28 + 1) one per lane, read back with v_readlane: a scalar load per tap would share its
             // counter with the window's LDS reads and put a memory round trip into every step of the loop
             const double tapv = lane <= 2 * rad ? taps[lane] : 0.0;
             const int tap_lo = (int)(uint32_t)__double_as_longlong(tapv), tap_hi = (int)(__double_as_longlong(tapv) >> 32);
+            const int tap_f = __float_as_int((float)tapv);
             for (int jb = 0; jb <= 2 * rad; jb += NB) {
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     const int j = jb + u;
                     if (j <= 2 * rad) {                         // (wave-uniform)
-                        const double tj = __longlong_as_double(((long long)__builtin_amdgcn_readlane(tap_hi, j) << 32) |
-                                                               (uint32_t)__builtin_amdgcn_readlane(tap_lo, j));
+                        if constexpr (V64) {
+                            const double tj = __longlong_as_double(((long long)__builtin_amdgcn_readlane(tap_hi, j) << 32) |
+                                                                   (uint32_t)__builtin_amdgcn_readlane(tap_lo, j));
 #pragma unroll
-                        for (int i = 0; i < NB; ++i) acc[i] += tj * xw[(i + u) % NB];
-                        xw[u] = (double)x0[j + NB];              // element j is done with; its slot takes element j + NB
+                            for (int i = 0; i < NB; ++i) acc[i] += tj * xw[(i + u) % NB];
+                        } else {
+                            const float tj = __int_as_float(__builtin_amdgcn_readlane(tap_f, j));
+#pragma unroll
+                            for (int i = 0; i < NB; ++i) acc[i] = __builtin_fmaf(tj, xw[(i + u) % NB], acc[i]);
+                        }
+                        xw[u] = (acc_t)x0[j + NB];               // element j is done with; its slot takes element j + NB
                     }
                 }
             }
@@ -113,20 +146,20 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
             for (int i = 0; i < NB; ++i) {
                 const int b = b0 + i;
                 if (live && b < B) {
-                    const double src = (double)row[b];
-                    tmp[b] = p.es_mode == 1 ? acc[i] : fmax(0.0, src + p.es_amount * (src - acc[i]));
+                    const acc_t src = (acc_t)row[b];
+                    tmp[b] = p.es_mode == 1 ? acc[i] : (V64 ? (acc_t)fmax(0.0, (double)(src + amount * (src - acc[i]))) : (acc_t)fmaxf(0.0f, (float)__builtin_fmaf((float)amount, (float)(src - acc[i]), (float)src)));
                 }
             }
             wave_lds_sync();
             // the two row sums in the order the strided layout took them (bin lane + 64 i per lane, then across the wave)
             for (int b = lane; b < B; b += WAVE) {
-                s_src += (double)row[b];
+                s_src += (acc_t)row[b];
                 s_mod += tmp[b];
             }
         };
-        auto finish_bin = [&](int b, double acc) {
-            double src = (double)row[b];
-            double mod = p.es_mode == 1 ? acc : fmax(0.0, src + p.es_amount * (src - acc));
+        auto finish_bin = [&](int b, acc_t acc) {
+            acc_t src = (acc_t)row[b];
+            acc_t mod = p.es_mode == 1 ? acc : (V64 ? (acc_t)fmax(0.0, (double)(src + amount * (src - acc))) : (acc_t)fmaxf(0.0f, (float)(src + amount * (src - acc))));
             tmp[b] = mod;
             s_src += src;
             s_mod += mod;
@@ -138,19 +171,25 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
         else if (halo && chunks == 5 && 5 + rad <= ES_HALO) blur_rows(std::integral_constant<int, 5>{});
         else
             for (int b = lane; b < B; b += WAVE) {
-                double acc = 0.0;
+                acc_t acc = 0;
                 if (halo) {
                     const float *x = row + (b - rad);
-                    for (int j = 0; j <= 2 * rad; ++j) acc += taps[j] * (double)x[j];
+                    for (int j = 0; j <= 2 * rad; ++j) acc += (acc_t)taps[j] * (acc_t)x[j];
                 } else {
-                    for (int j = 0; j <= 2 * rad; ++j) acc += taps[j] * (double)row[reflect_index(b + j - rad, B)];
+                    for (int j = 0; j <= 2 * rad; ++j) acc += (acc_t)taps[j] * (acc_t)row[reflect_index(b + j - rad, B)];
                 }
                 finish_bin(b, acc);
             }
         s_src = wave_sum(s_src);
         s_mod = wave_sum(s_mod);
-        const float m0 = (float)(s_src / (double)B);          // np.mean of the fp32 block row -> fp32
-        const double scale = (double)m0 / (s_mod / (double)B + 1e-12);
+        acc_t scale;
+        if constexpr (V64) {
+            const float m0 = (float)(s_src / (double)B);          // np.mean of the fp32 block row -> fp32
+            scale = (double)m0 / (s_mod / (double)B + 1e-12);
+        } else {
+            const float rB = 1.0f / (float)B;
+            scale = (s_src * rB) / (s_mod * rB + 1e-12f);          // (one division per row)
+        }
         wave_lds_sync();
         for (int b = lane; b < B; b += WAVE) {
             float v = (float)(tmp[b] * scale);
@@ -164,7 +203,14 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
     if (p.fw_plan >= 0) {
         const int *lo = a.fw_lo + (int64_t)p.fw_plan * B, *hi = a.fw_hi + (int64_t)p.fw_plan * B;
         const double *fr = a.fw_frac + (int64_t)p.fw_plan * B;
-        for (int b = lane; b < B; b += WAVE) out[b] = (float)((1.0 - fr[b]) * (double)row[lo[b]] + fr[b] * (double)row[hi[b]]);
+        for (int b = lane; b < B; b += WAVE) {
+            if constexpr (V64) {
+                out[b] = (float)((1.0 - fr[b]) * (double)row[lo[b]] + fr[b] * (double)row[hi[b]]);
+            } else {
+                const float r0 = row[lo[b]];
+                out[b] = __builtin_fmaf((float)fr[b], row[hi[b]] - r0, r0);
+            }
+        }
     } else {
         for (int b = lane; b < B; b += WAVE) out[b] = row[b];
     }
@@ -173,9 +219,14 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
 // ---------------------------------------------------------------------------------------------
 // WARP: also write the row as gf.synthesize's harmonic branch wants it — formant-anchored + uniform warp (GOOFER.py:1004-1017,
 // warp_row of binops_core.h) with the synthesis batch's per-note shifts and per-row formants — while the row is at hand
-// (goofer_render_batch: one read of the edited rows instead of a second pass over the assembled envelope).
+// (goofer_render_batch: one read of the edited rows instead of a second pass over the assembled envelope).  Rows of a note
+// that does not warp (every f_shift == 1 and formant_shift == 1: note_warps()) are NOT written a second time — the
+// harmonic walker reads the assembled row itself for them (frame_block::mark_plain, stems_core.h).
 // CH: 64-bin chunks of a row when known at compile time (the loop over them is unrolled: constant offsets, no per-chunk
 // address arithmetic), 0 = any width.
+// V64: the round-4 arithmetic — fp64 tap blend and fp64 warp interpolation (option "value_f64", A/B and error-budget tests).
+// The default blends and interpolates in fp32: no index, threshold or comparison depends on those values, and the
+// results stay within 2 ulp of fp32 of the fp64 ones.
 //
 // Everything that depends on the row only — the four bells' centres, widths and reach, the warp's anchors — is computed
 // once per row ACROSS lanes (lane k owns formant k) and handed to the per-bin code through v_readlane, instead of once per
@@ -185,9 +236,10 @@ struct env_loop_grid {
     float inv_fstep, nyq_f;
     warp_grid warp;
     int nt;                  // rows leave as non-temporal stores
+    const float *freqs_f;    // [B] np.linspace(0, sr/2, B) as fp32 (the plan's table), or null: computed per bin
 };
 
-template <bool WARP, int CH>
+template <bool WARP, int CH, bool V64>
 __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64_t total_out_rows, const int *__restrict__ row_note,
                                                   const double *__restrict__ w_formants, const goofer_note_params *__restrict__ w_params,
                                                   float *__restrict__ w_out, const env_loop_grid eg)
@@ -244,7 +296,18 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
     }
     const unsigned cm_any = cmk[0] | cmk[1] | cmk[2] | cmk[3];
     float *out = a.env_out + orow * (int64_t)a.ld;
-    float *ra = reinterpret_cast<float *>(smem) + (size_t)(2 * wave) * B;
+    float *ra = reinterpret_cast<float *>(smem) + (size_t)(2 * wave) * (B + 1);   // (+ 1: warp_row's pad element)
+    // does this row leave a warped copy?  (wave-uniform; the per-note scalars come in through scalar loads)
+    bool warp = false, warp_row_on = false;
+    double fs[4] = {1.0, 1.0, 1.0, 1.0}, ratio = 1.0;
+    if (WARP) {
+        const goofer_note_params &q = w_params[note];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fs[k] = q.f_shift[k];
+        ratio = (double)q.formant_shift;
+        warp = note_shifts_formants(q);
+        warp_row_on = note_warps(q, w_formants != nullptr);
+    }
     // a plain copy of one source row (most rows: slices and loop repeats outside the cross-fades): 0.0 + 1.0 x is x, and
     // both roundings of the product below — fp32, or fp64 rounded to fp32 — are the fp32 product, so the row stays in fp32
     const bool copy = w[0] == 1.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 0.0;
@@ -252,22 +315,31 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
     const float *src1 = nullptr, *src2 = nullptr, *src3 = nullptr;
     if (!copy) { src1 = src_row(1); src2 = src_row(2); src3 = src_row(3); }
     const int env_f64 = p.env_f64;
-    auto chunk = [&](int c, int c0) {
+    const float wf0 = (float)w[0], wf1 = (float)w[1], wf2 = (float)w[2], wf3 = (float)w[3];
+    auto chunk = [&](int c, int c0, bool last) {
         const int b = c0 + lane;
-        if (b >= B) return;
+        if (last && b >= B) return;                            // (only a row's last chunk can run past it)
         double v = 0.0;
         float vf = 0.f;
         if (copy) {
             vf = src0[b];
-        } else {
+        } else if constexpr (V64) {
             if (w[0] != 0.0) v += w[0] * (double)src0[b];
             if (w[1] != 0.0) v += w[1] * (double)src1[b];
             if (w[2] != 0.0) v += w[2] * (double)src2[b];
             if (w[3] != 0.0) v += w[3] * (double)src3[b];
+        } else {
+            // fp32 blend: zero-weight taps are skipped like above (their rows may hold anything), the others are one
+            // product and FMAs in tap order — an L1 mirror mean (0.5, 0.5) is still the exact fp32 (a + b) / 2
+            if (w[0] != 0.0) vf = wf0 * src0[b];
+            if (w[1] != 0.0) vf = __builtin_fmaf(wf1, src1[b], vf);
+            if (w[2] != 0.0) vf = __builtin_fmaf(wf2, src2[b], vf);
+            if (w[3] != 0.0) vf = __builtin_fmaf(wf3, src3[b], vf);
         }
         float gain = 1.0f;
         if ((cm_any >> c) & 1u) {
-            const float fb = (float)(b >= B - 1 ? (double)a.sr / 2.0 : (double)b * eg.fstep);    // np.linspace(0, sr/2, B) as fp32
+            // np.linspace(0, sr/2, B) as fp32: the plan's table where the plan has this many bins
+            const float fb = eg.freqs_f ? eg.freqs_f[b] : (float)(b >= B - 1 ? (double)a.sr / 2.0 : (double)b * eg.fstep);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if ((cmk[k] >> c) & 1u) {
@@ -277,35 +349,29 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
                 }
             }
         }
-        const float o = copy ? vf * gain : (env_f64 ? (float)(v * (double)gain) : ((float)v) * gain);
+        float o;
+        if constexpr (V64) o = copy ? vf * gain : (env_f64 ? (float)(v * (double)gain) : ((float)v) * gain);
+        else o = vf * gain;
         store_f1(out + b, o, eg.nt != 0);
-        if (WARP) ra[b] = o;
+        if (WARP && warp_row_on) ra[b] = o;
     };
     if (CH > 0) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c) chunk(c, c * WAVE);
+        for (int c = 0; c < CH; ++c) chunk(c, c * WAVE, c == CH - 1);
     } else {
-        for (int c = 0, c0 = 0; c0 < B; ++c, c0 += WAVE) chunk(c < 31 ? c : 31, c0);
+        for (int c = 0, c0 = 0; c0 < B; ++c, c0 += WAVE) chunk(c < 31 ? c : 31, c0, true);
     }
-    if (WARP) {
-        float *rb = ra + B;
+    if (WARP && warp_row_on) {
+        float *rb = ra + B + 1;
         wave_lds_sync();
-        const goofer_note_params &q = w_params[note];
-        double fs[4];
-        bool warp = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            fs[k] = q.f_shift[k];
-            warp |= fs[k] != 1.0;
-        }
-        const float *cur = warp_row<CH>(ra, rb, B, eg.warp, w_formants ? w_formants + orow * 4 : nullptr, fs, warp, (double)q.formant_shift,
-                                        lane, s_seg[wave]);
+        const float *cur = warp_row<CH, !V64>(ra, rb, B, eg.warp, w_formants ? w_formants + orow * 4 : nullptr, fs, warp, ratio, lane,
+                                              s_seg[wave]);
         float *wo = w_out + orow * (int64_t)a.ld;
         if (CH > 0) {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const int b = c * WAVE + lane;
-                if (b < B) store_f1(wo + b, cur[b], eg.nt != 0);
+                if (c < CH - 1 || b < B) store_f1(wo + b, cur[b], eg.nt != 0);
             }
         } else {
             for (int b = lane; b < B; b += WAVE) wo[b] = cur[b];
@@ -622,17 +688,18 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         size_t lds = (size_t)A_ROWS * ((3 * B + 2 * ES_HALO + a->max_K + 3) & ~3) * sizeof(float);
         if (lds > 64 * 1024) {
             if (lds > 160 * 1024) return goofer_fail(ctx, GOOFER_EINVAL, "envelope rows too wide for the edit kernel's LDS staging");
-            if (int arc = kernel_allow_max_lds(ctx, (const void *)k_env_edit)) return arc;
+            if (int arc = kernel_allow_max_lds(ctx, ctx->value_f64 ? (const void *)k_env_edit<true> : (const void *)k_env_edit<false>)) return arc;
         }
-        hipLaunchKernelGGL(k_env_edit, dim3((unsigned)((a->total_edit_rows + A_ROWS - 1) / A_ROWS)), dim3(256), lds, st, *a,
-                           a->total_edit_rows, row_note_edit);
+        const dim3 egrid((unsigned)((a->total_edit_rows + A_ROWS - 1) / A_ROWS));
+        if (ctx->value_f64) hipLaunchKernelGGL(k_env_edit<true>, egrid, dim3(256), lds, st, *a, a->total_edit_rows, row_note_edit);
+        else hipLaunchKernelGGL(k_env_edit<false>, egrid, dim3(256), lds, st, *a, a->total_edit_rows, row_note_edit);
         LAUNCH_CHECK(ctx);
     }
     if (a->total_out_rows > 0) {
         const dim3 lgrid((unsigned)((a->total_out_rows + A_ROWS - 1) / A_ROWS));
         ctx->warp_done = false;
         const bool fused_warp = ctx->warp_out && !a->any_fry;   // (the fry edit rewrites rows afterwards: the warp then stays a pass of its own)
-        const size_t lds_w = fused_warp ? sizeof(float) * 2 * A_ROWS * B : 0;
+        const size_t lds_w = fused_warp ? sizeof(float) * 2 * A_ROWS * (B + 1) : 0;
         const double *wf = fused_warp ? ctx->warp_formants : nullptr;
         const goofer_note_params *wp = fused_warp ? ctx->warp_params : nullptr;
         float *wo = fused_warp ? ctx->warp_out : nullptr;
@@ -642,7 +709,13 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         eg.inv_fstep = (float)(1.0 / eg.fstep);
         eg.nyq_f = (float)((double)a->sr * 0.5);
         eg.warp = make_warp_grid(ctx->plan.sr, B);
-#define ENV_LOOP(W, C) hipLaunchKernelGGL((k_env_loop<W, C>), lgrid, dim3(256), lds_w, st, *a, a->total_out_rows, row_note_out, wf, wp, wo, eg)
+        eg.freqs_f = (ctx->plan.n_bins == B && ctx->plan.sr == a->sr) ? ctx->plan.lin_freqs : nullptr;
+#define ENV_LOOP_V(W, C, V) hipLaunchKernelGGL((k_env_loop<W, C, V>), lgrid, dim3(256), lds_w, st, *a, a->total_out_rows, row_note_out, wf, wp, wo, eg)
+#define ENV_LOOP(W, C)                                                                                                              \
+    do {                                                                                                                            \
+        if (ctx->value_f64) ENV_LOOP_V(W, C, true);                                                                                 \
+        else ENV_LOOP_V(W, C, false);                                                                                               \
+    } while (0)
         const int chunks = (B + WAVE - 1) / WAVE;
         if (fused_warp) {
             if (chunks == 9) ENV_LOOP(true, 9);
@@ -655,6 +728,7 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
             else ENV_LOOP(false, 0);
         }
 #undef ENV_LOOP
+#undef ENV_LOOP_V
         LAUNCH_CHECK(ctx);
         if (a->any_fry) {
             size_t lds = (size_t)A_ROWS * ((B + 3) & ~3) * sizeof(float);

@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void k_warp_bins(const float *__restrict__ in,
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
     if (row >= rows) return;                       // no block-level barrier below
-    float *ra = s_all + (2 * wave) * n_bins;
-    float *rb = ra + n_bins;
+    float *ra = s_all + (2 * wave) * (n_bins + 1);       // (+ 1: the pad element of warp_row's fp32 lerp)
+    float *rb = ra + n_bins + 1;
     const int64_t src = row_src ? row_src[row] : row;
     for (int b = lane; b < n_bins; b += WAVE) ra[b] = in[src * ld + b];
     wave_lds_sync();
@@ -101,7 +101,7 @@ int launch_warp_bins(goofer_ctx *ctx, const float *in, float *out, int64_t rows,
                      const int64_t *row_src, double ratio, hipStream_t st)
 {
     if (rows <= 0) return GOOFER_OK;
-    size_t lds = sizeof(float) * 2 * ROWS_PER_BLOCK * n_bins;
+    size_t lds = sizeof(float) * 2 * ROWS_PER_BLOCK * (n_bins + 1);
     hipLaunchKernelGGL(k_warp_bins, dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), lds, st, in, out,
                        rows, n_bins, ld, formants, d_f_shift, params, row_note, row_src, ratio, make_warp_grid(ctx->plan.sr, n_bins));
     LAUNCH_CHECK(ctx);

@@ -126,6 +126,10 @@ __device__ __forceinline__ double row_interp(const float *r, int n_bins, double 
 // segment lookup is three LDS reads instead of a select chain over register arrays.
 // GOOFER.py:840-875, 618-627; each stage rounds to fp32 like the reference.
 constexpr int WARP_SEG_DOUBLES = 18;
+// fp32 segment record of the sorted-anchor warp (8-byte aligned like the table it overlays: one ds_read2_b64 per bin)
+struct alignas(8) warp_seg_f32 {
+    float d, s, c, pad;
+};
 
 // The bin grid of a plan, made once on the host (three fp64 divisions per row otherwise): np.linspace(0, nyq, n_bins)'s
 // spacing and its reciprocal.
@@ -141,14 +145,47 @@ static inline warp_grid make_warp_grid(int sr, int n_bins)
     return g;
 }
 
+// Which notes' harmonic rows differ from their assembled rows: some fa..fd shift with formant tracks at hand, or a
+// uniform shift (GOOFER.py:1004-1017).  One definition for the kernel that writes the warped copies and the walker that
+// chooses which row to read.
+__device__ __forceinline__ bool note_shifts_formants(const goofer_note_params &q)
+{
+    return q.f_shift[0] != 1.0 || q.f_shift[1] != 1.0 || q.f_shift[2] != 1.0 || q.f_shift[3] != 1.0;
+}
+__device__ __forceinline__ bool note_warps(const goofer_note_params &q, bool have_formants)
+{
+    return (have_formants && note_shifts_formants(q)) || (double)q.formant_shift != 1.0;
+}
+
 // CH: 64-bin chunks of a row when known at compile time (the per-bin loop of the common sorted-anchor case is then
 // unrolled, so its LDS round trips overlap), 0 = any width.
-template <int CH = 0>
+//
+// F32 (the default): the per-bin VALUE arithmetic of the sorted-anchor warp and of the uniform warp runs in fp32 — the
+// anchors, slopes, segment thresholds (everything that decides an index or a comparison, once per row) stay fp64.  The
+// source position of bin b is kept as the DISPLACEMENT delta(b) = pos(b) - b = A_k + (s_k - 1) b, whose magnitude is the
+// size of the formant shift in bins (a few), not the bin index (hundreds): its fp32 rounding is ~1e-6 bins against ~5e-5
+// for pos itself, j = b + floor(delta) is exact integer arithmetic and the fraction is delta - floor(delta), exact.  The
+// lerp is one subtraction and one FMA.  Error against the fp64 path: ~1e-6 bins of position (x the row's slope: far below
+// an ulp on the smooth envelopes of this path; the uniform warp's displacement grows to the bin index, 3e-5 bins) plus
+// 1.5 ulp of fp32 — DESIGN.md 4 (error budget); option "value_f64" keeps the fp64
+// arithmetic for A/B.  In F32 mode BOTH row buffers must have n_bins + 1 readable floats: the pad element makes the
+// right neighbour of the last bin a finite value (weight exactly 0) instead of a bounds test per bin.
+template <int CH = 0, bool F32 = true>
 __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, const warp_grid &grid, const double *formants, const double *fs,
                                            bool warp, double ratio, int lane, double *seg)
 {
     const double nyq = grid.nyq, step = grid.step, inv_step = grid.inv_step;
     float *cur = ra, *nxt = rb;
+    const float topf = (float)(n_bins - 1);
+    // one output bin of either fp32 stage: displacement dl (bins) -> clamp the position to [0, n_bins - 1] -> 2-tap lerp
+    auto lerp_f32 = [&](int b, float bf, float dl) {
+        dl = __builtin_amdgcn_fmed3f(dl, -bf, topf - bf);
+        const float fl = __builtin_floorf(dl);
+        const int j2 = b + (int)fl;
+        const float d = dl - fl;                                           // exact (Sterbenz / same binade), in [0, 1)
+        const float r0 = cur[j2], r1 = cur[j2 + 1];                        // j2 = n_bins - 1 only with d == 0: the pad element
+        nxt[b] = __builtin_fmaf(r1 - r0, d, r0);
+    };
 
     if (warp && formants) {
         // anchors: (0,0), valid (shifted -> orig) in formant order, (nyq, nyq)      GOOFER.py:850-865
@@ -184,14 +221,6 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, con
                 // pos(b) = A_k + s_k b on segment k, with s_k the np.interp slope and A_k = (y_k - s_k x_k) / step.
                 // Folding the two interpolations into that form moves the fp64 intermediates by ~1e-13 bins — far
                 // below the fp32 rounding of the result — and leaves ~25 vector instructions per bin instead of ~85.
-                wave_lds_sync();                                       // every lane holds its anchors: the table may be overwritten
-                if (lane < len) {
-                    const double sl = lane < len - 1 ? (yn - yk) * fast_rcp(xn - xk) : 0.0;
-                    seg[3 * lane] = (yk - sl * xk) * inv_step;         // A_k
-                    seg[3 * lane + 1] = sl;                            // s_k
-                    seg[3 * lane + 2] = xk;
-                }
-                wave_lds_sync();
                 // segment of bin b = number of anchors d_k (k >= 1) with d_k <= x(b), x(b) = b step (nyq for the last bin) — x is
                 // increasing in b, so anchor k contributes from the first bin thr_k on: lane k finds thr_k once per row with the
                 // very comparison the per-bin search would make, and the bins compare integers (five fp64 compares, a
@@ -208,12 +237,38 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, con
                     else if (c < n_bins && !(dk <= xb(c))) ++c;
                     thr = c;
                 }
+                wave_lds_sync();                                       // every lane holds its anchors: the table may be overwritten
+                warp_seg_f32 *segf = reinterpret_cast<warp_seg_f32 *>(seg);
+                if (lane < len) {
+                    const double sl = lane < len - 1 ? (yn - yk) * fast_rcp(xn - xk) : 0.0;
+                    if constexpr (F32) {
+                        // displacement on segment k, centred on the segment's first bin c_k: delta(b) = D_k + (s_k - 1)(b - c_k) with
+                        // D_k = pos(c_k) - c_k.  Both terms are of the size of the formant shift in bins, whatever |A_k| is (two
+                        // anchors shifted close together give slopes of 10 and intercepts of hundreds of bins)
+                        const double ck = lane >= 1 ? (double)thr : 0.0;
+                        const double A = (yk - sl * xk) * inv_step;
+                        segf[lane] = warp_seg_f32{(float)(A + (sl - 1.0) * ck), (float)(sl - 1.0), (float)ck, 0.f};
+                    } else {
+                        seg[3 * lane] = (yk - sl * xk) * inv_step;         // A_k
+                        seg[3 * lane + 1] = sl;                            // s_k
+                        seg[3 * lane + 2] = xk;
+                    }
+                }
+                if constexpr (F32) {
+                    if (lane == 0) cur[n_bins] = cur[n_bins - 1];      // pad element (see above)
+                }
+                wave_lds_sync();
                 // lanes >= len keep n_bins, so absent anchors never count
                 const int t1 = __builtin_amdgcn_readlane(thr, 1), t2 = __builtin_amdgcn_readlane(thr, 2), t3 = __builtin_amdgcn_readlane(thr, 3),
                           t4 = __builtin_amdgcn_readlane(thr, 4), t5 = __builtin_amdgcn_readlane(thr, 5);
                 const double top = (double)(n_bins - 1);
-                auto bin = [&](int b) {
-                    const int j = (b >= t1) + (b >= t2) + (b >= t3) + (b >= t4) + (b >= t5);
+                auto bin = [&](int b, int j) {
+                    if constexpr (F32) {
+                        const warp_seg_f32 as = segf[j];
+                        const float bf = (float)b;
+                        lerp_f32(b, bf, __builtin_fmaf(as.s, bf - as.c, as.d));
+                        return;
+                    }
                     double pos = fma(seg[3 * j + 1], (double)b, seg[3 * j]);
                     pos = __builtin_fmax(0.0, __builtin_fmin(pos, top));          // (finite: the anchors are)
                     int j2 = (int)pos;
@@ -222,14 +277,41 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, con
                     const double r0 = (double)cur[j2];
                     nxt[b] = (float)(((double)cur[j2 + 1] - r0) * d + r0);
                 };
-                if (CH > 0) {
+                auto seg_of = [&](int b) { return (b >= t1) + (b >= t2) + (b >= t3) + (b >= t4) + (b >= t5); };
+                if constexpr (CH > 0 && CH <= 18 && F32) {
+                    // The segment of the lane's bin in chunk c, for every chunk at once: anchor k counts from the lane's first chunk
+                    // ck = ceil((t_k - lane) / 64) on, so with 3-bit fields per chunk the packed segment indices are the sum over k of
+                    // the all-ones-fields constant shifted up by 3 ck (a field holds at most 5).  Five thresholds cost ~28 vector
+                    // instructions per row; a bin then takes its segment with one bit-field extract instead of five compares,
+                    // selects, shifts and adds (17 instructions as compiled).  Nine chunks per 32-bit word.
+                    constexpr int NW = (CH + 8) / 9;
+                    uint32_t jw[NW];
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) jw[q] = 0;
+                    const int tk[5] = {t1, t2, t3, t4, t5};
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const int ck = (tk[k] + 63 - lane) >> 6;                   // >= 0 for thresholds >= 0 (they are)
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) {
+                            int sh = ck - 9 * q;
+                            sh = sh < 0 ? 0 : (sh > 10 ? 10 : sh);
+                            jw[q] += 0x09249249u << (3 * sh);                      // fields past the word's nine fall off the top
+                        }
+                    }
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
                         const int b = lane + WAVE * c;
-                        if (c < CH - 1 || b < n_bins) bin(b);
+                        if (c < CH - 1 || b < n_bins) bin(b, (int)((jw[c / 9] >> (3 * (c % 9))) & 7u));
+                    }
+                } else if constexpr (CH > 0) {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int b = lane + WAVE * c;
+                        if (c < CH - 1 || b < n_bins) bin(b, seg_of(b));
                     }
                 } else {
-                    for (int b = lane; b < n_bins; b += WAVE) bin(b);
+                    for (int b = lane; b < n_bins; b += WAVE) bin(b, seg_of(b));
                 }
             } else {
                 for (int b = lane; b < n_bins; b += WAVE) {
@@ -314,6 +396,24 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, con
         // env(f) <- env(clip(f / ratio, 0, nyq)): in bin units the source position is b / ratio (GOOFER.py:618-627)
         const double inv_ratio = fast_rcp(ratio);
         const double top = (double)(n_bins - 1);
+        if constexpr (F32) {
+            if (lane == 0) cur[n_bins] = cur[n_bins - 1];
+            wave_lds_sync();
+            const float irm1 = (float)(inv_ratio - 1.0);                  // displacement per bin: b / ratio - b
+            if (CH > 0) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int b = lane + WAVE * c;
+                    const float bf = (float)b;
+                    if (c < CH - 1 || b < n_bins) lerp_f32(b, bf, irm1 * bf);
+                }
+            } else {
+                for (int b = lane; b < n_bins; b += WAVE) {
+                    const float bf = (float)b;
+                    lerp_f32(b, bf, irm1 * bf);
+                }
+            }
+        } else
         for (int b = lane; b < n_bins; b += WAVE) {
             double pos = (double)b * inv_ratio;
             pos = pos < 0.0 ? 0.0 : (pos > top ? top : pos);

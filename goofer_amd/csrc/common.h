@@ -19,6 +19,7 @@ struct goofer_plan_t {
     float *blur_edge = nullptr;   // [4][64] per-lane coefficients of the blur's edge correction (bins 1..6 and M-6..M-1)
     float *win_sq = nullptr;      // [n_fft] window*window in fp32 (OLA weights)  GOOFER.py:385
     float *freqs = nullptr;       // [n_bins] rfftfreq fp32                       GOOFER.py:20-26
+    float *lin_freqs = nullptr;   // [n_bins] np.linspace(0, sr/2, n_bins) rounded to fp32 (the bells' bin frequencies, SillySampler.py:812)
     float *boost = nullptr;       // [n_bins] linspace(1,100)                     GOOFER.py:28-35
     float *bright_h = nullptr;    // [n_bins] harmonic brightness                 GOOFER.py:42
     float *bright_b = nullptr;    // [n_bins] breath brightness                   GOOFER.py:43
@@ -87,6 +88,8 @@ struct goofer_ctx {
     int walk_lds_kb = 81;         // LDS the sequential phase walk reserves per workgroup (what it uses: 32 KiB)
     int finish_lds_kb = 0;        // KB of the breath stem k_note_finish parks in LDS between its passes (0: the default 144, < 0: none)
     int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
+    bool value_f64 = false;       // assembly kernels: round 4's fp64 value arithmetic (tap blend, warp / fw interpolation, es blur) instead of
+                                  // fp32 — A/B and the error-budget tests (option "value_f64")
     bool mask_side = false;       // goofer_render_batch: the mask smoothing on the side stream in front of the pulse chain (option "mask_side"; measured: -0.4 %)
     // n_fft 2048 (stems_ring.hip), both measured slower than the spectra-in-HBM kernels on BASELINE config 5 and off by default:
     bool rfft_shape = false;    // the framewise rFFT and the harmonic shaping as one kernel (10.3 ms against 2.9 + 5.7 ms)

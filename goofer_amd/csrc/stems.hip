@@ -656,9 +656,11 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
 
 // ---------------------------------------------------------------------------------------------
 // `env` holds the harmonic envelope rows as the shaping step needs them: already warped (k_warp_bins, one row per frame)
-// or, when no note of the batch warps, the source rows addressed through row_src.
+// or, when no note of the batch warps, the source rows addressed through row_src.  env_plain (goofer_render_batch): the
+// assembled rows; `env` then holds warped copies of the warping notes' rows only (frame_block::mark_plain).
 template <int M>
-__global__ __launch_bounds__(256, 3) void k_harm_stem(const float *__restrict__ pulse, const float *__restrict__ env, int ld,
+__global__ __launch_bounds__(256, 3) void k_harm_stem(const float *__restrict__ pulse, const float *__restrict__ env,
+                                                      const float *__restrict__ env_plain, int have_formants, int ld,
                                                       const int64_t *__restrict__ row_src, int64_t total_frames,
                                                       const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
                                                       const int64_t *__restrict__ sample_off, const float2 *__restrict__ picks,
@@ -680,6 +682,7 @@ __global__ __launch_bounds__(256, 3) void k_harm_stem(const float *__restrict__ 
     if (!w.range(total_frames, run, frame_note, frame_off, fs, f0, f1)) return;   // no block barrier below
     frame_block fb;
     fb.load(fs, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
+    if (env_plain) fb.mark_plain(params, have_formants != 0);
 
     // Three waves per SIMD (168 registers): the frame's inputs — raw sample pairs (reflect-padded at the note ends,
     // GOOFER.py:358-360) and the envelope row — are fetched at the head of the frame that uses them.  Round 3 held the NEXT
@@ -717,7 +720,8 @@ __global__ __launch_bounds__(256, 3) void k_harm_stem(const float *__restrict__ 
                 raw[r] = make_float2(a, b);
             }
         }
-        const float *er = env + (int64_t)FB_GET(fb, src, idx) * ld;
+        const int srow = FB_GET(fb, src, idx);                      // (bit 31: the note does not warp — read the assembled row)
+        const float *er = (srow < 0 ? env_plain : env) + (int64_t)(srow & 0x7fffffff) * ld;
 #pragma unroll
         for (int i = 0; i < PER; ++i) ev[i] = er[lane + WAVE * i < B ? lane + WAVE * i : B - 1];
     };
@@ -733,7 +737,10 @@ __global__ __launch_bounds__(256, 3) void k_harm_stem(const float *__restrict__ 
     for (int64_t f = fs; f < f1; ++f) {
         float2 X[PER];
         float evc[PER];
-        if (!fb.holds(f)) fb.load(f, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
+        if (!fb.holds(f)) {
+            fb.load(f, total_frames, frame_note, frame_off, sample_off, row_src, picks, lane);
+            if (env_plain) fb.mark_plain(params, have_formants != 0);
+        }
         const int idx = (int)(f - fb.blk0);
         fetch(idx);
         const int t = FB_GET(fb, t, idx);
@@ -1087,8 +1094,10 @@ int launch_noise_stems(goofer_ctx *ctx, const float *env, int ld, const int64_t 
     return GOOFER_OK;
 }
 
-// env: warped rows, one per frame (row_src == nullptr), or source rows through row_src when nothing warps
-int launch_harm_stem(goofer_ctx *ctx, const float *pulse, const float *env, int ld, const int64_t *row_src, int64_t F,
+// env: warped rows, one per frame (row_src == nullptr), or source rows through row_src when nothing warps; env_plain != nullptr:
+// `env` holds the warped copies of the warping notes only, the other notes' rows are read from env_plain (same row index)
+int launch_harm_stem(goofer_ctx *ctx, const float *pulse, const float *env, const float *env_plain, bool have_formants, int ld,
+                     const int64_t *row_src, int64_t F,
                      const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, const float2 *picks,
                      const goofer_note_params *params, float *harm, float *note_mag, hipStream_t st)
 {
@@ -1105,8 +1114,8 @@ int launch_harm_stem(goofer_ctx *ctx, const float *pulse, const float *env, int 
     if ((rc = kernel_resident_waves(ctx, fn, lds, &slots))) return rc;
     const int run = run_length(F, slots);
     const int64_t runs = (F + run - 1) / run;
-    hipLaunchKernelGGL(k_harm_stem<M>, dim3((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), dim3(256), lds, st, pulse, env, ld,
-                       row_src, F, frame_note, frame_off, sample_off, picks, params, p.freqs, p.boost, p.bright_h, harm,
+    hipLaunchKernelGGL(k_harm_stem<M>, dim3((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK)), dim3(256), lds, st, pulse, env,
+                       env_plain, have_formants ? 1 : 0, ld, row_src, F, frame_note, frame_off, sample_off, picks, params, p.freqs, p.boost, p.bright_h, harm,
                        note_mag, run, p.tw_full, p.tw_half, p.window, p.window_blur, p.blur_edge, ctx->td_blur ? 1 : 0);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;

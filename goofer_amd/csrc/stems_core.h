@@ -55,6 +55,12 @@ struct frame_block {
         const uint64_t key = seed ^ ((uint64_t)params[note].seed[0] | ((uint64_t)params[note].seed[1] << 32));
         ny_u = philox_u16(key, (uint64_t)t, (uint32_t)m_bin);
     }
+    // Harmonic walker behind goofer_render_batch: the assembly's gather kernel wrote warped copies only for the notes that warp
+    // (note_warps, binops_core.h); the frames of the others read the assembled row itself.  Bit 31 of `src` says which.
+    __device__ __forceinline__ void mark_plain(const goofer_note_params *__restrict__ params, bool have_formants)
+    {
+        if (!note_warps(params[note], have_formants)) src |= (int)0x80000000;
+    }
     __device__ __forceinline__ bool holds(int64_t f) const { return f >= blk0 && f < blk0 + WAVE; }
 };
 #define FB_GET(fb, field, idx) __builtin_amdgcn_readlane((fb).field, (idx))

@@ -20,7 +20,9 @@ for v in (v0, v1):
     outs[v] = {k: o[k].clone() for k in ("mix", "uv", "bre", "harm")}
 for k in ("mix", "uv", "bre", "harm"):
     same = torch.equal(outs[v0][k], outs[v1][k])
-    print(k, "bit-identical" if same else "DIFFERENT: max |d| = %g" % float((outs[v0][k] - outs[v1][k]).abs().max()))
+    d = (outs[v0][k].double() - outs[v1][k].double())
+    print(k, "bit-identical" if same else "DIFFERENT: max |d| = %g, rms d = %g (rms signal %g, max %g)" % (
+        float(d.abs().max()), float(d.pow(2).mean().sqrt()), float(outs[v0][k].double().pow(2).mean().sqrt()), float(outs[v0][k].abs().max())))
 for rep in range(2):
     for v in (v0, v1):
         ctx.set_option(name, v)

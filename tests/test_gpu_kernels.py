@@ -304,7 +304,8 @@ def test_warp_bins_crossing_anchors_follow_numpy_interp(ctx):
         assert crossing > 0.1
         assert np.max(np.abs(out - ref)) <= 2e-7 * np.abs(ref).max(), ratios
         both = ctx.warp_bins(rows, formants=dF, f_shift=ratios, ratio=1.25).cpu().numpy().T
-        assert np.max(np.abs(both - R.shift_formants(ref, 1.25, 44100))) <= 3e-7 * np.abs(ref).max()
+        # two chained fp32 interpolation stages (round 5: the per-bin lerps run in fp32): 4 ulp of the row maximum
+        assert np.max(np.abs(both - R.shift_formants(ref, 1.25, 44100))) <= 5e-7 * np.abs(ref).max()
 
 
 def test_knot_decode(ctx):
