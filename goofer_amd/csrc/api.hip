@@ -40,7 +40,8 @@ int launch_noise_spectra(goofer_ctx *, float2 *, float2 *, int, int64_t, const i
 int launch_frame_skip(goofer_ctx *, const double *, int64_t, const int64_t *, const int64_t *, const int *, int, int64_t, unsigned char *,
                       unsigned char *, unsigned char *, hipStream_t);
 int launch_mask_short(goofer_ctx *, const float *, const int64_t *, int, int64_t, const double *, int, double, double *, hipStream_t);
-int launch_assemble(goofer_ctx *, const goofer_assembly *, int *, int *, hipStream_t);
+int launch_assemble(goofer_ctx *, const goofer_assembly *, int *, int *, void *, hipStream_t);
+size_t env_row_rec_bytes();
 int launch_mag_rows(goofer_ctx *, const float2 *, int, int64_t, int, float *, int, hipStream_t);
 int launch_gauss_rows64(goofer_ctx *, const float *, int, double *, int, int64_t, int, const double *, int, hipStream_t);
 int launch_knot_error(goofer_ctx *, const double *, int, const int64_t *, int, int, const int *, int, const int *, const float *,
@@ -1078,8 +1079,9 @@ int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *asmb, void *st
     hipStream_t st = (hipStream_t)stream;
     goofer_assembly a = *asmb;
     size_t map_bytes = ((size_t)(a.total_edit_rows + a.total_out_rows) * sizeof(int) + 511) & ~(size_t)255;
-    size_t rows_bytes = a.edit_rows ? 0 : (size_t)a.total_edit_rows * a.ld * sizeof(float);
-    size_t need = map_bytes + rows_bytes + 4096;
+    size_t rows_bytes = a.edit_rows ? 0 : (((size_t)a.total_edit_rows * a.ld * sizeof(float) + 255) & ~(size_t)255);
+    size_t rec_bytes = ctx->value_f64 ? 0 : (size_t)a.total_out_rows * env_row_rec_bytes();   // per-row records of k_row_recs / k_env_rows
+    size_t need = map_bytes + rows_bytes + rec_bytes + 4096;
     if (ctx->asm_bytes < need) {
         HIP_TRY(ctx, hipDeviceSynchronize());
         if (ctx->asm_scratch) HIP_TRY(ctx, hipFree(ctx->asm_scratch));
@@ -1092,7 +1094,8 @@ int goofer_assemble_batch(goofer_ctx *ctx, const goofer_assembly *asmb, void *st
     int *map_edit = (int *)ctx->asm_scratch;
     int *map_out = map_edit + a.total_edit_rows;
     if (!a.edit_rows) a.edit_rows = (float *)((char *)ctx->asm_scratch + map_bytes);
-    return launch_assemble(ctx, &a, map_edit, map_out, st);
+    void *recs = (char *)ctx->asm_scratch + map_bytes + rows_bytes;
+    return launch_assemble(ctx, &a, map_edit, map_out, recs, st);
 }
 
 int goofer_stretch_rows(goofer_ctx *ctx, const float *in, int64_t ld_in, int64_t rows_in, float *out, int64_t ld_out, int64_t rows_out,

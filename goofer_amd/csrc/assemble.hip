@@ -380,6 +380,426 @@ __global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_row_recs + k_env_rows — k_env_loop's work (fp32 value arithmetic) with the per-row set-up taken off the rows' critical path.
+//
+// k_env_loop gives every output row a wave, and that wave walks a chain of dependent loads before it touches a bin:
+// row -> note -> plan -> taps -> source rows -> (formants, parameters) -> stores, with the bells' reach and the warp's anchor
+// table (fp64) computed across its lanes in between.  Measured (round 5, AMD_SERIALIZE_KERNEL trace): 0.43 ms alone for
+// 194 560 rows whether the per-bin arithmetic is fp64 or fp32 — three quarters of its wave-cycles are waits, the rest ~1 200
+// instructions per row of which the bins need a third.  (A wave walking a run of rows with the records built lane-parallel in
+// LDS was measured too: 0.50-0.62 ms — three or four such waves per SIMD hide less latency than eight short ones.)
+//
+// Here the set-up is a kernel of its own with one THREAD per row (k_row_recs): absolute source rows and fp32 weights of the
+// 4 taps, the four bells (centre, gain - 1, reach as a chunk mask), and the warp — anchors compacted, sortedness, per-segment
+// (D, s - 1, c) records and integer thresholds: exactly the fp64 set-up of warp_row's sorted path, in the same order of
+// operations.  It writes a 224-byte record per row (43 MB per 1024-note batch against 1.2 GB of rows).  k_env_rows then is
+// what is left: the record arrives through a few scalar loads (straight into SGPRs), the source row(s), bells, store, and
+// for warping notes the fp32 lerp(s) straight into the warped copy.  Rows with crossing anchors (np.interp's guess chain,
+// rare) take warp_row's cross-lane path unchanged.
+struct alignas(16) env_row_rec {
+    uint32_t src[4];         // rows of the edited-row scratch
+    float w[4];              // tap weights (fp32)
+    float F[4], g[4];        // bells: centre (Hz), gain - 1
+    uint32_t cm[4];          // ... and the 64-bin chunks each can move (0: bell off)
+    int32_t thr[5];          // sorted-anchor warp: first bin of segments 1..5 (n_bins: absent)
+    int32_t flags;           // ER_* bits
+    float irm1;              // uniform warp: displacement per bin, 1 / ratio - 1
+    int32_t note;
+    int32_t pad[2];
+    warp_seg_f32 seg[6];
+};
+static_assert(sizeof(env_row_rec) == 224, "record layout");
+enum { ER_COPY = 1, ER_NZ0 = 2, ER_WARP = 32, ER_STAGE1 = 64, ER_SORTED = 128, ER_STAGE2 = 256 };
+size_t env_row_rec_bytes() { return sizeof(env_row_rec); }
+
+template <bool WARP>
+__global__ __launch_bounds__(256) void k_row_recs(const goofer_assembly a, int64_t total_out_rows, const int *__restrict__ row_note,
+                                                  const double *__restrict__ w_formants, const goofer_note_params *__restrict__ w_params,
+                                                  env_row_rec *__restrict__ recs, const env_loop_grid eg)
+{
+    const int64_t orow = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (orow >= total_out_rows) return;
+    const int B = a.n_bins;
+    const double nyq = eg.warp.nyq, step = eg.warp.step, inv_step = eg.warp.inv_step;
+    const int note = row_note[orow];
+    const goofer_note_plan *pp = a.notes + note;
+    const int64_t t = orow - pp->env_off;
+    const int32_t *ti = a.tap_idx + (pp->tap_off + t) * 4;
+    const double *tw = a.tap_w + (pp->tap_off + t) * 4;
+    const int64_t e0 = pp->edit_off - pp->row_lo;
+    env_row_rec rc;
+    int flags = 0;
+    double w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        w[k] = tw[k];
+        rc.src[k] = (uint32_t)(e0 + ti[k]);
+        rc.w[k] = (float)w[k];
+        if (w[k] != 0.0) flags |= ER_NZ0 << k;
+    }
+    if (w[0] == 1.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 0.0) flags |= ER_COPY;
+    // formant-strength bells                                        SillySampler.py:817-830
+    // 1/sigma and -0.5*log2(e): the bell exp(-0.5 ((f - F)/sigma)^2) goes through the hardware exp2 in k_env_rows.  Bins a bell
+    // cannot move: the factor 1.0f + g*wt rounds to exactly 1.0f once |g| wt < 2^-25, i.e. beyond z^2 > (25 + log2|g|) /
+    // (0.5 log2 e).  Two more bits and a bin on either side cover the hardware exp2 / log2 and the rounding of the bin
+    // frequency; a 64-bin chunk wholly outside the reach skips the bell (a wave-uniform branch), which is most of them: sigma
+    // is 100-500 Hz against 22 kHz of bins.  The product is unchanged bit for bit.  The reach is a bit per chunk it touches
+    // (rounded outwards: an extra chunk only multiplies by exactly 1.0f).
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double sv = pp->fst[k];
+        const float Fl = a.fst_tracks[orow * 4 + k];
+        const bool on = !(fabs(sv) < 1e-6) && isfinite(Fl) && !(Fl <= 50.0f) && !(Fl >= eg.nyq_f);
+        const float gl = (float)((1.0 + sv) - 1.0);              // python-float (gain - 1.0), weak-cast to fp32
+        const float sgl = k == 0 ? 100.0f : (k == 1 ? 200.0f : (k == 2 ? 350.0f : 500.0f));
+        unsigned cm = 0;
+        if (on) {
+            const float lg = __builtin_amdgcn_logf(fabsf(gl));                    // log2
+            const float z2 = (27.0f + fmaxf(lg, 0.0f)) * 1.3862943611198906f;     // / (0.5 log2 e)
+            const float R = __builtin_amdgcn_sqrtf(z2) * sgl * 1.0001f;           // (x sigma for / (1/sigma): rounded outwards)
+            const float blo = (Fl - R) * eg.inv_fstep - 1.0f, bhi = (Fl + R) * eg.inv_fstep + 1.0f;
+            const int c_lo = (int)floorf(fminf(fmaxf((blo - 63.0f) * (1.0f / 64.0f), 0.0f), 31.0f));
+            const int c_hi = (int)ceilf(fminf(fmaxf(bhi * (1.0f / 64.0f), -1.0f), 31.0f));
+            if (c_hi >= c_lo) cm = (0xffffffffu >> (31 - c_hi)) & (0xffffffffu << c_lo);
+        }
+        rc.F[k] = Fl;
+        rc.g[k] = gl;
+        rc.cm[k] = cm;
+    }
+    rc.irm1 = 0.f;
+    rc.note = note;
+    rc.pad[0] = rc.pad[1] = 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) rc.thr[q] = B;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) rc.seg[q] = warp_seg_f32{0.f, 0.f, 0.f, 0.f};
+    if (WARP) {
+        const goofer_note_params *qp = w_params + note;
+        double fs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fs[k] = qp->f_shift[k];
+        const double ratio = (double)qp->formant_shift;
+        const bool stage1 = w_formants != nullptr && (fs[0] != 1.0 || fs[1] != 1.0 || fs[2] != 1.0 || fs[3] != 1.0);
+        const bool stage2 = ratio != 1.0;
+        if (stage1 || stage2) flags |= ER_WARP;
+        if (stage2) {
+            flags |= ER_STAGE2;
+            rc.irm1 = (float)(fast_rcp(ratio) - 1.0);
+        }
+        if (stage1) {
+            flags |= ER_STAGE1;
+            // anchors: (0,0), valid (shifted -> orig) in formant order, (nyq, nyq)      GOOFER.py:850-865
+            double x[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, y[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            int len = 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double fo = w_formants[orow * 4 + k];
+                const double fsft = fo * fs[k];
+                const bool valid = fo > 50.0 && fo < nyq && fsft > 50.0;
+#pragma unroll
+                for (int q = 1; q <= 4; ++q)
+                    if (valid && q == len) { x[q] = fsft; y[q] = fo; }
+                len += valid ? 1 : 0;
+            }
+#pragma unroll
+            for (int q = 1; q <= 5; ++q)
+                if (q == len) { x[q] = nyq; y[q] = nyq; }
+            ++len;
+            bool sorted = true;
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                if (q < len - 1 && !(x[q] <= x[q + 1])) sorted = false;
+            if (sorted) {
+                flags |= ER_SORTED;
+                auto xb = [&](int c) { return c >= B - 1 ? nyq : (double)c * step; };
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    if (q < len) {
+                        int thr = B;
+                        if (q >= 1) {
+                            const double dk = x[q];
+                            const double est = ceil(dk * inv_step);
+                            int c = est < 0.0 ? 0 : (est > (double)(B - 1) ? B - 1 : (int)est);
+                            if (c > 0 && dk <= xb(c - 1)) --c;
+                            else if (c < B && !(dk <= xb(c))) ++c;
+                            thr = c;
+                            rc.thr[q - 1] = thr;
+                        }
+                        const double xn = x[q < 5 ? q + 1 : 5], yn = y[q < 5 ? q + 1 : 5];
+                        const double sl = q < len - 1 ? (yn - y[q]) * fast_rcp(xn - x[q]) : 0.0;
+                        const double ck = q >= 1 ? (double)thr : 0.0;
+                        const double A = (y[q] - sl * x[q]) * inv_step;
+                        rc.seg[q] = warp_seg_f32{(float)(A + (sl - 1.0) * ck), (float)(sl - 1.0), (float)ck, 0.f};
+                    }
+                }
+            }
+        }
+    }
+    rc.flags = flags;
+    recs[orow] = rc;
+}
+
+template <bool WARP, int CH>
+__global__ __launch_bounds__(256) void k_env_rows(const goofer_assembly a, int64_t total_out_rows, const env_row_rec *__restrict__ recs,
+                                                  const double *__restrict__ w_formants, const goofer_note_params *__restrict__ w_params,
+                                                  float *__restrict__ w_out, const env_loop_grid eg)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double s_seg[A_ROWS][WARP_SEG_DOUBLES];
+    const int B = a.n_bins;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // uniform row: the record comes in through scalar loads
+    const int64_t orow = (int64_t)blockIdx.x * A_ROWS + wave;
+    if (orow >= total_out_rows) return;                      // no block barrier below
+    const env_row_rec &rc = recs[orow];
+    float *ra = reinterpret_cast<float *>(smem) + (size_t)(2 * wave) * (B + 1), *rb = ra + B + 1;
+    const float isig[4] = {1.0f / 100.0f, 1.0f / 200.0f, 1.0f / 350.0f, 1.0f / 500.0f};
+    const float topf = (float)(B - 1);
+    const bool nt = eg.nt != 0;
+    const int flags = rc.flags;
+    // (the matrices never overlap: without `restrict` every load of a later chunk has to stay behind the stores of the earlier
+    // ones, and a row became nine dependent round trips to memory instead of one — which, not the arithmetic, was k_env_loop's time)
+    const float *__restrict__ edit = a.edit_rows;
+    float *__restrict__ out = a.env_out + orow * (int64_t)a.ld;
+    const bool copy = (flags & ER_COPY) != 0;
+    auto row_ptr = [&](int k) { return edit + (uint64_t)rc.src[k] * (uint32_t)a.ld; };
+    unsigned cmk[4];
+    float Fk[4], gk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cmk[k] = rc.cm[k];
+        Fk[k] = rc.F[k];
+        gk[k] = rc.g[k];
+    }
+    const unsigned cm_any = cmk[0] | cmk[1] | cmk[2] | cmk[3];
+    const bool warp_on = WARP && (flags & ER_WARP) != 0;
+    auto bells = [&](int c, float fb) {
+        float gain = 1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((cmk[k] >> c) & 1u) {
+                const float z = (fb - Fk[k]) * isig[k];
+                const float wt = __builtin_amdgcn_exp2f((z * z) * -0.72134752044448170368f);
+                gain *= 1.0f + gk[k] * wt;
+            }
+        }
+        return gain;
+    };
+    // np.linspace(0, sr/2, B) as fp32: the plan's table where the plan has this many bins
+    auto bin_freq = [&](int b) { return eg.freqs_f ? eg.freqs_f[b] : (float)(b >= B - 1 ? (double)a.sr / 2.0 : (double)b * eg.fstep); };
+    const bool stage1 = (flags & ER_STAGE1) != 0, stage2 = (flags & ER_STAGE2) != 0;
+    const bool fast1 = warp_on && stage1 && (flags & ER_SORTED) != 0;
+    constexpr int CHS = (CH > 0 && CH <= 18) ? CH : 1;
+    warp_seg_f32 as[CHS];                                    // segment record of the lane's bin in every chunk (sorted-anchor warp)
+    if constexpr (CH > 0 && CH <= 18) {
+        // ... read per lane from the row's record (16-byte loads that hit the lines the scalar loads brought in), with the
+        // row's other loads: behind the row's stores they would wait for those to be acknowledged (one counter, in order)
+        if (fast1) {
+            constexpr int NW = (CH + 8) / 9;
+            uint32_t jw[NW];
+            const int tk[5] = {rc.thr[0], rc.thr[1], rc.thr[2], rc.thr[3], rc.thr[4]};
+            warp_seg_words<NW>(tk, lane, jw);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) as[c] = rc.seg[warp_seg_at<NW>(jw, c)];
+        }
+    }
+    if constexpr (CH > 0) {
+        // every load of the row first — the source row(s), the bin frequencies of the chunks a bell reaches — then the arithmetic
+        float v[CH], fb[CH];
+        auto idx = [&](int c) {
+            const int b = c * WAVE + lane;
+            return (c < CH - 1 || b < B) ? b : B - 1;
+        };
+        const float *s0 = row_ptr(0);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) v[c] = s0[idx(c)];
+        if (!copy) {
+            // zero-weight taps are skipped (their rows may hold anything); the others are one product and FMAs in tap order —
+            // an L1 mirror mean (0.5, 0.5) is still the exact fp32 (a + b) / 2
+            float t1[CH], t2[CH], t3[CH];
+            const float w0 = rc.w[0], w1 = rc.w[1], w2 = rc.w[2], w3 = rc.w[3];
+            if (flags & (ER_NZ0 << 1)) {
+                const float *s1 = row_ptr(1);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) t1[c] = s1[idx(c)];
+            }
+            if (flags & (ER_NZ0 << 2)) {
+                const float *s2 = row_ptr(2);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) t2[c] = s2[idx(c)];
+            }
+            if (flags & (ER_NZ0 << 3)) {
+                const float *s3 = row_ptr(3);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) t3[c] = s3[idx(c)];
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                float vf = 0.f;
+                if (flags & (ER_NZ0 << 0)) vf = w0 * v[c];
+                if (flags & (ER_NZ0 << 1)) vf = __builtin_fmaf(w1, t1[c], vf);
+                if (flags & (ER_NZ0 << 2)) vf = __builtin_fmaf(w2, t2[c], vf);
+                if (flags & (ER_NZ0 << 3)) vf = __builtin_fmaf(w3, t3[c], vf);
+                v[c] = vf;
+            }
+        }
+        if (cm_any) {
+            // (all nine table loads at once, needed or not: a load behind a per-chunk test would wait out its own round trip)
+            if (eg.freqs_f) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) fb[c] = eg.freqs_f[idx(c)];
+            } else {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) fb[c] = bin_freq(idx(c));
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if ((cm_any >> c) & 1u) v[c] *= bells(c, fb[c]);
+        }
+        if (!warp_on) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int b = c * WAVE + lane;
+                if (c < CH - 1 || b < B) store_f1(out + b, v[c], nt);
+            }
+            return;
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int b = c * WAVE + lane;
+            if (c < CH - 1 || b < B) {
+                ra[b] = v[c];
+                if (c == CH - 1 && b == B - 1) ra[B] = v[c];            // pad element of the fp32 lerp
+            }
+        }
+        if (fast1 || !stage1) {
+            // the usual warps, straight from the LDS row into registers; both rows' stores leave together at the end
+            wave_lds_sync();
+            float *__restrict__ wo = w_out + orow * (int64_t)a.ld;
+            float u[CH];
+            if (stage1) {
+                // sorted anchors: delta(b) = D_k + (s_k - 1)(b - c_k) on segment k, 2-tap lerp (warp_row's fp32 path)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int b = lane + WAVE * c;
+                    const float bf = (float)b;
+                    u[c] = (c < CH - 1 || b < B) ? warp_lerp_f32(ra, b, bf, __builtin_fmaf(as[c < CHS ? c : 0].s, bf - as[c < CHS ? c : 0].c, as[c < CHS ? c : 0].d), topf) : 0.f;
+                }
+                if (stage2) {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int b = lane + WAVE * c;
+                        if (c < CH - 1 || b < B) {
+                            rb[b] = u[c];
+                            if (c == CH - 1 && b == B - 1) rb[B] = u[c];
+                        }
+                    }
+                    wave_lds_sync();
+                }
+            }
+            if (stage2) {
+                const float *cur = stage1 ? rb : ra;
+                const float irm1 = rc.irm1;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int b = lane + WAVE * c;
+                    const float bf = (float)b;
+                    u[c] = (c < CH - 1 || b < B) ? warp_lerp_f32(cur, b, bf, irm1 * bf, topf) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int b = c * WAVE + lane;
+                if (c < CH - 1 || b < B) store_f1(out + b, v[c], nt);
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int b = c * WAVE + lane;
+                if (c < CH - 1 || b < B) store_f1(wo + b, u[c], nt);
+            }
+            return;
+        }
+        // (crossing anchors: below)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int b = c * WAVE + lane;
+            if (c < CH - 1 || b < B) store_f1(out + b, v[c], nt);
+        }
+    } else {
+        const float *src0 = row_ptr(0), *src1 = row_ptr(copy ? 0 : 1), *src2 = row_ptr(copy ? 0 : 2), *src3 = row_ptr(copy ? 0 : 3);
+        const float w0 = rc.w[0], w1 = rc.w[1], w2 = rc.w[2], w3 = rc.w[3];
+        for (int c = 0, b = lane; b < B; ++c, b += WAVE) {
+            float vf = 0.f;
+            if (copy) {
+                vf = src0[b];
+            } else {
+                if (flags & (ER_NZ0 << 0)) vf = w0 * src0[b];
+                if (flags & (ER_NZ0 << 1)) vf = __builtin_fmaf(w1, src1[b], vf);
+                if (flags & (ER_NZ0 << 2)) vf = __builtin_fmaf(w2, src2[b], vf);
+                if (flags & (ER_NZ0 << 3)) vf = __builtin_fmaf(w3, src3[b], vf);
+            }
+            const int cc = c < 31 ? c : 31;
+            if ((cm_any >> cc) & 1u) vf *= bells(cc, bin_freq(b));
+            store_f1(out + b, vf, nt);
+            if (warp_on) {
+                ra[b] = vf;
+                if (b == B - 1) ra[B] = vf;
+            }
+        }
+    }
+    if (!warp_on) return;
+    float *__restrict__ wo = w_out + orow * (int64_t)a.ld;
+    wave_lds_sync();
+    if (stage1 && !(flags & ER_SORTED)) {
+        // crossing anchors: np.interp's guess chain, resolved across the lanes (warp_row) — and the uniform stage behind it
+        const goofer_note_params &q = w_params[rc.note];
+        double fs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fs[k] = q.f_shift[k];
+        const float *cur = warp_row<CH, true>(ra, rb, B, eg.warp, w_formants + orow * 4, fs, true, (double)q.formant_shift, lane, s_seg[wave]);
+        for (int b = lane; b < B; b += WAVE) store_f1(wo + b, cur[b], nt);
+        return;
+    }
+    const float *cur = ra;
+    if (stage1) {
+        // sorted anchors: delta(b) = D_k + (s_k - 1)(b - c_k) on segment k, 2-tap lerp (warp_row's fp32 path); the segment
+        // records are read per lane from the row's record (16-byte loads that hit the lines the scalar loads brought in), all
+        // of a lane's bins before the first lerp
+        const int tk[5] = {rc.thr[0], rc.thr[1], rc.thr[2], rc.thr[3], rc.thr[4]};
+        const warp_seg_f32 *segs = rc.seg;
+        auto lerp_bin = [&](int b, const warp_seg_f32 &as, bool to_lds) {
+            const float bf = (float)b;
+            const float v = warp_lerp_f32(ra, b, bf, __builtin_fmaf(as.s, bf - as.c, as.d), topf);
+            if (to_lds) {
+                rb[b] = v;
+                if (b == B - 1) rb[B] = v;
+            } else {
+                store_f1(wo + b, v, nt);
+            }
+        };
+        for (int b = lane; b < B; b += WAVE)
+            lerp_bin(b, segs[(b >= tk[0]) + (b >= tk[1]) + (b >= tk[2]) + (b >= tk[3]) + (b >= tk[4])], stage2);
+        if (stage2) wave_lds_sync();
+        cur = rb;
+    }
+    if (stage2) {
+        const float irm1 = rc.irm1;
+        if (CH > 0) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int b = lane + WAVE * c;
+                const float bf = (float)b;
+                if (c < CH - 1 || b < B) store_f1(wo + b, warp_lerp_f32(cur, b, bf, irm1 * bf, topf), nt);
+            }
+        } else {
+            for (int b = lane; b < B; b += WAVE) {
+                const float bf = (float)b;
+                store_f1(wo + b, warp_lerp_f32(cur, b, bf, irm1 * bf, topf), nt);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // source mask value at index q of the (possibly reversed) source, before tiling.  Indices inside a note are 32-bit: the
 // plan's lengths are int32, and 64-bit integer arithmetic and int64 -> double conversions are several instructions each.
 __device__ __forceinline__ double mask_src(const float *__restrict__ m, const goofer_note_plan &p, int idx)
@@ -649,7 +1069,7 @@ __global__ void k_row_notes2(const goofer_note_plan *__restrict__ notes, int n_n
     if (r < out_rows) row_note_out[r] = lo2;
 }
 
-int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edit, int *row_note_out, hipStream_t st)
+int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edit, int *row_note_out, void *row_recs, hipStream_t st)
 {
     const int B = a->n_bins;
     // f0 and voicing mask first: the pulse chain of the synthesis (a long sequential walk) depends on nothing else, and
@@ -710,14 +1130,27 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         eg.nyq_f = (float)((double)a->sr * 0.5);
         eg.warp = make_warp_grid(ctx->plan.sr, B);
         eg.freqs_f = (ctx->plan.n_bins == B && ctx->plan.sr == a->sr) ? ctx->plan.lin_freqs : nullptr;
-#define ENV_LOOP_V(W, C, V) hipLaunchKernelGGL((k_env_loop<W, C, V>), lgrid, dim3(256), lds_w, st, *a, a->total_out_rows, row_note_out, wf, wp, wo, eg)
-#define ENV_LOOP(W, C)                                                                                                              \
-    do {                                                                                                                            \
-        if (ctx->value_f64) ENV_LOOP_V(W, C, true);                                                                                 \
-        else ENV_LOOP_V(W, C, false);                                                                                               \
-    } while (0)
+#define ENV_LOOP(W, C) hipLaunchKernelGGL((k_env_loop<W, C, true>), lgrid, dim3(256), lds_w, st, *a, a->total_out_rows, row_note_out, wf, wp, wo, eg)
         const int chunks = (B + WAVE - 1) / WAVE;
-        if (fused_warp) {
+        if (!ctx->value_f64) {
+            env_row_rec *recs = reinterpret_cast<env_row_rec *>(row_recs);
+            const dim3 tgrid((unsigned)((a->total_out_rows + 255) / 256));
+            if (fused_warp) hipLaunchKernelGGL(k_row_recs<true>, tgrid, dim3(256), 0, st, *a, a->total_out_rows, row_note_out, wf, wp, recs, eg);
+            else hipLaunchKernelGGL(k_row_recs<false>, tgrid, dim3(256), 0, st, *a, a->total_out_rows, row_note_out, wf, wp, recs, eg);
+            LAUNCH_CHECK(ctx);
+#define ENV_ROWS(W, C) hipLaunchKernelGGL((k_env_rows<W, C>), lgrid, dim3(256), lds_w, st, *a, a->total_out_rows, recs, wf, wp, wo, eg)
+            if (fused_warp) {
+                if (chunks == 9) ENV_ROWS(true, 9);
+                else if (chunks == 17) ENV_ROWS(true, 17);
+                else ENV_ROWS(true, 0);
+                ctx->warp_done = true;
+            } else {
+                if (chunks == 9) ENV_ROWS(false, 9);
+                else if (chunks == 17) ENV_ROWS(false, 17);
+                else ENV_ROWS(false, 0);
+            }
+#undef ENV_ROWS
+        } else if (fused_warp) {
             if (chunks == 9) ENV_LOOP(true, 9);
             else if (chunks == 17) ENV_LOOP(true, 17);
             else ENV_LOOP(true, 0);
@@ -728,7 +1161,6 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
             else ENV_LOOP(false, 0);
         }
 #undef ENV_LOOP
-#undef ENV_LOOP_V
         LAUNCH_CHECK(ctx);
         if (a->any_fry) {
             size_t lds = (size_t)A_ROWS * ((B + 3) & ~3) * sizeof(float);

@@ -157,6 +157,42 @@ __device__ __forceinline__ bool note_warps(const goofer_note_params &q, bool hav
     return (have_formants && note_shifts_formants(q)) || (double)q.formant_shift != 1.0;
 }
 
+// One output bin of an fp32 warp stage: displacement dl (bins) of bin b (bf = (float)b) -> the source position clamped to
+// [0, topf] -> 2-tap lerp of the LDS row `cur` (n_bins + 1 floats: see warp_row).
+__device__ __forceinline__ float warp_lerp_f32(const float *cur, int b, float bf, float dl, float topf)
+{
+    dl = __builtin_amdgcn_fmed3f(dl, -bf, topf - bf);
+    const float fl = __builtin_floorf(dl);
+    const int j2 = b + (int)fl;
+    const float d = dl - fl;                                           // exact (Sterbenz / same binade), in [0, 1)
+    const float r0 = cur[j2], r1 = cur[j2 + 1];                        // j2 = n_bins - 1 only with d == 0: the pad element
+    return __builtin_fmaf(r1 - r0, d, r0);
+}
+
+// The segment of the lane's bin in chunk c (bin lane + 64 c), for every chunk at once: anchor k counts from the lane's first
+// chunk ck = ceil((t_k - lane) / 64) on, so with 3-bit fields per chunk the packed segment indices are the sum over k of the
+// all-ones-fields constant shifted up by 3 ck (a field holds at most 5).  Five thresholds cost ~28 vector instructions per
+// row; a bin then takes its segment with one bit-field extract instead of five compares, selects, shifts and adds (17
+// instructions as compiled).  Nine chunks per 32-bit word.
+template <int NW>
+__device__ __forceinline__ void warp_seg_words(const int (&tk)[5], int lane, uint32_t (&jw)[NW])
+{
+#pragma unroll
+    for (int q = 0; q < NW; ++q) jw[q] = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int ck = (tk[k] + 63 - lane) >> 6;                       // >= 0 for thresholds >= 0 (they are)
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            int sh = ck - 9 * q;
+            sh = sh < 0 ? 0 : (sh > 10 ? 10 : sh);
+            jw[q] += 0x09249249u << (3 * sh);                          // fields past the word's nine fall off the top
+        }
+    }
+}
+template <int NW>
+__device__ __forceinline__ int warp_seg_at(const uint32_t (&jw)[NW], int c) { return (int)((jw[c / 9] >> (3 * (c % 9))) & 7u); }
+
 // CH: 64-bin chunks of a row when known at compile time (the per-bin loop of the common sorted-anchor case is then
 // unrolled, so its LDS round trips overlap), 0 = any width.
 //
@@ -178,14 +214,7 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, con
     float *cur = ra, *nxt = rb;
     const float topf = (float)(n_bins - 1);
     // one output bin of either fp32 stage: displacement dl (bins) -> clamp the position to [0, n_bins - 1] -> 2-tap lerp
-    auto lerp_f32 = [&](int b, float bf, float dl) {
-        dl = __builtin_amdgcn_fmed3f(dl, -bf, topf - bf);
-        const float fl = __builtin_floorf(dl);
-        const int j2 = b + (int)fl;
-        const float d = dl - fl;                                           // exact (Sterbenz / same binade), in [0, 1)
-        const float r0 = cur[j2], r1 = cur[j2 + 1];                        // j2 = n_bins - 1 only with d == 0: the pad element
-        nxt[b] = __builtin_fmaf(r1 - r0, d, r0);
-    };
+    auto lerp_f32 = [&](int b, float bf, float dl) { nxt[b] = warp_lerp_f32(cur, b, bf, dl, topf); };
 
     if (warp && formants) {
         // anchors: (0,0), valid (shifted -> orig) in formant order, (nyq, nyq)      GOOFER.py:850-865
@@ -279,30 +308,14 @@ __device__ __forceinline__ float *warp_row(float *ra, float *rb, int n_bins, con
                 };
                 auto seg_of = [&](int b) { return (b >= t1) + (b >= t2) + (b >= t3) + (b >= t4) + (b >= t5); };
                 if constexpr (CH > 0 && CH <= 18 && F32) {
-                    // The segment of the lane's bin in chunk c, for every chunk at once: anchor k counts from the lane's first chunk
-                    // ck = ceil((t_k - lane) / 64) on, so with 3-bit fields per chunk the packed segment indices are the sum over k of
-                    // the all-ones-fields constant shifted up by 3 ck (a field holds at most 5).  Five thresholds cost ~28 vector
-                    // instructions per row; a bin then takes its segment with one bit-field extract instead of five compares,
-                    // selects, shifts and adds (17 instructions as compiled).  Nine chunks per 32-bit word.
                     constexpr int NW = (CH + 8) / 9;
                     uint32_t jw[NW];
-#pragma unroll
-                    for (int q = 0; q < NW; ++q) jw[q] = 0;
                     const int tk[5] = {t1, t2, t3, t4, t5};
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) {
-                        const int ck = (tk[k] + 63 - lane) >> 6;                   // >= 0 for thresholds >= 0 (they are)
-#pragma unroll
-                        for (int q = 0; q < NW; ++q) {
-                            int sh = ck - 9 * q;
-                            sh = sh < 0 ? 0 : (sh > 10 ? 10 : sh);
-                            jw[q] += 0x09249249u << (3 * sh);                      // fields past the word's nine fall off the top
-                        }
-                    }
+                    warp_seg_words<NW>(tk, lane, jw);
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
                         const int b = lane + WAVE * c;
-                        if (c < CH - 1 || b < n_bins) bin(b, (int)((jw[c / 9] >> (3 * (c % 9))) & 7u));
+                        if (c < CH - 1 || b < n_bins) bin(b, warp_seg_at<NW>(jw, c));
                     }
                 } else if constexpr (CH > 0) {
 #pragma unroll

@@ -14,8 +14,12 @@ import torch
 from . import _lib
 
 
+_ROW_ALIGN = max(4, int(__import__("os").environ.get("GOOFER_ROW_ALIGN", "4")))
+
+
 def row_stride(n_bins: int) -> int:
-    return (n_bins + 3) & ~3
+    """floats per row of a [frames x bins] matrix (GOOFER_ROW_ALIGN: experiment knob, floats, a power of two >= 4)"""
+    return (n_bins + _ROW_ALIGN - 1) & ~(_ROW_ALIGN - 1)
 
 
 def spec_stride(n_bins: int) -> int:
