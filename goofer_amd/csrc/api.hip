@@ -842,6 +842,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "stem_lds_kb")) { ctx->stem_lds_kb = value < 0 ? 0 : (value > 160 ? 160 : value); return GOOFER_OK; }
     if (!strcmp(name, "pulse_scan")) { ctx->pulse_scan = value < 0 ? 0 : (value > 2 ? 2 : value); return GOOFER_OK; }
     if (!strcmp(name, "walk_npw")) { ctx->walk_npw = (value == 1 || value == 2 || value == 4) ? value : 0; return GOOFER_OK; }
+    if (!strcmp(name, "sa_fast")) { ctx->sa_fast = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "value_f64")) { ctx->value_f64 = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "sa_spt")) { ctx->sa_spt = value >= 16 ? 16 : (value >= 8 ? 8 : 4); return GOOFER_OK; }
     return goofer_fail(ctx, GOOFER_EINVAL, "unknown option %s", name);

@@ -823,6 +823,17 @@ __device__ __forceinline__ uint32_t mod_small(uint32_t k, uint32_t d, float rd)
     return (uint32_t)r;
 }
 
+// ... for callers that have checked d < 2^24 and k < 2^21 themselves
+__device__ __forceinline__ uint32_t mod_small_nb(uint32_t k, uint32_t d, float rd)
+{
+    const uint32_t q = (uint32_t)((float)k * rd);
+    uint32_t qd;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(qd) : "v"(q), "v"(d));
+    int32_t r = (int32_t)(k - qd);
+    r = r < 0 ? r + (int32_t)d : (r >= (int32_t)d ? r - (int32_t)d : r);
+    return (uint32_t)r;
+}
+
 // mask of the assembled note BEFORE the velocity stretch, at index q in [0, n_before_vel); rd ~ 1 / tail_len
 __device__ __forceinline__ double mask_stage1(const float *__restrict__ m, const goofer_note_plan &p, int q, float rd)
 {
@@ -945,8 +956,86 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
 // SA_SPT samples per thread, strided by the workgroup so loads and stores stay coalesced.  A workgroup starts with two rounds
 // of dependent loads (which note?) and the scalar loads of the note's 300-byte plan before its first sample: more samples
 // per workgroup amortise that latency.
+// The usual note — no velocity stretch, no fry, no 'pd' / 'sj' side outputs — for SA_SPT samples of a thread at once, without a
+// branch: first the index arithmetic of all of them (mask source index: slice / tile; tick index of the pitch curve with its
+// one-step correction as selects), then ALL their loads (one mask value, two curve knots each) in flight together, then the
+// fp64 curve, 2^x and the stores.  sample_assemble_one does the same per sample with a branch at every decision, so the
+// thread's samples wait out their round trips to memory one after the other (k_sample_assemble was 0.31 ms alone for the same
+// arithmetic).  Same operations on the same values: bit-identical to sample_assemble_one (tested through option "sa_fast" 0).
 template <int SA_SPT>
-__global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a, int64_t total_samples)
+__device__ __forceinline__ void sample_assemble_fast(const goofer_assembly &a, const goofer_note_plan &p, int64_t g0, int64_t total_samples)
+{
+    const float *__restrict__ m = a.mask_src + p.src_sample_off;
+    const double *__restrict__ bend = a.bend + p.bend_off;
+    float *__restrict__ mask_out = a.mask_out;
+    float *__restrict__ f0_out = a.f0_out;
+    const int n_pre = p.n_pre, s_pre = p.s_pre, s_tail = p.s_tail, tail_len = p.tail_len, ylen1 = (int)p.ylen - 1, nb1 = p.n_bend - 1;
+    const bool tile = tail_len < p.want_samples, rev = p.reverse != 0, fv = p.force_voiced != 0;
+    const float rd_tail = __builtin_amdgcn_rcpf((float)tail_len);
+    const double sr = (double)a.sr, rsr = 1.0 / sr;
+    const double dt = p.tick_dt, t_last = (double)nb1 * dt, rdt = fast_rcp(dt);
+    const int64_t nbase = p.out_sample_off;
+    int midx[SA_SPT], ja[SA_SPT], jb[SA_SPT];
+    double tsec[SA_SPT], x0[SA_SPT], x1[SA_SPT];
+    bool live[SA_SPT];
+#pragma unroll
+    for (int u = 0; u < SA_SPT; ++u) {
+        int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
+        live[u] = g < total_samples;
+        if (!live[u]) g = total_samples - 1;                  // (the block's note owns it: n_lo == n_hi covers the block's last sample)
+        const int i = (int)(g - nbase);
+        // voicing mask: slice of the source, the tail tiled                   SillySampler.py:698-712
+        uint32_t k = (uint32_t)(i - n_pre);
+        if (tile) k = mod_small_nb(k, (uint32_t)tail_len, rd_tail);
+        int idx = i < n_pre ? s_pre + i : s_tail + (int)k;
+        midx[u] = rev ? ylen1 - idx : idx;
+        // pitch curve: tick index of the sample, estimate and one conditional step either way (see sample_assemble_one)
+        double ts = div_by((double)i, sr, rsr);
+        ts = ts < 0.0 ? 0.0 : (ts > t_last ? t_last : ts);
+        int j = (int)(ts * rdt);
+        j = j > nb1 ? nb1 : j;
+        const double xa = (double)j * dt, xb = (double)(j + 1) * dt;
+        const bool up = j + 1 <= nb1 && xb <= ts;
+        const bool dn = !up && j > 0 && xa > ts;
+        j += (up ? 1 : 0) - (dn ? 1 : 0);
+        tsec[u] = ts;
+        x0[u] = (double)j * dt;
+        x1[u] = (double)(j + 1) * dt;
+        const bool last = j >= nb1;
+        ja[u] = last ? nb1 : j;
+        jb[u] = last ? nb1 : j + 1;
+    }
+    float mv[SA_SPT];
+    double y0[SA_SPT], y1[SA_SPT];
+#pragma unroll
+    for (int u = 0; u < SA_SPT; ++u) {
+        mv[u] = fv ? 1.0f : m[midx[u]];
+        y0[u] = bend[ja[u]];
+        y1[u] = bend[jb[u]];
+    }
+    float fo[SA_SPT];
+#pragma unroll
+    for (int u = 0; u < SA_SPT; ++u) {
+        // 1 / (x1 - x0): the spacing is dt up to the rounding of the two products (4e-14 relative), so one Newton step
+        // from RN(1 / dt) is the 1e-16 reciprocal fast_rcp would build from scratch
+        const double den = x1[u] - x0[u];
+        const double rden = fma(fma(-den, rdt, 1.0), rdt, rdt);
+        const double midi = (ja[u] == jb[u] || tsec[u] == x0[u]) ? y0[u] : ((y1[u] - y0[u]) * rden) * (tsec[u] - x0[u]) + y0[u];
+        const double hz = 440.0 * exp2_poly(div_by(midi - 69.0, 12.0, 0.083333333333333329));   // RN(1/12)
+        fo[u] = (float)((double)mv[u] * hz);
+    }
+#pragma unroll
+    for (int u = 0; u < SA_SPT; ++u) {
+        const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
+        if (live[u]) {
+            mask_out[g] = mv[u];
+            f0_out[g] = fo[u];
+        }
+    }
+}
+
+template <int SA_SPT>
+__global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a, int64_t total_samples, int fast)
 {
     __shared__ int s_pair[2];
     const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x * SA_SPT);
@@ -963,6 +1052,11 @@ __global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a
     const int n_lo = __builtin_amdgcn_readfirstlane(s_pair[0]), n_hi = __builtin_amdgcn_readfirstlane(s_pair[1]);
     if (n_lo == n_hi) {
         const goofer_note_plan &p = a.notes[n_lo];           // uniform note: the 300-byte plan comes in through scalar loads
+        if (fast && !p.vel_active && p.fry_dir == 0 && !(p.pd_on && a.bend_out) && !a.f0_mul_out && p.n_out < (1 << 21) && p.tail_len < (1 << 24) &&
+            p.tail_len > 0 && p.n_bend >= 1) {
+            sample_assemble_fast<SA_SPT>(a, p, g0, total_samples);
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < SA_SPT; ++u) {
             const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
@@ -1086,9 +1180,10 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         if (on_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_entry, 0));
         const int spt = ctx->sa_spt;
         const dim3 sgrid((unsigned)((a->total_samples + 256 * spt - 1) / (256 * spt)));
-        if (spt == 16) hipLaunchKernelGGL(k_sample_assemble<16>, sgrid, dim3(256), 0, fst, *a, a->total_samples);
-        else if (spt == 8) hipLaunchKernelGGL(k_sample_assemble<8>, sgrid, dim3(256), 0, fst, *a, a->total_samples);
-        else hipLaunchKernelGGL(k_sample_assemble<4>, sgrid, dim3(256), 0, fst, *a, a->total_samples);
+        const int sa_fast = ctx->sa_fast ? 1 : 0;
+        if (spt == 16) hipLaunchKernelGGL(k_sample_assemble<16>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast);
+        else if (spt == 8) hipLaunchKernelGGL(k_sample_assemble<8>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast);
+        else hipLaunchKernelGGL(k_sample_assemble<4>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast);
         LAUNCH_CHECK(ctx);
         if (ctx->early_req && ctx->ev_f0) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_f0, fst));

@@ -584,3 +584,32 @@ def test_source_arena_keeps_samples_resident(renderer):
     assert np.array_equal(out01[so[0]:so[1]], a[0]) and np.array_equal(out01[so[1]:so[2]], a[1])
     f = r.render(jobs[2:], seed=11)
     assert all(np.array_equal(x, y) for x, y in zip(e, f))
+
+
+def test_sample_assemble_fast_path_is_bit_identical(renderer):
+    """k_sample_assemble's branch-free path (all of a thread's loads in flight together; round 5) against the per-sample
+    function it restates: f0 and voicing mask of every reference flag set that takes it (and of those that do not) bit for bit,
+    plus 96 notes of BASELINE configs 3 and 4 (tiled tails, reverse, every loop mode)."""
+    from goofer_amd.render import Source
+    from goofer_amd import sampler as S
+    jobs = [_job(name)[1:] for name in SUPPORTED]
+    for config, ids in ((3, range(0, 1024, 16)), (4, range(32))):
+        for i in ids:
+            src, req, _ = syn.config_note(config, int(i))
+            jobs.append((Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]),
+                         S.decode_request(*syn.request_args(req))))
+    prep = renderer.prepare(jobs, phi_seeds=list(range(len(jobs))))
+    got = {}
+    for v in (0, 1):
+        renderer.ctx.set_option("sa_fast", v)
+        try:
+            prep["f0"].zero_()
+            prep["mask"].zero_()
+            renderer.assemble(prep)
+            torch.cuda.synchronize()
+            got[v] = (prep["f0"].cpu().numpy().copy(), prep["mask"].cpu().numpy().copy())
+        finally:
+            renderer.ctx.set_option("sa_fast", 1)
+    assert np.array_equal(got[0][0], got[1][0])
+    assert np.array_equal(got[0][1], got[1][1])
+    assert float(np.abs(got[1][0]).max()) > 50.0
