@@ -47,7 +47,10 @@ __device__ __forceinline__ float exp_split(float x)
 // ---------------------------------------------------------------------------------------------
 // V64: round 4's arithmetic (fp64 'es' blur, mean match and 'fw' interpolation, libm expf) — option "value_f64", A/B and the
 // error-budget tests.  Default: the same steps in fp32 (no index or comparison depends on these values).
-template <bool V64>
+// CH: 64-bin chunks of a row when known at compile time (9: n_fft 1024, 17: n_fft 2048; 0 = any width).  With CH the table loads of
+// a row's bins (lerp plan, tilt; the fw plan) are issued together before the first use — the rolled loops waited out one round
+// trip per chunk and table, ~20 per row.
+template <bool V64, int CH>
 __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64_t total_edit_rows, const int *__restrict__ row_note)
 {
     using acc_t = std::conditional_t<V64, double, float>;
@@ -74,6 +77,41 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
     const int *li = dense ? nullptr : a.lerp_idx + (int64_t)p.lerp_plan * B;
     const float *l0 = dense ? nullptr : a.lerp_w0 + (int64_t)p.lerp_plan * B, *l1 = dense ? nullptr : a.lerp_w1 + (int64_t)p.lerp_plan * B;
     const float *tilt = p.tilt >= 0 ? a.tilts + (int64_t)p.tilt * B : nullptr;
+    auto idx = [&](int c) {
+        const int b = c * WAVE + lane;
+        return (CH == 0 || c < CH - 1 || b < B) ? b : B - 1;
+    };
+    if constexpr (CH > 0) {
+        float v[CH], tv[CH];
+        if (tilt) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) tv[c] = tilt[idx(c)];
+        }
+        if (dense) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) v[c] = kv[idx(c)];
+        } else {
+            int iv[CH];
+            float a0[CH], a1[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                iv[c] = li[idx(c)];
+                a0[c] = l0[idx(c)];
+                a1[c] = l1[idx(c)];
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const float x = a0[c] * kv[iv[c]] + a1[c] * kv[iv[c] + 1];
+                v[c] = V64 ? expf(x) : exp_split(x);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int b = c * WAVE + lane;
+            if (tilt) v[c] *= tv[c];                           // 2. br: env *= tilt (fp32)   :513-515
+            if (c < CH - 1 || b < B) row[b] = v[c];
+        }
+    } else {
     for (int b = lane; b < B; b += WAVE) {
         float v;
         if (dense) {
@@ -85,6 +123,7 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
         }
         if (tilt) v *= tilt[b];                               // 2. br: env *= tilt (fp32)   :513-515
         row[b] = v;
+    }
     }
     wave_lds_sync();
 
@@ -199,10 +238,35 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
     }
 
     // 4. fw: affine stretch of the bin axis about its centre, linear interpolation   :553-574
-    float *out = a.edit_rows + er * (int64_t)a.ld;
+    float *__restrict__ out = a.edit_rows + er * (int64_t)a.ld;
     if (p.fw_plan >= 0) {
-        const int *lo = a.fw_lo + (int64_t)p.fw_plan * B, *hi = a.fw_hi + (int64_t)p.fw_plan * B;
-        const double *fr = a.fw_frac + (int64_t)p.fw_plan * B;
+        const int *__restrict__ lo = a.fw_lo + (int64_t)p.fw_plan * B, *__restrict__ hi = a.fw_hi + (int64_t)p.fw_plan * B;
+        const double *__restrict__ fr = a.fw_frac + (int64_t)p.fw_plan * B;
+        if constexpr (CH > 0) {
+            int lv[CH], hv[CH];
+            double fv[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                lv[c] = lo[idx(c)];
+                hv[c] = hi[idx(c)];
+                fv[c] = fr[idx(c)];
+            }
+            float o[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if constexpr (V64) {
+                    o[c] = (float)((1.0 - fv[c]) * (double)row[lv[c]] + fv[c] * (double)row[hv[c]]);
+                } else {
+                    const float r0 = row[lv[c]];
+                    o[c] = __builtin_fmaf((float)fv[c], row[hv[c]] - r0, r0);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int b = c * WAVE + lane;
+                if (c < CH - 1 || b < B) out[b] = o[c];
+            }
+        } else {
         for (int b = lane; b < B; b += WAVE) {
             if constexpr (V64) {
                 out[b] = (float)((1.0 - fr[b]) * (double)row[lo[b]] + fr[b] * (double)row[hi[b]]);
@@ -210,6 +274,13 @@ __global__ __launch_bounds__(256) void k_env_edit(const goofer_assembly a, int64
                 const float r0 = row[lo[b]];
                 out[b] = __builtin_fmaf((float)fr[b], row[hi[b]] - r0, r0);
             }
+        }
+        }
+    } else if constexpr (CH > 0) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int b = c * WAVE + lane;
+            if (c < CH - 1 || b < B) out[b] = row[b];
         }
     } else {
         for (int b = lane; b < B; b += WAVE) out[b] = row[b];
@@ -1203,11 +1274,24 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         size_t lds = (size_t)A_ROWS * ((3 * B + 2 * ES_HALO + a->max_K + 3) & ~3) * sizeof(float);
         if (lds > 64 * 1024) {
             if (lds > 160 * 1024) return goofer_fail(ctx, GOOFER_EINVAL, "envelope rows too wide for the edit kernel's LDS staging");
-            if (int arc = kernel_allow_max_lds(ctx, ctx->value_f64 ? (const void *)k_env_edit<true> : (const void *)k_env_edit<false>)) return arc;
+            const void *fns[] = {(const void *)k_env_edit<true, 0>, (const void *)k_env_edit<true, 9>, (const void *)k_env_edit<true, 17>,
+                                 (const void *)k_env_edit<false, 0>, (const void *)k_env_edit<false, 9>, (const void *)k_env_edit<false, 17>};
+            for (const void *fn : fns)
+                if (int arc = kernel_allow_max_lds(ctx, fn)) return arc;
         }
         const dim3 egrid((unsigned)((a->total_edit_rows + A_ROWS - 1) / A_ROWS));
-        if (ctx->value_f64) hipLaunchKernelGGL(k_env_edit<true>, egrid, dim3(256), lds, st, *a, a->total_edit_rows, row_note_edit);
-        else hipLaunchKernelGGL(k_env_edit<false>, egrid, dim3(256), lds, st, *a, a->total_edit_rows, row_note_edit);
+        const int echunks = (B + WAVE - 1) / WAVE;
+#define ENV_EDIT(V, C) hipLaunchKernelGGL((k_env_edit<V, C>), egrid, dim3(256), lds, st, *a, a->total_edit_rows, row_note_edit)
+        if (ctx->value_f64) {
+            if (echunks == 9) ENV_EDIT(true, 9);
+            else if (echunks == 17) ENV_EDIT(true, 17);
+            else ENV_EDIT(true, 0);
+        } else {
+            if (echunks == 9) ENV_EDIT(false, 9);
+            else if (echunks == 17) ENV_EDIT(false, 17);
+            else ENV_EDIT(false, 0);
+        }
+#undef ENV_EDIT
         LAUNCH_CHECK(ctx);
     }
     if (a->total_out_rows > 0) {

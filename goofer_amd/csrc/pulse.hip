@@ -749,8 +749,26 @@ __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__
             while (first > 0 && s_on[first - 1].end_max > j) --first;
             for (int k = first; k <= lo; ++k) {                                  // ascending onsets: the reference's order
                 const onset_t o = s_on[k];
+                if (o.T0 <= PULSE_TAB_MAX) {
+                    // the eight table values first (index clamped into the pulse), then the range test as a select: the loads of
+                    // a thread's samples are in flight together instead of one round trip per sample behind its own branch
+                    const float *__restrict__ row = tab + pulse_tab_row(o.T0);
+                    const int d0 = j - o.i;
+                    float tv[PP_SPT];
 #pragma unroll
-                for (int e = 0; e < PP_SPT; ++e) acc[e] += pulse_value(o, j + e, peak, tab);
+                    for (int e = 0; e < PP_SPT; ++e) {
+                        const int d = d0 + e;
+                        tv[e] = row[d < 0 ? 0 : (d >= o.T0 ? o.T0 - 1 : d)];
+                    }
+#pragma unroll
+                    for (int e = 0; e < PP_SPT; ++e) {
+                        const int d = d0 + e;
+                        acc[e] += (d < 0 || d >= o.T0) ? 0.f : tv[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < PP_SPT; ++e) acc[e] += pulse_value(o, j + e, peak, tab);
+                }
             }
         }
         if (live == PP_SPT) {
