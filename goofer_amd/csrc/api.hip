@@ -457,6 +457,8 @@ void goofer_destroy(goofer_ctx *ctx)
     if (ctx->ovf_flag) (void)hipFree(ctx->ovf_flag);
     for (int i = 0; i < ctx->prof_cap * (PROF_STAGES + 1); ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
     free(ctx->prof_ev);
+    for (int i = 0; ctx->prof_asm && i < ctx->prof_cap * 6; ++i) (void)hipEventDestroy(ctx->prof_asm[i]);
+    free(ctx->prof_asm);
     for (int i = 0; ctx->prof_side && i < ctx->prof_cap * 4; ++i) (void)hipEventDestroy(ctx->prof_side[i]);
     free(ctx->prof_side);
     for (int i = 0; ctx->prof_main2 && i < ctx->prof_cap * 2; ++i) (void)hipEventDestroy(ctx->prof_main2[i]);
@@ -731,7 +733,7 @@ int64_t goofer_debug_fetch(goofer_ctx *ctx, int which, void *host_out, int64_t c
 
 static const char *const PROF_NAMES[PROF_STAGES] = {
     "setup_maps", "", "", "phase_inc", "pulse_onsets", "pulse_place", "rfft_frames", "harm_shape",
-    "irfft_harm", "noise_spectra", "irfft_breath", "irfft_unvoiced", "mask_short", "ola3_gains", "apply_gain", "", "", ""};
+    "irfft_harm", "noise_spectra", "irfft_breath", "irfft_unvoiced", "mask_short", "ola3_gains", "apply_gain", "env_edit", "env_rows", "sample_assemble"};
 
 // Per-stage timing of goofer_synth_batch with HIP events recorded on the caller's stream (so the
 // numbers are what that stream really executed).  begin(max_steps) arms it; every synth batch then
@@ -746,6 +748,11 @@ int goofer_profile_begin(goofer_ctx *ctx, int max_steps)
         free(ctx->prof_side);
         for (int i = 0; ctx->prof_main2 && i < ctx->prof_cap * 2; ++i) (void)hipEventDestroy(ctx->prof_main2[i]);
         free(ctx->prof_main2);
+        for (int i = 0; ctx->prof_asm && i < ctx->prof_cap * 6; ++i) (void)hipEventDestroy(ctx->prof_asm[i]);
+        free(ctx->prof_asm);
+        ctx->prof_asm = (hipEvent_t *)calloc((size_t)max_steps * 6, sizeof(hipEvent_t));
+        if (!ctx->prof_asm) return goofer_fail(ctx, GOOFER_ENOMEM, "event pool");
+        for (int i = 0; i < max_steps * 6; ++i) HIP_TRY(ctx, hipEventCreate(&ctx->prof_asm[i]));
         ctx->prof_ev = (hipEvent_t *)calloc((size_t)max_steps * (PROF_STAGES + 1), sizeof(hipEvent_t));
         ctx->prof_side = (hipEvent_t *)calloc((size_t)max_steps * 4, sizeof(hipEvent_t));
         ctx->prof_main2 = (hipEvent_t *)calloc((size_t)max_steps * 2, sizeof(hipEvent_t));
@@ -756,6 +763,7 @@ int goofer_profile_begin(goofer_ctx *ctx, int max_steps)
         ctx->prof_cap = max_steps;
     }
     ctx->prof_steps = 0;
+    ctx->prof_asm_steps = 0;
     ctx->prof_on = true;
     return GOOFER_OK;
 }
@@ -769,6 +777,17 @@ int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages)
         double acc = 0.0;
         if (ctx->prof_only >= 0 && s != ctx->prof_only) {                // (its events were not recorded)
             ms_per_stage[s] = 0.0;
+            continue;
+        }
+        if (s >= PROF_ASM0) {
+            // the assembly's three large kernels (goofer_assemble_batch / goofer_render_batch), each bracketed on the stream it ran on
+            for (int k = 0; k < ctx->prof_asm_steps; ++k) {
+                hipEvent_t *q = ctx->prof_asm + (size_t)k * 6 + 2 * (s - PROF_ASM0);
+                float ms = 0.f;
+                if (ctx->prof_asm_mask[k] & (1u << (s - PROF_ASM0))) HIP_TRY(ctx, hipEventElapsedTime(&ms, q[0], q[1]));
+                acc += ms;
+            }
+            ms_per_stage[s] = acc;
             continue;
         }
         for (int k = 0; k < ctx->prof_steps; ++k) {
@@ -796,11 +815,11 @@ const char *goofer_profile_stage_name(int stage) { return stage >= 0 && stage < 
 
 static const char *const PROF_NAMES_STEMS[PROF_STAGES] = {
     "setup_maps", "", "", "phase_inc", "pulse_onsets", "pulse_place", "mask_short", "noise_stems",
-    "", "harm_stem", "", "", "", "note_finish", "", "", "", ""};
+    "", "harm_stem", "", "", "", "note_finish", "", "env_edit", "env_rows", "sample_assemble"};
 
 static const char *const PROF_NAMES_OLA[PROF_STAGES] = {
     "setup_maps", "", "", "phase_inc", "pulse_onsets", "pulse_place", "rfft_frames", "harm_shape",
-    "", "noise_spectra", "", "", "mask_short", "irfft_ola3", "apply_gain", "", "", ""};
+    "", "noise_spectra", "", "", "mask_short", "irfft_ola3", "apply_gain", "env_edit", "env_rows", "sample_assemble"};
 
 const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage)
 {

@@ -1237,6 +1237,17 @@ __global__ void k_row_notes2(const goofer_note_plan *__restrict__ notes, int n_n
 int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edit, int *row_note_out, void *row_recs, hipStream_t st)
 {
     const int B = a->n_bins;
+    // per-kernel HIP events of a profiled run (goofer_profile_begin): stage PROF_ASM0 + which, on the stream the kernel runs on
+    hipEvent_t *pq = nullptr;
+    if (ctx->prof_on && ctx->prof_asm && ctx->prof_asm_steps < ctx->prof_cap && ctx->prof_asm_steps < (int)sizeof(ctx->prof_asm_mask)) {
+        pq = ctx->prof_asm + (size_t)ctx->prof_asm_steps * 6;
+        ctx->prof_asm_mask[ctx->prof_asm_steps] = 0;
+    }
+    auto mark = [&](int which, int edge, hipStream_t s) -> hipError_t {
+        if (!pq || !(ctx->prof_only < 0 || ctx->prof_only == PROF_ASM0 + which)) return hipSuccess;
+        if (edge) ctx->prof_asm_mask[ctx->prof_asm_steps] |= (unsigned char)(1u << which);
+        return hipEventRecord(pq[2 * which + edge], s);
+    };
     // f0 and voicing mask first: the pulse chain of the synthesis (a long sequential walk) depends on nothing else, and
     // goofer_render_batch starts it on the side stream while the envelope kernels below are still running
     ctx->early_f0 = nullptr;
@@ -1252,10 +1263,12 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         const int spt = ctx->sa_spt;
         const dim3 sgrid((unsigned)((a->total_samples + 256 * spt - 1) / (256 * spt)));
         const int sa_fast = ctx->sa_fast ? 1 : 0;
+        HIP_TRY(ctx, mark(2, 0, fst));
         if (spt == 16) hipLaunchKernelGGL(k_sample_assemble<16>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast);
         else if (spt == 8) hipLaunchKernelGGL(k_sample_assemble<8>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast);
         else hipLaunchKernelGGL(k_sample_assemble<4>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast);
         LAUNCH_CHECK(ctx);
+        HIP_TRY(ctx, mark(2, 1, fst));
         if (ctx->early_req && ctx->ev_f0) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_f0, fst));
             ctx->early_f0 = a->f0_out;
@@ -1281,6 +1294,7 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         }
         const dim3 egrid((unsigned)((a->total_edit_rows + A_ROWS - 1) / A_ROWS));
         const int echunks = (B + WAVE - 1) / WAVE;
+        HIP_TRY(ctx, mark(0, 0, st));
 #define ENV_EDIT(V, C) hipLaunchKernelGGL((k_env_edit<V, C>), egrid, dim3(256), lds, st, *a, a->total_edit_rows, row_note_edit)
         if (ctx->value_f64) {
             if (echunks == 9) ENV_EDIT(true, 9);
@@ -1293,6 +1307,7 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         }
 #undef ENV_EDIT
         LAUNCH_CHECK(ctx);
+        HIP_TRY(ctx, mark(0, 1, st));
     }
     if (a->total_out_rows > 0) {
         const dim3 lgrid((unsigned)((a->total_out_rows + A_ROWS - 1) / A_ROWS));
@@ -1317,6 +1332,7 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
             if (fused_warp) hipLaunchKernelGGL(k_row_recs<true>, tgrid, dim3(256), 0, st, *a, a->total_out_rows, row_note_out, wf, wp, recs, eg);
             else hipLaunchKernelGGL(k_row_recs<false>, tgrid, dim3(256), 0, st, *a, a->total_out_rows, row_note_out, wf, wp, recs, eg);
             LAUNCH_CHECK(ctx);
+            HIP_TRY(ctx, mark(1, 0, st));
 #define ENV_ROWS(W, C) hipLaunchKernelGGL((k_env_rows<W, C>), lgrid, dim3(256), lds_w, st, *a, a->total_out_rows, recs, wf, wp, wo, eg)
             if (fused_warp) {
                 if (chunks == 9) ENV_ROWS(true, 9);
@@ -1329,15 +1345,22 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
                 else ENV_ROWS(false, 0);
             }
 #undef ENV_ROWS
-        } else if (fused_warp) {
-            if (chunks == 9) ENV_LOOP(true, 9);
-            else if (chunks == 17) ENV_LOOP(true, 17);
-            else ENV_LOOP(true, 0);
-            ctx->warp_done = true;
+            LAUNCH_CHECK(ctx);
+            HIP_TRY(ctx, mark(1, 1, st));
         } else {
-            if (chunks == 9) ENV_LOOP(false, 9);
-            else if (chunks == 17) ENV_LOOP(false, 17);
-            else ENV_LOOP(false, 0);
+            HIP_TRY(ctx, mark(1, 0, st));
+            if (fused_warp) {
+                if (chunks == 9) ENV_LOOP(true, 9);
+                else if (chunks == 17) ENV_LOOP(true, 17);
+                else ENV_LOOP(true, 0);
+                ctx->warp_done = true;
+            } else {
+                if (chunks == 9) ENV_LOOP(false, 9);
+                else if (chunks == 17) ENV_LOOP(false, 17);
+                else ENV_LOOP(false, 0);
+            }
+            LAUNCH_CHECK(ctx);
+            HIP_TRY(ctx, mark(1, 1, st));
         }
 #undef ENV_LOOP
         LAUNCH_CHECK(ctx);
@@ -1348,5 +1371,6 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
             LAUNCH_CHECK(ctx);
         }
     }
+    if (pq) ctx->prof_asm_steps++;
     return GOOFER_OK;
 }

@@ -10,6 +10,7 @@
 
 #define WAVE 64
 #define PROF_STAGES 18
+#define PROF_ASM0 15           // profile stages 15..17: the assembly's k_env_edit, k_env_rows / k_env_loop, k_sample_assemble
 #define PULSE_TAB_MAX 2048     // pulse lengths served from the shape table (f0 >= sr/2048); longer ones are evaluated on the fly
 
 struct goofer_plan_t {
@@ -77,6 +78,9 @@ struct goofer_ctx {
     bool f0_on_side = false;          // ... and did so in the assembly of the current call: the caller's stream waits for ev_f0 before it reads f0 / mask
     hipEvent_t *prof_side = nullptr;    // [prof_cap][4]: boundaries of the pulse chain on the side stream
     hipEvent_t *prof_main2 = nullptr;   // [prof_cap][2]: ends of noise_spectra / mask_short when they run beside it
+    hipEvent_t *prof_asm = nullptr;     // [prof_cap][3][2]: the assembly's three large kernels, each on its own stream
+    unsigned char prof_asm_mask[4096] = {0};   // which of the three pairs assembly k of the profiled run recorded
+    int prof_asm_steps = 0;
     bool prof_side_used = false;
     bool ola_fused = true;        // irFFT x3 + overlap-add + gains in one kernel (k_irfft_ola3); false: separate irFFT launches + k_ola3_gains
     bool stems = true;            // stem-split frame walkers (stems.hip) where the geometry allows (hop == n_fft / 4); false: the

@@ -40,12 +40,12 @@ meta = {"csrc_sha256": source_hash(), "workload": bench["config"]["workload"], "
 subs = max(1, int(bench["config"].get("sub_batches_per_gpu", 1)))
 steps = max(1, res.get("k_note_finish", res.get("k_sample_assemble", {})).get("launches_sampled", 1)) / subs
 stems = any(k.startswith("void k_harm_stem") for k in res)
-fused_warp = any(k.startswith("void k_env_loop<true") for k in res)
+fused_warp = any(k.startswith(("void k_env_loop<true", "void k_env_rows<true")) for k in res)
 tot, per_kernel = 0.0, {}
 for k, v in res.items():
     if not k.startswith(("k_", "void k_")) or "FETCH_SIZE_KB" not in v or "WRITE_SIZE_KB" not in v:
         continue
-    if (stems and k.startswith("void k_rfft_frames")) or (fused_warp and k.startswith("void k_env_loop<false")):
+    if (stems and k.startswith("void k_rfft_frames")) or (fused_warp and k.startswith(("void k_env_loop<false", "void k_env_rows<false", "void k_row_recs<false"))):
         continue
     per_step = min(float(subs), v["launches_sampled"] / steps)            # launches of this kernel inside one pass
     per_kernel[k] = (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 * per_step
