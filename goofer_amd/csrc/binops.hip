@@ -289,6 +289,9 @@ int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames,
 }
 
 // ---------------------------------------------------------------------------------------------
+// float2 slots of LDS per wave of k_noise_spectra: an fp32 row padded to 16 bytes + a complex row, an even count (16-byte waves)
+__host__ __device__ static inline int noise_spectra_wave_f2(int n_bins) { return ((((n_bins + 4) & ~3) / 2 + n_bins) + 1) & ~1; }
+
 // S_uv = U * env_noise ; S_br = (U * env_noise) * HP, brightened + blurred on voiced frames.
 template <int ITERS, bool NT>
 __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv, float2 *__restrict__ S_br, int ldc,
@@ -312,9 +315,10 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
     // overlap-add kernel will not read it
     const unsigned sk = frame_skip ? (unsigned)frame_skip[f] : 0u;
     if (sk == 3u) return;
-    const int rowf = (n_bins + 1) & ~1;
-    float2 *r = reinterpret_cast<float2 *>(smem) + (size_t)wave * (n_bins + rowf / 2 + 1);
-    float *ra = reinterpret_cast<float *>(r + n_bins);
+    // per wave: the fp32 row (16-byte aligned: the register blur stores it in 16-byte pieces), then the complex row of the 5-tap blur
+    const int rowf4 = (n_bins + 4) & ~3;
+    float *ra = reinterpret_cast<float *>(reinterpret_cast<float2 *>(smem) + (size_t)wave * noise_spectra_wave_f2(n_bins));
+    float2 *r = reinterpret_cast<float2 *>(ra + rowf4);
 
     const int64_t src = row_src ? row_src[f] : f;
     const float *er = env_noise + src * (int64_t)ld;
@@ -347,7 +351,62 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
 
     float2 *ru = S_uv + f * (int64_t)ldc;
     float2 *rb = S_br + f * (int64_t)ldc;
-    if (row_src && taps175) {
+    const bool do_blur = row_src && taps175;                 // taps175 == nullptr: the rows are the noise envelope already
+    float t175[15];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) t175[j] = do_blur ? (float)taps175[j] : 0.f;
+    // Rows of 64 NB + 1 bins (n_fft 1024 / 2048): the sigma-1.75 blur as register arithmetic.  A lane takes NB CONSECUTIVE bins
+    // (16-byte loads), the eight bins on either side come from the neighbouring lanes through DPP wave shifts, lane 63 also
+    // blurs the Nyquist bin; numpy's 'reflect' at the two ends of the row is a select on lanes 0 and 63.  The same products in
+    // the same ascending tap order as the LDS version below (bit-identical), for 16 vector moves and NB / 4 + 1 loads instead of
+    // 15 LDS reads per bin (255 per frame at n_fft 2048) and a bounds test per bin.  The blurred row then goes through LDS once
+    // into the layout of the spectrum rows, bin lane + 64 i.
+    constexpr int NB = ITERS - 1;
+    const bool reg_blur = do_blur && (NB == 8 || NB == 16) && n_bins == WAVE * NB + 1 && (ld & 3) == 0 && (((uintptr_t)env_noise) & 15) == 0;
+    bool blurred = false;
+    if constexpr (NB == 8 || NB == 16) {
+        if (reg_blur) {
+            float x[NB + 16];
+#pragma unroll
+            for (int q = 0; q < NB / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(er + NB * lane + 4 * q);
+                x[8 + 4 * q] = v.x; x[8 + 4 * q + 1] = v.y; x[8 + 4 * q + 2] = v.z; x[8 + 4 * q + 3] = v.w;
+            }
+            const float e_ny = er[n_bins - 1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                x[j] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[NB + j]), 0x138, 0xf, 0xf, false));           // wave_shr:1 <- lane - 1: its last eight
+                x[8 + NB + j] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[8 + j]), 0x130, 0xf, 0xf, false));   // wave_shl:1 <- lane + 1: its first eight
+            }
+            // bins -1..-7 are bins 1..7, bins B..B+6 are bins B-2..B-8 (B - 1 is the Nyquist bin, lane 63's extra one)
+#pragma unroll
+            for (int j = 1; j < 8; ++j) {
+                x[8 - j] = lane == 0 ? x[8 + j] : x[8 - j];
+                x[8 + NB + j] = lane == 63 ? x[8 + NB - j] : x[8 + NB + j];
+            }
+            x[8 + NB] = lane == 63 ? e_ny : x[8 + NB];
+            float o[NB + 1];
+#pragma unroll
+            for (int j = 0; j <= NB; ++j) {
+                float acc = t175[0] * x[j + 1];
+#pragma unroll
+                for (int q = 1; q < 15; ++q) acc = fmaf(t175[q], x[j + 1 + q], acc);
+                o[j] = acc;
+            }
+#pragma unroll
+            for (int q = 0; q < NB / 4; ++q)
+                *reinterpret_cast<float4 *>(ra + NB * lane + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+            if (lane == 63) ra[n_bins - 1] = o[NB];
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) {
+                const int k = lane + WAVE * i;
+                ev[i] = ra[k < n_bins ? k : n_bins - 1];
+            }
+            blurred = true;
+        }
+    }
+    if (do_blur && !blurred) {
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
             const int k = lane + WAVE * i;
@@ -357,10 +416,6 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
     }
     const uint64_t key = seed ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
     uint4 rnd = make_uint4(0, 0, 0, 0);
-    const bool do_blur = row_src && taps175;                 // taps175 == nullptr: the rows are the noise envelope already
-    float t175[15];
-#pragma unroll
-    for (int j = 0; j < 15; ++j) t175[j] = do_blur ? (float)taps175[j] : 0.f;
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
         const int k = lane + WAVE * i;
@@ -377,7 +432,7 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
             s = __builtin_amdgcn_sinf(rev);
         }
         float e;
-        if (do_blur) {
+        if (do_blur && !blurred) {
             // sigma-1.75 blur of the envelope row (GOOFER.py:993): the reference accumulates in fp64 and the product with
             // the unit phasor is rounded to complex64; fp32 FMAs in tap order stay within ~2e-7 relative
             float acc;
@@ -421,9 +476,8 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
 {
     if (total_frames <= 0) return GOOFER_OK;
     const goofer_plan_t &pl = ctx->plan;
-    const int rowf = (pl.n_bins + 1) & ~1;
     const dim3 grid((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-    const size_t lds = sizeof(float2) * ROWS_PER_BLOCK * (pl.n_bins + rowf / 2 + 1);
+    const size_t lds = sizeof(float2) * ROWS_PER_BLOCK * noise_spectra_wave_f2(pl.n_bins);
 #define NOISE_SPECTRA_NT(IT, NT)                                                                                                   \
     hipLaunchKernelGGL((k_noise_spectra<IT, NT>), grid, dim3(256), lds, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,  \
                        sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins, pl.hop, \
