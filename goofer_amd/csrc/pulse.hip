@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64) void k_onset_finish(const float *__restrict__ f
 // the last onset starting inside the tile — are staged once in LDS; every sample then scans that short
 // list in ascending onset order (the reference's accumulation order).  Other tiles (note boundaries, or
 // more onsets than the LDS list holds) take the per-sample search of the compact list in global memory.
-#define PP_SPT 8
+#define PP_SPT 16
 #define PP_MAXON 512
 
 __device__ __forceinline__ float pulse_value(const onset_t &o, int j, const float *__restrict__ peak, const float *__restrict__ tab)

@@ -12,6 +12,7 @@ import ctypes as C
 import weakref
 from dataclasses import dataclass
 
+import os
 import numpy as np
 import torch
 
@@ -322,7 +323,10 @@ class Renderer:
         self.hop = hop
         self.sources = SourceArena(self.ctx)
         self._stagings = []                                    # free Staging blocks (see prepare)
-        self.plan_threads = 0                                  # host threads of the library's planner (0: up to eight)
+        # host threads of the library's planner (0: up to eight).  One process per GPU shares the host with the other ranks of
+        # its node: under torchrun (LOCAL_WORLD_SIZE) each rank takes its share of the cores, at most eight
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+        self.plan_threads = 0 if lw <= 1 else max(1, min(8, (os.cpu_count() or 8) // lw))
 
     def render(self, jobs, seed: int = 0, phi_seeds=None, return_parts: bool = False):
         """jobs: list of (Source, Request).  Returns a list of fp32 arrays (the mix the reference writes to

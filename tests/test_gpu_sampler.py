@@ -125,11 +125,26 @@ def test_resampler_call_surface(renderer, tmp_path):
         GooferResampler(str(tmp_path / "none.wav"), str(out), *syn.request_args(req), renderer=renderer)
 
 
-@pytest.mark.parametrize("config,ids", [(1, [0]), (4, [0, 1, 2, 5, 7]), (5, [0, 1, 2]), (2, [0, 1, 2, 3]), (3, [0, 257, 640, 1023])])
+def _config4_ids():
+    """Notes of the 10 000-note job that cover every loop mode (the flag cycles L0 / L1 / L2 with the note id) in every decile
+    of the job's length distribution (log-uniform 100 ms .. 3 s): the first id of each of the 30 cells, plus the first five."""
+    frames = np.array([syn.config_note_frames(4, i) for i in range(10000)])
+    edges = np.quantile(frames, np.linspace(0.0, 1.0, 11))
+    ids = [0, 1, 2, 5, 7]
+    for mode in range(3):
+        for d in range(10):
+            cell = np.nonzero((np.arange(10000) % 3 == mode) & (frames >= edges[d]) & (frames <= edges[d + 1]))[0]
+            ids.append(int(cell[0]))
+    return sorted(set(ids))
+
+
+@pytest.mark.parametrize("config,ids", [(1, [0]), (4, _config4_ids()), (5, [0, 1, 2, 3, 257, 512, 777, 1023]), (2, [0, 1, 2, 3, 100, 255]),
+                                        (3, sorted(set(list(range(0, 1024, 33)) + [257, 640, 1023])))])
 def test_baseline_config_notes_vs_oracle(config, ids):
     """Notes of the BASELINE configs (config 1: the single 1 s note with default flags; 96 kHz / n_fft 2048 / hop 96 with
-    br+es; L0/L1/L2 with random lengths; config 3 at ids spread over the 1024-note batch) rendered as one batch vs the CPU
-    oracle's full render, same injected phases."""
+    br+es at 8 ids over the batch; config 4's L0/L1/L2 loops at 30+ ids covering every loop mode in every length decile of
+    the 10 000-note job; config 3 at 34 ids spread over the 1024-note batch) rendered as one batch vs the CPU oracle's full
+    render, same injected phases."""
     from goofer_amd.device import Context
     from goofer_amd.render import Renderer, Source
     from goofer_amd import sampler as S
@@ -270,7 +285,7 @@ def test_dense_feature_source_vs_oracle(renderer):
 _random_flags = syn.random_flags
 
 
-_FUZZ_DEFAULT = "480"   # the driver-run suite: 480 random flag strings, 40 mixed batches, 30 / 60 at other geometries / extreme requests
+_FUZZ_DEFAULT = "2000"  # the driver-run suite: 2000 random flag strings, 166 mixed batches, 125 / 250 at other geometries / extreme requests
 _FUZZ_FIRST = int(os.environ.get("GOOFER_FUZZ_FIRST", "0"))          # a soak run: GOOFER_FUZZ_FIRST=3000 GOOFER_FUZZ_CASES=9000
 
 

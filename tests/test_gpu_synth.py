@@ -214,7 +214,7 @@ def test_synthesize_roughness_matches_reference(ctx, name):
 _SOAK_FIRST = int(os.environ.get("GOOFER_FUZZ_FIRST", "0"))
 
 
-@pytest.mark.parametrize("case", range(_SOAK_FIRST, _SOAK_FIRST + max(12, int(os.environ.get("GOOFER_FUZZ_CASES", "480")) // 4)))
+@pytest.mark.parametrize("case", range(_SOAK_FIRST, _SOAK_FIRST + max(12, int(os.environ.get("GOOFER_FUZZ_CASES", "2000")) // 4)))
 def test_synthesize_random_kwargs_vs_oracle(ctx, case):
     """gf.synthesize's keyword surface in random combinations (shifts, strengths, switches, jitter, sub-harmonic layer,
     time stretch) against the oracle, same legacy RNG stream and injected phases on both sides."""
