@@ -22,7 +22,7 @@ int launch_pulse_train(goofer_ctx *, const float *, float, const int64_t *, int,
                        int32_t *, int32_t *, hipStream_t);
 int launch_pulse_onsets(goofer_ctx *, const float *, float, const int64_t *, int, onset_t *, int32_t *, int32_t *,
                         int32_t *, hipStream_t);
-int launch_pulse_place(goofer_ctx *, const onset_t *, const int32_t *, const int64_t *, int, int64_t, float *, hipStream_t);
+int launch_pulse_place(goofer_ctx *, const onset_t *, const int32_t *, const int64_t *, int, int64_t, float *, int32_t *, hipStream_t);
 int launch_subharm(goofer_ctx *, const float *, const float *, const int64_t *, int, int64_t, const goofer_note_params *, const double *, int,
                    int, double, double, double, float *, double *, onset_t *, int32_t *, int32_t *, int32_t *, const unsigned char *,
                    double *, unsigned long long *, float *, hipStream_t);
@@ -861,6 +861,7 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "stem_lds_kb")) { ctx->stem_lds_kb = value < 0 ? 0 : (value > 160 ? 160 : value); return GOOFER_OK; }
     if (!strcmp(name, "pulse_scan")) { ctx->pulse_scan = value < 0 ? 0 : (value > 2 ? 2 : value); return GOOFER_OK; }
     if (!strcmp(name, "walk_npw")) { ctx->walk_npw = (value == 1 || value == 2 || value == 4) ? value : 0; return GOOFER_OK; }
+    if (!strcmp(name, "pulse_tiles")) { ctx->pulse_tiles = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "sa_fast")) { ctx->sa_fast = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "value_f64")) { ctx->value_f64 = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "sa_spt")) { ctx->sa_spt = value >= 16 ? 16 : (value >= 8 ? 8 : 4); return GOOFER_OK; }
@@ -1606,7 +1607,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, b->sample_off, n, (onset_t *)onsets, onset_idx, onset_cnt, ovf, pst))) return rc;
     MARK();
     if (sev) HIP_TRY(ctx, hipEventRecord(sev[2], pst));
-    if ((rc = launch_pulse_place(ctx, (onset_t *)onsets, onset_cnt, b->sample_off, n, N, pulse, pst))) return rc;
+    if ((rc = launch_pulse_place(ctx, (onset_t *)onsets, onset_cnt, b->sample_off, n, N, pulse, onset_idx, pst))) return rc;
     // Harmonic envelope rows for the harmonic walker: formant-anchored + uniform warp, one wave per row (GOOFER.py:1004-1017),
     // behind the pulse placement on its stream (the caller's stream carries the mask smoothing and the noise walker meanwhile).
     // Not inside the walker: the crossing-anchor path is several times slower than the sorted one, and a walker wave holds

@@ -93,6 +93,7 @@ struct goofer_ctx {
     int finish_lds_kb = 0;        // KB of the breath stem k_note_finish parks in LDS between its passes (0: the default 144, < 0: none)
     int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
 
+    bool pulse_tiles = true;      // pulse placement: the onset range of every tile from a kernel of its own (option "pulse_tiles"; 0: A/B)
     bool sa_fast = true;          // k_sample_assemble: the branch-free path with all of a thread's loads in flight together (option "sa_fast"; 0: A/B)
     bool value_f64 = false;       // assembly kernels: round 4's fp64 value arithmetic (tap blend, warp / fw interpolation, es blur) instead of
                                   // fp32 — A/B and the error-budget tests (option "value_f64")

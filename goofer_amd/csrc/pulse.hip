@@ -680,10 +680,46 @@ __device__ __forceinline__ float pulse_value(const onset_t &o, int j, const floa
     return m > 0.0 ? (float)((double)raw / m) : raw;
 }
 
+// Which onsets can touch which tile, once per tile instead of once per workgroup through two rounds of note search, a count over
+// the note's whole onset list, two atomics and two barriers (k_pulse_place's set-up chain was most of its time): a thread per
+// tile finds the tile's note and, when the tile lies inside one note, the first onset whose running end_max passes the tile's
+// first sample and the last onset starting at or before its last sample — binary searches on the two monotone columns.
+// tiles[t] = {note or -1 (the tile crosses a note boundary), k0, k1, 0}.
+__global__ void k_pulse_tiles(const onset_t *__restrict__ onsets, const int32_t *__restrict__ onset_cnt, const int64_t *__restrict__ sample_off,
+                              int n_notes, int64_t total_samples, int n_tiles, int4 *__restrict__ tiles)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int64_t g0 = (int64_t)t * (256 * PP_SPT);
+    int64_t gl = g0 + 256 * PP_SPT - 1;
+    if (gl > total_samples - 1) gl = total_samples - 1;
+    const int lo_n = csr_find(sample_off, n_notes, g0), hi_n = csr_find(sample_off, n_notes, gl);
+    if (lo_n != hi_n) {
+        tiles[t] = make_int4(-1, lo_n, hi_n, 0);
+        return;
+    }
+    const int64_t base = sample_off[lo_n];
+    const onset_t *ol = onsets + (base / 2 + 16 * (int64_t)lo_n);
+    const int cnt = onset_cnt[lo_n];
+    const int32_t j_lo = (int32_t)(g0 - base), j_hi = (int32_t)(gl - base);
+    int a = 0, b = cnt;                                       // onsets with end_max <= j_lo: a prefix
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (ol[mid].end_max <= j_lo) a = mid + 1; else b = mid;
+    }
+    const int k0 = a;
+    a = 0; b = cnt;                                           // onsets with i <= j_hi: a prefix
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (ol[mid].i <= j_hi) a = mid + 1; else b = mid;
+    }
+    tiles[t] = make_int4(lo_n, k0, a - 1, 0);
+}
+
 __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__ onsets, const int32_t *__restrict__ onset_cnt,
                                                      const float *__restrict__ peak, const float *__restrict__ tab,
                                                      const int64_t *__restrict__ sample_off, int n_notes, int64_t total_samples,
-                                                     float *__restrict__ pulse)
+                                                     float *__restrict__ pulse, const int4 *__restrict__ tiles)
 {
     __shared__ int s_pair[2];
     __shared__ int s_rng[2];
@@ -691,13 +727,20 @@ __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__
     const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x * PP_SPT);
     int64_t gl = g0 + (int64_t)blockDim.x * PP_SPT - 1;
     if (gl > total_samples - 1) gl = total_samples - 1;
+    int lo_n, hi_n;
+    int k0 = 0, k1 = -1;
+    if (tiles) {
+        const int4 tl = tiles[blockIdx.x];                    // (workgroup-uniform: a scalar load)
+        lo_n = tl.x >= 0 ? tl.x : tl.y;
+        hi_n = tl.x >= 0 ? tl.x : tl.z;
+        k0 = tl.y;
+        k1 = tl.z;
+    } else {
     if (threadIdx.x == 0) {
         s_rng[0] = 0;
         s_rng[1] = 0;
     }
-    int lo_n, hi_n;
     block_note_range_last(sample_off, n_notes, g0, gl, s_pair, lo_n, hi_n);
-    int k0 = 0, k1 = -1;
     if (lo_n == hi_n) {
         // onsets that can touch the tile: [first with end_max > j_lo (end_max is monotone), last with i <= j_hi].  Both
         // are counts over the sorted list, taken by the whole workgroup at once instead of two serial binary searches.
@@ -722,6 +765,7 @@ __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__
         __syncthreads();
         k0 = __builtin_amdgcn_readfirstlane(s_rng[0]);
         k1 = __builtin_amdgcn_readfirstlane(s_rng[1]) - 1;
+    }
     }
     const int nk = k1 - k0 + 1;
     if (lo_n == hi_n && nk <= PP_MAXON) {
@@ -854,12 +898,22 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
     return GOOFER_OK;
 }
 
+// tile_scratch: at least 4 * ceil(total_samples / (256 * PP_SPT)) ints the kernels may overwrite (the scan's onset_idx array is
+// dead once k_onset_finish has run), 16-byte aligned; nullptr: every workgroup searches for itself (round 4's path, option "pulse_tiles" 0)
 int launch_pulse_place(goofer_ctx *ctx, const onset_t *onsets, const int32_t *onset_cnt, const int64_t *sample_off, int n_notes,
-                       int64_t total_samples, float *pulse, hipStream_t st)
+                       int64_t total_samples, float *pulse, int32_t *tile_scratch, hipStream_t st)
 {
     if (total_samples <= 0) return GOOFER_OK;
-    hipLaunchKernelGGL(k_pulse_place, dim3((unsigned)((total_samples + 256 * PP_SPT - 1) / (256 * PP_SPT))), dim3(256), 0, st, onsets, onset_cnt,
-                       ctx->plan.pulse_peak, ctx->plan.pulse_shape, sample_off, n_notes, total_samples, pulse);
+    const unsigned n_tiles = (unsigned)((total_samples + 256 * PP_SPT - 1) / (256 * PP_SPT));
+    int4 *tiles = nullptr;
+    if (ctx->pulse_tiles && tile_scratch && ((uintptr_t)tile_scratch & 15) == 0) {
+        tiles = reinterpret_cast<int4 *>(tile_scratch);
+        hipLaunchKernelGGL(k_pulse_tiles, dim3((n_tiles + 63) / 64), dim3(64), 0, st, onsets, onset_cnt, sample_off, n_notes, total_samples,
+                           (int)n_tiles, tiles);
+        LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(k_pulse_place, dim3(n_tiles), dim3(256), 0, st, onsets, onset_cnt, ctx->plan.pulse_peak, ctx->plan.pulse_shape,
+                       sample_off, n_notes, total_samples, pulse, (const int4 *)tiles);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
@@ -872,7 +926,7 @@ int launch_pulse_train(goofer_ctx *ctx, const float *f0, float f0_scale, const i
     int rc;
     (void)inc;                                                // the walk divides f0 by sr itself
     if ((rc = launch_pulse_onsets(ctx, f0, f0_scale, sample_off, n_notes, onsets, onset_idx, onset_cnt, overflow, st))) return rc;
-    return launch_pulse_place(ctx, onsets, onset_cnt, sample_off, n_notes, total_samples, pulse, st);
+    return launch_pulse_place(ctx, onsets, onset_cnt, sample_off, n_notes, total_samples, pulse, onset_idx, st);
 }
 
 // ---------------------------------------------------------------------------------------------
