@@ -107,7 +107,7 @@ class Batch(C.Structure):
         ("f0_jitter_sigma", C.c_float), ("vol_jitter_sigma", C.c_float),
         ("subharm_ratio", C.c_double), ("subharm_more", C.c_double * 15), ("subharm_vib_rate", C.c_double), ("subharm_vib_depth", C.c_double),
         ("subharm_vib_delay", C.c_double), ("subharm_vibrato", C.c_int32), ("volume_vibrato", C.c_int32),
-        ("unit_pitch_shift", C.c_int32), ("reserved6", C.c_int32),
+        ("unit_pitch_shift", C.c_int32), ("no_warp", C.c_int32),
         ("harm", C.c_void_p), ("uv", C.c_void_p), ("bre", C.c_void_p), ("rec", C.c_void_p), ("mix", C.c_void_p),
     ]
 

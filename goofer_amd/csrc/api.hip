@@ -33,7 +33,7 @@ int launch_knot_decode(goofer_ctx *, const uint16_t *, int, int64_t, const int *
                        hipStream_t);
 int launch_harm_shape(goofer_ctx *, float2 *, int, int64_t, const int *, const int64_t *, const int64_t *, const float *,
                       const float *, const float *, int, const goofer_note_params *, float *, const int64_t *, const double *,
-                      hipStream_t);
+                      bool, hipStream_t);
 int launch_noise_spectra(goofer_ctx *, float2 *, float2 *, int, int64_t, const int *, const int64_t *, const int64_t *,
                          const float *, const float *, const float *, const float *, int, const goofer_note_params *, uint64_t,
                          const int64_t *, bool, const unsigned char *, hipStream_t);
@@ -1767,7 +1767,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         } else if ((rc = launch_rfft_frames_mapped(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, st))) return rc;
         MARK();   // 7
         if (!fused_shape && (rc = launch_harm_shape(ctx, S_h, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, b->env, ld, b->params,
-                                    note_mag, row_src, b->formants, st)))
+                                    note_mag, row_src, b->formants, b->no_warp != 0, st)))
             return rc;
         MARK();   // 8
         if (!ola_one && (rc = launch_irfft_frames(ctx, S_h, ldc, F, frames, st))) return rc;

@@ -145,8 +145,19 @@ int launch_knot_decode(goofer_ctx *ctx, const uint16_t *knots, int K, int64_t ro
 // In place on S: optional high-pass, per-note max(|S| + 1e-8), then * env * boost, and on voiced
 // frames * brightness followed by the 5-tap blur.  The 1/max normalisation commutes with the
 // (linear) rest of the chain and is applied after the overlap-add.
+// LDS (round 5): the three per-bin tables (bin frequency, boost, brightness) once per workgroup — as register preloads they were
+// 3 x ITERS registers per lane and held the n_fft 2048 instantiation at 177 registers / two waves per SIMD — then per wave the
+// complex row of the 5-tap blur and, only when the batch may warp (`warp_rows`; the caller's goofer_batch.no_warp hint turns
+// them off), the warp's two fp32 rows: 45 KB instead of 66 KB per workgroup at n_fft 2048.
+__host__ __device__ static inline int harm_shape_tab_floats(int n_bins) { return (n_bins + 4) & ~3; }
+__host__ __device__ static inline size_t harm_shape_lds(int n_bins, bool warp_rows)
+{
+    const int rowf = (n_bins + 1) & ~1;
+    return sizeof(float) * 3 * harm_shape_tab_floats(n_bins) + sizeof(float2) * ROWS_PER_BLOCK * (n_bins + (warp_rows ? rowf : 0));
+}
+
 template <int ITERS, bool NT>
-__global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *__restrict__ S, int ldc, int64_t total_frames,
+__global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 3) void k_harm_shape(float2 *__restrict__ S, int ldc, int64_t total_frames,
                                                     const int *__restrict__ frame_note, const int64_t *__restrict__ frame_off,
                                                     const int64_t *__restrict__ sample_off, const float *__restrict__ f0,
                                                     const float *__restrict__ mask, const float *__restrict__ env, int ld,
@@ -155,20 +166,28 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
                                                     const float *__restrict__ bright, const double *__restrict__ taps5,
                                                     int n_bins, int hop, const int64_t *__restrict__ row_src,
                                                     const double *__restrict__ formants, const warp_grid grid,
-                                                    const float2 *__restrict__ picks)
+                                                    const float2 *__restrict__ picks, int warp_rows)
 {
     // env is either the already-warped [frames x ld] matrix (row_src == nullptr) or the source rows, in which
     // case the formant-anchored + uniform warp (GOOFER.py:1004-1017) runs here on the LDS row.
     // Latency plan: the frame index is made wave-uniform so every per-note scalar is a scalar load (its own
-    // counter), and all of the row's vector loads (spectrum, envelope, tables) are issued before the first wait.
+    // counter), and all of the row's vector loads (spectrum, envelope) are issued before the first wait.
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ double s_seg[ROWS_PER_BLOCK][WARP_SEG_DOUBLES];
+    const int tabf = harm_shape_tab_floats(n_bins);
+    float *t_fq = reinterpret_cast<float *>(smem), *t_bo = t_fq + tabf, *t_br = t_bo + tabf;
+    for (int k = threadIdx.x; k < n_bins; k += blockDim.x) {
+        t_fq[k] = freqs[k];
+        t_bo[k] = boost[k];
+        t_br[k] = bright[k];
+    }
+    __syncthreads();                                          // (every wave of the workgroup: the frame test comes after it)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int64_t f = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
     if (f >= total_frames) return;
     const int rowf = (n_bins + 1) & ~1;                           // floats per fp32 row (even)
-    float2 *r = reinterpret_cast<float2 *>(smem) + (size_t)wave * (n_bins + rowf);
-    float *ra = reinterpret_cast<float *>(r + n_bins), *rb = ra + rowf;
+    float2 *r = reinterpret_cast<float2 *>(t_br + tabf) + (size_t)wave * (n_bins + (warp_rows ? rowf : 0));
+    float *ra = reinterpret_cast<float *>(r + n_bins), *rb = ra + rowf;   // (only with warp_rows)
 
     float2 *row = S + f * (int64_t)ldc;
     float2 sv[ITERS];
@@ -179,15 +198,14 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
     }
     const int64_t src = row_src ? row_src[f] : f;
     const float *er = env + src * (int64_t)ld;
-    float ev[ITERS], fq[ITERS], bo[ITERS], br[ITERS];
+    float ev[ITERS];
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
         const int k = lane + WAVE * i;
-        const int kc = k < n_bins ? k : n_bins - 1;
-        ev[i] = er[kc]; fq[i] = freqs[kc]; bo[i] = boost[kc]; br[i] = bright[kc];
+        ev[i] = er[k < n_bins ? k : n_bins - 1];
     }
     const int note = frame_note[f];
-    const goofer_note_params p = params[note];
+    const goofer_note_params &p = params[note];
     float f0f;                                       // f0 already carries pitch_shift
     bool voiced;
     if (picks) {                                     // (f0, mask) record of the frame, written by the map kernel
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
     for (int j = 0; j < 5; ++j) t5[j] = taps5[j];
 
     const float *eg = nullptr;                       // LDS row of the warped envelope, or registers when no warp ran
-    if (row_src) {
+    if (row_src && warp_rows) {
         double fs[4];
         bool warp = false;
         for (int k = 0; k < 4; ++k) {
@@ -224,22 +242,32 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
                           s_seg[wave]);
         }
     }
+    const int cut = p.cut_below_f0;
+    // bins 64 and up sit a whole 64-bin stride above the lowest bins: when f0 + 100 Hz is still below bin 64 their high-pass
+    // factor is exactly 1.0f (1 + exp(-z) rounds to 1 for z > 18, i.e. 90 Hz above f0; rcp(1) = 1) and is not evaluated
+    const bool hp_low_only = n_bins > WAVE && t_fq[WAVE] - f0f > 100.0f;
     float mx = 0.f;
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
         const int k = lane + WAVE * i;
         if (k < n_bins) {
             float2 s = sv[i];
-            if (p.cut_below_f0) {
-                float h = hp_mask(fq[i], f0f);
+            if (cut && (i == 0 || !hp_low_only)) {
+                float h = hp_mask(t_fq[k], f0f);
                 s.x *= h; s.y *= h;
             }
             mx = fmaxf(mx, s.x * s.x + s.y * s.y);                 // |s|^2: the square root is taken once, of the maximum
             const float g = eg ? eg[k] : ev[i];
-            s.x = (s.x * g) * bo[i];
-            s.y = (s.y * g) * bo[i];
-            if (voiced) { s.x *= br[i]; s.y *= br[i]; r[k] = s; }
-            else store_f2(row + k, s, NT);
+            const float bo = t_bo[k];
+            s.x = (s.x * g) * bo;
+            s.y = (s.y * g) * bo;
+            if (voiced) {
+                const float br = t_br[k];
+                s.x *= br; s.y *= br;
+                r[k] = s;
+            } else {
+                store_f2(row + k, s, NT);
+            }
         }
     }
     mx = __builtin_amdgcn_sqrtf(wave_max(mx)) + 1e-8f;              // max(|s| + 1e-8) = sqrt(max |s|^2) + 1e-8: sqrt is monotone
@@ -257,17 +285,17 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 2) void k_harm_shape(float2 *
 int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames, const int *frame_note, const int64_t *frame_off,
                       const int64_t *sample_off, const float *f0, const float *mask, const float *env, int ld,
                       const goofer_note_params *params, float *note_mag, const int64_t *row_src, const double *formants,
-                      hipStream_t st)
+                      bool no_warp, hipStream_t st)
 {
     if (total_frames <= 0) return GOOFER_OK;
     const goofer_plan_t &pl = ctx->plan;
-    const int rowf = (pl.n_bins + 1) & ~1;
     const dim3 grid((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-    const size_t lds = sizeof(float2) * ROWS_PER_BLOCK * (pl.n_bins + rowf);
+    const int warp_rows = (row_src && !no_warp) ? 1 : 0;       // the batch may warp rows here: the kernel needs its two fp32 LDS rows
+    const size_t lds = harm_shape_lds(pl.n_bins, warp_rows != 0);
 #define HARM_SHAPE_NT(IT, NT)                                                                                                      \
     hipLaunchKernelGGL((k_harm_shape<IT, NT>), grid, dim3(256), lds, st, S, ldc, total_frames, frame_note, frame_off, sample_off, f0, \
                        mask, env, ld, params, note_mag, pl.freqs, pl.boost, pl.bright_h, pl.blur5, pl.n_bins, pl.hop, row_src,    \
-                       formants, make_warp_grid(pl.sr, pl.n_bins), ctx->frame_picks)
+                       formants, make_warp_grid(pl.sr, pl.n_bins), ctx->frame_picks, warp_rows)
     // (the shaped rows are written once and read once, by the inverse transform: non-temporal stores, option "nt_spectra")
 #define HARM_SHAPE(IT)                                                                                                             \
     do {                                                                                                                           \
@@ -290,11 +318,19 @@ int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames,
 
 // ---------------------------------------------------------------------------------------------
 // float2 slots of LDS per wave of k_noise_spectra: an fp32 row padded to 16 bytes + a complex row, an even count (16-byte waves)
-__host__ __device__ static inline int noise_spectra_wave_f2(int n_bins) { return ((((n_bins + 4) & ~3) / 2 + n_bins) + 1) & ~1; }
+__host__ __device__ static inline int noise_spectra_wave_f2(int n_bins, bool shared_rows)
+{
+    return shared_rows ? ((n_bins + 2) & ~1) : (((((n_bins + 4) & ~3) / 2 + n_bins) + 1) & ~1);
+}
 
 // S_uv = U * env_noise ; S_br = (U * env_noise) * HP, brightened + blurred on voiced frames.
-template <int ITERS, bool NT>
-__global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv, float2 *__restrict__ S_br, int ldc,
+// PHI: injected phases (parity runs; accurate libm sin / cos) instead of Philox + hardware sin / cos — a template parameter: the
+// phases of a row are ITERS registers the production kernel does not need.
+// reg_blur (decided by the launcher): the sigma-1.75 blur runs in registers (below); the fp32 row then shares its LDS with the
+// complex row of the 5-tap blur — the two are never live together on that path — and a workgroup takes 33 KB instead of 49 KB at
+// n_fft 2048 (four per CU instead of three).
+template <int ITERS, bool NT, bool PHI>
+__global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 3) void k_noise_spectra(float2 *__restrict__ S_uv, float2 *__restrict__ S_br, int ldc,
                                                        int64_t total_frames, const int *__restrict__ frame_note,
                                                        const int64_t *__restrict__ frame_off, const int64_t *__restrict__ sample_off,
                                                        const float *__restrict__ f0, const float *__restrict__ mask,
@@ -303,7 +339,8 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
                                                        const float *__restrict__ freqs, const float *__restrict__ bright,
                                                        const double *__restrict__ taps5, int n_bins, int hop,
                                                        const int64_t *__restrict__ row_src, const double *__restrict__ taps175,
-                                                       const float2 *__restrict__ picks, const unsigned char *__restrict__ frame_skip)
+                                                       const float2 *__restrict__ picks, const unsigned char *__restrict__ frame_skip,
+                                                       int reg_blur_ok)
 {
     // env_noise is either the already-blurred [frames x ld] matrix (row_src == nullptr) or the source rows, in
     // which case the sigma-1.75 bin blur (GOOFER.py:993) runs here from the LDS row.
@@ -317,18 +354,26 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
     if (sk == 3u) return;
     // per wave: the fp32 row (16-byte aligned: the register blur stores it in 16-byte pieces), then the complex row of the 5-tap blur
     const int rowf4 = (n_bins + 4) & ~3;
-    float *ra = reinterpret_cast<float *>(reinterpret_cast<float2 *>(smem) + (size_t)wave * noise_spectra_wave_f2(n_bins));
-    float2 *r = reinterpret_cast<float2 *>(ra + rowf4);
+    float *ra = reinterpret_cast<float *>(reinterpret_cast<float2 *>(smem) + (size_t)wave * noise_spectra_wave_f2(n_bins, reg_blur_ok != 0));
+    float2 *r = reg_blur_ok ? reinterpret_cast<float2 *>(ra) : reinterpret_cast<float2 *>(ra + rowf4);
 
     const int64_t src = row_src ? row_src[f] : f;
     const float *er = env_noise + src * (int64_t)ld;
-    float ev[ITERS], fq[ITERS], br[ITERS], ph[ITERS];
+    float ev[ITERS], br[ITERS], ph[PHI ? ITERS : 1];
+    const float fq0 = freqs[lane], fq64 = freqs[n_bins > WAVE ? WAVE : 0];
+    if (!reg_blur_ok) {                                      // (the register blur loads the row in its own layout)
 #pragma unroll
-    for (int i = 0; i < ITERS; ++i) {
-        const int k = lane + WAVE * i;
-        const int kc = k < n_bins ? k : n_bins - 1;
-        ev[i] = er[kc]; fq[i] = freqs[kc]; br[i] = bright[kc];
-        ph[i] = phi ? phi[f * (int64_t)ld + kc] : 0.f;
+        for (int i = 0; i < ITERS; ++i) {
+            const int k = lane + WAVE * i;
+            ev[i] = er[k < n_bins ? k : n_bins - 1];
+        }
+    }
+    if constexpr (PHI) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int k = lane + WAVE * i;
+            ph[i] = phi[f * (int64_t)ld + (k < n_bins ? k : n_bins - 1)];
+        }
     }
     const int note = frame_note[f];
     const goofer_note_params p = params[note];
@@ -362,7 +407,7 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
     // 15 LDS reads per bin (255 per frame at n_fft 2048) and a bounds test per bin.  The blurred row then goes through LDS once
     // into the layout of the spectrum rows, bin lane + 64 i.
     constexpr int NB = ITERS - 1;
-    const bool reg_blur = do_blur && (NB == 8 || NB == 16) && n_bins == WAVE * NB + 1 && (ld & 3) == 0 && (((uintptr_t)env_noise) & 15) == 0;
+    const bool reg_blur = do_blur && reg_blur_ok != 0;      // (the launcher checked: 64 NB + 1 bins, 16-byte aligned rows)
     bool blurred = false;
     if constexpr (NB == 8 || NB == 16) {
         if (reg_blur) {
@@ -414,14 +459,21 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
         }
         wave_lds_sync();
     }
+    // (the brightness curve after the blur: behind it the row's registers are free again)
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int k = lane + WAVE * i;
+        br[i] = bright[k < n_bins ? k : n_bins - 1];
+    }
     const uint64_t key = seed ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
     uint4 rnd = make_uint4(0, 0, 0, 0);
+    const bool hp_low_only = n_bins > WAVE && fq64 - f0f > 100.0f;
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
         const int k = lane + WAVE * i;
         if (k >= n_bins) continue;
         float c, s;
-        if (phi) {
+        if constexpr (PHI) {
             c = cosf(ph[i]);
             s = sinf(ph[i]);
         } else {
@@ -454,7 +506,8 @@ __global__ __launch_bounds__(256) void k_noise_spectra(float2 *__restrict__ S_uv
         float2 u2 = make_float2(c * e, s * e);
         if (!(sk & 1u)) store_f2(ru + k, u2, NT);
         if (sk & 2u) continue;
-        float h = hp_mask(fq[i], f0f);
+        // bins 64 and up: the factor is exactly 1.0f when f0 + 100 Hz lies below bin 64 (see k_harm_shape)
+        const float h = i == 0 ? hp_mask(fq0, f0f) : (hp_low_only ? 1.0f : hp_mask(freqs[k], f0f));
         float2 b = make_float2(u2.x * h, u2.y * h);
         if (voiced) { b.x *= br[i]; b.y *= br[i]; r[k] = b; }
         else store_f2(rb + k, b, NT);
@@ -477,15 +530,24 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
     if (total_frames <= 0) return GOOFER_OK;
     const goofer_plan_t &pl = ctx->plan;
     const dim3 grid((unsigned)((total_frames + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-    const size_t lds = sizeof(float2) * ROWS_PER_BLOCK * noise_spectra_wave_f2(pl.n_bins);
-#define NOISE_SPECTRA_NT(IT, NT)                                                                                                   \
-    hipLaunchKernelGGL((k_noise_spectra<IT, NT>), grid, dim3(256), lds, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,  \
+    const int chunks0 = (pl.n_bins + WAVE - 1) / WAVE;
+    // the register blur: rows of 64 NB + 1 bins with NB = 8 / 16 (the instantiations 9 / 17), 16-byte aligned envelope rows, and a blur to run
+    const int reg_blur = (row_src && !preblurred && (chunks0 == 9 || chunks0 == 17) && pl.n_bins == WAVE * (chunks0 - 1) + 1 && (ld & 3) == 0 &&
+                          (((uintptr_t)env_noise) & 15) == 0) ? 1 : 0;
+    const size_t lds = sizeof(float2) * ROWS_PER_BLOCK * noise_spectra_wave_f2(pl.n_bins, reg_blur != 0);
+#define NOISE_SPECTRA_P(IT, NT, PH)                                                                                                \
+    hipLaunchKernelGGL((k_noise_spectra<IT, NT, PH>), grid, dim3(256), lds, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,  \
                        sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins, pl.hop, \
-                       row_src, preblurred ? (const double *)nullptr : pl.blur175, ctx->frame_picks, frame_skip)
+                       row_src, preblurred ? (const double *)nullptr : pl.blur175, ctx->frame_picks, frame_skip, reg_blur)
 #define NOISE_SPECTRA(IT)                                                                                                          \
     do {                                                                                                                           \
-        if (ctx->nt_spectra) NOISE_SPECTRA_NT(IT, true);                                                                           \
-        else NOISE_SPECTRA_NT(IT, false);                                                                                          \
+        if (phi) {                                                                                                                 \
+            if (ctx->nt_spectra) NOISE_SPECTRA_P(IT, true, true);                                                                  \
+            else NOISE_SPECTRA_P(IT, false, true);                                                                                 \
+        } else {                                                                                                                   \
+            if (ctx->nt_spectra) NOISE_SPECTRA_P(IT, true, false);                                                                 \
+            else NOISE_SPECTRA_P(IT, false, false);                                                                                \
+        }                                                                                                                          \
     } while (0)
     // bins per lane: the instantiation with the smallest count that covers the row (the kernels test k < n_bins per bin)
     const int chunks = (pl.n_bins + WAVE - 1) / WAVE;
@@ -496,7 +558,7 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
     else if (chunks <= 17) NOISE_SPECTRA(17);
     else return goofer_fail(ctx, GOOFER_EINVAL, "unsupported bin count %d", pl.n_bins);
 #undef NOISE_SPECTRA
-#undef NOISE_SPECTRA_NT
+#undef NOISE_SPECTRA_P
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

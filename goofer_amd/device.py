@@ -412,6 +412,7 @@ class Context:
                        subharm_vib_delay=float(subharm.get("delay", 0.1)) if subharm else 0.0,
                        subharm_vibrato=int(bool(subharm.get("vibrato", False))) if subharm else 0,
                        unit_pitch_shift=int(bool(np.all(params["pitch_shift"] == 1.0))),
+                       no_warp=int(bool(np.all(params["f_shift"] == 1.0) and np.all(params["formant_shift"] == 1.0))),
                        harm=out["harm"].data_ptr(),
                        uv=out["uv"].data_ptr(), bre=out["bre"].data_ptr(),
                        rec=out["rec"].data_ptr() if want_rec else None, mix=out["mix"].data_ptr() if want_mix else None)

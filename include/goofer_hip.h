@@ -102,7 +102,10 @@ typedef struct {
     int32_t subharm_vibrato;    /* 0 / 1                                                                  */
     int32_t volume_vibrato;     /* 1: the volume jitter is a sinusoid, no noise draws needed  GOOFER.py:643-652  */
     int32_t unit_pitch_shift;   /* 1: the caller vouches params[i].pitch_shift == 1 for every note (the resampler  */
-    int32_t reserved6;          /* path: pitch lives in the curve), so f0 needs no scaling pass          :995    */
+    int32_t no_warp;            /* path: pitch lives in the curve), so f0 needs no scaling pass          :995    */
+                                /* no_warp = 1: the caller vouches that no note of the batch warps its envelope    */
+                                /* (every f_shift == 1 and formant_shift == 1): kernels that could warp rows in    */
+                                /* LDS need not reserve those rows (a note that warps anyway is rendered unwarped) */
     float *harm, *uv, *bre;     /* [total_samples] stems, gain-normalised like the reference   */
     float *rec;                 /* [total_samples] harm+uv+bre (reconstruct), may be NULL      */
     float *mix;                 /* [total_samples] (harm*V + bre*B + uv*U)*volume, may be NULL */
