@@ -21,8 +21,8 @@ struct onset_t;
 int launch_pulse_train(goofer_ctx *, const float *, float, const int64_t *, int, int64_t, float *, double *, onset_t *, int32_t *,
                        int32_t *, int32_t *, hipStream_t);
 int launch_pulse_onsets(goofer_ctx *, const float *, float, const int64_t *, int, onset_t *, int32_t *, int32_t *,
-                        int32_t *, hipStream_t);
-int launch_pulse_place(goofer_ctx *, const onset_t *, const int32_t *, const int64_t *, int, int64_t, float *, int32_t *, hipStream_t);
+                        int32_t *, int64_t, int32_t *, hipStream_t);
+int launch_pulse_place(goofer_ctx *, const onset_t *, const int32_t *, const int64_t *, int, int64_t, float *, const int32_t *, hipStream_t);
 int launch_subharm(goofer_ctx *, const float *, const float *, const int64_t *, int, int64_t, const goofer_note_params *, const double *, int,
                    int, double, double, double, float *, double *, onset_t *, int32_t *, int32_t *, int32_t *, const unsigned char *,
                    double *, unsigned long long *, float *, hipStream_t);
@@ -326,6 +326,7 @@ static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t sampl
     add(notes * sizeof(int32_t) + 64);            // onset counts
     add(64);                                      // overflow flag
     add(samples * sizeof(float));                 // pulse
+    add((samples / 1024 + 64) * sizeof(int32_t)); // pulse placement: 4 ints per 4096-sample tile
     if (spectra == 1) {
         add(3 * frames * ldc * sizeof(float2));       // S_h, S_uv, S_br
         add(3 * frames * (size_t)p.n_fft * sizeof(float));  // windowed time frames (three stems in the fused path)
@@ -1377,6 +1378,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     int32_t *onset_cnt = a.take<int32_t>(n + 16);
     int32_t *ovf = ctx->ovf_flag;
     float *pulse = a.take<float>(N);
+    int32_t *pulse_tiles = a.take<int32_t>(N / 1024 + 64);
     const size_t spec_n = (walkers || ring_path) ? 0 : (size_t)F * ldc, frame_n = (walkers || ring_path) ? 0 : (size_t)F * p.n_fft;
     float2 *S_h = a.take<float2>(spec_n);
     float2 *S_uv = a.take<float2>(spec_n);
@@ -1395,7 +1397,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     unsigned char *frame_skip = skip_frames ? a.take<unsigned char>((size_t)F + 16) : nullptr;
     unsigned char *knot_eq = skip_frames ? a.take<unsigned char>((size_t)(N / 4 + n + 16)) : nullptr;
     if (skip_frames && (!hop_flat || !frame_skip || !knot_eq)) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
-    if (!picks || !frames_u || !frames_b || !frame_note || !row_src || !f0s || (sub_on && !inc) || !onsets || !onset_idx || !onset_cnt || !ovf || !pulse || !S_h || !S_uv || !S_br || !frames ||
+    if (!picks || !frames_u || !frames_b || !frame_note || !row_src || !f0s || (sub_on && !inc) || !onsets || !onset_idx || !onset_cnt || !ovf || !pulse || !pulse_tiles || !S_h || !S_uv || !S_br || !frames ||
         !env_h || !env_n || !short_s || !note_mag || !note_steps)
         return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     float *note_peak = note_mag + n;
@@ -1604,10 +1606,10 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     if (sev) HIP_TRY(ctx, hipEventRecord(sev[0], pst));
     MARK();
     if (sev) HIP_TRY(ctx, hipEventRecord(sev[1], pst));
-    if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, b->sample_off, n, (onset_t *)onsets, onset_idx, onset_cnt, ovf, pst))) return rc;
+    if ((rc = launch_pulse_onsets(ctx, f0s, 1.0f, b->sample_off, n, (onset_t *)onsets, onset_idx, onset_cnt, ovf, N, pulse_tiles, pst))) return rc;
     MARK();
     if (sev) HIP_TRY(ctx, hipEventRecord(sev[2], pst));
-    if ((rc = launch_pulse_place(ctx, (onset_t *)onsets, onset_cnt, b->sample_off, n, N, pulse, onset_idx, pst))) return rc;
+    if ((rc = launch_pulse_place(ctx, (onset_t *)onsets, onset_cnt, b->sample_off, n, N, pulse, pulse_tiles, pst))) return rc;
     // Harmonic envelope rows for the harmonic walker: formant-anchored + uniform warp, one wave per row (GOOFER.py:1004-1017),
     // behind the pulse placement on its stream (the caller's stream carries the mask smoothing and the noise walker meanwhile).
     // Not inside the walker: the crossing-anchor path is several times slower than the sorted one, and a walker wave holds

@@ -857,8 +857,11 @@ int launch_phase_inc(goofer_ctx *ctx, const float *f0, float f0_scale, int64_t t
     return GOOFER_OK;
 }
 
+// tiles != nullptr (16-byte aligned, 4 ints per tile of 256 * PP_SPT samples of total_samples): also the pulse placement's tile table
+// (k_pulse_tiles) — launch_pulse_place then is a single launch
 int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const int64_t *sample_off,
-                        int n_notes, onset_t *onsets, int32_t *onset_idx, int32_t *onset_cnt, int32_t *overflow, hipStream_t st)
+                        int n_notes, onset_t *onsets, int32_t *onset_idx, int32_t *onset_cnt, int32_t *overflow, int64_t total_samples,
+                        int32_t *tiles, hipStream_t st)
 {
     if (n_notes <= 0) return GOOFER_OK;
     if (f0_scale != 1.0f) return goofer_fail(ctx, GOOFER_EINVAL, "pulse onsets expect pre-scaled f0");
@@ -895,25 +898,25 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
     hipLaunchKernelGGL(k_onset_finish, dim3(n_notes), dim3(64), 0, st, f0, sample_off, n_notes, (double)ctx->plan.sr, onset_idx,
                        onset_cnt, onsets);
     LAUNCH_CHECK(ctx);
+    if (total_samples > 0 && tiles && ctx->pulse_tiles && ((uintptr_t)tiles & 15) == 0) {
+        const unsigned n_tiles = (unsigned)((total_samples + 256 * PP_SPT - 1) / (256 * PP_SPT));
+        hipLaunchKernelGGL(k_pulse_tiles, dim3((n_tiles + 63) / 64), dim3(64), 0, st, onsets, onset_cnt, sample_off, n_notes, total_samples,
+                           (int)n_tiles, reinterpret_cast<int4 *>(tiles));
+        LAUNCH_CHECK(ctx);
+    }
     return GOOFER_OK;
 }
 
-// tile_scratch: at least 4 * ceil(total_samples / (256 * PP_SPT)) ints the kernels may overwrite (the scan's onset_idx array is
-// dead once k_onset_finish has run), 16-byte aligned; nullptr: every workgroup searches for itself (round 4's path, option "pulse_tiles" 0)
+// tiles: the table launch_pulse_onsets made (4 ints per tile of 256 * PP_SPT samples), or nullptr: every
+// workgroup searches for itself (round 4's path, option "pulse_tiles" 0)
 int launch_pulse_place(goofer_ctx *ctx, const onset_t *onsets, const int32_t *onset_cnt, const int64_t *sample_off, int n_notes,
-                       int64_t total_samples, float *pulse, int32_t *tile_scratch, hipStream_t st)
+                       int64_t total_samples, float *pulse, const int32_t *tiles, hipStream_t st)
 {
     if (total_samples <= 0) return GOOFER_OK;
     const unsigned n_tiles = (unsigned)((total_samples + 256 * PP_SPT - 1) / (256 * PP_SPT));
-    int4 *tiles = nullptr;
-    if (ctx->pulse_tiles && tile_scratch && ((uintptr_t)tile_scratch & 15) == 0) {
-        tiles = reinterpret_cast<int4 *>(tile_scratch);
-        hipLaunchKernelGGL(k_pulse_tiles, dim3((n_tiles + 63) / 64), dim3(64), 0, st, onsets, onset_cnt, sample_off, n_notes, total_samples,
-                           (int)n_tiles, tiles);
-        LAUNCH_CHECK(ctx);
-    }
+    const int4 *tl = (ctx->pulse_tiles && tiles && ((uintptr_t)tiles & 15) == 0) ? reinterpret_cast<const int4 *>(tiles) : nullptr;
     hipLaunchKernelGGL(k_pulse_place, dim3(n_tiles), dim3(256), 0, st, onsets, onset_cnt, ctx->plan.pulse_peak, ctx->plan.pulse_shape,
-                       sample_off, n_notes, total_samples, pulse, (const int4 *)tiles);
+                       sample_off, n_notes, total_samples, pulse, tl);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
@@ -924,9 +927,10 @@ int launch_pulse_train(goofer_ctx *ctx, const float *f0, float f0_scale, const i
 {
     if (total_samples <= 0 || n_notes <= 0) return GOOFER_OK;
     int rc;
-    (void)inc;                                                // the walk divides f0 by sr itself
-    if ((rc = launch_pulse_onsets(ctx, f0, f0_scale, sample_off, n_notes, onsets, onset_idx, onset_cnt, overflow, st))) return rc;
-    return launch_pulse_place(ctx, onsets, onset_cnt, sample_off, n_notes, total_samples, pulse, onset_idx, st);
+    // the walk divides f0 by sr itself: the increments array (8 bytes per sample) is free and holds the placement's tile table
+    int32_t *tiles = reinterpret_cast<int32_t *>(inc);
+    if ((rc = launch_pulse_onsets(ctx, f0, f0_scale, sample_off, n_notes, onsets, onset_idx, onset_cnt, overflow, total_samples, tiles, st))) return rc;
+    return launch_pulse_place(ctx, onsets, onset_cnt, sample_off, n_notes, total_samples, pulse, tiles, st);
 }
 
 // ---------------------------------------------------------------------------------------------
