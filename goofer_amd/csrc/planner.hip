@@ -729,6 +729,7 @@ int64_t goofer_host_decode_bends(const char *text, const int64_t *text_off, int 
     for (int i = 0; i < n; ++i) {
         out_off[i] = total;
         const char *p = text + text_off[i], *e = text + text_off[i + 1];
+        if (e > p && e[-1] == '\0') --e;                       // (strings joined with a NUL separator: it belongs to neither)
         bool have = false;
         float last = 0.f;
         int64_t count = 0;
@@ -782,6 +783,7 @@ int goofer_host_parse_floats(const char *text, const int64_t *text_off, int n, i
     int bad = 0;
     for (int i = 0; i < n; ++i) {
         const char *p = text + text_off[i], *e = text + text_off[i + 1];
+        if (e > p && e[-1] == '\0') --e;                       // (strings joined with a NUL separator: it belongs to neither)
         if (strip_bang)
             while (p < e && *p == '!') ++p;
         char buf[64];

@@ -164,7 +164,7 @@ class Context:
 
     def frame_counts(self, sample_lengths, hop=None):
         hop = self.geom[2] if hop is None else int(hop)
-        return [1 + int(n) // hop for n in sample_lengths]
+        return (1 + np.asarray(sample_lengths, dtype=np.int64) // hop).tolist()
 
     # -- single-kernel entry points -------------------------------------------------------------
     def rfft_frames(self, x, sample_off, frame_off, total_frames: int, out=None):

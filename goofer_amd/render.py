@@ -32,6 +32,10 @@ class Source:
     sr: int
     ylen: int
     n_fft: int = S.N_FFT
+    # SourceArena registry key of this sample: (arena epoch token << 32) | index into the arena's per-sample tables, -1: in none.
+    # An instance attribute once the sample is resident; a batch then finds its samples' table rows with one C-level pass over
+    # the list (operator.attrgetter) instead of half a dozen Python loops over the sources.
+    _reg_key = -1
 
     def knot_rows(self) -> np.ndarray:
         """The knot table frame-major ([T, K] contiguous, flattened), the layout the device kernels index; made once per source
@@ -206,10 +210,22 @@ class SourceArena:
             except Exception:                                  # noqa: BLE001 - no device query: the fixed default
                 budget_bytes = 48 << 30
         self.ctx, self.budget = ctx, int(budget_bytes)
-        self.lock = threading.Lock()
+        self.lock = threading.RLock()                          # (lookup places missing samples under it)
         self._reset()
 
+    _EPOCH = [0]                                              # process-wide counter: every arena state gets its own token
+
     def _reset(self):
+        SourceArena._EPOCH[0] += 1
+        self.token = SourceArena._EPOCH[0]
+        # per-sample tables, indexed by the low half of Source._reg_key (rows are never re-used inside an epoch)
+        self.n_reg = 0
+        cap = 1024
+        self.t = {"koff": np.zeros(cap, np.int64), "soff": np.zeros(cap, np.int64), "K": np.zeros(cap, np.int64),
+                  "T": np.zeros(cap, np.int64), "ylen": np.zeros(cap, np.int64), "sr": np.zeros(cap, np.int64),
+                  "n_fft": np.zeros(cap, np.int64), "lerp": np.full(cap, -1, np.int64), "trk_ok": np.zeros(cap, np.bool_),
+                  "trk_ptr": np.zeros((cap, 4), np.uint64), "trk_len": np.zeros((cap, 4), np.int32)}
+        self.lerp_ids, self.lerp_tabs = {}, []                 # (sr, n_fft, K, hz bytes) -> index; the 2-tap plans themselves
         self.where = {}                                        # id(Source) -> (weak reference, knot_off, sample_off)
         self.knots = torch.empty(0, dtype=torch.int16, device=self.ctx.device)
         self.mask = torch.empty(0, dtype=torch.float32, device=self.ctx.device)
@@ -310,11 +326,61 @@ class SourceArena:
                         if where.pop(key, None) is not None:
                             dead[0] += nbytes
                     ref = weakref.ref(sc, gone)
-                    self.where[id(sc)] = (ref, self.k_used, self.m_used)
+                    self.where[id(sc)] = (ref, self.k_used, self.m_used, self._register(sc, self.k_used, self.m_used))
                     self.k_used += sc.knots.size
                     self.m_used += sc.ylen
             at = [self.where[id(sc)] for sc in sources]
             return (np.array([a[1] for a in at], dtype=np.int64), np.array([a[2] for a in at], dtype=np.int64), self.knots, self.mask)
+
+    def _register(self, sc, koff, soff):
+        """A row of the per-sample tables for a sample that has just been placed (under the lock)."""
+        u = self.n_reg
+        if u >= self.t["K"].shape[0]:
+            for k, v in self.t.items():
+                grown = np.zeros((2 * v.shape[0],) + v.shape[1:], dtype=v.dtype)
+                if k == "lerp":
+                    grown[:] = -1
+                grown[:v.shape[0]] = v
+                self.t[k] = grown
+        t = self.t
+        t["koff"][u], t["soff"][u], t["K"][u], t["T"][u] = koff, soff, sc.knots.shape[0], sc.knots.shape[1]
+        t["ylen"][u], t["sr"][u], t["n_fft"][u] = sc.ylen, sc.sr, sc.n_fft
+        if sc.hz_knots is not None:                            # (dense sources: no lerp plan, -1)
+            key = (sc.sr, sc.n_fft, sc.knots.shape[0], sc.hz_knots.tobytes())
+            g = self.lerp_ids.get(key)
+            if g is None:
+                g = self.lerp_ids[key] = len(self.lerp_tabs)
+                self.lerp_tabs.append(_lerp_plan(sc.sr, sc.n_fft, sc.hz_knots))
+            t["lerp"][u] = g
+        tr = sc.tracks64()
+        t["trk_ok"][u] = tr is not None
+        if tr is not None:
+            t["trk_ptr"][u], t["trk_len"][u] = tr.ptrs, tr.lens
+        object.__setattr__(sc, "_reg_key", (self.token << 32) | u)
+        self.n_reg = u + 1
+        return u
+
+    def lookup(self, sources, stg=None):
+        """Rows of the per-sample tables for ``sources`` (an int64 array, one per element) plus the tables and device arrays to
+        index with them — samples not resident yet are placed (uploaded) first.  One C-level pass over the list when every
+        sample is resident, which is every batch of a job after a voicebank sample's first."""
+        import operator
+        n = len(sources)
+        get = operator.attrgetter("_reg_key")
+        with self.lock:
+            keys = np.fromiter(map(get, sources), dtype=np.int64, count=n)
+            for _ in range(2):                                 # (a second round when placing the first misses started a new epoch)
+                miss = np.nonzero((keys >> 32) != self.token)[0] if n else ()
+                if not len(miss):
+                    break
+                ms = [sources[i] for i in miss]
+                self.place(ms, stg)                            # uploads the ones that are not resident (may start a new epoch)
+                # a sample carries the key of ONE arena; one that lives in several (two Renderers, two GPUs) is re-stamped from
+                # this arena's own table whenever it comes back
+                for sc in ms:
+                    object.__setattr__(sc, "_reg_key", (self.token << 32) | self.where[id(sc)][3])
+                keys = np.fromiter(map(get, sources), dtype=np.int64, count=n)
+            return keys & 0xFFFFFFFF, dict(self.t), list(self.lerp_tabs), self.knots, self.mask
 
 
 class Renderer:
@@ -507,6 +573,13 @@ class Renderer:
                 del stg
 
     def _prepare(self, stg, jobs, phi_seeds, note_ids, trim_rows, device_calls=True):
+        tr = getattr(self, "trace_prepare", None)              # a list: (label, perf_counter) marks of the host phases (scripts/prepare_phases.py)
+        if tr is None:
+            _T = lambda label: None
+        else:
+            import time
+            _T = lambda label: tr.append((label, time.perf_counter()))
+        _T("start")
         ctx = self.ctx
         if isinstance(jobs, tuple) and len(jobs) == 2 and isinstance(jobs[1], S.RequestBatch):
             srcs, rb = list(jobs[0]), jobs[1]
@@ -518,45 +591,40 @@ class Renderer:
         sr, n_fft = srcs[0].sr, srcs[0].n_fft
         n = rb.n
         c = rb.col
-        # distinct sources (a voicebank sample rendered by several notes is uploaded once: same Source object)
-        uniq, src_ix = {}, np.empty(n, dtype=np.int64)
-        for i, sc in enumerate(srcs):
-            src_ix[i] = uniq.setdefault(id(sc), len(uniq))
-        usrc = [None] * len(uniq)
-        for sc in srcs:
-            usrc[uniq[id(sc)]] = sc
-        if any(sc.sr != sr or sc.n_fft != n_fft for sc in usrc):
+        # the samples' rows in the arena's tables (a voicebank sample rendered by several notes is resident once: same Source object)
+        rows, T_, g_lerp_tabs, d_knots, d_mask_src = self.sources.lookup(srcs, stg)   # resident in HBM; new samples are uploaded here
+        _T("uniq")
+        uu, src_ix = np.unique(rows, return_inverse=True)
+        u_K, u_T, u_ylen, u_koff, u_soff = T_["K"][uu], T_["T"][uu], T_["ylen"][uu], T_["koff"][uu], T_["soff"][uu]
+        if (T_["sr"][uu] != sr).any() or (T_["n_fft"][uu] != n_fft).any():
             raise ValueError("one batch must share sr / n_fft")
         if device_calls:
             ctx.plan(sr, n_fft, self.hop)
         B = n_fft // 2 + 1
         ld = row_stride(B)
-        for sc in usrc:
-            T_src = sc.knots.shape[1]
-            if T_src != 1 + sc.ylen // self.hop:               # frames of the analysis STFT (GOOFER.py:355-370)
-                raise ValueError(f"bad features: envelope has {T_src} frames, y_len {sc.ylen} at hop {self.hop} implies "
-                                 f"{1 + sc.ylen // self.hop}")
-        u_K = np.array([sc.knots.shape[0] for sc in usrc], dtype=np.int64)
-        u_T = np.array([sc.knots.shape[1] for sc in usrc], dtype=np.int64)
-        u_ylen = np.array([sc.ylen for sc in usrc], dtype=np.int64)
-        u_koff, u_soff, d_knots, d_mask_src = self.sources.place(usrc, stg)   # resident in HBM; new samples are uploaded here
-        lerp_keys, lerp_tabs, u_lerp = {}, [], np.full(len(usrc), -1, dtype=np.int64)
-        for k, sc in enumerate(usrc):
-            if sc.hz_knots is None:                            # dense source: rows are the envelope, no lerp plan
-                if sc.knots.shape[0] != B:
-                    raise ValueError("dense envelope has %d bins, the plan has %d" % (sc.knots.shape[0], B))
-                continue
-            key = (sc.knots.shape[0], sc.hz_knots.tobytes())
-            if key not in lerp_keys:
-                lerp_keys[key] = len(lerp_tabs)
-                lerp_tabs.append(_lerp_plan(sr, n_fft, sc.hz_knots))
-            u_lerp[k] = lerp_keys[key]
+        bad = np.nonzero(u_T != 1 + u_ylen // self.hop)[0]     # frames of the analysis STFT (GOOFER.py:355-370)
+        if bad.size:
+            k = int(bad[0])
+            raise ValueError(f"bad features: envelope has {int(u_T[k])} frames, y_len {int(u_ylen[k])} at hop {self.hop} implies "
+                             f"{1 + int(u_ylen[k]) // self.hop}")
+        _T("place")
+        # 2-tap lerp plans of the batch: the arena's plans its samples use, renumbered from 0
+        g = T_["lerp"][uu]
+        dense = g < 0
+        if dense.any() and (u_K[dense] != B).any():            # dense source: rows are the envelope, no lerp plan
+            raise ValueError("dense envelope has %d bins, the plan has %d" % (int(u_K[dense][u_K[dense] != B][0]), B))
+        used = np.unique(g[~dense])
+        remap = np.full(len(g_lerp_tabs) + 1, -1, dtype=np.int64)
+        remap[used] = np.arange(used.size)
+        u_lerp = np.where(dense, -1, remap[np.maximum(g, 0)])
+        lerp_tabs = [g_lerp_tabs[int(i)] for i in used]
 
+        _T("lerp")
         # -- the notes' plans: cut points, frame taps, sample counts, formant tracks (SillySampler.py:449-833)
-        tracks = [sc.tracks64() for sc in usrc]
         pb = None
-        if all(t is not None for t in tracks):
-            rec = S.plan_records(rb, sr, u_ylen[src_ix], u_T[src_ix], [tracks[k] for k in src_ix])
+        if T_["trk_ok"][uu].all():
+            tracks = srcs                                      # (what keeps the track arrays alive while the planner reads them)
+            rec = S.plan_records(rb, sr, u_ylen[src_ix], u_T[src_ix], None, track_ptrs=T_["trk_ptr"][rows], track_lens=T_["trk_len"][rows])
             # the rows go straight into the staging block: whatever the block has left after ~2 MiB for the small pieces
             geo_h, _ = stg.reserve(n, _lib.PLAN_GEOMETRY)
             cap = max(0, (stg.nbytes - stg.used - (2 << 20) - 600 * n - 8 * int(rb.bend.size)) // 96 - 8)
@@ -573,6 +641,7 @@ class Renderer:
         if pb is None:                                         # odd formant dicts, or a note the reference refuses (raises here)
             pb = S.plans_to_arrays(S.plan_notes([(rb.request(i), sc.sr, sc.ylen, sc.knots.shape[1], sc.formants)
                                                  for i, sc in enumerate(srcs)], self.hop), self.hop, trim_rows)
+        _T("planner")
         geo = pb.geo
         if (geo["n_out"] <= 0).any():
             raise ValueError("a note assembles to zero samples")
@@ -583,6 +652,7 @@ class Renderer:
         env_off, sample_off, edit_off = csum0(env_lens), csum0(lens), csum0(n_edit)
         t_off, o_off, e_off = int(env_off[-1]), int(sample_off[-1]), int(edit_off[-1])
 
+        _T("geo")
         # -- request scalars as columns
         c_rev, c_be, c_es, c_fw, c_fv, c_pm, c_tempo, c_fhz = (c["reverse"], c["brightness_env"], c["env_shape"], c["formant_width"],
                                                                 c["force_voiced"], c["pitch_m"], c["tempo"], c["fry_hz"])
@@ -613,6 +683,7 @@ class Renderer:
         es_rad = np.array([(t.size - 1) // 2 for t in es_tabs], dtype=np.int64)
         es_on = es_id >= 0
 
+        _T("tables")
         P = np.zeros(n, dtype=_lib.NOTE_PLAN)
         P["knot_off"], P["K"], P["lerp_plan"], P["n_src_rows"] = u_koff[src_ix], u_K[src_ix], u_lerp[src_ix], u_T[src_ix]
         P["reverse"], P["tilt"], P["fw_plan"] = c_rev, tilt_id, fw_id
@@ -637,6 +708,7 @@ class Renderer:
             sel = np.repeat(c_tc != 0.0, n_bend)
             bend[sel] = bend[sel] + np.repeat(c_tc / 100.0, n_bend)[sel]
 
+        _T("P")
         def cat_tab(tabs, k, dtype):
             return stg.put(np.concatenate([t[k] for t in tabs]), dtype) if tabs else None
 
@@ -653,6 +725,7 @@ class Renderer:
             bend=stg.put(bend),
             lease=_StagingLease(stg, self._stagings),
         )
+        _T("puts")
         d_formants = on_dev["formants"] if on_dev else stg.put(pb.formants)
         env = torch.empty((t_off, ld), dtype=torch.float32, device=ctx.device)[:, :B]   # (= ctx.rows, without asking the handle for B)
         f0 = torch.empty(o_off, dtype=torch.float32, device=ctx.device)
@@ -669,6 +742,7 @@ class Renderer:
                           fst_tracks=ptr(d["fst_tracks"]), mask_src=ptr(d["mask_src"]), bend=ptr(d["bend"]), edit_rows=None,
                           env_out=env.data_ptr(), f0_out=f0.data_ptr(), mask_out=mask.data_ptr(), bend_out=ptr(bend_out),
                           any_fry=int(any_fry))
+        _T("alloc+assembly")
         # per-note synthesize parameters
         par = default_params(n)
         par["formant_shift"], par["normalize"] = c_fs, c_norm
@@ -677,8 +751,8 @@ class Renderer:
         nids = np.asarray(note_ids if note_ids is not None else range(n), dtype=np.uint64)   # Philox stream of the note: its id, not its batch position
         par["seed"] = np.stack([nids & np.uint64(0xFFFFFFFF), (nids >> np.uint64(32)) & np.uint64(0xFFFFFFFF)], axis=1)
         par["f0_jitter"], par["vol_jitter_harm"], par["vol_jitter_breath"], par["subharm_weight"] = c_f0j, c_vj, c_vj * 2, c_sub
-        lens_l = [int(v) for v in lens]
-        env_lens_l = [int(v) for v in env_lens]
+        lens_l = lens.tolist()
+        env_lens_l = env_lens.tolist()
         # sh / sr draws come from the legacy global np.random stream, note by note, in the reference's order
         # (f0 jitter, harmonic volume, breath volume: GOOFER.py:666, 653)
         noise_f0 = noise_vol = None
@@ -693,6 +767,7 @@ class Renderer:
                 noise_f0 = ctx.tensor(np.concatenate(nf))
             if any_vj:
                 noise_vol = (ctx.tensor(np.concatenate(nh)), ctx.tensor(np.concatenate(nb)))
+        _T("par")
         # sample-domain post chain: per-note table (offsets into the extra synth calls are filled in by run())
         post = np.zeros(n, dtype=_lib.POST_NOTE)
         post["su_off"] = post["sj_off"] = post["sa_off"] = -1
@@ -720,12 +795,15 @@ class Renderer:
                 T = 1 + n_ // self.hop
                 mats.append(np.random.default_rng(sd).uniform(0.0, 2.0 * np.pi, size=(B, T)).astype(np.float32).T)
             phi = ctx.rows_from(np.concatenate(mats))
+        _T("post")
         offsets = ctx.device_offsets(env_lens_l, lens_l, par, put=stg.put, hop=self.hop)
         frames = int(offsets["f_off"][-1])
+        _T("offsets")
         stg.ship()                                             # one H2D copy for everything above
         if device_calls:
             ctx.reserve(frames, o_off, n)
             torch.cuda.current_stream(ctx.device).synchronize()   # (this batch's uploads; other lanes' streams are not waited for)
+        _T("ship+sync")
         return {"assembly": a, "keep": d, "env": env, "f0": f0, "mask": mask, "params": par, "lens": lens_l, "env_lens": env_lens_l,
                 "noise_f0": noise_f0, "noise_vol": noise_vol, "subharm": bool((c_sub > 0).any()),
                 "post": post if has_post else None, "growl": growl, "f0_growl": f0_growl, "bend_out": bend_out, "requests": rb, "sources": srcs, "geometry": (sr, n_fft, self.hop, frames, o_off, n),
