@@ -213,11 +213,10 @@ class SourceArena:
         self.lock = threading.RLock()                          # (lookup places missing samples under it)
         self._reset()
 
-    _EPOCH = [0]                                              # process-wide counter: every arena state gets its own token
-
     def _reset(self):
-        SourceArena._EPOCH[0] += 1
-        self.token = SourceArena._EPOCH[0]
+        # every arena state gets its own 31-bit random token: a Source that carries another arena's key (another Renderer, an
+        # earlier epoch, a pickled copy from another process) never matches by accident
+        self.token = int.from_bytes(os.urandom(4), "little") >> 1
         # per-sample tables, indexed by the low half of Source._reg_key (rows are never re-used inside an epoch)
         self.n_reg = 0
         cap = 1024

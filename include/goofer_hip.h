@@ -430,7 +430,8 @@ int goofer_pcm16(goofer_ctx *ctx, const float *x, int64_t n, int16_t *out, void 
 
 /* HIP-event timing of every stage of goofer_synth_batch on the caller's stream: begin() arms up to
  * max_steps batches, end() synchronises and writes the summed milliseconds of each stage
- * (goofer_profile_stage_name(i), i < 18); returns the number of batches recorded. */
+ * (goofer_profile_stage_name(i), i < 18); returns the number of batches recorded.  Stages 15..17 are the assembly's three
+ * large kernels ("env_edit", "env_rows", "sample_assemble"), each bracketed on the stream it runs on. */
 int goofer_profile_begin(goofer_ctx *ctx, int max_steps);
 int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages);
 const char *goofer_profile_stage_name(int stage);
@@ -449,6 +450,11 @@ const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage);   /*
  *   "pulse_scan" 1 (default): pulse onsets from a parallel fp64 phase scan wherever its rounding band provably cannot move
  *               floor(phase), the sequential walk only for the remaining notes; 0: the sequential walk for every note;
  *               2: the scan kernel walks every note (tests the hand-over)
+ *   "value_f64" 0 (default): the assembly's VALUE arithmetic (tap blend, warp / fw interpolation, es blur, knot exp) in fp32 —
+ *               everything that decides an index, a threshold or the pitch curve stays fp64; 1: round 4's
+ *               fp64 arithmetic and gather kernel (agrees to 2e-8 sample-RMS on the 1024-note batch; not bit-identical)
+ *   "sa_fast"   1 (default): k_sample_assemble's branch-free path with all of a thread's loads in flight together; 0: per sample
+ *   "pulse_tiles" 1 (default): the onset range of every placement tile from a kernel of its own; 0: per workgroup
  *   tuning knobs kept for A/B runs: "walk_lds_kb", "finish_lds_kb", "sa_spt", "walk_npw", "maps_side"       */
 int goofer_set_option(goofer_ctx *ctx, const char *name, int value);
 

@@ -20,7 +20,7 @@ for cfg in 4 5; do
   out=$root/gpurun_out/prof_$jt
   mkdir -p "$out"
   args="--config $cfg --job-notes $notes --sub-batch 4096 --no-cpu-baseline"
-  python3 bench.py $args --steps 5 --warmup 2 > "$out/bench.json" 2> "$out/bench.err"
+  python3 bench.py $args --steps 10 --warmup 4 > "$out/bench.json" 2> "$out/bench.err"
   cd /tmp && export TMPDIR=/tmp
   # (traced / counted runs without the two-in-flight variant: its overlapped launches would sit in the per-kernel averages)
   rocprofv3 --kernel-trace --stats -d "$out/trace" -o r --output-format csv -- python3 "$root/bench.py" $args --no-variants --steps 2 --warmup 1 > "$out/trace.log" 2>&1
