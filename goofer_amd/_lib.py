@@ -124,6 +124,7 @@ EXPORTS = {
                                      C.c_int, C.c_void_p]),
     "goofer_irfft_ola": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64,
                                    C.c_void_p, C.c_void_p]),
+    "goofer_pulse_model": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "goofer_pulse_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "goofer_gauss_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p]),

@@ -108,8 +108,8 @@ def istft(S, hop_length=512, window=None, length=None, sr=44100, ctx=None):
 
 
 def pulse_train_numba(f0_interp, sr, Ra=0.02, Rg=1.7, Rk=0.8, ctx=None):
-    if (Ra, Rg, Rk) != (0.02, 1.7, 0.8):
-        raise NotImplementedError("the backend fixes Ra=0.02, Rg=1.7, Rk=0.8 (the only values the reference uses)")
+    """gf.pulse_train_numba (GOOFER.py:473-554).  Ra, Rg, Rk other than gf.synthesize's constants rebuild the handle's pulse
+    tables for this call (Context.pulse_model) and put the constants back behind it."""
     c = ctx or default_context()
     if c.geom is None:
         c.plan(int(sr), 1024, 256)
@@ -118,7 +118,12 @@ def pulse_train_numba(f0_interp, sr, Ra=0.02, Rg=1.7, Rk=0.8, ctx=None):
     f0 = np.asarray(f0_interp, dtype=np.float32)
     if f0.size == 0:
         return np.zeros(0, dtype=np.float32)
-    return c.pulse_train(c.tensor(f0), c.tensor(np.array([0, f0.size], dtype=np.int64))).cpu().numpy()
+    before = getattr(c, "lf", (0.02, 1.7, 0.8))
+    c.pulse_model(Ra, Rg, Rk)
+    try:
+        return c.pulse_train(c.tensor(f0), c.tensor(np.array([0, f0.size], dtype=np.int64))).cpu().numpy()
+    finally:
+        c.pulse_model(*before)
 
 
 def decode_env_from_knots(env_pack, ctx=None):

@@ -619,11 +619,28 @@ int goofer_plan(goofer_ctx *ctx, int sr, int n_fft, int hop)
     if ((rc = upload(ctx, &p.blur175, t175))) return rc;
     for (int j = 0; j < 5; ++j) p.taps5_f[j] = (float)t5[j];
     for (int j = 0; j < 15; ++j) p.taps175_f[j] = (float)t175[j];
-    HIP_TRY(ctx, hipMalloc((void **)&p.pulse_peak, 8193 * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc((void **)&p.pulse_peak, PULSE_PEAK_FLOATS * sizeof(float)));
     p.sr = sr; p.n_fft = n_fft; p.hop = hop; p.n_bins = B;
     if ((rc = launch_pulse_peak(ctx, p.pulse_peak, (double)sr, 0))) return rc;
     HIP_TRY(ctx, hipMalloc((void **)&p.pulse_shape, pulse_shape_table_floats() * sizeof(float)));
     if ((rc = launch_pulse_shape_table(ctx, p.pulse_shape, p.pulse_peak, (double)sr, 0))) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return GOOFER_OK;
+}
+
+int goofer_pulse_model(goofer_ctx *ctx, double Ra, double Rg, double Rk)
+{
+    if (!ctx) return GOOFER_EINVAL;
+    goofer_plan_t &p = ctx->plan;
+    if (!p.pulse_peak || !p.pulse_shape) return goofer_fail(ctx, GOOFER_EINVAL, "goofer_pulse_model needs a plan (goofer_plan)");
+    if (!std::isfinite(Ra) || !std::isfinite(Rg) || !std::isfinite(Rk))
+        return goofer_fail(ctx, GOOFER_EINVAL, "Ra, Rg, Rk must be finite (got %g, %g, %g)", Ra, Rg, Rk);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());                     // nothing in flight still reads the tables
+    p.lf.ra = Ra; p.lf.rg = Rg; p.lf.rk = Rk;
+    int rc;
+    if ((rc = launch_pulse_peak(ctx, p.pulse_peak, (double)p.sr, 0))) return rc;
+    if ((rc = launch_pulse_shape_table(ctx, p.pulse_shape, p.pulse_peak, (double)p.sr, 0))) return rc;
     HIP_TRY(ctx, hipDeviceSynchronize());
     return GOOFER_OK;
 }

@@ -13,6 +13,12 @@
 #define PROF_ASM0 15           // profile stages 15..17: the assembly's k_env_edit, k_env_rows / k_env_loop, k_sample_assemble
 #define PULSE_TAB_MAX 2048     // pulse lengths served from the shape table (f0 >= sr/2048); longer ones are evaluated on the fly
 
+// the LF glottal-pulse model of gf.pulse_train_numba (GOOFER.py:474, 508): its keyword arguments, defaults = what gf.synthesize passes
+struct lf_model {
+    double ra = 0.02, rg = 1.7, rk = 0.8;
+};
+#define PULSE_PEAK_FLOATS (8193 + 1 + 6)   // k_pulse_peak's table + the model's three doubles behind it (8-byte aligned), for k_pulse_place's rare on-the-fly path
+
 struct goofer_plan_t {
     int sr = 0, n_fft = 0, hop = 0, n_bins = 0;
     float *window = nullptr;      // [n_fft] sqrt-Hann, fp32                      GOOFER.py:12-18
@@ -33,7 +39,8 @@ struct goofer_plan_t {
     float2 *bl_bhat = nullptr;    // [bl_L]  FFT of the wrapped chirp
     float2 *bl_tw = nullptr;      // [bl_L]  exp(-2 pi i k / bl_L)
     float2 *bl_twh = nullptr;     // [M + 1] exp(-i pi k / M)
-    float *pulse_peak = nullptr;  // [8193] 1/peak-normaliser of the LF shape per T0 (fp64 math)
+    lf_model lf;                  // goofer_pulse_model
+    float *pulse_peak = nullptr;  // [PULSE_PEAK_FLOATS] peak of the un-normalised LF shape per T0 (fp64 math), then the model's Ra, Rg, Rk
     float *pulse_shape = nullptr; // normalised LF pulses for T0 = 3..PULSE_TAB_MAX back to back (row T0 at T0(T0-1)/2 - 3)
     double *blur5 = nullptr;      // [5] sigma=0.5 taps (brightness blur)         GOOFER.py:1143
     double *blur175 = nullptr;    // [15] sigma=1.75 taps                         GOOFER.py:993

@@ -13,25 +13,23 @@
 // Shapes are evaluated on the fly in fp64 (numba's typing) and normalised by a per-T0 peak table.
 #include "common.h"
 
-#define PT_RA 0.02
-#define PT_RG 1.7
-#define PT_RK 0.8
 #define PT_PI 3.141592653589793
 
 // un-normalised LF shape sample k of a T0-sample pulse with period T (GOOFER.py:509-519), rounded
-// to fp32 like the reference's `buf[j] = ...` store
-__device__ __forceinline__ float lf_raw(int k, int T0, double T)
+// to fp32 like the reference's `buf[j] = ...` store.  lf: the model's Ra, Rg, Rk (gf.pulse_train_numba's keyword arguments;
+// 0.02 / 1.7 / 0.8 is what gf.synthesize passes, GOOFER.py:1074)
+__device__ __forceinline__ float lf_raw(int k, int T0, double T, const lf_model &lf)
 {
     double ti = ((double)k * T) / (double)T0;
-    double Tp = PT_RA * T;
-    double Tc = Tp + PT_RK * (T - Tp);
+    double Tp = lf.ra * T;
+    double Tc = Tp + lf.rk * (T - Tp);
     double v;
     if (ti < Tp) {
         double s = sin(PT_PI * ti / (2.0 * Tp + 1e-12));
         v = s * s;
     } else if (ti < Tc) {
         double tau = (ti - Tp) / (Tc - Tp + 1e-12);
-        v = exp(-PT_RG * tau) * cos(PT_PI * tau / 2.0);
+        v = exp(-lf.rg * tau) * cos(PT_PI * tau / 2.0);
     } else {
         v = 0.0;
     }
@@ -39,19 +37,23 @@ __device__ __forceinline__ float lf_raw(int k, int T0, double T)
 }
 
 // peak[T0] = max_k |buf[k]| for the nominal period T = T0/sr; one block per T0
-__global__ __launch_bounds__(256) void k_pulse_peak(float *__restrict__ peak, double sr)
+__global__ __launch_bounds__(256) void k_pulse_peak(float *__restrict__ peak, double sr, const lf_model lf)
 {
     __shared__ float red[4];
     int T0 = blockIdx.x;
     float m = 0.f;
     if (T0 >= 3) {
         double T = (double)T0 / sr;
-        for (int k = threadIdx.x; k < T0; k += blockDim.x) m = fmaxf(m, fabsf(lf_raw(k, T0, T)));
+        for (int k = threadIdx.x; k < T0; k += blockDim.x) m = fmaxf(m, fabsf(lf_raw(k, T0, T, lf)));
     }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) peak[T0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (T0 == 0 && threadIdx.x == 0) {
+        double *tail = reinterpret_cast<double *>(peak + 8194);   // (pulse_value reads the model from here)
+        tail[0] = lf.ra; tail[1] = lf.rg; tail[2] = lf.rk;
+    }
 }
 
 // The normalised pulse of length T0, tabulated at the nominal period T = T0/sr.  The LF shape depends on the period
@@ -59,21 +61,21 @@ __global__ __launch_bounds__(256) void k_pulse_peak(float *__restrict__ peak, do
 // 1/f0 moves the fp64 value by ~1e-11 relative (the 1e-12 guards) — below fp32 resolution except on rare ties.
 __device__ __forceinline__ int64_t pulse_tab_row(int T0) { return (int64_t)T0 * (T0 - 1) / 2 - 3; }
 
-__global__ __launch_bounds__(256) void k_pulse_shape_table(float *__restrict__ tab, const float *__restrict__ peak, double sr)
+__global__ __launch_bounds__(256) void k_pulse_shape_table(float *__restrict__ tab, const float *__restrict__ peak, double sr, const lf_model lf)
 {
     const int T0 = blockIdx.x + 3;
     const double T = (double)T0 / sr;
     const double m = (double)peak[T0];
     float *row = tab + pulse_tab_row(T0);
     for (int k = threadIdx.x; k < T0; k += blockDim.x) {
-        const float raw = lf_raw(k, T0, T);
+        const float raw = lf_raw(k, T0, T, lf);
         row[k] = m > 0.0 ? (float)((double)raw / m) : raw;
     }
 }
 
 int launch_pulse_peak(goofer_ctx *ctx, float *peak, double sr, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_pulse_peak, dim3(8193), dim3(256), 0, st, peak, sr);
+    hipLaunchKernelGGL(k_pulse_peak, dim3(8193), dim3(256), 0, st, peak, sr, ctx->plan.lf);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
@@ -82,7 +84,7 @@ size_t pulse_shape_table_floats() { return (size_t)((int64_t)(PULSE_TAB_MAX + 1)
 
 int launch_pulse_shape_table(goofer_ctx *ctx, float *tab, const float *peak, double sr, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_pulse_shape_table, dim3(PULSE_TAB_MAX - 2), dim3(256), 0, st, tab, peak, sr);
+    hipLaunchKernelGGL(k_pulse_shape_table, dim3(PULSE_TAB_MAX - 2), dim3(256), 0, st, tab, peak, sr, ctx->plan.lf);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
@@ -675,7 +677,10 @@ __device__ __forceinline__ float pulse_value(const onset_t &o, int j, const floa
     const int d = j - o.i;
     if (d < 0 || d >= o.T0) return 0.f;
     if (o.T0 <= PULSE_TAB_MAX) return tab[pulse_tab_row(o.T0) + d];
-    const float raw = lf_raw(d, o.T0, o.T);
+    const double *tail = reinterpret_cast<const double *>(peak + 8194);
+    lf_model lf;
+    lf.ra = tail[0]; lf.rg = tail[1]; lf.rk = tail[2];
+    const float raw = lf_raw(d, o.T0, o.T, lf);
     const double m = (double)peak[o.T0];
     return m > 0.0 ? (float)((double)raw / m) : raw;
 }

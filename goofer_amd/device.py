@@ -82,6 +82,16 @@ class Context:
         if self.geom != g:
             self._check(self.lib.goofer_plan(self.h, *g))
             self.geom = g
+            self.lf = (0.02, 1.7, 0.8)
+        return self
+
+    def pulse_model(self, Ra: float = 0.02, Rg: float = 1.7, Rk: float = 0.8):
+        """gf.pulse_train_numba's Ra, Rg, Rk (GOOFER.py:474) for every pulse this handle makes from now on (the plan's tables
+        are rebuilt; a new plan starts from the defaults again)."""
+        lf = (float(Ra), float(Rg), float(Rk))
+        if getattr(self, "lf", (0.02, 1.7, 0.8)) != lf:
+            self._check(self.lib.goofer_pulse_model(self.h, *lf))
+            self.lf = lf
         return self
 
     @property

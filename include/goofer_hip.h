@@ -249,7 +249,14 @@ int goofer_rfft_frames(goofer_ctx *ctx, const float *x, const int64_t *sample_of
 int goofer_irfft_ola(goofer_ctx *ctx, const float *S, int ldc, const int64_t *sample_off, const int64_t *frame_off,
                      int n_notes, int64_t total_frames, int64_t total_samples, float *y, void *stream);
 
-/* gf.pulse_train_numba (GOOFER.py:473-554), Ra=0.02 Rg=1.7 Rk=0.8: f0 [total_samples] -> pulse. */
+/* The LF glottal-pulse model of gf.pulse_train_numba — its keyword arguments Ra, Rg, Rk (GOOFER.py:474, 508-519: opening
+ * phase sin^2 up to Tp = Ra T, return phase exp(-Rg tau) cos(pi tau / 2) up to Tc = Tp + Rk (T - Tp)).  A plan starts with
+ * 0.02 / 1.7 / 0.8, the values gf.synthesize passes (GOOFER.py:1074); this call rebuilds the plan's pulse tables for other
+ * values (it synchronises the device) and they hold until the next goofer_plan.  Every pulse the handle makes afterwards —
+ * goofer_pulse_train and the synthesis — uses them. */
+int goofer_pulse_model(goofer_ctx *ctx, double Ra, double Rg, double Rk);
+
+/* gf.pulse_train_numba (GOOFER.py:473-554) with the plan's pulse model (goofer_pulse_model): f0 [total_samples] -> pulse. */
 int goofer_pulse_train(goofer_ctx *ctx, const float *f0, const int64_t *sample_off, int n_notes,
                        int64_t total_samples, float *pulse, void *stream);
 

@@ -196,6 +196,29 @@ def gen_pulse():
     save("pulse_train", **out)
 
 
+def gen_pulse_lf():
+    """pulse_train_numba with Ra / Rg / Rk other than the constants gf.synthesize passes (GOOFER.py:474, 508-519)."""
+    out = {}
+    sr = 44100
+    n = 5000
+    t = np.arange(n) / sr
+    f0s = {
+        "glide": 140.0 + 200.0 * t / t[-1] + 5.0 * np.sin(2 * np.pi * 4.1 * t),
+        "low": np.full(n, 18.3),          # T0 = 2410: longer than the shape table, evaluated on the fly
+        "gaps": np.where((t > 0.02) & (t < 0.05), 0.0, 311.0 + 15 * np.sin(33 * t)),
+    }
+    models = [(0.01, 1.47, 0.34), (0.05, 3.0, 1.0), (0.2, 0.5, 0.6), (0.02, 1.7, 0.8)]
+    for k, f in f0s.items():
+        f = f.astype(np.float32)
+        out["f0_" + k] = f
+        for m, (Ra, Rg, Rk) in enumerate(models):
+            out["pulse_%s_%d" % (k, m)] = gf.pulse_train_numba(f, sr, Ra=Ra, Rg=Rg, Rk=Rk)
+    out["names"] = np.array(list(f0s.keys()))
+    out["models"] = np.array(models, dtype=np.float64)
+    out["sr"] = np.array(sr)
+    save("pulse_train_lf", **out)
+
+
 def gen_gauss():
     out = {}
     r = _orig_default_rng(31)
@@ -752,6 +775,7 @@ elif __name__ == "__main__":
     gen_tables()
     gen_stft_istft()
     gen_pulse()
+    gen_pulse_lf()
     gen_gauss()
     gen_mask_interp()
     gen_knots()

@@ -101,6 +101,44 @@ def test_pulse_train_against_reference(ctx):
     assert np.max(np.abs(out - g["pulse_sr96"])) < 5e-6
 
 
+def test_pulse_train_other_lf_models_against_reference(ctx):
+    """goofer_pulse_model: Ra / Rg / Rk other than gf.synthesize's constants (GOOFER.py:474, 508-519) against pulse trains the
+    reference wrote — the shape table (T0 <= 2048) and the on-the-fly path (f0 18.3 Hz: T0 = 2410) — through the handle and
+    through core.pulse_train_numba, which puts the constants back; a new plan starts from the constants as well."""
+    from goofer_amd import core
+    g = golden("pulse_train_lf")
+    sr = int(g["sr"])
+    ctx.plan(sr, 1024, 256)
+    names = [str(k) for k in g["names"]]
+    f0s = [g["f0_" + k] for k in names]
+    lens = [len(f) for f in f0s]
+    d_f0, off = ctx.tensor(np.concatenate(f0s)), _off(ctx, lens)
+    try:
+        for m, (Ra, Rg, Rk) in enumerate(g["models"]):
+            ctx.pulse_model(Ra, Rg, Rk)
+            out = ctx.pulse_train(d_f0, off).cpu().numpy()
+            o = 0
+            for k, n in zip(names, lens):
+                err = np.max(np.abs(out[o:o + n] - g["pulse_%s_%d" % (k, m)]))
+                assert err < 5e-6, (k, m, err)
+                o += n
+    finally:
+        ctx.pulse_model()
+    default = ctx.pulse_train(d_f0, off).cpu().numpy()
+    assert np.max(np.abs(default[:lens[0]] - g["pulse_glide_3"])) < 5e-6          # model 3 is the constants
+    Ra, Rg, Rk = g["models"][1]
+    got = core.pulse_train_numba(f0s[0], sr, Ra=Ra, Rg=Rg, Rk=Rk, ctx=ctx)
+    assert np.max(np.abs(got - g["pulse_glide_1"])) < 5e-6
+    assert ctx.lf == (0.02, 1.7, 0.8)
+    assert np.array_equal(ctx.pulse_train(d_f0, off).cpu().numpy(), default)
+    ctx.pulse_model(Ra, Rg, Rk)
+    ctx.plan(sr, 2048, 512)
+    ctx.plan(sr, 1024, 256)
+    assert np.array_equal(ctx.pulse_train(d_f0, off).cpu().numpy(), default)
+    with pytest.raises(RuntimeError):
+        ctx.pulse_model(float("nan"), 1.7, 0.8)
+
+
 def test_pulse_train_many_random_notes_vs_oracle(ctx):
     from oracle import goofer_ref as R
     ctx.plan(44100, 1024, 256)

@@ -65,6 +65,17 @@ def test_pulse_train(native, monkeypatch):
             assert oi.size == 0 and not p.any()
 
 
+def test_pulse_train_other_lf_models():
+    """Ra / Rg / Rk other than gf.synthesize's constants (GOOFER.py:474, 508-519): four models x three f0 curves written by
+    the reference, one of them with pulses longer than 2048 samples."""
+    g = golden("pulse_train_lf")
+    sr = int(g["sr"])
+    for name in g["names"]:
+        for m, (Ra, Rg, Rk) in enumerate(g["models"]):
+            p = R.pulse_train(g["f0_" + str(name)], sr, Ra=float(Ra), Rg=float(Rg), Rk=float(Rk))
+            assert np.max(np.abs(p - g["pulse_%s_%d" % (name, m)])) < 5e-6, (name, m)
+
+
 def test_pulse_native_matches_python_bitwise(monkeypatch):
     g = golden("pulse_train")
     f0 = g["f0_many"]
