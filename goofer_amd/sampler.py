@@ -652,8 +652,9 @@ def _interp_rows(x_old, y, x_new):
     if n == 1:
         return np.repeat(yd[..., :1], x_new.size, axis=-1).astype(y.dtype if y.dtype == np.float64 else np.float64)
     j = np.clip(np.searchsorted(x_old, x_new, side="right") - 1, 0, n - 2)
-    slope = (yd[..., j + 1] - yd[..., j]) / (x_old[j + 1] - x_old[j])
-    out = slope * (x_new - x_old[j]) + yd[..., j]
+    with np.errstate(invalid="ignore"):                        # (inf - inf of a broken track: nan, as np.interp gives, without the warning)
+        slope = (yd[..., j + 1] - yd[..., j]) / (x_old[j + 1] - x_old[j])
+        out = slope * (x_new - x_old[j]) + yd[..., j]
     out = np.where(x_new == x_old[j], yd[..., j], out)
     out = np.where(x_new >= x_old[-1], yd[..., -1:], out)
     lo, hi = x_new < x_old[0], x_new > x_old[-1]
