@@ -13,6 +13,7 @@ import weakref
 from dataclasses import dataclass
 
 import os
+import time
 import numpy as np
 import torch
 
@@ -576,7 +577,6 @@ class Renderer:
         if tr is None:
             _T = lambda label: None
         else:
-            import time
             _T = lambda label: tr.append((label, time.perf_counter()))
         _T("start")
         ctx = self.ctx
@@ -877,7 +877,7 @@ class PipelinedRenderer:
     ``render_iter`` yields ``(mix, sample_off)`` per batch, in order: ``mix`` is a float32 numpy view of the lane's pinned
     buffer, valid until ``depth`` more batches have been taken from the iterator (copy what must live longer)."""
 
-    def __init__(self, device: int = 0, hop: int = S.HOP, depth: int = 2, workers: int = 3, staging_bytes: int = 48 << 20,
+    def __init__(self, device: int = 0, hop: int = S.HOP, depth: int = 2, workers: int = 4, staging_bytes: int = 48 << 20,
                  freeze_gc: bool = True):
         from concurrent.futures import ThreadPoolExecutor
         self.device = torch.device("cuda", device)
@@ -909,7 +909,6 @@ class PipelinedRenderer:
 
     def _prepare(self, k, batch, note_ids):
         if self.trace is not None:
-            import time
             t0 = time.perf_counter()
             try:
                 return self._prepare_batch(k, batch, note_ids)
@@ -969,7 +968,6 @@ class PipelinedRenderer:
         while ahead or flying:
             if ahead:
                 if self.trace is not None:
-                    import time
                     tw = time.perf_counter()
                 prep = ahead.popleft().result()
                 if self.trace is not None:
@@ -980,14 +978,7 @@ class PipelinedRenderer:
                 k += 1
                 r = ln["r"]
                 sr, n_fft, hop, frames, samples, n = prep["geometry"]
-                with torch.cuda.stream(ln["stream"]):
-                    r.ctx.plan(sr, n_fft, hop)                 # no-ops once the lane has seen the geometry / the sizes
-                    r.ctx.reserve(frames, samples, n)
-                    out = r.run(prep, seed=seed)
-                    if pcm16:
-                        out["pcm"] = r.ctx.pcm16(out["mix"])
-                    done = torch.cuda.Event()
-                    done.record()
+                marks = [] if self.trace is not None else None   # (sub-steps of the launch, for scripts/pipeline_job.py --trace)
                 want = torch.int16 if pcm16 else torch.float32
                 # two pinned buffers per lane, taking turns: the lane's next batch may be launched while this one's audio is still
                 # on its way home (or being read by the caller)
@@ -997,23 +988,39 @@ class PipelinedRenderer:
                 hb = ln["host"][slot]
                 if hb is None or hb.numel() < samples or hb.dtype != want:
                     hb = ln["host"][slot] = torch.empty(max(samples, int(1.25 * samples)), dtype=want).pin_memory()
+                with torch.cuda.stream(ln["stream"]):
+                    r.ctx.plan(sr, n_fft, hop)                 # no-ops once the lane has seen the geometry / the sizes
+                    r.ctx.reserve(frames, samples, n)
+                    if marks is not None:
+                        marks.append(time.perf_counter())
+                    out = r.run(prep, seed=seed)
+                    if marks is not None:
+                        marks.append(time.perf_counter())
+                    if pcm16:
+                        out["pcm"] = r.ctx.pcm16(out["mix"])
+                    done = torch.cuda.Event()
+                    done.record()
+                    if marks is not None:
+                        marks.append(time.perf_counter())
                 mix = out["pcm"] if pcm16 else out["mix"]
                 mix.record_stream(self.copy_stream)
-                with torch.cuda.stream(self.copy_stream):
-                    self.copy_stream.wait_event(done)
-                    hb[:samples].copy_(mix, non_blocking=True)
-                    home = torch.cuda.Event()
-                    home.record()
+                # (on this ROCm an asynchronous call now and then holds its caller for as long as the work queued in front of it
+                # takes, 6-8 ms every ten to twenty batches — this copy, or the next launch when the copy is queued from a thread of
+                # its own or on the lane's stream, which therefore bought nothing, and neither did HSA_KERNARG_POOL_SIZE,
+                # ROC_SIGNAL_POOL_SIZE or GPU_MAX_HW_QUEUES; the conversion kernel storing its int16 samples straight into the
+                # pinned buffer instead of a copy: 3.8 ms per batch against 2.8: scripts/pipeline_job.py --trace)
+                home = self._ship_home(hb[:samples], mix, done)
+                if marks is not None:
+                    marks.append(time.perf_counter())
                 flying.append((hb, home, prep, out, samples))
                 if self.trace is not None:
-                    self.trace.append(("launch", k - 1, tw, time.perf_counter()))
+                    self.trace.append(("launch", k - 1, tw, time.perf_counter(), tuple(marks)))
             # one more batch in flight than there are lanes: batch k + 1 is queued behind batch k on the device before batch k - 1 is
             # home, so the device never waits for the host's launch (with `lanes` in flight it idled ~0.5 ms per batch: the launch
             # came after the previous audio's 1.8 ms trip home)
             if flying and (len(flying) >= len(self.lanes) + 1 or not ahead):
                 hb, home, prep, out, samples = flying.popleft()
                 if self.trace is not None:
-                    import time
                     tw = time.perf_counter()
                 home.synchronize()
                 if self.trace is not None:
@@ -1022,6 +1029,15 @@ class PipelinedRenderer:
                 del prep, out
         for ln in self.lanes:                                  # the device is idle now: what the asynchronous calls flagged
             ln["r"].ctx.check()
+
+    def _ship_home(self, dst, src, done):
+        """the D2H copy behind ``done`` on the copy stream; returns the event behind it"""
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(done)
+            dst.copy_(src, non_blocking=True)
+            home = torch.cuda.Event()
+            home.record()
+        return home
 
     def render_all(self, batches, seed: int = 0, note_ids=None):
         """Every note of every batch as its own float32 array (copies), batch by batch."""

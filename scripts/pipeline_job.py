@@ -13,7 +13,7 @@ from goofer_amd.render import PipelinedRenderer, Source
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]   # [batches] [depth] [workers] [--pcm16] [--trace] [--plan-threads=N] [--extra] [--nogc]
 rounds = int(argv[0]) if len(argv) > 0 else 40
 depth = int(argv[1]) if len(argv) > 1 else 2
-workers = int(argv[2]) if len(argv) > 2 else 2
+workers = int(argv[2]) if len(argv) > 2 else 4
 raw = [syn.config_note(3, i) for i in range(1024)]
 args = [syn.request_args(q) for _, q, _ in raw]
 srcs = [Source.from_pack(s["env_pack"], s["f0"], s["mask"], s["formants"], s["sr"], s["y_len"]) for s, _, _ in raw]
@@ -37,9 +37,20 @@ if "--extra" in sys.argv:
         if "--keepb" not in sys.argv:
             del wb, both
             cb.close()
+for a in sys.argv:
+    if a.startswith("--switch="):                              # the interpreter's thread switch interval (bench.py: 1e-4)
+        sys.setswitchinterval(float(a.split("=")[1]))
 if "--nogc" in sys.argv:
     import gc
     gc.disable()
+def _throttled():
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0)), int(d.get("usage_usec", 0))
+    except OSError:
+        return 0, 0, 0
+print("cpu.max:", open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "-", " torch threads:", torch.get_num_threads())
+thr = [("setup", _throttled(), time.perf_counter())]
 pipe = PipelinedRenderer(0, depth=depth, workers=workers)
 for a in sys.argv:
     if a.startswith("--plan-threads="):
@@ -54,10 +65,15 @@ t_prev = time.perf_counter()
 for mix, off in pipe.render_iter(((srcs, args) for _ in range(rounds)), note_ids=lambda k, n: ids, pcm16="--pcm16" in sys.argv):
     now = time.perf_counter()
     stamps.append(1e3 * (now - t_prev))
+    if len(stamps) in (rounds // 4, rounds // 2, 3 * rounds // 4):
+        thr.append(("batch %d" % len(stamps), _throttled(), now))
     allocs.append(torch.cuda.memory_stats().get("num_device_alloc", 0))
     t_prev = now
 trace = pipe.trace
 pipe.close()
+thr.append(("end", _throttled(), time.perf_counter()))
+for (a, ta, wa), (b, tb, wb) in zip(thr, thr[1:]):
+    print("%-10s -> %-10s: %5.2f s wall, %6.2f s of CPU, throttled %d times for %.2f s" % (a, b, wb - wa, (tb[2] - ta[2]) / 1e6, tb[0] - ta[0], (tb[1] - ta[1]) / 1e6))
 print("intervals (ms):", " ".join("%.1f" % v for v in stamps))
 print("device allocations by the caching allocator in the second half of the job: %d; reserved %d MiB" % (allocs[-1] - allocs[len(allocs) // 2], torch.cuda.memory_stats().get("reserved_bytes.all.current", 0) >> 20))
 tail = stamps[len(stamps) // 2:]
@@ -69,3 +85,9 @@ if trace:
         ev = [e for e in trace if e[0] == what]
         d = [1e3 * (e[3] - e[2]) for e in ev]
         print("%-14s n %3d  mean %.2f ms  median %.2f  max %.2f   per batch over the job: %s" % (what, len(d), np.mean(d), np.median(d), max(d), " ".join("%.1f" % v for v in d[:80])))
+    ev = [e for e in trace if e[0] == "launch" and len(e) > 4 and e[3] - e[2] > 4e-3]
+    for e in ev[:12]:
+        m = (e[2],) + e[4]
+        print("slow launch of batch %d: plan/reserve %.2f, run %.2f, pcm16 + event %.2f, copy home queued %.2f ms" % ((e[1],) + tuple(1e3 * (b - a) for a, b in zip(m, m[1:]))))
+        over = [(p[1], 1e3 * (max(p[2], e[2]) - e[2]), 1e3 * (min(p[3], e[3]) - e[2])) for p in trace if p[0] == "prepare" and p[3] > e[2] and p[2] < e[3]]
+        print("   prepares running meanwhile (batch, from, to ms within the launch):", over)
