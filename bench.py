@@ -319,7 +319,7 @@ def host_inclusive(wl, ctx, step_s):
                                                                # 4-8 ms: allocator pools filling, threads falling into step, and on a shared
                                                                # host phases in which the planner threads do not get their cores) AND the
                                                                # mean over everything behind the lead-in
-    pipe = PipelinedRenderer(torch.cuda.current_device(), hop=wl.geo["hop"], depth=2, workers=4)
+    pipe = PipelinedRenderer(torch.cuda.current_device(), hop=wl.geo["hop"], depth=2, workers=4, coalesce=4)
     try:
         def job(pcm16):
             stamps = []
@@ -336,7 +336,9 @@ def host_inclusive(wl, ctx, step_s):
         gc.unfreeze()
     best["pipelined"] = {"ms_per_batch": 1e3 * dt, "frames_per_s": frames / dt, "batches": rounds,
                          "job_mean_ms_per_batch": 1e3 * dt_job, "job_mean_frames_per_s": frames / dt_job, "job_batches": total - lead,
-                         "note": "goofer_amd.render.PipelinedRenderer(depth=2, workers=4): 13 argument strings -> audio in pinned host memory, "
+                         "note": "goofer_amd.render.PipelinedRenderer(depth=2, workers=4, coalesce=4): the job's 1024-note batches, four of them planned and "
+                                 "rendered as one device batch and handed back one by one (same audio, half the host's per-call overhead "
+                                 "per note); 13 argument strings -> audio in pinned host memory, "
                                  "two handles / streams with three batches in flight (the next step is queued on the device before the "
                                  "previous audio is home), decode + planning of the next batches on four worker threads, D2H of the "
                                  "previous mix on a copy stream under the running step; ms_per_batch = the best 32 consecutive batches of "

@@ -874,12 +874,20 @@ class PipelinedRenderer:
     (round 5): batch k + 1 is queued on the device before batch k - 1 is home, two pinned buffers per lane taking turns, so the
     device does not idle while the host waits for audio — the steady state runs at the device step (1.9-2.0 ms per 1024 notes).
 
+    ``coalesce`` (long jobs): that many consecutive batches of the caller are planned and rendered as ONE device batch and handed
+    back one by one — the host's cost per batch is mostly per-call overhead of ~150 numpy operations under the interpreter lock,
+    which the worker threads queue for (a ``prepare`` of 3.7 ms alone takes 6-10 ms beside three others); twice the notes per call
+    is half of that per note.  The notes keep the Philox ids of their own batch, so the audio is what the un-coalesced job
+    renders.  Batches handed over as ``RequestBatch`` objects are not merged.  The default 1 keeps a server's latency.
+
     ``render_iter`` yields ``(mix, sample_off)`` per batch, in order: ``mix`` is a float32 numpy view of the lane's pinned
     buffer, valid until ``depth`` more batches have been taken from the iterator (copy what must live longer)."""
 
     def __init__(self, device: int = 0, hop: int = S.HOP, depth: int = 2, workers: int = 4, staging_bytes: int = 48 << 20,
-                 freeze_gc: bool = True):
+                 freeze_gc: bool = True, coalesce: int = 1):
         from concurrent.futures import ThreadPoolExecutor
+        self.coalesce = max(1, int(coalesce))
+        staging_bytes = int(staging_bytes) * self.coalesce
         self.device = torch.device("cuda", device)
         self.freeze_gc = bool(freeze_gc)
         self.lanes = []
@@ -907,23 +915,53 @@ class PipelinedRenderer:
             ln["r"].ctx.close()
         self.lanes = []
 
-    def _prepare(self, k, batch, note_ids):
+    def _prepare(self, k, group, note_ids):
         if self.trace is not None:
             t0 = time.perf_counter()
             try:
-                return self._prepare_batch(k, batch, note_ids)
+                return self._prepare_batch(k, group, note_ids)
             finally:
                 self.trace.append(("prepare", k, t0, time.perf_counter()))
-        return self._prepare_batch(k, batch, note_ids)
+        return self._prepare_batch(k, group, note_ids)
 
-    def _prepare_batch(self, k, batch, note_ids):
+    def _prepare_batch(self, k, group, note_ids):
+        """group: [(index of the caller's batch, (sources, requests)), ...] — one device batch.  Returns (prep, note counts)."""
         ln = self.lanes[k % len(self.lanes)]
-        srcs, reqs = batch
-        if not isinstance(reqs, S.RequestBatch):
-            reqs = list(reqs)
+        if len(group) == 1:
+            j, (srcs, reqs) = group[0]
+            if not isinstance(reqs, S.RequestBatch):
+                reqs = list(reqs)
+                reqs = S.RequestBatch.from_requests(reqs) if (reqs and isinstance(reqs[0], S.Request)) else S.decode_request_batch(reqs)
+            counts = [len(reqs)]
+            ids = note_ids(j, len(reqs)) if note_ids else None
+        else:
+            srcs, reqs, counts, ids = [], [], [], []
+            for j, (sj, rj) in group:
+                rj = list(rj)
+                srcs.extend(sj)
+                reqs.extend(rj)
+                counts.append(len(rj))
+                ids.extend(note_ids(j, len(rj)) if note_ids else range(len(rj)))   # the ids the batch has when it is rendered alone
             reqs = S.RequestBatch.from_requests(reqs) if (reqs and isinstance(reqs[0], S.Request)) else S.decode_request_batch(reqs)
         with torch.cuda.stream(ln["stream"]):
-            return ln["r"].prepare((srcs, reqs), note_ids=note_ids(k, len(reqs)) if note_ids else None, device_calls=False)
+            return ln["r"].prepare((srcs, reqs), note_ids=ids, device_calls=False), counts
+
+    def _groups(self, batches):
+        """The caller's batches, ``coalesce`` of them to a device batch (RequestBatch objects and the tail of the job: as they come)."""
+        group = []
+        for j, b in enumerate(batches):
+            if self.coalesce == 1 or isinstance(b[1], S.RequestBatch):
+                if group:
+                    yield group
+                    group = []
+                yield [(j, b)]
+                continue
+            group.append((j, b))
+            if len(group) == self.coalesce:
+                yield group
+                group = []
+        if group:
+            yield group
 
     def render_iter(self, batches, seed: int = 0, note_ids=None, pcm16: bool = False):
         """``batches``: an iterable of (sources, requests) — requests as a ``RequestBatch``, a list of ``Request`` or a list of
@@ -932,7 +970,7 @@ class PipelinedRenderer:
         ``write_wav`` computes on the host) — half the bytes over PCIe, which is what bounds a long job."""
         import collections
         import sys
-        it = iter(enumerate(batches))
+        it = iter(enumerate(self._groups(batches)))
         ahead = collections.deque()                           # futures of prepared batches, in order
         # the worker threads and this one hand the interpreter lock over every 0.1 ms while a job runs (the default 5 ms makes a
         # thread that is ready to launch the next step wait for a planner's whole Python stretch)
@@ -969,7 +1007,7 @@ class PipelinedRenderer:
             if ahead:
                 if self.trace is not None:
                     tw = time.perf_counter()
-                prep = ahead.popleft().result()
+                prep, counts = ahead.popleft().result()
                 if self.trace is not None:
                     self.trace.append(("wait_prepared", k, tw, time.perf_counter()))
                     tw = time.perf_counter()
@@ -1012,20 +1050,26 @@ class PipelinedRenderer:
                 home = self._ship_home(hb[:samples], mix, done)
                 if marks is not None:
                     marks.append(time.perf_counter())
-                flying.append((hb, home, prep, out, samples))
+                flying.append((hb, home, prep, out, samples, counts))
                 if self.trace is not None:
                     self.trace.append(("launch", k - 1, tw, time.perf_counter(), tuple(marks)))
             # one more batch in flight than there are lanes: batch k + 1 is queued behind batch k on the device before batch k - 1 is
             # home, so the device never waits for the host's launch (with `lanes` in flight it idled ~0.5 ms per batch: the launch
             # came after the previous audio's 1.8 ms trip home)
             if flying and (len(flying) >= len(self.lanes) + 1 or not ahead):
-                hb, home, prep, out, samples = flying.popleft()
+                hb, home, prep, out, samples, counts = flying.popleft()
                 if self.trace is not None:
                     tw = time.perf_counter()
                 home.synchronize()
                 if self.trace is not None:
                     self.trace.append(("wait_audio", -1, tw, time.perf_counter()))
-                yield hb[:samples].numpy(), prep["sample_off"]
+                if len(counts) == 1:
+                    yield hb[:samples].numpy(), prep["sample_off"]
+                else:                                          # the caller's batches of a coalesced device batch, one by one
+                    audio, off, a = hb[:samples].numpy(), prep["sample_off"], 0
+                    for c in counts:
+                        yield audio[off[a]:off[a + c]], off[a:a + c + 1] - off[a]
+                        a += c
                 del prep, out
         for ln in self.lanes:                                  # the device is idle now: what the asynchronous calls flagged
             ln["r"].ctx.check()

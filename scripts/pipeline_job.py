@@ -51,13 +51,27 @@ def _throttled():
         return 0, 0, 0
 print("cpu.max:", open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "-", " torch threads:", torch.get_num_threads())
 thr = [("setup", _throttled(), time.perf_counter())]
-pipe = PipelinedRenderer(0, depth=depth, workers=workers)
+coalesce = 1
+for a in sys.argv:
+    if a.startswith("--coalesce="):
+        coalesce = int(a.split("=")[1])
+pipe = PipelinedRenderer(0, depth=depth, workers=workers, coalesce=coalesce)
 for a in sys.argv:
     if a.startswith("--plan-threads="):
         for ln in pipe.lanes:
             ln["r"].plan_threads = int(a.split("=")[1])
 if "--trace" in sys.argv:
     pipe.trace = []
+phase_marks = []
+if "--phases" in sys.argv:
+    import threading
+
+    class _Marks(list):
+        def append(self, m):
+            list.append(self, (m[0], m[1], threading.get_ident()))
+    for ln in pipe.lanes:
+        ln["r"].trace_prepare = _Marks()
+        phase_marks.append(ln["r"].trace_prepare)
 ids = list(range(1024))
 stamps = []
 allocs = []
@@ -91,3 +105,20 @@ if trace:
         print("slow launch of batch %d: plan/reserve %.2f, run %.2f, pcm16 + event %.2f, copy home queued %.2f ms" % ((e[1],) + tuple(1e3 * (b - a) for a, b in zip(m, m[1:]))))
         over = [(p[1], 1e3 * (max(p[2], e[2]) - e[2]), 1e3 * (min(p[3], e[3]) - e[2])) for p in trace if p[0] == "prepare" and p[3] > e[2] and p[2] < e[3]]
         print("   prepares running meanwhile (batch, from, to ms within the launch):", over)
+
+if "--phases" in sys.argv:
+    # Renderer.prepare's phases on the worker threads while the job runs (marks tagged with their thread)
+    import collections
+    acc, cnt = collections.OrderedDict(), 0
+    for ln_marks in phase_marks:
+        by_thread = collections.defaultdict(list)
+        for label, t, ident in ln_marks:
+            by_thread[ident].append((label, t))
+        for seq in by_thread.values():
+            for (a, ta), (b, tb) in zip(seq, seq[1:]):
+                if b == "start":
+                    cnt += 1
+                    continue
+                acc[b] = acc.get(b, 0.0) + (tb - ta)
+    cnt = max(cnt, 1)
+    print("prepare phases on the worker threads, mean ms over %d batches: %s" % (cnt, ", ".join("%s %.2f" % (k, 1e3 * v / cnt) for k, v in acc.items())))

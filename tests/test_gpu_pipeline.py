@@ -41,8 +41,9 @@ def test_pipelined_batches_equal_single_batches(config, sizes):
             want.append(r.render(list(zip(srcs, reqs)), seed=11))
     finally:
         ctx.close()
-    for depth, workers in ((2, 2), (1, 1), (3, 1)):
-        p = PipelinedRenderer(0, hop=geo["hop"], depth=depth, workers=workers)
+    # (coalesce: two / four of the caller's batches as one device batch, handed back one by one with the ids of their own batch)
+    for depth, workers, coalesce in ((2, 2, 1), (1, 1, 1), (3, 1, 1), (2, 3, 2), (2, 2, 4)):
+        p = PipelinedRenderer(0, hop=geo["hop"], depth=depth, workers=workers, coalesce=coalesce)
         try:
             got = p.render_all(batches, seed=11)
         finally:
@@ -51,7 +52,7 @@ def test_pipelined_batches_equal_single_batches(config, sizes):
         for b, (g, w) in enumerate(zip(got, want)):
             assert len(g) == len(w)
             for i, (a, c) in enumerate(zip(g, w)):
-                assert np.array_equal(a, c), (depth, b, i)
+                assert np.array_equal(a, c), (depth, coalesce, b, i)
 
 
 def test_prepare_from_columns_equals_prepare_from_requests():
