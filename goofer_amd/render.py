@@ -948,14 +948,19 @@ class PipelinedRenderer:
 
     def _groups(self, batches):
         """The caller's batches, ``coalesce`` of them to a device batch (RequestBatch objects and the tail of the job: as they come)."""
-        group = []
+        group, geom = [], None
         for j, b in enumerate(batches):
-            if self.coalesce == 1 or isinstance(b[1], S.RequestBatch):
+            if self.coalesce == 1 or isinstance(b[1], S.RequestBatch) or not len(b[0]):
                 if group:
                     yield group
                     group = []
                 yield [(j, b)]
                 continue
+            g = (b[0][0].sr, b[0][0].n_fft)                    # (a device batch shares sr / n_fft: batches of another geometry start a new one)
+            if group and g != geom:
+                yield group
+                group = []
+            geom = g
             group.append((j, b))
             if len(group) == self.coalesce:
                 yield group
