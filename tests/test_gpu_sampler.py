@@ -171,6 +171,40 @@ def test_baseline_config_notes_vs_oracle(config, ids):
         ctx.close()
 
 
+@pytest.mark.parametrize("config,ids", [(3, range(1024)), (4, range(0, 10000, 10)), (5, range(0, 1024, 16))])
+def test_whole_batches_of_the_baseline_configs_vs_oracle(config, ids):
+    """All 1024 notes of BASELINE config 3 — the batch the headline number is quoted on —, every tenth note of config 4's 10 000-note
+    job and every sixteenth of config 5's batch, each set rendered as ONE device batch against the CPU oracle's render of each
+    note, same injected phases: every note within the 2e-5 bound (worst and mean printed).  ~20 s of oracle time per set on one core."""
+    from goofer_amd.device import Context
+    from goofer_amd.render import Renderer, Source
+    from goofer_amd import sampler as S
+    from oracle import sampler_ref as SR
+    geo = syn.config_geometry(config)
+    ctx = Context(0)
+    try:
+        r = Renderer(ctx, hop=geo["hop"])
+        jobs, refs, seeds = [], [], []
+        for i in ids:
+            src, req, phi_seed = syn.config_note(config, i)
+            jobs.append((Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]),
+                         S.decode_request(*syn.request_args(req))))
+            feats = (src["env_pack"], src["f0"].copy(), src["mask"].copy(), {k: v.copy() for k, v in src["formants"].items()},
+                     src["sr"], src["y_len"])
+            refs.append(SR.render(feats, SR.decode_request(*syn.request_args(req)), seed=phi_seed, n_fft=geo["n_fft"], hop=geo["hop"]))
+            seeds.append(phi_seed)
+        outs = r.render(jobs, phi_seeds=seeds)
+        errs = []
+        for i, (o, ref) in enumerate(zip(outs, refs)):
+            assert o.shape == ref.shape, i
+            errs.append(rms_err(o, ref) / max(1.0, float(np.max(np.abs(ref)))))
+        errs = np.asarray(errs)
+        assert errs.max() < 2e-5, (config, int(errs.argmax()), float(errs.max()), float(errs.mean()))
+        print("config %d, %d notes vs oracle: worst %.3g (position %d), mean %.3g" % (config, errs.size, errs.max(), int(errs.argmax()), errs.mean()))
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("config", [3, 4])
 def test_render_batch_equals_separate_calls(config):
     """goofer_render_batch (pulse chain forked as soon as the assembled f0 exists) against goofer_assemble_batch followed by
