@@ -283,6 +283,77 @@ __device__ __forceinline__ void radix8_pass(float2 *buf, const float2 *tw, int l
     wave_lds_sync();
 }
 
+// The 8 x 8 transpose between a lane's register index and bits 3..5 of its lane id — x[t] of lane (h, lo) <-> x[h] of lane
+// (t, lo) — in registers: v_permlane32_swap (lane bit 5), v_permlane16_swap (bit 4), DPP row_ror:8 under bank masks (bit 3);
+// each step swaps "a in the lanes with the bit set" with "b in the lanes with it clear".  32 vector instructions for eight
+// float2 per lane, no LDS (checked on the device: scripts/micro/lane_transpose.hip).
+__device__ __forceinline__ void swap_lane32(float &a, float &b)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_lane16(float &a, float &b)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_lane8(float &a, float &b)
+{
+    const int ai = __float_as_int(a), bi = __float_as_int(b);
+    const int na = __builtin_amdgcn_update_dpp(ai, bi, 0x128, 0xf, 0xc, false);   // row_ror:8 into lanes 8..15 of each row
+    const int nb = __builtin_amdgcn_update_dpp(bi, ai, 0x128, 0xf, 0x3, false);   // ... into lanes 0..7
+    a = __int_as_float(na);
+    b = __int_as_float(nb);
+}
+__device__ __forceinline__ void transpose_reg_lanehi(float2 (&x)[8])
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { swap_lane32(x[t].x, x[t + 4].x); swap_lane32(x[t].y, x[t + 4].y); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int t = (q & 1) | ((q & 2) << 1);                // 0, 1, 4, 5
+        swap_lane16(x[t].x, x[t + 2].x);
+        swap_lane16(x[t].y, x[t + 2].y);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) { swap_lane8(x[t].x, x[t + 1].x); swap_lane8(x[t].y, x[t + 1].y); }
+}
+
+// Pass 0's output to pass 1's butterflies without LDS, for 8 or 16 points per lane (M = 512 / 1024), then pass 1 itself
+// (radix8_pass<M, R>: same twiddles, same butterfly, same stores).  Pass 0 leaves y[R l + t] in register t of lane l; butterfly b
+// of pass 1 wants y[b + t' M / 8], t' < 8, i.e. register b % R of the lanes (t', b / R) — eight lanes that differ in their top
+// digit only — so after transpose_reg_lanehi on registers 8 g .. 8 g + 7, lane (s, lo) holds the inputs of butterfly
+// b = R lo + 8 g + s.  Every value goes through the same operations as in radix8_pass (bit-identical; the next exchange, through
+// LDS, puts the points back in order); 32 vector instructions per eight points instead of 16 LDS instructions, a barrier
+// and an LDS round trip.
+template <int M>
+__device__ __forceinline__ void pass1_regx(const float2 *v, float2 *buf, const float2 *tw, int lane)
+{
+    constexpr int R = fft_cfg<M>::R, STEP = M / (8 * R);
+    static_assert(R == 8 || R == 16, "eight-register groups");
+    const int s = lane >> 3, lo = lane & 7;
+#pragma unroll
+    for (int g = 0; g < R / 8; ++g) {
+        float2 x[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = v[8 * g + t];
+        transpose_reg_lanehi(x);
+        const int k = 8 * g + s;                               // b % R
+#pragma unroll
+        for (int t = 1; t < 8; ++t) x[t] = cmul(x[t], tw[tw_wrap<M>(t * k * STEP)]);
+        dft<8>::run(x);
+        const int j0 = lo * R * 8 + k;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) buf[lds_pad(j0 + t * R)] = x[t];
+    }
+    wave_lds_sync();
+}
+// (16 points per lane, n_fft 2048: measured no faster — k_irfft_ola1<1024> 8.93 -> 9.01 ms, eight more spilled registers in a kernel
+// that already holds 256 — so only the eight-point sizes take it)
+template <int M> constexpr bool fft_regx = fft_cfg<M>::R == 8;
+
 // Complex forward FFT of size M for one wave.  `v` holds x[lane + 64 t], t < R on entry; the result
 // is left in natural order in `buf` (padded).
 template <int M>
@@ -290,10 +361,14 @@ __device__ __forceinline__ void wave_fft(float2 *v, float2 *buf, const float2 *t
 {
     constexpr int R = fft_cfg<M>::R;
     dft<R>::run(v);                       // pass 0: NS = 1, no twiddle, y[lane*R + t]
+    if constexpr (fft_regx<M>) {
+        pass1_regx<M>(v, buf, tw, lane);
+    } else {
 #pragma unroll
-    for (int t = 0; t < R; ++t) buf[lds_pad(lane * R + t)] = v[t];
-    wave_lds_sync();
-    radix8_pass<M, R>(buf, tw, lane);
+        for (int t = 0; t < R; ++t) buf[lds_pad(lane * R + t)] = v[t];
+        wave_lds_sync();
+        radix8_pass<M, R>(buf, tw, lane);
+    }
     radix8_pass<M, R * 8>(buf, tw, lane);
     static_assert(R * 64 == M, "M must be 64 * first radix");
 }
@@ -307,10 +382,14 @@ __device__ __forceinline__ void wave_fft_keep(float2 *v, float2 *buf, const floa
     static_assert(M >= 512, "the last pass needs at least 64 butterflies");
     constexpr int R = fft_cfg<M>::R, NB = M / 8, PER = NB / WAVE;
     dft<R>::run(v);
+    if constexpr (fft_regx<M>) {
+        pass1_regx<M>(v, buf, tw, lane);
+    } else {
 #pragma unroll
-    for (int t = 0; t < R; ++t) buf[lds_pad(lane * R + t)] = v[t];
-    wave_lds_sync();
-    radix8_pass<M, R>(buf, tw, lane);
+        for (int t = 0; t < R; ++t) buf[lds_pad(lane * R + t)] = v[t];
+        wave_lds_sync();
+        radix8_pass<M, R>(buf, tw, lane);
+    }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int b = lane + WAVE * u;
@@ -348,12 +427,33 @@ __device__ __forceinline__ void fill_tw_tabs(float2 *tw1, float2 *tw2, const flo
         tw2[i] = tw[(t * b) & (M - 1)];
     }
 }
-template <int M>
+// REGX (the default): the exchange between pass 0 and pass 1 runs in registers.  Pass 0 leaves y[8 l + t] in register t of lane
+// l; butterfly b of pass 1 wants y[b + 64 t], i.e. register b % 8 of the lanes (t, b / 8) — eight lanes that differ in their top
+// digit only — so after transpose_reg_lanehi lane (b % 8, b / 8) holds exactly butterfly b's inputs: the lane runs butterfly
+// b = 8 (lane % 8) + lane / 8 instead of b = lane.  Same values through the same operations (bit-identical: the other
+// exchange, through LDS, puts everything back in order), 32 vector instructions for 16 LDS instructions, a barrier and an LDS
+// round trip; and pass 1's stores, now 64 (lane % 8) + lane / 8 + 8 t, fall on 32 different banks per 16 lanes where
+// 64 (lane / 8) + lane % 8 + 8 t took two turns.
+template <int M, bool REGX = true>
 __device__ __forceinline__ void wave_fft_keep_tab(float2 *v, float2 *buf, const float2 *tw1, const float2 *tw2, int lane, float2 *out)
 {
     static_assert(M == 512, "one butterfly per lane and pass");
     constexpr int R = fft_cfg<M>::R, NB = M / 8;
     dft<R>::run(v);
+    if constexpr (REGX) {
+        float2 x[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = v[t];
+        transpose_reg_lanehi(x);
+        const int k = lane >> 3;                               // b % 8 of this lane's butterfly
+#pragma unroll
+        for (int t = 1; t < 8; ++t) x[t] = cmul(x[t], tw1[(t - 1) * 8 + k]);
+        dft<8>::run(x);
+        const int j0 = (lane & 7) * R * 8 + k;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) buf[lds_pad(j0 + t * R)] = x[t];
+        wave_lds_sync();
+    } else {
 #pragma unroll
     for (int t = 0; t < R; ++t) buf[lds_pad(lane * R + t)] = v[t];
     wave_lds_sync();
@@ -370,6 +470,7 @@ __device__ __forceinline__ void wave_fft_keep_tab(float2 *v, float2 *buf, const 
 #pragma unroll
         for (int t = 0; t < 8; ++t) buf[lds_pad(j0 + t * R)] = x[t];
         wave_lds_sync();
+    }
     }
     float2 x[8];
 #pragma unroll
@@ -389,7 +490,7 @@ __device__ __forceinline__ void fft_lane_twiddles(const float2 *tw, int lane, fl
 {
     static_assert(M == 512, "one butterfly per lane and pass");
     constexpr int R = fft_cfg<M>::R;
-    const int k1 = lane % R;                                  // pass 1: NS = R, twiddle exp(-2 pi i t k / (8 R))
+    const int k1 = lane >> 3;                                 // pass 1: NS = R, twiddle exp(-2 pi i t k / (8 R)), k = b % 8 of the lane's butterfly b = 8 (lane % 8) + lane / 8 (pass1_regx)
 #pragma unroll
     for (int t = 1; t < 8; ++t) {
         tw1[t - 1] = tw[(t * k1 * (M / (8 * R))) & (M - 1)];
@@ -403,18 +504,15 @@ __device__ __forceinline__ void wave_fft_keep_tw(float2 *v, float2 *buf, const f
     static_assert(M == 512, "one butterfly per lane and pass");
     constexpr int R = fft_cfg<M>::R, NB = M / 8;
     dft<R>::run(v);
-#pragma unroll
-    for (int t = 0; t < R; ++t) buf[lds_pad(lane * R + t)] = v[t];
-    wave_lds_sync();
-    {   // pass 1 (NS = R): reads x[b + t NB], writes y[(b / NS) NS 8 + b % NS + t NS]
+    {   // pass 1 (NS = R) on butterfly b = 8 (lane % 8) + lane / 8, its inputs through the register transpose (pass1_regx)
         float2 x[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] = buf[lds_pad(lane + t * NB)];
-        wave_lds_sync();
+        for (int t = 0; t < 8; ++t) x[t] = v[t];
+        transpose_reg_lanehi(x);
 #pragma unroll
         for (int t = 1; t < 8; ++t) x[t] = cmul(x[t], tw1[t - 1]);
         dft<8>::run(x);
-        const int j0 = (lane / R) * R * 8 + lane % R;
+        const int j0 = (lane & 7) * R * 8 + (lane >> 3);
 #pragma unroll
         for (int t = 0; t < 8; ++t) buf[lds_pad(j0 + t * R)] = x[t];
         wave_lds_sync();
