@@ -427,20 +427,15 @@ __device__ __forceinline__ void fill_tw_tabs(float2 *tw1, float2 *tw2, const flo
         tw2[i] = tw[(t * b) & (M - 1)];
     }
 }
-// REGX (the default): the exchange between pass 0 and pass 1 runs in registers.  Pass 0 leaves y[8 l + t] in register t of lane
-// l; butterfly b of pass 1 wants y[b + 64 t], i.e. register b % 8 of the lanes (t, b / 8) — eight lanes that differ in their top
-// digit only — so after transpose_reg_lanehi lane (b % 8, b / 8) holds exactly butterfly b's inputs: the lane runs butterfly
-// b = 8 (lane % 8) + lane / 8 instead of b = lane.  Same values through the same operations (bit-identical: the other
-// exchange, through LDS, puts everything back in order), 32 vector instructions for 16 LDS instructions, a barrier and an LDS
-// round trip; and pass 1's stores, now 64 (lane % 8) + lane / 8 + 8 t, fall on 32 different banks per 16 lanes where
-// 64 (lane / 8) + lane % 8 + 8 t took two turns.
-template <int M, bool REGX = true>
+// The first exchange runs in registers (pass1_regx above, with the pass's twiddles from their own table): the lane runs butterfly
+// b = 8 (lane % 8) + lane / 8 of pass 1, whose stores 64 (lane % 8) + lane / 8 + 8 t fall on 32 different banks per 16 lanes.
+template <int M>
 __device__ __forceinline__ void wave_fft_keep_tab(float2 *v, float2 *buf, const float2 *tw1, const float2 *tw2, int lane, float2 *out)
 {
     static_assert(M == 512, "one butterfly per lane and pass");
     constexpr int R = fft_cfg<M>::R, NB = M / 8;
     dft<R>::run(v);
-    if constexpr (REGX) {
+    {
         float2 x[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) x[t] = v[t];
@@ -453,24 +448,6 @@ __device__ __forceinline__ void wave_fft_keep_tab(float2 *v, float2 *buf, const 
 #pragma unroll
         for (int t = 0; t < 8; ++t) buf[lds_pad(j0 + t * R)] = x[t];
         wave_lds_sync();
-    } else {
-#pragma unroll
-    for (int t = 0; t < R; ++t) buf[lds_pad(lane * R + t)] = v[t];
-    wave_lds_sync();
-    {   // pass 1 (NS = R): reads x[b + t NB], writes y[(b / NS) NS 8 + b % NS + t NS]
-        float2 x[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] = buf[lds_pad(lane + t * NB)];
-        wave_lds_sync();
-        const int k = lane % R;
-#pragma unroll
-        for (int t = 1; t < 8; ++t) x[t] = cmul(x[t], tw1[(t - 1) * 8 + k]);
-        dft<8>::run(x);
-        const int j0 = (lane / R) * R * 8 + k;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) buf[lds_pad(j0 + t * R)] = x[t];
-        wave_lds_sync();
-    }
     }
     float2 x[8];
 #pragma unroll
