@@ -326,7 +326,7 @@ static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t sampl
     add(notes * sizeof(int32_t) + 64);            // onset counts
     add(64);                                      // overflow flag
     add(samples * sizeof(float));                 // pulse
-    add((samples / 1024 + 64) * sizeof(int32_t)); // pulse placement: 4 ints per 4096-sample tile
+    add((size_t)PULSE_TILE_INTS(samples) * sizeof(int32_t)); // pulse placement: 4 ints per tile
     if (spectra == 1) {
         add(3 * frames * ldc * sizeof(float2));       // S_h, S_uv, S_br
         add(3 * frames * (size_t)p.n_fft * sizeof(float));  // windowed time frames (three stems in the fused path)
@@ -941,7 +941,7 @@ int goofer_pulse_train(goofer_ctx *ctx, const float *f0, const int64_t *sample_o
     int rc = ensure_scratch(ctx, need);
     if (rc) return rc;
     arena a{(char *)ctx->scratch, ctx->scratch_bytes, 0};
-    double *inc = a.take<double>(total_samples);
+    double *inc = a.take<double>(total_samples + 16);          // (also holds the placement's tile table: 16 bytes per 256 * PP_SPT samples)
     char *onsets = a.take<char>((total_samples / 2 + 16 * (size_t)n_notes + 16) * ONSET_BYTES);
     int32_t *oidx = a.take<int32_t>(total_samples / 2 + 16 * (size_t)n_notes + 16);
     int32_t *cnt = a.take<int32_t>(n_notes + 16);
@@ -1395,7 +1395,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     int32_t *onset_cnt = a.take<int32_t>(n + 16);
     int32_t *ovf = ctx->ovf_flag;
     float *pulse = a.take<float>(N);
-    int32_t *pulse_tiles = a.take<int32_t>(N / 1024 + 64);
+    int32_t *pulse_tiles = a.take<int32_t>((size_t)PULSE_TILE_INTS(N));
     const size_t spec_n = (walkers || ring_path) ? 0 : (size_t)F * ldc, frame_n = (walkers || ring_path) ? 0 : (size_t)F * p.n_fft;
     float2 *S_h = a.take<float2>(spec_n);
     float2 *S_uv = a.take<float2>(spec_n);

@@ -660,17 +660,17 @@ __global__ __launch_bounds__(256) void k_env_rows(const goofer_assembly a, int64
     const bool stage1 = (flags & ER_STAGE1) != 0, stage2 = (flags & ER_STAGE2) != 0;
     const bool fast1 = warp_on && stage1 && (flags & ER_SORTED) != 0;
     constexpr int CHS = (CH > 0 && CH <= 18) ? CH : 1;
-    warp_seg_f32 as[CHS];                                    // segment record of the lane's bin in every chunk (sorted-anchor warp)
+    constexpr int NWS = (CHS + 8) / 9;
+    uint32_t jws[NWS] = {0};                                 // packed segment index of the lane's bin in every chunk (sorted-anchor warp)
+    __shared__ __align__(16) float s_rec[A_ROWS][24];                      // ... and the row's six segment records, staged once per row
     if constexpr (CH > 0 && CH <= 18) {
-        // ... read per lane from the row's record (16-byte loads that hit the lines the scalar loads brought in), with the
-        // row's other loads: behind the row's stores they would wait for those to be acknowledged (one counter, in order)
+        // the records come in with the row's other loads (behind the row's stores they would wait for those to be acknowledged: one
+        // counter, in order): one dword per lane into LDS, read back per bin where the lerp wants them — per-lane copies of every
+        // chunk's record were 27 registers held across the row (96 VGPRs, five waves per SIMD)
         if (fast1) {
-            constexpr int NW = (CH + 8) / 9;
-            uint32_t jw[NW];
             const int tk[5] = {rc.thr[0], rc.thr[1], rc.thr[2], rc.thr[3], rc.thr[4]};
-            warp_seg_words<NW>(tk, lane, jw);
-#pragma unroll
-            for (int c = 0; c < CH; ++c) as[c] = rc.seg[warp_seg_at<NW>(jw, c)];
+            warp_seg_words<NWS>(tk, lane, jws);
+            if (lane < 24) s_rec[wave][lane] = reinterpret_cast<const float *>(rc.seg)[lane];
         }
     }
     if constexpr (CH > 0) {
@@ -753,7 +753,8 @@ __global__ __launch_bounds__(256) void k_env_rows(const goofer_assembly a, int64
                 for (int c = 0; c < CH; ++c) {
                     const int b = lane + WAVE * c;
                     const float bf = (float)b;
-                    u[c] = (c < CH - 1 || b < B) ? warp_lerp_f32(ra, b, bf, __builtin_fmaf(as[c < CHS ? c : 0].s, bf - as[c < CHS ? c : 0].c, as[c < CHS ? c : 0].d), topf) : 0.f;
+                    const warp_seg_f32 as = *reinterpret_cast<const warp_seg_f32 *>(&s_rec[wave][4 * warp_seg_at<NWS>(jws, c < CHS ? c : 0)]);
+                    u[c] = (c < CH - 1 || b < B) ? warp_lerp_f32(ra, b, bf, __builtin_fmaf(as.s, bf - as.c, as.d), topf) : 0.f;
                 }
                 if (stage2) {
 #pragma unroll

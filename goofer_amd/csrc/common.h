@@ -11,13 +11,17 @@
 #define WAVE 64
 #define PROF_STAGES 18
 #define PROF_ASM0 15           // profile stages 15..17: the assembly's k_env_edit, k_env_rows / k_env_loop, k_sample_assemble
-#define PULSE_TAB_MAX 2048     // pulse lengths served from the shape table (f0 >= sr/2048); longer ones are evaluated on the fly
+#define PP_SPT 8                // k_pulse_place: consecutive samples per thread; a tile = one workgroup = 256 * PP_SPT samples
+#define PULSE_TILE_INTS(samples) (4 * (((samples) + 256 * PP_SPT - 1) / (256 * PP_SPT)) + 64)   // k_pulse_tiles' table: 4 ints per tile
+#define PULSE_TAB_MAX 8192     // pulse lengths served from the shape table: all of them (the reference caps T0 at 8192, GOOFER.py:497-498) — 134 MB of
+                               // a 288 GB device; until late in round 5 the table ended at 2048 and k_pulse_place evaluated longer pulses on the fly, whose
+                               // fp64 sin / exp / cos set the kernel's registers (115, four waves per SIMD) though no note of the workloads reached them
 
 // the LF glottal-pulse model of gf.pulse_train_numba (GOOFER.py:474, 508): its keyword arguments, defaults = what gf.synthesize passes
 struct lf_model {
     double ra = 0.02, rg = 1.7, rk = 0.8;
 };
-#define PULSE_PEAK_FLOATS (8193 + 1 + 6)   // k_pulse_peak's table + the model's three doubles behind it (8-byte aligned), for k_pulse_place's rare on-the-fly path
+#define PULSE_PEAK_FLOATS (8193 + 1 + 6)   // k_pulse_peak's table + the model's three doubles behind it (8-byte aligned; goofer_debug_table, tests)
 
 struct goofer_plan_t {
     int sr = 0, n_fft = 0, hop = 0, n_bins = 0;

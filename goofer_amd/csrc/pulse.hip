@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void k_pulse_peak(float *__restrict__ peak, do
 // The normalised pulse of length T0, tabulated at the nominal period T = T0/sr.  The LF shape depends on the period
 // only through ratios (ti/Tp = k / (Ra T0), tau = (k/T0 - Ra) / (Rk (1 - Ra))), so an onset's true period
 // 1/f0 moves the fp64 value by ~1e-11 relative (the 1e-12 guards) — below fp32 resolution except on rare ties.
-__device__ __forceinline__ int64_t pulse_tab_row(int T0) { return (int64_t)T0 * (T0 - 1) / 2 - 3; }
+static_assert((int64_t)PULSE_TAB_MAX * (PULSE_TAB_MAX + 1) / 2 < (1ll << 31), "32-bit row offsets");
+__device__ __forceinline__ int pulse_tab_row(int T0) { return T0 * (T0 - 1) / 2 - 3; }
 
 __global__ __launch_bounds__(256) void k_pulse_shape_table(float *__restrict__ tab, const float *__restrict__ peak, double sr, const lf_model lf)
 {
@@ -669,20 +670,15 @@ __global__ __launch_bounds__(64) void k_onset_finish(const float *__restrict__ f
 // the last onset starting inside the tile — are staged once in LDS; every sample then scans that short
 // list in ascending onset order (the reference's accumulation order).  Other tiles (note boundaries, or
 // more onsets than the LDS list holds) take the per-sample search of the compact list in global memory.
-#define PP_SPT 16
+// PP_SPT (common.h): eight — 48 registers, eight waves per SIMD, 0.135 -> 0.113 ms against sixteen (87 registers, five waves)
+// once the on-the-fly pulses had left the kernel (with them it held 115 registers either way and sixteen was the faster)
 #define PP_MAXON 512
 
 __device__ __forceinline__ float pulse_value(const onset_t &o, int j, const float *__restrict__ peak, const float *__restrict__ tab)
 {
     const int d = j - o.i;
     if (d < 0 || d >= o.T0) return 0.f;
-    if (o.T0 <= PULSE_TAB_MAX) return tab[pulse_tab_row(o.T0) + d];
-    const double *tail = reinterpret_cast<const double *>(peak + 8194);
-    lf_model lf;
-    lf.ra = tail[0]; lf.rg = tail[1]; lf.rk = tail[2];
-    const float raw = lf_raw(d, o.T0, o.T, lf);
-    const double m = (double)peak[o.T0];
-    return m > 0.0 ? (float)((double)raw / m) : raw;
+    return tab[pulse_tab_row(o.T0) + d];                      // (T0 <= PULSE_TAB_MAX = the cap of the onset kernels)
 }
 
 // Which onsets can touch which tile, once per tile instead of once per workgroup through two rounds of note search, a count over
@@ -798,7 +794,7 @@ __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__
             while (first > 0 && s_on[first - 1].end_max > j) --first;
             for (int k = first; k <= lo; ++k) {                                  // ascending onsets: the reference's order
                 const onset_t o = s_on[k];
-                if (o.T0 <= PULSE_TAB_MAX) {
+                {
                     // the eight table values first (index clamped into the pulse), then the range test as a select: the loads of
                     // a thread's samples are in flight together instead of one round trip per sample behind its own branch
                     const float *__restrict__ row = tab + pulse_tab_row(o.T0);
@@ -814,9 +810,6 @@ __global__ __launch_bounds__(256) void k_pulse_place(const onset_t *__restrict__
                         const int d = d0 + e;
                         acc[e] += (d < 0 || d >= o.T0) ? 0.f : tv[e];
                     }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < PP_SPT; ++e) acc[e] += pulse_value(o, j + e, peak, tab);
                 }
             }
         }
