@@ -329,8 +329,10 @@ __host__ __device__ static inline int noise_spectra_wave_f2(int n_bins, bool sha
 // reg_blur (decided by the launcher): the sigma-1.75 blur runs in registers (below); the fp32 row then shares its LDS with the
 // complex row of the 5-tap blur — the two are never live together on that path — and a workgroup takes 33 KB instead of 49 KB at
 // n_fft 2048 (four per CU instead of three).
-template <int ITERS, bool NT, bool PHI>
-__global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 3) void k_noise_spectra(float2 *__restrict__ S_uv, float2 *__restrict__ S_br, int ldc,
+// RB: reg_blur_ok as a template parameter — the LDS version of the blur, compiled beside the register one, cost the kernel 30
+// registers it never used (ITERS 17: 144 -> 114, three -> four waves per SIMD; ITERS 9: 96 -> 62, five -> eight)
+template <int ITERS, bool NT, bool PHI, bool RB>
+__global__ __launch_bounds__(256, (ITERS <= 9 || RB) ? 4 : 3) void k_noise_spectra(float2 *__restrict__ S_uv, float2 *__restrict__ S_br, int ldc,
                                                        int64_t total_frames, const int *__restrict__ frame_note,
                                                        const int64_t *__restrict__ frame_off, const int64_t *__restrict__ sample_off,
                                                        const float *__restrict__ f0, const float *__restrict__ mask,
@@ -339,9 +341,9 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 3) void k_noise_spectra(float
                                                        const float *__restrict__ freqs, const float *__restrict__ bright,
                                                        const double *__restrict__ taps5, int n_bins, int hop,
                                                        const int64_t *__restrict__ row_src, const double *__restrict__ taps175,
-                                                       const float2 *__restrict__ picks, const unsigned char *__restrict__ frame_skip,
-                                                       int reg_blur_ok)
+                                                       const float2 *__restrict__ picks, const unsigned char *__restrict__ frame_skip)
 {
+    constexpr int reg_blur_ok = RB ? 1 : 0;
     // env_noise is either the already-blurred [frames x ld] matrix (row_src == nullptr) or the source rows, in
     // which case the sigma-1.75 bin blur (GOOFER.py:993) runs here from the LDS row.
     extern __shared__ __align__(16) unsigned char smem[];
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 3) void k_noise_spectra(float
     const float *er = env_noise + src * (int64_t)ld;
     float ev[ITERS], br[ITERS], ph[PHI ? ITERS : 1];
     const float fq0 = freqs[lane], fq64 = freqs[n_bins > WAVE ? WAVE : 0];
-    if (!reg_blur_ok) {                                      // (the register blur loads the row in its own layout)
+    if constexpr (!RB) {                                     // (the register blur loads the row in its own layout)
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
             const int k = lane + WAVE * i;
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 3) void k_noise_spectra(float
     constexpr int NB = ITERS - 1;
     const bool reg_blur = do_blur && reg_blur_ok != 0;      // (the launcher checked: 64 NB + 1 bins, 16-byte aligned rows)
     bool blurred = false;
-    if constexpr (NB == 8 || NB == 16) {
+    if constexpr (RB && (NB == 8 || NB == 16)) {
         if (reg_blur) {
             float x[NB + 16];
 #pragma unroll
@@ -451,13 +453,15 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 3) void k_noise_spectra(float
             blurred = true;
         }
     }
-    if (do_blur && !blurred) {
+    if constexpr (!RB) {
+        if (do_blur && !blurred) {
 #pragma unroll
-        for (int i = 0; i < ITERS; ++i) {
-            const int k = lane + WAVE * i;
-            if (k < n_bins) ra[k] = ev[i];
+            for (int i = 0; i < ITERS; ++i) {
+                const int k = lane + WAVE * i;
+                if (k < n_bins) ra[k] = ev[i];
+            }
+            wave_lds_sync();
         }
-        wave_lds_sync();
     }
     // (the brightness curve after the blur: behind it the row's registers are free again)
 #pragma unroll
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(256, ITERS <= 9 ? 4 : 3) void k_noise_spectra(float
             s = __builtin_amdgcn_sinf(rev);
         }
         float e;
-        if (do_blur && !blurred) {
+        if (!RB && do_blur && !blurred) {
             // sigma-1.75 blur of the envelope row (GOOFER.py:993): the reference accumulates in fp64 and the product with
             // the unit phasor is rounded to complex64; fp32 FMAs in tap order stay within ~2e-7 relative
             float acc;
@@ -535,10 +539,19 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
     const int reg_blur = (row_src && !preblurred && (chunks0 == 9 || chunks0 == 17) && pl.n_bins == WAVE * (chunks0 - 1) + 1 && (ld & 3) == 0 &&
                           (((uintptr_t)env_noise) & 15) == 0) ? 1 : 0;
     const size_t lds = sizeof(float2) * ROWS_PER_BLOCK * noise_spectra_wave_f2(pl.n_bins, reg_blur != 0);
-#define NOISE_SPECTRA_P(IT, NT, PH)                                                                                                \
-    hipLaunchKernelGGL((k_noise_spectra<IT, NT, PH>), grid, dim3(256), lds, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,  \
+#define NOISE_SPECTRA_RB(IT, NT, PH, RBV)                                                                                          \
+    hipLaunchKernelGGL((k_noise_spectra<IT, NT, PH, RBV>), grid, dim3(256), lds, st, S_uv, S_br, ldc, total_frames, frame_note, frame_off,  \
                        sample_off, f0, mask, env_noise, phi, ld, params, seed, pl.freqs, pl.bright_b, pl.blur5, pl.n_bins, pl.hop, \
-                       row_src, preblurred ? (const double *)nullptr : pl.blur175, ctx->frame_picks, frame_skip, reg_blur)
+                       row_src, preblurred ? (const double *)nullptr : pl.blur175, ctx->frame_picks, frame_skip)
+#define NOISE_SPECTRA_P(IT, NT, PH)                                                                                                \
+    do {                                                                                                                           \
+        if constexpr (IT == 9 || IT == 17) {                                                                                       \
+            if (reg_blur) NOISE_SPECTRA_RB(IT, NT, PH, true);                                                                      \
+            else NOISE_SPECTRA_RB(IT, NT, PH, false);                                                                              \
+        } else {                                                                                                                   \
+            NOISE_SPECTRA_RB(IT, NT, PH, false);                                                                                   \
+        }                                                                                                                          \
+    } while (0)
 #define NOISE_SPECTRA(IT)                                                                                                          \
     do {                                                                                                                           \
         if (phi) {                                                                                                                 \
@@ -559,6 +572,7 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
     else return goofer_fail(ctx, GOOFER_EINVAL, "unsupported bin count %d", pl.n_bins);
 #undef NOISE_SPECTRA
 #undef NOISE_SPECTRA_P
+#undef NOISE_SPECTRA_RB
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }
