@@ -11,8 +11,12 @@ of synthetic notes already resident in HBM.  Notes are independent, so ranks sha
 `--notes` per GPU); the only collectives are the barriers and the MAX of the elapsed time.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      HIP-event duration of the longest kernel of the timed steps vs its algorithmic bytes; `traffic` (HBM bytes from the
-                committed counter passes) only when those passes were measured on this very source tree, else "stale": true
+  roofline      HIP-event duration of the longest kernel of the timed steps against its SURVEY 8(d) algorithmic bytes: `frac` is
+                that kernel's fraction of the 8 TB/s HBM peak; `traffic` (HBM bytes from the committed counter passes) only when
+                those passes were measured on this very source tree, else "stale": true; `valu`: its vector instructions per
+                second against 1024 SIMDs x one wave64 instruction per 2 cycles (SQ_INSTS_VALU of the same tree)
+  config4 / config5   BASELINE configs 4 (10 000 notes, mixed loop modes) and 5 (96 kHz, n_fft 2048, hop 96) as fixed jobs on
+                this GPU, after the timed region: value, ms per pass, sub-batches, their own roofline + roofline_step
   value_skip_zero_off / value_unvoiced_30pct   the same step with no transform skipped / on 30 %-unvoiced sources
   roofline_fft  the same for the framewise rFFT kernel (the kernel BASELINE's 40 % target names)
   roofline_step the whole step against its end-to-end algorithmic bytes and the HBM traffic the counter passes measured
@@ -36,6 +40,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured ceiling
+VALU_PEAK = 1024 * 2.4e9 / 2.0   # wave64 vector instructions/s: 1024 SIMDs, one per 2 cycles on the SIMD-32 (same guide)
 
 
 def stage_alg_bytes(stage: str, F: int, N: int, B: int, hop: int, n_fft: int, executed: float = 1.0, E: float = 0.0, K: int = 0) -> float:
@@ -79,27 +84,132 @@ STAGE_KERNEL = {"rfft_frames": "void k_rfft_frames<512>", "rfft_frames_standalon
                 "env_edit": "void k_env_edit<false, 9>", "env_rows": "void k_env_rows<true, 9>", "sample_assemble": "void k_sample_assemble<4>"}
 
 
+# kernel names of the fixed-job legs where they differ from the default step's (instantiations per row width / transform size)
+LEG_KERNEL = {4: {"env_rows": "void k_env_rows<false, 9>"},
+              5: {"rfft_frames": "void k_rfft_frames<1024, true>", "harm_shape": "void k_harm_shape<17, true>",
+                  "noise_spectra": "void k_noise_spectra<17, true, false, true>", "irfft_ola3": "void k_irfft_ola1<1024, 8>",
+                  "apply_gain": "k_note_finish", "env_edit": "void k_env_edit<false, 17>", "env_rows": "void k_env_rows<false, 17>"}}
+SHARED_WITH = {"noise_stems": "the tail of the pulse chain on the side stream (its time alone is a few percent lower)",
+               "noise_spectra": "the pulse chain on the side stream", "mask_short": "the pulse chain on the side stream",
+               "pulse_place": "the envelope gather / noise walker on the caller's stream",
+               "env_edit": "the f0 / mask kernel on the side stream", "env_rows": "the phase scan / pulse placement on the side stream",
+               "sample_assemble": "the envelope edit on the caller's stream"}
+
+
+def make_roof(per, Fb, Nb, B, hop, n_fft, executed, Eb, Kmax, pmc_frames, leg=None, counters=True):
+    """roof(stage) -> the `roofline` object of one kernel: SURVEY 8(d) algorithmic bytes of one launch / its HIP-event time
+    against the 8 TB/s HBM peak (`frac` is always this fraction), the counter-measured HBM bytes per launch (`traffic`) and the
+    vector-pipe figure (`valu`) from the committed passes of this very tree."""
+    def roof(stage, frames=None, samples=None):
+        frames = Fb if frames is None else frames
+        samples = Nb if samples is None else samples
+        ms = per[stage]
+        alg = stage_alg_bytes(stage, frames, samples, B, hop, n_fft, executed, E=Eb, K=Kmax)
+        a = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        kern = LEG_KERNEL.get(leg, {}).get(stage)
+        tr = pmc_traffic(stage, pmc_frames, leg, kern) if counters else {"bytes": None, "source": None, "stale": None}
+        valu = sq_valu_issue(stage, ms, pmc_frames, leg, kern) if counters else None
+        return {"kernel": stage, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": a / HBM_PEAK_GBS, "traffic": tr["bytes"], "traffic_source": tr["source"], "stale": tr["stale"],
+                "ms_per_launch": ms, "alg_bytes_per_launch": alg, "transforms_executed": executed if stage == "irfft_ola3" else None,
+                "shared_with": SHARED_WITH.get(stage), "valu": valu}
+    return roof
+
+
+def executed_share(ctx):
+    """share of the stem transforms the overlap-add kernel executed (configs with per-frame skipping: the last sub-batch's bits)"""
+    try:
+        fsk = ctx.debug_fetch("frame_skip")
+        if fsk.size:
+            return 1.0 - float(((fsk & 1) != 0).sum() + ((fsk & 2) != 0).sum()) / (3.0 * fsk.size)
+    except Exception:
+        pass
+    return 1.0
+
+
+def job_leg(local, config, job_notes, sub_batch, steps, warmup):
+    """One BASELINE fixed job (config 4: 10 000 notes with mixed loop modes; config 5: 96 kHz / n_fft 2048 / hop 96) on this GPU,
+    on a handle of its own: notes ordered by length into sub-batches, `warmup` untimed passes, `steps` timed passes (HIP events
+    around them + a device synchronise), then one bracketed pass for the stage times.  Returns the leg's object of the line."""
+    import torch
+    from goofer_amd import synthetic as syn
+    from goofer_amd.device import Context
+    from goofer_amd.workload import SamplerWorkload
+    ctx = Context(local)
+    try:
+        est = [syn.config_note_frames(config, i) for i in range(job_notes)]
+        ids = sorted(range(job_notes), key=lambda i: (-est[i], i))
+        subs = [SamplerWorkload(ctx, config, ids[k:k + sub_batch]) for k in range(0, len(ids), sub_batch)]
+        geo = subs[0].geo
+        B, hop, n_fft, sr = geo["n_fft"] // 2 + 1, geo["hop"], geo["n_fft"], geo["sr"]
+        frames, samples = sum(w.frames for w in subs), sum(w.samples for w in subs)
+
+        def one_pass():
+            out = None
+            for w in subs:
+                out = w.step()
+            return out
+
+        for _ in range(warmup):
+            one_pass()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = one_pass()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        mix = last["mix"]
+        assert bool(torch.isfinite(mix).all()) and float(mix.abs().max()) > 0.0, "the leg produced no valid audio"
+        ctx.profile_begin(len(subs))
+        one_pass()
+        prof = ctx.profile_end()
+        n = max(1, prof["steps"])
+        per = {k: v / n for k, v in prof["ms"].items()}
+        single = {k: v for k, v in per.items() if k not in MULTI_STAGES and v > 0} or per
+        dom = max(single, key=single.get)
+        Eb = sum(int(w.prep["assembly"].total_edit_rows) for w in subs) / len(subs)
+        Kmax = max(int(w.prep["assembly"].max_K) for w in subs)
+        roof = make_roof(per, frames / len(subs), samples / len(subs), B, hop, n_fft, executed_share(ctx), Eb, Kmax, frames, leg=config)
+        ms = elapsed / steps * 1e3
+        alg = (4 * B + 20 * hop) * frames
+        return {"workload": f"BASELINE config {config} as ONE fixed job of {job_notes} notes on 1 GPU, sub-batches of {sub_batch} notes "
+                            f"(longest first), sr {sr}, n_fft {n_fft}, hop {hop}; per-note flags {wl_flags(config)}",
+                "value": frames * steps / elapsed, "unit": "frames/s", "realtime_factor": frames * steps / elapsed * hop / sr,
+                "ms_per_step": ms, "steps": steps, "warmup": warmup, "sub_batches": len(subs), "notes": job_notes,
+                "frames": frames, "samples": samples, "stage_ms": per,
+                "stage_ms_from": "one bracketed pass after the timed ones: mean launch of every stage over the sub-batches",
+                "roofline": roof(dom),
+                "roofline_step": {"bound": "hbm", "alg_bytes_per_step": alg, "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_step_traffic(frames, config)}}
+    finally:
+        ctx.close()
+
+
 def _tree_hash():
     from goofer_amd.build import source_hash
     return source_hash()
 
 
-def _pmc_file():
-    """Newest committed rocprofv3 counter passes (profiles/<tag>_pmc_traffic.json, tags sort in time order)."""
+def _profile_file(kind, leg=None):
+    """Newest committed counter file of the default workload (profiles/<tag>_<kind>) or of a fixed-job leg (<tag>_c4_<kind>,
+    <tag>_c5_<kind>); tags sort in time order."""
     import glob
-    files = sorted(glob.glob(os.path.join(HERE, "profiles", "r*_pmc_traffic.json")))
+    import re
+    pat = re.compile(r"^r\d+[a-z]*_" + ("c%d_" % leg if leg else "") + re.escape(kind) + "$")
+    files = sorted(f for f in glob.glob(os.path.join(HERE, "profiles", "r*_" + kind)) if pat.match(os.path.basename(f)))
     return files[-1] if files else None
 
 
-def pmc_traffic(stage, frames):
+def pmc_traffic(stage, frames, leg=None, kernel=None):
     """{bytes, source, stale} from the newest committed rocprofv3 PMC passes of this same command (scripts/collect_profiles.sh),
     with the gfx950 FETCH_SIZE correction.  The counters cannot be read inside this process, so the figure is the committed
     measurement of a code tree, and only that tree's: the file carries the sha256 of goofer_amd/csrc it was measured on, and when
-    it differs from the tree being timed (or the workload size does) the bytes are withheld and `stale` is true."""
+    it differs from the tree being timed (or the workload size does) the bytes are withheld and `stale` is true.  Per launch:
+    a fixed job's kernels are launched once per sub-batch, and the file holds their mean launch."""
     try:
-        fn = _pmc_file()
+        fn = _profile_file("pmc_traffic.json", leg)
         d = json.load(open(fn))
-        k = d["kernels"][STAGE_KERNEL[stage]]
+        k = d["kernels"][kernel or STAGE_KERNEL[stage]]
         src = os.path.basename(fn)
         if d["_meta"].get("csrc_sha256") != _tree_hash() or d["_meta"]["frames"] != frames:
             return {"bytes": None, "source": src, "stale": True}
@@ -108,9 +218,9 @@ def pmc_traffic(stage, frames):
         return {"bytes": None, "source": None, "stale": None}
 
 
-def pmc_step_traffic(frames):
+def pmc_step_traffic(frames, leg=None):
     try:
-        fn = _pmc_file()
+        fn = _profile_file("pmc_traffic.json", leg)
         d = json.load(open(fn))
         src = os.path.basename(fn)
         if d["_meta"].get("csrc_sha256") != _tree_hash() or d["_meta"]["frames"] != frames:
@@ -120,33 +230,28 @@ def pmc_step_traffic(frames):
         return {"bytes": None, "source": None, "stale": None}
 
 
-def sq_valu_issue(stage, ms, frames):
-    """Vector-issue fraction of a kernel from the newest committed SQ counter pass (profiles/r*_sq_counters.txt, collected with
-    scripts/pmc_pass.sh on the 1024-note default workload): SQ_INSTS_VALU per launch / this run's kernel time, against what
-    1024 SIMDs can issue (one wave instruction per 4 cycles at 2.4 GHz).  The walkers are bound by what the vector and LDS pipes
-    issue, not by HBM: this is the fraction that says how close they are.  The file's first line carries the sha256 of the
-    kernel sources it was measured on; a different tree gets {"stale": true} and no number."""
+def sq_valu_issue(stage, ms, frames, leg=None, kernel=None):
+    """Vector-pipe fraction of a kernel from the newest committed SQ counter pass (profiles/r*_sq_counters.txt, collected with
+    scripts/pmc_pass.sh on the 1024-note default workload; r*_c4_ / r*_c5_ for the fixed jobs): SQ_INSTS_VALU per launch / this
+    run's kernel time, against what 1024 SIMDs can issue — one wave64 vector instruction per 2 cycles at 2.4 GHz
+    (MI355X_MICROARCH.md; scripts/micro/valu_rates.hip measures one per 2.2 cycles at four waves per SIMD).  Vector
+    instructions only: scalar, LDS and memory instructions do not take VALU issue turns.  The file's first line carries the
+    sha256 of the kernel sources it was measured on; a different tree gets {"stale": true} and no number."""
     try:
-        if frames != 194560:
+        if leg is None and frames != 194560:
             return None
-        import glob
-        files = sorted(glob.glob(os.path.join(HERE, "profiles", "r*_sq_counters.txt")))
-        name = STAGE_KERNEL[stage].replace("void ", "").split("<")[0]
-        lines = open(files[-1]).read().splitlines()
-        src = os.path.basename(files[-1])
+        fn = _profile_file("sq_counters.txt", leg)
+        name = (kernel or STAGE_KERNEL[stage]).replace("void ", "").split("<")[0]
+        lines = open(fn).read().splitlines()
+        src = os.path.basename(fn)
         if not (lines and lines[0].startswith("# csrc_sha256=") and lines[0].split("=", 1)[1].strip() == _tree_hash()):
             return {"stale": True, "source": src}
         for ln in lines:
             if ln.startswith(name + " ") and "SQ_INSTS_VALU=" in ln:
                 cnt = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in ln.split()[1:] if "=" in kv and kv.split("=")[0].startswith("SQ_INSTS_")}
                 insts = cnt["SQ_INSTS_VALU"]
-                peak = 1024 * 2.4e9 / 4.0
-                every = sum(cnt.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM"))
-                return {"insts_valu_per_launch": insts, "issue_frac": insts / (ms * 1e-3) / peak, "peak_wave_insts_per_s": peak,
-                        # every instruction a wave issues takes one of its SIMD's issue turns (one per 4 cycles); with two or three
-                        # waves per SIMD few turns carry two instructions, so this is the fraction that says how much is left
-                        "insts_all_per_launch": every, "issue_frac_all_types": every / (ms * 1e-3) / peak,
-                        "source": src, "stale": False}
+                return {"insts_valu_per_launch": insts, "achieved": insts / (ms * 1e-3) / 1e9, "unit": "G wave-instructions/s",
+                        "peak_wave_insts_per_s": VALU_PEAK, "frac": insts / (ms * 1e-3) / VALU_PEAK, "source": src, "stale": False}
     except Exception:
         pass
     return None
@@ -354,6 +459,21 @@ def host_inclusive(wl, ctx, step_s):
     return best
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` (N > 1) started WITHOUT a launcher: run the same command under torch.distributed.run, one rank per
+    GPU, as a CHILD process and exit with its status.  This process has not touched the GPU (nothing here imports torch), and it
+    never replaces itself: the child is spawned, not exec'd."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: starting %s\n" % (n, " ".join(cmd)))
+    sys.exit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -368,13 +488,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the skip_zero-off / 30 %%-unvoiced variants of the step")
-    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="goofer_set_option on the handle before anything runs (e.g. ring_walkers=1, rfft_shape=1: "
-                    "the fused n_fft-2048 alternatives); the line carries them as `options` and is not the headline configuration")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="goofer_set_option on the handle before anything runs (e.g. skip_zero=0); the line carries them as `options` and is not the headline configuration")
     ap.add_argument("--gather", action="store_true", help="also time the optional ragged gather of finished audio to rank 0 "
                     "(RCCL over xGMI; never part of `value`)")
     ap.add_argument("--rehearse", action="store_true", help="dress rehearsal of the multi-rank logic WITHOUT a GPU: gloo process "
                     "group, the same assignment / sub-batching / planning / reductions, a sleep standing in for the device step")
+    ap.add_argument("--no-legs", action="store_true", help="skip the config4 / config5 legs of the default line")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
     if args.rehearse:
         return rehearse(args)
 
@@ -384,8 +506,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py with --gpus equal to the number of ranks")
     # The CPU baseline runs first, before this process touches the GPU: its pool leg starts worker processes, and nothing
     # that holds a device context should be forked / exec'd from.
     cpu_line = None
@@ -599,50 +721,16 @@ def main():
         steps = max(1, prof["steps"])
         per = {k: v / steps for k, v in prof["ms"].items()}              # ms per launch (per sub-batch), this rank
         # the dominant kernel = the longest single kernel of the step.  (Stages bracketing several launches — the assembly, the
-        # map kernels — and the latency-bound phase walk, which moves 4 B per sample in half a millisecond by design, are not
-        # roofline candidates.)  Some stages share the chip with the side stream: their event time includes that, see `shared_with`.
-        multi = MULTI_STAGES
-        shared_with = {"noise_stems": "the tail of k_pulse_place on the side stream (its time alone is a few percent lower)",
-                       "noise_spectra": "the pulse chain on the side stream", "mask_short": "the pulse chain on the side stream",
-                       "pulse_place": "the envelope gather / noise walker on the caller's stream",
-                       "env_edit": "the f0 / mask kernel on the side stream", "env_rows": "the phase scan / pulse placement on the side stream",
-                       "sample_assemble": "the envelope edit on the caller's stream"}
-        single = {k: v for k, v in per.items() if k not in multi and v > 0} or per
+        # map kernels — and the latency-bound phase scan, which moves 4 B per sample by design, are not roofline candidates.)
+        # Some stages share the chip with the side stream: their event time includes that, see `shared_with`.
+        single = {k: v for k, v in per.items() if k not in MULTI_STAGES and v > 0} or per
         dom = max(single, key=single.get)
         per["rfft_frames_standalone"] = rfft_ms
         Fb, Nb = my_frames / len(subs), my_samples / len(subs)           # frames / samples per launch (mean sub-batch)
         Eb = sum(int(w.prep["assembly"].total_edit_rows) for w in subs) / len(subs)   # edited source rows per launch
         Kmax = max(int(w.prep["assembly"].max_K) for w in subs)
-
-        # share of the stem transforms the overlap-add kernel executed (configs with per-frame skipping: the last sub-batch's bits)
-        executed = 1.0
-        try:
-            fsk = ctx.debug_fetch("frame_skip")
-            if fsk.size:
-                executed = 1.0 - float(((fsk & 1) != 0).sum() + ((fsk & 2) != 0).sum()) / (3.0 * fsk.size)
-        except Exception:
-            pass
-
-        def roof(stage, frames=None, samples=None):
-            frames = Fb if frames is None else frames
-            samples = Nb if samples is None else samples
-            ms = per[stage]
-            alg = stage_alg_bytes(stage, frames, samples, B, hop, n_fft, executed, E=Eb, K=Kmax)
-            a = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            tr = pmc_traffic(stage, wl.frames) if not job else {"bytes": None, "source": None, "stale": None}
-            valu = sq_valu_issue(stage, ms, wl.frames) if not job else None
-            r = {"kernel": stage, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": a / HBM_PEAK_GBS, "traffic": tr["bytes"], "traffic_source": tr["source"], "stale": tr["stale"],
-                 "ms_per_launch": ms, "alg_bytes_per_launch": alg, "transforms_executed": executed if stage == "irfft_ola3" else None,
-                 "shared_with": shared_with.get(stage), "valu": valu}
-            # The nearer roof: when the committed SQ counter pass of this tree says the kernel issues a larger share of what its
-            # SIMDs can issue (every instruction type: one issue turn per SIMD and 4 cycles) than it moves of the HBM peak, the
-            # headline fraction is that one, and the HBM figures stay beside it.
-            if valu and not valu.get("stale") and valu.get("issue_frac_all_types", 0.0) > r["frac"]:
-                r["hbm"] = {"achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS}
-                r.update({"bound": "valu_issue", "achieved": valu["insts_all_per_launch"] / (ms * 1e-3) / 1e9,
-                          "peak": valu["peak_wave_insts_per_s"] / 1e9, "unit": "G wave-instructions/s", "frac": valu["issue_frac_all_types"]})
-            return r
+        executed = executed_share(ctx)
+        roof = make_roof(per, Fb, Nb, B, hop, n_fft, executed, Eb, Kmax, wl.frames, leg=None, counters=not job)
 
         step_ms = elapsed / args.steps * 1e3
         alg_step = (4 * B + 20 * hop) * frames_total / world            # SURVEY 8d ALG_BYTES_FRAME x frames of one rank's step
@@ -681,8 +769,8 @@ def main():
             "roofline_step": {"bound": "hbm", "alg_bytes_per_step": alg_step, "achieved": alg_step / (step_ms * 1e-3) / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "traffic": None if job else pmc_step_traffic(wl.frames),
-                              "note": "the stem walkers are vector-issue / latency bound (about 30 flop per algorithmic byte), "
-                                      "not HBM bound: DESIGN.md section 3"},
+                              "note": "the stem walkers are latency bound at two / three waves per SIMD (about 30 flop per algorithmic "
+                                      "byte): a quarter of the HBM peak and a quarter of the vector pipe each, DESIGN.md section 3"},
         }
         if job or world > 1:
             line["per_rank_frames"] = per_rank
@@ -712,6 +800,15 @@ def main():
             line["options"] = options
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
+        # BASELINE configs 4 and 5 are 8-GPU jobs: their single-GPU passes ride on the default line, after the timed region,
+        # each on a handle of its own (the default workload's buffers are released first)
+        if world == 1 and not job and args.config == 3 and not args.no_legs and not options:
+            del last, mix, subs, wl
+            ctx.close()
+            torch.cuda.empty_cache()
+            line["config4"] = job_leg(local, 4, 10000, args.sub_batch, steps=5, warmup=2)
+            torch.cuda.empty_cache()
+            line["config5"] = job_leg(local, 5, 1024, args.sub_batch, steps=5, warmup=2)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
@@ -734,8 +831,8 @@ def rehearse(args):
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py with --gpus equal to the number of ranks")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgoofer_hip.so")
-SOURCES = ["api.hip", "fft.hip", "pulse.hip", "binops.hip", "samples.hip", "assemble.hip", "stems.hip", "stems_ring.hip", "analysis.hip", "jitter.hip", "post.hip", "resample.hip", "planner.hip"]
+SOURCES = ["api.hip", "fft.hip", "pulse.hip", "binops.hip", "samples.hip", "assemble.hip", "stems.hip", "analysis.hip", "jitter.hip", "post.hip", "resample.hip", "planner.hip"]
 HOST_ONLY = ("planner.hip",)      # host code in the library: no kernel, cannot change what a counter pass measures
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-align-mismatch"]
 

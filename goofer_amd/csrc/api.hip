@@ -92,13 +92,6 @@ int launch_note_steps(goofer_ctx *, const int64_t *, int, double *, hipStream_t)
 int launch_mask_upsample(goofer_ctx *, const double *, const int64_t *, int, int64_t, double *, bool, float *, hipStream_t);
 bool stems_supported(const goofer_plan_t &);
 bool ola_split_supported(const goofer_plan_t &);
-bool ring_walkers_supported(const goofer_plan_t &);
-bool rfft_shape_supported(const goofer_plan_t &);
-int launch_rfft_shape(goofer_ctx *, const float *, const int64_t *, const int64_t *, const int *, int64_t, float2 *, int, const float *,
-                      const float *, const float *, int, const goofer_note_params *, float *, const int64_t *, const double *, hipStream_t);
-int launch_stem_ring(goofer_ctx *, int, const float *, const float *, const float *, bool, const float *, int, const int64_t *, const double *,
-                     int64_t, const int *, const int64_t *, const int64_t *, const float2 *, const goofer_note_params *, uint64_t,
-                     const double *, const double *, float *, float *, float *, float *, const unsigned char *, hipStream_t);
 int launch_irfft_ola1(goofer_ctx *, const float2 *, const float2 *, const float2 *, int, int64_t, const int *, const int64_t *,
                       const int64_t *, int, const double *, double *, const goofer_note_params *, float *, float *, float *,
                       const unsigned char *, hipStream_t);
@@ -307,10 +300,8 @@ struct arena {
     }
 };
 
-// spectra: the one-kernel-per-step pipeline will run (complex spectra + windowed frames of the three stems in HBM: 24 KB per
-// frame); the stem walkers need none of it.  subharm: the 'sg' trackers' fp64 phase increments.
-// spectra: 1 = the one-kernel-per-step pipeline (three spectra, windowed frames, the noise envelope), 0 = the stem walkers,
-// 2 = the ring walkers of n_fft 2048 (no spectra; the per-frame skip bits stay)
+// spectra: 1 = the one-kernel-per-step pipeline will run (complex spectra + windowed frames of the three stems in HBM: 24 KB per
+// frame, the noise envelope); 0 = the stem walkers, which need none of it.  subharm: the 'sg' trackers' fp64 phase increments.
 static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t samples, int64_t notes, int spectra = 1, bool subharm = true)
 {
     size_t ldc = spec_stride(p.n_bins), ld = (p.n_bins + 3) & ~3;
@@ -470,7 +461,6 @@ void goofer_destroy(goofer_ctx *ctx)
     if (ctx->ev_entry) (void)hipEventDestroy(ctx->ev_entry);
     if (ctx->ev_f0) (void)hipEventDestroy(ctx->ev_f0);
     if (ctx->ev_f0s) (void)hipEventDestroy(ctx->ev_f0s);
-    if (ctx->ev_mask) (void)hipEventDestroy(ctx->ev_mask);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     delete ctx;
 }
@@ -650,8 +640,7 @@ int goofer_reserve(goofer_ctx *ctx, int64_t max_frames, int64_t max_samples, int
     if (!ctx) return GOOFER_EINVAL;
     if (!ctx->plan.n_fft) return goofer_fail(ctx, GOOFER_ENOPLAN, "goofer_plan first");
     const bool walkers = ctx->stems && ctx->ola_fused && stems_supported(ctx->plan);   // else: room for the spectra of the one-kernel-per-step path
-    const bool ring = !walkers && ctx->stems && ctx->ola_fused && ctx->ring_walkers && ring_walkers_supported(ctx->plan) && (ctx->plan.hop % 2 == 0);
-    return ensure_scratch(ctx, scratch_need(ctx->plan, max_frames, max_samples, max_notes, walkers ? 0 : (ring ? 2 : 1), !walkers));
+    return ensure_scratch(ctx, scratch_need(ctx->plan, max_frames, max_samples, max_notes, walkers ? 0 : 1, !walkers));
 }
 
 // copy one plan table to host memory (tests / debugging); which: 0 window 1 freqs 2 boost 3 bright_h
@@ -854,35 +843,11 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "overlap")) { ctx->overlap = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "stems")) { ctx->stems = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "prof_only")) { ctx->prof_only = value < 0 || value >= PROF_STAGES ? -1 : value; return GOOFER_OK; }   // stage index, -1: all
-    if (!strcmp(name, "rfft_shape")) { ctx->rfft_shape = value != 0; return GOOFER_OK; }   // n_fft 2048: 0 = k_rfft_frames + k_harm_shape (A/B)
-    if (!strcmp(name, "ring_walkers")) { ctx->ring_walkers = value != 0; return GOOFER_OK; }   // n_fft 2048: 0 = the spectra-in-HBM kernels (A/B)
     if (!strcmp(name, "skip_zero")) { ctx->skip_zero = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "td_blur")) { ctx->td_blur = value != 0; return GOOFER_OK; }
-    if (!strcmp(name, "walk_lds_kb")) { ctx->walk_lds_kb = value < 32 ? 32 : (value > 160 ? 160 : value); return GOOFER_OK; }
-    if (!strcmp(name, "finish_lds_kb")) { ctx->finish_lds_kb = value > 160 ? 160 : value; return GOOFER_OK; }   // KB of the breath stem k_note_finish parks in LDS between its passes (0: 144, < 0: none)
-    if (!strcmp(name, "maps_side")) { ctx->maps_side = value != 0; return GOOFER_OK; }
-    if (!strcmp(name, "f0_side")) { ctx->f0_side = value != 0; return GOOFER_OK; }
-    if (!strcmp(name, "side_prio")) {
-        const int v = value > 0 ? 1 : (value < 0 ? -1 : 0);
-        if (v != ctx->side_prio && ctx->side) {                // the side stream is made again with the other priority
-            HIP_TRY(ctx, hipDeviceSynchronize());
-            HIP_TRY(ctx, hipStreamDestroy(ctx->side));
-            ctx->side = nullptr;
-        }
-        ctx->side_prio = v;
-        return GOOFER_OK;
-    }
-    if (!strcmp(name, "mask_side")) { ctx->mask_side = value != 0; return GOOFER_OK; }
-    if (!strcmp(name, "harm_side")) { ctx->harm_side = value != 0; return GOOFER_OK; }
-    if (!strcmp(name, "nt_mask")) { ctx->nt_mask = value; return GOOFER_OK; }
-    if (!strcmp(name, "nt_spectra")) { ctx->nt_spectra = value != 0; return GOOFER_OK; }
-    if (!strcmp(name, "stem_lds_kb")) { ctx->stem_lds_kb = value < 0 ? 0 : (value > 160 ? 160 : value); return GOOFER_OK; }
     if (!strcmp(name, "pulse_scan")) { ctx->pulse_scan = value < 0 ? 0 : (value > 2 ? 2 : value); return GOOFER_OK; }
-    if (!strcmp(name, "walk_npw")) { ctx->walk_npw = (value == 1 || value == 2 || value == 4) ? value : 0; return GOOFER_OK; }
-    if (!strcmp(name, "pulse_tiles")) { ctx->pulse_tiles = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "sa_fast")) { ctx->sa_fast = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "value_f64")) { ctx->value_f64 = value != 0; return GOOFER_OK; }
-    if (!strcmp(name, "sa_spt")) { ctx->sa_spt = value >= 16 ? 16 : (value >= 8 ? 8 : 4); return GOOFER_OK; }
     return goofer_fail(ctx, GOOFER_EINVAL, "unknown option %s", name);
 }
 
@@ -1343,16 +1308,14 @@ int goofer_post_batch(goofer_ctx *ctx, const goofer_post *p, void *stream)
 static int ensure_side_stream(goofer_ctx *ctx)
 {
     if (ctx->side) return GOOFER_OK;
-    if (ctx->side_prio) {
+    {
         // the pulse chain (f0 kernel -> onsets -> placement) is the longest dependency chain of a step and shares the chip with
-        // the envelope kernels and the noise walker of the caller's stream: its workgroups go first
+        // the envelope kernels and the noise walker of the caller's stream: its workgroups go first (highest stream priority)
         int least = 0, greatest = 0;
         HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, ctx->side_prio > 0 ? greatest : least));
-    } else {
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, greatest));
     }
-    hipEvent_t *evs[] = {&ctx->ev_fork, &ctx->ev_join, &ctx->ev_maps, &ctx->ev_entry, &ctx->ev_f0, &ctx->ev_f0s, &ctx->ev_mask};
+    hipEvent_t *evs[] = {&ctx->ev_fork, &ctx->ev_join, &ctx->ev_maps, &ctx->ev_entry, &ctx->ev_f0, &ctx->ev_f0s};
     for (hipEvent_t *e : evs)
         if (!*e) HIP_TRY(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     return GOOFER_OK;
@@ -1380,9 +1343,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     const bool walkers = ctx->stems && ctx->ola_fused && (p.hop % 2 == 0) && stems_supported(p) && !sub_on && !jit_vol;
     // n_fft 2048: one stem per wave (two waves per SIMD instead of one), then the per-note finish of the stem-split path
     const bool ola_split = !walkers && ctx->ola_fused && (p.hop % 2 == 0) && ctx->stems && ola_split_supported(p) && !jit_vol;
-    // ... and with the waves making the spectra themselves (stems_ring.hip): nothing of a frame but its inputs and its samples in HBM
-    const bool ring_path = ola_split && ctx->ring_walkers && ring_walkers_supported(p);
-    int rc = ensure_scratch(ctx, scratch_need(p, F, N, n, walkers ? 0 : (ring_path ? 2 : 1), sub_on) + (size_t)F * (ld - ((p.n_bins + 3) & ~3)) * 2 * sizeof(float) + jit_bytes);
+    int rc = ensure_scratch(ctx, scratch_need(p, F, N, n, walkers ? 0 : 1, sub_on) + (size_t)F * (ld - ((p.n_bins + 3) & ~3)) * 2 * sizeof(float) + jit_bytes);
     if (rc) return rc;
     arena a{(char *)ctx->scratch, ctx->scratch_bytes, 0};
     int *frame_note = a.take<int>(F);
@@ -1396,7 +1357,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     int32_t *ovf = ctx->ovf_flag;
     float *pulse = a.take<float>(N);
     int32_t *pulse_tiles = a.take<int32_t>((size_t)PULSE_TILE_INTS(N));
-    const size_t spec_n = (walkers || ring_path) ? 0 : (size_t)F * ldc, frame_n = (walkers || ring_path) ? 0 : (size_t)F * p.n_fft;
+    const size_t spec_n = walkers ? 0 : (size_t)F * ldc, frame_n = walkers ? 0 : (size_t)F * p.n_fft;
     float2 *S_h = a.take<float2>(spec_n);
     float2 *S_uv = a.take<float2>(spec_n);
     float2 *S_br = a.take<float2>(spec_n);
@@ -1404,7 +1365,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     float *frames_u = a.take<float>(frame_n);
     float *frames_b = a.take<float>(frame_n);
     float *env_h = a.take<float>((size_t)F * ld);
-    float *env_n = a.take<float>((walkers || ring_path) ? 0 : (size_t)F * ld);
+    float *env_n = a.take<float>(walkers ? 0 : (size_t)F * ld);
     double *short_s = a.take<double>(N / 4 + n + 16);
     float *note_mag = a.take<float>(2 * (size_t)n + 16);
     double *note_steps = a.take<double>(2 * (size_t)n + 16);
@@ -1441,7 +1402,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         const void *ptrs[] = {frame_note, row_src, f0s, pulse, S_h, S_uv, S_br, frames, env_h, env_n, short_s, note_mag, note_peak, onset_cnt};
         size_t bytes[] = {F * sizeof(int), F * sizeof(int64_t), N * sizeof(float), N * sizeof(float), spec_n * sizeof(float2),
                           spec_n * sizeof(float2), spec_n * sizeof(float2), frame_n * sizeof(float),
-                          (size_t)F * ld * sizeof(float), (walkers || ring_path) ? 0 : (size_t)F * ld * sizeof(float), (N / 4 + n) * sizeof(double),
+                          (size_t)F * ld * sizeof(float), walkers ? 0 : (size_t)F * ld * sizeof(float), (N / 4 + n) * sizeof(double),
                           n * sizeof(float), n * sizeof(float), n * sizeof(int32_t)};
         for (int i = 0; i < 14; ++i) { ctx->dbg_ptr[i] = ptrs[i]; ctx->dbg_bytes[i] = bytes[i]; }
         ctx->dbg_ptr[14] = onset_idx; ctx->dbg_bytes[14] = (N / 2 + 16 * (size_t)n) * sizeof(int32_t);
@@ -1481,11 +1442,10 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     } while (0)
 #define MARK()                                                       \
     do {                                                             \
-        if (pev && !(harm_side && (stage == 9 || stage == 10)) && (only < 0 || stage == only || stage == only + 1 || (stage == 5 && (only == 6 || only == 9)))) \
+        if (pev && (only < 0 || stage == only || stage == only + 1 || (stage == 5 && (only == 6 || only == 9)))) \
             HIP_TRY(ctx, hipEventRecord(pev[stage], st));           \
         ++stage;                                                     \
     } while (0)
-    bool harm_side = false;                                   // the harmonic walker runs on the side stream (its two marks are recorded there)
 
     // the fused overlap-add rings index by position mod n_fft with a mask: power-of-two transforms only (768 / 1536 take the
     // separate irFFT + gather kernels)
@@ -1507,25 +1467,18 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         f0s = const_cast<float *>(b->f0);
         ctx->dbg_ptr[2] = f0s;
     }
-    // goofer_render_batch, stem path: the frame maps (frame -> note, frame -> envelope row, per-frame picks, mask steps) need
-    // nothing but the offsets and the assembled f0 / mask, so they go to the side stream in front of the pulse chain and run
-    // beside the envelope assembly — on the caller's stream they sat, with their launch gaps, between the envelope gather
-    // and the mask smoothing (0.07 ms of the critical path).
-    const bool maps_side = early && f0_alias && stem_path && ctx->maps_side;
-    hipStream_t mst = maps_side ? ctx->side : st;
     // goofer_render_batch ran the f0 / mask kernel on the side stream: the caller's stream reads them from here on
     if (ctx->f0_on_side) {
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_f0, 0));
         ctx->f0_on_side = false;
     }
-    // one launch for all the maps when they stay on the caller's stream
-    const bool maps_fused = stem_path && !maps_side;
-    if (!maps_side && !maps_fused) HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), st));
+    // stem path: one launch for all the frame maps
+    const bool maps_fused = stem_path;
+    if (!maps_fused) HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), st));
     MARK();   // 0: setup
     if (early) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_entry, 0));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_f0, 0));
-        if (maps_side) HIP_TRY(ctx, hipMemsetAsync(note_mag, 0, 2 * (size_t)n * sizeof(float), ctx->side));
         if (!f0_alias) {
             hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, ctx->side, b->f0, b->sample_off, n, N,
                                b->params, f0s);
@@ -1533,7 +1486,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_f0s, ctx->side));
     }
-    if (!maps_fused && (rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, mst))) return rc;
+    if (!maps_fused && (rc = launch_frame_note(ctx, b->frame_off, n, F, frame_note, st))) return rc;
     if (!early && !f0_alias) {
         hipLaunchKernelGGL(k_scale_f0, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b->f0, b->sample_off, n, N, b->params,
                            f0s);                                     // (the pulse walk divides by sr itself)
@@ -1548,14 +1501,10 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         hipLaunchKernelGGL(k_frame_maps, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, b->frame_off, b->env_off, n, F, frame_note,
                            row_src, b->sample_off, (const float *)f0s, b->mask, p.hop, picks_on ? picks : (float2 *)nullptr, note_steps, note_mag);
     } else {
-        hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, mst, b->frame_off, b->env_off, frame_note, F, row_src, b->sample_off,
+        hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, st, b->frame_off, b->env_off, frame_note, F, row_src, b->sample_off,
                            (const float *)f0s, b->mask, p.hop, picks_on ? picks : (float2 *)nullptr);
     }
     LAUNCH_CHECK(ctx);
-    if (maps_side) {
-        if ((rc = launch_note_steps(ctx, b->sample_off, n, note_steps, mst))) return rc;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, mst));
-    }
     if (jit_f0 || jit_vol) {
         hipLaunchKernelGGL(k_note_flags, dim3((n + 255) / 256), dim3(256), 0, st, b->params, n, on_f0, on_vol);
         LAUNCH_CHECK(ctx);
@@ -1570,14 +1519,12 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     }
     // aperiodic half of the stem-split path: smoothed mask knots, then the two noise stems straight to samples.  Needs the
     // final scaled f0 (frame picks) and nothing of the pulse chain.
-    bool mask_side = false;                                   // the mask smoothing ran on the side stream, in front of the pulse chain
     auto stems_aperiodic = [&]() -> int {
         int r2;
         if (!picks_on && (r2 = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return r2;
-        if (mask_side) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_mask, 0));   // the smoothed mask comes from the side stream
-        else if ((r2 = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return r2;
+        if ((r2 = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return r2;
         if (side_on) MARK_Q(0);
-        if (!maps_side && !maps_fused && (r2 = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return r2;
+        if (!maps_fused && (r2 = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return r2;
         if ((r2 = launch_noise_stems(ctx, b->env_noise ? b->env_noise : b->env, ld, row_src, b->phi, F, frame_note, b->frame_off,
                                      b->sample_off, picks, b->params, b->seed, b->env_noise != nullptr, short_s, note_steps, b->uv,
                                      b->bre, st)))
@@ -1594,10 +1541,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         int rc2 = ensure_side_stream(ctx);
         if (rc2) return rc2;
         if (pev && (only < 0 || (only >= 3 && only <= 5))) sev = ctx->prof_side + (size_t)ctx->prof_steps * 4;
-        // the harmonic walker beside the noise walker: it needs the pulse signal (side stream), the warped rows and the frame maps
-        // (caller's stream, both enqueued by now), nothing of the noise walker — on the caller's stream it only waited its turn
-        harm_side = stem_path && ctx->warp_done && ctx->harm_side && !maps_side;
-        if (stem_path && (!ctx->warp_done || harm_side) && !maps_side) HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st));   // the frame maps and everything before them on this stream (for k_warp_bins / the harmonic walker)
+        if (stem_path && !ctx->warp_done) HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st));   // the frame maps and everything before them on this stream (for k_warp_bins)
         if (!early) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
@@ -1611,14 +1555,6 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // (folded into k_noise_spectra / k_harm_shape: the standalone envelope kernels remain as C-ABI entry points)
     MARK();   // 2: harmonic envelope = formant-anchored + uniform warp
 
-    // The mask smoothing needs nothing but the assembled mask, which the side stream has as soon as its f0 / mask kernel is done.
-    // On the caller's stream it sat between the envelope gather and the noise walker — the longest chain of the step since the
-    // phase walk became a scan; the side stream has the slack (its chain ends half a millisecond before the noise walker does).
-    if (side_on && early && stem_path && ctx->mask_side) {
-        if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, pst))) return rc;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_mask, pst));
-        mask_side = true;
-    }
     MARK();   // 3..5: pulse train
     if (sev) HIP_TRY(ctx, hipEventRecord(sev[0], pst));
     MARK();
@@ -1633,25 +1569,16 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // ~95 frames of ONE note, so the slow notes would set the kernel's time.
     const bool warp_ready = stem_path && ctx->warp_done;               // goofer_render_batch: the assembly already wrote the warped rows
     if (stem_path && side_on && !warp_ready) {
-        if (!maps_side) HIP_TRY(ctx, hipStreamWaitEvent(pst, ctx->ev_maps, 0));   // frame_note / row_src come from the caller's stream
+        HIP_TRY(ctx, hipStreamWaitEvent(pst, ctx->ev_maps, 0));   // frame_note / row_src come from the caller's stream
         if ((rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, pst)))
             return rc;
     }
     if (side_on) {
         if (sev) HIP_TRY(ctx, hipEventRecord(sev[3], pst));
-        if (harm_side) {
-            HIP_TRY(ctx, hipStreamWaitEvent(pst, ctx->ev_maps, 0));
-            if (pev && (only < 0 || only == 9 || only == 8)) HIP_TRY(ctx, hipEventRecord(pev[9], pst));
-            if ((rc = launch_harm_stem(ctx, pulse, ctx->warp_rows, b->env, b->formants != nullptr, ld, row_src, F, frame_note, b->frame_off, b->sample_off, picks, b->params,
-                                       b->harm, note_mag, pst)))
-                return rc;
-            if (pev && (only < 0 || only == 9 || only == 10)) HIP_TRY(ctx, hipEventRecord(pev[10], pst));
-        }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_join, pst));
         // meanwhile, on the caller's stream
         if (early && !f0_alias) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_f0s, 0));   // the scaled f0 comes from the side stream
         if (stem_path) {
-            if (maps_side) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_maps, 0));        // the maps come from the side stream
             if ((rc = stems_aperiodic())) return rc;
         } else {
             // (the skip bits need the smoothed mask: it goes first then)
@@ -1659,18 +1586,6 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                 if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
                 if ((rc = launch_frame_skip(ctx, short_s, N / 4 + n, b->sample_off, b->frame_off, frame_note, n, F, knot_eq, hop_flat, frame_skip, st))) return rc;
             }
-            if (ring_path) {
-                // the two noise stems straight to samples beside the pulse chain (stems_ring.hip): needs the smoothed mask first
-                if (!skip_frames && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
-                if (!picks_on && (rc = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return rc;
-                if ((rc = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return rc;
-                MARK_Q(0);
-                if ((rc = launch_stem_ring(ctx, 2, pulse, b->env, b->env_noise ? b->env_noise : b->env, b->env_noise != nullptr, b->phi, ld,
-                                           row_src, b->formants, F, frame_note, b->frame_off, b->sample_off, picks, b->params, b->seed,
-                                           short_s, note_steps, note_mag, b->harm, b->uv, b->bre, frame_skip, st)))
-                    return rc;
-                MARK_Q(1);
-            } else {
             if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
                                            b->env_noise ? b->env_noise : b->env, b->phi, ld, b->params, b->seed, row_src,
                                            b->env_noise != nullptr, frame_skip, st)))
@@ -1678,7 +1593,6 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
             MARK_Q(0);
             if (!skip_frames && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
             MARK_Q(1);
-            }
         }
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     }
@@ -1721,8 +1635,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         }
         MARK();   // 8
         MARK();   // 9: harm_stem = rFFT + shaping + irFFT + overlap-add of the harmonic stem
-        if (!harm_side &&
-            (rc = launch_harm_stem(ctx, pulse, ctx->warp_done ? ctx->warp_rows : env_h, ctx->warp_done ? b->env : nullptr, b->formants != nullptr, ld,
+        if ((rc = launch_harm_stem(ctx, pulse, ctx->warp_done ? ctx->warp_rows : env_h, ctx->warp_done ? b->env : nullptr, b->formants != nullptr, ld,
                                    ctx->warp_done ? row_src : nullptr, F, frame_note,
                                    b->frame_off, b->sample_off, picks, b->params, b->harm, note_mag, st)))
             return rc;
@@ -1742,50 +1655,12 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         ctx->frame_picks = nullptr;
         return GOOFER_OK;
     }
-    if (ring_path) {
-        // Ring walkers (stems_ring.hip): the harmonic stem from the pulse train to samples — and, when nothing ran beside the pulse
-        // chain, the two noise stems in the same launch.  No spectrum in HBM.
-        MARK();   // 6..12
-        MARK();
-        MARK();
-        MARK();
-        MARK();
-        MARK();
-        if (!side_on) {
-            if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
-            if (!picks_on && (rc = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return rc;
-            if ((rc = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return rc;
-        }
-        MARK();
-        MARK();   // 13: the walkers
-        if ((rc = launch_stem_ring(ctx, side_on ? 1 : 3, pulse, b->env, b->env_noise ? b->env_noise : b->env, b->env_noise != nullptr, b->phi,
-                                   ld, row_src, b->formants, F, frame_note, b->frame_off, b->sample_off, picks, b->params, b->seed, short_s,
-                                   note_steps, note_mag, b->harm, b->uv, b->bre, nullptr, st)))
-            return rc;
-        MARK();   // 14
-        if ((rc = launch_note_finish(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, b->params, note_mag, note_peak,
-                                     !(b->mix_only && (b->mix || b->rec)), st)))
-            return rc;
-        MARK();   // 15..17 unused
-        MARK();
-        MARK();
-        MARK();   // end
-        if (pev) ctx->prof_steps++;
-        ctx->frame_picks = nullptr;
-        return GOOFER_OK;
-    }
     // spectra -> windowed time frames of the three stems
     {
         MARK();   // 6: framewise rFFT of the pulse train
-        // n_fft 2048: transform and shaping as one kernel (the unshaped spectrum never reaches HBM; option "rfft_shape" 0: apart)
-        const bool fused_shape = ctx->rfft_shape && rfft_shape_supported(p);
-        if (fused_shape) {
-            if ((rc = launch_rfft_shape(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, f0s, b->mask, b->env, ld, b->params,
-                                        note_mag, row_src, b->formants, st)))
-                return rc;
-        } else if ((rc = launch_rfft_frames_mapped(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, st))) return rc;
+        if ((rc = launch_rfft_frames_mapped(ctx, pulse, b->sample_off, b->frame_off, frame_note, F, S_h, ldc, st))) return rc;
         MARK();   // 7
-        if (!fused_shape && (rc = launch_harm_shape(ctx, S_h, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, b->env, ld, b->params,
+        if ((rc = launch_harm_shape(ctx, S_h, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask, b->env, ld, b->params,
                                     note_mag, row_src, b->formants, b->no_warp != 0, st)))
             return rc;
         MARK();   // 8
@@ -1873,7 +1748,7 @@ int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *asmb, const goof
         ctx->early_req = true;
     }
     // Stem-split path: the harmonic walker wants warped envelope rows.  The assembly's frame-gather kernel has every row in
-    // hand, so it writes the warped copy too (k_env_loop<true>) — one pass instead of a separate read + write of the matrix.
+    // hand, so it writes the warped copy too (k_env_rows<true>) — one pass instead of a separate read + write of the matrix.
     ctx->warp_out = nullptr;
     ctx->warp_done = false;
     if (ctx->stems && ctx->ola_fused && ctx->overlap && stems_supported(ctx->plan) && asmb->env_out == b->env &&

@@ -2,7 +2,7 @@
 //
 //   k_env_edit         knot decode + br tilt + es smooth/sharpen + fw width warp on the source rows a note
 //                      uses                                 GOOFER.py:149-168, SillySampler.py:502-574
-//   k_env_loop         4-tap frame gather (slicing, L0 cross-fades / L1 mirror mean / L2 stretch, velocity
+//   k_row_recs + k_env_rows  4-tap frame gather (slicing, L0 cross-fades / L1 mirror mean / L2 stretch, velocity
 //                      prefix stretch) + formant-strength gain bells
 //                                                           SillySampler.py:625-696, 765-773, 791-833
 //   k_sample_assemble  per-sample voicing mask (slice, tile, reverse, force-voiced, velocity stretch) and
@@ -310,150 +310,11 @@ struct env_loop_grid {
     const float *freqs_f;    // [B] np.linspace(0, sr/2, B) as fp32 (the plan's table), or null: computed per bin
 };
 
-template <bool WARP, int CH, bool V64>
-__global__ __launch_bounds__(256) void k_env_loop(const goofer_assembly a, int64_t total_out_rows, const int *__restrict__ row_note,
-                                                  const double *__restrict__ w_formants, const goofer_note_params *__restrict__ w_params,
-                                                  float *__restrict__ w_out, const env_loop_grid eg)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ double s_seg[A_ROWS][WARP_SEG_DOUBLES];
-    const int B = a.n_bins;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // uniform row: scalar plan / tap loads
-    const int64_t orow = (int64_t)blockIdx.x * A_ROWS + wave;
-    if (orow >= total_out_rows) return;
-    const int note = row_note[orow];
-    const goofer_note_plan &p = a.notes[note];
-    const int64_t t = orow - p.env_off;
-    const int32_t *ti = a.tap_idx + (p.tap_off + t) * 4;
-    const double *tw = a.tap_w + (p.tap_off + t) * 4;
-    double w[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) w[k] = tw[k];
-    // row r of the edited-row scratch (row counts and strides are 32-bit: one 32 x 32 -> 64 multiply per pointer)
-    const int64_t e0 = p.edit_off - p.row_lo;
-    auto src_row = [&](int k) { return a.edit_rows + (uint64_t)(uint32_t)(e0 + ti[k]) * (uint32_t)a.ld; };
-    // formant-strength bells for this frame                    SillySampler.py:817-830
-    // lane k < 4: bell k.  1/sigma and -0.5*log2(e): the bell exp(-0.5 ((f - F)/sigma)^2) through the hardware exp2 (<= 1e-6
-    // relative on the gain where the bell is not negligible) instead of an IEEE division and libm expf per bin and formant
-    const int li = lane & 3;
-    const double sv = p.fst[li];
-    const float Fl = a.fst_tracks[(p.env_off + t) * 4 + li];
-    const bool on = !(fabs(sv) < 1e-6) && isfinite(Fl) && !(Fl <= 50.0f) && !(Fl >= eg.nyq_f);
-    const float gl = (float)((1.0 + sv) - 1.0);                 // python-float (gain - 1.0), weak-cast to fp32
-    const float sgl = li == 0 ? 100.0f : (li == 1 ? 200.0f : (li == 2 ? 350.0f : 500.0f));
-    // Bins a bell cannot move: the factor 1.0f + gk*wt rounds to exactly 1.0f once |gk| wt < 2^-25, i.e. beyond
-    // z^2 > (25 + log2|gk|) / (0.5 log2 e).  Two more bits and a bin on either side cover the hardware exp2 / log2 and the
-    // rounding of fb; a 64-bin chunk wholly outside the reach skips the bell (a wave-uniform branch), which is most of
-    // them: sigma is 100-500 Hz against 22 kHz of bins.  The product is unchanged bit for bit.  The reach is kept as a bit
-    // per chunk it touches (rounded outwards: an extra chunk only multiplies by exactly 1.0f).
-    unsigned cm = 0;
-    if (on) {
-        const float lg = __builtin_amdgcn_logf(fabsf(gl));                    // log2
-        const float z2 = (27.0f + fmaxf(lg, 0.0f)) * 1.3862943611198906f;     // / (0.5 log2 e)
-        const float R = __builtin_amdgcn_sqrtf(z2) * sgl * 1.0001f;           // (x sigma for / (1/sigma): rounded outwards)
-        const float blo = (Fl - R) * eg.inv_fstep - 1.0f, bhi = (Fl + R) * eg.inv_fstep + 1.0f;
-        const int c_lo = (int)floorf(fminf(fmaxf((blo - 63.0f) * (1.0f / 64.0f), 0.0f), 31.0f));
-        const int c_hi = (int)ceilf(fminf(fmaxf(bhi * (1.0f / 64.0f), -1.0f), 31.0f));
-        if (c_hi >= c_lo) cm = (0xffffffffu >> (31 - c_hi)) & (0xffffffffu << c_lo);
-    }
-    float Fk[4], gk[4];
-    const float isig[4] = {1.0f / 100.0f, 1.0f / 200.0f, 1.0f / 350.0f, 1.0f / 500.0f};
-    unsigned cmk[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        Fk[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Fl), k));
-        gk[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), k));
-        cmk[k] = (unsigned)__builtin_amdgcn_readlane((int)cm, k);
-    }
-    const unsigned cm_any = cmk[0] | cmk[1] | cmk[2] | cmk[3];
-    float *out = a.env_out + orow * (int64_t)a.ld;
-    float *ra = reinterpret_cast<float *>(smem) + (size_t)(2 * wave) * (B + 1);   // (+ 1: warp_row's pad element)
-    // does this row leave a warped copy?  (wave-uniform; the per-note scalars come in through scalar loads)
-    bool warp = false, warp_row_on = false;
-    double fs[4] = {1.0, 1.0, 1.0, 1.0}, ratio = 1.0;
-    if (WARP) {
-        const goofer_note_params &q = w_params[note];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) fs[k] = q.f_shift[k];
-        ratio = (double)q.formant_shift;
-        warp = note_shifts_formants(q);
-        warp_row_on = note_warps(q, w_formants != nullptr);
-    }
-    // a plain copy of one source row (most rows: slices and loop repeats outside the cross-fades): 0.0 + 1.0 x is x, and
-    // both roundings of the product below — fp32, or fp64 rounded to fp32 — are the fp32 product, so the row stays in fp32
-    const bool copy = w[0] == 1.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 0.0;
-    const float *src0 = src_row(0);
-    const float *src1 = nullptr, *src2 = nullptr, *src3 = nullptr;
-    if (!copy) { src1 = src_row(1); src2 = src_row(2); src3 = src_row(3); }
-    const int env_f64 = p.env_f64;
-    const float wf0 = (float)w[0], wf1 = (float)w[1], wf2 = (float)w[2], wf3 = (float)w[3];
-    auto chunk = [&](int c, int c0, bool last) {
-        const int b = c0 + lane;
-        if (last && b >= B) return;                            // (only a row's last chunk can run past it)
-        double v = 0.0;
-        float vf = 0.f;
-        if (copy) {
-            vf = src0[b];
-        } else if constexpr (V64) {
-            if (w[0] != 0.0) v += w[0] * (double)src0[b];
-            if (w[1] != 0.0) v += w[1] * (double)src1[b];
-            if (w[2] != 0.0) v += w[2] * (double)src2[b];
-            if (w[3] != 0.0) v += w[3] * (double)src3[b];
-        } else {
-            // fp32 blend: zero-weight taps are skipped like above (their rows may hold anything), the others are one
-            // product and FMAs in tap order — an L1 mirror mean (0.5, 0.5) is still the exact fp32 (a + b) / 2
-            if (w[0] != 0.0) vf = wf0 * src0[b];
-            if (w[1] != 0.0) vf = __builtin_fmaf(wf1, src1[b], vf);
-            if (w[2] != 0.0) vf = __builtin_fmaf(wf2, src2[b], vf);
-            if (w[3] != 0.0) vf = __builtin_fmaf(wf3, src3[b], vf);
-        }
-        float gain = 1.0f;
-        if ((cm_any >> c) & 1u) {
-            // np.linspace(0, sr/2, B) as fp32: the plan's table where the plan has this many bins
-            const float fb = eg.freqs_f ? eg.freqs_f[b] : (float)(b >= B - 1 ? (double)a.sr / 2.0 : (double)b * eg.fstep);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if ((cmk[k] >> c) & 1u) {
-                    const float z = (fb - Fk[k]) * isig[k];
-                    const float wt = __builtin_amdgcn_exp2f((z * z) * -0.72134752044448170368f);
-                    gain *= 1.0f + gk[k] * wt;
-                }
-            }
-        }
-        float o;
-        if constexpr (V64) o = copy ? vf * gain : (env_f64 ? (float)(v * (double)gain) : ((float)v) * gain);
-        else o = vf * gain;
-        store_f1(out + b, o, eg.nt != 0);
-        if (WARP && warp_row_on) ra[b] = o;
-    };
-    if (CH > 0) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) chunk(c, c * WAVE, c == CH - 1);
-    } else {
-        for (int c = 0, c0 = 0; c0 < B; ++c, c0 += WAVE) chunk(c < 31 ? c : 31, c0, true);
-    }
-    if (WARP && warp_row_on) {
-        float *rb = ra + B + 1;
-        wave_lds_sync();
-        const float *cur = warp_row<CH, !V64>(ra, rb, B, eg.warp, w_formants ? w_formants + orow * 4 : nullptr, fs, warp, ratio, lane,
-                                              s_seg[wave]);
-        float *wo = w_out + orow * (int64_t)a.ld;
-        if (CH > 0) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const int b = c * WAVE + lane;
-                if (c < CH - 1 || b < B) store_f1(wo + b, cur[b], eg.nt != 0);
-            }
-        } else {
-            for (int b = lane; b < B; b += WAVE) wo[b] = cur[b];
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// k_row_recs + k_env_rows — k_env_loop's work (fp32 value arithmetic) with the per-row set-up taken off the rows' critical path.
+// k_row_recs + k_env_rows — the frame gather with the per-row set-up taken off the rows' critical path.
 //
-// k_env_loop gives every output row a wave, and that wave walks a chain of dependent loads before it touches a bin:
+// Round 4's single kernel (k_env_loop, removed in round 6) gave every output row a wave, and that wave walked a chain of
+// dependent loads before it touched a bin:
 // row -> note -> plan -> taps -> source rows -> (formants, parameters) -> stores, with the bells' reach and the warp's anchor
 // table (fp64) computed across its lanes in between.  Measured (round 5, AMD_SERIALIZE_KERNEL trace): 0.43 ms alone for
 // 194 560 rows whether the per-bin arithmetic is fp64 or fp32 — three quarters of its wave-cycles are waits, the rest ~1 200
@@ -1258,16 +1119,14 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         // are the pulse walk and placement queued behind it there, and the envelope kernels below then run BESIDE it on the
         // caller's stream instead of behind it (it is 0.3 ms at the head of a 2.6 ms step).  The caller's stream waits for
         // ev_f0 where it first reads f0 / mask (goofer_synth_batch).  Not with the fry edit, which reads them here.
-        const bool on_side = ctx->early_req && ctx->ev_f0 && ctx->side && ctx->f0_side && !a->any_fry;
+        const bool on_side = ctx->early_req && ctx->ev_f0 && ctx->side && !a->any_fry;
         hipStream_t fst = on_side ? ctx->side : st;
         if (on_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_entry, 0));
-        const int spt = ctx->sa_spt;
+        constexpr int spt = 4;                                  // (8 / 16 samples per thread measured no faster)
         const dim3 sgrid((unsigned)((a->total_samples + 256 * spt - 1) / (256 * spt)));
         const int sa_fast = ctx->sa_fast ? 1 : 0;
         HIP_TRY(ctx, mark(2, 0, fst));
-        if (spt == 16) hipLaunchKernelGGL(k_sample_assemble<16>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast);
-        else if (spt == 8) hipLaunchKernelGGL(k_sample_assemble<8>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast);
-        else hipLaunchKernelGGL(k_sample_assemble<4>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast);
+        hipLaunchKernelGGL(k_sample_assemble<spt>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast);
         LAUNCH_CHECK(ctx);
         HIP_TRY(ctx, mark(2, 1, fst));
         if (ctx->early_req && ctx->ev_f0) {
@@ -1319,51 +1178,33 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         const goofer_note_params *wp = fused_warp ? ctx->warp_params : nullptr;
         float *wo = fused_warp ? ctx->warp_out : nullptr;
         env_loop_grid eg;
-        eg.nt = (ctx->nt_mask & 2) ? 1 : 0;
+        eg.nt = 0;
         eg.fstep = ((double)a->sr / 2.0) / (double)(B - 1);
         eg.inv_fstep = (float)(1.0 / eg.fstep);
         eg.nyq_f = (float)((double)a->sr * 0.5);
         eg.warp = make_warp_grid(ctx->plan.sr, B);
         eg.freqs_f = (ctx->plan.n_bins == B && ctx->plan.sr == a->sr) ? ctx->plan.lin_freqs : nullptr;
-#define ENV_LOOP(W, C) hipLaunchKernelGGL((k_env_loop<W, C, true>), lgrid, dim3(256), lds_w, st, *a, a->total_out_rows, row_note_out, wf, wp, wo, eg)
         const int chunks = (B + WAVE - 1) / WAVE;
-        if (!ctx->value_f64) {
-            env_row_rec *recs = reinterpret_cast<env_row_rec *>(row_recs);
-            const dim3 tgrid((unsigned)((a->total_out_rows + 255) / 256));
-            if (fused_warp) hipLaunchKernelGGL(k_row_recs<true>, tgrid, dim3(256), 0, st, *a, a->total_out_rows, row_note_out, wf, wp, recs, eg);
-            else hipLaunchKernelGGL(k_row_recs<false>, tgrid, dim3(256), 0, st, *a, a->total_out_rows, row_note_out, wf, wp, recs, eg);
-            LAUNCH_CHECK(ctx);
-            HIP_TRY(ctx, mark(1, 0, st));
+        env_row_rec *recs = reinterpret_cast<env_row_rec *>(row_recs);
+        const dim3 tgrid((unsigned)((a->total_out_rows + 255) / 256));
+        if (fused_warp) hipLaunchKernelGGL(k_row_recs<true>, tgrid, dim3(256), 0, st, *a, a->total_out_rows, row_note_out, wf, wp, recs, eg);
+        else hipLaunchKernelGGL(k_row_recs<false>, tgrid, dim3(256), 0, st, *a, a->total_out_rows, row_note_out, wf, wp, recs, eg);
+        LAUNCH_CHECK(ctx);
+        HIP_TRY(ctx, mark(1, 0, st));
 #define ENV_ROWS(W, C) hipLaunchKernelGGL((k_env_rows<W, C>), lgrid, dim3(256), lds_w, st, *a, a->total_out_rows, recs, wf, wp, wo, eg)
-            if (fused_warp) {
-                if (chunks == 9) ENV_ROWS(true, 9);
-                else if (chunks == 17) ENV_ROWS(true, 17);
-                else ENV_ROWS(true, 0);
-                ctx->warp_done = true;
-            } else {
-                if (chunks == 9) ENV_ROWS(false, 9);
-                else if (chunks == 17) ENV_ROWS(false, 17);
-                else ENV_ROWS(false, 0);
-            }
-#undef ENV_ROWS
-            LAUNCH_CHECK(ctx);
-            HIP_TRY(ctx, mark(1, 1, st));
+        if (fused_warp) {
+            if (chunks == 9) ENV_ROWS(true, 9);
+            else if (chunks == 17) ENV_ROWS(true, 17);
+            else ENV_ROWS(true, 0);
+            ctx->warp_done = true;
         } else {
-            HIP_TRY(ctx, mark(1, 0, st));
-            if (fused_warp) {
-                if (chunks == 9) ENV_LOOP(true, 9);
-                else if (chunks == 17) ENV_LOOP(true, 17);
-                else ENV_LOOP(true, 0);
-                ctx->warp_done = true;
-            } else {
-                if (chunks == 9) ENV_LOOP(false, 9);
-                else if (chunks == 17) ENV_LOOP(false, 17);
-                else ENV_LOOP(false, 0);
-            }
-            LAUNCH_CHECK(ctx);
-            HIP_TRY(ctx, mark(1, 1, st));
+            if (chunks == 9) ENV_ROWS(false, 9);
+            else if (chunks == 17) ENV_ROWS(false, 17);
+            else ENV_ROWS(false, 0);
         }
-#undef ENV_LOOP
+#undef ENV_ROWS
+        LAUNCH_CHECK(ctx);
+        HIP_TRY(ctx, mark(1, 1, st));
         LAUNCH_CHECK(ctx);
         if (a->any_fry) {
             size_t lds = (size_t)A_ROWS * ((B + 3) & ~3) * sizeof(float);

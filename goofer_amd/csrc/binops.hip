@@ -296,12 +296,8 @@ int launch_harm_shape(goofer_ctx *ctx, float2 *S, int ldc, int64_t total_frames,
     hipLaunchKernelGGL((k_harm_shape<IT, NT>), grid, dim3(256), lds, st, S, ldc, total_frames, frame_note, frame_off, sample_off, f0, \
                        mask, env, ld, params, note_mag, pl.freqs, pl.boost, pl.bright_h, pl.blur5, pl.n_bins, pl.hop, row_src,    \
                        formants, make_warp_grid(pl.sr, pl.n_bins), ctx->frame_picks, warp_rows)
-    // (the shaped rows are written once and read once, by the inverse transform: non-temporal stores, option "nt_spectra")
-#define HARM_SHAPE(IT)                                                                                                             \
-    do {                                                                                                                           \
-        if (ctx->nt_spectra) HARM_SHAPE_NT(IT, true);                                                                              \
-        else HARM_SHAPE_NT(IT, false);                                                                                             \
-    } while (0)
+    // (the shaped rows are written once and read once, by the inverse transform: non-temporal stores)
+#define HARM_SHAPE(IT) HARM_SHAPE_NT(IT, true)
     // bins per lane: the instantiation with the smallest count that covers the row (the kernels test k < n_bins per bin)
     const int chunks = (pl.n_bins + WAVE - 1) / WAVE;
     if (chunks <= 5) HARM_SHAPE(5);
@@ -554,13 +550,8 @@ int launch_noise_spectra(goofer_ctx *ctx, float2 *S_uv, float2 *S_br, int ldc, i
     } while (0)
 #define NOISE_SPECTRA(IT)                                                                                                          \
     do {                                                                                                                           \
-        if (phi) {                                                                                                                 \
-            if (ctx->nt_spectra) NOISE_SPECTRA_P(IT, true, true);                                                                  \
-            else NOISE_SPECTRA_P(IT, false, true);                                                                                 \
-        } else {                                                                                                                   \
-            if (ctx->nt_spectra) NOISE_SPECTRA_P(IT, true, false);                                                                 \
-            else NOISE_SPECTRA_P(IT, false, false);                                                                                \
-        }                                                                                                                          \
+        if (phi) NOISE_SPECTRA_P(IT, true, true);                                                                                  \
+        else NOISE_SPECTRA_P(IT, true, false);                                                                                     \
     } while (0)
     // bins per lane: the instantiation with the smallest count that covers the row (the kernels test k < n_bins per bin)
     const int chunks = (pl.n_bins + WAVE - 1) / WAVE;

@@ -10,7 +10,7 @@
 
 #define WAVE 64
 #define PROF_STAGES 18
-#define PROF_ASM0 15           // profile stages 15..17: the assembly's k_env_edit, k_env_rows / k_env_loop, k_sample_assemble
+#define PROF_ASM0 15           // profile stages 15..17: the assembly's k_env_edit, k_env_rows, k_sample_assemble
 #define PP_SPT 8                // k_pulse_place: consecutive samples per thread; a tile = one workgroup = 256 * PP_SPT samples
 #define PULSE_TILE_INTS(samples) (4 * (((samples) + 256 * PP_SPT - 1) / (256 * PP_SPT)) + 64)   // k_pulse_tiles' table: 4 ints per tile
 #define PULSE_TAB_MAX 8192     // pulse lengths served from the shape table: all of them (the reference caps T0 at 8192, GOOFER.py:497-498) — 134 MB of
@@ -67,11 +67,10 @@ struct goofer_ctx {
     size_t dbg_bytes[16] = {0};
     bool overlap = true;          // noise spectra + mask smoothing on a side stream, beside the latency-bound pulse walk
     hipStream_t side = nullptr;   // created on first use
-    int side_prio = 1;            // ... with the highest (1) / lowest (-1) stream priority (option "side_prio"; 0: default priority).  Measured
-                                  // with the parallel phase scan in place: 2.41 ms per step against 2.50 (0) and 2.54 (-1) on one box
+                                  // ... with the highest stream priority (measured: 2.41 ms per step against 2.50 at the default, 2.54 at the lowest)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_maps = nullptr;
     // goofer_render_batch: the pulse chain forks as soon as the assembled f0 exists, not when the synthesis call starts
-    hipEvent_t ev_entry = nullptr, ev_f0 = nullptr, ev_f0s = nullptr, ev_mask = nullptr;
+    hipEvent_t ev_entry = nullptr, ev_f0 = nullptr, ev_f0s = nullptr;
     int32_t *ovf_flag = nullptr;           // handle-owned device words ([1], [2]: cumulative counters, goofer_counter); [0] sticky between goofer_check calls: 1 + index (inside its batch) of a
                                            // note whose pulse onsets overflowed their slots, written with atomicMax by every pulse-chain launch
     // goofer_render_batch, stem-split path: the assembly's frame-gather kernel also writes the rows the harmonic walker needs
@@ -85,8 +84,8 @@ struct goofer_ctx {
     const float2 *frame_picks = nullptr;   // per-frame (f0, mask) picks of the running goofer_synth_batch, or null
     bool early_req = false;           // set for the duration of one goofer_render_batch
     const float *early_f0 = nullptr;  // f0 array ev_f0 stands for (null: no event recorded)
-    bool f0_side = true;              // goofer_render_batch: the f0 / mask kernel runs on the side stream, in front of the pulse chain it feeds (option "f0_side")
-    bool f0_on_side = false;          // ... and did so in the assembly of the current call: the caller's stream waits for ev_f0 before it reads f0 / mask
+    bool f0_on_side = false;          // goofer_render_batch ran the f0 / mask kernel on the side stream, in front of the pulse chain it feeds: the
+                                      // caller's stream waits for ev_f0 before it reads f0 / mask
     hipEvent_t *prof_side = nullptr;    // [prof_cap][4]: boundaries of the pulse chain on the side stream
     hipEvent_t *prof_main2 = nullptr;   // [prof_cap][2]: ends of noise_spectra / mask_short when they run beside it
     hipEvent_t *prof_asm = nullptr;     // [prof_cap][3][2]: the assembly's three large kernels, each on its own stream
@@ -99,27 +98,11 @@ struct goofer_ctx {
     bool skip_zero = true;        // noise walker: skip transforms whose stem gain is exactly zero over everything they reach (option "skip_zero")
     bool td_blur = true;          // stem walkers: the 5-tap bin blur of voiced frames as a window on the frame's samples (option "td_blur")
     bool prof_stems = false;      // the last profiled batch ran the stem-split path (stage order differs)
-    // tuning knobs (goofer_set_option; the defaults are the measured optima — round 3 swept them: nothing within 1 % to gain)
-    int walk_lds_kb = 81;         // LDS the sequential phase walk reserves per workgroup (what it uses: 32 KiB)
-    int finish_lds_kb = 0;        // KB of the breath stem k_note_finish parks in LDS between its passes (0: the default 144, < 0: none)
-    int sa_spt = 4;               // samples per thread of k_sample_assemble (4, 8 or 16)
-
-    bool pulse_tiles = true;      // pulse placement: the onset range of every tile from a kernel of its own (option "pulse_tiles"; 0: A/B)
     bool sa_fast = true;          // k_sample_assemble: the branch-free path with all of a thread's loads in flight together (option "sa_fast"; 0: A/B)
-    bool value_f64 = false;       // assembly kernels: round 4's fp64 value arithmetic (tap blend, warp / fw interpolation, es blur) instead of
-                                  // fp32 — A/B and the error-budget tests (option "value_f64")
-    bool mask_side = false;       // goofer_render_batch: the mask smoothing on the side stream in front of the pulse chain (option "mask_side"; measured: -0.4 %)
-    // n_fft 2048 (stems_ring.hip), both measured slower than the spectra-in-HBM kernels on BASELINE config 5 and off by default:
-    bool rfft_shape = false;    // the framewise rFFT and the harmonic shaping as one kernel (10.3 ms against 2.9 + 5.7 ms)
-    bool ring_walkers = false;  // the ring walkers: no spectrum in HBM (step 42.9 ms against 29.3 ms)
-    bool harm_side = false;       // goofer_render_batch: the harmonic walker on the side stream, beside the noise walker (option "harm_side")
-    int nt_mask = 1;              // non-temporal stores: 1 note_finish mix / rec (the final output: -0.7 % per step), 2 env_loop rows (measured: nothing)
-    int nt_spectra = 1;           // framewise rFFT: spectrum rows leave as non-temporal stores (option "nt_spectra")
-    int stem_lds_kb = 0;          // stem walkers: LDS to reserve per workgroup beyond what they use (tuning: 100 -> one workgroup per CU)
-    int walk_npw = 0;             // notes per wave of the phase walk: 1, 2, 4; 0 = by batch size
+    bool value_f64 = false;       // k_env_edit: round 4's fp64 value arithmetic (fw interpolation, es blur) instead of fp32 — A/B and the
+                                  // error-budget tests (option "value_f64")
     int pulse_scan = 1;           // 1: onsets from the parallel phase scan, the sequential walk only for the notes it cannot settle;
                                   // 0: the sequential walk kernel for every note; 2: the scan kernel walks every note (tests)
-    int maps_side = 0;            // goofer_render_batch: frame maps on the side stream in front of the pulse chain (A/B: +0.4 %, off)
     // per-context kernel state: hipFuncSetAttribute is per device, and a handle belongs to one device, so what was set /
     // queried is remembered here and never in process-wide statics
     struct kernel_state {

@@ -870,33 +870,23 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
                            n_notes, onset_idx, onset_cnt, overflow, overflow, ctx->pulse_scan == 2 ? 1 : 0);
         LAUNCH_CHECK(ctx);
     } else {
-        // One note per wave.  Two or four per wave (option walk_npw) cut the walk's vector instructions to a half / a third —
-        // 94 M -> 30 M per 1024-note batch — and make the STEP slower (2.77 -> 2.78 / 2.89 ms, A/B in one run): a lane then
-        // replays 16 / 32 samples per chunk when the onsets are extracted, the walk takes longer, the pulse placement behind
-        // it runs further into the noise walker.  What the rest of the step feels is the walk's duration, not its issue slots.
-        const int npw = ctx->walk_npw > 0 ? ctx->walk_npw : 1;
-        const int blocks = (n_notes + 3) / 4;                  // four notes per workgroup, in 4 / npw waves
+        // the sequential walk for every note (A/B reference of the scan): one note per wave, four notes per workgroup
+        const int blocks = (n_notes + 3) / 4;
         const int per_cu = (blocks + 255) / 256;              // MI355X: 256 CUs, 160 KiB LDS each
         size_t lds = (size_t)(160 * 1024) / per_cu;
-        if (lds > (size_t)ctx->walk_lds_kb * 1024) lds = (size_t)ctx->walk_lds_kb * 1024;   // 81 KiB: two of these cannot share a CU,
-                                                              // and 79 KiB stay free for the kernel running beside the walk
+        if (lds > (size_t)81 * 1024) lds = (size_t)81 * 1024;   // 81 KiB: two of these cannot share a CU, and 79 KiB stay free for
+                                                                // the kernel running beside the walk
         lds = lds / 1024 * 1024;
         const size_t need = 4 * 2 * OC * sizeof(double);      // 32 KiB actually used
         if (lds < need) lds = need;
-        const void *fn = npw == 4 ? (const void *)k_pulse_onsets_scan<4> : (npw == 2 ? (const void *)k_pulse_onsets_scan<2> : (const void *)k_pulse_onsets_scan<1>);
-        if (int arc = kernel_allow_max_lds(ctx, fn)) return arc;
-        if (npw == 4)
-            hipLaunchKernelGGL(k_pulse_onsets_scan<4>, dim3(blocks), dim3(64), lds, st, f0, (double)ctx->plan.sr, sample_off, n_notes, onset_idx, onset_cnt, overflow);
-        else if (npw == 2)
-            hipLaunchKernelGGL(k_pulse_onsets_scan<2>, dim3(blocks), dim3(128), lds, st, f0, (double)ctx->plan.sr, sample_off, n_notes, onset_idx, onset_cnt, overflow);
-        else
-            hipLaunchKernelGGL(k_pulse_onsets_scan<1>, dim3(blocks), dim3(256), lds, st, f0, (double)ctx->plan.sr, sample_off, n_notes, onset_idx, onset_cnt, overflow);
+        if (int arc = kernel_allow_max_lds(ctx, (const void *)k_pulse_onsets_scan<1>)) return arc;
+        hipLaunchKernelGGL(k_pulse_onsets_scan<1>, dim3(blocks), dim3(256), lds, st, f0, (double)ctx->plan.sr, sample_off, n_notes, onset_idx, onset_cnt, overflow);
         LAUNCH_CHECK(ctx);
     }
     hipLaunchKernelGGL(k_onset_finish, dim3(n_notes), dim3(64), 0, st, f0, sample_off, n_notes, (double)ctx->plan.sr, onset_idx,
                        onset_cnt, onsets);
     LAUNCH_CHECK(ctx);
-    if (total_samples > 0 && tiles && ctx->pulse_tiles && ((uintptr_t)tiles & 15) == 0) {
+    if (total_samples > 0 && tiles && ((uintptr_t)tiles & 15) == 0) {
         const unsigned n_tiles = (unsigned)((total_samples + 256 * PP_SPT - 1) / (256 * PP_SPT));
         hipLaunchKernelGGL(k_pulse_tiles, dim3((n_tiles + 63) / 64), dim3(64), 0, st, onsets, onset_cnt, sample_off, n_notes, total_samples,
                            (int)n_tiles, reinterpret_cast<int4 *>(tiles));
@@ -906,13 +896,13 @@ int launch_pulse_onsets(goofer_ctx *ctx, const float *f0, float f0_scale, const 
 }
 
 // tiles: the table launch_pulse_onsets made (4 ints per tile of 256 * PP_SPT samples), or nullptr: every
-// workgroup searches for itself (round 4's path, option "pulse_tiles" 0)
+// workgroup searches for itself (goofer_pulse_train with an unaligned scratch pointer)
 int launch_pulse_place(goofer_ctx *ctx, const onset_t *onsets, const int32_t *onset_cnt, const int64_t *sample_off, int n_notes,
                        int64_t total_samples, float *pulse, const int32_t *tiles, hipStream_t st)
 {
     if (total_samples <= 0) return GOOFER_OK;
     const unsigned n_tiles = (unsigned)((total_samples + 256 * PP_SPT - 1) / (256 * PP_SPT));
-    const int4 *tl = (ctx->pulse_tiles && tiles && ((uintptr_t)tiles & 15) == 0) ? reinterpret_cast<const int4 *>(tiles) : nullptr;
+    const int4 *tl = (tiles && ((uintptr_t)tiles & 15) == 0) ? reinterpret_cast<const int4 *>(tiles) : nullptr;
     hipLaunchKernelGGL(k_pulse_place, dim3(n_tiles), dim3(256), 0, st, onsets, onset_cnt, ctx->plan.pulse_peak, ctx->plan.pulse_shape,
                        sample_off, n_notes, total_samples, pulse, tl);
     LAUNCH_CHECK(ctx);

@@ -1075,7 +1075,6 @@ int launch_noise_stems(goofer_ctx *ctx, const float *env, int ld, const int64_t 
     constexpr int M = 512;
     const void *fn = phi ? (const void *)k_noise_stems<M, true> : (const void *)k_noise_stems<M, false>;
     size_t lds = stem_cfg<M>::lds_bytes<2, false>();
-    if (lds < (size_t)ctx->stem_lds_kb * 1024) lds = (size_t)ctx->stem_lds_kb * 1024;   // (tuning: fewer workgroups per CU)
     int rc, slots = 0;
     if ((rc = kernel_allow_max_lds(ctx, fn))) return rc;
     if ((rc = kernel_resident_waves(ctx, fn, lds, &slots))) return rc;
@@ -1108,7 +1107,6 @@ int launch_harm_stem(goofer_ctx *ctx, const float *pulse, const float *env, cons
     constexpr int M = 512;
     const void *fn = (const void *)k_harm_stem<M>;
     size_t lds = stem_cfg<M>::lds_bytes<3, true>();
-    if (lds < (size_t)ctx->stem_lds_kb * 1024) lds = (size_t)ctx->stem_lds_kb * 1024;
     int rc, slots = 0;
     if ((rc = kernel_allow_max_lds(ctx, fn))) return rc;
     if ((rc = kernel_resident_waves(ctx, fn, lds, &slots))) return rc;
@@ -1127,15 +1125,13 @@ int launch_note_finish(goofer_ctx *ctx, float *harm, float *uv, float *bre, floa
 {
     if (n_notes <= 0) return GOOFER_OK;
     // One 1024-thread workgroup fills a CU's register file (16 waves x 128 VGPRs), so its LDS is the workgroup's own: the first
-    // rows of the breath stem wait there between the passes (9 rows x 16 KB; option "finish_lds_kb": another size, 0 = none)
-    int rows = ctx->finish_lds_kb < 0 ? 0 : (ctx->finish_lds_kb == 0 ? 9 : ctx->finish_lds_kb / 16);
-    rows = rows > FIN_KEEP ? FIN_KEEP : rows;
-    if (rows * 16 * 1024 > 159 * 1024) rows = 9;
+    // rows of the breath stem wait there between the passes (9 rows x 16 KB)
+    const int rows = 9;
     const size_t lds = (size_t)rows * FIN_THREADS * sizeof(float4);
     if (lds > 48 * 1024)
         if (int arc = kernel_allow_max_lds(ctx, (const void *)k_note_finish, FIN_KEEP * FIN_THREADS * (int)sizeof(float4) > 159 * 1024 ? 159 * 1024 : FIN_KEEP * FIN_THREADS * (int)sizeof(float4))) return arc;   // (beside 64 B of static LDS)
     hipLaunchKernelGGL(k_note_finish, dim3((unsigned)n_notes), dim3(FIN_THREADS), lds, st, harm, uv, bre, rec, mix, sample_off, params,
-                       note_mag, note_peak, (write_stems ? 1 : 0) | ((ctx->nt_mask & 1) ? 2 : 0), rows);
+                       note_mag, note_peak, (write_stems ? 1 : 0) | 2 /* mix / rec: non-temporal stores */, rows);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

@@ -1,4 +1,4 @@
-// Shared pieces of the frame walkers (stems.hip: registers for the overlap-add, hop == n_fft / 4; stems_ring.hip: an LDS
+// Shared pieces of the frame walkers (stems.hip: registers for the overlap-add, hop == n_fft / 4; round 5's stems_ring.hip, removed: an LDS
 // ring, n_fft 2048 with any even hop): kernel arguments read where they are used, and the per-frame records of 64 frames.
 #pragma once
 #include "binops_core.h"

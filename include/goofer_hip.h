@@ -444,7 +444,7 @@ int goofer_profile_end(goofer_ctx *ctx, double *ms_per_stage, int n_stages);
 const char *goofer_profile_stage_name(int stage);
 const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage);   /* names of the path the last profiled batch took */
 
-/* Options (all exist for A/B parity runs; every setting but td_blur produces the same stems):
+/* Options (each is an A/B reference a parity test needs; every setting but td_blur and value_f64 produces the same stems):
  *   "fused_ola" 1 (default): irFFT of the three stems + overlap-add + gains in one kernel; 0: separate kernels
  *   "overlap"   1 (default): pulse chain on the handle's side stream beside the aperiodic branch; 0: one stream
  *   "stems"     1 (default): stem-split walker kernels where the geometry allows (hop == n_fft / 4); 0: one kernel per
@@ -453,16 +453,14 @@ const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage);   /*
  *               (the walkers decide per hop; the n_fft 2048 pipeline per frame up front); 0: every frame runs every transform
  *   "td_blur"   1 (default): the stem walkers fold the voiced frames' 5-tap bin blur into the synthesis window (agrees with
  *               0, the blur over the bins, to fp32 rounding — the only option that is not bit-identical)
- *   "f0_side"   1 (default): goofer_render_batch runs the f0 / mask kernel on the handle's side stream
  *   "pulse_scan" 1 (default): pulse onsets from a parallel fp64 phase scan wherever its rounding band provably cannot move
  *               floor(phase), the sequential walk only for the remaining notes; 0: the sequential walk for every note;
  *               2: the scan kernel walks every note (tests the hand-over)
- *   "value_f64" 0 (default): the assembly's VALUE arithmetic (tap blend, warp / fw interpolation, es blur, knot exp) in fp32 —
- *               everything that decides an index, a threshold or the pitch curve stays fp64; 1: round 4's
- *               fp64 arithmetic and gather kernel (agrees to 2e-8 sample-RMS on the 1024-note batch; not bit-identical)
+ *   "value_f64" 0 (default): k_env_edit's VALUE arithmetic (fw interpolation, es blur, knot exp) in fp32 — everything that
+ *               decides an index, a threshold or the pitch curve stays fp64; 1: round 4's fp64
+ *               arithmetic there (agrees to 2e-8 sample-RMS on the 1024-note batch; not bit-identical)
  *   "sa_fast"   1 (default): k_sample_assemble's branch-free path with all of a thread's loads in flight together; 0: per sample
- *   "pulse_tiles" 1 (default): the onset range of every placement tile from a kernel of its own; 0: per workgroup
- *   tuning knobs kept for A/B runs: "walk_lds_kb", "finish_lds_kb", "sa_spt", "walk_npw", "maps_side"       */
+ *   "prof_only" s >= 0: goofer_profile_begin .. end record the events of stage s only; -1 (default): every stage     */
 int goofer_set_option(goofer_ctx *ctx, const char *name, int value);
 
 /* Copy a plan table (0 window, 1 freqs, 2 boost, 3 bright_harm, 4 bright_breath, 5 pulse peak) or an

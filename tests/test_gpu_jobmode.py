@@ -140,6 +140,14 @@ def test_config5_frame_skipping_changes_no_bit():
         ctx.set_option("skip_zero", 1)
         for k in ("harm", "uv", "bre", "mix"):
             assert np.array_equal(outs[1][k], outs[0][k]), k
+        ctx.set_option("overlap", 0)                          # ... and everything on one stream (n_fft 2048: the spectra pipeline)
+        try:
+            o = r.run(prep, seed=5, keep_stems=True)
+            ctx.check()
+            for k in ("harm", "uv", "bre", "mix"):
+                assert np.array_equal(outs[1][k], o[k].cpu().numpy()), k
+        finally:
+            ctx.set_option("overlap", 1)
         uv, bre = outs[1]["uv"], outs[1]["bre"]
         assert np.isfinite(outs[1]["mix"]).all() and np.abs(uv).max() > 0 and np.abs(bre).max() > 0
         assert (uv == 0).mean() > 0.2 and (bre == 0).mean() > 0.02        # both kinds of silence occur

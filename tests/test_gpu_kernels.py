@@ -162,37 +162,6 @@ def test_pulse_train_many_random_notes_vs_oracle(ctx):
         o += n
 
 
-def test_pulse_walk_packed_notes_equal_one_note_per_wave(ctx):
-    """Option walk_npw: two / four notes per wave of the phase walk (a quarter-wave per note, scans inside DPP rows) give the
-    same pulse trains bit for bit as one note per wave — ragged lengths, a note count that is not a multiple of four,
-    knife-edge f0, negative and oversized increments."""
-    ctx.plan(44100, 1024, 256)
-    rng = np.random.default_rng(29)
-    f0s = []
-    for i in range(23):
-        n = int(rng.integers(30, 7000))
-        t = np.arange(n) / 44100
-        f = rng.uniform(60, 900) * 2 ** (rng.uniform(-0.5, 0.5) * np.sin(2 * np.pi * rng.uniform(1, 9) * t))
-        f[rng.uniform(size=n) < 0.02] = 0
-        if i % 5 == 0:
-            f[:] = [441.0, 220.5, 882.0, 110.25, 440.0][i // 5]
-        if i % 6 == 1:
-            f[int(rng.integers(0, n))] = 90000.0
-            f[n // 3:n // 3 + 20] = -500.0
-        f0s.append(f.astype(np.float32))
-    lens = [len(f) for f in f0s]
-    d_f0, off = ctx.tensor(np.concatenate(f0s)), _off(ctx, lens)
-    ref = ctx.pulse_train(d_f0, off).cpu().numpy()
-    assert np.abs(ref).max() > 0.1
-    try:
-        for npw in (2, 4):
-            ctx.set_option("walk_npw", npw)
-            got = ctx.pulse_train(d_f0, off).cpu().numpy()
-            assert np.array_equal(got, ref), npw
-    finally:
-        ctx.set_option("walk_npw", 0)
-
-
 def _onset_lists(c, lens):
     cnt = c.debug_fetch("onset_cnt")
     idx = c.debug_fetch("onset_idx")

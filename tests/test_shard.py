@@ -196,3 +196,25 @@ def test_eight_rank_dress_rehearsal_of_bench(argv):
     else:
         assert total == sum(syn.config_note_frames(3, i) for i in range(8 * 40)) and line["imbalance"] < 1.05
     assert abs(line["value"] - total * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+
+
+def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`bench.py --gpus 2` started WITHOUT torch.distributed.run (WORLD_SIZE unset) must not measure one rank and print
+    n_gpus 1: it starts the ranks itself as a child process, before anything touches a GPU, and exits with the child's status.
+    A WORLD_SIZE that contradicts --gpus is refused."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.join(here, "bench.py"), "--rehearse", "--gpus", "2", "--steps", "2", "--notes", "12"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=here)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and len(line["per_rank_frames"]) == 2
+    assert sum(line["per_rank_frames"]) == sum(syn.config_note_frames(3, i) for i in range(24))
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="1"), cwd=here)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
