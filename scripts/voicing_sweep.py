@@ -39,6 +39,6 @@ for rep in range(2):
 del wl
 for share in (0.1, 0.2, 0.4):
     wl = SamplerWorkload(ctx, 3, list(range(notes)), unvoiced_share=share)
-    voiced = float((wl.prep["mask"] > 0).float().mean())
+    voiced = float((wl.prep["f0"] > 0).float().mean())
     print(f"{share:.0%} of the source unvoiced in 50 ms gaps (assembled mask {voiced:.0%} voiced): {time_step(wl):.3f} ms")
     del wl
