@@ -1789,13 +1789,13 @@ int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *asmb, const goof
     // Lean hand-off (assemble.hip: lean_out): when the caller does not want the assembled mask itself (goofer_assembly.lean) and
     // nothing of this synthesis reads it per sample — no f0 / volume jitter, no sub-harmonic layer, f0 not rescaled — the f0 / mask
     // kernel writes the smoothed mask knots and the per-frame picks the synthesis needs, and mask_out stays unwritten.
-    ctx->lean_short = nullptr;
+    ctx->lean_want = false;
     ctx->lean_done = false;
     if (asmb->lean && ctx->lean_opt && ctx->overlap && asmb->f0_out == b->f0 && asmb->mask_out == b->mask && asmb->n_notes == b->n_notes &&
         asmb->n_notes > 0 && asmb->total_samples == b->total_samples && b->total_samples > 0 && b->unit_pitch_shift && !b->noise_f0 &&
         !b->noise_subharm && !(b->subharm_ratio > 0.0) && !(b->volume_vibrato != 0 || (b->noise_vol_h != nullptr && b->noise_vol_b != nullptr))) {
         if ((rc = ensure_mask_taps(ctx, b->transition_sigma))) return rc;
-        if (2 * ctx->mask_taps_radius + 256 <= 1152) {        // LEAN_MAXWIN
+        if (ctx->mask_taps_radius <= 128) {                   // LEAN_MAXR (assemble.hip): sigma / 4 = 25 -> radius 100
             const size_t short_bytes = (((size_t)b->total_samples / 4 + (size_t)b->n_notes + 16) * sizeof(double) + 255) & ~(size_t)255;
             const size_t need = short_bytes + ((size_t)b->total_frames + 16) * sizeof(float2);
             if (need > ctx->lean_buf_bytes) {
@@ -1809,11 +1809,12 @@ int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *asmb, const goof
             ctx->lean_short = reinterpret_cast<double *>(ctx->lean_buf);
             ctx->lean_picks = reinterpret_cast<float2 *>((char *)ctx->lean_buf + short_bytes);
             ctx->lean_frame_off = b->frame_off;
+            ctx->lean_want = true;
         }
     }
     rc = goofer_assemble_batch(ctx, asmb, stream);
     ctx->warp_out = nullptr;
-    ctx->lean_short = nullptr;
+    ctx->lean_want = false;
     if (!rc) rc = goofer_synth_batch(ctx, b, stream);
     ctx->warp_done = false;
     ctx->lean_done = false;

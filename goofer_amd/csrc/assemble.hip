@@ -818,7 +818,9 @@ struct lean_out {
     double tap_sum;              // their running fp64 sum in tap order
     int radius, hop;
 };
-#define LEAN_MAXWIN 1152         // floats of LDS: 256 knots of a tile + 2 * radius (radius <= 448)
+#define LEAN_MAXR 128            // largest filter radius the lean path takes (sigma / 4 = 25 -> radius 100: the reference's only setting)
+#define LEAN_MAXWIN (256 + 2 * LEAN_MAXR)   // floats of LDS: 256 knots of a tile + the radius on either side
+
 
 // voicing mask of output sample i: direct, or np.interp over the pre-velocity sequence at old_pos   :176-187, 787-788
 __device__ __forceinline__ double mask_value(const float *__restrict__ m, const goofer_note_plan &p, int i, float rd_tail)
@@ -858,24 +860,41 @@ __device__ __forceinline__ void lean_pick(const lean_out &L, const goofer_note_p
     if (i + hop == p.n_out) L.picks[f + 1] = make_float2(f0, mk);
 }
 
-// The smoothed knots q of one note whose samples 4 q lie in [i_a, i_b] (note-local, inside the tile), by the whole workgroup:
-// the window of decimated mask values (numpy 'reflect' at the note's ends) is evaluated from the plan into LDS, then every
-// wave takes 64 knots at a time — an all-zero / all-one window answers 0 / the tap sum without the tap loop, exactly as
-// k_mask_short (samples.hip) does on the written mask.
-__device__ __forceinline__ void lean_short_tile(const goofer_assembly &a, const lean_out &L, const goofer_note_plan &p, int note,
-                                                int i_a, int i_b, float *s_win, const double *s_taps)
+// The smoothed knots q of one note whose samples 4 q lie in [i_a, i_b] (note-local, inside the tile), by the whole workgroup.
+// lean_window_fill: the window of decimated mask values (numpy 'reflect' at the note's ends) evaluated from the plan into LDS;
+// lean_window_finish (behind a barrier): every wave takes 64 knots at a time — an all-zero / all-one window answers 0 / the
+// tap sum without the tap loop, exactly as k_mask_short (samples.hip) does on the written mask; the taps come through uniform
+// (scalar) loads, only where a window is neither.
+__device__ __forceinline__ int refl32(int q, int ns)
 {
-    const int n = p.n_out;
-    const int ns = (n + 3) >> 2;
-    const int q0 = (i_a + 3) >> 2, q1 = i_b >> 2;
-    const int len = q1 - q0 + 1;
+    if (ns <= 1) return 0;
+    const int period = 2 * (ns - 1);
+    if (q < 0 || q >= period) {
+        q %= period;
+        if (q < 0) q += period;
+    }
+    return q < ns ? q : period - q;
+}
+
+__device__ __forceinline__ void lean_window_fill(const goofer_assembly &a, const lean_out &L, const goofer_note_plan &p, int i_a, int i_b,
+                                                 float *s_win)
+{
+    const int ns = (p.n_out + 3) >> 2;
+    const int q0 = (i_a + 3) >> 2, len = (i_b >> 2) - q0 + 1;
     if (len <= 0) return;                                     // (workgroup-uniform)
-    const int radius = L.radius;
     const float *m = a.mask_src + p.src_sample_off;
     const float rd_tail = __builtin_amdgcn_rcpf((float)p.tail_len);
-    for (int w = threadIdx.x; w < len + 2 * radius; w += blockDim.x)
-        s_win[w] = (float)mask_value(m, p, 4 * (int)reflect_index((int64_t)q0 - radius + w, ns), rd_tail);
-    __syncthreads();
+    for (int w = threadIdx.x; w < len + 2 * L.radius; w += blockDim.x)
+        s_win[w] = (float)mask_value(m, p, 4 * refl32(q0 - L.radius + w, ns), rd_tail);
+}
+
+__device__ __forceinline__ void lean_window_finish(const lean_out &L, const goofer_note_plan &p, int note, int i_a, int i_b,
+                                                   const float *s_win)
+{
+    const int q0 = (i_a + 3) >> 2, len = (i_b >> 2) - q0 + 1;
+    if (len <= 0) return;
+    const int radius = L.radius;
+    const double *__restrict__ taps = L.taps;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double *out = L.short_s + (p.out_sample_off / 4 + note) + q0;
     for (int c0 = wv * WAVE; c0 < len; c0 += 4 * WAVE) {
@@ -897,7 +916,7 @@ __device__ __forceinline__ void lean_short_tile(const goofer_assembly &a, const 
             acc = 0.0;
             const float *x = x0 + lane;
             if (live)
-                for (int j = 0; j <= 2 * radius; ++j) acc += s_taps[j] * (double)x[j];
+                for (int j = 0; j <= 2 * radius; ++j) acc += taps[j] * (double)x[j];
         }
         if (live) out[c0 + lane] = acc;
     }
@@ -982,7 +1001,7 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
 // arithmetic).  Same operations on the same values: bit-identical to sample_assemble_one (tested through option "sa_fast" 0).
 template <int SA_SPT, bool LEAN>
 __device__ __forceinline__ void sample_assemble_fast(const goofer_assembly &a, const goofer_note_plan &p, int64_t g0, int64_t total_samples,
-                                                     const lean_out &L, int note)
+                                                     const lean_out &L, int note, float *s_win, int i_a, int i_b)
 {
     const float *__restrict__ m = a.mask_src + p.src_sample_off;
     const double *__restrict__ bend = a.bend + p.bend_off;
@@ -1024,7 +1043,22 @@ __device__ __forceinline__ void sample_assemble_fast(const goofer_assembly &a, c
         ja[u] = last ? nb1 : j;
         jb[u] = last ? nb1 : j + 1;
     }
-    float mv[SA_SPT];
+    // LEAN: the tile's window of decimated mask values for the smoothing (lean_window_fill, restated for the plain slice / tile
+    // case).  The tile's own knots are the mask values of its samples 4 q, which go to LDS as they are stored; the radius on either
+    // side is one more look-up for the first 2 * radius threads, issued here with the samples' own loads (it lands behind the
+    // fp64 curve arithmetic).
+    int hidx = 0, hw = -1;
+    const int lq0 = (i_a + 3) >> 2, llen = (i_b >> 2) - lq0 + 1;
+    if (LEAN && llen > 0 && (int)threadIdx.x < 2 * L.radius) {
+        const int ns = (p.n_out + 3) >> 2;
+        hw = (int)threadIdx.x < L.radius ? (int)threadIdx.x : llen + (int)threadIdx.x;   // window slot: left / right of the own knots
+        const int i = 4 * refl32(lq0 - L.radius + hw, ns);
+        uint32_t kk = (uint32_t)(i - n_pre);
+        if (tile) kk = mod_small_nb(kk, (uint32_t)tail_len, rd_tail);
+        const int idx = i < n_pre ? s_pre + i : s_tail + (int)kk;
+        hidx = rev ? ylen1 - idx : idx;
+    }
+    float mv[SA_SPT], hv = 0.f;
     double y0[SA_SPT], y1[SA_SPT];
 #pragma unroll
     for (int u = 0; u < SA_SPT; ++u) {
@@ -1032,6 +1066,7 @@ __device__ __forceinline__ void sample_assemble_fast(const goofer_assembly &a, c
         y0[u] = bend[ja[u]];
         y1[u] = bend[jb[u]];
     }
+    if (LEAN && hw >= 0) hv = fv ? 1.0f : m[hidx];
     float fo[SA_SPT];
 #pragma unroll
     for (int u = 0; u < SA_SPT; ++u) {
@@ -1049,9 +1084,14 @@ __device__ __forceinline__ void sample_assemble_fast(const goofer_assembly &a, c
         if (live[u]) {
             if (!LEAN) mask_out[g] = mv[u];
             f0_out[g] = fo[u];
-            if (LEAN) lean_pick(L, p, note, (int)(g - nbase), fo[u], mv[u]);
+            if (LEAN) {
+                const int i = (int)(g - nbase);
+                lean_pick(L, p, note, i, fo[u], mv[u]);
+                if ((i & 3) == 0) s_win[L.radius + (i >> 2) - lq0] = mv[u];
+            }
         }
     }
+    if (LEAN && hw >= 0) s_win[hw] = hv;
 }
 
 template <int SA_SPT, bool LEAN>
@@ -1059,13 +1099,9 @@ __global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a
 {
     __shared__ int s_pair[2];
     __shared__ float s_win[LEAN ? LEAN_MAXWIN : 1];
-    extern __shared__ __align__(16) unsigned char sa_smem[];   // LEAN: the 2 * radius + 1 taps
-    double *s_taps = reinterpret_cast<double *>(sa_smem);
     const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x * SA_SPT);
     int64_t gl = g0 + (int64_t)blockDim.x * SA_SPT - 1;
     if (gl > total_samples - 1) gl = total_samples - 1;
-    if (LEAN)
-        for (int k = threadIdx.x; k < 2 * L.radius + 1; k += blockDim.x) s_taps[k] = L.taps[k];
     if (threadIdx.x < WAVE) {
         // notes own [out_sample_off, out_sample_off + n_out): first wave searches the plan array cooperatively
         auto key = [&](int k) { return a.notes[k].out_sample_off; };
@@ -1079,15 +1115,19 @@ __global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a
         const goofer_note_plan &p = a.notes[n_lo];           // uniform note: the 300-byte plan comes in through scalar loads
         if (fast && !p.vel_active && p.fry_dir == 0 && !(p.pd_on && a.bend_out) && !a.f0_mul_out && p.n_out < (1 << 21) && p.tail_len < (1 << 24) &&
             p.tail_len > 0 && p.n_bend >= 1) {
-            sample_assemble_fast<SA_SPT, LEAN>(a, p, g0, total_samples, L, n_lo);
+            sample_assemble_fast<SA_SPT, LEAN>(a, p, g0, total_samples, L, n_lo, s_win, (int)(g0 - p.out_sample_off), (int)(gl - p.out_sample_off));
         } else {
 #pragma unroll
             for (int u = 0; u < SA_SPT; ++u) {
                 const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
                 if (g < total_samples) sample_assemble_one<LEAN>(a, p, g, L, n_lo);
             }
+            if (LEAN) lean_window_fill(a, L, p, (int)(g0 - p.out_sample_off), (int)(gl - p.out_sample_off), s_win);
         }
-        if (LEAN) lean_short_tile(a, L, p, n_lo, (int)(g0 - p.out_sample_off), (int)(gl - p.out_sample_off), s_win, s_taps);
+        if (LEAN) {
+            __syncthreads();
+            lean_window_finish(L, p, n_lo, (int)(g0 - p.out_sample_off), (int)(gl - p.out_sample_off), s_win);
+        }
     } else {
         for (int u = 0; u < SA_SPT; ++u) {
             const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
@@ -1103,7 +1143,9 @@ __global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a
                 const int64_t hi = gl < p.out_sample_off + p.n_out - 1 ? gl : p.out_sample_off + p.n_out - 1;
                 if (hi < lo) continue;
                 __syncthreads();                              // the previous note's window is no longer read
-                lean_short_tile(a, L, p, note, (int)(lo - p.out_sample_off), (int)(hi - p.out_sample_off), s_win, s_taps);
+                lean_window_fill(a, L, p, (int)(lo - p.out_sample_off), (int)(hi - p.out_sample_off), s_win);
+                __syncthreads();
+                lean_window_finish(L, p, note, (int)(lo - p.out_sample_off), (int)(hi - p.out_sample_off), s_win);
             }
         }
     }
@@ -1230,10 +1272,10 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         const int sa_fast = ctx->sa_fast ? 1 : 0;
         HIP_TRY(ctx, mark(2, 0, fst));
         lean_out L{};
-        if (ctx->lean_short) {                                  // goofer_render_batch set up the lean hand-off for this call
+        if (ctx->lean_want) {                                   // goofer_render_batch set up the lean hand-off for this call
             L.short_s = ctx->lean_short; L.picks = ctx->lean_picks; L.frame_off = ctx->lean_frame_off; L.taps = ctx->mask_taps;
             L.tap_sum = ctx->mask_taps_sum; L.radius = ctx->mask_taps_radius; L.hop = ctx->plan.hop;
-            hipLaunchKernelGGL((k_sample_assemble<spt, true>), sgrid, dim3(256), (2 * L.radius + 1) * sizeof(double), fst, *a, a->total_samples, sa_fast, L);
+            hipLaunchKernelGGL((k_sample_assemble<spt, true>), sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast, L);
             ctx->lean_done = true;
         } else {
             hipLaunchKernelGGL((k_sample_assemble<spt, false>), sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast, L);

@@ -87,7 +87,8 @@ struct goofer_ctx {
     bool lean_opt = true;                 // option "lean" (0: A/B — mask_out written, k_mask_short and the map kernel's picks as before)
     void *lean_buf = nullptr;
     size_t lean_buf_bytes = 0;
-    double *lean_short = nullptr;         // non-null for the duration of the assembly of a goofer_render_batch that goes lean
+    bool lean_want = false;               // set for the duration of the assembly of a goofer_render_batch that goes lean
+    double *lean_short = nullptr;         // the knots / picks / frame offsets of that call (inside lean_buf)
     float2 *lean_picks = nullptr;
     const int64_t *lean_frame_off = nullptr;
     bool lean_done = false;               // the assembly of the batch being synthesised wrote them

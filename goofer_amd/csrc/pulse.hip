@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_pulse_peak(float *__restrict__ peak, do
     __syncthreads();
     if (threadIdx.x == 0) peak[T0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     if (T0 == 0 && threadIdx.x == 0) {
-        double *tail = reinterpret_cast<double *>(peak + 8194);   // (pulse_value reads the model from here)
+        double *tail = reinterpret_cast<double *>(peak + 8194);   // (the model behind the table: goofer_debug_table and the tests read it; no kernel does)
         tail[0] = lf.ra; tail[1] = lf.rg; tail[2] = lf.rk;
     }
 }

@@ -14,7 +14,9 @@ import torch
 from . import _lib
 
 
-_ROW_ALIGN = max(4, int(__import__("os").environ.get("GOOFER_ROW_ALIGN", "4")))
+_ROW_ALIGN = int(__import__("os").environ.get("GOOFER_ROW_ALIGN", "4"))
+if _ROW_ALIGN < 4 or _ROW_ALIGN & (_ROW_ALIGN - 1):
+    raise ValueError("GOOFER_ROW_ALIGN must be a power of two >= 4 (floats per row are rounded up to it; the row kernels load 16 bytes at a time)")
 
 
 def row_stride(n_bins: int) -> int:

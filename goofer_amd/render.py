@@ -37,6 +37,20 @@ class Source:
     # An instance attribute once the sample is resident; a batch then finds its samples' table rows with one C-level pass over
     # the list (operator.attrgetter) instead of half a dozen Python loops over the sources.
     _reg_key = -1
+    _DERIVED = ("_reg_key", "_knot_rows", "_tracks64")
+
+    def __setattr__(self, name, value):
+        # a feature array re-assigned after the sample was registered: the arena's table row (K, T, ylen, the raw addresses of the
+        # track arrays) and the cached layouts describe the OLD arrays — forget them, the next batch registers the sample afresh
+        object.__setattr__(self, name, value)
+        if name in ("knots", "hz_knots", "mask", "formants", "sr", "ylen", "n_fft"):
+            for k in Source._DERIVED:
+                self.__dict__.pop(k, None)
+
+    def __getstate__(self):
+        # copy.copy / copy.deepcopy / pickle: a copy is another object with its own arrays — it must not inherit the original's
+        # arena key (whose table row holds host addresses of the ORIGINAL's track arrays) nor its cached layouts
+        return {k: v for k, v in self.__dict__.items() if k not in Source._DERIVED}
 
     def knot_rows(self) -> np.ndarray:
         """The knot table frame-major ([T, K] contiguous, flattened), the layout the device kernels index; made once per source
@@ -368,18 +382,26 @@ class SourceArena:
         n = len(sources)
         get = operator.attrgetter("_reg_key")
         with self.lock:
+            # The attribute is a HINT: a sample carries the key of one arena, and one that lives in several (two Renderers, one
+            # PipelinedRenderer per GPU on threads) is re-stamped by whichever saw it last.  A key is trusted only when it
+            # carries this epoch's token (rows are never re-used inside an epoch); every other row comes from this arena's own
+            # table under its lock, never from a second read of the shared attribute.
             keys = np.fromiter(map(get, sources), dtype=np.int64, count=n)
-            for _ in range(2):                                 # (a second round when placing the first misses started a new epoch)
-                miss = np.nonzero((keys >> 32) != self.token)[0] if n else ()
-                if not len(miss):
-                    break
+            token = self.token
+            miss = np.nonzero((keys >> 32) != token)[0] if n else ()
+            if len(miss):
                 ms = [sources[i] for i in miss]
                 self.place(ms, stg)                            # uploads the ones that are not resident (may start a new epoch)
-                # a sample carries the key of ONE arena; one that lives in several (two Renderers, two GPUs) is re-stamped from
-                # this arena's own table whenever it comes back
-                for sc in ms:
-                    object.__setattr__(sc, "_reg_key", (self.token << 32) | self.where[id(sc)][3])
-                keys = np.fromiter(map(get, sources), dtype=np.int64, count=n)
+                if self.token != token:
+                    # a new epoch: the rows behind the keys that matched are gone with the old one — place the whole batch here
+                    self.place(list(sources), stg)
+                    miss, ms = np.arange(n), sources
+                rows = np.fromiter((self.where[id(sc)][3] for sc in ms), dtype=np.int64, count=len(ms))
+                keys[miss] = (self.token << 32) | rows
+                for sc, k in zip(ms, keys[miss].tolist()):
+                    object.__setattr__(sc, "_reg_key", k)
+            if n and not bool(((keys >> 32) == self.token).all()):
+                raise RuntimeError("SourceArena.lookup: a sample's row belongs to another arena or epoch")
             return keys & 0xFFFFFFFF, dict(self.t), list(self.lerp_tabs), self.knots, self.mask
 
 
@@ -881,8 +903,13 @@ class PipelinedRenderer:
     ``coalesce`` (long jobs): that many consecutive batches of the caller are planned and rendered as ONE device batch and handed
     back one by one — the host's cost per batch is mostly per-call overhead of ~150 numpy operations under the interpreter lock,
     which the worker threads queue for (a ``prepare`` of 3.7 ms alone takes 6-10 ms beside three others); twice the notes per call
-    is half of that per note.  The notes keep the Philox ids of their own batch, so the audio is what the un-coalesced job
-    renders.  Batches handed over as ``RequestBatch`` objects are not merged.  The default 1 keeps a server's latency.
+    is half of that per note.  The notes keep the Philox ids of their own batch.  The audio is bit-identical to the un-coalesced
+    job's WHEN the merged batches take the same kernel path: the library picks some paths per device batch (a note with the 'sg'
+    layer or the volume jitter moves its whole device batch to the one-kernel-per-step pipeline, a fry note turns the fused
+    warp off), and those agree with the default path to fp32 rounding, not to the bit — so a note's last bits can depend on
+    the batches it was merged with (never beyond the 1e-4 parity bound).  Batches of another geometry or request type
+    (``Request`` objects / argument lists) start a new device batch; ``RequestBatch`` objects are not merged.  First-audio
+    latency grows with ``coalesce``.  The default 1 keeps a server's latency and per-batch path choice.
 
     ``render_iter`` yields ``(mix, sample_off)`` per batch, in order: ``mix`` is a float32 numpy view of the lane's pinned
     buffer, valid until ``depth`` more batches have been taken from the iterator (copy what must live longer)."""
@@ -960,7 +987,8 @@ class PipelinedRenderer:
                     group = []
                 yield [(j, b)]
                 continue
-            g = (b[0][0].sr, b[0][0].n_fft)                    # (a device batch shares sr / n_fft: batches of another geometry start a new one)
+            # a device batch shares sr / n_fft and one request type: batches of another geometry or kind start a new one
+            g = (b[0][0].sr, b[0][0].n_fft, isinstance(b[1][0], S.Request) if len(b[1]) else None)
             if group and g != geom:
                 yield group
                 group = []

@@ -96,6 +96,76 @@ def make_source(seed: int, sr: int = 44100, n_fft: int = 1024, hop: int = 256,
     }
 
 
+def make_hard_source(seed: int, sr: int = 44100, n_fft: int = 1024, hop: int = 256, seconds: float = 0.6,
+                     n_knots: int = 64) -> dict:
+    """A voicebank sample with what real ``.goofy`` files hold and ``make_source`` does not: 3-6 interior
+    voiced / unvoiced transitions of random length with short fp16 ramps between them and fractional mask plateaus
+    (GOOFER.py:556-569, 1131-1144, 1179-1183), formant frames that are 0 / NaN / negative / above Nyquist, tracks that cross and
+    one track in four that is invalid throughout (SillySampler.py:242-283, GOOFER.py:849-873), envelope frames 40 dB above / below
+    their neighbours and a band of near-zero bins.  Seeded like make_source; same dict layout."""
+    src = make_source(seed, sr, n_fft, hop, seconds, n_knots)
+    rng = np.random.default_rng((seed << 8) ^ 0x5EED)
+    n = src["y_len"]
+    T = 1 + n // hop
+    # voicing: alternating segments, the first one unvoiced or voiced at random
+    k = int(rng.integers(3, 7))
+    cuts = np.sort(rng.choice(np.arange(int(0.04 * n), int(0.97 * n)), size=k, replace=False))
+    mask = np.empty(n, dtype=np.float64)
+    level, a = float(rng.integers(0, 2)), 0
+    plateau = [0.25, 0.5, 0.7, 0.999, 1.0, 1.0]
+    for c in list(cuts) + [n]:
+        mask[a:c] = level if level == 0.0 else plateau[int(rng.integers(0, len(plateau)))]
+        level, a = (1.0 if level == 0.0 else 0.0), c
+    for c in cuts:                                             # half of the transitions are 3-20 ms linear ramps, not steps
+        if rng.random() < 0.5:
+            w = int(rng.uniform(0.003, 0.02) * sr)
+            lo, hi = max(0, c - w // 2), min(n, c + w // 2)
+            if hi - lo > 1:
+                mask[lo:hi] = np.linspace(mask[lo], mask[hi - 1], hi - lo)
+    mask = mask.astype(np.float16).astype(np.float32)
+    # formant tracks
+    formants = {kk: v.copy() for kk, v in src["formants"].items()}
+    for kk in (1, 2, 3, 4):
+        tr = formants[kk]
+        for bad in (0.0, np.nan, -120.0, 0.6 * sr, 30.0):
+            i0 = int(rng.integers(0, T))
+            tr[i0:i0 + int(rng.integers(1, 6))] = bad
+    a0 = int(rng.integers(0, max(1, T - 12)))
+    w = int(rng.integers(4, 12))
+    f1, f2 = formants[1][a0:a0 + w].copy(), formants[2][a0:a0 + w].copy()
+    formants[1][a0:a0 + w], formants[2][a0:a0 + w] = f2, f1      # crossing tracks
+    if seed % 4 == 0:
+        formants[int(rng.integers(1, 5))][:] = [np.nan, 0.0, 0.7 * sr][int(rng.integers(0, 3))]   # a track with no valid frame
+    # envelope: 40 dB frame-to-frame jumps, a band of near-zero bins
+    logk = src["env_pack"]["knot_vals_log"].astype(np.float64)
+    for _ in range(int(rng.integers(2, 5))):
+        t0 = int(rng.integers(0, T))
+        logk[:, t0:t0 + int(rng.integers(1, 4))] += np.log(100.0) * (1.0 if rng.random() < 0.5 else -1.0)
+    b0 = int(rng.integers(4, n_knots - 12))
+    t0 = int(rng.integers(0, max(1, T - 20)))
+    logk[b0:b0 + int(rng.integers(3, 10)), t0:t0 + int(rng.integers(5, 20))] += np.log(1e-6)
+    out = dict(src)
+    out["env_pack"] = dict(src["env_pack"], knot_vals_log=logk.astype(np.float16))
+    out["mask"] = mask
+    out["f0"] = (220.0 * mask).astype(np.float16).astype(np.float32)
+    out["formants"] = formants
+    return out
+
+
+HARD_FLAGS = ["t0g0", "fa30fb-20fc10fd-10fw50fst40fsta20fstb-20fstc10fstd-10V80B20U-30", "L0g-30fst-50", "L1fa-25fc20B40", "L2fb30U30",
+              "br40es-50fstd60", "br-40es60g40", "R1fa20fst30", "FV1fst40fa-30", "t-7g20fw-60", "L0es30fsta-40fb-30", "P50V70B-20fst60fc-20"]
+
+
+def hard_case(i: int) -> tuple:
+    """(source, request) of hard-source fixture ``i`` (tests/golden/sampler_hard_XX.npz; make_golden.gen_sampler_hard)."""
+    rng = np.random.default_rng(8800 + i)
+    src = make_hard_source(3000 + i, seconds=float(rng.uniform(0.35, 0.6)))
+    req = make_request(3000 + i, HARD_FLAGS[i % len(HARD_FLAGS)], length_ms=float(rng.integers(250, 900)), offset_ms=float(rng.integers(0, 60)),
+                       consonant_ms=float(rng.integers(20, 120)), cutoff_ms=float(rng.choice([-250, 30, 80])),
+                       velocity=float(rng.choice([70, 100, 100, 130])), volume=float(rng.integers(60, 111)))
+    return src, req
+
+
 def make_request(seed: int, flags: str, length_ms: float = 1000.0, offset_ms: float = 50.0,
                  consonant_ms: float = 100.0, cutoff_ms: float = 100.0, velocity: float = 100.0,
                  volume: float = 100.0, tempo: float = 120.0) -> dict:
@@ -172,10 +242,11 @@ def config_geometry(config: int) -> dict:
     return {"sr": 44100, "n_fft": 1024, "hop": 256}
 
 
-def config_note(config: int, i: int) -> tuple:
-    """(source, request, phi_seed) for note ``i`` of a BASELINE config (seeds 1000+i / 5000+i)."""
+def config_note(config: int, i: int, hard: bool = False) -> tuple:
+    """(source, request, phi_seed) for note ``i`` of a BASELINE config (seeds 1000+i / 5000+i).  ``hard``: the same request on
+    make_hard_source's version of the sample (parity tests; never the benchmark)."""
     geo = config_geometry(config)
-    src = make_source(1000 + i, geo["sr"], geo["n_fft"], geo["hop"])
+    src = (make_hard_source if hard else make_source)(1000 + i, geo["sr"], geo["n_fft"], geo["hop"])
     length = 1000.0
     if config == 4:
         rng = np.random.default_rng(9000 + i)

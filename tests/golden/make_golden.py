@@ -579,6 +579,31 @@ def gen_sampler_combos():
     save("combo_index", names=np.array(names))
 
 
+N_HARD = 12
+
+
+def gen_sampler_hard():
+    """Hard sources (synthetic.make_hard_source: interior V/UV transitions, fractional fp16 mask values, formant frames that are
+    0 / NaN / out of range / crossing, 40 dB envelope jumps, near-zero bins) through the real GooferResampler — what real .goofy
+    content does to the path, pinned by the reference itself."""
+    names = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for i in range(N_HARD):
+            src, req = syn.hard_case(i)
+            seed = 6800 + i
+            out, sr, cap, _ = _run_sampler(src, req, seed, tmp, legacy_seed=4800 + i)
+            ins, res = cap.calls[0]
+            name = "sampler_hard_%02d" % i
+            assert np.isfinite(out).all(), name
+            save(name, out=out, seed=np.array([seed, 4800 + i, 3000 + i]), args=np.array(syn.request_args(req)),
+                 seconds=np.array([src["y_len"] / src["sr"]]), n_calls=np.array([len(cap.calls)]),
+                 mask_new=ins["mask"], f0_new=ins["f0"].astype(np.float32), harm=res[1].astype(np.float32),
+                 uv=res[2].astype(np.float32), bre=res[3].astype(np.float32))
+            names.append(name)
+            print(name, req["flags"], "voiced share %.2f" % float((ins["mask"] > 0).mean()), "rms %.3f" % float(np.sqrt(np.mean(out ** 2))), flush=True)
+    save("sampler_hard_index", names=np.array(names))
+
+
 def gen_index_plans():
     """Loop-mode / slicing index plans, bit-exact: feed env[b,t] = t and mask[n] = n so the
     assembled arrays spell out which source frame / sample every output position came from."""
@@ -789,5 +814,6 @@ elif __name__ == "__main__":
     gen_index_plans()
     gen_sampler()
     gen_sampler_combos()
+    gen_sampler_hard()
     total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE))
     print("total fixture bytes: %.1f MB" % (total / 1e6))

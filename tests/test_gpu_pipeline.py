@@ -116,3 +116,67 @@ def test_device_pcm16_equals_the_wav_writers_arithmetic():
     for (a, oa), (b, ob) in zip(f32, i16):
         assert b.dtype == np.int16 and np.array_equal(oa, ob)
         assert np.array_equal(b, np.round(np.clip(a.astype(np.float64), -1.0, 1.0 - 1.0 / 32768) * 32768.0).astype(np.int16))
+
+
+def test_two_arenas_sharing_sources_from_two_threads():
+    """Source._reg_key holds the key of ONE arena.  Two Renderers (own handles, own arenas) render the same Source
+    objects from two threads with a 10 us switch interval: every lookup must return rows of ITS arena (checked inside
+    SourceArena.lookup) and every render must equal the single-threaded one bit for bit.  A copied Source registers afresh."""
+    import copy
+    import sys
+    import threading
+    from goofer_amd import sampler as S
+    from goofer_amd import synthetic as syn
+    from goofer_amd.device import Context
+    from goofer_amd.render import Renderer, Source
+    srcs, reqs = [], []
+    for i in range(24):
+        src, req, _ = syn.config_note(3, i)
+        srcs.append(Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]))
+        reqs.append(S.decode_request(*syn.request_args(req)))
+    jobs = list(zip(srcs, reqs))
+    ctxs = [Context(0), Context(0)]
+    try:
+        rs = [Renderer(c) for c in ctxs]
+        seeds = list(range(100, 124))                          # injected phases: a note's noise does not depend on its position
+        ref = [m.copy() for m in rs[0].render(jobs, phi_seeds=seeds)]
+        errs = []
+        where = {id(sc): j for j, sc in enumerate(srcs)}
+
+        def work(r, k):
+            try:
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    for it in range(12):
+                        rot = (it + k) % 5                      # different orders: different rows per arena
+                        sub, sd = jobs[rot:] + jobs[:rot], seeds[rot:] + seeds[:rot]
+                        outs = r.render(sub, phi_seeds=sd)
+                        for (sc, _), o in zip(sub, outs):
+                            if not np.array_equal(o, ref[where[id(sc)]]):
+                                errs.append((k, it))
+            except Exception as e:                            # noqa: BLE001
+                errs.append(repr(e))
+
+        old = sys.getswitchinterval()
+        sys.setswitchinterval(1e-5)
+        try:
+            ts = [threading.Thread(target=work, args=(rs[k], k)) for k in range(2)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+        finally:
+            sys.setswitchinterval(old)
+        assert not errs, errs[:3]
+        # a copy is another sample: it does not inherit the original's arena row
+        c2 = copy.copy(srcs[0])
+        assert c2._reg_key == -1 and srcs[0]._reg_key != -1
+        d2 = copy.deepcopy(srcs[1])
+        assert d2._reg_key == -1
+        (o,) = rs[0].render([(d2, reqs[1])], phi_seeds=[seeds[1]])
+        assert np.array_equal(o, ref[1])
+        srcs[2].mask = srcs[2].mask.copy()                     # re-assigned feature array: the registration is forgotten
+        assert srcs[2]._reg_key == -1
+    finally:
+        for c in ctxs:
+            c.close()

@@ -331,7 +331,8 @@ def test_random_flag_combinations_vs_oracle(renderer, case):
     from goofer_amd import sampler as S
     from oracle import sampler_ref as SR
     rng = np.random.default_rng(9000 + case)
-    src = syn.make_source(4000 + case, seconds=float(rng.uniform(0.3, 0.6)))
+    # every fourth case on a hard source (interior V/UV transitions, fractional mask, bad / crossing formant frames, 40 dB jumps)
+    src = (syn.make_hard_source if case % 4 == 3 else syn.make_source)(4000 + case, seconds=float(rng.uniform(0.3, 0.6)))
     flags = _random_flags(rng)
     pitch = ["A3", "C4", "E4", "G#4", "D5"][int(rng.integers(0, 5))]
     args = (pitch, str(int(rng.choice([60, 100, 140]))), flags, str(int(rng.integers(0, 60))), str(int(rng.integers(200, 700))),

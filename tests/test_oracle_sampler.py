@@ -186,3 +186,25 @@ def test_flag_combinations_against_reference(name):
     assert out.shape == ref.shape
     scale = max(1.0, float(np.max(np.abs(ref))))
     assert rms_err(out, ref) < 1e-5 * scale, (name, args[2], rms_err(out, ref), scale)
+
+
+HARD = [str(n) for n in golden("sampler_hard_index")["names"]]
+
+
+@pytest.mark.parametrize("name", HARD)
+def test_hard_sources_against_reference(name):
+    """Hard sources (synthetic.make_hard_source: 3-6 interior V/UV transitions with fp16 ramps and fractional plateaus, formant
+    frames that are 0 / NaN / negative / above Nyquist, crossing and all-invalid tracks, 40 dB envelope jumps, near-zero bins)
+    rendered by the reference itself: the oracle follows it through the full sampler path — assembled mask and f0 exactly, the
+    stems and the note to 1e-5 (SillySampler.py:242-283, GOOFER.py:556-569, 849-873, 1131-1144)."""
+    g = golden(name)
+    src, req = syn.hard_case(HARD.index(name))
+    args = [str(a) for a in g["args"]]
+    assert args == [str(a) for a in syn.request_args(req)] and abs(src["y_len"] / src["sr"] - float(g["seconds"][0])) < 1e-9
+    seed, legacy, _ = (int(v) for v in g["seed"])
+    np.random.seed(legacy)
+    out = S.render(_features(src), S.decode_request(*args), seed=seed)
+    ref = g["out"]
+    assert out.shape == ref.shape and np.isfinite(out).all()
+    scale = max(1.0, float(np.max(np.abs(ref))))
+    assert rms_err(out, ref) < 1e-5 * scale, (name, args[2], rms_err(out, ref), scale)
