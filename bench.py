@@ -419,39 +419,46 @@ def host_inclusive(wl, ctx, step_s):
     # the previous ones render, the mix of batch k - 1 crossing PCIe under step k.  The same 1024 argument lists and sources as
     # batch after batch (the sources resident, as in a job that renders a voicebank's samples thousands of times).
     from goofer_amd.render import PipelinedRenderer
-    rounds, lead, total = 32, 24, 120                          # one job of 120 batches per sample format; reported: the best window of 32
-                                                               # consecutive batches behind the first 24 (a job's first dozens of batches run
-                                                               # 4-8 ms: allocator pools filling, threads falling into step, and on a shared
-                                                               # host phases in which the planner threads do not get their cores) AND the
-                                                               # mean over everything behind the lead-in
-    pipe = PipelinedRenderer(torch.cuda.current_device(), hop=wl.geo["hop"], depth=2, workers=4, coalesce=4)
+    rounds, lead, total = 32, 24, 120                          # one job of 120 batches per setting; reported: the MEAN over everything
+                                                               # behind the first 24 batches (a job's first dozens run 4-8 ms: allocator
+                                                               # pools filling, threads falling into step); the best window of 32
+                                                               # consecutive batches rides along as a secondary figure only
+
+    def pipelined(coalesce):
+        pipe = PipelinedRenderer(torch.cuda.current_device(), hop=wl.geo["hop"], depth=2, workers=4, coalesce=coalesce)
+        try:
+            def job(pcm16):
+                stamps = []
+                for mix, off in pipe.render_iter(((srcs, args) for _ in range(total)), seed=0, note_ids=lambda k, n: ids, pcm16=pcm16):
+                    stamps.append(time.perf_counter())
+                assert len(stamps) == total and float(np.abs(mix).max()) > 0.0
+                s = np.asarray(stamps[lead - 1:])
+                win = float(np.min(s[rounds:] - s[:-rounds])) / rounds
+                return win, float(s[-1] - s[0]) / (s.size - 1)
+            w32, m32 = job(False)
+            w16, m16 = job(True)
+        finally:
+            pipe.close()
+        return {"coalesce": coalesce, "ms_per_batch": 1e3 * m32, "frames_per_s": frames / m32, "best_window_ms_per_batch": 1e3 * w32,
+                "pcm16": {"ms_per_batch": 1e3 * m16, "frames_per_s": frames / m16, "job_mean_ms_per_batch": 1e3 * m16,
+                          "job_mean_frames_per_s": frames / m16, "best_window_ms_per_batch": 1e3 * w16}}
+
     try:
-        def job(pcm16):
-            stamps = []
-            for mix, off in pipe.render_iter(((srcs, args) for _ in range(total)), seed=0, note_ids=lambda k, n: ids, pcm16=pcm16):
-                stamps.append(time.perf_counter())
-            assert len(stamps) == total and float(np.abs(mix).max()) > 0.0
-            s = np.asarray(stamps[lead - 1:])
-            win = float(np.min(s[rounds:] - s[:-rounds])) / rounds
-            return win, float(s[-1] - s[0]) / (s.size - 1)
-        dt, dt_job = job(False)
-        dt16, dt16_job = job(True)
+        p4 = pipelined(4)
+        p1 = pipelined(1)
     finally:
-        pipe.close()
         gc.unfreeze()
-    best["pipelined"] = {"ms_per_batch": 1e3 * dt, "frames_per_s": frames / dt, "batches": rounds,
-                         "job_mean_ms_per_batch": 1e3 * dt_job, "job_mean_frames_per_s": frames / dt_job, "job_batches": total - lead,
-                         "note": "goofer_amd.render.PipelinedRenderer(depth=2, workers=4, coalesce=4): the job's 1024-note batches, four of them planned and "
-                                 "rendered as one device batch and handed back one by one (same audio, half the host's per-call overhead "
-                                 "per note); 13 argument strings -> audio in pinned host memory, "
-                                 "two handles / streams with three batches in flight (the next step is queued on the device before the "
-                                 "previous audio is home), decode + planning of the next batches on four worker threads, D2H of the "
-                                 "previous mix on a copy stream under the running step; ms_per_batch = the best 32 consecutive batches of "
-                                 "a 120-batch job, job_mean = all of it behind the first 24",
-                         "pcm16": {"ms_per_batch": 1e3 * dt16, "frames_per_s": frames / dt16,
-                                   "job_mean_ms_per_batch": 1e3 * dt16_job, "job_mean_frames_per_s": frames / dt16_job,
-                                   "note": "the same with the mix converted to the wav's int16 samples on the device (goofer_pcm16: what the "
-                                           "reference's PCM_16 file holds): half the bytes over PCIe"}}
+    p4["job_batches"] = p1["job_batches"] = total - lead
+    p4["job_mean_ms_per_batch"], p4["job_mean_frames_per_s"] = p4["ms_per_batch"], p4["frames_per_s"]
+    p4["uncoalesced"] = p1
+    p4["note"] = ("goofer_amd.render.PipelinedRenderer(depth=2, workers=4): a job of 120 batches of 1024 notes, 13 argument strings -> audio in "
+                  "pinned host memory; two handles / streams with three batches in flight, decode + planning of the next batches on four "
+                  "worker threads, D2H of the previous mix on a copy stream under the running step.  ms_per_batch / frames_per_s = the MEAN "
+                  "over the job behind its first 24 batches (best_window_ms_per_batch: the best 32 consecutive batches, for reference "
+                  "only).  coalesce=4: four caller batches planned and rendered as one device batch and handed back one by one (first audio "
+                  "four batches later); `uncoalesced`: the same job with coalesce=1.  pcm16: the mix converted to the wav's int16 samples "
+                  "on the device (goofer_pcm16: what the reference's PCM_16 file holds), half the bytes over PCIe")
+    best["pipelined"] = p4
     best["note"] = ("serial, one host thread: 13 argument strings -> request columns (decode_request_batch), plans written by the library's "
                     "host planner into a pinned staging block + tables, one H2D copy (Renderer.prepare; the voicebank samples are resident "
                     "in HBM, see first_batch), device step, D2H of the mix into pinned memory; the best of three passes; the device step "
@@ -652,7 +659,7 @@ def main():
         ctx.set_option("skip_zero", 1)
         wl30 = SamplerWorkload(ctx, args.config, ids, unvoiced_share=0.3)
         ms_30 = timed(wl30, args.steps)
-        voiced30 = float((wl30.prep["f0"] > 0).float().mean())   # (f0 = mask x pitch curve; the mask itself is not written: lean hand-off)
+        voiced30 = float((wl30.prep["f0"] > 0).float().mean())
         variants = {"skip_zero_off": {"value": my_frames / (ms_off * 1e-3), "ms_per_step": ms_off,
                                       "what": "option skip_zero = 0: no transform is skipped (one rFFT + three irFFT-OLA on every frame)"},
                     "unvoiced_30pct": {"value": wl30.frames / (ms_30 * 1e-3), "ms_per_step": ms_30, "voiced_share_of_samples": voiced30,

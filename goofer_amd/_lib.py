@@ -78,7 +78,7 @@ class Assembly(C.Structure):
         ("tilts", C.c_void_p), ("es_taps", C.c_void_p), ("fw_lo", C.c_void_p), ("fw_hi", C.c_void_p), ("fw_frac", C.c_void_p),
         ("tap_idx", C.c_void_p), ("tap_w", C.c_void_p), ("fst_tracks", C.c_void_p), ("mask_src", C.c_void_p), ("bend", C.c_void_p),
         ("edit_rows", C.c_void_p), ("env_out", C.c_void_p), ("f0_out", C.c_void_p), ("mask_out", C.c_void_p),
-        ("bend_out", C.c_void_p), ("any_fry", C.c_int32), ("lean", C.c_int32),
+        ("bend_out", C.c_void_p), ("any_fry", C.c_int32), ("reserved5", C.c_int32),
         ("f0_mul", C.c_void_p), ("f0_mul_out", C.c_void_p),
     ]
 

@@ -446,7 +446,6 @@ void goofer_destroy(goofer_ctx *ctx)
     if (ctx->asm_scratch) (void)hipFree(ctx->asm_scratch);
     if (ctx->mask_taps) (void)hipFree(ctx->mask_taps);
     if (ctx->warp_rows) (void)hipFree(ctx->warp_rows);
-    if (ctx->lean_buf) (void)hipFree(ctx->lean_buf);
     if (ctx->ovf_flag) (void)hipFree(ctx->ovf_flag);
     for (int i = 0; i < ctx->prof_cap * (PROF_STAGES + 1); ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
     free(ctx->prof_ev);
@@ -732,7 +731,7 @@ int goofer_counter(goofer_ctx *ctx, const char *name, int64_t *value)
 
 int64_t goofer_debug_fetch(goofer_ctx *ctx, int which, void *host_out, int64_t capacity_bytes)
 {
-    if (!ctx || which < 0 || which >= 18 || !ctx->dbg_ptr[which]) return GOOFER_EINVAL;
+    if (!ctx || which < 0 || which >= 16 || !ctx->dbg_ptr[which]) return GOOFER_EINVAL;
     if (int rc = goofer_check(ctx)) return rc;
     size_t nb = ctx->dbg_bytes[which] < (size_t)capacity_bytes ? ctx->dbg_bytes[which] : (size_t)capacity_bytes;
     if (hipMemcpy(host_out, ctx->dbg_ptr[which], nb, hipMemcpyDeviceToHost) != hipSuccess) return GOOFER_EHIP;
@@ -849,7 +848,6 @@ int goofer_set_option(goofer_ctx *ctx, const char *name, int value)
     if (!strcmp(name, "pulse_scan")) { ctx->pulse_scan = value < 0 ? 0 : (value > 2 ? 2 : value); return GOOFER_OK; }
     if (!strcmp(name, "sa_fast")) { ctx->sa_fast = value != 0; return GOOFER_OK; }
     if (!strcmp(name, "value_f64")) { ctx->value_f64 = value != 0; return GOOFER_OK; }
-    if (!strcmp(name, "lean")) { ctx->lean_opt = value != 0; return GOOFER_OK; }
     return goofer_fail(ctx, GOOFER_EINVAL, "unknown option %s", name);
 }
 
@@ -914,7 +912,7 @@ int goofer_pulse_train(goofer_ctx *ctx, const float *f0, const int64_t *sample_o
     int32_t *cnt = a.take<int32_t>(n_notes + 16);
     int32_t *ovf = ctx->ovf_flag;
     if (!inc || !onsets || !oidx || !cnt) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
-    for (int i = 0; i < 18; ++i) ctx->dbg_ptr[i] = nullptr;
+    for (int i = 0; i < 16; ++i) ctx->dbg_ptr[i] = nullptr;
     ctx->dbg_ptr[13] = cnt; ctx->dbg_bytes[13] = n_notes * sizeof(int32_t);
     ctx->dbg_ptr[14] = oidx; ctx->dbg_bytes[14] = (total_samples / 2 + 16 * (size_t)n_notes) * sizeof(int32_t);
     return launch_pulse_train(ctx, f0, 1.0f, sample_off, n_notes, total_samples, pulse, inc, (onset_t *)onsets, oidx, cnt, ovf, st);
@@ -1307,26 +1305,6 @@ int goofer_post_batch(goofer_ctx *ctx, const goofer_post *p, void *stream)
                            p->mix, st);
 }
 
-// mask-smoothing taps for a call's sigma (GOOFER.py:561); device copy cached on the handle (steady state: no host work, no
-// synchronisation)
-static int ensure_mask_taps(goofer_ctx *ctx, float transition_sigma)
-{
-    if (ctx->mask_taps_sigma == transition_sigma && ctx->mask_taps) return GOOFER_OK;
-    std::vector<double> mtaps;
-    int mrad;
-    gauss_taps_host(std::max(1.0, (double)transition_sigma / 4.0), mtaps, mrad);
-    if (mrad > 2048) return goofer_fail(ctx, GOOFER_EINVAL, "transition sigma too large");
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    if (!ctx->mask_taps) HIP_TRY(ctx, hipMalloc((void **)&ctx->mask_taps, 4097 * sizeof(double)));
-    HIP_TRY(ctx, hipMemcpy(ctx->mask_taps, mtaps.data(), mtaps.size() * sizeof(double), hipMemcpyHostToDevice));
-    ctx->mask_taps_sigma = transition_sigma;
-    ctx->mask_taps_radius = mrad;
-    double acc = 0.0;
-    for (double tv : mtaps) acc += tv * 1.0;
-    ctx->mask_taps_sum = acc;
-    return GOOFER_OK;
-}
-
 static int ensure_side_stream(goofer_ctx *ctx)
 {
     if (ctx->side) return GOOFER_OK;
@@ -1431,7 +1409,22 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         ctx->dbg_ptr[15] = frame_skip; ctx->dbg_bytes[15] = frame_skip ? (size_t)F : 0;   // per frame: bit 0 unvoiced, bit 1 breath transform skipped
     }
 
-    if ((rc = ensure_mask_taps(ctx, b->transition_sigma))) return rc;
+    // mask-smoothing taps for this call's sigma; device copy cached on the handle (steady state:
+    // no host work, no synchronisation)
+    if (ctx->mask_taps_sigma != b->transition_sigma || !ctx->mask_taps) {
+        std::vector<double> mtaps;
+        int mrad;
+        gauss_taps_host(std::max(1.0, (double)b->transition_sigma / 4.0), mtaps, mrad);   // GOOFER.py:561
+        if (mrad > 2048) return goofer_fail(ctx, GOOFER_EINVAL, "transition sigma too large");
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        if (!ctx->mask_taps) HIP_TRY(ctx, hipMalloc((void **)&ctx->mask_taps, 4097 * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpy(ctx->mask_taps, mtaps.data(), mtaps.size() * sizeof(double), hipMemcpyHostToDevice));
+        ctx->mask_taps_sigma = b->transition_sigma;
+        ctx->mask_taps_radius = mrad;
+        double acc = 0.0;
+        for (double tv : mtaps) acc += tv * 1.0;
+        ctx->mask_taps_sum = acc;
+    }
     const double *d_mtaps = ctx->mask_taps;
     const int mrad = ctx->mask_taps_radius;
 
@@ -1474,14 +1467,6 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         f0s = const_cast<float *>(b->f0);
         ctx->dbg_ptr[2] = f0s;
     }
-    // goofer_render_batch, lean hand-off: the assembly's f0 / mask kernel already wrote the smoothed mask knots and the per-frame
-    // picks (assemble.hip: lean_out) — no k_mask_short, no pick gathers, and b->mask was never written
-    const bool lean = ctx->lean_done && f0_alias && !jit_vol && !sub_on;
-    if (lean) {
-        short_s = ctx->lean_short;
-        picks = ctx->lean_picks;
-        ctx->dbg_ptr[10] = short_s;
-    }
     // goofer_render_batch ran the f0 / mask kernel on the side stream: the caller's stream reads them from here on
     if (ctx->f0_on_side) {
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_f0, 0));
@@ -1511,15 +1496,13 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     // nothing jitters it in place later, and it is not being produced on the side stream
     const bool picks_on = !jit_f0 && !sub_jit && !(early && !f0_alias);
     ctx->frame_picks = picks_on ? picks : nullptr;
-    float2 *picks_w = (picks_on && !lean) ? picks : nullptr;   // what the map kernel fills (lean: they are there already)
-    ctx->dbg_ptr[16] = picks; ctx->dbg_bytes[16] = (size_t)F * sizeof(float2);
     if (maps_fused) {
         const int64_t threads = std::max<int64_t>(F, 2 * (int64_t)n);
         hipLaunchKernelGGL(k_frame_maps, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, b->frame_off, b->env_off, n, F, frame_note,
-                           row_src, b->sample_off, (const float *)f0s, b->mask, p.hop, picks_w, note_steps, note_mag);
+                           row_src, b->sample_off, (const float *)f0s, b->mask, p.hop, picks_on ? picks : (float2 *)nullptr, note_steps, note_mag);
     } else {
         hipLaunchKernelGGL(k_row_src, dim3(fb), dim3(256), 0, st, b->frame_off, b->env_off, frame_note, F, row_src, b->sample_off,
-                           (const float *)f0s, b->mask, p.hop, picks_w);
+                           (const float *)f0s, b->mask, p.hop, picks_on ? picks : (float2 *)nullptr);
     }
     LAUNCH_CHECK(ctx);
     if (jit_f0 || jit_vol) {
@@ -1539,7 +1522,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     auto stems_aperiodic = [&]() -> int {
         int r2;
         if (!picks_on && (r2 = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return r2;
-        if (!lean && (r2 = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return r2;
+        if ((r2 = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return r2;
         if (side_on) MARK_Q(0);
         if (!maps_fused && (r2 = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return r2;
         if ((r2 = launch_noise_stems(ctx, b->env_noise ? b->env_noise : b->env, ld, row_src, b->phi, F, frame_note, b->frame_off,
@@ -1600,7 +1583,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         } else {
             // (the skip bits need the smoothed mask: it goes first then)
             if (skip_frames) {
-                if (!lean && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
+                if ((rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
                 if ((rc = launch_frame_skip(ctx, short_s, N / 4 + n, b->sample_off, b->frame_off, frame_note, n, F, knot_eq, hop_flat, frame_skip, st))) return rc;
             }
             if ((rc = launch_noise_spectra(ctx, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, f0s, b->mask,
@@ -1608,7 +1591,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                                            b->env_noise != nullptr, frame_skip, st)))
                 return rc;
             MARK_Q(0);
-            if (!skip_frames && !lean && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
+            if (!skip_frames && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
             MARK_Q(1);
         }
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
@@ -1637,7 +1620,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     }
     if (stem_path) {
         MARK();   // 6: mask_short, 7: noise_stems (here when nothing runs beside the pulse chain)
-        if (!side_on && !lean && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
+        if (!side_on && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
         MARK();
         if (!side_on) {
             if (!picks_on && (rc = launch_frame_picks(ctx, b->frame_off, frame_note, F, b->sample_off, f0s, b->mask, picks, st))) return rc;
@@ -1693,7 +1676,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if (!ola_one && (rc = launch_irfft_frames(ctx, S_uv, ldc, F, frames_u, st))) return rc;
     }
     MARK();   // 12: decimated + smoothed voicing mask
-    if (!side_on && !lean && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
+    if (!side_on && (rc = launch_mask_short(ctx, b->mask, b->sample_off, n, N, d_mtaps, mrad, ctx->mask_taps_sum, short_s, st))) return rc;
     MARK();   // 13: (irFFT of the three stems +) overlap-add + gains + per-note peak, one pass
     if (ola_split) {
         if ((rc = launch_irfft_ola1(ctx, S_h, S_uv, S_br, ldc, F, frame_note, b->frame_off, b->sample_off, n, short_s, note_steps,
@@ -1786,38 +1769,10 @@ int goofer_render_batch(goofer_ctx *ctx, const goofer_assembly *asmb, const goof
         ctx->warp_params = b->params;
         ctx->warp_out = ctx->warp_rows;
     }
-    // Lean hand-off (assemble.hip: lean_out): when the caller does not want the assembled mask itself (goofer_assembly.lean) and
-    // nothing of this synthesis reads it per sample — no f0 / volume jitter, no sub-harmonic layer, f0 not rescaled — the f0 / mask
-    // kernel writes the smoothed mask knots and the per-frame picks the synthesis needs, and mask_out stays unwritten.
-    ctx->lean_want = false;
-    ctx->lean_done = false;
-    if (asmb->lean && ctx->lean_opt && ctx->overlap && asmb->f0_out == b->f0 && asmb->mask_out == b->mask && asmb->n_notes == b->n_notes &&
-        asmb->n_notes > 0 && asmb->total_samples == b->total_samples && b->total_samples > 0 && b->unit_pitch_shift && !b->noise_f0 &&
-        !b->noise_subharm && !(b->subharm_ratio > 0.0) && !(b->volume_vibrato != 0 || (b->noise_vol_h != nullptr && b->noise_vol_b != nullptr))) {
-        if ((rc = ensure_mask_taps(ctx, b->transition_sigma))) return rc;
-        if (ctx->mask_taps_radius <= 128) {                   // LEAN_MAXR (assemble.hip): sigma / 4 = 25 -> radius 100
-            const size_t short_bytes = (((size_t)b->total_samples / 4 + (size_t)b->n_notes + 16) * sizeof(double) + 255) & ~(size_t)255;
-            const size_t need = short_bytes + ((size_t)b->total_frames + 16) * sizeof(float2);
-            if (need > ctx->lean_buf_bytes) {
-                HIP_TRY(ctx, hipDeviceSynchronize());
-                if (ctx->lean_buf) HIP_TRY(ctx, hipFree(ctx->lean_buf));
-                ctx->lean_buf = nullptr;
-                ctx->lean_buf_bytes = 0;
-                HIP_TRY(ctx, hipMalloc((void **)&ctx->lean_buf, need + need / 4));
-                ctx->lean_buf_bytes = need + need / 4;
-            }
-            ctx->lean_short = reinterpret_cast<double *>(ctx->lean_buf);
-            ctx->lean_picks = reinterpret_cast<float2 *>((char *)ctx->lean_buf + short_bytes);
-            ctx->lean_frame_off = b->frame_off;
-            ctx->lean_want = true;
-        }
-    }
     rc = goofer_assemble_batch(ctx, asmb, stream);
     ctx->warp_out = nullptr;
-    ctx->lean_want = false;
     if (!rc) rc = goofer_synth_batch(ctx, b, stream);
     ctx->warp_done = false;
-    ctx->lean_done = false;
     if (ctx->f0_on_side) {                                    // (the synthesis returned before it placed the wait)
         (void)hipStreamWaitEvent(st, ctx->ev_f0, 0);
         ctx->f0_on_side = false;

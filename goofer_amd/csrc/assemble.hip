@@ -804,132 +804,29 @@ __device__ __forceinline__ double exp2_poly(double x)
     return ldexp(q, (int)n);
 }
 
-// Lean hand-off of goofer_render_batch (round 6).  What the synthesis reads of the assembled voicing mask is two things: the
-// decimated, Gaussian-smoothed mask (smooth_mask_ds, GOOFER.py:556-562: mask[::4], sigma / 4, fp64) that the walkers upsample
-// into the stem gains, and one (f0, mask) pick per frame (GOOFER.py:1104-1106).  With `lean` the f0 / mask kernel writes those
-// itself — a tile's decimated window plus the filter's radius on either side is re-evaluated from the plan (a fifth more mask
-// look-ups) — and the per-sample mask array is neither written nor read again: k_mask_short and the picks' gathers leave the
-// step.  Same values, same tap order: bit-identical to k_mask_short over mask_out (tested through option "lean" 0).
-struct lean_out {
-    double *short_s;             // [total_samples / 4 + n_notes + ..] note k's knots at short_base = out_sample_off / 4 + k
-    float2 *picks;               // [total_frames] (f0, mask) at sample t * hop of the frame's note, edge-padded
-    const int64_t *frame_off;    // [n_notes + 1]
-    const double *taps;          // 2 * radius + 1 Gaussian taps
-    double tap_sum;              // their running fp64 sum in tap order
-    int radius, hop;
-};
-#define LEAN_MAXR 128            // largest filter radius the lean path takes (sigma / 4 = 25 -> radius 100: the reference's only setting)
-#define LEAN_MAXWIN (256 + 2 * LEAN_MAXR)   // floats of LDS: 256 knots of a tile + the radius on either side
-
-
-// voicing mask of output sample i: direct, or np.interp over the pre-velocity sequence at old_pos   :176-187, 787-788
-__device__ __forceinline__ double mask_value(const float *__restrict__ m, const goofer_note_plan &p, int i, float rd_tail)
+__device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, const goofer_note_plan &p, int64_t g)
 {
+    const int i = (int)(g - p.out_sample_off);
+    const float *m = a.mask_src + p.src_sample_off;
+    const float rd_tail = __builtin_amdgcn_rcpf((float)p.tail_len);   // per note
+
+    // voicing mask: direct, or np.interp over the pre-velocity sequence at old_pos   :176-187, 787-788
+    double mk;
     if (p.vel_active) {
         const double pos = i < p.pre_new ? (double)i / p.vel_factor : (double)(i - p.pre_new) + (double)p.n_pre;
         const int n1 = p.n_before_vel;
         int j = pos >= 2147483647.0 ? n1 - 1 : (int)floor(pos);
         if (j > n1 - 1) j = n1 - 1;
         if (j < 0) j = 0;
-        if (j >= n1 - 1) return mask_stage1(m, p, n1 - 1, rd_tail);
-        const double y0 = mask_stage1(m, p, j, rd_tail), y1 = mask_stage1(m, p, j + 1, rd_tail);
-        return pos == (double)j ? y0 : (y1 - y0) * (pos - (double)j) + y0;
-    }
-    return mask_stage1(m, p, i, rd_tail);
-}
-
-// the frame(s) whose pick is output sample i of the note: t = i / hop when hop divides i — and the note's last frame too when
-// its own sample lies past the end (n a multiple of hop: x[::hop] edge-padded repeats the last pick, GOOFER.py:1104-1106)
-__device__ __forceinline__ void lean_pick(const lean_out &L, const goofer_note_plan &p, int note, int i, float f0, float mk)
-{
-    const int hop = L.hop;
-    int t;
-    if (i < (1 << 21) && hop < (1 << 24)) {                   // float quotient estimate + one correction (see mod_small)
-        t = (int)((float)i * __builtin_amdgcn_rcpf((float)hop));
-        int qd;
-        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(qd) : "v"(t), "v"(hop));
-        const int r = i - qd;
-        t += r < 0 ? -1 : (r >= hop ? 1 : 0);
-        if (r != 0 && r != hop && r != -hop) return;
-    } else {
-        t = i / hop;
-        if (t * hop != i) return;
-    }
-    const int64_t f = L.frame_off[note] + t;
-    L.picks[f] = make_float2(f0, mk);
-    if (i + hop == p.n_out) L.picks[f + 1] = make_float2(f0, mk);
-}
-
-// The smoothed knots q of one note whose samples 4 q lie in [i_a, i_b] (note-local, inside the tile), by the whole workgroup.
-// lean_window_fill: the window of decimated mask values (numpy 'reflect' at the note's ends) evaluated from the plan into LDS;
-// lean_window_finish (behind a barrier): every wave takes 64 knots at a time — an all-zero / all-one window answers 0 / the
-// tap sum without the tap loop, exactly as k_mask_short (samples.hip) does on the written mask; the taps come through uniform
-// (scalar) loads, only where a window is neither.
-__device__ __forceinline__ int refl32(int q, int ns)
-{
-    if (ns <= 1) return 0;
-    const int period = 2 * (ns - 1);
-    if (q < 0 || q >= period) {
-        q %= period;
-        if (q < 0) q += period;
-    }
-    return q < ns ? q : period - q;
-}
-
-__device__ __forceinline__ void lean_window_fill(const goofer_assembly &a, const lean_out &L, const goofer_note_plan &p, int i_a, int i_b,
-                                                 float *s_win)
-{
-    const int ns = (p.n_out + 3) >> 2;
-    const int q0 = (i_a + 3) >> 2, len = (i_b >> 2) - q0 + 1;
-    if (len <= 0) return;                                     // (workgroup-uniform)
-    const float *m = a.mask_src + p.src_sample_off;
-    const float rd_tail = __builtin_amdgcn_rcpf((float)p.tail_len);
-    for (int w = threadIdx.x; w < len + 2 * L.radius; w += blockDim.x)
-        s_win[w] = (float)mask_value(m, p, 4 * refl32(q0 - L.radius + w, ns), rd_tail);
-}
-
-__device__ __forceinline__ void lean_window_finish(const lean_out &L, const goofer_note_plan &p, int note, int i_a, int i_b,
-                                                   const float *s_win)
-{
-    const int q0 = (i_a + 3) >> 2, len = (i_b >> 2) - q0 + 1;
-    if (len <= 0) return;
-    const int radius = L.radius;
-    const double *__restrict__ taps = L.taps;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double *out = L.short_s + (p.out_sample_off / 4 + note) + q0;
-    for (int c0 = wv * WAVE; c0 < len; c0 += 4 * WAVE) {
-        const float *x0 = s_win + c0;
-        const int cl = len - c0 < WAVE ? len - c0 : WAVE;
-        const bool live = lane < cl;
-        bool all0 = true, all1 = true;
-        for (int w = lane; w < cl + 2 * radius; w += WAVE) {
-            const float v = x0[w];
-            all0 &= v == 0.0f;
-            all1 &= v == 1.0f;
-        }
-        double acc;
-        if (__all(all0)) {
-            acc = 0.0;
-        } else if (__all(all1)) {
-            acc = L.tap_sum;
+        if (j >= n1 - 1) {
+            mk = mask_stage1(m, p, n1 - 1, rd_tail);
         } else {
-            acc = 0.0;
-            const float *x = x0 + lane;
-            if (live)
-                for (int j = 0; j <= 2 * radius; ++j) acc += taps[j] * (double)x[j];
+            const double y0 = mask_stage1(m, p, j, rd_tail), y1 = mask_stage1(m, p, j + 1, rd_tail);
+            mk = pos == (double)j ? y0 : (y1 - y0) * (pos - (double)j) + y0;
         }
-        if (live) out[c0 + lane] = acc;
+    } else {
+        mk = mask_stage1(m, p, i, rd_tail);
     }
-}
-
-template <bool LEAN>
-__device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, const goofer_note_plan &p, int64_t g, const lean_out &L, int note)
-{
-    const int i = (int)(g - p.out_sample_off);
-    const float *m = a.mask_src + p.src_sample_off;
-    const float rd_tail = __builtin_amdgcn_rcpf((float)p.tail_len);   // per note
-
-    const double mk = mask_value(m, p, i, rd_tail);
 
     // pitch curve: bend cents/100 + MIDI (+t), ticks of 60/(tempo*96) s, clamped linear interpolation
     const double *bend = a.bend + p.bend_off;                // MIDI semitones per tick, built on the host like the reference
@@ -968,7 +865,7 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
         }
     }
     const double hz = 440.0 * exp2_poly(div_by(midi - 69.0, 12.0, 0.083333333333333329));   // RN(1/12)
-    if (!LEAN) a.mask_out[g] = (float)mk;
+    a.mask_out[g] = (float)mk;
     double f0 = mk * hz;
     if (p.pd_on && a.bend_out) a.bend_out[g] = (float)(midi - p.pd_base);                    // 'pd' bend in semitones   :861-863
     // vocal fry part 1: f0 pulled to fry_hz over a constant stretch plus a linear glide       :883-934
@@ -986,7 +883,6 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
     }
     a.f0_out[g] = (float)f0;
     if (a.f0_mul_out) a.f0_mul_out[g] = (float)(f0 * a.f0_mul[g]);                           // 'sj' layer f0, one rounding   :1065
-    if (LEAN) lean_pick(L, p, note, i, (float)f0, (float)mk);
 }
 
 
@@ -999,9 +895,8 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
 // fp64 curve, 2^x and the stores.  sample_assemble_one does the same per sample with a branch at every decision, so the
 // thread's samples wait out their round trips to memory one after the other (k_sample_assemble was 0.31 ms alone for the same
 // arithmetic).  Same operations on the same values: bit-identical to sample_assemble_one (tested through option "sa_fast" 0).
-template <int SA_SPT, bool LEAN>
-__device__ __forceinline__ void sample_assemble_fast(const goofer_assembly &a, const goofer_note_plan &p, int64_t g0, int64_t total_samples,
-                                                     const lean_out &L, int note, float *s_win, int i_a, int i_b)
+template <int SA_SPT>
+__device__ __forceinline__ void sample_assemble_fast(const goofer_assembly &a, const goofer_note_plan &p, int64_t g0, int64_t total_samples)
 {
     const float *__restrict__ m = a.mask_src + p.src_sample_off;
     const double *__restrict__ bend = a.bend + p.bend_off;
@@ -1043,22 +938,7 @@ __device__ __forceinline__ void sample_assemble_fast(const goofer_assembly &a, c
         ja[u] = last ? nb1 : j;
         jb[u] = last ? nb1 : j + 1;
     }
-    // LEAN: the tile's window of decimated mask values for the smoothing (lean_window_fill, restated for the plain slice / tile
-    // case).  The tile's own knots are the mask values of its samples 4 q, which go to LDS as they are stored; the radius on either
-    // side is one more look-up for the first 2 * radius threads, issued here with the samples' own loads (it lands behind the
-    // fp64 curve arithmetic).
-    int hidx = 0, hw = -1;
-    const int lq0 = (i_a + 3) >> 2, llen = (i_b >> 2) - lq0 + 1;
-    if (LEAN && llen > 0 && (int)threadIdx.x < 2 * L.radius) {
-        const int ns = (p.n_out + 3) >> 2;
-        hw = (int)threadIdx.x < L.radius ? (int)threadIdx.x : llen + (int)threadIdx.x;   // window slot: left / right of the own knots
-        const int i = 4 * refl32(lq0 - L.radius + hw, ns);
-        uint32_t kk = (uint32_t)(i - n_pre);
-        if (tile) kk = mod_small_nb(kk, (uint32_t)tail_len, rd_tail);
-        const int idx = i < n_pre ? s_pre + i : s_tail + (int)kk;
-        hidx = rev ? ylen1 - idx : idx;
-    }
-    float mv[SA_SPT], hv = 0.f;
+    float mv[SA_SPT];
     double y0[SA_SPT], y1[SA_SPT];
 #pragma unroll
     for (int u = 0; u < SA_SPT; ++u) {
@@ -1066,7 +946,6 @@ __device__ __forceinline__ void sample_assemble_fast(const goofer_assembly &a, c
         y0[u] = bend[ja[u]];
         y1[u] = bend[jb[u]];
     }
-    if (LEAN && hw >= 0) hv = fv ? 1.0f : m[hidx];
     float fo[SA_SPT];
 #pragma unroll
     for (int u = 0; u < SA_SPT; ++u) {
@@ -1082,29 +961,22 @@ __device__ __forceinline__ void sample_assemble_fast(const goofer_assembly &a, c
     for (int u = 0; u < SA_SPT; ++u) {
         const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
         if (live[u]) {
-            if (!LEAN) mask_out[g] = mv[u];
+            mask_out[g] = mv[u];
             f0_out[g] = fo[u];
-            if (LEAN) {
-                const int i = (int)(g - nbase);
-                lean_pick(L, p, note, i, fo[u], mv[u]);
-                if ((i & 3) == 0) s_win[L.radius + (i >> 2) - lq0] = mv[u];
-            }
         }
     }
-    if (LEAN && hw >= 0) s_win[hw] = hv;
 }
 
-template <int SA_SPT, bool LEAN>
-__global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a, int64_t total_samples, int fast, const lean_out L)
+template <int SA_SPT>
+__global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a, int64_t total_samples, int fast)
 {
     __shared__ int s_pair[2];
-    __shared__ float s_win[LEAN ? LEAN_MAXWIN : 1];
     const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x * SA_SPT);
-    int64_t gl = g0 + (int64_t)blockDim.x * SA_SPT - 1;
-    if (gl > total_samples - 1) gl = total_samples - 1;
     if (threadIdx.x < WAVE) {
         // notes own [out_sample_off, out_sample_off + n_out): first wave searches the plan array cooperatively
         auto key = [&](int k) { return a.notes[k].out_sample_off; };
+        int64_t gl = g0 + (int64_t)blockDim.x * SA_SPT - 1;
+        if (gl > total_samples - 1) gl = total_samples - 1;
         const int lo = wave_find(a.n_notes, g0, (int)threadIdx.x, key);
         const int hi = wave_find(a.n_notes, gl, (int)threadIdx.x, key);
         if (threadIdx.x == 0) { s_pair[0] = lo; s_pair[1] = hi; }
@@ -1115,18 +987,13 @@ __global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a
         const goofer_note_plan &p = a.notes[n_lo];           // uniform note: the 300-byte plan comes in through scalar loads
         if (fast && !p.vel_active && p.fry_dir == 0 && !(p.pd_on && a.bend_out) && !a.f0_mul_out && p.n_out < (1 << 21) && p.tail_len < (1 << 24) &&
             p.tail_len > 0 && p.n_bend >= 1) {
-            sample_assemble_fast<SA_SPT, LEAN>(a, p, g0, total_samples, L, n_lo, s_win, (int)(g0 - p.out_sample_off), (int)(gl - p.out_sample_off));
-        } else {
-#pragma unroll
-            for (int u = 0; u < SA_SPT; ++u) {
-                const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
-                if (g < total_samples) sample_assemble_one<LEAN>(a, p, g, L, n_lo);
-            }
-            if (LEAN) lean_window_fill(a, L, p, (int)(g0 - p.out_sample_off), (int)(gl - p.out_sample_off), s_win);
+            sample_assemble_fast<SA_SPT>(a, p, g0, total_samples);
+            return;
         }
-        if (LEAN) {
-            __syncthreads();
-            lean_window_finish(L, p, n_lo, (int)(g0 - p.out_sample_off), (int)(gl - p.out_sample_off), s_win);
+#pragma unroll
+        for (int u = 0; u < SA_SPT; ++u) {
+            const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
+            if (g < total_samples) sample_assemble_one(a, p, g);
         }
     } else {
         for (int u = 0; u < SA_SPT; ++u) {
@@ -1134,19 +1001,7 @@ __global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a
             if (g >= total_samples) break;
             int note = n_lo;
             while (note + 1 < a.n_notes && a.notes[note + 1].out_sample_off <= g) ++note;
-            sample_assemble_one<LEAN>(a, a.notes[note], g, L, note);
-        }
-        if (LEAN) {
-            for (int note = n_lo; note <= n_hi; ++note) {    // (workgroup-uniform loop: every note the tile touches)
-                const goofer_note_plan &p = a.notes[note];
-                const int64_t lo = g0 > p.out_sample_off ? g0 : p.out_sample_off;
-                const int64_t hi = gl < p.out_sample_off + p.n_out - 1 ? gl : p.out_sample_off + p.n_out - 1;
-                if (hi < lo) continue;
-                __syncthreads();                              // the previous note's window is no longer read
-                lean_window_fill(a, L, p, (int)(lo - p.out_sample_off), (int)(hi - p.out_sample_off), s_win);
-                __syncthreads();
-                lean_window_finish(L, p, note, (int)(lo - p.out_sample_off), (int)(hi - p.out_sample_off), s_win);
-            }
+            sample_assemble_one(a, a.notes[note], g);
         }
     }
 }
@@ -1271,15 +1126,7 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         const dim3 sgrid((unsigned)((a->total_samples + 256 * spt - 1) / (256 * spt)));
         const int sa_fast = ctx->sa_fast ? 1 : 0;
         HIP_TRY(ctx, mark(2, 0, fst));
-        lean_out L{};
-        if (ctx->lean_want) {                                   // goofer_render_batch set up the lean hand-off for this call
-            L.short_s = ctx->lean_short; L.picks = ctx->lean_picks; L.frame_off = ctx->lean_frame_off; L.taps = ctx->mask_taps;
-            L.tap_sum = ctx->mask_taps_sum; L.radius = ctx->mask_taps_radius; L.hop = ctx->plan.hop;
-            hipLaunchKernelGGL((k_sample_assemble<spt, true>), sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast, L);
-            ctx->lean_done = true;
-        } else {
-            hipLaunchKernelGGL((k_sample_assemble<spt, false>), sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast, L);
-        }
+        hipLaunchKernelGGL(k_sample_assemble<spt>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast);
         LAUNCH_CHECK(ctx);
         HIP_TRY(ctx, mark(2, 1, fst));
         if (ctx->early_req && ctx->ev_f0) {

@@ -63,8 +63,8 @@ struct goofer_ctx {
     void *small = nullptr;        // small staging buffer for taps etc.
     size_t small_bytes = 0;
     // device pointers of the last synth batch's intermediates (goofer_debug_fetch; tests only)
-    const void *dbg_ptr[18] = {nullptr};
-    size_t dbg_bytes[18] = {0};
+    const void *dbg_ptr[16] = {nullptr};
+    size_t dbg_bytes[16] = {0};
     bool overlap = true;          // noise spectra + mask smoothing on a side stream, beside the latency-bound pulse walk
     hipStream_t side = nullptr;   // created on first use
                                   // ... with the highest stream priority (measured: 2.41 ms per step against 2.50 at the default, 2.54 at the lowest)
@@ -82,16 +82,6 @@ struct goofer_ctx {
     float *warp_rows = nullptr;
     size_t warp_rows_bytes = 0;
     const float2 *frame_picks = nullptr;   // per-frame (f0, mask) picks of the running goofer_synth_batch, or null
-    // goofer_render_batch, lean hand-off (assemble.hip: lean_out): the f0 / mask kernel writes the smoothed mask knots and the
-    // per-frame picks into a buffer the handle owns; the per-sample mask is then neither written nor read
-    bool lean_opt = true;                 // option "lean" (0: A/B — mask_out written, k_mask_short and the map kernel's picks as before)
-    void *lean_buf = nullptr;
-    size_t lean_buf_bytes = 0;
-    bool lean_want = false;               // set for the duration of the assembly of a goofer_render_batch that goes lean
-    double *lean_short = nullptr;         // the knots / picks / frame offsets of that call (inside lean_buf)
-    float2 *lean_picks = nullptr;
-    const int64_t *lean_frame_off = nullptr;
-    bool lean_done = false;               // the assembly of the batch being synthesised wrote them
     bool early_req = false;           // set for the duration of one goofer_render_batch
     const float *early_f0 = nullptr;  // f0 array ev_f0 stands for (null: no event recorded)
     bool f0_on_side = false;          // goofer_render_batch ran the f0 / mask kernel on the side stream, in front of the pulse chain it feeds: the

@@ -114,7 +114,7 @@ class Context:
             "S_harm": (4, np.complex64), "S_uv": (5, np.complex64), "S_breath": (6, np.complex64), "frames": (7, np.float32),
             "env_harm": (8, np.float32), "env_noise": (9, np.float32), "mask_short": (10, np.float64),
             "note_mag": (11, np.float32), "note_peak": (12, np.float32), "onset_cnt": (13, np.int32),
-            "onset_idx": (14, np.int32), "frame_skip": (15, np.uint8), "picks": (16, np.float32)}
+            "onset_idx": (14, np.int32), "frame_skip": (15, np.uint8)}
 
     def debug_fetch(self, name: str) -> np.ndarray:
         """Intermediate of the last synth_batch (onset_cnt / onset_idx: also of the last pulse_train) as a flat host array

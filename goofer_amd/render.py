@@ -424,7 +424,7 @@ class Renderer:
         if not jobs:
             return []
         prep = self.prepare(jobs, phi_seeds=phi_seeds, trim_rows=not return_parts)   # tests look at the whole assembled envelope
-        out = self.run(prep, seed=seed, keep_stems=return_parts, want_mask=return_parts)
+        out = self.run(prep, seed=seed, keep_stems=return_parts)
         self.ctx.check()                                   # synchronises; raises if the device flagged a note
         mix = out["mix"].cpu().numpy()
         offs = prep["sample_off"]
@@ -440,15 +440,11 @@ class Renderer:
         ctx = self.ctx
         ctx._check(ctx.lib.goofer_assemble_batch(ctx.h, C.byref(prep["assembly"]), ctx._stream()))
 
-    def run(self, prep, seed: int = 0, keep_stems: bool = False, split: bool = False, want_mask: bool = False):
+    def run(self, prep, seed: int = 0, keep_stems: bool = False, split: bool = False):
         """The device work of one batch (asynchronous): goofer_render_batch, i.e. assembly + synthesis as one call;
-        ``split=True`` issues goofer_assemble_batch and goofer_synth_batch separately (same results).
-        ``want_mask``: the caller reads ``prep["mask"]`` (the assembled per-sample voicing mask) afterwards.  Otherwise — and
-        when no post chain needs it — the library may leave it unwritten and hand the synthesis the smoothed mask knots and
-        per-frame picks directly (goofer_assembly.lean; same audio bit for bit)."""
+        ``split=True`` issues goofer_assemble_batch and goofer_synth_batch separately (same results)."""
         ctx = self.ctx
         par = prep["params"]
-        prep["assembly"].lean = 0 if (want_mask or split or prep["post"] is not None) else 1
         # Notes with the 'sg' pulse layer or the 'sr' volume jitter are synthesised by the one-kernel-per-step pipeline (those
         # layers edit the pulse train / the stems between its steps), everything else by the stem walkers — and the library
         # picks the pipeline per BATCH.  So that a note renders to the same bits whatever company it keeps (the two pipelines

@@ -171,10 +171,7 @@ typedef struct {
     float *env_out;                  /* [total_out_rows x ld] assembled envelope                           */
     float *f0_out, *mask_out;        /* [total_samples]                                                    */
     float *bend_out;                 /* [total_samples] pitch-bend semitones of the 'pd' notes, or NULL    */
-    int32_t any_fry;                 /* some note has fry_a < fry_b: run the envelope fry warp             */
-    int32_t lean;                    /* 1: the caller does not read mask_out after goofer_render_batch: the library may leave it */
-                                     /* unwritten and hand the synthesis the smoothed mask knots and per-frame picks directly  */
-                                     /* (GOOFER.py:556-562, 1104-1106); goofer_assemble_batch alone always writes mask_out      */
+    int32_t any_fry, reserved5;      /* some note has fry_a < fry_b: run the envelope fry warp             */
     /* 'sj' growl layer (SillySampler.py:1061-1065): its f0 is f0_new * (0.5 * 2^noise) with f0_new still fp64, rounded */
     /* to fp32 ONCE inside synthesize.  f0_mul [total_samples] fp64 factors (anything on notes without the layer) and   */
     /* f0_mul_out [total_samples] = (float)(fp64 f0 * f0_mul), or both NULL.  Scaling the rounded f0_out instead moves    */
@@ -463,8 +460,6 @@ const char *goofer_profile_stage_name_ex(const goofer_ctx *ctx, int stage);   /*
  *               decides an index, a threshold or the pitch curve stays fp64; 1: round 4's fp64
  *               arithmetic there (agrees to 2e-8 sample-RMS on the 1024-note batch; not bit-identical)
  *   "sa_fast"   1 (default): k_sample_assemble's branch-free path with all of a thread's loads in flight together; 0: per sample
- *   "lean"      1 (default): goofer_render_batch honours goofer_assembly.lean; 0: mask_out is always written and the synthesis
- *               smooths and picks from it (bit-identical; A/B)
  *   "prof_only" s >= 0: goofer_profile_begin .. end record the events of stage s only; -1 (default): every stage     */
 int goofer_set_option(goofer_ctx *ctx, const char *name, int value);
 

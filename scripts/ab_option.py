@@ -38,3 +38,19 @@ for rep in range(2):
         torch.cuda.synchronize()
         st = ctx.profile_end()
         print("%s=%d: step %.3f ms; " % (name, v, t0.elapsed_time(t1) / 20) + ", ".join("%s %.3f" % (k, x / st["steps"]) for k, x in st["ms"].items() if x > 0))
+# ... and the plain step (no event records), alternating, five rounds
+best = {v0: 1e9, v1: 1e9}
+for rep in range(5):
+    for v in (v0, v1):
+        ctx.set_option(name, v)
+        for _ in range(3):
+            wl.step()
+        torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(30):
+            wl.step()
+        t1.record()
+        torch.cuda.synchronize()
+        best[v] = min(best[v], t0.elapsed_time(t1) / 30)
+print("plain step, best of five alternating rounds: " + ", ".join("%s=%d %.3f ms" % (name, v, best[v]) for v in (v0, v1)))

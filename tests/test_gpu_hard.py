@@ -57,7 +57,7 @@ def test_hard_source_matches_reference(renderer, name):
 
 
 def test_hard_sources_as_one_batch(renderer):
-    """All twelve as ONE ragged batch (the lean hand-off path: no per-sample mask is written), against the same renders."""
+    """All twelve as ONE ragged batch, against the same renders."""
     jobs, seeds, refs = [], [], []
     for name in HARD:
         g, source, req = _job(name)
