@@ -80,9 +80,22 @@ def load_features(path):
 
 
 # -- single-array entry points ---------------------------------------------------------------------
+def _check_window(window, n_fft):
+    """The kernels window with the plan's sqrt-Hann (GOOFER.py:12-18: ``np.sqrt(np.hanning(n_fft))`` in fp32, the only window the
+    reference ever passes to stft / istft, :1099, :1146).  A caller's ``window`` must BE that window (to fp32 rounding): any other
+    one used to be silently ignored, which is a wrong answer — it raises instead."""
+    if window is None:
+        return
+    w = np.asarray(window)
+    ref = np.sqrt(np.hanning(n_fft)).astype(np.float32)
+    if w.shape != ref.shape or not np.allclose(w.astype(np.float64), ref.astype(np.float64), rtol=0.0, atol=3e-7):
+        raise ValueError("goofer_amd.stft / istft support the reference's cached window only: sqrt(hanning(n_fft)) in fp32 "
+                         "(GOOFER.py:12-18); got a different window of shape %s" % (w.shape,))
+
+
 def stft(x, n_fft=2048, hop_length=512, window=None, sr=44100, ctx=None):
-    """complex64 ``[bins, T]``.  ``window`` is accepted for signature parity; the backend always uses
-    the reference's cached sqrt-Hann (the only window the reference ever passes)."""
+    """complex64 ``[bins, T]``.  ``window``: None or the reference's cached sqrt-Hann (anything else raises: `_check_window`)."""
+    _check_window(window, n_fft)
     c = _ctx(sr, n_fft, hop_length, ctx)
     x = np.asarray(x, dtype=np.float32)
     n = len(x)
@@ -94,6 +107,7 @@ def stft(x, n_fft=2048, hop_length=512, window=None, sr=44100, ctx=None):
 def istft(S, hop_length=512, window=None, length=None, sr=44100, ctx=None):
     S = np.asarray(S, dtype=np.complex64)
     n_fft = (S.shape[0] - 1) * 2
+    _check_window(window, n_fft)
     c = _ctx(sr, n_fft, hop_length, ctx)
     T = S.shape[1]
     n = hop_length * (T - 1) if length is None else int(length)

@@ -95,3 +95,22 @@ def test_core_exposes_the_reference_module_surface():
                  "gaussian_filter1d", "gaussian_filter", "stretch_feature", "create_volume_jitter", "rms", "pulse_train_numba",
                  "stft", "istft", "compress_env_to_knots", "make_mel_knots", "formants_to_int_keys", "to_compute"):
         assert callable(getattr(core, name)), name
+
+
+def test_stft_refuses_a_window_that_is_not_the_reference_window():
+    """gf.stft / gf.istft take a ``window`` (GOOFER.py:355, 392); the kernels use the plan's sqrt-Hann.  The reference's own window
+    passes, any other raises before anything touches the device (it used to be ignored silently: VERDICT r5)."""
+    import numpy as np
+    import pytest
+    from goofer_amd import core
+    n_fft = 1024
+    core._check_window(None, n_fft)
+    core._check_window(np.sqrt(np.hanning(n_fft)).astype(np.float32), n_fft)
+    core._check_window(np.sqrt(np.hanning(n_fft)), n_fft)                       # the same window in fp64
+    for bad in (np.hanning(n_fft), np.ones(n_fft, np.float32), np.sqrt(np.hanning(n_fft // 2)), np.sqrt(np.hamming(n_fft))):
+        with pytest.raises(ValueError):
+            core._check_window(bad, n_fft)
+    with pytest.raises(ValueError):
+        core.stft(np.zeros(4096, np.float32), n_fft=n_fft, hop_length=256, window=np.ones(n_fft, np.float32))
+    with pytest.raises(ValueError):
+        core.istft(np.zeros((513, 8), np.complex64), hop_length=256, window=np.ones(n_fft, np.float32))
