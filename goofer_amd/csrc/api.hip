@@ -99,11 +99,11 @@ int launch_frame_picks(goofer_ctx *, const int64_t *, const int *, int64_t, cons
                        hipStream_t);
 int launch_noise_stems(goofer_ctx *, const float *, int, const int64_t *, const float *, int64_t, const int *, const int64_t *,
                        const int64_t *, const float2 *, const goofer_note_params *, uint64_t, bool, const double *, const double *, float *,
-                       float *, hipStream_t);
+                       float *, unsigned char *, hipStream_t);
 int launch_harm_stem(goofer_ctx *, const float *, const float *, const float *, bool, int, const int64_t *, int64_t, const int *, const int64_t *,
                      const int64_t *, const float2 *, const goofer_note_params *, float *, float *, hipStream_t);
 int launch_note_finish(goofer_ctx *, float *, float *, float *, float *, float *, const int64_t *, int, const goofer_note_params *,
-                       const float *, float *, bool, hipStream_t);
+                       const float *, float *, bool, const unsigned char *, const int64_t *, hipStream_t);
 
 static const size_t ONSET_BYTES = 24;
 
@@ -326,6 +326,7 @@ static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t sampl
     add((samples / 4 + notes + 16) * sizeof(double));  // smoothed decimated mask
     add(2 * notes * sizeof(float) + 64);          // note_mag, note_peak
     add(2 * notes * sizeof(double) + 64);         // per-note linspace steps
+    add((size_t)frames + 3 * (size_t)notes + 64); // per-hop stem sparsity bytes of the walkers
     if (spectra) {                                // per-hop flatness + per-frame skip bits of the LDS-ring pipeline
         const int64_t reach = (p.n_fft + p.hop - 1) / p.hop;
         add((size_t)(frames + reach * notes) + 64);
@@ -1369,6 +1370,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     double *short_s = a.take<double>(N / 4 + n + 16);
     float *note_mag = a.take<float>(2 * (size_t)n + 16);
     double *note_steps = a.take<double>(2 * (size_t)n + 16);
+    // stem walkers: a byte per output hop of a note (T + 3 of them) — which stems the noise walker left unstored because they are
+    // exactly zero there (k_noise_stems -> k_note_finish)
+    unsigned char *hopz = a.take<unsigned char>(walkers ? (size_t)F + 3 * (size_t)n + 64 : 0);
     // ... with the exact sparsity of the noise stems decided per frame up front (k_frame_skip)
     const bool skip_frames = ola_split && ctx->skip_zero && ctx->overlap && !sub_on && p.hop <= 512;
     unsigned char *hop_flat = skip_frames ? a.take<unsigned char>((size_t)F + (size_t)((p.n_fft + p.hop - 1) / p.hop) * n + 16) : nullptr;
@@ -1376,7 +1380,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     unsigned char *knot_eq = skip_frames ? a.take<unsigned char>((size_t)(N / 4 + n + 16)) : nullptr;
     if (skip_frames && (!hop_flat || !frame_skip || !knot_eq)) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     if (!picks || !frames_u || !frames_b || !frame_note || !row_src || !f0s || (sub_on && !inc) || !onsets || !onset_idx || !onset_cnt || !ovf || !pulse || !pulse_tiles || !S_h || !S_uv || !S_br || !frames ||
-        !env_h || !env_n || !short_s || !note_mag || !note_steps)
+        !env_h || !env_n || !short_s || !note_mag || !note_steps || !hopz)
         return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     float *note_peak = note_mag + n;
     double *jit_a = nullptr, *jit_b = nullptr, *jit_c = nullptr;
@@ -1527,7 +1531,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if (!maps_fused && (r2 = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return r2;
         if ((r2 = launch_noise_stems(ctx, b->env_noise ? b->env_noise : b->env, ld, row_src, b->phi, F, frame_note, b->frame_off,
                                      b->sample_off, picks, b->params, b->seed, b->env_noise != nullptr, short_s, note_steps, b->uv,
-                                     b->bre, st)))
+                                     b->bre, hopz, st)))
             return r2;
         if (side_on) MARK_Q(1);
         return GOOFER_OK;
@@ -1627,7 +1631,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
             if (!maps_fused && (rc = launch_note_steps(ctx, b->sample_off, n, note_steps, st))) return rc;
             if ((rc = launch_noise_stems(ctx, b->env_noise ? b->env_noise : b->env, ld, row_src, b->phi, F, frame_note, b->frame_off,
                                          b->sample_off, picks, b->params, b->seed, b->env_noise != nullptr, short_s, note_steps, b->uv,
-                                         b->bre, st)))
+                                         b->bre, hopz, st)))
                 return rc;
             if (!ctx->warp_done &&
                 (rc = launch_warp_bins(ctx, b->env, env_h, F, p.n_bins, ld, b->formants, nullptr, b->params, frame_note, row_src, 1.0, st)))
@@ -1644,7 +1648,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         MARK();
         MARK();   // 13: harm / max|S|, peak, gain, reconstruct, mix
         if ((rc = launch_note_finish(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, b->params, note_mag, note_peak,
-                                     !(b->mix_only && (b->mix || b->rec)), st)))
+                                     !(b->mix_only && (b->mix || b->rec)), hopz, b->frame_off, st)))
             return rc;
         MARK();   // 14..17 unused
         MARK();
@@ -1684,7 +1688,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
             return rc;
         MARK();   // 14
         if ((rc = launch_note_finish(ctx, b->harm, b->uv, b->bre, b->rec, b->mix, b->sample_off, n, b->params, note_mag, note_peak,
-                                     !(b->mix_only && (b->mix || b->rec)), st)))
+                                     !(b->mix_only && (b->mix || b->rec)), nullptr, nullptr, st)))
             return rc;
         MARK();   // 15..17 unused
         MARK();

@@ -283,6 +283,8 @@ struct noise_args {
     // used every frame
     const float *env, *phi;
     float *uv, *bre;
+    unsigned char *hopz;           // per output hop of a note (slot: first frame of the note + 3 * note + hop): bit 0 the unvoiced stem's
+                                   // samples of the hop are exactly zero and were NOT stored, bit 1 the same for the breath stem
     const double *short_s;
     int ld, mode, run;             // mode bit 0: blur the rows here; bit 1: never skip a transform (A/B); bit 2: the 5-tap bin blur
                                    // of voiced frames as a window on the samples
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
     const float *__restrict__ env = A.env;
     const float *__restrict__ phi = A.phi;
     float *__restrict__ uv = A.uv, *__restrict__ bre = A.bre;
+    unsigned char *__restrict__ hopz = A.hopz;
     const int ld = A.ld, mode = A.mode;
     // frame indices as 32-bit integers in the loop (a batch of 2^31 frames would be 4 TB of envelope rows): four scalar
     // registers fewer in a loop that spills them
@@ -570,21 +573,22 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
         //    hop's mask gain is one constant (see hop_check_done) — the same quotients and products as the general loop below
         const int p0t = t * HOP - M;
         const bool flat1_t = (one_bits & 1u) != 0, flat0_t = (zero_bits & 1u) != 0;
+        const int hop_slot = f - t + 3 * w.note;               // (f - t: the note's first frame)
         if (f >= f0 && (flat1_t || flat0_t) && w.interior(t) && t != w.T - 1 && p0t >= 0 && p0t + HOP <= w.n && p0t + HOP <= w.out_len) {
-            const float ms = flat1_t ? 1.0f : 0.0f;
+            // The hop's mask gain is one constant: the stem it multiplies by exactly zero is exactly zero over the whole hop (a
+            // product with 0.0f: +-0).  That stem's 1 KB is not stored; the hop's byte says so and k_note_finish takes zeros.
+            if (lane == 0) hopz[hop_slot + t] = (unsigned char)((flat1_t ? 1 : 0) | (flat0_t ? 2 : 0));
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int i0 = p0t + 2 * (lane + WAVE * g);
-                float xu[2] = {ou[g].x, ou[g].y}, xb[2] = {ob[g].x, ob[g].y};
+                float x[2] = {flat1_t ? ob[g].x : ou[g].x, flat1_t ? ob[g].y : ou[g].y};
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const float ws = w.ws_of(g, c), rw = w.rws_of(g, c);
-                    if (ws > 1e-9f) { xu[c] = div_by(xu[c], ws, rw); xb[c] = div_by(xb[c], ws, rw); }
-                    xb[c] = (xb[c] * ms) * g_b;
-                    xu[c] = (xu[c] * (1.0f - ms)) * g_u;
+                    if (ws > 1e-9f) x[c] = div_by(x[c], ws, rw);
+                    x[c] = (x[c] * 1.0f) * (flat1_t ? g_b : g_u);          // (x * ms) * g_b with ms = 1 / (x * (1 - ms)) * g_u with ms = 0
                 }
-                *reinterpret_cast<float2_u *>(uv + w.base + i0) = make_float2(xu[0], xu[1]);
-                *reinterpret_cast<float2_u *>(bre + w.base + i0) = make_float2(xb[0], xb[1]);
+                *reinterpret_cast<float2_u *>((flat1_t ? bre : uv) + w.base + i0) = make_float2(x[0], x[1]);
             }
         } else if (f >= f0) {
             //    ... and the general case: behind a note's last frame also the hop still open in the registers and the zero tail
@@ -603,6 +607,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
                     }
                     wave_lds_sync();
                 }
+                if (lane == 0) hopz[hop_slot + h] = 0;         // both stems stored
                 const int p0 = h * HOP - M;
                 const int e_hi = KN - 1, lo = kn_lo;
                 auto knot = [&](int k) {
@@ -890,7 +895,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
                                                              const int64_t *__restrict__ sample_off,
                                                              const goofer_note_params *__restrict__ params,
                                                              const float *__restrict__ note_mag, float *__restrict__ note_peak,
-                                                             int write_stems, int lds_rows)
+                                                             int write_stems, int lds_rows, const unsigned char *__restrict__ hopz,
+                                                             const int64_t *__restrict__ frame_off, int hz_m, int hz_shift)
 {
     __shared__ float s_red[FIN_THREADS / WAVE];
     extern __shared__ __align__(16) unsigned char fin_smem[];
@@ -905,20 +911,55 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
     if (a0 > n) a0 = n;
     const int a1 = a0 + ((n - a0) & ~3);
     const bool vec = ((((uintptr_t)harm | (uintptr_t)uv | (uintptr_t)bre | (uintptr_t)rec | (uintptr_t)mix) & 15) == 0);
+    // The noise walker does not store a stem over a hop on which its gain is exactly zero (hopz, see k_noise_stems): bit 0 of a
+    // hop's byte: the unvoiced stem is zero there and ABSENT (the array holds anything), bit 1: the breath stem.  Sample i lies in
+    // hop (i + n_fft/2) / hop.  A 16-byte group may straddle two hops: zpair(i) = the bytes of the hops of samples i and i + 3
+    // (bits 0-1 and 2-3), stem4 loads a group and puts zeros where its hop says so.
+    const unsigned char *hz = hopz ? hopz + (frame_off[note] + 3 * (int64_t)note) : nullptr;
+    auto zbits = [&](int i) -> unsigned { return hz ? (unsigned)hz[(i + hz_m) >> hz_shift] : 0u; };
+    auto zpair = [&](int i) -> unsigned {
+        if (!hz) return 0u;
+        const int h0 = (i + hz_m) >> hz_shift, h1 = (i + 3 + hz_m) >> hz_shift;
+        const unsigned z0 = hz[h0] & 3u;
+        return z0 | ((h1 != h0 ? (hz[h1] & 3u) : z0) << 2);
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto stem4 = [&](const float *p, int i, unsigned zp, unsigned bit) -> float4 {
+        const bool s0 = (zp & bit) != 0, s1 = ((zp >> 2) & bit) != 0;
+        if (s0 && s1) return zero4;
+        float4 v = *reinterpret_cast<const float4 *>(p + i);
+        if (s0 || s1) {
+            const int split = ((((i + hz_m) >> hz_shift) + 1) << hz_shift) - hz_m - i;   // samples of the group in its first hop (1..3)
+            v.x = s0 ? 0.f : v.x;
+            v.y = (1 < split ? s0 : s1) ? 0.f : v.y;
+            v.z = (2 < split ? s0 : s1) ? 0.f : v.z;
+            v.w = s1 ? 0.f : v.w;
+        }
+        return v;
+    };
 
     float pk = 0.f;
     const bool keep = vec;                                              // workgroup-uniform; rows past FIN_KEEP take the re-reading loops
     const int a_keep = a0 + 4 * FIN_THREADS * FIN_KEEP;                 // first sample past the kept rows
     float4 kh[FIN_KEEP], ku[FIN_KEEP];
+    uint64_t zall = 0;                                                  // four bits per kept row: fetched up front, off the loads' chain
+    if (keep && hz) {
+#pragma unroll
+        for (int q = 0; q < FIN_KEEP; ++q) {
+            const int i = a0 + 4 * ((int)threadIdx.x + FIN_THREADS * q);
+            if (i < a1) zall |= (uint64_t)zpair(i) << (4 * q);
+        }
+    }
     if (keep) {
 #pragma unroll
         for (int q = 0; q < FIN_KEEP; ++q) {
             const int i = a0 + 4 * ((int)threadIdx.x + FIN_THREADS * q);
             kh[q] = ku[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < a1) {
+                const unsigned z = (unsigned)(zall >> (4 * q)) & 15u;
                 const float4 h = *reinterpret_cast<const float4 *>(h_ + i);
-                const float4 u = *reinterpret_cast<const float4 *>(u_ + i);
-                const float4 b = *reinterpret_cast<const float4 *>(b_ + i);
+                const float4 u = stem4(u_, i, z, 1u);
+                const float4 b = stem4(b_, i, z, 2u);
                 kh[q] = make_float4(div_by(h.x, mag, rmag), div_by(h.y, mag, rmag), div_by(h.z, mag, rmag), div_by(h.w, mag, rmag));
                 ku[q] = u;
                 if (q < lds_rows) sb4[q * FIN_THREADS + (int)threadIdx.x] = b;     // (read back by this thread only)
@@ -932,9 +973,10 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
             if (q % 2 == 1) asm volatile("" ::: "memory");
         }
         for (int i = a_keep + 4 * (int)threadIdx.x; i < a1; i += 4 * FIN_THREADS) {
+            const unsigned z = zpair(i);
             const float4 h = *reinterpret_cast<const float4 *>(h_ + i);
-            const float4 u = *reinterpret_cast<const float4 *>(u_ + i);
-            const float4 b = *reinterpret_cast<const float4 *>(b_ + i);
+            const float4 u = stem4(u_, i, z, 1u);
+            const float4 b = stem4(b_, i, z, 2u);
             pk = fmaxf(pk, fabsf((div_by(h.x, mag, rmag) + u.x) + b.x));
             pk = fmaxf(pk, fabsf((div_by(h.y, mag, rmag) + u.y) + b.y));
             pk = fmaxf(pk, fabsf((div_by(h.z, mag, rmag) + u.z) + b.z));
@@ -943,7 +985,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
     }
     for (int i = (int)threadIdx.x; i < n; i += FIN_THREADS) {
         if (vec && i >= a0 && i < a1) continue;
-        pk = fmaxf(pk, fabsf((div_by(h_[i], mag, rmag) + u_[i]) + b_[i]));
+        const unsigned z = zbits(i);
+        pk = fmaxf(pk, fabsf((div_by(h_[i], mag, rmag) + ((z & 1u) ? 0.f : u_[i])) + ((z & 2u) ? 0.f : b_[i])));
     }
     pk = wave_max(pk);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = pk;
@@ -977,7 +1020,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
             const int i = a0 + 4 * ((int)threadIdx.x + FIN_THREADS * q);
             if (i < a1) {
                 const float4 h = kh[q], u = ku[q];
-                const float4 b = q < lds_rows ? sb4[q * FIN_THREADS + (int)threadIdx.x] : *reinterpret_cast<const float4 *>(b_ + i);
+                const float4 b = q < lds_rows ? sb4[q * FIN_THREADS + (int)threadIdx.x] : stem4(b_, i, (unsigned)(zall >> (4 * q)) & 15u, 2u);
                 float4 ho, uo, bo, ro, mo;
                 one_kept(h.x, u.x, b.x, ho.x, uo.x, bo.x, ro.x, mo.x);
                 one_kept(h.y, u.y, b.y, ho.y, uo.y, bo.y, ro.y, mo.y);
@@ -994,9 +1037,10 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
             if (q % 2 == 1) asm volatile("" ::: "memory");
         }
         for (int i = a_keep + 4 * (int)threadIdx.x; i < a1; i += 4 * FIN_THREADS) {
+            const unsigned z = zpair(i);
             const float4 h = *reinterpret_cast<const float4 *>(h_ + i);
-            const float4 u = *reinterpret_cast<const float4 *>(u_ + i);
-            const float4 b = *reinterpret_cast<const float4 *>(b_ + i);
+            const float4 u = stem4(u_, i, z, 1u);
+            const float4 b = stem4(b_, i, z, 2u);
             float4 ho, uo, bo, ro, mo;
             one(h.x, u.x, b.x, ho.x, uo.x, bo.x, ro.x, mo.x);
             one(h.y, u.y, b.y, ho.y, uo.y, bo.y, ro.y, mo.y);
@@ -1013,8 +1057,9 @@ __global__ __launch_bounds__(FIN_THREADS) void k_note_finish(float *__restrict__
     }
     for (int i = (int)threadIdx.x; i < n; i += FIN_THREADS) {
         if (vec && i >= a0 && i < a1) continue;
+        const unsigned z = zbits(i);
         float ho, uo, bo, ro, mo;
-        one(h_[i], u_[i], b_[i], ho, uo, bo, ro, mo);
+        one(h_[i], (z & 1u) ? 0.f : u_[i], (z & 2u) ? 0.f : b_[i], ho, uo, bo, ro, mo);
         if (write_stems & 1) { h_[i] = ho; u_[i] = uo; b_[i] = bo; }
         if (rec) rec[base + i] = ro;
         if (mix) mix[base + i] = mo;
@@ -1065,7 +1110,7 @@ int launch_frame_picks(goofer_ctx *ctx, const int64_t *frame_off, const int *fra
 int launch_noise_stems(goofer_ctx *ctx, const float *env, int ld, const int64_t *row_src, const float *phi, int64_t F,
                        const int *frame_note, const int64_t *frame_off, const int64_t *sample_off, const float2 *picks,
                        const goofer_note_params *params, uint64_t seed, bool preblurred, const double *short_s, const double *steps,
-                       float *uv, float *bre, hipStream_t st)
+                       float *uv, float *bre, unsigned char *hopz, hipStream_t st)
 {
     if (F <= 0) return GOOFER_OK;
     const goofer_plan_t &p = ctx->plan;
@@ -1082,7 +1127,7 @@ int launch_noise_stems(goofer_ctx *ctx, const float *env, int ld, const int64_t 
     const int64_t runs = (F + run - 1) / run;
     const dim3 grid((unsigned)((runs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
     noise_args A;
-    A.env = env; A.phi = phi; A.uv = uv; A.bre = bre; A.short_s = short_s;
+    A.env = env; A.phi = phi; A.uv = uv; A.bre = bre; A.hopz = hopz; A.short_s = short_s;
     A.ld = ld; A.mode = (preblurred ? 0 : 1) | (ctx->skip_zero ? 0 : 2) | (ctx->td_blur ? 4 : 0); A.run = run;
     A.total_frames = F; A.seed = seed; A.row_src = row_src; A.frame_note = frame_note; A.frame_off = frame_off;
     A.sample_off = sample_off; A.picks = picks; A.params = params; A.steps = steps; A.freqs = p.freqs; A.bright = p.bright_b;
@@ -1119,9 +1164,11 @@ int launch_harm_stem(goofer_ctx *ctx, const float *pulse, const float *env, cons
     return GOOFER_OK;
 }
 
+// hopz / frame_off: the noise walker's per-hop bytes (stems it did not store because they are exactly zero), or nullptr: every
+// sample of every stem is there
 int launch_note_finish(goofer_ctx *ctx, float *harm, float *uv, float *bre, float *rec, float *mix, const int64_t *sample_off,
                        int n_notes, const goofer_note_params *params, const float *note_mag, float *note_peak, bool write_stems,
-                       hipStream_t st)
+                       const unsigned char *hopz, const int64_t *frame_off, hipStream_t st)
 {
     if (n_notes <= 0) return GOOFER_OK;
     // One 1024-thread workgroup fills a CU's register file (16 waves x 128 VGPRs), so its LDS is the workgroup's own: the first
@@ -1131,7 +1178,8 @@ int launch_note_finish(goofer_ctx *ctx, float *harm, float *uv, float *bre, floa
     if (lds > 48 * 1024)
         if (int arc = kernel_allow_max_lds(ctx, (const void *)k_note_finish, FIN_KEEP * FIN_THREADS * (int)sizeof(float4) > 159 * 1024 ? 159 * 1024 : FIN_KEEP * FIN_THREADS * (int)sizeof(float4))) return arc;   // (beside 64 B of static LDS)
     hipLaunchKernelGGL(k_note_finish, dim3((unsigned)n_notes), dim3(FIN_THREADS), lds, st, harm, uv, bre, rec, mix, sample_off, params,
-                       note_mag, note_peak, (write_stems ? 1 : 0) | 2 /* mix / rec: non-temporal stores */, rows);
+                       note_mag, note_peak, (write_stems ? 1 : 0) | 2 /* mix / rec: non-temporal stores */, rows, hopz, frame_off,
+                       ctx->plan.n_fft / 2, 31 - __builtin_clz((unsigned)ctx->plan.hop));
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;
 }

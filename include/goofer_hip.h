@@ -62,8 +62,9 @@ typedef struct {
     int32_t n_notes;
     int32_t n_bins;             /* n_fft/2 + 1 */
     int32_t ld;                 /* row stride of env / phi in floats */
-    int32_t mix_only;           /* 1: only `mix` (and `rec`) are final; harm / uv / bre are left holding the     */
-                                /* stems before the peak gain (callers that need just the mixed note)             */
+    int32_t mix_only;           /* 1: only `mix` (and `rec`) are final; harm / uv / bre are scratch: the stems   */
+                                /* before the peak gain, and (round 6) UNDEFINED wherever the noise walker found  */
+                                /* a stem exactly zero over a whole hop and did not store it                      */
     int64_t total_frames;       /* frame_off[n_notes]: sum over notes of 1 + n_samples/hop */
     int64_t total_samples;      /* sample_off[n_notes] */
     int64_t total_env_rows;     /* env_off[n_notes] */

@@ -185,3 +185,55 @@ def test_unvoiced_stem_band_power_matches_the_oracle_over_64_seeds(ctx):
     assert np.all(np.abs(pd / pr - 1.0) < 0.05), pd / pr
     # and the two agree in total power to 1 %
     assert abs(np.sum(uv.astype(np.float64) ** 2) / np.sum(np.stack(ref).astype(np.float64) ** 2) - 1.0) < 0.02
+
+
+def test_unstored_zero_hops_give_the_same_mix():
+    """Round 6: over a hop whose mask gain is one constant the noise walker does not STORE the stem that constant zeroes (1 KB per
+    hop and stem); a byte per hop tells k_note_finish to take zeros.  With skip_zero 0 no hop is ever flat, every sample is stored
+    and read: the two must give the same mix and — when the stems are asked for — the same stems, on sources with interior
+    unvoiced gaps, fractional mask plateaus and ramps (hard sources), loops, reversed sources and notes of a few hundred samples
+    (so that the finish pass's 16-byte groups straddle hop boundaries at every alignment)."""
+    from goofer_amd import sampler as S
+    from goofer_amd import synthetic as syn
+    from goofer_amd.device import Context
+    from goofer_amd.render import Renderer, Source
+    ctx = Context(0)
+    try:
+        r = Renderer(ctx, hop=HOP)
+        jobs = []
+        cases = [("C4", "100", "g10", "30", "900", "80", "40", "100", "0", "!120", "AA#5#AF#3#/+"),
+                 ("A3", "60", "L1fa20", "10", "701", "120", "30", "90", "0", "!100", "AB#9#"),
+                 ("G4", "100", "R1U20", "20", "653", "90", "50", "100", "0", "!120", "AA#20#"),
+                 ("F4", "100", "L0", "40", "2903", "100", "60", "100", "0", "!90", "AA#60#"),
+                 ("C5", "100", "t30", "40", "7", "2", "60", "100", "0", "!120", "AA"),
+                 ("B3", "100", "FV1", "40", "333", "11", "60", "100", "0", "!120", "AA")]
+        for k, args in enumerate(cases):
+            src = syn.make_hard_source(78000 + k, seconds=0.5) if k % 2 else syn.with_unvoiced_gaps(syn.make_source(78000 + k, seconds=0.5), 0.4, 600 + k)
+            jobs.append((Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]), S.decode_request(*args)))
+        for i in (0, 1, 5, 130):
+            src, req, _ = syn.config_note(3, i, hard=bool(i % 2))
+            jobs.append((Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"]),
+                         S.decode_request(*syn.request_args(req))))
+        prep = r.prepare(jobs, note_ids=list(range(len(jobs))))
+        # the stems' arrays come from torch's caching allocator: make sure what it hands out is NaN, not fresh zero pages, so that
+        # a sample read where nothing was stored shows
+        junk = [torch.full((int(prep["samples"]) + 4096,), float("nan"), device="cuda") for _ in range(6)]
+        del junk
+        res = {}
+        for skip in (1, 0):
+            ctx.set_option("skip_zero", skip)
+            try:
+                for keep in (False, True):
+                    o = r.run(prep, seed=21, keep_stems=keep)
+                    ctx.check()
+                    res[(skip, keep)] = {k: o[k].cpu().numpy().copy() for k in (("harm", "uv", "bre", "mix") if keep else ("mix",))}
+            finally:
+                ctx.set_option("skip_zero", 1)
+        for keep in (False, True):
+            for k in res[(1, keep)]:
+                assert np.array_equal(res[(1, keep)][k], res[(0, keep)][k]), (keep, k)
+        assert np.array_equal(res[(1, False)]["mix"], res[(1, True)]["mix"])
+        uv, bre = res[(1, True)]["uv"], res[(1, True)]["bre"]
+        assert np.isfinite(res[(1, True)]["mix"]).all() and (uv == 0).mean() > 0.2 and (bre == 0).mean() > 0.02 and np.abs(uv).max() > 0
+    finally:
+        ctx.close()
