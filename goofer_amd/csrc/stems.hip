@@ -310,14 +310,13 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
     constexpr int R = C::R, G = C::G, HOP = C::HOP, B = C::B, PER = C::PER, KN = C::KN, KPL = C::KPL, ROWF = C::ROWF;
     static_assert(R == 8, "the row staging below moves two 16-byte pieces per lane");
     extern __shared__ __align__(16) unsigned char smem[];
-    walker<M, 2, false> w;
+    walker<M, 2, false, true> w;
     w.init(smem, NCOLD(g_tw), NCOLD(g_twh), NCOLD(g_win), NCOLD(g_winb), NCOLD(freqs), NCOLD(bright), nullptr);
     const int lane = w.lane;
     const float *t_fq = w.tab, *t_br = w.tab + ROWF;
     const float *__restrict__ env = A.env;
     const float *__restrict__ phi = A.phi;
     float *__restrict__ uv = A.uv, *__restrict__ bre = A.bre;
-    unsigned char *__restrict__ hopz = A.hopz;
     const int ld = A.ld, mode = A.mode;
     // frame indices as 32-bit integers in the loop (a batch of 2^31 frames would be 4 TB of envelope rows): four scalar
     // registers fewer in a loop that spills them
@@ -364,7 +363,6 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
     // note scalars of the output stage
     int ns = 0;
     float g_b = 0.f, g_u = 0.f, kps = 0.f;
-    double step_n = 0.0, step_s = 0.0;
     const double *ss = nullptr;
     uint64_t key = 0;
     int apply_bright = 0;
@@ -441,9 +439,6 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
             ns = (w.n + MASK_DS - 1) / MASK_DS;
             g_b = p.breath_strength;
             g_u = p.uv_strength;
-            const double *steps = NCOLD(steps);
-            step_n = steps[2 * nt];
-            step_s = steps[2 * nt + 1];
             kps = w.n > 1 ? (float)(ns - 1) / (float)(w.n - 1) : 0.f;
             ss = A.short_s + (w.base / MASK_DS + nt);         // short_base()
             key = NCOLD(seed) ^ ((uint64_t)p.seed[0] | ((uint64_t)p.seed[1] << 32));
@@ -577,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
         if (f >= f0 && (flat1_t || flat0_t) && w.interior(t) && t != w.T - 1 && p0t >= 0 && p0t + HOP <= w.n && p0t + HOP <= w.out_len) {
             // The hop's mask gain is one constant: the stem it multiplies by exactly zero is exactly zero over the whole hop (a
             // product with 0.0f: +-0).  That stem's 1 KB is not stored; the hop's byte says so and k_note_finish takes zeros.
-            if (lane == 0) hopz[hop_slot + t] = (unsigned char)((flat1_t ? 1 : 0) | (flat0_t ? 2 : 0));
+            if (lane == 0) NCOLD(hopz)[hop_slot + t] = (unsigned char)((flat1_t ? 1 : 0) | (flat0_t ? 2 : 0));
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int i0 = p0t + 2 * (lane + WAVE * g);
@@ -607,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
                     }
                     wave_lds_sync();
                 }
-                if (lane == 0) hopz[hop_slot + h] = 0;         // both stems stored
+                if (lane == 0) NCOLD(hopz)[hop_slot + h] = 0;  // both stems stored
                 const int p0 = h * HOP - M;
                 const int e_hi = KN - 1, lo = kn_lo;
                 auto knot = [&](int k) {
@@ -615,6 +610,14 @@ __global__ __launch_bounds__(256, 2) void k_noise_stems(const noise_args A)
                     return w.kbuf[e < e_hi ? e : e_hi];
                 };
                 const bool inner = w.interior(h);
+                // (the two linspace steps of the note: read here, where a hop that is not flat interpolates its gains — two scalar
+                // loads per such hop instead of four scalar registers held across every frame)
+                double step_n = 0.0, step_s = 0.0;
+                if (!flat) {
+                    const double *steps = NCOLD(steps);
+                    step_n = steps[2 * w.note];
+                    step_s = steps[2 * w.note + 1];
+                }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const int i0 = p0 + 2 * (lane + WAVE * g);
