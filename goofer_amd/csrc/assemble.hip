@@ -898,13 +898,6 @@ __device__ __forceinline__ void sample_assemble_one(const goofer_assembly &a, co
 template <int SA_SPT>
 __device__ __forceinline__ void sample_assemble_fast(const goofer_assembly &a, const goofer_note_plan &p, int64_t g0, int64_t total_samples)
 {
-    static_assert(SA_SPT == 4, "a thread owns four consecutive samples");
-    // Round 6: a thread owns four CONSECUTIVE samples (two 16-byte stores; round 5: four samples a workgroup apart).  Consecutive
-    // samples almost always share their pitch-curve tick (a tick is ~230 samples at 120 bpm) and their place in the source mask
-    // (index + 1), so the tick search — half of a sample's fp64 index arithmetic — and the slice / tile arithmetic are done for the
-    // first sample and taken over by the next ones wherever EVERY lane of the wave may do so (a wave-uniform branch; a wave covers
-    // 256 samples, so about one step in four still recomputes).  What is taken over is exactly what the per-sample code would find:
-    // the tick j with j dt <= t < (j + 1) dt on the same fp64 products is unique.  Bit-identical to sample_assemble_one ("sa_fast" 0).
     const float *__restrict__ m = a.mask_src + p.src_sample_off;
     const double *__restrict__ bend = a.bend + p.bend_off;
     float *__restrict__ mask_out = a.mask_out;
@@ -915,144 +908,100 @@ __device__ __forceinline__ void sample_assemble_fast(const goofer_assembly &a, c
     const double sr = (double)a.sr, rsr = 1.0 / sr;
     const double dt = p.tick_dt, t_last = (double)nb1 * dt, rdt = fast_rcp(dt);
     const int64_t nbase = p.out_sample_off;
-    const int64_t gq = g0 + 4 * (int64_t)threadIdx.x;          // the thread's first sample
-    int left = (int)((total_samples - gq < 4) ? (total_samples - gq) : 4);
-    left = left < 0 ? 0 : left;                                // live samples of the thread (the tile lies inside one note)
-    const int i0 = (int)((left > 0 ? gq : total_samples - 1) - nbase);
-    const int n_note = p.n_out;
-
-    // -- where in the source mask: slice of the source, the tail tiled                        SillySampler.py:698-712
-    int midx[4];
-    auto src_index = [&](int i) -> int {
+    int midx[SA_SPT], ja[SA_SPT], jb[SA_SPT];
+    double tsec[SA_SPT], x0[SA_SPT], x1[SA_SPT];
+    bool live[SA_SPT];
+#pragma unroll
+    for (int u = 0; u < SA_SPT; ++u) {
+        int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
+        live[u] = g < total_samples;
+        if (!live[u]) g = total_samples - 1;                  // (the block's note owns it: n_lo == n_hi covers the block's last sample)
+        const int i = (int)(g - nbase);
+        // voicing mask: slice of the source, the tail tiled                   SillySampler.py:698-712
         uint32_t k = (uint32_t)(i - n_pre);
         if (tile) k = mod_small_nb(k, (uint32_t)tail_len, rd_tail);
-        const int idx = i < n_pre ? s_pre + i : s_tail + (int)k;
-        return rev ? ylen1 - idx : idx;
-    };
-    {
-        uint32_t k0 = (uint32_t)(i0 - n_pre);
-        if (tile) k0 = mod_small_nb(k0, (uint32_t)tail_len, rd_tail);
-        const int idx0 = i0 < n_pre ? s_pre + i0 : s_tail + (int)k0;
-        midx[0] = rev ? ylen1 - idx0 : idx0;
-        // the next three are the next three source samples unless the run leaves the consonant part or wraps around the tail
-        const bool run = (i0 + 3 < n_pre) || (i0 >= n_pre && (!tile || (int)k0 + 3 < tail_len));
-        if (__all(run)) {
-#pragma unroll
-            for (int k = 1; k < 4; ++k) midx[k] = rev ? midx[0] - k : midx[0] + k;
-        } else {
-#pragma unroll
-            for (int k = 1; k < 4; ++k) midx[k] = src_index(i0 + k < n_note ? i0 + k : n_note - 1);
-        }
-    }
-
-    float mv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) mv[k] = fv ? 1.0f : m[midx[k]];
-
-    // -- which tick of the pitch curve: estimate and one conditional step either way (see sample_assemble_one).  One tick's state
-    // is carried from sample to sample; a step on which some lane of the wave leaves its tick searches again (and loads that
-    // tick's two curve knots) for the whole wave.
-    double x0 = 0.0, x1 = 0.0, rden = 0.0, y0 = 0.0, y1 = 0.0;
-    int ja = 0, jb = 0;
-    float fo[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        double ts = div_by((double)(i0 + k), sr, rsr);
+        int idx = i < n_pre ? s_pre + i : s_tail + (int)k;
+        midx[u] = rev ? ylen1 - idx : idx;
+        // pitch curve: tick index of the sample, estimate and one conditional step either way (see sample_assemble_one)
+        double ts = div_by((double)i, sr, rsr);
         ts = ts < 0.0 ? 0.0 : (ts > t_last ? t_last : ts);
-        const bool same = k > 0 && ja != jb && x0 <= ts && ts < x1;   // inside the previous sample's tick, which is not the last
-        if (k == 0 || !__all(same)) {
-            int j = (int)(ts * rdt);
-            j = j > nb1 ? nb1 : j;
-            const double xa = (double)j * dt, xb = (double)(j + 1) * dt;
-            const bool up = j + 1 <= nb1 && xb <= ts;
-            const bool dn = !up && j > 0 && xa > ts;
-            j += (up ? 1 : 0) - (dn ? 1 : 0);
-            x0 = (double)j * dt;
-            x1 = (double)(j + 1) * dt;
-            const bool last = j >= nb1;
-            ja = last ? nb1 : j;
-            jb = last ? nb1 : j + 1;
-            // 1 / (x1 - x0): the spacing is dt up to the rounding of the two products (4e-14 relative), so one Newton step
-            // from RN(1 / dt) is the 1e-16 reciprocal fast_rcp would build from scratch
-            const double den = x1 - x0;
-            rden = fma(fma(-den, rdt, 1.0), rdt, rdt);
-            y0 = bend[ja];
-            y1 = bend[jb];
-        }
-        const double midi = (ja == jb || ts == x0) ? y0 : ((y1 - y0) * rden) * (ts - x0) + y0;
-        const double hz = 440.0 * exp2_poly(div_by(midi - 69.0, 12.0, 0.083333333333333329));   // RN(1/12)
-        fo[k] = (float)((double)mv[k] * hz);
+        int j = (int)(ts * rdt);
+        j = j > nb1 ? nb1 : j;
+        const double xa = (double)j * dt, xb = (double)(j + 1) * dt;
+        const bool up = j + 1 <= nb1 && xb <= ts;
+        const bool dn = !up && j > 0 && xa > ts;
+        j += (up ? 1 : 0) - (dn ? 1 : 0);
+        tsec[u] = ts;
+        x0[u] = (double)j * dt;
+        x1[u] = (double)(j + 1) * dt;
+        const bool last = j >= nb1;
+        ja[u] = last ? nb1 : j;
+        jb[u] = last ? nb1 : j + 1;
     }
-    if (left == 4) {
-        *reinterpret_cast<float4 *>(mask_out + gq) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-        *reinterpret_cast<float4 *>(f0_out + gq) = make_float4(fo[0], fo[1], fo[2], fo[3]);
-    } else {
+    float mv[SA_SPT];
+    double y0[SA_SPT], y1[SA_SPT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < left) {
-                mask_out[gq + k] = mv[k];
-                f0_out[gq + k] = fo[k];
-            }
+    for (int u = 0; u < SA_SPT; ++u) {
+        mv[u] = fv ? 1.0f : m[midx[u]];
+        y0[u] = bend[ja[u]];
+        y1[u] = bend[jb[u]];
+    }
+    float fo[SA_SPT];
+#pragma unroll
+    for (int u = 0; u < SA_SPT; ++u) {
+        // 1 / (x1 - x0): the spacing is dt up to the rounding of the two products (4e-14 relative), so one Newton step
+        // from RN(1 / dt) is the 1e-16 reciprocal fast_rcp would build from scratch
+        const double den = x1[u] - x0[u];
+        const double rden = fma(fma(-den, rdt, 1.0), rdt, rdt);
+        const double midi = (ja[u] == jb[u] || tsec[u] == x0[u]) ? y0[u] : ((y1[u] - y0[u]) * rden) * (tsec[u] - x0[u]) + y0[u];
+        const double hz = 440.0 * exp2_poly(div_by(midi - 69.0, 12.0, 0.083333333333333329));   // RN(1/12)
+        fo[u] = (float)((double)mv[u] * hz);
+    }
+#pragma unroll
+    for (int u = 0; u < SA_SPT; ++u) {
+        const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
+        if (live[u]) {
+            mask_out[g] = mv[u];
+            f0_out[g] = fo[u];
+        }
     }
 }
 
-constexpr int SA_TILES = 4;       // measured in one process: 1 tile 1.827 ms per step, 3: 1.774, 4: 1.747, 6: 1.756, 8: 1.780
 template <int SA_SPT>
-__global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a, int64_t total_samples, int fast, int sa_tiles)
+__global__ __launch_bounds__(256) void k_sample_assemble(const goofer_assembly a, int64_t total_samples, int fast)
 {
-    // A workgroup takes `sa_tiles` (SA_TILES) consecutive tiles of 256 * SA_SPT samples: the note search (two rounds of dependent
-    // loads and a barrier) is paid once for as long as the tiles stay inside one note, and a quarter as many workgroups come and
-    // go beside the envelope kernels of the other stream.  (A run-time bound: as a constant the loop is unrolled four times.)
-    // Alone the kernel is no faster (0.20-0.23 ms; 80 registers, six waves); the step is: 1.832 -> 1.788 ms on one box.
     __shared__ int s_pair[2];
-    int n_lo = -1, n_hi = -2;
-    int64_t cur_lo = 0, cur_hi = -1;                          // samples of note n_lo while n_lo == n_hi
-    for (int tt = 0; tt < sa_tiles; ++tt) {
-        const int64_t g0 = ((int64_t)blockIdx.x * sa_tiles + tt) * (blockDim.x * SA_SPT);
-        if (g0 >= total_samples) break;
+    const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x * SA_SPT);
+    if (threadIdx.x < WAVE) {
+        // notes own [out_sample_off, out_sample_off + n_out): first wave searches the plan array cooperatively
+        auto key = [&](int k) { return a.notes[k].out_sample_off; };
         int64_t gl = g0 + (int64_t)blockDim.x * SA_SPT - 1;
         if (gl > total_samples - 1) gl = total_samples - 1;
-        if (!(n_lo == n_hi && g0 >= cur_lo && gl <= cur_hi)) {   // (workgroup-uniform)
-            if (tt > 0) __syncthreads();                      // every thread has read the previous pair
-            if (threadIdx.x < WAVE) {
-                // notes own [out_sample_off, out_sample_off + n_out): first wave searches the plan array cooperatively
-                auto key = [&](int k) { return a.notes[k].out_sample_off; };
-                const int lo = wave_find(a.n_notes, g0, (int)threadIdx.x, key);
-                const int hi = wave_find(a.n_notes, gl, (int)threadIdx.x, key);
-                if (threadIdx.x == 0) { s_pair[0] = lo; s_pair[1] = hi; }
-            }
-            __syncthreads();
-            n_lo = __builtin_amdgcn_readfirstlane(s_pair[0]);
-            n_hi = __builtin_amdgcn_readfirstlane(s_pair[1]);
-            if (n_lo == n_hi) {
-                cur_lo = a.notes[n_lo].out_sample_off;
-                cur_hi = cur_lo + a.notes[n_lo].n_out - 1;
-            }
+        const int lo = wave_find(a.n_notes, g0, (int)threadIdx.x, key);
+        const int hi = wave_find(a.n_notes, gl, (int)threadIdx.x, key);
+        if (threadIdx.x == 0) { s_pair[0] = lo; s_pair[1] = hi; }
+    }
+    __syncthreads();
+    const int n_lo = __builtin_amdgcn_readfirstlane(s_pair[0]), n_hi = __builtin_amdgcn_readfirstlane(s_pair[1]);
+    if (n_lo == n_hi) {
+        const goofer_note_plan &p = a.notes[n_lo];           // uniform note: the 300-byte plan comes in through scalar loads
+        if (fast && !p.vel_active && p.fry_dir == 0 && !(p.pd_on && a.bend_out) && !a.f0_mul_out && p.n_out < (1 << 21) && p.tail_len < (1 << 24) &&
+            p.tail_len > 0 && p.n_bend >= 1) {
+            sample_assemble_fast<SA_SPT>(a, p, g0, total_samples);
+            return;
         }
-        if (n_lo == n_hi) {
-            // uniform note: the 300-byte plan comes in through scalar loads — per tile (the empty asm keeps the compiler from
-            // hoisting forty plan fields out of the tile loop, where they would live in SGPRs it does not have)
-            int nl = __builtin_amdgcn_readfirstlane(n_lo);
-            asm volatile("" : "+s"(nl));
-            const goofer_note_plan &p = a.notes[nl];
-            if (fast && !p.vel_active && p.fry_dir == 0 && !(p.pd_on && a.bend_out) && !a.f0_mul_out && p.n_out < (1 << 21) && p.tail_len < (1 << 24) &&
-                p.tail_len > 0 && p.n_bend >= 1) {
-                sample_assemble_fast<SA_SPT>(a, p, g0, gl + 1);
-                continue;
-            }
 #pragma unroll
-            for (int u = 0; u < SA_SPT; ++u) {
-                const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
-                if (g <= gl) sample_assemble_one(a, p, g);
-            }
-        } else {
-            for (int u = 0; u < SA_SPT; ++u) {
-                const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
-                if (g > gl) break;
-                int note = n_lo;
-                while (note + 1 < a.n_notes && a.notes[note + 1].out_sample_off <= g) ++note;
-                sample_assemble_one(a, a.notes[note], g);
-            }
+        for (int u = 0; u < SA_SPT; ++u) {
+            const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
+            if (g < total_samples) sample_assemble_one(a, p, g);
+        }
+    } else {
+        for (int u = 0; u < SA_SPT; ++u) {
+            const int64_t g = g0 + threadIdx.x + (int64_t)u * blockDim.x;
+            if (g >= total_samples) break;
+            int note = n_lo;
+            while (note + 1 < a.n_notes && a.notes[note + 1].out_sample_off <= g) ++note;
+            sample_assemble_one(a, a.notes[note], g);
         }
     }
 }
@@ -1174,11 +1123,10 @@ int launch_assemble(goofer_ctx *ctx, const goofer_assembly *a, int *row_note_edi
         hipStream_t fst = on_side ? ctx->side : st;
         if (on_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_entry, 0));
         constexpr int spt = 4;                                  // (8 / 16 samples per thread measured no faster)
-        const int sa_tiles = SA_TILES;
-        const dim3 sgrid((unsigned)((a->total_samples + 256 * spt * sa_tiles - 1) / (256 * spt * sa_tiles)));
+        const dim3 sgrid((unsigned)((a->total_samples + 256 * spt - 1) / (256 * spt)));
         const int sa_fast = ctx->sa_fast ? 1 : 0;
         HIP_TRY(ctx, mark(2, 0, fst));
-        hipLaunchKernelGGL(k_sample_assemble<spt>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast, sa_tiles);
+        hipLaunchKernelGGL(k_sample_assemble<spt>, sgrid, dim3(256), 0, fst, *a, a->total_samples, sa_fast);
         LAUNCH_CHECK(ctx);
         HIP_TRY(ctx, mark(2, 1, fst));
         if (ctx->early_req && ctx->ev_f0) {

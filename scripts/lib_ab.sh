@@ -1,17 +1,17 @@
 #!/bin/bash
-# the plain step of the default workload under two builds of the library, alternating processes on one box
-# usage: scripts/lib_ab.sh <libA.so> <libB.so> [rounds]
-A=$1; B=$2; R=${3:-3}
+# the plain step of a workload under two builds of the library, alternating processes on one box
+# usage: scripts/lib_ab.sh <libA.so> <libB.so> [rounds] [notes] [config]
+A=$1; B=$2; R=${3:-3}; N=${4:-1024}; C=${5:-3}
 for r in $(seq 1 $R); do
   for L in "$A" "$B"; do
-    GOOFER_HIP_LIB=$PWD/$L python - <<'PY'
+    GOOFER_HIP_LIB=$PWD/$L python - $N $C <<'PY'
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 from goofer_amd.device import Context
 from goofer_amd.workload import SamplerWorkload
 ctx = Context(0)
-wl = SamplerWorkload(ctx, 3, list(range(1024)))
+wl = SamplerWorkload(ctx, int(sys.argv[2]), list(range(int(sys.argv[1]))))
 best = 1e9
 for rep in range(4):
     for _ in range(3):
@@ -24,7 +24,7 @@ for rep in range(4):
     t1.record()
     torch.cuda.synchronize()
     best = min(best, t0.elapsed_time(t1) / 30)
-print(os.path.basename(os.environ["GOOFER_HIP_LIB"]), "%.3f ms" % best)
+print(os.path.basename(os.environ["GOOFER_HIP_LIB"]), "config %s, %s notes: %.3f ms" % (sys.argv[2], sys.argv[1], best))
 PY
   done
 done
