@@ -74,10 +74,11 @@ def test_hard_sources_as_one_batch(renderer):
     print("hard fixtures as one batch: worst %.3g" % worst)
 
 
-@pytest.mark.parametrize("config,ids", [(3, list(range(0, 1024, 16))), (4, list(range(5, 10000, 157)))])
+@pytest.mark.parametrize("config,ids", [(3, list(range(0, 1024, 16))), (4, list(range(5, 10000, 157))), (5, list(range(3, 1024, 64)))])
 def test_baseline_requests_on_hard_sources_vs_oracle(config, ids):
-    """64 requests each of BASELINE configs 3 (full formant set, V/B/U mix) and 4 (L0 / L1 / L2 over log-uniform lengths) on the
-    hard version of their samples, one device batch per config, against the CPU oracle's render of every note."""
+    """64 requests each of BASELINE configs 3 (full formant set, V/B/U mix) and 4 (L0 / L1 / L2 over log-uniform lengths), 16 of
+    config 5 (96 kHz, n_fft 2048, hop 96, br + es: the spectra pipeline with per-frame skipping) on the hard version of their
+    samples, one device batch per config, against the CPU oracle's render of every note."""
     from goofer_amd.device import Context
     from goofer_amd.render import Renderer, Source
     from goofer_amd import sampler as S
