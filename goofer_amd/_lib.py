@@ -44,7 +44,7 @@ NOTE_PLAN = np.dtype([
 PLAN_REQUEST = np.dtype([
     ("offset", "<f8"), ("length", "<f8"), ("consonant", "<f8"), ("cutoff", "<f8"), ("vel_factor", "<f8"), ("fry", "<f8"),
     ("fry_glide", "<f8"), ("ylen", "<i8"), ("sr", "<i4"), ("n_src_frames", "<i4"), ("loop_mode", "<i4"), ("reverse", "<i4"),
-    ("tracks", "<u8", 4), ("track_len", "<i4", 4),
+    ("tracks", "<u8", 4), ("track_len", "<i4", 4), ("fst_skip", "<i4", 4),
 ], align=True)
 PLAN_GEOMETRY = np.dtype([
     ("start_sample", "<i8"), ("consonant_sample", "<i8"), ("end_sample", "<i8"), ("tap_off", "<i8"), ("vel_factor", "<f8"),

@@ -119,13 +119,6 @@ inline void prefix_positions(int64_t n, int64_t pre_len, double factor, std::vec
     for (int64_t i = 0; i < m; ++i) pos[i] = i < pre_new ? (double)i / factor : (double)(i - pre_new) + (double)pre_len;
 }
 
-struct note_out {
-    goofer_plan_geometry g;
-    std::vector<tap4> taps;       // [n_out_rows]
-    std::vector<double> F;        // [n_out_rows x 4]
-    std::vector<float> fst;       // [n_out_rows x 4]
-};
-
 // pad_trim_to_len (GOOFER.py:64-70) on a non-empty vector
 template <typename T> inline void fit_len(std::vector<T> &v, int64_t T_)
 {
@@ -134,7 +127,7 @@ template <typename T> inline void fit_len(std::vector<T> &v, int64_t T_)
 }
 
 struct scratch {
-    std::vector<tap4> stage1;
+    std::vector<tap4> stage1, taps;
     std::vector<double> xo, xn, pos, f, tmp, pad;
     std::vector<float> tr, lp, canon, work;
     std::vector<int32_t> rows;
@@ -148,14 +141,31 @@ __attribute__((target_clones("avx2", "default")))
 #endif
 void fir_rows(const double *pp, const double *taps, int n_taps, int64_t T, double *acc)
 {
-    for (int64_t t = 0; t < T; ++t) acc[t] = taps[0] * pp[t];
-    for (int j = 1; j < n_taps; ++j) {
-        const double kj = taps[j];
-        const double *pj = pp + j;
-        for (int64_t t = 0; t < T; ++t) {
-            const double prod = kj * pj[t];
-            acc[t] = acc[t] + prod;
+    // sixteen frames at a time, their sums in registers across the taps (round 6: one pass over the taps per block instead of a
+    // pass over the whole track per tap, which loaded and stored every partial sum 33 times)
+    constexpr int W = 16;
+    int64_t t0 = 0;
+    for (; t0 + W <= T; t0 += W) {
+        double a[W];
+        const double *p0 = pp + t0;
+        for (int u = 0; u < W; ++u) a[u] = taps[0] * p0[u];
+        for (int j = 1; j < n_taps; ++j) {
+            const double kj = taps[j];
+            const double *pj = p0 + j;
+            for (int u = 0; u < W; ++u) {
+                const double prod = kj * pj[u];
+                a[u] = a[u] + prod;
+            }
         }
+        for (int u = 0; u < W; ++u) acc[t0 + u] = a[u];
+    }
+    for (int64_t t = t0; t < T; ++t) {
+        double a = taps[0] * pp[t];
+        for (int j = 1; j < n_taps; ++j) {
+            const double prod = taps[j] * pp[t + j];
+            a = a + prod;
+        }
+        acc[t] = a;
     }
 }
 
@@ -204,15 +214,17 @@ bool repair_track(float *x, int64_t T, float min_hz, float max_hz, scratch &s)
     return true;
 }
 
-// One note.  status != 0: a case the reference answers with an exception (or Python slicing of negative counts) — the caller
-// re-plans the batch with the numpy planner, which raises what the reference raises.
-void plan_one(const goofer_plan_request &r, int hop, int trim_rows, const double *gtaps, int gradius, note_out &o, scratch &s)
+// Cut points and clipped slices of a note (:453-500): what both passes of the planner start from.
+struct cuts {
+    int64_t s0, s1, s2, fr0, fr1, fr2;
+    int64_t f0a, f0b, f1a, f1b, n_pre_f, n_tail, want_f, want_s;
+    int64_t s0a, s1a, n_pre, tail_len;
+};
+// false: a case the reference answers with an exception (or Python slicing of negative counts)
+inline bool plan_cuts(const goofer_plan_request &r, int hop, cuts &c)
 {
-    goofer_plan_geometry &g = o.g;
-    std::memset(&g, 0, sizeof(g));
     const double sr = (double)r.sr;
     const int64_t ylen = r.ylen, T_src = r.n_src_frames;
-    // -- cut points (:453-487)
     const double total = (double)ylen / sr;
     const double a0 = r.offset;
     const double b0 = r.cutoff < 0 ? (r.offset - r.cutoff) : (total - r.cutoff);
@@ -222,69 +234,101 @@ void plan_one(const goofer_plan_request &r, int hop, int trim_rows, const double
         off = total - b0;
         cut = total - (off + L);
     }
-    const int64_t s0 = (int64_t)(off * sr);
-    const int64_t s1 = s0 + (int64_t)(r.consonant * sr);
-    const int64_t s2 = (int64_t)((cut < 0 ? (off - cut) : (total - cut)) * sr);
-    const int64_t fr0 = floor_div(s0, hop), fr1 = floor_div(s1, hop), fr2 = floor_div(s2, hop);
-    g.start_sample = s0; g.consonant_sample = s1; g.end_sample = s2;
-    g.start_frame = (int32_t)fr0; g.consonant_frame = (int32_t)fr1; g.end_frame = (int32_t)fr2;
+    c.s0 = (int64_t)(off * sr);
+    c.s1 = c.s0 + (int64_t)(r.consonant * sr);
+    c.s2 = (int64_t)((cut < 0 ? (off - cut) : (total - cut)) * sr);
+    c.fr0 = floor_div(c.s0, hop);
+    c.fr1 = floor_div(c.s1, hop);
+    c.fr2 = floor_div(c.s2, hop);
+    clip_slice(c.fr0, c.fr1, T_src, c.f0a, c.f0b);
+    clip_slice(c.fr1, c.fr2, T_src, c.f1a, c.f1b);
+    c.n_pre_f = c.f0b - c.f0a;
+    c.n_tail = c.f1b - c.f1a;
+    c.want_f = (int64_t)std::ceil(r.length * sr / (double)hop);
+    c.want_s = (int64_t)(r.length * sr);
+    int64_t s0b, s1b;
+    clip_slice(c.s0, c.s1, ylen, c.s0a, s0b);
+    clip_slice(c.s1, c.s2, ylen, c.s1a, s1b);
+    c.n_pre = s0b - c.s0a;
+    c.tail_len = s1b - c.s1a;
+    return !(c.want_f < 0 || c.want_s < 0 || (c.n_tail < c.want_f && c.n_tail == 0) || (c.tail_len < c.want_s && c.tail_len == 0));
+}
 
-    int64_t f0a, f0b, f1a, f1b;
-    clip_slice(fr0, fr1, T_src, f0a, f0b);
-    clip_slice(fr1, fr2, T_src, f1a, f1b);
-    const int64_t n_pre_f = f0b - f0a, n_tail = f1b - f1a;
-    const int64_t want_f = (int64_t)std::ceil(r.length * sr / (double)hop);
-    const int64_t want_s = (int64_t)(r.length * sr);
-    int64_t s0a, s0b, s1a, s1b;
-    clip_slice(s0, s1, ylen, s0a, s0b);
-    clip_slice(s1, s2, ylen, s1a, s1b);
-    const int64_t n_pre = s0b - s0a, tail_len = s1b - s1a;
-    if (want_f < 0 || want_s < 0 || (n_tail < want_f && n_tail == 0) || (tail_len < want_s && tail_len == 0)) {
-        g.status = 1;
-        return;
-    }
-    // -- loop-mode frame taps (:631-696)
-    std::vector<tap4> &st = s.stage1;
-    st.clear();
-    bool f64 = false;
-    auto copy_row = [&](int64_t row) { st.push_back(tap4{{(int32_t)row, (int32_t)row, 0, 0}, {1.0, 0.0, 0.0, 0.0}}); };
-    for (int64_t q = f0a; q < f0b; ++q) copy_row(q);
+// Where stage 1 puts its rows: the note's tap list — or a counter, for the pass that only sizes the batch.
+struct tap_list {
+    static constexpr bool counting = false;
+    std::vector<tap4> &st;
+    void row(int64_t q) { st.push_back(tap4{{(int32_t)q, (int32_t)q, 0, 0}, {1.0, 0.0, 0.0, 0.0}}); }
+    void tap(const tap4 &t) { st.push_back(t); }
+    void many(int64_t) {}
+};
+struct tap_count {
+    static constexpr bool counting = true;
+    int64_t n = 0;
+    void row(int64_t) { ++n; }
+    void tap(const tap4 &) { ++n; }
+    void many(int64_t k) { n += std::max<int64_t>(k, 0); }
+};
+
+// -- loop-mode frame taps (:631-696): one source for the rows and for their count
+template <class Sink> void loop_taps(const goofer_plan_request &r, const cuts &c, Sink &st, scratch &s, bool &f64)
+{
+    const int64_t f0a = c.f0a, f0b = c.f0b, f1a = c.f1a, n_tail = c.n_tail, want_f = c.want_f;
+    f64 = false;
+    if (Sink::counting) st.many(f0b - f0a);
+    else for (int64_t q = f0a; q < f0b; ++q) st.row(q);
     if (n_tail >= want_f) {
-        for (int64_t q = 0; q < want_f; ++q) copy_row(f1a + q);
+        if (Sink::counting) st.many(want_f);
+        else for (int64_t q = 0; q < want_f; ++q) st.row(f1a + q);
     } else if (r.loop_mode == 2) {
         const int64_t n_new = (int64_t)((double)n_tail * ((double)want_f / (double)n_tail));
-        linspace(0.0, 1.0, n_tail, s.xo);
-        linspace(0.0, 1.0, n_new, s.xn);
-        for (int64_t q = 0; q < n_new; ++q) {
-            const lerp_tap t = interp_tap(s.xo, s.xn[q]);
-            const int32_t j1 = n_tail == 1 ? t.j : t.j + 1;
-            st.push_back(tap4{{(int32_t)(f1a + t.j), (int32_t)(f1a + j1), 0, 0}, {t.w0, t.w1, 0.0, 0.0}});
+        if (Sink::counting) {
+            st.many(n_new);
+        } else {
+            linspace(0.0, 1.0, n_tail, s.xo);
+            linspace(0.0, 1.0, n_new, s.xn);
+            for (int64_t q = 0; q < n_new; ++q) {
+                const lerp_tap t = interp_tap(s.xo, s.xn[q]);
+                const int32_t j1 = n_tail == 1 ? t.j : t.j + 1;
+                st.tap(tap4{{(int32_t)(f1a + t.j), (int32_t)(f1a + j1), 0, 0}, {t.w0, t.w1, 0.0, 0.0}});
+            }
         }
-        f64 = true;                                            // even when n_new == 0: Taps(.., True) of an empty stretch is not counted (len 0)
-        if (n_new == 0) f64 = false;
+        f64 = n_new > 0;                                       // Taps(.., True) of an empty stretch is not counted (len 0)
     } else if (r.loop_mode == 1) {
         const int64_t reps = want_f / n_tail, rem = want_f % n_tail;
-        for (int64_t c = 0; c <= reps; ++c) {
-            const int64_t m = c < reps ? n_tail : rem;
-            for (int64_t q = 0; q < m; ++q) st.push_back(tap4{{(int32_t)(f1a + q), (int32_t)(f1a + n_tail - 1 - q), 0, 0}, {0.5, 0.5, 0.0, 0.0}});
+        if (Sink::counting) {
+            st.many(reps * n_tail + rem);
+        } else {
+            for (int64_t cc = 0; cc <= reps; ++cc) {
+                const int64_t m = cc < reps ? n_tail : rem;
+                for (int64_t q = 0; q < m; ++q) st.tap(tap4{{(int32_t)(f1a + q), (int32_t)(f1a + n_tail - 1 - q), 0, 0}, {0.5, 0.5, 0.0, 0.0}});
+            }
         }
     } else {
         // L0: every repeat but the last is "the tail, its last k frames cross-faded into the first k of a fresh copy, then the
         // rest of that copy" — and the fresh copy is appended again as the next chunk (:657-672)
         const int64_t n = n_tail, reps = want_f / n, rem = want_f % n;
+        auto rows = [&](int64_t a, int64_t b) {                // tail[a:b]
+            if (Sink::counting) st.many(b - a);
+            else for (int64_t q = a; q < b; ++q) st.row(f1a + q);
+        };
         auto faded = [&](int64_t m, int64_t k) {               // tail[:n-k] + cross-fade(k) + first m frames of the tail from k on
-            for (int64_t q = 0; q < n - k; ++q) copy_row(f1a + q);
+            rows(0, n - k);
             if (k > 0) {
-                linspace(0.0, 1.0, k, s.xo);                   // up
-                linspace(1.0, 0.0, k, s.xn);                   // down
-                for (int64_t q = 0; q < k; ++q) st.push_back(tap4{{(int32_t)(f1a + n - k + q), (int32_t)(f1a + q), 0, 0}, {s.xn[q], s.xo[q], 0.0, 0.0}});
+                if (Sink::counting) {
+                    st.many(k);
+                } else {
+                    linspace(0.0, 1.0, k, s.xo);               // up
+                    linspace(1.0, 0.0, k, s.xn);               // down
+                    for (int64_t q = 0; q < k; ++q) st.tap(tap4{{(int32_t)(f1a + n - k + q), (int32_t)(f1a + q), 0, 0}, {s.xn[q], s.xo[q], 0.0, 0.0}});
+                }
                 f64 = true;
             }
-            for (int64_t q = k; q < m; ++q) copy_row(f1a + q);
+            rows(k, m);
         };
         const int64_t k = std::min<int64_t>(8, n / 2);
-        for (int64_t c = 0; c + 1 < reps; ++c) {
-            if (k == 0) for (int64_t q = 0; q < n; ++q) copy_row(f1a + q);      // a one-frame tail: the chunk is the tail itself
+        for (int64_t cc = 0; cc + 1 < reps; ++cc) {
+            if (k == 0) rows(0, n);                            // a one-frame tail: the chunk is the tail itself
             else faded(n, k);
         }
         if (rem) {
@@ -292,26 +336,108 @@ void plan_one(const goofer_plan_request &r, int hop, int trim_rows, const double
             if (kr > 0) {
                 faded(rem, kr);
             } else {
-                for (int64_t q = 0; q < n; ++q) copy_row(f1a + q);
-                for (int64_t q = 0; q < rem; ++q) copy_row(f1a + q);
+                rows(0, n);
+                rows(0, rem);
             }
         } else {
-            for (int64_t q = 0; q < n; ++q) copy_row(f1a + q);
+            rows(0, n);
         }
+    }
+}
+
+// Sample counts and the velocity prefix stretch's geometry (:698-788) from the note's T_target = n1 frames; returns the
+// frames of the stretched note (T_full) and sets g.n_out_rows (what synthesize can reach when trim_rows).
+inline int64_t plan_sizes(const goofer_plan_request &r, const cuts &c, int64_t n1, int hop, int trim_rows, goofer_plan_geometry &g)
+{
+    g.n_pre = (int32_t)c.n_pre; g.tail_len = (int32_t)c.tail_len; g.want_samples = (int32_t)c.want_s;
+    g.s_pre = (int32_t)c.s0a; g.s_tail = (int32_t)c.s1a;
+    g.n_before_vel = (int32_t)(c.n_pre + c.want_s);
+    const double vel = r.vel_factor;
+    const bool vel_active = std::fabs(vel - 1.0) > 1e-6 && c.n_pre_f > 1 && c.n_pre > 1;
+    g.vel_active = vel_active ? 1 : 0;
+    g.vel_factor = vel_active ? vel : 1.0;
+    int64_t T_full = n1;
+    if (vel_active) {
+        const int64_t pre_new_f = std::max<int64_t>(1, py_round((double)c.n_pre_f * vel));   // (prefix_positions' frame count)
+        T_full = std::max<int64_t>(pre_new_f + (n1 - c.n_pre_f), 0);
+        const int64_t pre_new = std::max<int64_t>(1, py_round((double)c.n_pre * vel));
+        g.pre_new = (int32_t)pre_new;
+        g.n_out = (int32_t)(pre_new + c.want_s);
+    } else {
+        g.pre_new = (int32_t)c.n_pre;
+        g.n_out = g.n_before_vel;
+    }
+    g.n_rows = (int32_t)T_full;
+    int64_t T_env = T_full;
+    if (trim_rows && g.n_out > 0 && T_env > 1 + g.n_out / hop) T_env = 1 + g.n_out / hop;   // gf.synthesize never reads further (GOOFER.py:1115-1119)
+    g.n_out_rows = (int32_t)T_env;
+    return T_full;
+}
+
+// Pass 1: a note's status and row count (g.status, g.n_out_rows), nothing else of g is final.
+inline void plan_count(const goofer_plan_request &r, int hop, int trim_rows, goofer_plan_geometry &g, scratch &s)
+{
+    std::memset(&g, 0, sizeof(g));
+    cuts c;
+    if (!plan_cuts(r, hop, c)) {
+        g.status = 1;
+        return;
+    }
+    tap_count k;
+    bool f64;
+    loop_taps(r, c, k, s, f64);
+    plan_sizes(r, c, k.n, hop, trim_rows, g);
+}
+
+// Where a note's rows go: the caller's arrays at the note's first row (four values per row each).
+struct row_dest {
+    int32_t *tap_idx;
+    double *tap_w, *F;
+    float *fst;
+};
+
+// Pass 2, one note: everything, its rows written at `d`.  status 1: a case the reference answers with an exception (or Python
+// slicing of negative counts) — the caller re-plans the batch with the numpy planner, which raises what the reference raises.
+// status 2: the two passes disagree about the note's row count (a defect here; the caller takes the numpy planner as well).
+void plan_one(const goofer_plan_request &r, int hop, int trim_rows, const double *gtaps, int gradius, int64_t rows_expected,
+              goofer_plan_geometry &g, const row_dest &d, scratch &s)
+{
+    std::memset(&g, 0, sizeof(g));
+    const double sr = (double)r.sr;
+    cuts c;
+    const bool ok = plan_cuts(r, hop, c);
+    const int64_t fr0 = c.fr0, fr1 = c.fr1, fr2 = c.fr2, want_f = c.want_f, n_pre_f = c.n_pre_f;
+    g.start_sample = c.s0; g.consonant_sample = c.s1; g.end_sample = c.s2;
+    g.start_frame = (int32_t)fr0; g.consonant_frame = (int32_t)fr1; g.end_frame = (int32_t)fr2;
+    if (!ok) {
+        g.status = 1;
+        return;
+    }
+    std::vector<tap4> &st = s.stage1;
+    st.clear();
+    bool f64 = false;
+    {
+        tap_list sink{st};
+        loop_taps(r, c, sink, s, f64);
     }
     const int64_t n1 = (int64_t)st.size();                     // T_target
     // -- samples and the velocity prefix stretch (:698-788)
-    g.n_pre = (int32_t)n_pre; g.tail_len = (int32_t)tail_len; g.want_samples = (int32_t)want_s;
-    g.s_pre = (int32_t)s0a; g.s_tail = (int32_t)s1a;
-    g.n_before_vel = (int32_t)(n_pre + want_s);
+    const int64_t T_full = plan_sizes(r, c, n1, hop, trim_rows, g);
+    const int64_t T_env = g.n_out_rows;
+    const bool vel_active = g.vel_active != 0;
     const double vel = r.vel_factor;
-    const bool vel_active = std::fabs(vel - 1.0) > 1e-6 && n_pre_f > 1 && n_pre > 1;
-    g.vel_active = vel_active ? 1 : 0;
-    g.vel_factor = vel_active ? vel : 1.0;
-    std::vector<tap4> &out = o.taps;
+    if (T_env != rows_expected) {
+        g.status = 2;
+        return;
+    }
+    std::vector<tap4> &out = s.taps;
     out.clear();
     if (vel_active) {
         prefix_positions(n1, n_pre_f, vel, s.pos);
+        if ((int64_t)s.pos.size() != T_full) {
+            g.status = 2;
+            return;
+        }
         s.xo.resize((size_t)n1);
         for (int64_t q = 0; q < n1; ++q) s.xo[q] = (double)q;
         out.reserve(s.pos.size());
@@ -321,28 +447,22 @@ void plan_one(const goofer_plan_request &r, int hop, int trim_rows, const double
             out.push_back(tap4{{a.i[0], a.i[1], b.i[0], b.i[1]}, {a.w[0] * t.w0, a.w[1] * t.w0, b.w[0] * t.w1, b.w[1] * t.w1}});
         }
         f64 = true;
-        const int64_t pre_new = std::max<int64_t>(1, py_round((double)n_pre * vel));
-        g.pre_new = (int32_t)pre_new;
-        g.n_out = (int32_t)(pre_new + want_s);
     } else {
         out.reserve((size_t)n1);
         for (const tap4 &a : st) out.push_back(tap4{{a.i[0], a.i[1], a.i[0], a.i[1]}, {a.w[0], a.w[1], 0.0, 0.0}});
-        g.pre_new = (int32_t)n_pre;
-        g.n_out = g.n_before_vel;
     }
     g.env_f64 = f64 ? 1 : 0;
-    const int64_t T_full = (int64_t)out.size();
-    g.n_rows = (int32_t)T_full;
-    int64_t T_env = T_full;
-    if (trim_rows && g.n_out > 0 && T_env > 1 + g.n_out / hop) T_env = 1 + g.n_out / hop;   // gf.synthesize never reads further (GOOFER.py:1115-1119)
-    g.n_out_rows = (int32_t)T_env;
     int32_t lo = INT32_MAX, hi = -1;
-    for (int64_t t = 0; t < T_env; ++t)
-        for (int c = 0; c < 4; ++c)
-            if (out[t].w[c] != 0.0) {
-                lo = std::min(lo, out[t].i[c]);
-                hi = std::max(hi, out[t].i[c]);
+    for (int64_t t = 0; t < T_env; ++t) {
+        for (int cc = 0; cc < 4; ++cc) {
+            if (out[t].w[cc] != 0.0) {
+                lo = std::min(lo, out[t].i[cc]);
+                hi = std::max(hi, out[t].i[cc]);
             }
+            d.tap_idx[(size_t)t * 4 + cc] = out[t].i[cc];
+            d.tap_w[(size_t)t * 4 + cc] = out[t].w[cc];
+        }
+    }
     g.row_lo = hi < 0 ? 0 : lo;
     g.row_hi = hi < 0 ? 0 : hi + 1;
 
@@ -379,8 +499,8 @@ void plan_one(const goofer_plan_request &r, int hop, int trim_rows, const double
     }
 
     // -- formant tracks (:714-763, 771-806)
-    o.F.assign((size_t)T_env * 4, 0.0);
-    o.fst.assign((size_t)T_env * 4, 0.f);
+    std::fill(d.F, d.F + (size_t)T_env * 4, 0.0);
+    std::fill(d.fst, d.fst + (size_t)T_env * 4, 0.f);
     const float max_hz = (float)(sr * 0.48);
     const float min_hz[4] = {120.0f, 300.0f, 1500.0f, 2000.0f};
     for (int c = 0; c < 4; ++c) {
@@ -461,15 +581,16 @@ void plan_one(const goofer_plan_request &r, int hop, int trim_rows, const double
         if (T_full > 0) {
             all_bad = !repair_track(wp, T_full, min_hz[c], max_hz, s);   // (writes only when some value is good: an all-bad canon stays)
         }
-        // sigma-4 blur of the repaired track (fp64 taps in ascending order, numpy 'reflect'), rounded to fp32
-        if (T_full > 0) {
+        // sigma-4 blur of the repaired track (fp64 taps in ascending order, numpy 'reflect'), rounded to fp32 — unless the caller
+        // says the note's strength for this formant is off (the assembly then never reads the column: it stays 0)
+        if (T_full > 0 && !r.fst_skip[c]) {
             std::vector<double> &pad = s.pad;
             pad.resize((size_t)(T_full + 2 * gradius));
             const int64_t period = T_full > 1 ? 2 * (T_full - 1) : 1;
             // numpy 'reflect' as a periodic map; one reflection covers every index when the radius is below the track length
             // (two 64-bit divisions per element were half of this function's time)
             const bool near = gradius < T_full;
-            for (int64_t q = -gradius; q < T_full + gradius; ++q) {
+            auto edge = [&](int64_t q) {
                 int64_t m;
                 if (T_full <= 1) m = 0;
                 else if (near) m = q < 0 ? -q : (q >= T_full ? period - q : q);
@@ -478,20 +599,26 @@ void plan_one(const goofer_plan_request &r, int hop, int trim_rows, const double
                     m = m < T_full ? m : period - m;
                 }
                 pad[q + gradius] = all_bad ? 300.0 : (double)wp[m];
-            }
+            };
+            // (only the frames the blur below reads: the first T_env + 2 radius of the padded track)
+            const int64_t q_end = std::min<int64_t>(T_full + gradius, T_env + gradius);
+            for (int64_t q = -gradius; q < 0; ++q) edge(q);
+            const int64_t mid = std::min<int64_t>(T_full, q_end);
+            if (all_bad) std::fill(pad.begin() + gradius, pad.begin() + gradius + mid, 300.0);
+            else for (int64_t q = 0; q < mid; ++q) pad[q + gradius] = (double)wp[q];
+            for (int64_t q = T_full; q < q_end; ++q) edge(q);
             // taps outside, frames inside: every frame still adds its products in ascending tap order (the sums are the same
             // bits), and the inner loop is a plain vector loop over t instead of a reduction over j
             std::vector<double> &acc = s.tmp;
             acc.resize((size_t)T_env);
             fir_rows(pad.data(), gtaps, 2 * gradius + 1, T_env, acc.data());
-            for (int64_t t = 0; t < T_env; ++t) o.fst[(size_t)t * 4 + c] = (float)acc[t];
+            for (int64_t t = 0; t < T_env; ++t) d.fst[(size_t)t * 4 + c] = (float)acc[t];
         }
         if (have) {
             const int64_t Lc = (int64_t)canon.size();
-            for (int64_t t = 0; t < T_env; ++t) o.F[(size_t)t * 4 + c] = (double)canon[t < Lc ? t : Lc - 1];
+            for (int64_t t = 0; t < T_env; ++t) d.F[(size_t)t * 4 + c] = (double)canon[t < Lc ? t : Lc - 1];
         }
     }
-    out.resize((size_t)T_env);
 }
 
 }  // namespace
@@ -537,22 +664,7 @@ static int run_threads(int nt, const std::function<void(int)> &fn)
     return GOOFER_OK;
 }
 
-// What the worker threads produce: per note its geometry and where its rows sit in the buffers of the thread that planned it.
-// (A vector triple per note was 3 x n_notes allocations — and as many frees on the calling thread — per batch.)
-struct thread_rows {
-    std::vector<tap4> taps;
-    std::vector<double> F;
-    std::vector<float> fst;
-};
-struct planned {
-    std::vector<goofer_plan_geometry> geo;
-    std::vector<int64_t> at;           // first row of the note inside its thread's buffers
-    std::vector<thread_rows> rows;     // [nt]
-    int nt = 1;
-};
-
-static int plan_all(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps, int gauss_radius,
-                    int n_threads, planned &P)
+static int check_requests(const goofer_plan_request *req, int n_notes, int hop, const double *gauss_taps, int gauss_radius)
 {
     if (!req || n_notes < 0 || hop <= 0 || !gauss_taps || gauss_radius < 0) return GOOFER_EINVAL;
     for (int i = 0; i < n_notes; ++i) {
@@ -574,57 +686,56 @@ static int plan_all(const goofer_plan_request *req, int n_notes, int hop, int tr
         for (int c = 0; c < 4; ++c)
             if (q.track_len[c] > 0 && !q.tracks[c]) return GOOFER_EINVAL;
     }
-    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-    nt = std::max(1, std::min(nt, (n_notes + 31) / 32));
-    P.nt = nt;
-    try {
-        P.geo.resize((size_t)n_notes);
-        P.at.assign((size_t)n_notes, 0);
-        P.rows.resize((size_t)nt);
-    } catch (...) {
-        return GOOFER_ENOMEM;
+    return GOOFER_OK;
+}
+
+static int pick_threads(int n_threads, int n_notes)
+{
+    const int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    return std::max(1, std::min(nt, (n_notes + 31) / 32));
+}
+
+// Pass 1: every note's status and row count, then its first row (tap_off); returns the rows of the batch.  A note is sized
+// in ~0.1 us (cut points and the loop mode's counting arithmetic — the same code that emits the rows, with a counter for a
+// sink), so the rows can go straight to where they belong in pass 2.  (Until round 6 every thread planned into buffers of
+// its own and a second pass gathered them: 18.7 MB of freshly mapped memory and a copy of it per 1024 notes, which was
+// 45 % of the planner's time.)
+static int64_t size_batch(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, goofer_plan_geometry *geo)
+{
+    std::fesetround(FE_TONEAREST);
+    scratch s;
+    int64_t rows = 0;
+    for (int i = 0; i < n_notes; ++i) {
+        plan_count(req[i], hop, trim_rows, geo[i], s);
+        geo[i].tap_off = rows;
+        if (geo[i].status == 0) rows += geo[i].n_out_rows;
+    }
+    return rows;
+}
+
+// Pass 2: the notes' plans, each thread a contiguous range of notes holding its share of the rows.
+static int fill_batch(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps, int gauss_radius,
+                      int nt, int64_t rows, goofer_plan_geometry *geo, int32_t *tap_idx, double *tap_w, double *F, float *fst)
+{
+    std::vector<int> first((size_t)nt + 1, n_notes);           // thread t: notes [first[t], first[t + 1])
+    first[0] = 0;
+    for (int t = 1, i = 0; t < nt; ++t) {
+        const int64_t want = rows * t / nt;
+        while (i < n_notes && geo[i].tap_off < want) ++i;
+        first[(size_t)t] = i;
     }
     return run_threads(nt, [&](int t) {
         std::fesetround(FE_TONEAREST);
         scratch s;
-        note_out o;                                            // re-used from note to note: its vectors keep their capacity
-        thread_rows &R = P.rows[(size_t)t];
-        const size_t guess = (size_t)((n_notes + nt - 1) / nt) * 224;
-        R.taps.reserve(guess);
-        R.F.reserve(guess * 4);
-        R.fst.reserve(guess * 4);
-        for (int i = t; i < n_notes; i += nt) {
-            plan_one(req[i], hop, trim_rows, gauss_taps, gauss_radius, o, s);
-            P.geo[(size_t)i] = o.g;
-            P.at[(size_t)i] = (int64_t)R.taps.size();
-            if (o.g.status != 0) continue;
-            const size_t T = (size_t)o.g.n_out_rows;
-            R.taps.insert(R.taps.end(), o.taps.begin(), o.taps.begin() + T);
-            R.F.insert(R.F.end(), o.F.begin(), o.F.begin() + 4 * T);
-            R.fst.insert(R.fst.end(), o.fst.begin(), o.fst.begin() + 4 * T);
-        }
-    });
-}
-
-// rows of the planned notes into four arrays (any of them may be the caller's pinned staging memory); geo[i].tap_off = first row
-static int gather_rows(const planned &P, const goofer_plan_geometry *geo, int32_t *tap_idx, double *tap_w, double *F, float *fst)
-{
-    const int n_notes = (int)P.geo.size(), nt = P.nt;
-    return run_threads(nt, [&](int t) {
-        const thread_rows &R = P.rows[(size_t)t];
-        for (int i = t; i < n_notes; i += nt) {
-            const goofer_plan_geometry &g = geo[i];
-            if (g.status != 0) continue;
-            const int64_t r0 = g.tap_off, T = g.n_out_rows, a = P.at[(size_t)i];
-            for (int64_t q = 0; q < T; ++q)
-                for (int c = 0; c < 4; ++c) {
-                    tap_idx[(size_t)(r0 + q) * 4 + c] = R.taps[(size_t)(a + q)].i[c];
-                    tap_w[(size_t)(r0 + q) * 4 + c] = R.taps[(size_t)(a + q)].w[c];
-                }
-            if (T > 0) {
-                std::memcpy(&F[(size_t)r0 * 4], &R.F[(size_t)a * 4], (size_t)T * 4 * sizeof(double));
-                std::memcpy(&fst[(size_t)r0 * 4], &R.fst[(size_t)a * 4], (size_t)T * 4 * sizeof(float));
-            }
+        for (int i = first[(size_t)t]; i < first[(size_t)t + 1]; ++i) {
+            if (geo[i].status != 0) continue;                  // (its cut points stay unwritten: the caller re-plans the batch)
+            const int64_t r0 = geo[i].tap_off, T = geo[i].n_out_rows;
+            goofer_plan_geometry g;
+            const row_dest d{tap_idx + (size_t)r0 * 4, tap_w + (size_t)r0 * 4, F + (size_t)r0 * 4, fst + (size_t)r0 * 4};
+            plan_one(req[i], hop, trim_rows, gauss_taps, gauss_radius, T, g, d, s);
+            g.tap_off = r0;
+            if (g.status != 0) g.n_out_rows = (int32_t)T;      // (status 2: the rows of the note are not written)
+            geo[i] = g;
         }
     });
 }
@@ -636,23 +747,19 @@ int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop,
     *out = nullptr;
     goofer_host_plans *h = nullptr;
     try {
-        planned P;
-        int rc = plan_all(req, n_notes, hop, trim_rows, gauss_taps, gauss_radius, n_threads, P);
+        int rc = check_requests(req, n_notes, hop, gauss_taps, gauss_radius);
         if (rc) return rc;
         h = new (std::nothrow) goofer_host_plans;
         if (!h) return GOOFER_ENOMEM;
-        h->geo = P.geo;
-        int64_t rows = 0;
-        for (int i = 0; i < n_notes; ++i) {
-            h->geo[i].tap_off = rows;
-            if (h->geo[i].status == 0) rows += h->geo[i].n_out_rows;
-        }
+        h->geo.resize((size_t)n_notes);
+        const int64_t rows = size_batch(req, n_notes, hop, trim_rows, h->geo.data());
         h->rows = rows;
         h->tap_idx.resize((size_t)rows * 4);
         h->tap_w.resize((size_t)rows * 4);
         h->F.resize((size_t)rows * 4);
         h->fst.resize((size_t)rows * 4);
-        if ((rc = gather_rows(P, h->geo.data(), h->tap_idx.data(), h->tap_w.data(), h->F.data(), h->fst.data()))) {
+        if ((rc = fill_batch(req, n_notes, hop, trim_rows, gauss_taps, gauss_radius, pick_threads(n_threads, n_notes), rows, h->geo.data(),
+                             h->tap_idx.data(), h->tap_w.data(), h->F.data(), h->fst.data()))) {
             delete h;
             return rc;
         }
@@ -667,25 +774,21 @@ int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop,
 /* The same plans written straight into memory of the caller (pinned staging buffers that one H2D copy then ships, re-used from
  * batch to batch: no allocation, no page faults, no second copy).  geometry[n_notes]; the four row arrays hold row_capacity
  * rows x 4.  *rows_out = rows of the batch (sum of n_out_rows over the notes with status 0).  Returns GOOFER_OK with the arrays
- * filled; 1 when row_capacity is too small (only geometry and *rows_out are written: grow and call again); an error code. */
+ * filled; 1 when row_capacity is too small (only *rows_out and the geometry's status / n_out_rows / tap_off are written: grow
+ * and call again); an error code. */
 int goofer_host_plan_into(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps,
                           int gauss_radius, int n_threads, goofer_plan_geometry *geometry, int64_t row_capacity, int32_t *tap_idx,
                           double *tap_w, double *formants, float *fst_tracks, int64_t *rows_out)
 {
     if (!geometry || !rows_out || row_capacity < 0 || (row_capacity > 0 && (!tap_idx || !tap_w || !formants || !fst_tracks))) return GOOFER_EINVAL;
     try {
-        planned P;
-        int rc = plan_all(req, n_notes, hop, trim_rows, gauss_taps, gauss_radius, n_threads, P);
+        int rc = check_requests(req, n_notes, hop, gauss_taps, gauss_radius);
         if (rc) return rc;
-        int64_t rows = 0;
-        for (int i = 0; i < n_notes; ++i) {
-            geometry[i] = P.geo[(size_t)i];
-            geometry[i].tap_off = rows;
-            if (geometry[i].status == 0) rows += geometry[i].n_out_rows;
-        }
+        const int64_t rows = size_batch(req, n_notes, hop, trim_rows, geometry);
         *rows_out = rows;
         if (rows > row_capacity) return 1;
-        return gather_rows(P, geometry, tap_idx, tap_w, formants, fst_tracks);
+        return fill_batch(req, n_notes, hop, trim_rows, gauss_taps, gauss_radius, pick_threads(n_threads, n_notes), rows, geometry, tap_idx,
+                          tap_w, formants, fst_tracks);
     } catch (...) {
         return GOOFER_ENOMEM;
     }

@@ -645,7 +645,8 @@ class Renderer:
         pb = None
         if T_["trk_ok"][uu].all():
             tracks = srcs                                      # (what keeps the track arrays alive while the planner reads them)
-            rec = S.plan_records(rb, sr, u_ylen[src_ix], u_T[src_ix], None, track_ptrs=T_["trk_ptr"][rows], track_lens=T_["trk_len"][rows])
+            rec = S.plan_records(rb, sr, u_ylen[src_ix], u_T[src_ix], None, track_ptrs=T_["trk_ptr"][rows], track_lens=T_["trk_len"][rows],
+                                 skip_unused_fst=True)
             # the rows go straight into the staging block: whatever the block has left after ~2 MiB for the small pieces
             geo_h, _ = stg.reserve(n, _lib.PLAN_GEOMETRY)
             cap = max(0, (stg.nbytes - stg.used - (2 << 20) - 600 * n - 8 * int(rb.bend.size)) // 96 - 8)

@@ -1008,10 +1008,13 @@ class StagingFull(Exception):
     """The staging block handed to the planner is too small: args[0] = rows (or bytes) needed."""
 
 
-def plan_records(reqs, srs, ylens, n_src_frames, tracks, track_ptrs=None, track_lens=None):
+def plan_records(reqs, srs, ylens, n_src_frames, tracks, track_ptrs=None, track_lens=None, skip_unused_fst: bool = False):
     """``_lib.PLAN_REQUEST`` records of a batch: the requests' scalars as columns (``reqs``: a RequestBatch or a list of
     Requests), ``tracks`` = per note the tuple of ``source_tracks64`` (kept alive by the caller) — or their addresses / lengths
-    as [n, 4] arrays (``track_ptrs`` / ``track_lens``: what render.SourceArena keeps per resident sample)."""
+    as [n, 4] arrays (``track_ptrs`` / ``track_lens``: what render.SourceArena keeps per resident sample).
+    ``skip_unused_fst``: the smoothed track of a formant whose 'fst' strength is off for the note (|s| < 1e-6: the assembly's
+    own test, SillySampler.py:817-830) is not computed — its column of ``fst`` stays 0 and is never read (the render path;
+    the numpy planner always makes all four)."""
     from . import _lib
     rb = reqs if isinstance(reqs, RequestBatch) else RequestBatch.from_requests(reqs)
     n = rb.n
@@ -1024,6 +1027,8 @@ def plan_records(reqs, srs, ylens, n_src_frames, tracks, track_ptrs=None, track_
     rec["vel_factor"] = np.array([float(2.0 ** (1.0 - (float(v) / 100.0))) for v in vel], dtype=np.float64)[inv] if n else 0.0
     rec["loop_mode"] = rb.loop_code
     rec["sr"], rec["ylen"], rec["n_src_frames"] = srs, ylens, n_src_frames
+    if skip_unused_fst:
+        rec["fst_skip"] = np.abs(rb.formant_strength) < 1e-6
     if track_ptrs is not None:
         rec["tracks"], rec["track_len"] = track_ptrs, track_lens
     else:

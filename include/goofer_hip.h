@@ -335,6 +335,8 @@ typedef struct {
     int32_t loop_mode, reverse;                 /* 0 concat (L0), 1 mirror mean (L1), 2 stretch (L2); 'R1'                 */
     const double *tracks[4];                    /* the source's F1..F4 tracks (Hz, fp64, HOST memory)                      */
     int32_t track_len[4];                       /* their lengths; -1: the source has no such track                         */
+    int32_t fst_skip[4];                        /* != 0: this formant's 'fst' strength is off for the note (|s| < 1e-6), so */
+                                                /* its fst_tracks column is never read: left 0, the sigma-4 blur not run    */
 } goofer_plan_request;
 
 typedef struct {
@@ -362,8 +364,8 @@ int goofer_host_plan_notes(const goofer_plan_request *req, int n_notes, int hop,
                            int gauss_radius, int n_threads, goofer_host_plans **out);
 /* The same plans written into memory of the caller — pinned staging buffers one H2D copy ships, re-used from batch to batch.
  * geometry[n_notes]; the four row arrays hold row_capacity rows x 4 (layout as goofer_host_plans_view); *rows_out = rows of the
- * batch.  Returns 0 with the arrays filled, 1 when row_capacity is too small (geometry and *rows_out are written: grow, call
- * again), or a negative error code as goofer_host_plan_notes. */
+ * batch.  Returns 0 with the arrays filled, 1 when row_capacity is too small (*rows_out and the geometry's status / n_out_rows /
+ * tap_off are written: grow, call again), or a negative error code as goofer_host_plan_notes. */
 int goofer_host_plan_into(const goofer_plan_request *req, int n_notes, int hop, int trim_rows, const double *gauss_taps,
                           int gauss_radius, int n_threads, goofer_plan_geometry *geometry, int64_t row_capacity, int32_t *tap_idx,
                           double *tap_w, double *formants, float *fst_tracks, int64_t *rows_out);

@@ -126,6 +126,50 @@ def test_thread_count_changes_nothing():
     _same(one, many)
 
 
+def test_unused_strength_columns_are_left_zero():
+    """skip_unused_fst: the smoothed track of a formant whose 'fst' strength is off for the note is not computed (its column
+    stays 0, the assembly never reads it); every other value of the plan is what the full plan holds."""
+    jobs = _plannable(_random_jobs(11, 200), 256)
+    rng = np.random.default_rng(4)
+    flagged = []
+    for j in jobs:                                            # the strengths: none, one, some, all
+        fl = "".join("fst%s%d" % (c, int(rng.integers(-80, 80))) for c in "abcd" if rng.random() < 0.4)
+        r = j[0]
+        req = S.decode_request("C4", "100", fl, "0", "500", "0", "0", "100", "0", "!120", "AA")
+        flagged.append((S.Request(**{**r.__dict__, "formant_strength": req.formant_strength}),) + tuple(j[1:]))
+    tracks = [S.source_tracks64(j[4]) for j in flagged]
+    a = [j[0] for j in flagged], [j[1] for j in flagged], [j[2] for j in flagged], [j[3] for j in flagged], tracks
+    full = S.plan_native(S.plan_records(*a), 256, True, keep=tracks)
+    rec = S.plan_records(*a, skip_unused_fst=True)
+    lean = S.plan_native(rec, 256, True, keep=(tracks, rec))
+    off = np.array([[abs(v) < 1e-6 for v in j[0].formant_strength] for j in flagged])
+    assert off.any() and (~off).any() and off.all(axis=1).any() and np.array_equal(rec["fst_skip"] != 0, off)
+    for nm in ("tap_idx", "tap_w", "formants"):
+        assert np.array_equal(getattr(full, nm), getattr(lean, nm), equal_nan=True), nm
+    for name in full.geo.dtype.names:
+        assert np.array_equal(full.geo[name], lean.geo[name]), name
+    rows_off = np.repeat(off, full.geo["n_out_rows"], axis=0)
+    assert np.array_equal(lean.fst[~rows_off], full.fst[~rows_off]) and not lean.fst[rows_off].any() and full.fst[rows_off].any()
+
+
+def test_a_block_too_small_for_the_batch_says_how_many_rows_it_needs():
+    from goofer_amd import _lib
+    jobs = _plannable(_random_jobs(12, 64), 256)
+    tracks = [S.source_tracks64(j[4]) for j in jobs]
+    rec = S.plan_records([j[0] for j in jobs], [j[1] for j in jobs], [j[2] for j in jobs], [j[3] for j in jobs], tracks)
+    want = S.plan_native(rec, 256, True, keep=(tracks, rec))
+    rows = want.tap_idx.shape[0]
+    geo = np.zeros(len(jobs), dtype=_lib.PLAN_GEOMETRY)
+    mk = lambda cap: (np.full((cap, 4), -7, np.int32), np.zeros((cap, 4)), np.zeros((cap, 4)), np.zeros((cap, 4), np.float32))
+    small = mk(rows - 1)
+    with pytest.raises(S.StagingFull) as e:
+        S.plan_native_into(rec, 256, True, geo, rows - 1, *small, keep=(tracks, rec))
+    assert e.value.args[0] == rows and (small[0] == -7).all()          # sized, nothing written
+    fit = mk(rows)
+    got = S.plan_native_into(rec, 256, True, geo, rows, *fit, keep=(tracks, rec))
+    _same(want, got)
+
+
 def test_odd_sources_take_the_numpy_planner():
     jobs = _plannable(_random_jobs(5, 6), 256)
     odd = [(j[0], j[1], j[2], j[3], {k: v.astype(np.float32) for k, v in j[4].items()}) for j in jobs]
