@@ -263,9 +263,9 @@ def pcie_leg(wl, step_s):
     through pinned staging buffers, timed with events around the copies."""
     import torch
     dev = [t for t in wl.prep["keep"].values() if torch.is_tensor(t)] + [wl.prep["formants"]]
-    host = [t.cpu().pin_memory() for t in dev]
+    host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t) for t in dev]
     out = wl.step()
-    mix_host = torch.empty(out["mix"].shape, dtype=out["mix"].dtype).pin_memory()
+    mix_host = torch.empty(out["mix"].shape, dtype=out["mix"].dtype, pin_memory=True)
     torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     e[0].record()
@@ -365,7 +365,7 @@ def host_inclusive(wl, ctx, step_s):
     args = [syn.request_args(q) for _, q, _ in raw]
     srcs = [Source.from_pack(s["env_pack"], s["f0"], s["mask"], s["formants"], s["sr"], s["y_len"]) for s, _, _ in raw]
     ids = list(range(len(raw)))
-    host_mix = torch.empty(wl.samples, dtype=torch.float32).pin_memory()
+    host_mix = torch.empty(wl.samples, dtype=torch.float32, pin_memory=True)
 
     def prepare():
         t0 = time.perf_counter()

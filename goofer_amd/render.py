@@ -146,7 +146,7 @@ class Staging:
 
     def __init__(self, device, nbytes: int):
         self.nbytes = int(nbytes)
-        self.host = torch.empty(self.nbytes, dtype=torch.uint8).pin_memory()
+        self.host = torch.empty(self.nbytes, dtype=torch.uint8, pin_memory=True)   # (not .pin_memory(): that is a second block and a copy)
         self.dev = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
         self.np = self.host.numpy()
         self.used = 0
@@ -1059,7 +1059,7 @@ class PipelinedRenderer:
                 slot = ((k - 1) // len(self.lanes)) & 1
                 hb = ln["host"][slot]
                 if hb is None or hb.numel() < samples or hb.dtype != want:
-                    hb = ln["host"][slot] = torch.empty(max(samples, int(1.25 * samples)), dtype=want).pin_memory()
+                    hb = ln["host"][slot] = torch.empty(max(samples, int(1.25 * samples)), dtype=want, pin_memory=True)
                 with torch.cuda.stream(ln["stream"]):
                     r.ctx.plan(sr, n_fft, hop)                 # no-ops once the lane has seen the geometry / the sizes
                     r.ctx.reserve(frames, samples, n)

@@ -99,6 +99,11 @@ if trace:
         ev = [e for e in trace if e[0] == what]
         d = [1e3 * (e[3] - e[2]) for e in ev]
         print("%-14s n %3d  mean %.2f ms  median %.2f  max %.2f   per batch over the job: %s" % (what, len(d), np.mean(d), np.median(d), max(d), " ".join("%.1f" % v for v in d[:80])))
+    ev = [e for e in trace if e[0] == "launch" and len(e) > 4 and len(e[4]) == 4][len(trace) // 8:]
+    if ev:
+        parts = np.array([[1e3 * (b - a) for a, b in zip((e[2],) + e[4], e[4])] for e in ev])
+        print("launch sub-steps behind the warm-up, median / mean ms: plan+reserve %.2f / %.2f, run %.2f / %.2f, pcm16 + event %.2f / %.2f, copy home queued %.2f / %.2f"
+              % tuple(v for k in range(4) for v in (np.median(parts[:, k]), parts[:, k].mean())))
     ev = [e for e in trace if e[0] == "launch" and len(e) > 4 and e[3] - e[2] > 4e-3]
     for e in ev[:12]:
         m = (e[2],) + e[4]
