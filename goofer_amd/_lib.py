@@ -109,6 +109,7 @@ class Batch(C.Structure):
         ("subharm_vib_delay", C.c_double), ("subharm_vibrato", C.c_int32), ("volume_vibrato", C.c_int32),
         ("unit_pitch_shift", C.c_int32), ("no_warp", C.c_int32),
         ("harm", C.c_void_p), ("uv", C.c_void_p), ("bre", C.c_void_p), ("rec", C.c_void_p), ("mix", C.c_void_p),
+        ("f0_64", C.c_void_p),
     ]
 
 

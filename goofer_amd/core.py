@@ -445,6 +445,21 @@ def _stretch(c, x, a, b, factor):
     return out
 
 
+def _stretch64(x, a, b, factor):
+    """concat(x[:a], stretch_feature(x[a:b], factor), x[b:]) of a 1-D float32 array in the type the reference holds it in
+    afterwards: FLOAT64 — its interp1d is np.interp on float64 abscissae (GOOFER.py:173-239, 597-606, 1019-1053).  None where
+    the result is not float64 (a one-sample region comes back in y's own type) or the reference raises (an empty one)."""
+    x = np.asarray(x)
+    n = x.shape[0]
+    a, b, _ = slice(a, b).indices(n)
+    b = max(a, b)
+    seg = x[a:b]
+    if seg.size < 2:
+        return None
+    mid = np.interp(np.linspace(0, 1, int(seg.size * factor)), np.linspace(0, 1, seg.size), seg)
+    return np.concatenate([x[:a].astype(np.float64), mid, x[b:].astype(np.float64)])
+
+
 def _roughness_params(params, kw):
     """roughness_on needs the stems BEFORE the peak gain (the gain is taken from the roughened sum, GOOFER.py:1195-1217): the
     batch runs with normalize = 0 (gain 1) and `_finish` applies the reference's gain."""
@@ -504,9 +519,13 @@ def _synthesize_stretched(c, d_env, f0, mask, F, params, sr, hop, phi, seed, kw)
         fa, fb = int((s0 * sr) / hop), int((s1 * sr) / hop)
     else:
         a, b, fa, fb = 0, None, 0, None
+    # f0_interp is a float64 array from here on in the reference: the jitter's product and the sub-harmonic phase trackers work on
+    # it (their float32 versions land one event in ~10^5 a sample off, which a soak run of random keyword sets found)
+    f0_64 = _stretch64(f0, a, b, factor) if (kw.get("f0_jitter") or kw.get("add_subharm")) else None
     d_f0, d_mask = _stretch(c, d_f0, a, b, factor), _stretch(c, d_mask, a, b, factor)
     env_h, env_n = _stretch(c, env_h, fa, fb, factor), _stretch(c, env_n, fa, fb, factor)
     n = int(d_f0.numel())
+    d_f0_64 = c.tensor(f0_64) if f0_64 is not None and f0_64.size == n else None
     if n == 0:
         z = np.zeros(0, dtype=np.float32)
         return z, z.copy(), z.copy(), z.copy()
@@ -525,7 +544,7 @@ def _synthesize_stretched(c, d_env, f0, mask, F, params, sr, hop, phi, seed, kw)
                         transition_sigma=float(kw.get("noise_transition_smoothness", 100)), want_mix=False,
                         noise_f0=noise_f0, noise_vol=noise_vol, f0_jitter_speed=float(kw.get("f0_jitter_speed", 100)),
                         vol_jitter_speed=float(kw.get("volume_jitter_speed", 150)), subharm=subharm_from_kwargs(kw),
-                        volume_vibrato=vib, env_noise=env_n, noise_subharm=noise_sub)
+                        volume_vibrato=vib, env_noise=env_n, noise_subharm=noise_sub, f0_64=d_f0_64)
     return _finish(c, out, d_mask, n, sr, kw)
 
 

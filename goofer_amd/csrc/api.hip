@@ -23,8 +23,8 @@ int launch_pulse_train(goofer_ctx *, const float *, float, const int64_t *, int,
 int launch_pulse_onsets(goofer_ctx *, const float *, float, const int64_t *, int, onset_t *, int32_t *, int32_t *,
                         int32_t *, int64_t, int32_t *, hipStream_t);
 int launch_pulse_place(goofer_ctx *, const onset_t *, const int32_t *, const int64_t *, int, int64_t, float *, const int32_t *, hipStream_t);
-int launch_subharm(goofer_ctx *, const float *, const float *, const int64_t *, int, int64_t, const goofer_note_params *, const double *, int,
-                   int, double, double, double, float *, double *, onset_t *, int32_t *, int32_t *, int32_t *, const unsigned char *,
+int launch_subharm(goofer_ctx *, const float *, const double *, const float *, const int64_t *, int, int64_t, const goofer_note_params *, const double *, int,
+                   int, double, double, double, double *, double *, onset_t *, int32_t *, int32_t *, int32_t *, const unsigned char *,
                    double *, unsigned long long *, float *, hipStream_t);
 int launch_gauss_bins(goofer_ctx *, const float *, float *, int64_t, int, int, const double *, int, const int64_t *, hipStream_t);
 int launch_warp_bins(goofer_ctx *, const float *, float *, int64_t, int, int, const double *, const double *,
@@ -54,7 +54,7 @@ int launch_gauss_samples(goofer_ctx *, const Tin *, const int64_t *, int, int64_
                          hipStream_t);
 int launch_note_absmax(goofer_ctx *, const double *, const int64_t *, int, int64_t, const unsigned char *, unsigned long long *,
                        hipStream_t);
-int launch_f0_jitter(goofer_ctx *, float *, const float *, const double *, const unsigned long long *, const int64_t *, int, int64_t,
+int launch_f0_jitter(goofer_ctx *, float *, double *, const float *, const double *, const unsigned long long *, const int64_t *, int, int64_t,
                      const goofer_note_params *, int, hipStream_t);
 int launch_volume_jitter(goofer_ctx *, float *, float *, const double *, const double *, const double *, const unsigned long long *,
                          const unsigned long long *, const int64_t *, int, int64_t, const goofer_note_params *, int, double, hipStream_t);
@@ -1338,8 +1338,13 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
                jit_vol = vol_vib || (b->noise_vol_h != nullptr && b->noise_vol_b != nullptr);
     const bool sub_on = b->subharm_ratio > 0.0;
     const bool sub_jit = sub_on && b->noise_subharm != nullptr;
+    // gf.synthesize behind its time stretch: f0_interp is a float64 array from there on (GOOFER.py:1053) — the f0 jitter multiplies
+    // it (the pulse train sees the float32 cast of the product, :1071-1074) and the sub-harmonic trackers accumulate it (:1077-1097);
+    // a private copy, since the jitters work in place
+    const bool f64_on = b->f0_64 != nullptr && (jit_f0 || sub_on);
     const size_t jit_bytes = ((jit_f0 || jit_vol || sub_jit) ? (3 * (size_t)N * sizeof(double) + 3 * 256 * (size_t)n + 8192) : 0) +
-                             (sub_on ? ((size_t)N * (sizeof(double) + sizeof(float)) + 3 * 256 * (size_t)n + 8192) : 0);
+                             (sub_on ? ((size_t)N * (sizeof(double) + sizeof(double)) + 3 * 256 * (size_t)n + 8192) : 0) +
+                             (f64_on ? (size_t)N * sizeof(double) + 1024 : 0);
     // which pipeline will run decides what the arena holds (the same predicate as `stem_path` below)
     const bool walkers = ctx->stems && ctx->ola_fused && (p.hop % 2 == 0) && stems_supported(p) && !sub_on && !jit_vol;
     // n_fft 2048: one stem per wave (two waves per SIMD instead of one), then the per-note finish of the stem-split path
@@ -1393,14 +1398,20 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if (!jit_a || !jit_b || !jit_c || !jit_max || !on_f0 || !on_vol) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
     }
     double *sub_buf = nullptr;
-    float *sub_fm = nullptr;
+    double *sub_fm = nullptr;
     unsigned long long *sub_max = nullptr;
     unsigned char *on_sub = nullptr, *on_subj = nullptr;
     if (sub_on) {
-        sub_buf = a.take<double>(N); sub_fm = a.take<float>(N);
+        sub_buf = a.take<double>(N); sub_fm = a.take<double>(N);
         sub_max = a.take<unsigned long long>(n + 16); on_sub = a.take<unsigned char>(n + 16);
         on_subj = a.take<unsigned char>(n + 16);
         if (!sub_buf || !sub_fm || !sub_max || !on_sub || !on_subj) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
+    }
+    double *f0d = nullptr;
+    if (f64_on) {
+        f0d = a.take<double>(N);
+        if (!f0d) return goofer_fail(ctx, GOOFER_ENOMEM, "scratch arena too small");
+        HIP_TRY(ctx, hipMemcpyAsync(f0d, b->f0_64, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
     {
         const void *ptrs[] = {frame_note, row_src, f0s, pulse, S_h, S_uv, S_br, frames, env_h, env_n, short_s, note_mag, note_peak, onset_cnt};
@@ -1519,7 +1530,7 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
         if ((rc = upload_jitter_taps(ctx, (double)b->f0_jitter_sigma, 0, &d_t, &r, st))) return rc;
         if ((rc = launch_gauss_samples<double>(ctx, b->noise_f0, b->sample_off, n, N, d_t, r, on_f0, jit_a, st))) return rc;
         if ((rc = launch_note_absmax(ctx, jit_a, b->sample_off, n, N, on_f0, jit_max, st))) return rc;
-        if ((rc = launch_f0_jitter(ctx, f0s, b->mask, jit_a, jit_max, b->sample_off, n, N, b->params, 0, st))) return rc;
+        if ((rc = launch_f0_jitter(ctx, f0s, f0d, b->mask, jit_a, jit_max, b->sample_off, n, N, b->params, 0, st))) return rc;
     }
     // aperiodic half of the stem-split path: smoothed mask knots, then the two noise stems straight to samples.  Needs the
     // final scaled f0 (frame picks) and nothing of the pulse chain.
@@ -1610,14 +1621,14 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
             HIP_TRY(ctx, hipMemsetAsync(jit_max, 0, (size_t)n * sizeof(unsigned long long), st));
             if ((rc = launch_gauss_samples<double>(ctx, b->noise_subharm, b->sample_off, n, N, d_t, r, on_subj, jit_a, st))) return rc;
             if ((rc = launch_note_absmax(ctx, jit_a, b->sample_off, n, N, on_subj, jit_max, st))) return rc;
-            if ((rc = launch_f0_jitter(ctx, f0s, b->mask, jit_a, jit_max, b->sample_off, n, N, b->params, 1, st))) return rc;
+            if ((rc = launch_f0_jitter(ctx, f0s, f0d, b->mask, jit_a, jit_max, b->sample_off, n, N, b->params, 1, st))) return rc;
         }
         double ratios[16];
         ratios[0] = b->subharm_ratio;
         for (int q = 0; q < 15; ++q) ratios[q + 1] = b->subharm_more[q];
         int n_ratios = 1;
         while (n_ratios < 16 && ratios[n_ratios] > 0.0) ++n_ratios;
-        if ((rc = launch_subharm(ctx, f0s, b->mask, b->sample_off, n, N, b->params, ratios, n_ratios, b->subharm_vibrato,
+        if ((rc = launch_subharm(ctx, f0s, f0d, b->mask, b->sample_off, n, N, b->params, ratios, n_ratios, b->subharm_vibrato,
                                  b->subharm_vib_rate, b->subharm_vib_depth, b->subharm_vib_delay, sub_fm, inc, (onset_t *)onsets,
                                  onset_idx, onset_cnt, ovf, on_sub, sub_buf, sub_max, pulse, st)))
             return rc;

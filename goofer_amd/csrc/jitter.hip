@@ -93,8 +93,11 @@ __global__ __launch_bounds__(256) void k_note_absmax(const double *__restrict__ 
     }
 }
 
-// f0 (fp32, in place) *= 1 + ((1 + noise/max*strength) - 1) * mask, evaluated in fp64 then rounded to fp32
-__global__ __launch_bounds__(256) void k_f0_jitter(float *__restrict__ f0, const float *__restrict__ mask, const double *__restrict__ noise_s,
+// f0 (fp32, in place) *= 1 + ((1 + noise/max*strength) - 1) * mask, evaluated in fp64 then rounded to fp32.
+// f0_64 (gf.synthesize behind its time stretch: f0_interp is a float64 array there, GOOFER.py:1053): that array takes the product,
+// and the fp32 one becomes its cast — what pulse_train_numba is handed (:1074).
+__global__ __launch_bounds__(256) void k_f0_jitter(float *__restrict__ f0, double *__restrict__ f0_64, const float *__restrict__ mask,
+                                                   const double *__restrict__ noise_s,
                                                    const unsigned long long *__restrict__ max_bits, const int64_t *__restrict__ sample_off,
                                                    int n_notes, int64_t total, const goofer_note_params *__restrict__ params, int which)
 {
@@ -111,7 +114,14 @@ __global__ __launch_bounds__(256) void k_f0_jitter(float *__restrict__ f0, const
     if (!(strength > 0.0)) return;
     const double mx = __longlong_as_double((long long)max_bits[note]);
     const double jit = 1.0 + (noise_s[g] / mx) * strength;     // python-float strength: fp64 like the reference
-    f0[g] = (float)((double)f0[g] * (1.0 + ((jit - 1.0) * (double)mask[g])));
+    const double fac = 1.0 + ((jit - 1.0) * (double)mask[g]);
+    if (f0_64) {
+        const double v = f0_64[g] * fac;
+        f0_64[g] = v;
+        f0[g] = (float)v;
+    } else {
+        f0[g] = (float)((double)f0[g] * fac);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_volume_jitter(float *__restrict__ harm, float *__restrict__ bre, const double *__restrict__ nh,
@@ -176,11 +186,11 @@ int launch_note_absmax(goofer_ctx *ctx, const double *x, const int64_t *sample_o
     return GOOFER_OK;
 }
 
-int launch_f0_jitter(goofer_ctx *ctx, float *f0, const float *mask, const double *noise_s, const unsigned long long *max_bits,
+int launch_f0_jitter(goofer_ctx *ctx, float *f0, double *f0_64, const float *mask, const double *noise_s, const unsigned long long *max_bits,
                      const int64_t *sample_off, int n_notes, int64_t total, const goofer_note_params *params, int which, hipStream_t st)
 {
     if (total <= 0) return GOOFER_OK;
-    hipLaunchKernelGGL(k_f0_jitter, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, f0, mask, noise_s, max_bits, sample_off,
+    hipLaunchKernelGGL(k_f0_jitter, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, f0, f0_64, mask, noise_s, max_bits, sample_off,
                        n_notes, total, params, which);
     LAUNCH_CHECK(ctx);
     return GOOFER_OK;

@@ -924,7 +924,8 @@ int launch_pulse_train(goofer_ctx *ctx, const float *f0, float f0_scale, const i
 // ---------------------------------------------------------------------------------------------
 // Sub-harmonic pulse layer ('sg' flag) — gf.add_subharms + apply_subharm_vibrato (GOOFER.py:672-766).
 //
-//   k_subharm_inc     vibrato'd f0 (fp32 like the reference's array) and the tracker increments sub_f0/sr
+//   k_subharm_inc     vibrato'd f0 (in the precision of the reference's array: float32 — or float64 behind gf.synthesize's time
+//                     stretch, goofer_batch.f0_64) and the tracker increments sub_f0/sr
 //   k_pulse_onsets_wrap  the wrapped phase tracker, exact sequential order
 //   k_subharm_finish  per event: T = 1/sub_f0, n = max(3, round_half_even(sr T)), fp32 peak of its LF pulse, end_max
 //   k_subharm_place   gather of the covering LF pulses (ascending events), * voicing mask, per-note max
@@ -955,10 +956,11 @@ __device__ __forceinline__ float sub_lf_raw(int k, int n, double T)
     return 0.f;
 }
 
-__global__ __launch_bounds__(256) void k_subharm_inc(const float *__restrict__ f0, const float *__restrict__ mask,
+__global__ __launch_bounds__(256) void k_subharm_inc(const float *__restrict__ f0, const double *__restrict__ f0_64,
+                                                     const float *__restrict__ mask,
                                                      const int64_t *__restrict__ sample_off, int n_notes, int64_t total,
                                                      const goofer_note_params *__restrict__ params, sub_cfg c,
-                                                     float *__restrict__ fm, double *__restrict__ inc)
+                                                     double *__restrict__ fm, double *__restrict__ inc)
 {
     __shared__ int s_pair[2];
     const int64_t g0 = (int64_t)blockIdx.x * blockDim.x;
@@ -968,21 +970,24 @@ __global__ __launch_bounds__(256) void k_subharm_inc(const float *__restrict__ f
     if (g >= total) return;
     int note = lo;
     while (sample_off[note + 1] <= g) ++note;
-    if (!(params[note].subharm_weight > 0.f)) { inc[g] = 0.0; fm[g] = 0.f; return; }
+    if (!(params[note].subharm_weight > 0.f)) { inc[g] = 0.0; fm[g] = 0.0; return; }
     const int64_t base = sample_off[note], n = sample_off[note + 1] - base, i = g - base;
-    float f = f0[g];
-    if (c.vib_on && f > 0.f) {
+    // the f0 array the layer tracks is float32 in the reference (modulated_f0 = f0_interp.copy() keeps the type, :763-764) —
+    // and float64 when the time stretch made it one (:1053): f0_64
+    double f = f0_64 ? f0_64[g] : (double)f0[g];
+    if (c.vib_on && f > 0.0) {
         double v = sin(((2.0 * 3.141592653589793) * c.vib_rate) * ((double)i / c.sr) + 0.0);
         if (c.vib_fade < n && i < c.vib_fade) {
             const double fade = c.vib_fade > 1 ? (i >= c.vib_fade - 1 ? 1.0 : (double)i * (1.0 / (double)(c.vib_fade - 1))) : 0.0;
             v *= fade;
         }
-        f = (float)((double)f * (1.0 + v * c.vib_depth));
+        f = f * (1.0 + v * c.vib_depth);
+        if (!f0_64) f = (double)(float)f;
     }
     fm[g] = f;
     double a = 0.0;
-    if (mask[g] > 0.f && f > 0.f) {
-        const double sub = (double)f * c.ratio;
+    if (mask[g] > 0.f && f > 0.0) {
+        const double sub = f * c.ratio;
         if (!(sub < 1e-2)) a = sub / c.sr;
     }
     inc[g] = a;
@@ -991,7 +996,7 @@ __global__ __launch_bounds__(256) void k_subharm_inc(const float *__restrict__ f
 // The reference keeps one LF pulse per '{sub_f0:.2f}' key (GOOFER.py:716-724): an event reuses the pulse of the FIRST
 // event whose sub_f0 prints to the same two decimals.  keys = the note's slice of the increment buffer (free once
 // the tracker has run), holding each event's own sub_f0.
-__global__ __launch_bounds__(64) void k_subharm_finish(const float *__restrict__ fm, const int64_t *__restrict__ sample_off, int n_notes,
+__global__ __launch_bounds__(64) void k_subharm_finish(const double *__restrict__ fm, const int64_t *__restrict__ sample_off, int n_notes,
                                                        sub_cfg c, const int32_t *__restrict__ onset_idx,
                                                        const int32_t *__restrict__ onset_cnt, double *__restrict__ keys_all,
                                                        onset_t *__restrict__ onsets)
@@ -1003,7 +1008,7 @@ __global__ __launch_bounds__(64) void k_subharm_finish(const float *__restrict__
     double *keys = keys_all + base;                              // cnt <= n/2 + 16 would not fit a tiny note: clamp below
     const int64_t n_note = sample_off[note + 1] - base;
     const int kcap = (int)(cnt < n_note ? cnt : n_note);
-    for (int k = lane; k < kcap; k += WAVE) keys[k] = (double)fm[base + onset_idx[obase + k]] * c.ratio;
+    for (int k = lane; k < kcap; k += WAVE) keys[k] = fm[base + onset_idx[obase + k]] * c.ratio;
     __threadfence_block();
     wave_lds_sync();
     int32_t carry = 0;
@@ -1014,7 +1019,7 @@ __global__ __launch_bounds__(64) void k_subharm_finish(const float *__restrict__
         double T = 0.0;
         if (k < cnt) {
             i = onset_idx[obase + k];
-            double sub = (double)fm[base + i] * c.ratio;
+            double sub = fm[base + i] * c.ratio;
             if (k < kcap) {
                 const double key = rint(sub * 100.0);
                 for (int j = 0; j < k; ++j) {
@@ -1116,9 +1121,9 @@ __global__ __launch_bounds__(256) void k_subharm_add(float *__restrict__ pulse, 
     pulse[g] = (float)((double)pulse[g] + v);
 }
 
-int launch_subharm(goofer_ctx *ctx, const float *f0s, const float *mask, const int64_t *sample_off, int n_notes, int64_t total,
-                   const goofer_note_params *params, const double *ratios, int n_ratios, int vib_on, double vib_rate, double vib_depth,
-                   double vib_delay, float *fm, double *inc, onset_t *onsets, int32_t *onset_idx, int32_t *onset_cnt,
+int launch_subharm(goofer_ctx *ctx, const float *f0s, const double *f0_64, const float *mask, const int64_t *sample_off, int n_notes,
+                   int64_t total, const goofer_note_params *params, const double *ratios, int n_ratios, int vib_on, double vib_rate,
+                   double vib_depth, double vib_delay, double *fm, double *inc, onset_t *onsets, int32_t *onset_idx, int32_t *onset_cnt,
                    int32_t *overflow, const unsigned char *note_on, double *sub, unsigned long long *max_bits, float *pulse,
                    hipStream_t st)
 {
@@ -1129,7 +1134,7 @@ int launch_subharm(goofer_ctx *ctx, const float *f0s, const float *mask, const i
         c.ratio = ratios[ri]; c.vib_rate = vib_rate; c.vib_depth = vib_depth; c.vib_on = vib_on;
         c.sr = (double)ctx->plan.sr;
         c.vib_fade = (int)(vib_delay * c.sr);
-        hipLaunchKernelGGL(k_subharm_inc, dim3(nb), dim3(256), 0, st, f0s, mask, sample_off, n_notes, total, params, c, fm, inc);
+        hipLaunchKernelGGL(k_subharm_inc, dim3(nb), dim3(256), 0, st, f0s, f0_64, mask, sample_off, n_notes, total, params, c, fm, inc);
         LAUNCH_CHECK(ctx);
         {
             const int blocks = (n_notes + 3) / 4;

@@ -369,7 +369,7 @@ class Context:
                     seed: int = 0, transition_sigma: float = 100.0, want_rec=True, want_mix=True, offsets=None,
                     noise_f0=None, noise_vol=None, f0_jitter_speed: float = 100.0, vol_jitter_speed: float = 150.0,
                     subharm=None, volume_vibrato: bool = False, env_noise=None, mix_only: bool = False, noise_subharm=None,
-                    assembly=None):
+                    assembly=None, f0_64=None):
         """Run goofer_synth_batch — or, given the ``assembly`` descriptor that produces this batch's f0 / mask / env,
         goofer_render_batch (assembly + synthesis as one call, the pulse chain forked as soon as f0 exists).
 
@@ -379,6 +379,7 @@ class Context:
         env fp32 [R_total, n_bins] ld-strided device tensor; env_lengths rows per note;
         f0 / mask fp32 [N_total]; sample_lengths per note; params structured array (NOTE_PARAMS);
         formants fp64 [R_total, 4] or None; phi fp32 [F_total, n_bins] ld-strided or None.
+        ``f0_64``: the same f0 as a float64 device tensor (goofer_batch.f0_64: what the reference holds behind its time stretch).
         Returns dict of device tensors harm / uv / bre / rec / mix, plus the CSR offsets.
         """
         nb = self.n_bins
@@ -427,12 +428,15 @@ class Context:
                        no_warp=int(bool(np.all(params["f_shift"] == 1.0) and np.all(params["formant_shift"] == 1.0))),
                        harm=out["harm"].data_ptr(),
                        uv=out["uv"].data_ptr(), bre=out["bre"].data_ptr(),
-                       rec=out["rec"].data_ptr() if want_rec else None, mix=out["mix"].data_ptr() if want_mix else None)
+                       rec=out["rec"].data_ptr() if want_rec else None, mix=out["mix"].data_ptr() if want_mix else None,
+                       f0_64=f0_64.data_ptr() if f0_64 is not None else None)
+        if f0_64 is not None:
+            assert f0_64.dtype == torch.float64 and f0_64.numel() == N and f0_64.is_contiguous()
         if assembly is not None:
             self._check(self.lib.goofer_render_batch(self.h, C.byref(assembly), C.byref(b), self._stream()))
         else:
             self._check(self.lib.goofer_synth_batch(self.h, C.byref(b), self._stream()))
-        out["_keep"] = (d_s, d_f, d_e, d_par)   # keep device-side descriptors alive until the caller syncs
+        out["_keep"] = (d_s, d_f, d_e, d_par, f0_64)   # keep device-side descriptors alive until the caller syncs
         out["sample_off"], out["frame_off"] = s_off, f_off
         return out
 

@@ -110,6 +110,13 @@ typedef struct {
     float *harm, *uv, *bre;     /* [total_samples] stems, gain-normalised like the reference   */
     float *rec;                 /* [total_samples] harm+uv+bre (reconstruct), may be NULL      */
     float *mix;                 /* [total_samples] (harm*V + bre*B + uv*U)*volume, may be NULL */
+    const double *f0_64;        /* NULL, or [total_samples] the same f0 as a float64 array: what f0_interp IS in      */
+                                /* gf.synthesize behind its time stretch (interp1d returns float64, GOOFER.py:1053).  */
+                                /* The f0 jitters then multiply THIS array (`f0` becomes its float32 cast, which is   */
+                                /* what the pulse train is handed, :1071-1074) and the sub-harmonic phase trackers    */
+                                /* accumulate it (:1077-1097): on a float32 copy one event in ~10^5 lands a sample    */
+                                /* off.  Final values (no pitch_shift is applied to it); read only with noise_f0 or   */
+                                /* a sub-harmonic ratio set; not modified (the library works on a copy)                */
 } goofer_batch;
 
 /* One note's assembly plan (host-computed scalars, SillySampler.py:449-855).  "Logical" source rows /

@@ -274,6 +274,30 @@ def test_synthesize_random_kwargs_vs_oracle(ctx, case):
         assert e < bound, (key, e, kw)
 
 
+def test_stretched_f0_stays_float64_for_the_jitter_and_the_subharmonic_trackers(ctx):
+    """Soak case 186377 (round 6): time stretch + f0 jitter + a +5-semitone sub-harmonic layer.  Behind the stretch the reference's
+    f0_interp is a float64 array (np.interp, GOOFER.py:1053); accumulating its float32 cast in the layer's phase tracker put one
+    event a sample off (7e-4 of full scale over 60 samples).  goofer_batch.f0_64 carries the float64 array."""
+    from goofer_amd import core
+    from oracle import goofer_ref as R
+    g = golden("synthesize")
+    c = _case(g, "plain")
+    case = 186377
+    kw = {"pitch_shift": 1.064, "formant_shift": 1.37, "F1_shift": 0.73, "F3_shift": 1.21, "cut_subharm_below_f0": True, "f0_jitter": True,
+          "f0_jitter_strength": 1.013, "volume_jitter": True, "volume_jitter_strength_harm": 0.392, "volume_jitter_strength_breath": 1.327,
+          "add_subharm": True, "subharm_weight": 1.057, "subharm_semitones": [-24, -5, -12, 5, 19, 7], "stretch_factor": 1.23}
+    n_new = len(R.stretch_feature(c["f0"], kw["stretch_factor"]))
+    phi = np.random.default_rng(case).uniform(0.0, 2.0 * np.pi, size=(c["env"].shape[0], 1 + n_new // c["hop"])).astype(np.float32)
+    args = (c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"])
+    for trial in (kw, {**kw, "subharm_semitones": [5]}, {**kw, "subharm_f0_jitter": 0.4, "subharm_vibrato": True}):
+        np.random.seed(300 + case)
+        ref = R.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=phi, **trial)
+        np.random.seed(300 + case)
+        got = core.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=phi, ctx=ctx, **trial)
+        for a, b, key in zip(got, ref, ("rec", "harm", "uv", "bre")):
+            assert rms_err(a, b) / max(1.0, float(np.max(np.abs(b)))) < 2e-6, (key, trial)
+
+
 @pytest.mark.parametrize("config,ids", [(3, [0, 1, 2, 3, 4, 5, 6]), (4, [0, 1, 2, 5, 7, 9]), (5, [0, 1])])
 def test_fused_overlap_add_equals_separate_kernels(ctx, config, ids):
     """k_irfft_ola3 (irFFT x3 + OLA + gains in one kernel, runs with replayed halo frames) must produce the bits

@@ -257,3 +257,22 @@ def test_product_interp1d_matches_oracle_interpolant():
         core.interp1d([], [])
     with pytest.raises(ValueError):
         core.interp1d(x, y, kind="cubic")
+
+
+def test_stretched_f0_is_the_float64_array_the_reference_holds():
+    """gf.synthesize's time stretch turns f0_interp into a float64 array (np.interp inside the reference's interp1d,
+    GOOFER.py:173-239, 1053); the f0 jitter and the sub-harmonic phase trackers then work on THAT array.  core._stretch64 makes it
+    for goofer_batch.f0_64: against the reference's own stretch fixture and the oracle, bit for bit, float32 input included."""
+    from goofer_amd import core
+    g = golden("mask_interp")
+    got = core._stretch64(g["feat"][0], 0, None, 2.3)
+    assert got.dtype == np.float64 and np.array_equal(got, g["stretch_1d_2.3"])
+    rng = np.random.default_rng(0)
+    for n, fac in ((1000, 1.23), (777, 0.61), (2, 1.5), (5000, 1.499)):
+        x = (rng.random(n) * 400 + 80).astype(np.float32)
+        a = core._stretch64(x, 0, None, fac)
+        assert a.dtype == np.float64 and np.array_equal(a, R.stretch_feature(x, fac))
+    x = (rng.random(3000) * 400 + 80).astype(np.float32)
+    want = np.concatenate([x[:500], R.stretch_feature(x[500:2000], 1.3), x[2000:]])
+    assert want.dtype == np.float64 and np.array_equal(core._stretch64(x, 500, 2000, 1.3), want)
+    assert core._stretch64(x[:1], 0, None, 2.0) is None            # (one sample: the reference's result keeps float32)
