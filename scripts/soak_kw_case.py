@@ -1,6 +1,6 @@
 """Errors per output of one case of tests/test_gpu_synth.py::test_synthesize_random_kwargs_vs_oracle (soak triage): the case's
 keyword set, then the same with one keyword group left out at a time, then under library options.
-Usage (GPU box): python scripts/soak_kw_case.py <case> ["{...keywords...}"]"""
+Usage (GPU box): python scripts/soak_kw_case.py <case> ["{...keywords instead of the case's own...}"] [--only]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,8 @@ from oracle import goofer_ref as R
 import test_gpu_synth as T
 
 case = int(sys.argv[1])
-kw0 = eval(sys.argv[2])
+args_ = [a for a in sys.argv[2:] if not a.startswith("--")]
+kw0 = eval(args_[0]) if args_ else T._random_kwargs(case)
 g = golden("synthesize")
 c = T._case(g, "plain")
 ctx = Context(0)
@@ -41,6 +42,8 @@ def run(kw, label):
 
 
 run(kw0, "the case: %r" % (kw0,))
+if "--only" in sys.argv:
+    sys.exit(0)
 groups = {"stretch": ["stretch_factor"], "f0 jitter": ["f0_jitter", "f0_jitter_strength"],
           "volume jitter": ["volume_jitter", "volume_jitter_strength_harm", "volume_jitter_strength_breath", "volume_vibrato", "volume_jitter_speed"],
           "sub-harmonics": ["add_subharm", "subharm_weight", "subharm_semitones", "subharm_vibrato", "subharm_vibrato_rate", "subharm_vibrato_depth",
