@@ -25,6 +25,9 @@ def run(kw, label):
     phi = c["phi"]
     if "stretch_factor" in kw:
         n_new = len(R.stretch_feature(c["f0"], kw["stretch_factor"]))
+        if "start_sec" in kw:
+            a, b = int(kw["start_sec"] * c["sr"]), int(kw["end_sec"] * c["sr"])
+            n_new = a + int((b - a) * kw["stretch_factor"]) + (len(c["f0"]) - b)
         phi = np.random.default_rng(case).uniform(0.0, 2.0 * np.pi, size=(c["env"].shape[0], 1 + n_new // c["hop"])).astype(np.float32)
     np.random.seed(300 + case)
     ref = R.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=phi, **kw)
@@ -44,7 +47,7 @@ def run(kw, label):
 run(kw0, "the case: %r" % (kw0,))
 if "--only" in sys.argv:
     sys.exit(0)
-groups = {"stretch": ["stretch_factor"], "f0 jitter": ["f0_jitter", "f0_jitter_strength"],
+groups = {"stretch": ["stretch_factor", "start_sec", "end_sec"], "stretch region": ["start_sec", "end_sec"], "f0 jitter": ["f0_jitter", "f0_jitter_strength"],
           "volume jitter": ["volume_jitter", "volume_jitter_strength_harm", "volume_jitter_strength_breath", "volume_vibrato", "volume_jitter_speed"],
           "sub-harmonics": ["add_subharm", "subharm_weight", "subharm_semitones", "subharm_vibrato", "subharm_vibrato_rate", "subharm_vibrato_depth",
                             "subharm_vibrato_delay", "subharm_f0_jitter"],

@@ -249,6 +249,12 @@ def _random_kwargs(case):
         if pick(0.5): kw["rough_k_list"] = tuple(int(v) for v in rng.choice([2, 3, 4, 5, 6], size=int(rng.integers(1, 5)), replace=False))
     if pick(0.25):
         kw["stretch_factor"] = float(np.round(rng.uniform(0.6, 1.5), 2))
+    # (later additions draw behind everything above, so a case number keeps the keywords it had)
+    if "stretch_factor" in kw and pick(0.3):                  # only a region is stretched (GOOFER.py:1019-1051)
+        a = float(np.round(rng.uniform(0.0, 0.1), 3))
+        kw.update(start_sec=a, end_sec=float(np.round(a + rng.uniform(0.02, 0.15), 3)))
+    if pick(0.15): kw["noise_transition_smoothness"] = float(np.round(rng.uniform(20.0, 300.0), 1))
+    if kw.get("f0_jitter") and pick(0.3): kw["f0_jitter_speed"] = float(np.round(rng.uniform(20.0, 200.0), 1))
     return kw
 
 
@@ -264,6 +270,9 @@ def test_synthesize_random_kwargs_vs_oracle(ctx, case):
     phi = c["phi"]
     if "stretch_factor" in kw:
         n_new = len(R.stretch_feature(c["f0"], kw["stretch_factor"]))
+        if "start_sec" in kw:
+            a, b = int(kw["start_sec"] * c["sr"]), int(kw["end_sec"] * c["sr"])
+            n_new = a + int((b - a) * kw["stretch_factor"]) + (len(c["f0"]) - b)
         phi = np.random.default_rng(case).uniform(0.0, 2.0 * np.pi, size=(c["env"].shape[0], 1 + n_new // c["hop"])).astype(np.float32)
     args = (c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"])
     np.random.seed(300 + case)
