@@ -269,15 +269,18 @@ __global__ void k_note_flags(const goofer_note_params *__restrict__ params, int 
 }
 
 // taps of a sample-axis Gaussian, uploaded into the handle's small buffer at `slot` (3 slots of 16 KiB after 64 KiB)
+// three tap slots behind the 64 KiB of tables in ctx->small: radius <= 8000, i.e. a jitter speed down to sr / 12 000 Hz (3.7 Hz at
+// 44.1 kHz; the reference's defaults are 100 and 150 Hz.  Until round 6: radius <= 1000 = 29.4 Hz, which a random keyword set hit)
+constexpr size_t JIT_SLOT_BYTES = 131072;
 static int upload_jitter_taps(goofer_ctx *ctx, double sigma, int slot, const double **d_taps, int *radius, hipStream_t st)
 {
     std::vector<double> taps;
     int r;
     gauss_taps_host(sigma, taps, r);
-    if (r > 1000) return goofer_fail(ctx, GOOFER_EINVAL, "jitter sigma %g too large", sigma);
-    int rc = ensure_small(ctx, 65536 + 3 * 16384);
+    if (r > 8000) return goofer_fail(ctx, GOOFER_EINVAL, "jitter sigma %g too large", sigma);
+    int rc = ensure_small(ctx, 65536 + 3 * JIT_SLOT_BYTES);
     if (rc) return rc;
-    double *dst = (double *)((char *)ctx->small + 65536 + (size_t)slot * 16384);
+    double *dst = (double *)((char *)ctx->small + 65536 + (size_t)slot * JIT_SLOT_BYTES);
     HIP_TRY(ctx, hipMemcpyAsync(dst, taps.data(), taps.size() * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     *d_taps = dst;
@@ -1121,7 +1124,7 @@ int goofer_gauss_rows_f64(goofer_ctx *ctx, const double *in, const int64_t *row_
     if (n_rows <= 0 || total <= 0) return GOOFER_OK;
     hipStream_t st = (hipStream_t)stream;
     // taps behind the fixed small areas (tables at 0, the three jitter tap slots at 64 KiB)
-    const size_t tap_off = 65536 + 3 * 16384, tap_bytes = (size_t)(2 * radius + 1) * sizeof(double);
+    const size_t tap_off = 65536 + 3 * JIT_SLOT_BYTES, tap_bytes = (size_t)(2 * radius + 1) * sizeof(double);
     int rc = ensure_small(ctx, tap_off + tap_bytes);
     if (rc) return rc;
     double *d_taps = (double *)((char *)ctx->small + tap_off);

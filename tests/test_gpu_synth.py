@@ -312,6 +312,24 @@ def test_stretched_f0_stays_float64_for_the_jitter_and_the_subharmonic_trackers(
             assert rms_err(a, b) / max(1.0, float(np.max(np.abs(b)))) < 2e-6, (key, trial)
 
 
+@pytest.mark.parametrize("kw", [dict(f0_jitter=True, f0_jitter_strength=0.8, f0_jitter_speed=12.0),
+                                dict(volume_jitter=True, volume_jitter_strength_harm=0.5, volume_jitter_strength_breath=0.9, volume_jitter_speed=9.0)])
+def test_slow_jitters(ctx, kw):
+    """Jitter speeds far below the defaults (100 / 150 Hz): sigma = sr / (6 speed) is 600-800 samples, a 2 500-3 300-tap Gaussian
+    (until round 6 the tap slots held a radius of 1000, i.e. speeds above 29.4 Hz, and the library refused the rest)."""
+    from goofer_amd import core
+    from oracle import goofer_ref as R
+    g = golden("synthesize")
+    c = _case(g, "plain")
+    args = (c["env"], c["f0"], c["mask"], np.empty(c["n"], bool), c["sr"])
+    np.random.seed(77)
+    ref = R.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=c["phi"], **kw)
+    np.random.seed(77)
+    got = core.synthesize(*args, n_fft=c["n_fft"], hop_length=c["hop"], formants=c["formants"], phi=c["phi"], ctx=ctx, **kw)
+    for a, b, key in zip(got, ref, ("rec", "harm", "uv", "bre")):
+        assert rms_err(a, b) / max(1.0, float(np.max(np.abs(b)))) < 2e-6, (key, kw)
+
+
 @pytest.mark.parametrize("config,ids", [(3, [0, 1, 2, 3, 4, 5, 6]), (4, [0, 1, 2, 5, 7, 9]), (5, [0, 1])])
 def test_fused_overlap_add_equals_separate_kernels(ctx, config, ids):
     """k_irfft_ola3 (irFFT x3 + OLA + gains in one kernel, runs with replayed halo frames) must produce the bits
