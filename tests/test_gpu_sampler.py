@@ -338,6 +338,13 @@ def test_random_flag_combinations_vs_oracle(renderer, case):
     args = (pitch, str(int(rng.choice([60, 100, 140]))), flags, str(int(rng.integers(0, 60))), str(int(rng.integers(200, 700))),
             str(int(rng.integers(0, 120))), str(int(rng.choice([-200, 30, 80]))), str(int(rng.integers(50, 121))), "0",
             "!" + str(int(rng.choice([90, 120, 150]))), ["AA", "AA#5#AF#3#/+", "B7CPCV#2#Cb"][int(rng.integers(0, 3))])
+    # (drawn behind everything above, so a case number keeps the request it had) the two per-formant strengths random_flags does
+    # not hold — 'fstb', 'fstd': with 'fsta' / 'fstc' every column of the strength tracks is switched on and off on its own
+    if rng.random() < 0.25:
+        for name in ("fstb", "fstd"):
+            if rng.random() < 0.6 and name not in flags:
+                flags += "%s%d" % (name, int(rng.integers(-40, 41)))
+        args = args[:2] + (flags,) + args[3:]
     feats = (src["env_pack"], src["f0"].copy(), src["mask"].copy(), {k: v.copy() for k, v in src["formants"].items()},
              src["sr"], src["y_len"])
     seed = 800 + case
