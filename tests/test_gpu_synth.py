@@ -288,6 +288,35 @@ def test_synthesize_random_kwargs_vs_oracle(ctx, case):
         assert e < bound, (key, e, kw)
 
 
+@pytest.mark.parametrize("case", range(_SOAK_FIRST, _SOAK_FIRST + max(8, int(os.environ.get("GOOFER_FUZZ_CASES", "2000")) // 8)))
+def test_synthesize_random_kwargs_on_hard_sources_vs_oracle(ctx, case):
+    """The same random keyword sets on sources with interior voiced / unvoiced transitions, fractional fp16 mask plateaus, bad and
+    crossing formant frames and 40 dB envelope jumps (synthetic.make_hard_source), a new source per case: what the f0 > 0 /
+    mask > 0 tests, the sub-harmonic trackers' last_f0 and the stretched (fractional, float64) mask see on real .goofy content."""
+    from goofer_amd import core, synthetic as syn
+    from oracle import goofer_ref as R
+    src = syn.make_hard_source(9000 + case, seconds=0.3 + 0.05 * (case % 5))
+    env = R.decode_env_from_knots(src["env_pack"])
+    f0, mask, sr, n, hop, n_fft = src["f0"], src["mask"], src["sr"], src["y_len"], 256, 1024
+    kw = _random_kwargs(case)
+    n_new = n
+    if "stretch_factor" in kw:
+        n_new = len(R.stretch_feature(f0, kw["stretch_factor"]))
+        if "start_sec" in kw:
+            a, b = int(kw["start_sec"] * sr), int(kw["end_sec"] * sr)
+            n_new = a + int((b - a) * kw["stretch_factor"]) + (n - b)
+    phi = np.random.default_rng(case).uniform(0.0, 2.0 * np.pi, size=(env.shape[0], 1 + n_new // hop)).astype(np.float32)
+    args = (env, f0, mask, np.empty(n, bool), sr)
+    np.random.seed(300 + case)
+    ref = R.synthesize(*args, n_fft=n_fft, hop_length=hop, formants=src["formants"], phi=phi, **kw)
+    np.random.seed(300 + case)
+    got = core.synthesize(*args, n_fft=n_fft, hop_length=hop, formants=src["formants"], phi=phi, ctx=ctx, **kw)
+    for a_, b_, key in zip(got, ref, ("rec", "harm", "uv", "bre")):
+        assert a_.shape == b_.shape, (key, kw)
+        e = rms_err(a_, b_) / max(1.0, float(np.max(np.abs(b_))))
+        assert e < 2e-5, (key, e, kw)
+
+
 def test_stretched_f0_stays_float64_for_the_jitter_and_the_subharmonic_trackers(ctx):
     """Soak case 186377 (round 6): time stretch + f0 jitter + a +5-semitone sub-harmonic layer.  Behind the stretch the reference's
     f0_interp is a float64 array (np.interp, GOOFER.py:1053); accumulating its float32 cast in the layer's phase tracker put one
