@@ -546,6 +546,12 @@ void plan_one(const goofer_plan_request &r, int hop, int trim_rows, const double
         }
         std::vector<float> &canon = s.canon;
         canon.clear();
+        if (f.empty() && Tk >= 0 && n1 > 0) {
+            // the reference edge-pads this track to the envelope's n1 frames and np.pad refuses an empty array (:755-760): a
+            // stretch-mode tail longer than wanted, resampled to int(L * (want / L)) = 0 frames behind an empty prefix
+            g.status = 1;
+            return;
+        }
         if (!f.empty()) {
             if (n1 == 0) {                                     // pad_trim of a non-empty track to zero frames: empty, i.e. no track
                 f.clear();

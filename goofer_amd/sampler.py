@@ -790,6 +790,12 @@ def _plan_tracks(g: NotePlan, tracks: list):
                 lp = np.concatenate([lp, tile[..., :rem]], axis=-1)
             lp = lp.astype(np.float32)
         f = np.concatenate([pre_t, lp], axis=-1)
+        if f.shape[-1] == 0 and T_target > 0:
+            # the reference edge-pads every track to the envelope's frames (SillySampler.py:755-760) and np.pad refuses an empty
+            # one: a stretch-mode tail LONGER than wanted is cut for the envelope (:631-636) but resampled for the tracks
+            # (:721-726), to int(L * (want / L)) frames — 0 for want = 1 and L = 49, 98, 103, ...; with no consonant frames
+            # in front of it the track is empty and the render fails there
+            raise ValueError("can't extend empty axis 0 using modes other than 'constant' or 'empty'")
         f = _fit_len(f, T_target) if f.shape[-1] else np.zeros(lead + (0,))
         if g.vel_active:
             Lk = f.shape[-1]

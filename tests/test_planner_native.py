@@ -170,6 +170,30 @@ def test_a_block_too_small_for_the_batch_says_how_many_rows_it_needs():
     _same(want, got)
 
 
+def test_an_empty_stretched_track_is_refused_like_the_reference():
+    """Soak case 240370 (round 6): 'L2', a 5 ms note (one frame wanted), no consonant frames, a 98-frame tail.  The reference cuts
+    the envelope's tail to the frame it wants (SillySampler.py:631-636) but resamples the formant tracks (:721-726) to
+    int(98 * (1 / 98)) = 0 frames, and np.pad(mode='edge') then refuses the empty track (:755-760): the render fails with a
+    ValueError.  Both planners rendered it; now the numpy planner raises np.pad's error and the native one steps aside."""
+    from goofer_amd import synthetic as syn
+    from oracle import sampler_ref as SR
+    src = syn.make_source(95000 + 240370, seconds=0.5711272864751321)
+    args = ("C2", "0", "t-12L2sa25", "1", "5", "1", "0", "100", "0", "!120", "/+/+/+#9#AAAA#3#gA")
+    assert int(98 * (1 / 98.0)) == 0
+    feats = (src["env_pack"], src["f0"].copy(), src["mask"].copy(), {k: v.copy() for k, v in src["formants"].items()}, src["sr"], src["y_len"])
+    with pytest.raises(ValueError, match="empty axis"):
+        SR.render(feats, SR.decode_request(*args), seed=1)
+    req, T = S.decode_request(*args), 1 + src["y_len"] // 256
+    S._GEO_CACHE.clear()
+    with pytest.raises(ValueError, match="empty axis"):
+        S.plan_notes([(req, src["sr"], src["y_len"], T, src["formants"])], 256)
+    assert _native([(req, src["sr"], src["y_len"], T, src["formants"])], 256, True) is None
+    ok = S.decode_request(*(args[:4] + ("10",) + args[5:]))               # two frames wanted: int(98 * (2 / 98)) = 2
+    S._GEO_CACHE.clear()
+    _same(S.plans_to_arrays(S.plan_notes([(ok, src["sr"], src["y_len"], T, src["formants"])], 256), 256, True),
+          _native([(ok, src["sr"], src["y_len"], T, src["formants"])], 256, True))
+
+
 def test_odd_sources_take_the_numpy_planner():
     jobs = _plannable(_random_jobs(5, 6), 256)
     odd = [(j[0], j[1], j[2], j[3], {k: v.astype(np.float32) for k, v in j[4].items()}) for j in jobs]
