@@ -315,8 +315,12 @@ static size_t scratch_need(const goofer_plan_t &p, int64_t frames, int64_t sampl
     add(frames * sizeof(float2));                 // per-frame (f0, mask) picks
     add(samples * sizeof(float));                 // f0 scaled
     if (subharm) add(samples * sizeof(double));   // phase increments
-    add((samples / 2 + 16 * notes + 16) * ONSET_BYTES);
-    add((samples / 2 + 16 * notes + 16) * sizeof(int32_t));   // raw onset sample indices
+    // onset slots: n / 2 + 16 per note for the pulse train (an f0 above sr / 2 is refused) — n + 16 with the sub-harmonic layer,
+    // whose tracker fires at most once per sample and does so on every sample once its increment passes 1 (the resampler's
+    // vibrato depth of 3 takes the layer to 8 x f0: above sr / 2 from F7 on)
+    const size_t slots = (size_t)(subharm ? samples : samples / 2) + 16 * (size_t)notes + 16;
+    add(slots * ONSET_BYTES);
+    add(slots * sizeof(int32_t));                 // raw onset sample indices
     add(notes * sizeof(int32_t) + 64);            // onset counts
     add(64);                                      // overflow flag
     add(samples * sizeof(float));                 // pulse
@@ -1360,8 +1364,9 @@ int goofer_synth_batch(goofer_ctx *ctx, const goofer_batch *b, void *stream)
     float2 *picks = a.take<float2>(F);
     float *f0s = a.take<float>(N);
     double *inc = sub_on ? a.take<double>(N) : nullptr;       // increments of the sub-harmonic trackers ('sg') only
-    char *onsets = a.take<char>((N / 2 + 16 * (size_t)n + 16) * ONSET_BYTES);
-    int32_t *onset_idx = a.take<int32_t>(N / 2 + 16 * (size_t)n + 16);
+    const size_t onset_slots = (size_t)(sub_on ? N : N / 2) + 16 * (size_t)n + 16;   // (see scratch_need)
+    char *onsets = a.take<char>(onset_slots * ONSET_BYTES);
+    int32_t *onset_idx = a.take<int32_t>(onset_slots);
     int32_t *onset_cnt = a.take<int32_t>(n + 16);
     int32_t *ovf = ctx->ovf_flag;
     float *pulse = a.take<float>(N);

@@ -142,8 +142,9 @@ __global__ __launch_bounds__(256) void k_pulse_onsets_wrap(const double *__restr
     double (*tile)[OC] = reinterpret_cast<double (*)[OC]>(smem) + 2 * wv;
     const int64_t base = sample_off[note];
     const int64_t n = sample_off[note + 1] - base;
-    const int64_t obase = base / 2 + 16 * (int64_t)note;
-    const int32_t cap = (int32_t)((sample_off[note + 1] / 2 + 16 * (int64_t)(note + 1)) - obase);
+    // a slot per sample (+ 16): the tracker fires at most once per sample — and on every sample once the increment passes 1
+    const int64_t obase = base + 16 * (int64_t)note;
+    const int32_t cap = (int32_t)(n + 16);
     const double *__restrict__ a = inc + base;
     int32_t *__restrict__ out = onset_idx + obase;
     double phase = 0.0;
@@ -1003,9 +1004,9 @@ __global__ __launch_bounds__(64) void k_subharm_finish(const double *__restrict_
 {
     const int note = blockIdx.x, lane = threadIdx.x;
     const int64_t base = sample_off[note];
-    const int64_t obase = base / 2 + 16 * (int64_t)note;
+    const int64_t obase = base + 16 * (int64_t)note;         // (the sub-harmonic layer's slots: one per sample, k_pulse_onsets_wrap)
     const int cnt = onset_cnt[note];
-    double *keys = keys_all + base;                              // cnt <= n/2 + 16 would not fit a tiny note: clamp below
+    double *keys = keys_all + base;                              // (cnt <= n: at most one event per sample)
     const int64_t n_note = sample_off[note + 1] - base;
     const int kcap = (int)(cnt < n_note ? cnt : n_note);
     for (int k = lane; k < kcap; k += WAVE) keys[k] = fm[base + onset_idx[obase + k]] * c.ratio;
@@ -1068,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_subharm_place(const onset_t *__restrict
     if (!(params[note].subharm_weight > 0.f)) return;
     const int64_t base = sample_off[note];
     const int32_t j = (int32_t)(g - base);
-    const onset_t *ol = onsets + (base / 2 + 16 * (int64_t)note);
+    const onset_t *ol = onsets + (base + 16 * (int64_t)note);
     const int cnt = onset_cnt[note];
     double acc = 0.0;
     int lo = -1, hi = cnt;

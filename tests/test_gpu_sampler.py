@@ -476,6 +476,31 @@ def test_random_extreme_requests_vs_oracle(renderer, case):
         assert e < TOL, (flags, args, e)
 
 
+def test_subharmonic_layer_above_nyquist_fires_on_every_sample(renderer):
+    """Soak case 259412 (round 6): a forced-voiced C7 note with 'sh' and 'sg'.  The resampler runs the sub-harmonic layer at
+    2 x f0 with a vibrato of depth 3 (SillySampler.py:1013-1020): up to 8 x f0, here above the sample rate.  The reference's tracker
+    (`if phase >= 1`, GOOFER.py:693-696) then fires on every sample — more events than the n / 2 + 16 slots the layer shared with the
+    pulse train, and the library refused the note.  The layer has a slot per sample now."""
+    from goofer_amd.render import Source
+    from goofer_amd import sampler as S
+    from oracle import sampler_ref as SR
+    case = 259412
+    src = syn.make_source(95000 + case, seconds=0.6625507038454174)
+    bend = "AAABACADAEAFAGAH" * 4
+    for args in (("C7", "100", "g61es74B45FV1sh72sr73sg67vl23", "1", "5", "0", "-400", "100", "0", "!60", bend),
+                 ("C7", "100", "FV1sh72sg67", "60", "300", "40", "30", "100", "0", "!120", bend)):     # ... and where it is audible
+        feats = (src["env_pack"], src["f0"].copy(), src["mask"].copy(), {k: v.copy() for k, v in src["formants"].items()},
+                 src["sr"], src["y_len"])
+        np.random.seed(277 + case)
+        ref = SR.render(feats, SR.decode_request(*args), seed=1900 + case)
+        source = Source.from_pack(src["env_pack"], src["f0"], src["mask"], src["formants"], src["sr"], src["y_len"])
+        np.random.seed(277 + case)
+        (out,) = renderer.render([(source, S.decode_request(*args))], phi_seeds=[1900 + case])
+        assert out.shape == ref.shape
+        assert rms_err(out, ref) / max(1.0, float(np.max(np.abs(ref)))) < TOL, args
+    assert float(np.max(np.abs(ref))) > 0.05
+
+
 @pytest.mark.parametrize("name", COMBOS)
 def test_flag_combinations_match_reference(renderer, name):
     """The same 16 random flag subsets the reference rendered (tests/golden/combo_*.npz), on the device."""
