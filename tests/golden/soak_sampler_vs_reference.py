@@ -17,7 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 import numpy as np
+import logging
 import make_golden as MG                      # installs the stubs, imports the reference
+logging.disable(logging.CRITICAL)             # (the reference narrates every render)
 
 from oracle import sampler_ref as SR          # noqa: E402
 from goofer_amd import synthetic as syn       # noqa: E402
